@@ -1,0 +1,127 @@
+// oracle/ref_shim.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// C-ABI wrapper around the *real* reference (simdjson v4.6.1, compiled from the sources where they
+// lie under /root/reference by oracle/Makefile; outputs only into oracle/_ref/).  It gives the
+// tests and bench.py's `cpu_baseline` leg ctypes access to the reference's own x86 kernels
+// (`icelake`, `haswell`, `westmere`, `fallback`) for the three entry points of the hot path:
+//
+//   * dom_parser_implementation::stage1   (/root/reference/include/simdjson/internal/dom_parser_implementation.h:80)
+//   * implementation::minify              (/root/reference/include/simdjson/implementation.h:116)
+//   * implementation::validate_utf8       (/root/reference/include/simdjson/implementation.h:128)
+//
+// Kernels are addressed by name through get_available_implementations() so the global "active
+// implementation" pointer is never touched.  Nothing under simdjson_amd/ may link or load this.
+#include "simdjson.h"
+
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+
+using simdjson::internal::dom_parser_implementation;
+
+namespace {
+const simdjson::implementation *find_impl(const char *name) {
+  auto impl = simdjson::get_available_implementations()[name];
+  if (!impl || !impl->supported_by_runtime_system()) { return nullptr; }
+  return impl;
+}
+struct ref_parser {
+  std::unique_ptr<dom_parser_implementation> p;
+  size_t capacity;
+};
+} // namespace
+
+extern "C" {
+
+// 1 if the named reference kernel exists and the host CPU can run it.
+int sjref_available(const char *impl_name) { return find_impl(impl_name) != nullptr; }
+
+// Persistent parser (mirrors benchmark/benchmarker.h:315-346: allocate once, time only stage1()).
+void *sjref_parser_create(const char *impl_name, size_t capacity) {
+  auto impl = find_impl(impl_name);
+  if (!impl) { return nullptr; }
+  auto *rp = new ref_parser();
+  rp->capacity = capacity;
+  if (impl->create_dom_parser_implementation(capacity, 1024, rp->p) != simdjson::SUCCESS) {
+    delete rp;
+    return nullptr;
+  }
+  return rp;
+}
+void sjref_parser_destroy(void *h) { delete static_cast<ref_parser *>(h); }
+
+// Runs the reference stage1 and returns its error_code.  Afterwards *n_out is
+// parser.n_structural_indexes and idx_out (if non-null, >= n+3 words) holds idx[0..n+2].
+int sjref_parser_stage1(void *h, const uint8_t *buf, size_t len, int mode, uint32_t *idx_out,
+                        uint32_t *n_out, uint32_t *next_structural_index_out) {
+  auto *rp = static_cast<ref_parser *>(h);
+  auto err = rp->p->stage1(buf, len, static_cast<simdjson::stage1_mode>(mode));
+  if (n_out) { *n_out = rp->p->n_structural_indexes; }
+  if (next_structural_index_out) { *next_structural_index_out = rp->p->next_structural_index; }
+  if (idx_out && rp->p->structural_indexes) {
+    std::memcpy(idx_out, rp->p->structural_indexes.get(),
+                (size_t(rp->p->n_structural_indexes) + 3) * sizeof(uint32_t));
+  }
+  return int(err);
+}
+
+// One-shot convenience: fresh parser with capacity `capacity` (0 => len), so stale state never leaks.
+int sjref_stage1(const char *impl_name, const uint8_t *buf, size_t len, int mode, size_t capacity,
+                 uint32_t *idx_out, uint32_t *n_out) {
+  void *h = sjref_parser_create(impl_name, capacity ? capacity : (len ? len : 1));
+  if (!h) { return -1; }
+  int err = sjref_parser_stage1(h, buf, len, mode, idx_out, n_out, nullptr);
+  sjref_parser_destroy(h);
+  return err;
+}
+
+int sjref_minify(const char *impl_name, const uint8_t *buf, size_t len, uint8_t *dst, size_t *dst_len) {
+  auto impl = find_impl(impl_name);
+  if (!impl) { return -1; }
+  size_t n = 0;
+  auto err = impl->minify(buf, len, dst, n);
+  *dst_len = n;
+  return int(err);
+}
+
+int sjref_validate_utf8(const char *impl_name, const uint8_t *buf, size_t len) {
+  auto impl = find_impl(impl_name);
+  if (!impl) { return -1; }
+  return impl->validate_utf8(reinterpret_cast<const char *>(buf), len) ? 1 : 0;
+}
+
+// ---- timing legs for bench.py's cpu_baseline (reference convention: best-of-N, input bytes only,
+// ---- /root/reference/benchmark/benchmarker.h:315-346,418) -------------------------------------
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// which: 0 = stage1(regular), 1 = minify, 2 = validate_utf8.  Returns best seconds over `iters`
+// runs (after one warm run), or a negative number on failure.  `scratch` must hold len bytes for minify.
+double sjref_bench(const char *impl_name, int which, const uint8_t *buf, size_t len, int iters,
+                   uint8_t *scratch, int *err_out) {
+  auto impl = find_impl(impl_name);
+  if (!impl) { return -1.0; }
+  std::unique_ptr<dom_parser_implementation> p;
+  if (which == 0 && impl->create_dom_parser_implementation(len, 1024, p) != simdjson::SUCCESS) { return -2.0; }
+  double best = 1e300;
+  int err = 0;
+  for (int it = 0; it < iters + 1; it++) {
+    double t0 = now_s();
+    if (which == 0) {
+      err = int(p->stage1(buf, len, simdjson::stage1_mode::regular));
+    } else if (which == 1) {
+      size_t n = 0;
+      err = int(impl->minify(buf, len, scratch, n));
+    } else {
+      err = impl->validate_utf8(reinterpret_cast<const char *>(buf), len) ? 0 : int(simdjson::UTF8_ERROR);
+    }
+    double dt = now_s() - t0;
+    if (it > 0 && dt < best) { best = dt; }
+  }
+  if (err_out) { *err_out = err; }
+  return best;
+}
+
+} // extern "C"

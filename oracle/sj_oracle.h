@@ -1,0 +1,69 @@
+/* oracle/sj_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C, byte-at-a-time restatement of simdjson's stage 1 (structural indexing), minify and
+ * validate_utf8 as the reference's x86 SIMD kernels (icelake == haswell == westmere) behave.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it, and only as
+ * the checker.  Parity status: PINNED -- tests/test_oracle_vs_reference.py checks this file
+ * against the real reference (oracle/_ref/libsjref.so, built from /root/reference by
+ * oracle/Makefile) and against the known answers committed under tests/golden/.
+ */
+#ifndef SJ_ORACLE_H
+#define SJ_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* simdjson::error_code values used on this path (/root/reference/include/simdjson/error.h:19-53) */
+enum {
+  SJO_SUCCESS = 0,
+  SJO_CAPACITY = 1,
+  SJO_UTF8_ERROR = 11,
+  SJO_EMPTY = 13,
+  SJO_UNESCAPED_CHARS = 14,
+  SJO_UNCLOSED_STRING = 15,
+  SJO_UNEXPECTED_ERROR = 24
+};
+
+/* simdjson::stage1_mode (/root/reference/include/simdjson/internal/dom_parser_implementation.h:22-27) */
+enum {
+  SJO_REGULAR = 0,
+  SJO_STREAMING_PARTIAL = 1,
+  SJO_STREAMING_FINAL = 2,
+  SJO_JSON_SEQUENCE_PARTIAL = 3,
+  SJO_JSON_SEQUENCE_FINAL = 4,
+  SJO_COMMA_DELIMITED_PARTIAL = 5,
+  SJO_COMMA_DELIMITED_FINAL = 6
+};
+
+/* Raw scan: writes ascending structural offsets to idx (room for len words),
+ * returns their count; flags: bit0 unclosed string, bit1 unescaped control char inside a string,
+ * bit2 invalid UTF-8. */
+uint32_t sjo_scan(const uint8_t *buf, size_t len, uint32_t *idx, uint32_t *flags);
+
+/* Full stage1 protocol.  idx needs room for len+3 words.  *n is the parser's
+ * n_structural_indexes: read-modify-write exactly where the reference touches it. */
+int sjo_stage1(const uint8_t *buf, size_t len, int mode, size_t capacity, uint32_t *idx, uint32_t *n);
+
+/* minify (App. A.7): dst needs len bytes. */
+int sjo_minify(const uint8_t *buf, size_t len, uint8_t *dst, size_t *dst_len);
+
+/* validate_utf8 (App. A.8): 1 = well-formed. */
+int sjo_validate_utf8(const uint8_t *buf, size_t len);
+
+/* host-side helpers of finish(), exposed so tests can pin them one by one */
+size_t sjo_trim_partial_utf8(const uint8_t *buf, size_t len);
+uint32_t sjo_find_next_document_index(const uint8_t *buf, const uint32_t *idx, uint32_t n);
+
+/* FNV-1a-64 over the n+3 index words (little-endian bytes): the digest SURVEY App. B quotes. */
+uint64_t sjo_fnv1a64(const void *data, size_t nbytes);
+
+/* best-of-iters seconds for which = 0 stage1 / 1 minify / 2 validate_utf8 (bench.py "port" leg) */
+double sjo_bench(int which, const uint8_t *buf, size_t len, int iters, void *scratch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,84 @@
+"""In-tree native builds (explicit compiler invocations; outputs under simdjson_amd/lib/ and oracle/_ref/).
+
+    libsjgpu.so            hipcc --offload-arch=gfx950   HIP kernels + C-ABI (include/sjgpu.h)   [product]
+    libsjcorpus.so         gcc                           synthetic corpora                         [tooling]
+    libsimdjson_mi355x.so  g++ against the reference's public headers: the simdjson::implementation
+                           plug-in shim.  Needs /root/reference at BUILD time only; the built file travels.
+    oracle/_ref/*.so       make -C oracle                CPU checkers                              [tests]
+
+Run `python -m simdjson_amd.build` or call build_all(); each target is rebuilt only when a source
+is newer than its output.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+from . import _paths
+
+HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+GFX_ARCH = "gfx950"
+
+
+def _stale(out, srcs):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(s) > t for s in srcs if os.path.exists(s))
+
+
+def _run(cmd, cwd=None):
+    print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=cwd)
+
+
+def _csrc(*names):
+    return [os.path.join(_paths.CSRC_DIR, n) for n in names]
+
+
+def build_corpus(force=False):
+    srcs = _csrc("corpus.c")
+    if force or _stale(_paths.LIB_CORPUS, srcs):
+        os.makedirs(_paths.LIB_DIR, exist_ok=True)
+        _run(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", *srcs, "-o", _paths.LIB_CORPUS])
+    return _paths.LIB_CORPUS
+
+
+def build_sjgpu(force=False):
+    srcs = _csrc("sjgpu_kernels.hip", "sjgpu_capi.hip", "stage1_finish.cpp")
+    deps = srcs + _csrc("sj_block.h", "sjgpu_internal.h") + [os.path.join(_paths.INCLUDE_DIR, "sjgpu.h")]
+    if force or _stale(_paths.LIB_SJGPU, deps):
+        os.makedirs(_paths.LIB_DIR, exist_ok=True)
+        _run([HIPCC, f"--offload-arch={GFX_ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+              "-I", _paths.INCLUDE_DIR, "-I", _paths.CSRC_DIR, *srcs, "-o", _paths.LIB_SJGPU])
+    return _paths.LIB_SJGPU
+
+
+def build_plugin(force=False):
+    """simdjson::implementation shim; skipped (prebuilt kept) when the reference headers are absent."""
+    srcs = _csrc("plugin/mi355x_implementation.cpp")
+    hdr = os.path.join(_paths.REFERENCE_DIR, "include", "simdjson.h")
+    if not os.path.exists(hdr) or not all(os.path.exists(s) for s in srcs):
+        return _paths.LIB_PLUGIN if os.path.exists(_paths.LIB_PLUGIN) else None
+    deps = srcs + _csrc("plugin/mi355x_implementation.h") + [os.path.join(_paths.INCLUDE_DIR, "sjgpu.h")]
+    if force or _stale(_paths.LIB_PLUGIN, deps):
+        os.makedirs(_paths.LIB_DIR, exist_ok=True)
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared",
+              "-I", os.path.join(_paths.REFERENCE_DIR, "include"), "-I", _paths.INCLUDE_DIR, "-I", _paths.CSRC_DIR,
+              *srcs, "-o", _paths.LIB_PLUGIN, f"-L{_paths.LIB_DIR}", "-lsjgpu", "-Wl,-rpath,$ORIGIN"])
+    return _paths.LIB_PLUGIN
+
+
+def build_oracle():
+    _run(["make", "-s", "-C", _paths.ORACLE_DIR, f"REFERENCE={_paths.REFERENCE_DIR}"])
+
+
+def build_all(force=False):
+    build_corpus(force)
+    build_sjgpu(force)
+    build_plugin(force)
+    build_oracle()
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

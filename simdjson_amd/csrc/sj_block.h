@@ -1,0 +1,222 @@
+// simdjson_amd/csrc/sj_block.h -- per-lane math of the MI355X stage-1 kernels.
+//
+// Mapping: ONE LANE owns ONE 64-byte block of the input (a wave64 owns 4 KiB).  A lane turns its
+// 16 dwords into eight 64-bit BIT PLANES (plane k, bit i = bit k of byte i) with a 3-stage
+// byte-permute / bit-field-insert network (v_perm_b32 + v_bfi_b32, 9 VALU ops per dword), after
+// which every character class of the reference is a handful of 64-bit logic ops and the
+// string/escape algebra runs on the same 64-bit masks the reference's CPU kernels use.
+// This is deliberately NOT the reference's pshufb-nibble-table formulation
+// (/root/reference/src/haswell.cpp:43-94): gfx950 has no 16-entry byte shuffle, but it has a
+// 2-source byte permute and a full-rate bit-field insert, which make the transposition cheap.
+//
+// What each function reproduces (behaviour, not code) is cited next to it.  All functions are
+// __host__ __device__ so tests/host/test_block_math.cpp can check them on the CPU against
+// byte-at-a-time definitions; the kernels in sjgpu_kernels.hip are the only product users.
+#ifndef SJGPU_SJ_BLOCK_H
+#define SJGPU_SJ_BLOCK_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SJ_HD __host__ __device__ __forceinline__
+#else
+#define SJ_HD inline
+#endif
+
+namespace sjgpu {
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// v_perm_b32: result byte j = byte sel[j] of the 8-byte value {hi:lo} (0-3 -> lo, 4-7 -> hi).
+SJ_HD u32 byte_perm(u32 hi, u32 lo, u32 sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+  u64 v = (u64(hi) << 32) | lo;
+  u32 r = 0;
+  for (int j = 0; j < 4; j++) {
+    u32 s = (sel >> (8 * j)) & 0xFF;
+    r |= u32((v >> (8 * (s & 7))) & 0xFF) << (8 * j);
+  }
+  return r;
+#endif
+}
+// v_bfi_b32: bits of a where mask is 1, bits of b elsewhere.
+SJ_HD u32 bfi(u32 mask, u32 a, u32 b) { return (a & mask) | (b & ~mask); }
+
+SJ_HD int popc64(u64 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __popcll(x);
+#else
+  return __builtin_popcountll(x);
+#endif
+}
+
+// One butterfly of the serial->parallel bit transposition.  (s0,s1) hold consecutive bytes; the
+// odd bytes go to t0, the even bytes to t1, then the bit-fields selected by `himask` are merged so
+// that p0 keeps the upper half of every field pair and p1 the lower half, the byte order of the
+// stream being preserved (earlier byte -> lower bit position).
+SJ_HD void s2p_step(u32 s0, u32 s1, u32 himask, int sh, u32 &p0, u32 &p1) {
+  u32 t0 = byte_perm(s1, s0, 0x07050301u);
+  u32 t1 = byte_perm(s1, s0, 0x06040200u);
+  p0 = bfi(himask, t0, t1 >> sh);
+  p1 = bfi(himask, t0 << sh, t1);
+}
+
+// 32 bytes (8 dwords, little-endian byte order) -> eight 32-bit plane halves.
+SJ_HD void s2p32(const u32 *s, u32 *p) {
+  u32 o[4], e[4], b73[2], b51[2], b62[2], b40[2];
+#pragma unroll
+  for (int j = 0; j < 4; j++) { s2p_step(s[2 * j], s[2 * j + 1], 0xAAAAAAAAu, 1, o[j], e[j]); }
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    s2p_step(o[2 * j], o[2 * j + 1], 0xCCCCCCCCu, 2, b73[j], b51[j]);
+    s2p_step(e[2 * j], e[2 * j + 1], 0xCCCCCCCCu, 2, b62[j], b40[j]);
+  }
+  s2p_step(b73[0], b73[1], 0xF0F0F0F0u, 4, p[7], p[3]);
+  s2p_step(b51[0], b51[1], 0xF0F0F0F0u, 4, p[5], p[1]);
+  s2p_step(b62[0], b62[1], 0xF0F0F0F0u, 4, p[6], p[2]);
+  s2p_step(b40[0], b40[1], 0xF0F0F0F0u, 4, p[4], p[0]);
+}
+
+struct planes { u64 b[8]; };
+
+// 64 bytes (16 dwords) -> eight 64-bit planes.
+SJ_HD planes transpose64(const u32 *w) {
+  u32 lo[8], hi[8];
+  s2p32(w, lo);
+  s2p32(w + 8, hi);
+  planes P;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { P.b[k] = (u64(hi[k]) << 32) | lo[k]; }
+  return P;
+}
+
+// Character classes of the x86 reference kernels (/root/reference/src/haswell.cpp:43-94,
+// src/icelake.cpp:48-96): whitespace = {20,09,0A,0D}; "operators" =
+// {2C,3A,5B,5D,7B,7D} plus 0C and 1A (the |0x20 artefact), never a byte >= 0x80.
+struct classes {
+  u64 backslash, quote, ws, op, ctrl;
+};
+SJ_HD classes classify(const planes &P) {
+  const u64 b0 = P.b[0], b1 = P.b[1], b2 = P.b[2], b3 = P.b[3], b4 = P.b[4], b5 = P.b[5], b6 = P.b[6], b7 = P.b[7];
+  const u64 n0 = ~b0, n1 = ~b1, n2 = ~b2, n3 = ~b3, n4 = ~b4, n5 = ~b5, n6 = ~b6, n7 = ~b7;
+  classes c;
+  const u64 hi_0 = n7 & n6 & n5 & n4;           // 0x0_
+  const u64 hi_2 = n7 & n6 & b5 & n4;           // 0x2_
+  const u64 lo_x0 = n3 & n2 & n0;               // low nibble 0000 or 0010
+  c.backslash = n7 & b6 & n5 & b4 & b3 & b2 & n1 & n0;                  // 0x5C
+  c.quote = hi_2 & lo_x0 & b1;                                          // 0x22
+  const u64 space = hi_2 & lo_x0 & n1;                                  // 0x20
+  const u64 tab_lf_cr = hi_0 & b3 & ((n2 & (b1 ^ b0)) | (b2 & n1 & b0)); // 09 0A | 0D
+  c.ws = space | tab_lf_cr;
+  const u64 comma = n6 & n4 & b2 & n1 & n0;     // x0x0 1100 : 2C (0C)
+  const u64 colon = n6 & b4 & n2 & b1 & n0;     // x0x1 1010 : 3A (1A)
+  const u64 open = b6 & b4 & n2 & b1 & b0;      // x1x1 1011 : 5B 7B
+  const u64 close = b6 & b4 & b2 & n1 & b0;     // x1x1 1101 : 5D 7D
+  c.op = n7 & b3 & (comma | colon | open | close);
+  c.ctrl = n7 & n6 & n5;                        // <= 0x1F
+  return c;
+}
+
+// prefix-XOR over the 64 bit positions (bit i of the result = XOR of bits 0..i).  The reference
+// gets this from one carry-less multiply (/root/reference/include/simdjson/haswell/bitmask.h:18-24);
+// on a lane it is six shift-xor steps.
+SJ_HD u64 prefix_xor(u64 x) {
+  x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16; x ^= x << 32;
+  return x;
+}
+
+// Escaped-character mask of a block given its backslash mask and the 1-bit carry "the first byte
+// is escaped".  A character is escaped iff preceded by an odd-length backslash run; run parity is
+// resolved with the add-carry identity the reference uses
+// (/root/reference/src/generic/stage1/json_escape_scanner.h:50-71,96-143).
+SJ_HD u64 escaped_mask(u64 backslash, u64 first_is_escaped, u64 &next_is_escaped) {
+  const u64 ODD = 0xAAAAAAAAAAAAAAAAull;
+  u64 potential = backslash & ~first_is_escaped;
+  u64 code = (((potential << 1) | ODD) - potential) ^ ODD; // escaping backslashes + the char each one escapes
+  next_is_escaped = (code & backslash) >> 63;
+  return code ^ (backslash | first_is_escaped);
+}
+
+// ---- UTF-8 ------------------------------------------------------------------------------------
+// Position-wise well-formedness test on bit planes (decides exactly what the reference's lookup
+// algorithm decides, /root/reference/src/generic/stage1/utf8_lookup4_algorithm.h:16-202: RFC 3629,
+// no overlongs, no surrogates, <= U+10FFFF).  `carry` packs what the previous 3 bytes demand of
+// this block:
+//   bit 0      byte[-1] is a 2/3/4-byte lead
+//   bits 1-2   byte[-2], byte[-1] is a 3/4-byte lead
+//   bits 3-5   byte[-3], byte[-2], byte[-1] is a 4-byte lead
+//   bit 6..9   byte[-1] is E0 / ED / F0 / F4
+SJ_HD u64 utf8_errors(const planes &P, u32 carry_in, u32 &carry_out) {
+  const u64 b0 = P.b[0], b1 = P.b[1], b2 = P.b[2], b3 = P.b[3], b4 = P.b[4], b5 = P.b[5], b6 = P.b[6], b7 = P.b[7];
+  const u64 cont = b7 & ~b6;
+  const u64 l2 = b7 & b6 & ~b5;                 // C0..DF
+  const u64 l3 = b7 & b6 & b5 & ~b4;            // E0..EF
+  const u64 l4 = b7 & b6 & b5 & b4 & ~b3;       // F0..F7
+  const u64 bad = (b7 & b6 & b5 & b4 & b3)      // F8..FF
+                  | (l2 & ~b4 & ~b3 & ~b2 & ~b1) // C0, C1 (overlong 2-byte)
+                  | (l4 & b2 & (b1 | b0));      // F5..F7 (> U+10FFFF)
+  const u64 lowz = ~b2 & ~b1 & ~b0;
+  const u64 e0 = l3 & ~b3 & lowz;
+  const u64 ed = l3 & b3 & b2 & ~b1 & b0;
+  const u64 f0 = l4 & lowz;
+  const u64 f4 = l4 & b2 & ~b1 & ~b0;
+  const u64 l234 = l2 | l3 | l4, l34 = l3 | l4;
+  const u64 expect = ((l234 << 1) | (carry_in & 1u)) | ((l34 << 2) | ((carry_in >> 1) & 3u)) |
+                     ((l4 << 3) | ((carry_in >> 3) & 7u));
+  const u64 after_e0 = (e0 << 1) | ((carry_in >> 6) & 1u);
+  const u64 after_ed = (ed << 1) | ((carry_in >> 7) & 1u);
+  const u64 after_f0 = (f0 << 1) | ((carry_in >> 8) & 1u);
+  const u64 after_f4 = (f4 << 1) | ((carry_in >> 9) & 1u);
+  const u64 second = (after_e0 & ~b5)          // E0 80..9F : overlong 3-byte
+                     | (after_ed & b5)         // ED A0..BF : surrogate
+                     | (after_f0 & ~b5 & ~b4)  // F0 80..8F : overlong 4-byte
+                     | (after_f4 & (b5 | b4)); // F4 90..BF : > U+10FFFF
+  carry_out = u32(l234 >> 63) | (u32(l34 >> 62) << 1) | (u32(l4 >> 61) << 3) | (u32(e0 >> 63) << 6) |
+              (u32(ed >> 63) << 7) | (u32(f0 >> 63) << 8) | (u32(f4 >> 63) << 9);
+  return (expect ^ cont) | bad | second;
+}
+
+// The same carry word computed from three raw bytes (used once per segment for the look-back).
+SJ_HD u32 utf8_carry_from_bytes(u32 p3, u32 p2, u32 p1) {
+  auto lead234 = [](u32 x) { return u32(x >= 0xC0 && x <= 0xF7); };
+  auto lead34 = [](u32 x) { return u32(x >= 0xE0 && x <= 0xF7); };
+  auto lead4 = [](u32 x) { return u32(x >= 0xF0 && x <= 0xF7); };
+  return lead234(p1) | (lead34(p2) << 1) | (lead34(p1) << 2) | (lead4(p3) << 3) | (lead4(p2) << 4) | (lead4(p1) << 5) |
+         (u32(p1 == 0xE0) << 6) | (u32(p1 == 0xED) << 7) | (u32(p1 == 0xF0) << 8) | (u32(p1 == 0xF4) << 9);
+}
+// Bits of the carry word that mean "a multi-byte sequence is still open" (EOF rule,
+// utf8_lookup4_algorithm.h:164-171).
+static const u32 UTF8_CARRY_OPEN = 0x3Fu;
+
+// ---- per-block string/structural algebra -----------------------------------
+// Everything a block contributes once its three 1-bit carries are known.  `in_string` here is
+// RELATIVE to the state at the segment start; the absolute mask is in_string ^ S with S = all-ones
+// iff the segment starts inside a string.
+struct block_masks {
+  u64 cand;        // op | (scalar & ~follows): structural candidates ignoring strings
+  u64 string_tail; // in_string ^ quote (relative)
+  u64 in_string;   // relative; includes opening quote, excludes closing quote
+  u64 quote;       // unescaped quotes
+  u64 ws;
+};
+SJ_HD block_masks string_algebra(const classes &c, u64 escaped, u32 in_string_carry, u32 prev_scalar_carry,
+                                 u32 &nonquote_scalar_msb) {
+  block_masks m;
+  m.quote = c.quote & ~escaped;
+  m.in_string = prefix_xor(m.quote) ^ (0 - u64(in_string_carry));
+  const u64 scalar = ~(c.ws | c.op);
+  const u64 nonquote_scalar = scalar & ~m.quote;
+  const u64 follows = (nonquote_scalar << 1) | prev_scalar_carry;
+  nonquote_scalar_msb = u32(nonquote_scalar >> 63);
+  m.cand = c.op | (scalar & ~follows);
+  m.string_tail = m.in_string ^ m.quote;
+  m.ws = c.ws;
+  return m;
+}
+
+} // namespace sjgpu
+#endif

@@ -1,0 +1,152 @@
+"""ctypes access to the CPU checkers under oracle/ (TEST INFRASTRUCTURE: oracle + real reference)."""
+import ctypes
+import os
+
+import numpy as np
+
+from simdjson_amd import _paths
+
+SUCCESS, CAPACITY, UTF8_ERROR, EMPTY, UNESCAPED_CHARS, UNCLOSED_STRING = 0, 1, 11, 13, 14, 15
+MODES = {"regular": 0, "streaming_partial": 1, "streaming_final": 2, "json_sequence_partial": 3,
+         "json_sequence_final": 4, "comma_delimited_partial": 5, "comma_delimited_final": 6}
+# error codes after which the reference has not (re)written n_structural_indexes / the array
+EARLY = (UNCLOSED_STRING, UNESCAPED_CHARS)
+
+_u8p = ctypes.c_void_p
+
+
+def _ptr(a):
+    return a.ctypes.data if isinstance(a, np.ndarray) else ctypes.cast(ctypes.c_char_p(a), ctypes.c_void_p).value
+
+
+def as_u8(data):
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(bytes(data), dtype=np.uint8).copy() if len(data) else np.zeros(0, np.uint8)
+
+
+class Oracle:
+    """oracle/sj_oracle.c"""
+
+    def __init__(self):
+        L = ctypes.CDLL(_paths.LIB_ORACLE)
+        L.sjo_scan.restype = ctypes.c_uint32
+        L.sjo_scan.argtypes = [_u8p, ctypes.c_size_t, _u8p, ctypes.POINTER(ctypes.c_uint32)]
+        L.sjo_stage1.restype = ctypes.c_int
+        L.sjo_stage1.argtypes = [_u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, _u8p, ctypes.POINTER(ctypes.c_uint32)]
+        L.sjo_minify.restype = ctypes.c_int
+        L.sjo_minify.argtypes = [_u8p, ctypes.c_size_t, _u8p, ctypes.POINTER(ctypes.c_size_t)]
+        L.sjo_validate_utf8.restype = ctypes.c_int
+        L.sjo_validate_utf8.argtypes = [_u8p, ctypes.c_size_t]
+        L.sjo_fnv1a64.restype = ctypes.c_uint64
+        L.sjo_fnv1a64.argtypes = [_u8p, ctypes.c_size_t]
+        L.sjo_bench.restype = ctypes.c_double
+        L.sjo_bench.argtypes = [ctypes.c_int, _u8p, ctypes.c_size_t, ctypes.c_int, _u8p]
+        self.L = L
+
+    def scan(self, data):
+        a = as_u8(data)
+        idx = np.empty(len(a) + 3, dtype=np.uint32)
+        flags = ctypes.c_uint32(0)
+        n = self.L.sjo_scan(a.ctypes.data, len(a), idx.ctypes.data, ctypes.byref(flags))
+        return idx[:n].copy(), int(flags.value)
+
+    def stage1(self, data, mode=0, capacity=None, n_prev=0):
+        """Returns (err, n, idx[0..n+2]) with the reference's stale-n semantics."""
+        a = as_u8(data)
+        idx = np.zeros(len(a) + 3, dtype=np.uint32)
+        n = ctypes.c_uint32(n_prev)
+        err = self.L.sjo_stage1(a.ctypes.data, len(a), mode, len(a) if capacity is None else capacity,
+                                idx.ctypes.data, ctypes.byref(n))
+        return err, int(n.value), idx[: n.value + 3].copy()
+
+    def minify(self, data):
+        a = as_u8(data)
+        dst = np.empty(max(len(a), 1), dtype=np.uint8)
+        n = ctypes.c_size_t(0)
+        err = self.L.sjo_minify(a.ctypes.data, len(a), dst.ctypes.data, ctypes.byref(n))
+        return err, dst[: n.value].copy()
+
+    def validate_utf8(self, data):
+        a = as_u8(data)
+        return bool(self.L.sjo_validate_utf8(a.ctypes.data, len(a)))
+
+    def fnv(self, arr):
+        a = np.ascontiguousarray(arr)
+        return int(self.L.sjo_fnv1a64(a.ctypes.data, a.nbytes))
+
+
+class Reference:
+    """oracle/_ref/libsjref.so: the real simdjson kernels (icelake / haswell / westmere / fallback)."""
+
+    def __init__(self):
+        L = ctypes.CDLL(_paths.LIB_REF)
+        L.sjref_available.restype = ctypes.c_int
+        L.sjref_available.argtypes = [ctypes.c_char_p]
+        L.sjref_stage1.restype = ctypes.c_int
+        L.sjref_stage1.argtypes = [ctypes.c_char_p, _u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, _u8p,
+                                   ctypes.POINTER(ctypes.c_uint32)]
+        L.sjref_minify.restype = ctypes.c_int
+        L.sjref_minify.argtypes = [ctypes.c_char_p, _u8p, ctypes.c_size_t, _u8p, ctypes.POINTER(ctypes.c_size_t)]
+        L.sjref_validate_utf8.restype = ctypes.c_int
+        L.sjref_validate_utf8.argtypes = [ctypes.c_char_p, _u8p, ctypes.c_size_t]
+        L.sjref_bench.restype = ctypes.c_double
+        L.sjref_bench.argtypes = [ctypes.c_char_p, ctypes.c_int, _u8p, ctypes.c_size_t, ctypes.c_int, _u8p,
+                                  ctypes.POINTER(ctypes.c_int)]
+        self.L = L
+
+    def available(self, impl):
+        return bool(self.L.sjref_available(impl.encode()))
+
+    def best_impl(self):
+        for name in ("icelake", "haswell", "westmere"):
+            if self.available(name):
+                return name
+        return None
+
+    def stage1(self, impl, data, mode=0, capacity=None):
+        a = as_u8(data)
+        cap = len(a) if capacity is None else capacity
+        idx = np.zeros(max(len(a), cap) + 64 + 9 + 3, dtype=np.uint32)
+        n = ctypes.c_uint32(0)
+        err = self.L.sjref_stage1(impl.encode(), a.ctypes.data, len(a), mode, max(cap, 1) if capacity is not None else 0,
+                                  idx.ctypes.data, ctypes.byref(n))
+        return err, int(n.value), idx[: n.value + 3].copy()
+
+    def minify(self, impl, data):
+        a = as_u8(data)
+        dst = np.empty(len(a) + 64, dtype=np.uint8)
+        n = ctypes.c_size_t(0)
+        err = self.L.sjref_minify(impl.encode(), a.ctypes.data, len(a), dst.ctypes.data, ctypes.byref(n))
+        return err, dst[: n.value].copy()
+
+    def validate_utf8(self, impl, data):
+        a = as_u8(data)
+        return bool(self.L.sjref_validate_utf8(impl.encode(), a.ctypes.data, len(a)))
+
+
+def trim_partial_utf8_len(a):
+    """Length after the streaming modes' partial-UTF-8 trim (json_structural_indexer.h:156-174)."""
+    n = len(a)
+    if n >= 1 and a[n - 1] >= 0xC0:
+        return n - 1
+    if n >= 2 and a[n - 2] >= 0xE0:
+        return n - 2
+    if n >= 3 and a[n - 3] >= 0xF0:
+        return n - 3
+    return n
+
+
+def observable(data, mode, err, n, idx):
+    """The part of a stage1 result that callers can rely on: the error code always; n and
+    idx[0..n+2] unless the reference returned before (re)writing them."""
+    a = as_u8(data)
+    if err in EARLY:
+        return (err,)
+    if len(a) == 0 or (mode != 0 and trim_partial_utf8_len(a) == 0):
+        return (err,)
+    return (err, n, tuple(int(x) for x in idx[: n + 3]))
+
+
+def have_reference_lib():
+    return os.path.exists(_paths.LIB_REF)

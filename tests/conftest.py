@@ -1,0 +1,19 @@
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_builds():
+    """Build the host-side libraries that every test tier needs (no GPU required to compile)."""
+    from simdjson_amd import build
+    build.build_corpus()
+    build.build_oracle()
+    yield
