@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- stage-1 structural indexing throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--op stage1|minify|validate_utf8]
+                    [--workload large_random|amazon_ndjson|twitter_like] [--size BYTES]
+
+A "step" = one pass of the hot path (sjgpu_*_device through the C-ABI) over one synthetic buffer that
+is already resident in HBM.  N = 1: BASELINE.json configs[1] -- 1 GiB large_random-style JSON.
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank scans its OWN 1 GiB shard
+(independent documents, SURVEY 8(e): no data-path collective), weak scaling; value = bytes all ranks
+scanned / max-over-ranks time.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 measured copy
+KERNELS = {"stage1": ["k_stage1_summarize", "k_resolve_segments", "k_stage1_emit"],
+           "minify": ["k_minify_summarize", "k_resolve_segments", "k_minify_emit"],
+           "validate_utf8": ["k_validate_utf8"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--op", default="stage1", choices=list(KERNELS))
+    ap.add_argument("--workload", default="large_random", choices=["large_random", "amazon_ndjson", "twitter_like"])
+    ap.add_argument("--size", type=int, default=1 << 30, help="bytes per GPU")
+    ap.add_argument("--cpu-iters", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from simdjson_amd import build, capi, corpus
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if local_rank == 0:
+        build.build_corpus()
+        build.build_sjgpu()
+    if world > 1:
+        dist.barrier()
+
+    # ---- workload: one synthetic buffer per rank, resident in HBM before anything is timed ----
+    host, units = getattr(corpus, args.workload)(args.size, 1000 + rank)
+    L = len(host)
+    parser = capi.DomParserImplementation(L, device=local_rank)
+    buf = torch.from_numpy(host).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    if args.op == "stage1":
+        out = torch.empty(L + 3, dtype=torch.int32, device="cuda")
+        step = lambda: parser.stage1_device(buf.data_ptr(), L, out.data_ptr(), L + 3, stream)
+    elif args.op == "minify":
+        out = torch.empty(L + 16, dtype=torch.uint8, device="cuda")
+        step = lambda: parser.minify_device(buf.data_ptr(), L, out.data_ptr(), stream)
+    else:
+        out = None
+        step = lambda: parser.validate_utf8_device(buf.data_ptr(), L, stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        assert step() == 0
+    n, flags, out_len = parser.result(stream)
+    err = capi.stage1_error_from_flags(n, flags) if args.op == "stage1" else (15 if flags & 1 else 0)
+    if args.op == "validate_utf8":
+        err = 11 if flags & capi.F_UTF8_ERROR else 0
+    if err != 0:
+        raise SystemExit(f"rank {rank}: {args.op} returned error_code {err} on the synthetic buffer")
+
+    parser.profile_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ms_sum, calls = parser.profile_read()
+    parser.profile_enable(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tot = torch.tensor([float(L)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_bytes = float(tot.item())
+    else:
+        total_bytes = float(L)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = total_bytes * args.steps / dt / 1e9
+        # roofline: algorithmic bytes per launch over the GPU time of the kernels of one
+        # step, measured with HIP events on the launch stream inside the timed region
+        if args.op == "stage1":
+            alg = L + 4 * (n + 3)
+        elif args.op == "minify":
+            alg = L + out_len
+        else:
+            alg = L
+        kms = [m / max(calls, 1) for m in ms_sum][: len(KERNELS[args.op])]
+        gpu_ms = sum(kms)
+        achieved = alg / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(f"{args.op}:{args.workload}:{args.size}")
+        line = {
+            "metric": "stage1 GB/s (structural indexing)" if args.op == "stage1" else f"{args.op} GB/s",
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.workload} {L} B per GPU (seed 1000+rank), op={args.op}, regular mode, "
+                                   f"device-resident input and output", "bytes_per_gpu": L, "units_per_gpu": units,
+                       "structurals": n if args.op == "stage1" else None, "out_bytes": out_len if args.op == "minify" else None,
+                       "parallelism": f"{world} independent shard(s), one rank per GPU, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg, "gpu_ms_per_step": round(gpu_ms, 4),
+                         "kernels_ms": dict(zip(KERNELS[args.op], [round(x, 4) for x in kms])),
+                         "timing": "hipEvent pairs around each kernel on the launch stream, averaged over the timed steps"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import cpu_baseline  # test infrastructure: the CPU side of the comparison only
+            cb = cpu_baseline.time_cpu(host, args.op, args.cpu_iters)
+            if args.op == "stage1" and cb["n"] is not None and cb["n"] != n:
+                raise SystemExit(f"PARITY FAILURE: GPU n={n} vs CPU reference n={cb['n']}")
+            line["cpu_baseline"] = {"value": round(cb["value"], 3), "unit": "GB/s", "cores": cb["cores"], "kind": cb["kind"],
+                                    "sample": f"the same {L}-byte buffer, {cb['impl']} kernel, 1 thread, best of {args.cpu_iters}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    parser.close()
+
+
+if __name__ == "__main__":
+    main()

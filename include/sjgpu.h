@@ -1,0 +1,129 @@
+/* include/sjgpu.h -- C-ABI of libsjgpu: simdjson's stage 1 (structural indexing), minify and
+ * validate_utf8 on AMD Instinct MI355X (gfx950, hand-written HIP).
+ *
+ * This is the drop-in boundary below simdjson's plug-in classes.  Each entry point replaces one
+ * virtual of the reference (citations relative to /root/reference):
+ *
+ *   sjgpu_stage1         internal::dom_parser_implementation::stage1(buf, len, stage1_mode)
+ *                        include/simdjson/internal/dom_parser_implementation.h:80
+ *                        (behaviour: src/generic/stage1/json_structural_indexer.h:193-397)
+ *   sjgpu_minify         implementation::minify(buf, len, dst, dst_len)      include/simdjson/implementation.h:116
+ *   sjgpu_validate_utf8  implementation::validate_utf8(buf, len)             include/simdjson/implementation.h:128
+ *   sjgpu_ctx_create / sjgpu_set_capacity / sjgpu_ctx_destroy
+ *                        implementation::create_dom_parser_implementation    include/simdjson/implementation.h:97-101
+ *                        dom_parser_implementation::set_capacity / dtor      internal/dom_parser_implementation.h:154,170
+ *
+ * The *_device variants take buffers that already live in HBM (device-resident pipelines, bench.py,
+ * multi-GPU NDJSON shards) and are asynchronous on the caller's HIP stream.
+ *
+ * Conventions: plain pointers and sizes only.  Return value >= 0 is a simdjson::error_code
+ * (include/simdjson/error.h:19-53: 0 SUCCESS, 1 CAPACITY, 2 MEMALLOC, 11 UTF8_ERROR, 13 EMPTY,
+ * 14 UNESCAPED_CHARS, 15 UNCLOSED_STRING, 24 UNEXPECTED_ERROR); < 0 is an infrastructure error the
+ * plug-in shim maps to UNSUPPORTED_ARCHITECTURE / MEMALLOC / UNEXPECTED_ERROR.  Nothing throws,
+ * prints or aborts.  One context per parser object; a context serves one call at a time and may be
+ * used from any thread.  There is NO CPU fallback inside this library: without a usable GPU every
+ * compute entry point fails with SJGPU_E_NO_DEVICE.
+ */
+#ifndef SJGPU_H
+#define SJGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SJGPU_E_NO_DEVICE (-1) /* no HIP device / runtime unusable */
+#define SJGPU_E_HIP       (-2) /* a HIP call failed; see sjgpu_last_error() */
+#define SJGPU_E_NOMEM     (-3) /* device or pinned-host allocation failed */
+#define SJGPU_E_BADARG    (-4) /* null/misaligned pointer, len > 0xFFFFFFFF, unknown mode */
+#define SJGPU_E_OVERFLOW  (-5) /* caller's index buffer too small for n+3 words */
+
+/* simdjson::stage1_mode (internal/dom_parser_implementation.h:22-27) */
+enum sjgpu_stage1_mode {
+  SJGPU_REGULAR = 0,
+  SJGPU_STREAMING_PARTIAL = 1,
+  SJGPU_STREAMING_FINAL = 2,
+  SJGPU_JSON_SEQUENCE_PARTIAL = 3,
+  SJGPU_JSON_SEQUENCE_FINAL = 4,
+  SJGPU_COMMA_DELIMITED_PARTIAL = 5,
+  SJGPU_COMMA_DELIMITED_FINAL = 6
+};
+
+/* scan flags (device result) */
+#define SJGPU_F_UNCLOSED_STRING 1u /* input ends inside a string */
+#define SJGPU_F_UNESCAPED_CTRL  2u /* byte <= 0x1F inside a string */
+#define SJGPU_F_UTF8_ERROR      4u /* not well-formed UTF-8 */
+#define SJGPU_F_IDX_OVERFLOW    8u /* index buffer too small; indices beyond it were dropped */
+
+typedef struct sjgpu_ctx sjgpu_ctx;
+
+/* What a device-resident call produced (valid after sjgpu_result()). */
+typedef struct sjgpu_scan_result {
+  uint32_t n;       /* stage1: number of structural indexes written (sentinels follow at idx[n..n+2]) */
+  uint32_t flags;   /* SJGPU_F_* */
+  uint64_t out_len; /* minify: bytes written to dst (0 if unclosed string) */
+} sjgpu_scan_result;
+
+int sjgpu_device_count(void); /* number of usable HIP devices, 0 if none */
+
+/* Context = per-parser device workspace for documents up to `capacity` bytes on HIP device `device`. */
+int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out);
+void sjgpu_ctx_destroy(sjgpu_ctx *ctx);
+int sjgpu_set_capacity(sjgpu_ctx *ctx, size_t capacity);
+size_t sjgpu_capacity(const sjgpu_ctx *ctx);
+const char *sjgpu_last_error(const sjgpu_ctx *ctx); /* text of the last HIP failure ("" if none) */
+
+/* ---- host-buffer entry points (what the simdjson plug-in shim binds) --------------------------------
+ * buf: len readable bytes, no padding required (the reference's stage 1 never reads past len,
+ * src/generic/stage1/buf_block_reader.h:99-104).
+ * idx_out: the parser's structural_indexes array, idx_words >= len+3 words available
+ * (include/simdjson/generic/dom_parser_implementation.h:63-78 allocates ROUNDUP(capacity,64)+9).
+ * *n_io: the parser's n_structural_indexes, read-modify-written exactly where the reference does
+ * (untouched on CAPACITY / len==0 / UNCLOSED_STRING(regular) / UNESCAPED_CHARS). */
+int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint32_t *idx_out, size_t idx_words,
+                 uint32_t *n_io);
+/* dst: len writable bytes; never written beyond dst+len.  UNCLOSED_STRING => *dst_len = 0. */
+int sjgpu_minify(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, uint8_t *dst, size_t *dst_len);
+/* *ok = 1 iff buf[0..len) is well-formed UTF-8 (len == 0 => 1). */
+int sjgpu_validate_utf8(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int *ok);
+
+/* ---- device-resident entry points --------------------------------------------------------------------
+ * buf_dev: device pointer, 16-byte aligned, len readable bytes (nothing is read past len).
+ * stream: a hipStream_t (NULL = the context's own stream).  Calls only enqueue work; fetch the
+ * outcome with sjgpu_result(), which waits for that stream.
+ * sjgpu_stage1_device: regular-mode scan; writes idx_dev[0..n) ascending byte offsets and the three
+ * sentinels idx_dev[n]=len, idx_dev[n+1]=len, idx_dev[n+2]=0 (json_structural_indexer.h:284-286);
+ * needs idx_words >= n+3 (len+3 always suffices).  Error precedence is applied by the caller from
+ * `flags` (helper below). */
+int sjgpu_stage1_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *idx_dev, size_t idx_words, void *stream);
+int sjgpu_minify_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *dst_dev, void *stream);
+int sjgpu_validate_utf8_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *stream);
+int sjgpu_result(sjgpu_ctx *ctx, void *stream, sjgpu_scan_result *out);
+
+/* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).  While enabled,
+ * each *_device call brackets every kernel it enqueues with events (up to 4096 calls are retained);
+ * sjgpu_profile_read waits for the stream, adds the elapsed milliseconds per kernel slot into
+ * ms_sum[0..3] (stage1: summarize, resolve, emit; minify: summarize, resolve, emit; validate_utf8:
+ * slot 0), stores the number of calls accumulated and resets. */
+int sjgpu_profile_enable(sjgpu_ctx *ctx, int on);
+int sjgpu_profile_read(sjgpu_ctx *ctx, double *ms_sum, uint32_t *calls);
+
+/* regular-mode error_code from a scan result (json_structural_indexer.h:249-294,395-396):
+ * UNCLOSED_STRING > UNESCAPED_CHARS > EMPTY > UTF8_ERROR > SUCCESS. */
+int sjgpu_stage1_error_from_flags(uint32_t n, uint32_t flags);
+
+/* Host post-pass of finish() for all seven modes on host-resident arrays: sentinels, streaming
+ * truncation, RS / root-comma filtering (json_structural_indexer.h:249-397,
+ * src/generic/stage1/find_next_document_index.h:39-369).  idx holds the n_raw raw structurals and
+ * has room for n_raw+3 words; len is the (already trimmed) scanned length. */
+int sjgpu_stage1_finish_host(const uint8_t *buf, size_t len, int mode, uint32_t *idx, uint32_t n_raw, uint32_t flags,
+                             uint32_t *n_io);
+/* streaming modes: length after dropping a trailing partial UTF-8 character (…indexer.h:156-174) */
+size_t sjgpu_trim_partial_utf8(const uint8_t *buf, size_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SJGPU_H */

@@ -40,7 +40,7 @@ def build_corpus(force=False):
     srcs = _csrc("corpus.c")
     if force or _stale(_paths.LIB_CORPUS, srcs):
         os.makedirs(_paths.LIB_DIR, exist_ok=True)
-        _run(["gcc", "-O2", "-std=c99", "-fPIC", "-shared", *srcs, "-o", _paths.LIB_CORPUS])
+        _run(["gcc", "-O2", "-std=c99", "-fopenmp", "-fPIC", "-shared", *srcs, "-o", _paths.LIB_CORPUS])
     return _paths.LIB_CORPUS
 
 

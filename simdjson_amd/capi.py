@@ -1,0 +1,208 @@
+"""ctypes mirror of include/sjgpu.h (the C-ABI of libsjgpu.so, HIP kernels for gfx950).
+
+Host-side names follow the reference's plug-in interface for this path
+(/root/reference/include/simdjson/implementation.h:97-128,
+ /root/reference/include/simdjson/internal/dom_parser_implementation.h:80): `stage1`, `minify`,
+`validate_utf8`, `set_capacity`, error codes as simdjson::error_code integers.
+
+There is no CPU fallback: a missing library or a missing GPU raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _paths
+
+# simdjson::error_code values on this path (include/simdjson/error.h:19-53)
+SUCCESS, CAPACITY, MEMALLOC, UTF8_ERROR, EMPTY, UNESCAPED_CHARS, UNCLOSED_STRING, UNEXPECTED_ERROR = 0, 1, 2, 11, 13, 14, 15, 24
+# simdjson::stage1_mode (internal/dom_parser_implementation.h:22-27)
+REGULAR, STREAMING_PARTIAL, STREAMING_FINAL, JSON_SEQUENCE_PARTIAL, JSON_SEQUENCE_FINAL, COMMA_DELIMITED_PARTIAL, COMMA_DELIMITED_FINAL = range(7)
+F_UNCLOSED_STRING, F_UNESCAPED_CTRL, F_UTF8_ERROR, F_IDX_OVERFLOW = 1, 2, 4, 8
+
+EXPORTS = [
+    "sjgpu_device_count", "sjgpu_ctx_create", "sjgpu_ctx_destroy", "sjgpu_set_capacity", "sjgpu_capacity",
+    "sjgpu_last_error", "sjgpu_stage1", "sjgpu_minify", "sjgpu_validate_utf8", "sjgpu_stage1_device",
+    "sjgpu_minify_device", "sjgpu_validate_utf8_device", "sjgpu_result", "sjgpu_stage1_error_from_flags",
+    "sjgpu_stage1_finish_host", "sjgpu_trim_partial_utf8", "sjgpu_profile_enable", "sjgpu_profile_read",
+]
+
+
+class SjgpuError(RuntimeError):
+    pass
+
+
+class ScanResult(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("out_len", ctypes.c_uint64)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libsjgpu.so (raises if it has not been built: the product path never degrades to CPU)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_paths.LIB_SJGPU):
+        raise SjgpuError(f"{_paths.LIB_SJGPU} not built (run python -m simdjson_amd.build)")
+    L = ctypes.CDLL(_paths.LIB_SJGPU)
+    vp, sz, u32p = ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32)
+    L.sjgpu_device_count.restype = ctypes.c_int
+    L.sjgpu_ctx_create.restype = ctypes.c_int
+    L.sjgpu_ctx_create.argtypes = [ctypes.c_int, sz, ctypes.POINTER(vp)]
+    L.sjgpu_ctx_destroy.restype = None
+    L.sjgpu_ctx_destroy.argtypes = [vp]
+    L.sjgpu_set_capacity.restype = ctypes.c_int
+    L.sjgpu_set_capacity.argtypes = [vp, sz]
+    L.sjgpu_capacity.restype = sz
+    L.sjgpu_capacity.argtypes = [vp]
+    L.sjgpu_last_error.restype = ctypes.c_char_p
+    L.sjgpu_last_error.argtypes = [vp]
+    L.sjgpu_stage1.restype = ctypes.c_int
+    L.sjgpu_stage1.argtypes = [vp, vp, sz, ctypes.c_int, vp, sz, u32p]
+    L.sjgpu_minify.restype = ctypes.c_int
+    L.sjgpu_minify.argtypes = [vp, vp, sz, vp, ctypes.POINTER(sz)]
+    L.sjgpu_validate_utf8.restype = ctypes.c_int
+    L.sjgpu_validate_utf8.argtypes = [vp, vp, sz, ctypes.POINTER(ctypes.c_int)]
+    L.sjgpu_stage1_device.restype = ctypes.c_int
+    L.sjgpu_stage1_device.argtypes = [vp, vp, sz, vp, sz, vp]
+    L.sjgpu_minify_device.restype = ctypes.c_int
+    L.sjgpu_minify_device.argtypes = [vp, vp, sz, vp, vp]
+    L.sjgpu_validate_utf8_device.restype = ctypes.c_int
+    L.sjgpu_validate_utf8_device.argtypes = [vp, vp, sz, vp]
+    L.sjgpu_result.restype = ctypes.c_int
+    L.sjgpu_result.argtypes = [vp, vp, ctypes.POINTER(ScanResult)]
+    L.sjgpu_stage1_error_from_flags.restype = ctypes.c_int
+    L.sjgpu_stage1_error_from_flags.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    L.sjgpu_stage1_finish_host.restype = ctypes.c_int
+    L.sjgpu_stage1_finish_host.argtypes = [vp, sz, ctypes.c_int, vp, ctypes.c_uint32, ctypes.c_uint32, u32p]
+    L.sjgpu_profile_enable.restype = ctypes.c_int
+    L.sjgpu_profile_enable.argtypes = [vp, ctypes.c_int]
+    L.sjgpu_profile_read.restype = ctypes.c_int
+    L.sjgpu_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), u32p]
+    L.sjgpu_trim_partial_utf8.restype = sz
+    L.sjgpu_trim_partial_utf8.argtypes = [vp, sz]
+    _lib = L
+    return L
+
+
+def _as_u8(data):
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(bytes(data), dtype=np.uint8).copy() if len(data) else np.zeros(0, np.uint8)
+
+
+class DomParserImplementation:
+    """One GPU parser context == one simdjson dom_parser_implementation instance (stage-1 part).
+
+    Mirrors the members the reference's callers touch: `n_structural_indexes`, `structural_indexes`,
+    `capacity()` / `set_capacity()`, `stage1(buf, len, mode)`."""
+
+    def __init__(self, capacity, device=0):
+        self.L = load_library()
+        h = ctypes.c_void_p()
+        rc = self.L.sjgpu_ctx_create(int(device), int(capacity), ctypes.byref(h))
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_ctx_create(device={device}, capacity={capacity}) failed with {rc} "
+                             f"(-1 = no HIP device; this backend has no CPU fallback)")
+        self.h = h
+        self.device = device
+        self.n_structural_indexes = 0
+        self.structural_indexes = np.zeros(((int(capacity) + 63) // 64) * 64 + 9, dtype=np.uint32)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sjgpu_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def capacity(self):
+        return int(self.L.sjgpu_capacity(self.h))
+
+    def set_capacity(self, capacity):
+        rc = self.L.sjgpu_set_capacity(self.h, int(capacity))
+        if rc == 0:
+            self.structural_indexes = np.zeros(((int(capacity) + 63) // 64) * 64 + 9, dtype=np.uint32)
+        return rc
+
+    def last_error(self):
+        return self.L.sjgpu_last_error(self.h).decode()
+
+    # ---- host-buffer path (what dom::parser / ondemand::parser drive through the plug-in shim) ----
+    def stage1(self, data, mode=REGULAR):
+        a = _as_u8(data)
+        n = ctypes.c_uint32(self.n_structural_indexes)
+        rc = self.L.sjgpu_stage1(self.h, a.ctypes.data, len(a), int(mode), self.structural_indexes.ctypes.data,
+                                 len(self.structural_indexes), ctypes.byref(n))
+        self.n_structural_indexes = int(n.value)
+        if rc < 0:
+            raise SjgpuError(f"sjgpu_stage1 infrastructure error {rc}: {self.last_error()}")
+        return rc
+
+    def minify(self, data):
+        a = _as_u8(data)
+        dst = np.empty(max(len(a), 1), dtype=np.uint8)
+        n = ctypes.c_size_t(0)
+        rc = self.L.sjgpu_minify(self.h, a.ctypes.data, len(a), dst.ctypes.data, ctypes.byref(n))
+        if rc < 0:
+            raise SjgpuError(f"sjgpu_minify infrastructure error {rc}: {self.last_error()}")
+        return rc, dst[: n.value]
+
+    def validate_utf8(self, data):
+        a = _as_u8(data)
+        ok = ctypes.c_int(0)
+        rc = self.L.sjgpu_validate_utf8(self.h, a.ctypes.data, len(a), ctypes.byref(ok))
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_validate_utf8 error {rc}: {self.last_error()}")
+        return bool(ok.value)
+
+    # ---- device-resident path (pointers are raw device addresses, e.g. torch.Tensor.data_ptr()) ----
+    def stage1_device(self, buf_ptr, length, idx_ptr, idx_words, stream=0):
+        rc = self.L.sjgpu_stage1_device(self.h, buf_ptr, int(length), idx_ptr, int(idx_words), stream or None)
+        if rc < 0:
+            raise SjgpuError(f"sjgpu_stage1_device error {rc}: {self.last_error()}")
+        return rc
+
+    def minify_device(self, buf_ptr, length, dst_ptr, stream=0):
+        rc = self.L.sjgpu_minify_device(self.h, buf_ptr, int(length), dst_ptr, stream or None)
+        if rc < 0:
+            raise SjgpuError(f"sjgpu_minify_device error {rc}: {self.last_error()}")
+        return rc
+
+    def validate_utf8_device(self, buf_ptr, length, stream=0):
+        rc = self.L.sjgpu_validate_utf8_device(self.h, buf_ptr, int(length), stream or None)
+        if rc < 0:
+            raise SjgpuError(f"sjgpu_validate_utf8_device error {rc}: {self.last_error()}")
+        return rc
+
+    def result(self, stream=0):  # waits for `stream`
+        r = ScanResult()
+        rc = self.L.sjgpu_result(self.h, stream or None, ctypes.byref(r))
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_result error {rc}: {self.last_error()}")
+        return int(r.n), int(r.flags), int(r.out_len)
+
+
+    def profile_enable(self, on=True):
+        rc = self.L.sjgpu_profile_enable(self.h, 1 if on else 0)
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_profile_enable error {rc}: {self.last_error()}")
+
+    def profile_read(self):
+        """-> ([ms_sum per kernel slot], calls) accumulated since the last read (HIP events on the launch stream)."""
+        ms = (ctypes.c_double * 3)()
+        calls = ctypes.c_uint32(0)
+        rc = self.L.sjgpu_profile_read(self.h, ms, ctypes.byref(calls))
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_profile_read error {rc}: {self.last_error()}")
+        return [float(x) for x in ms], int(calls.value)
+
+
+def stage1_error_from_flags(n, flags):
+    return int(load_library().sjgpu_stage1_error_from_flags(int(n), int(flags)))
+
+
+def device_count():
+    return int(load_library().sjgpu_device_count())

@@ -10,10 +10,14 @@
  *                  (ASIN, brand, title, two URLs, rating, review URL, review count, price).
  *   twitter_like : pretty-printed nested objects with escapes and 2/3/4-byte UTF-8, in the spirit of
  *                  jsonexamples/twitter.json (which does not travel to the GPU box).
- * The RNG is our own xorshift64* so every buffer is a pure function of (kind, seed, size).
+ * The RNG is our own xorshift64* so every buffer is a pure function of (kind, seed, size): units
+ * (records / lines / statuses) come in blocks of UNITS_PER_BLOCK, block b drawing from a stream seeded
+ * by (kind, seed, b), which lets the blocks be generated on all host cores (OpenMP) without changing
+ * the bytes.
  */
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 typedef struct { uint64_t s; } rng_t;
@@ -40,22 +44,9 @@ static void put_record(out_t *o, rng_t *r) {
   int k = snprintf(tmp, sizeof tmp, "{ \"x\":%g,  \"y\":%g, \"z\":%g}", rnd_unit(r), rnd_unit(r), rnd_unit(r));
   put(o, tmp, (size_t)k);
 }
-/* Fills dst with the smallest record count whose text is >= target bytes (and <= cap). Returns
- * the byte length, or 0 if cap is too small. */
-size_t sjc_large_random(uint8_t *dst, size_t cap, size_t target, uint64_t seed, uint64_t *n_records) {
-  rng_t r = { seed * 0x9E3779B97F4A7C15ull + 0x1234567ull };
-  out_t o = { dst, 0, cap };
-  uint64_t n = 0;
-  puts_(&o, "[\n");
-  put_record(&o, &r); n++;
-  puts_(&o, "\n");
-  while (o.len + 3 < target) {
-    puts_(&o, ",\n");
-    put_record(&o, &r); n++;
-  }
-  puts_(&o, "\n]\n");
-  if (n_records) { *n_records = n; }
-  return o.len <= cap ? o.len : 0;
+static void unit_large_random(out_t *o, rng_t *r, uint64_t index) {
+  if (index == 0) { put_record(o, r); puts_(o, "\n"); }
+  else { puts_(o, ",\n"); put_record(o, r); }
 }
 
 /* ---- amazon-style NDJSON -------------------------------------------------------------------- */
@@ -97,15 +88,7 @@ static void put_line(out_t *o, rng_t *r) {
   if (rnd_below(r, 4)) { k = snprintf(tmp, sizeof tmp, "$%u.%02u", 5 + rnd_below(r, 900), rnd_below(r, 100)); put(o, tmp, (size_t)k); }
   puts_(o, "\"]\n");
 }
-size_t sjc_amazon_ndjson(uint8_t *dst, size_t cap, size_t target, uint64_t seed, uint64_t *n_lines) {
-  rng_t r = { seed * 0x9E3779B97F4A7C15ull + 0x7654321ull };
-  out_t o = { dst, 0, cap };
-  uint64_t n = 1;
-  puts_(&o, "[\"asin\",\"brand\",\"title\",\"url\",\"image\",\"rating\",\"reviewUrl\",\"totalReviews\",\"prices\"]\n");
-  while (o.len < target) { put_line(&o, &r); n++; }
-  if (n_lines) { *n_lines = n; }
-  return o.len <= cap ? o.len : 0;
-}
+static void unit_amazon(out_t *o, rng_t *r, uint64_t index) { (void)index; put_line(o, r); }
 
 /* ---- twitter-like ---------------------------------------------------------------------------- */
 static const char *const TEXT[] = { "RT", "@user", "hello", "world", "\\n", "\\\"quoted\\\"", "http:\\/\\/t.co\\/AbC123",
@@ -152,16 +135,106 @@ static void put_status(out_t *o, rng_t *r, int d) {
   indent(o, d + 1); put(o, tmp, (size_t)k);
   indent(o, d); puts_(o, "}");
 }
+static void unit_twitter(out_t *o, rng_t *r, uint64_t index) {
+  if (index) { puts_(o, ",\n"); }
+  put_status(o, r, 2);
+}
+
+/* ---- block-parallel driver ----------------------------------------------------------------------------
+ * text = header + unit(0) + unit(1) + ... + unit(n-1) + trailer with the smallest n >= 1 such that
+ * the total is >= target. */
+#define UNITS_PER_BLOCK 16384u
+typedef void (*unit_fn)(out_t *, rng_t *, uint64_t);
+
+static rng_t block_rng(uint64_t salt, uint64_t seed, uint64_t block) {
+  rng_t r = { (seed + 1) * 0x9E3779B97F4A7C15ull ^ (block + 1) * 0xD1B54A32D192ED03ull ^ salt };
+  if (r.s == 0) { r.s = 0x1234567ull; }
+  (void)rnd(&r); (void)rnd(&r);
+  return r;
+}
+/* generates units [first, first+count) of block `block` into o (o may be a counting-only sink) */
+static void gen_block(out_t *o, unit_fn fn, uint64_t salt, uint64_t seed, uint64_t block, uint32_t count) {
+  rng_t r = block_rng(salt, seed, block);
+  for (uint32_t i = 0; i < count; i++) { fn(o, &r, block * UNITS_PER_BLOCK + i); }
+}
+
+static size_t generate(uint8_t *dst, size_t cap, size_t target, uint64_t seed, uint64_t salt, const char *header,
+                       const char *trailer, unit_fn fn, size_t approx_unit, uint64_t *n_units) {
+  const size_t hl = strlen(header), tl = strlen(trailer);
+  size_t nblk_cap = target / (approx_unit * UNITS_PER_BLOCK / 2) + 2, nblk = 0;
+  size_t *blen = (size_t *)calloc(nblk_cap, sizeof(size_t));
+  uint8_t **bbuf = (uint8_t **)calloc(nblk_cap, sizeof(uint8_t *));
+  if (!blen || !bbuf) { free(blen); free(bbuf); return 0; }
+  size_t total = hl + tl;
+  int oom = 0;
+  /* generate waves of blocks until header+units+trailer reaches the target */
+  while (total < target && nblk < nblk_cap && !oom) {
+    size_t want = (target - total) / (approx_unit * UNITS_PER_BLOCK) + 1;
+    if (want > nblk_cap - nblk) { want = nblk_cap - nblk; }
+    const size_t bcap = (size_t)UNITS_PER_BLOCK * approx_unit * 4 + 4096;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long b = (long)nblk; b < (long)(nblk + want); b++) {
+      uint8_t *p = (uint8_t *)malloc(bcap);
+      out_t o = { p, 0, p ? bcap : 0 };
+      gen_block(&o, fn, salt, seed, (uint64_t)b, UNITS_PER_BLOCK);
+      if (!p || o.len > bcap) { free(p); p = NULL; }
+      bbuf[b] = p;
+      blen[b] = o.len;
+    }
+    for (size_t b = nblk; b < nblk + want; b++) {
+      if (!bbuf[b]) { oom = 1; }
+      total += blen[b];
+    }
+    nblk += want;
+  }
+  size_t result = 0;
+  if (!oom && total >= target && nblk > 0) {
+    /* drop whole surplus blocks, then cut the last block at unit granularity */
+    while (nblk > 1 && total - blen[nblk - 1] >= target) { total -= blen[--nblk]; }
+    const size_t before_last = total - blen[nblk - 1];
+    rng_t r = block_rng(salt, seed, nblk - 1);
+    out_t cnt = { NULL, 0, 0 };
+    uint32_t units_last = 0;
+    while (units_last < UNITS_PER_BLOCK && (units_last == 0 || before_last + cnt.len < target)) {
+      fn(&cnt, &r, (uint64_t)(nblk - 1) * UNITS_PER_BLOCK + units_last);
+      units_last++;
+    }
+    const size_t last_len = cnt.len;
+    total = before_last + last_len;
+    if (total <= cap) {
+      size_t *boff = (size_t *)malloc(nblk * sizeof(size_t));
+      if (boff) {
+        size_t o = hl;
+        for (size_t b = 0; b < nblk; b++) { boff[b] = o; o += (b + 1 == nblk) ? last_len : blen[b]; }
+        memcpy(dst, header, hl);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (long b = 0; b < (long)nblk; b++) { memcpy(dst + boff[b], bbuf[b], ((size_t)b + 1 == nblk) ? last_len : blen[b]); }
+        memcpy(dst + o, trailer, tl);
+        result = total;
+        if (n_units) { *n_units = (uint64_t)(nblk - 1) * UNITS_PER_BLOCK + units_last; }
+        free(boff);
+      }
+    }
+  }
+  for (size_t b = 0; b < nblk_cap; b++) { free(bbuf[b]); }
+  free(bbuf);
+  free(blen);
+  return result;
+}
+
+/* Each fills dst (capacity cap) with the smallest unit count whose text is >= target bytes; returns
+ * the byte length, or 0 if cap is too small / out of memory. */
+size_t sjc_large_random(uint8_t *dst, size_t cap, size_t target, uint64_t seed, uint64_t *n_records) {
+  return generate(dst, cap, target, seed, 0x1234567ull, "[\n", "\n]\n", unit_large_random, 48, n_records);
+}
+size_t sjc_amazon_ndjson(uint8_t *dst, size_t cap, size_t target, uint64_t seed, uint64_t *n_lines) {
+  size_t n = generate(dst, cap, target, seed, 0x7654321ull,
+                      "[\"asin\",\"brand\",\"title\",\"url\",\"image\",\"rating\",\"reviewUrl\",\"totalReviews\",\"prices\"]\n", "",
+                      unit_amazon, 400, n_lines);
+  if (n && n_lines) { *n_lines += 1; }
+  return n;
+}
 size_t sjc_twitter_like(uint8_t *dst, size_t cap, size_t target, uint64_t seed, uint64_t *n_statuses) {
-  rng_t r = { seed * 0x9E3779B97F4A7C15ull + 0xABCDEFull };
-  out_t o = { dst, 0, cap };
-  uint64_t n = 0;
-  puts_(&o, "{\n  \"statuses\": [\n");
-  do {
-    if (n) { puts_(&o, ",\n"); }
-    put_status(&o, &r, 2); n++;
-  } while (o.len + 64 < target);
-  puts_(&o, "\n  ],\n  \"search_metadata\": { \"count\": 100, \"since_id\": 0 }\n}\n");
-  if (n_statuses) { *n_statuses = n; }
-  return o.len <= cap ? o.len : 0;
+  return generate(dst, cap, target, seed, 0xABCDEFull, "{\n  \"statuses\": [\n",
+                  "\n  ],\n  \"search_metadata\": { \"count\": 100, \"since_id\": 0 }\n}\n", unit_twitter, 900, n_statuses);
 }

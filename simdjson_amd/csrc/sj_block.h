@@ -150,34 +150,47 @@ SJ_HD u64 escaped_mask(u64 backslash, u64 first_is_escaped, u64 &next_is_escaped
 //   bits 1-2   byte[-2], byte[-1] is a 3/4-byte lead
 //   bits 3-5   byte[-3], byte[-2], byte[-1] is a 4-byte lead
 //   bit 6..9   byte[-1] is E0 / ED / F0 / F4
-SJ_HD u64 utf8_errors(const planes &P, u32 carry_in, u32 &carry_out) {
+struct utf8_leads {
+  u64 cont, l234, l34, l4, e0, ed, f0, f4, bad;
+};
+SJ_HD utf8_leads utf8_classify(const planes &P) {
   const u64 b0 = P.b[0], b1 = P.b[1], b2 = P.b[2], b3 = P.b[3], b4 = P.b[4], b5 = P.b[5], b6 = P.b[6], b7 = P.b[7];
-  const u64 cont = b7 & ~b6;
+  utf8_leads L;
+  L.cont = b7 & ~b6;
   const u64 l2 = b7 & b6 & ~b5;                 // C0..DF
   const u64 l3 = b7 & b6 & b5 & ~b4;            // E0..EF
-  const u64 l4 = b7 & b6 & b5 & b4 & ~b3;       // F0..F7
-  const u64 bad = (b7 & b6 & b5 & b4 & b3)      // F8..FF
-                  | (l2 & ~b4 & ~b3 & ~b2 & ~b1) // C0, C1 (overlong 2-byte)
-                  | (l4 & b2 & (b1 | b0));      // F5..F7 (> U+10FFFF)
+  L.l4 = b7 & b6 & b5 & b4 & ~b3;               // F0..F7
+  L.bad = (b7 & b6 & b5 & b4 & b3)              // F8..FF
+          | (l2 & ~b4 & ~b3 & ~b2 & ~b1)        // C0, C1 (overlong 2-byte)
+          | (L.l4 & b2 & (b1 | b0));            // F5..F7 (> U+10FFFF)
   const u64 lowz = ~b2 & ~b1 & ~b0;
-  const u64 e0 = l3 & ~b3 & lowz;
-  const u64 ed = l3 & b3 & b2 & ~b1 & b0;
-  const u64 f0 = l4 & lowz;
-  const u64 f4 = l4 & b2 & ~b1 & ~b0;
-  const u64 l234 = l2 | l3 | l4, l34 = l3 | l4;
-  const u64 expect = ((l234 << 1) | (carry_in & 1u)) | ((l34 << 2) | ((carry_in >> 1) & 3u)) |
-                     ((l4 << 3) | ((carry_in >> 3) & 7u));
-  const u64 after_e0 = (e0 << 1) | ((carry_in >> 6) & 1u);
-  const u64 after_ed = (ed << 1) | ((carry_in >> 7) & 1u);
-  const u64 after_f0 = (f0 << 1) | ((carry_in >> 8) & 1u);
-  const u64 after_f4 = (f4 << 1) | ((carry_in >> 9) & 1u);
+  L.e0 = l3 & ~b3 & lowz;
+  L.ed = l3 & b3 & b2 & ~b1 & b0;
+  L.f0 = L.l4 & lowz;
+  L.f4 = L.l4 & b2 & ~b1 & ~b0;
+  L.l34 = l3 | L.l4;
+  L.l234 = l2 | L.l34;
+  return L;
+}
+// What this block demands of the next one (independent of its own carry-in).
+SJ_HD u32 utf8_carry_out(const utf8_leads &L) {
+  return u32(L.l234 >> 63) | (u32(L.l34 >> 62) << 1) | (u32(L.l4 >> 61) << 3) | (u32(L.e0 >> 63) << 6) |
+         (u32(L.ed >> 63) << 7) | (u32(L.f0 >> 63) << 8) | (u32(L.f4 >> 63) << 9);
+}
+// Mask of offending positions given the previous block's demands.
+SJ_HD u64 utf8_errors(const planes &P, const utf8_leads &L, u32 carry_in) {
+  const u64 b4 = P.b[4], b5 = P.b[5];
+  const u64 expect = ((L.l234 << 1) | (carry_in & 1u)) | ((L.l34 << 2) | ((carry_in >> 1) & 3u)) |
+                     ((L.l4 << 3) | ((carry_in >> 3) & 7u));
+  const u64 after_e0 = (L.e0 << 1) | ((carry_in >> 6) & 1u);
+  const u64 after_ed = (L.ed << 1) | ((carry_in >> 7) & 1u);
+  const u64 after_f0 = (L.f0 << 1) | ((carry_in >> 8) & 1u);
+  const u64 after_f4 = (L.f4 << 1) | ((carry_in >> 9) & 1u);
   const u64 second = (after_e0 & ~b5)          // E0 80..9F : overlong 3-byte
                      | (after_ed & b5)         // ED A0..BF : surrogate
                      | (after_f0 & ~b5 & ~b4)  // F0 80..8F : overlong 4-byte
                      | (after_f4 & (b5 | b4)); // F4 90..BF : > U+10FFFF
-  carry_out = u32(l234 >> 63) | (u32(l34 >> 62) << 1) | (u32(l4 >> 61) << 3) | (u32(e0 >> 63) << 6) |
-              (u32(ed >> 63) << 7) | (u32(f0 >> 63) << 8) | (u32(f4 >> 63) << 9);
-  return (expect ^ cont) | bad | second;
+  return (expect ^ L.cont) | L.bad | second;
 }
 
 // The same carry word computed from three raw bytes (used once per segment for the look-back).
@@ -200,21 +213,28 @@ struct block_masks {
   u64 cand;        // op | (scalar & ~follows): structural candidates ignoring strings
   u64 string_tail; // in_string ^ quote (relative)
   u64 in_string;   // relative; includes opening quote, excludes closing quote
-  u64 quote;       // unescaped quotes
-  u64 ws;
 };
-SJ_HD block_masks string_algebra(const classes &c, u64 escaped, u32 in_string_carry, u32 prev_scalar_carry,
-                                 u32 &nonquote_scalar_msb) {
+// Step 1 (needs only the escaped mask): real quotes and "non-quote scalar" bytes.  Their bit 63 /
+// parity are what a lane hands to its right-hand neighbour.
+struct quote_scalar {
+  u64 quote;           // unescaped quotes
+  u64 scalar;          // neither whitespace nor operator
+  u64 nonquote_scalar; // scalar & ~quote
+};
+SJ_HD quote_scalar quotes_and_scalars(const classes &c, u64 escaped) {
+  quote_scalar q;
+  q.quote = c.quote & ~escaped;
+  q.scalar = ~(c.ws | c.op);
+  q.nonquote_scalar = q.scalar & ~q.quote;
+  return q;
+}
+// Step 2 (needs the two 1-bit carries of the lane).
+SJ_HD block_masks finish_block(const classes &c, const quote_scalar &q, u32 in_string_carry, u32 prev_scalar_carry) {
   block_masks m;
-  m.quote = c.quote & ~escaped;
-  m.in_string = prefix_xor(m.quote) ^ (0 - u64(in_string_carry));
-  const u64 scalar = ~(c.ws | c.op);
-  const u64 nonquote_scalar = scalar & ~m.quote;
-  const u64 follows = (nonquote_scalar << 1) | prev_scalar_carry;
-  nonquote_scalar_msb = u32(nonquote_scalar >> 63);
-  m.cand = c.op | (scalar & ~follows);
-  m.string_tail = m.in_string ^ m.quote;
-  m.ws = c.ws;
+  m.in_string = prefix_xor(q.quote) ^ (0 - u64(in_string_carry));
+  const u64 follows = (q.nonquote_scalar << 1) | prev_scalar_carry;
+  m.cand = c.op | (q.scalar & ~follows);
+  m.string_tail = m.in_string ^ q.quote;
   return m;
 }
 

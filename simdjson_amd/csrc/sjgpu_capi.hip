@@ -1,0 +1,329 @@
+// simdjson_amd/csrc/sjgpu_capi.hip -- the C-ABI of include/sjgpu.h: context/workspace management,
+// host<->device staging for the plug-in path, and kernel enqueueing.  No CPU compute path exists
+// here: if HIP is unusable every entry point returns a negative code.
+#include "sjgpu.h"
+#include "sjgpu_internal.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace sjgpu;
+
+struct sjgpu_ctx {
+  int device = 0;
+  size_t capacity = 0;
+  hipStream_t stream = nullptr;
+  // scan workspace (sized by capacity)
+  uint4 *masks = nullptr;
+  seg_summary *summ = nullptr;
+  seg_prefix *pref = nullptr;
+  scan_result_dev *d_result = nullptr;
+  scan_result_dev *h_result = nullptr; // pinned
+  // staging for the host-buffer entry points (allocated on first use)
+  uint8_t *d_in = nullptr;
+  size_t d_in_bytes = 0;
+  uint32_t *d_idx = nullptr;
+  size_t d_idx_words = 0;
+  uint8_t *d_out = nullptr;
+  size_t d_out_bytes = 0;
+  // event profiling (sjgpu_profile_*)
+  bool profile = false;
+  std::vector<hipEvent_t> events; // PROFILE_EVENTS per recorded call
+  char err[256] = {0};
+};
+
+namespace {
+
+constexpr int E_CAPACITY = 1, E_UTF8 = 11, E_EMPTY = 13, E_UNCLOSED = 15, E_UNEXPECTED = 24;
+
+int fail(sjgpu_ctx *ctx, hipError_t e, const char *what) {
+  if (ctx) { std::snprintf(ctx->err, sizeof ctx->err, "%s: %s", what, hipGetErrorString(e)); }
+  return (e == hipErrorOutOfMemory) ? SJGPU_E_NOMEM : SJGPU_E_HIP;
+}
+#define SJ_TRY(ctx, call)                                  \
+  do {                                                     \
+    hipError_t e_ = (call);                                \
+    if (e_ != hipSuccess) { return fail((ctx), e_, #call); } \
+  } while (0)
+
+template <class T> void dev_free(T *&p) {
+  if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+int grow(sjgpu_ctx *ctx, void **p, size_t *have, size_t want) {
+  if (*have >= want) { return 0; }
+  if (*p) { (void)hipFree(*p); *p = nullptr; *have = 0; }
+  SJ_TRY(ctx, hipMalloc(p, want));
+  *have = want;
+  return 0;
+}
+
+void release_workspace(sjgpu_ctx *ctx) {
+  dev_free(ctx->masks);
+  dev_free(ctx->summ);
+  dev_free(ctx->pref);
+  dev_free(ctx->d_in);
+  dev_free(ctx->d_idx);
+  dev_free(ctx->d_out);
+  ctx->d_in_bytes = ctx->d_out_bytes = 0;
+  ctx->d_idx_words = 0;
+  ctx->capacity = 0;
+}
+
+int fetch_result(sjgpu_ctx *ctx, hipStream_t s, sjgpu_scan_result *out) {
+  SJ_TRY(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_result, sizeof(scan_result_dev), hipMemcpyDeviceToHost, s));
+  SJ_TRY(ctx, hipStreamSynchronize(s));
+  out->n = ctx->h_result->n;
+  out->flags = ctx->h_result->flags;
+  out->out_len = ctx->h_result->out_len;
+  return 0;
+}
+
+constexpr size_t MAX_PROFILED_CALLS = 4096;
+
+// events for the next call, or nullptr when profiling is off / the ring is full
+hipEvent_t *next_events(sjgpu_ctx *ctx) {
+  if (!ctx->profile || ctx->events.size() >= MAX_PROFILED_CALLS * PROFILE_EVENTS) { return nullptr; }
+  const size_t at = ctx->events.size();
+  for (int k = 0; k < PROFILE_EVENTS; k++) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) {
+      while (ctx->events.size() > at) { (void)hipEventDestroy(ctx->events.back()); ctx->events.pop_back(); }
+      return nullptr;
+    }
+    ctx->events.push_back(e);
+  }
+  return ctx->events.data() + at;
+}
+
+void drop_events(sjgpu_ctx *ctx) {
+  for (hipEvent_t e : ctx->events) { (void)hipEventDestroy(e); }
+  ctx->events.clear();
+}
+
+hipStream_t pick(sjgpu_ctx *ctx, void *stream) { return stream ? static_cast<hipStream_t>(stream) : ctx->stream; }
+
+} // namespace
+
+extern "C" {
+
+int sjgpu_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { return 0; }
+  return n;
+}
+
+int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out) {
+  if (!out) { return SJGPU_E_BADARG; }
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) { return SJGPU_E_NO_DEVICE; }
+  sjgpu_ctx *ctx = new (std::nothrow) sjgpu_ctx();
+  if (!ctx) { return SJGPU_E_NOMEM; }
+  ctx->device = device;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) { e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking); }
+  if (e == hipSuccess) { e = hipMalloc(reinterpret_cast<void **>(&ctx->d_result), sizeof(scan_result_dev)); }
+  if (e == hipSuccess) { e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_result), sizeof(scan_result_dev), hipHostMallocDefault); }
+  if (e != hipSuccess) {
+    int rc = fail(nullptr, e, "ctx_create");
+    sjgpu_ctx_destroy(ctx);
+    return rc;
+  }
+  int rc = sjgpu_set_capacity(ctx, capacity);
+  if (rc != 0) {
+    sjgpu_ctx_destroy(ctx);
+    return rc;
+  }
+  *out = ctx;
+  return 0;
+}
+
+void sjgpu_ctx_destroy(sjgpu_ctx *ctx) {
+  if (!ctx) { return; }
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+  release_workspace(ctx);
+  drop_events(ctx);
+  dev_free(ctx->d_result);
+  if (ctx->h_result) { (void)hipHostFree(ctx->h_result); }
+  if (ctx->stream) { (void)hipStreamDestroy(ctx->stream); }
+  delete ctx;
+}
+
+int sjgpu_set_capacity(sjgpu_ctx *ctx, size_t capacity) {
+  if (!ctx || capacity > 0xFFFFFFFFull) { return SJGPU_E_BADARG; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->stream) { SJ_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
+  release_workspace(ctx);
+  if (capacity == 0) { return 0; }
+  const size_t nseg = num_segments(capacity);
+  SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->masks), nseg * (SEG_BYTES / BLOCK_BYTES) * sizeof(uint4)));
+  SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->summ), nseg * sizeof(seg_summary)));
+  SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->pref), nseg * sizeof(seg_prefix)));
+  ctx->capacity = capacity;
+  return 0;
+}
+
+size_t sjgpu_capacity(const sjgpu_ctx *ctx) { return ctx ? ctx->capacity : 0; }
+const char *sjgpu_last_error(const sjgpu_ctx *ctx) { return ctx ? ctx->err : ""; }
+
+// ---- device-resident entry points ------------------------------------------------------------------
+int sjgpu_stage1_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *idx_dev, size_t idx_words, void *stream) {
+  if (!ctx || !buf_dev || !idx_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u) || (reinterpret_cast<uintptr_t>(idx_dev) & 3u)) {
+    return SJGPU_E_BADARG;
+  }
+  if (len > ctx->capacity) { return E_CAPACITY; }
+  if (len == 0) { return E_EMPTY; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  launch_stage1(static_cast<const uint8_t *>(buf_dev), len, ctx->masks, ctx->summ, ctx->pref, static_cast<uint32_t *>(idx_dev),
+                idx_words, ctx->d_result, pick(ctx, stream), next_events(ctx));
+  SJ_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int sjgpu_minify_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *dst_dev, void *stream) {
+  if (!ctx || !buf_dev || !dst_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u) || (reinterpret_cast<uintptr_t>(dst_dev) & 15u)) {
+    return SJGPU_E_BADARG;
+  }
+  if (len > ctx->capacity) { return E_CAPACITY; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  if (len == 0) { // SUCCESS with zero bytes (json_minifier.h:68-97 with an empty reader)
+    SJ_TRY(ctx, hipMemsetAsync(ctx->d_result, 0, sizeof(scan_result_dev), pick(ctx, stream)));
+    return 0;
+  }
+  launch_minify(static_cast<const uint8_t *>(buf_dev), len, ctx->summ, ctx->pref, static_cast<uint8_t *>(dst_dev), ctx->d_result,
+                pick(ctx, stream), next_events(ctx));
+  SJ_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int sjgpu_validate_utf8_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *stream) {
+  if (!ctx || (len && (!buf_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u)))) { return SJGPU_E_BADARG; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  if (len == 0) {
+    SJ_TRY(ctx, hipMemsetAsync(ctx->d_result, 0, sizeof(scan_result_dev), pick(ctx, stream)));
+    return 0;
+  }
+  launch_validate_utf8(static_cast<const uint8_t *>(buf_dev), len, ctx->d_result, pick(ctx, stream), next_events(ctx));
+  SJ_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int sjgpu_result(sjgpu_ctx *ctx, void *stream, sjgpu_scan_result *out) {
+  if (!ctx || !out) { return SJGPU_E_BADARG; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  return fetch_result(ctx, pick(ctx, stream), out);
+}
+
+int sjgpu_profile_enable(sjgpu_ctx *ctx, int on) {
+  if (!ctx) { return SJGPU_E_BADARG; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  SJ_TRY(ctx, hipDeviceSynchronize());
+  drop_events(ctx);
+  ctx->profile = on != 0;
+  if (ctx->profile) { ctx->events.reserve(MAX_PROFILED_CALLS * PROFILE_EVENTS); } // pointers handed out stay valid
+  return 0;
+}
+
+int sjgpu_profile_read(sjgpu_ctx *ctx, double *ms_sum, uint32_t *calls) {
+  if (!ctx || !ms_sum || !calls) { return SJGPU_E_BADARG; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  SJ_TRY(ctx, hipDeviceSynchronize());
+  const size_t ncalls = ctx->events.size() / PROFILE_EVENTS;
+  for (int k = 0; k < PROFILE_SLOTS; k++) { ms_sum[k] = 0.0; }
+  for (size_t c = 0; c < ncalls; c++) {
+    for (int k = 0; k < PROFILE_SLOTS; k++) {
+      float ms = 0.f;
+      SJ_TRY(ctx, hipEventElapsedTime(&ms, ctx->events[c * PROFILE_EVENTS + k], ctx->events[c * PROFILE_EVENTS + k + 1]));
+      ms_sum[k] += double(ms);
+    }
+  }
+  *calls = uint32_t(ncalls);
+  drop_events(ctx);
+  return 0;
+}
+
+// ---- host-buffer entry points (the plug-in path: H2D, scan, D2H, host finish) ---------------------------
+int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint32_t *idx_out, size_t idx_words, uint32_t *n_io) {
+  if (!ctx || !n_io || mode < SJGPU_REGULAR || mode > SJGPU_COMMA_DELIMITED_FINAL) { return SJGPU_E_BADARG; }
+  if (len > ctx->capacity) { return E_CAPACITY; } // json_structural_indexer.h:195
+  if (len == 0) { return E_EMPTY; }               // :197
+  if (!buf || !idx_out) { return SJGPU_E_BADARG; }
+  if (mode != SJGPU_REGULAR) {                    // :198-204
+    len = sjgpu_trim_partial_utf8(buf, len);
+    if (len == 0) { return E_UTF8; }
+  }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_in), &ctx->d_in_bytes, ctx->capacity);
+  if (rc) { return rc; }
+  size_t idx_bytes = ctx->d_idx_words * sizeof(uint32_t);
+  rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_idx), &idx_bytes, (ctx->capacity + 3) * sizeof(uint32_t));
+  ctx->d_idx_words = idx_bytes / sizeof(uint32_t);
+  if (rc) { return rc; }
+  hipStream_t s = ctx->stream;
+  SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
+  launch_stage1(ctx->d_in, len, ctx->masks, ctx->summ, ctx->pref, ctx->d_idx, ctx->d_idx_words, ctx->d_result, s, nullptr);
+  SJ_TRY(ctx, hipGetLastError());
+  sjgpu_scan_result res;
+  rc = fetch_result(ctx, s, &res);
+  if (rc) { return rc; }
+  if (res.flags & SJGPU_F_IDX_OVERFLOW) { return E_UNEXPECTED; }
+  // the two early exits of finish() need no index traffic (json_structural_indexer.h:255-263)
+  if ((res.flags & SJGPU_F_UNCLOSED_STRING) && mode == SJGPU_REGULAR) { return E_UNCLOSED; }
+  if (res.flags & SJGPU_F_UNESCAPED_CTRL) { return 14; }
+  if (size_t(res.n) + 3 > idx_words) { return SJGPU_E_OVERFLOW; }
+  SJ_TRY(ctx, hipMemcpyAsync(idx_out, ctx->d_idx, (size_t(res.n) + 3) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  SJ_TRY(ctx, hipStreamSynchronize(s));
+  return sjgpu_stage1_finish_host(buf, len, mode, idx_out, res.n, res.flags, n_io);
+}
+
+int sjgpu_minify(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, uint8_t *dst, size_t *dst_len) {
+  if (!ctx || !dst_len) { return SJGPU_E_BADARG; }
+  *dst_len = 0;
+  if (len == 0) { return 0; }
+  if (!buf || !dst) { return SJGPU_E_BADARG; }
+  if (len > ctx->capacity) { return E_CAPACITY; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_in), &ctx->d_in_bytes, ctx->capacity);
+  if (rc) { return rc; }
+  rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_out), &ctx->d_out_bytes, ctx->capacity + 16);
+  if (rc) { return rc; }
+  hipStream_t s = ctx->stream;
+  SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
+  launch_minify(ctx->d_in, len, ctx->summ, ctx->pref, ctx->d_out, ctx->d_result, s, nullptr);
+  SJ_TRY(ctx, hipGetLastError());
+  sjgpu_scan_result res;
+  rc = fetch_result(ctx, s, &res);
+  if (rc) { return rc; }
+  if (res.flags & SJGPU_F_UNCLOSED_STRING) { return E_UNCLOSED; }
+  if (res.out_len > len) { return E_UNEXPECTED; }
+  SJ_TRY(ctx, hipMemcpyAsync(dst, ctx->d_out, res.out_len, hipMemcpyDeviceToHost, s));
+  SJ_TRY(ctx, hipStreamSynchronize(s));
+  *dst_len = res.out_len;
+  return 0;
+}
+
+int sjgpu_validate_utf8(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int *ok) {
+  if (!ctx || !ok) { return SJGPU_E_BADARG; }
+  *ok = 1;
+  if (len == 0) { return 0; }
+  if (!buf) { return SJGPU_E_BADARG; }
+  if (len > ctx->capacity) { return E_CAPACITY; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_in), &ctx->d_in_bytes, ctx->capacity);
+  if (rc) { return rc; }
+  hipStream_t s = ctx->stream;
+  SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
+  launch_validate_utf8(ctx->d_in, len, ctx->d_result, s, nullptr);
+  SJ_TRY(ctx, hipGetLastError());
+  sjgpu_scan_result res;
+  rc = fetch_result(ctx, s, &res);
+  if (rc) { return rc; }
+  *ok = (res.flags & SJGPU_F_UTF8_ERROR) ? 0 : 1;
+  return 0;
+}
+
+} // extern "C"

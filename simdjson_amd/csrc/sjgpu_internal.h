@@ -1,0 +1,62 @@
+// simdjson_amd/csrc/sjgpu_internal.h -- launch interface between the C-ABI (sjgpu_capi.hip) and the
+// gfx950 kernels (sjgpu_kernels.hip).  Geometry:
+//
+//   block   = 64 input bytes                = one lane
+//   chunk   = 64 blocks = 4 KiB             = one wave64 pass
+//   segment = SEG_CHUNKS chunks = 16 KiB    = one wave's (= one workgroup's) contiguous share
+//
+// Device workspace per context (all sized from `capacity`, resident in HBM between calls):
+//   masks  [ceil(cap/64)] x uint4  {cand_lo, cand_hi, string_tail_lo, string_tail_hi} per block
+//   summ   [nseg] x seg_summary    per-segment carry summary (quote parity, counts for both in-string
+//                                  hypotheses, error bits)
+//   pref   [nseg] x seg_prefix     per-segment resolved carry-in (in-string bit, output base)
+//   result                          one scan_result, mirrored to pinned host memory
+#ifndef SJGPU_INTERNAL_H
+#define SJGPU_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sjgpu {
+
+constexpr uint32_t BLOCK_BYTES = 64;
+constexpr uint32_t CHUNK_BYTES = 4096;
+constexpr uint32_t SEG_CHUNKS = 4;
+constexpr uint32_t SEG_BYTES = CHUNK_BYTES * SEG_CHUNKS;
+
+// summary flags
+constexpr uint32_t SF_PARITY = 1u;     // odd number of unescaped quotes in the segment
+constexpr uint32_t SF_CTRL_IF_OUT = 2u; // control char inside a string if the segment starts OUTSIDE a string
+constexpr uint32_t SF_CTRL_IF_IN = 4u;  // ... if it starts INSIDE a string
+constexpr uint32_t SF_UTF8 = 8u;        // UTF-8 error in the segment
+
+struct seg_summary {
+  uint32_t count_if_out; // structurals (stage1) / kept bytes (minify) if the segment starts outside a string
+  uint32_t count_if_in;  // ... inside a string
+  uint32_t flags;
+  uint32_t pad;
+};
+struct seg_prefix {
+  uint32_t base; // exclusive prefix of counts = first output slot of the segment
+  uint32_t in_string;
+};
+struct scan_result_dev {
+  uint32_t n;
+  uint32_t flags;
+  uint64_t out_len;
+};
+
+inline uint32_t num_segments(uint64_t len) { return uint32_t((len + SEG_BYTES - 1) / SEG_BYTES); }
+
+// ---- launchers (sjgpu_kernels.hip); every one only enqueues on `stream` ---------------------------------
+// ev: nullptr, or PROFILE_EVENTS events recorded around the kernels (ev[k], ev[k+1] bracket kernel k).
+constexpr int PROFILE_SLOTS = 3;
+constexpr int PROFILE_EVENTS = PROFILE_SLOTS + 1;
+void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *summ, seg_prefix *pref, uint32_t *idx,
+                   uint64_t idx_words, scan_result_dev *result, hipStream_t stream, hipEvent_t *ev);
+void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_prefix *pref, uint8_t *dst,
+                   scan_result_dev *result, hipStream_t stream, hipEvent_t *ev);
+void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *result, hipStream_t stream, hipEvent_t *ev);
+
+} // namespace sjgpu
+#endif

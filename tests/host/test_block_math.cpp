@@ -76,14 +76,15 @@ int main() {
       classes c = classify(P);
       u64 e_out;
       u64 escaped = escaped_mask(c.backslash, e, e_out);
-      u32 msb;
-      block_masks m = string_algebra(c, escaped, s, p, msb);
+      quote_scalar qs = quotes_and_scalars(c, escaped);
+      u32 msb = u32(qs.nonquote_scalar >> 63);
+      block_masks m = finish_block(c, qs, s, p);
       u64 structural = m.cand & ~m.string_tail;
       for (int i = 0; i < 64; i++) { if ((structural >> i) & 1) { got_idx.push_back(uint32_t(64 * bk + i)); } }
       ctrl_err |= c.ctrl & m.in_string;
-      u32 carry_out;
-      utf_err |= utf8_errors(P, carry, carry_out);
-      carry = carry_out;
+      utf8_leads L = utf8_classify(P);
+      utf_err |= utf8_errors(P, L, carry);
+      carry = utf8_carry_out(L);
       e = e_out; s = u32(m.in_string >> 63); p = msb;
     }
     if (len % 64 == 0 && (carry & UTF8_CARRY_OPEN)) { utf_err |= 1; }
@@ -99,8 +100,7 @@ int main() {
     u32 w[16];
     std::memcpy(w, blk, 64);
     planes P = transpose64(w);
-    u32 co;
-    (void)utf8_errors(P, 0, co);
+    u32 co = utf8_carry_out(utf8_classify(P));
     CHECK(co == utf8_carry_from_bytes(blk[61], blk[62], blk[63]), "carry bytes it %d", it);
   }
   std::printf("block math OK\n");

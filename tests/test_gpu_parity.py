@@ -1,0 +1,251 @@
+"""GPU tier (-m gpu): the HIP path, called through the C-ABI (simdjson_amd.capi -> libsjgpu.so), against
+  * the committed golden fixtures produced by the real reference (tests/golden/*.json),
+  * the C oracle run live on the same seeded inputs,
+  * size-independent properties at BASELINE.json's full size (1 GiB).
+Bit-exact everywhere: indices, sentinels, n, error codes, minified bytes, UTF-8 verdicts."""
+import os
+
+import numpy as np
+import pytest
+
+import checkers
+from simdjson_amd import _paths, build, capi, corpus
+from test_oracle_golden import digest_results, load, make_corpus
+
+pytestmark = pytest.mark.gpu
+
+CAP = 128 << 20
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    build.build_sjgpu()
+    p = capi.DomParserImplementation(CAP)  # raises loudly if the HIP library or the GPU is missing
+    yield p
+    p.close()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return checkers.Oracle()
+
+
+def g_stage1(p, data, mode=0):
+    err = p.stage1(data, mode)
+    n = p.n_structural_indexes
+    return err, n, p.structural_indexes[: n + 3].copy()
+
+
+def first_diff(a, b):
+    m = min(len(a), len(b))
+    d = np.nonzero(a[:m] != b[:m])[0]
+    return (int(d[0]), int(a[d[0]]), int(b[d[0]])) if len(d) else ("len", len(a), len(b))
+
+
+def assert_same_stage1(p, orc, data, mode=0, tag=""):
+    got = checkers.observable(data, mode, *g_stage1(p, data, mode))
+    want = checkers.observable(data, mode, *orc.stage1(data, mode))
+    if got != want:
+        detail = (got[:2], want[:2])
+        if len(got) > 2 and len(want) > 2:
+            detail += (first_diff(np.array(got[2]), np.array(want[2])),)
+        raise AssertionError(f"stage1 mismatch {tag} mode={mode} len={len(data)}: {detail}")
+
+
+def assert_same_all(p, orc, data, tag="", modes=(0,)):
+    for mode in modes:
+        assert_same_stage1(p, orc, data, mode, tag)
+    gerr, gout = p.minify(data)
+    oerr, oout = orc.minify(data)
+    assert gerr == oerr and np.array_equal(gout, oout), f"minify mismatch {tag} len={len(data)}: {gerr} vs {oerr}, " \
+        f"{first_diff(np.asarray(gout), np.asarray(oout)) if gerr == oerr else ''}"
+    assert p.validate_utf8(data) == orc.validate_utf8(data), f"utf8 mismatch {tag}"
+
+
+# ---- golden fixtures (reference outputs) ------------------------------------------------------------------
+def test_small_cases_all_modes_golden(gpu):
+    for case in load("small_cases.json")["cases"]:
+        data = bytes.fromhex(case["hex"])
+        for mname, mode in checkers.MODES.items():
+            obs = checkers.observable(data, mode, *g_stage1(gpu, data, mode))
+            got = {"err": obs[0]} if len(obs) == 1 else {"err": obs[0], "n": obs[1], "idx": list(obs[2])}
+            assert got == case["stage1"][mname], (data, mname, got)
+        merr, mout = gpu.minify(data)
+        assert merr == case["minify"]["err"] and bytes(mout).hex() == case["minify"]["hex"], data
+        assert gpu.validate_utf8(data) == case["utf8"], data
+
+
+def test_utf8_known_answer_vectors_golden(gpu):
+    v = load("utf8_vectors.json")
+    for g in v["good"]:
+        assert gpu.validate_utf8(bytes.fromhex(g)), g
+    for b in v["bad"]:
+        assert not gpu.validate_utf8(bytes.fromhex(b)), b
+    # tests/dom/basictests.cpp:1814-1909 shapes
+    for n in range(0, 129, 7):
+        assert gpu.validate_utf8(b" " * n)
+        for off in range(0, n, 5):
+            a = bytearray(b" " * n)
+            a[off] = 0xFF
+            assert not gpu.validate_utf8(bytes(a))
+    assert not gpu.validate_utf8(b"\xf0\x8f\xbf\xbf")
+
+
+def test_random_adversarial_digests_golden(gpu, orc):
+    g = load("random_digest.json")
+    for d in g["digests"][:6]:
+        got = digest_results(orc, lambda a, m: g_stage1(gpu, a, m), gpu.minify, gpu.validate_utf8, d["seed"])
+        assert got == d["fnv"], d["seed"]
+
+
+def test_corpora_digests_golden(gpu, orc):
+    for d in load("corpora.json")["corpora"]:
+        a = make_corpus(d["name"])
+        if a is None:
+            continue  # jsonexamples/* exist only in the build container
+        assert len(a) == d["len"] and orc.fnv(a) == d["buf_fnv"], d["name"]
+        err, n, idx = g_stage1(gpu, a, 0)
+        assert (err, n) == (d["stage1_err"], d["n"]), (d["name"], err, n)
+        assert orc.fnv(idx) == d["idx_fnv"], d["name"]
+        merr, mout = gpu.minify(a)
+        assert (merr, len(mout), orc.fnv(mout)) == (d["minify_err"], d["minify_len"], d["minify_fnv"]), d["name"]
+        assert gpu.validate_utf8(a) == d["utf8"], d["name"]
+
+
+# ---- live oracle: boundaries, carries, adversarial --------------------------------------------------------------
+BOUNDARIES = (64, 4096, 16384, 32768)
+
+
+def test_payloads_straddling_every_boundary(gpu, orc):
+    v = load("utf8_vectors.json")
+    payloads = [bytes.fromhex(x) for x in v["good"] + v["bad"] if len(x) <= 20]
+    payloads += [b'"', b'\\"', b'\\\\"', b'\\\\\\"', b'"a\\"b"', b'"ab"cd', b"true", b"[1,2]", b'{"a":"\\\\"}', b"\x01", b'"\x01"',
+                 b"\x0c\x1a", b'"\\', b'\\', b"\xe2\x82\xac", b"\xf0\x9f\x98\x80", b'"\xf0\x9f\x98\x80"', b'a"b"c', b'" "', b"\x1e1"]
+    for B in BOUNDARIES:
+        for pay in payloads:
+            for before in range(0, len(pay) + 2):
+                for filler, pre in ((b" ", b""), (b"x", b'["'), (b" ", b'"')):
+                    start = B - before
+                    body = pre + filler * (start - len(pre)) + pay + filler * 70
+                    assert_same_all(gpu, orc, body, tag=f"B={B} before={before} pay={pay!r} filler={filler!r}")
+
+
+def test_quote_parity_and_escape_carry_across_segments(gpu, orc):
+    rng = np.random.default_rng(7)
+    for trial in range(12):
+        n = int(rng.integers(100_000, 400_000))
+        a = corpus.random_adversarial(n, 100 + trial, ascii_only=bool(trial % 2), p_backslash=(0.0, 0.05, 0.3)[trial % 3])
+        assert_same_all(gpu, orc, a, tag=f"random trial {trial}", modes=(0, 1, 2))
+    # backslash runs of critical lengths ending exactly at block / chunk / segment boundaries
+    for B in BOUNDARIES:
+        for run in (1, 2, 63, 64, 65, 127, 128, 129, 4095, 4096, 4097, 16383, 16384, 16385, 40000):
+            for shift in (0, 1):
+                start = max(1, B - run + shift)
+                body = b'"' + b"x" * (start - 1) + b"\\" * run + b'" ,"y"' + b" " * 100
+                assert_same_all(gpu, orc, body, tag=f"run={run} B={B} shift={shift}")
+    # strings that stay open across many segments; parity flips exactly at boundaries
+    for B in BOUNDARIES:
+        for off in (-1, 0, 1):
+            body = b"[" + b" " * (B + off - 2) + b'"' + b"z{[,:]}" * 9000 + b'"' + b",1]" + b" " * 50
+            assert_same_all(gpu, orc, body, tag=f"long string B={B} off={off}")
+
+
+def test_adversarial_shapes(gpu, orc):
+    for k in (1, 31, 32, 33, 2047, 2048, 2049, 8191, 8192, 8193, 100_000, 1 << 20):
+        assert_same_all(gpu, orc, corpus.deep_nesting(k), tag=f"deep_nesting {k}")
+    runs = [1, 2, 63, 64, 65, 127, 128, 129, 4095, 4096, 4097, 16383, 16384, 16385, (1 << 20) - 1, 1 << 20, (1 << 20) + 1]
+    for pad in (0, 1, 37, 63):
+        assert_same_all(gpu, orc, corpus.backslash_runs(runs, pad), tag=f"backslash_runs pad {pad}")
+    # control characters 0x00-0x1F inside and outside strings, incl. the 0x0C / 0x1A operator quirk
+    for c in range(0x20):
+        assert_same_all(gpu, orc, b"[1," + bytes([c]) + b"2]", tag=f"ctrl outside {c}")
+        assert_same_all(gpu, orc, b'["a' + bytes([c]) + b'b"]', tag=f"ctrl inside {c}")
+    # every length 0..200 of a few shapes (tail handling)
+    base = b'{"k":"v\\"w","n":[1,2,3],"u":"\xe2\x82\xac\xf0\x9f\x98\x80"} ' * 5
+    for n in range(0, 201):
+        assert_same_all(gpu, orc, base[:n], tag=f"prefix {n}", modes=(0, 1, 2))
+
+
+def test_streaming_modes_on_bulk(gpu, orc):
+    a, _ = corpus.amazon_ndjson(3 << 20, 5)
+    cut = a[: len(a) - 777]  # ends inside a line
+    for mode in (1, 2):
+        assert_same_stage1(gpu, orc, cut, mode, "ndjson cut")
+    seq = np.frombuffer(b"".join(b"\x1e" + bytes(l) + b"\n" for l in bytes(a[:200_000]).split(b"\n") if l), dtype=np.uint8)
+    for mode in (3, 4):
+        assert_same_stage1(gpu, orc, seq, mode, "json_sequence")
+        assert_same_stage1(gpu, orc, seq[:-300], mode, "json_sequence cut")
+    com = np.frombuffer(b",".join(bytes(l) for l in bytes(a[:200_000]).split(b"\n") if l), dtype=np.uint8)
+    for mode in (5, 6):
+        assert_same_stage1(gpu, orc, com, mode, "comma_delimited")
+        assert_same_stage1(gpu, orc, com[:-300], mode, "comma_delimited cut")
+
+
+def test_capacity_and_empty_guards(gpu):
+    small = capi.DomParserImplementation(16)
+    assert small.stage1(b"[1,2,3,4,5,6,7,8,9,10]") == capi.CAPACITY
+    assert small.stage1(b"") == capi.EMPTY
+    assert small.stage1(b"[1]") == capi.SUCCESS and small.n_structural_indexes == 3
+    assert small.minify(b"")[0] == capi.SUCCESS
+    assert small.validate_utf8(b"")
+    small.close()
+
+
+def test_reference_examples_if_present(gpu, orc):
+    ex = os.path.join(_paths.REFERENCE_DIR, "jsonexamples")
+    if not os.path.isdir(ex):
+        pytest.skip("jsonexamples live only in the build container")
+    for fn in ("twitter.json", "citm_catalog.json", "amazon_cellphones.ndjson"):
+        assert_same_all(gpu, orc, np.fromfile(os.path.join(ex, fn), dtype=np.uint8), tag=fn, modes=(0, 2))
+
+
+# ---- full size (BASELINE.json configs 2/3): device-resident path, 1 GiB ------------------------------------------
+@pytest.mark.parametrize("kind", ["large_random", "amazon_ndjson"])
+def test_full_size_device_resident(orc, kind):
+    import torch
+    size = int(os.environ.get("SJGPU_FULL_SIZE", str(1 << 30)))
+    a, _ = getattr(corpus, kind)(size, 11)
+    L = len(a)
+    p = capi.DomParserImplementation(L)
+    buf = torch.from_numpy(a).cuda()
+    idx = torch.empty(L + 3, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    assert p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, stream) == 0
+    n, flags, _ = p.result(stream)
+    oerr, on, oidx = orc.stage1(a, 0)
+    assert capi.stage1_error_from_flags(n, flags) == oerr == 0 and n == on
+    # properties: strictly ascending, in range, sentinels
+    got = idx[: n + 3]
+    assert bool((got[1:n] > got[: n - 1]).all()) and int(got[n - 1]) < L
+    assert [int(x) & 0xFFFFFFFF for x in got[n:]] == [L, L, 0]
+    # exact: digest of all n+3 words against the oracle's
+    host = got.cpu().numpy().view(np.uint32)
+    assert orc.fnv(host) == orc.fnv(oidx), first_diff(host, oidx)
+    del idx, got
+    # minify: exact vs oracle, idempotent, structural count preserved
+    dst = torch.empty(L + 16, dtype=torch.uint8, device="cuda")
+    assert p.minify_device(buf.data_ptr(), L, dst.data_ptr(), stream) == 0
+    _, mflags, mlen = p.result(stream)
+    oerr, oout = orc.minify(a)
+    assert oerr == 0 and mflags & 1 == 0 and mlen == len(oout)
+    mhost = dst[:mlen].cpu().numpy()
+    assert orc.fnv(mhost) == orc.fnv(oout), first_diff(mhost, oout)
+    dst2 = torch.empty(L + 16, dtype=torch.uint8, device="cuda")
+    mbuf = dst[:mlen].clone()
+    assert p.minify_device(mbuf.data_ptr(), mlen, dst2.data_ptr(), stream) == 0
+    _, _, mlen2 = p.result(stream)
+    assert mlen2 == mlen and bool((dst2[:mlen] == mbuf).all())
+    idx2 = torch.empty(mlen + 3, dtype=torch.int32, device="cuda")
+    assert p.stage1_device(mbuf.data_ptr(), mlen, idx2.data_ptr(), mlen + 3, stream) == 0
+    n2, flags2, _ = p.result(stream)
+    assert n2 == n and flags2 == 0
+    # utf8: valid; one corrupted byte anywhere makes it invalid
+    assert p.validate_utf8_device(buf.data_ptr(), L, stream) == 0
+    assert p.result(stream)[1] & capi.F_UTF8_ERROR == 0
+    for pos in (0, 4095, 4096, L // 2 + 63, L - 1):
+        old = int(buf[pos])
+        buf[pos] = 0xFF
+        assert p.validate_utf8_device(buf.data_ptr(), L, stream) == 0
+        assert p.result(stream)[1] & capi.F_UTF8_ERROR, pos
+        buf[pos] = old
+    p.close()

@@ -1,0 +1,82 @@
+"""CPU tier: the C-ABI library loads, exports what include/sjgpu.h declares, refuses to run without a
+GPU (no CPU fallback), and its host post-pass (stage1_finish.cpp) reproduces the reference's finish()
+for all seven modes when fed the raw scan of the oracle."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import checkers
+from simdjson_amd import _paths, build, capi
+from test_oracle_golden import load, random_case_stream
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_sjgpu()
+    return capi.load_library()
+
+
+def test_exports_match_header(lib):
+    hdr = open(os.path.join(_paths.INCLUDE_DIR, "sjgpu.h")).read()
+    declared = sorted(set(re.findall(r"\b(sjgpu_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == sorted(capi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_no_gpu_means_loud_failure(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert capi.device_count() == 0
+    h = ctypes.c_void_p()
+    assert lib.sjgpu_ctx_create(0, 1024, ctypes.byref(h)) == -1  # SJGPU_E_NO_DEVICE
+    with pytest.raises(capi.SjgpuError):
+        capi.DomParserImplementation(1024)
+
+
+def host_stage1(lib, orc, data, mode):
+    """sjgpu_stage1's host half: guards + trim, raw scan (here: the oracle's), sjgpu_stage1_finish_host."""
+    a = checkers.as_u8(data)
+    n_io = ctypes.c_uint32(0)
+    idx = np.zeros(len(a) + 3, dtype=np.uint32)
+    if len(a) == 0:
+        return capi.EMPTY, 0, idx[:3]
+    ln = len(a)
+    if mode != 0:
+        ln = lib.sjgpu_trim_partial_utf8(a.ctypes.data, ln)
+        if ln == 0:
+            return capi.UTF8_ERROR, 0, idx[:3]
+    raw, flags = orc.scan(a[:ln])
+    idx[: len(raw)] = raw
+    err = lib.sjgpu_stage1_finish_host(a.ctypes.data, ln, mode, idx.ctypes.data, len(raw), flags, ctypes.byref(n_io))
+    return err, int(n_io.value), idx[: n_io.value + 3].copy()
+
+
+def test_finish_host_small_cases(lib):
+    orc = checkers.Oracle()
+    for case in load("small_cases.json")["cases"]:
+        data = bytes.fromhex(case["hex"])
+        for mname, mode in checkers.MODES.items():
+            obs = checkers.observable(data, mode, *host_stage1(lib, orc, data, mode))
+            got = {"err": obs[0]} if len(obs) == 1 else {"err": obs[0], "n": obs[1], "idx": list(obs[2])}
+            assert got == case["stage1"][mname], (data, mname)
+
+
+def test_finish_host_random(lib):
+    orc = checkers.Oracle()
+    for seed in (1000, 1007):
+        for a in random_case_stream(seed):
+            for mode in range(7):
+                want = checkers.observable(a, mode, *orc.stage1(a, mode))
+                assert checkers.observable(a, mode, *host_stage1(lib, orc, a, mode)) == want, (bytes(a), mode)
+
+
+def test_error_from_flags(lib):
+    f = capi.stage1_error_from_flags
+    assert f(5, 0) == capi.SUCCESS and f(0, 0) == capi.EMPTY and f(5, 4) == capi.UTF8_ERROR
+    assert f(5, 1 | 2 | 4) == capi.UNCLOSED_STRING and f(5, 2 | 4) == capi.UNESCAPED_CHARS and f(0, 4) == capi.EMPTY
