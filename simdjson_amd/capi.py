@@ -46,6 +46,17 @@ def load_library():
         return _lib
     if not os.path.exists(_paths.LIB_SJGPU):
         raise SjgpuError(f"{_paths.LIB_SJGPU} not built (run python -m simdjson_amd.build)")
+    # PyTorch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1, and two HIP runtimes in
+    # one process cannot both open the GPU ("No HIP GPUs are available" in whichever comes second).
+    # Importing torch FIRST makes the loader resolve libsjgpu's DT_NEEDED libamdhip64.so.7 to the
+    # already-loaded copy (same SONAME), so a process that uses torch for device memory / streams /
+    # torch.distributed and libsjgpu for the kernels runs on ONE runtime.  Pure C/C++ users of
+    # libsjgpu (the simdjson plug-in shim) simply get /opt/rocm's runtime.
+    if os.environ.get("SJGPU_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = ctypes.CDLL(_paths.LIB_SJGPU)
     vp, sz, u32p = ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32)
     L.sjgpu_device_count.restype = ctypes.c_int
