@@ -91,8 +91,9 @@ int sjgpu_validate_utf8(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int *ok)
 
 /* ---- device-resident entry points --------------------------------------------------------------------
  * buf_dev: device pointer, 16-byte aligned, len readable bytes (nothing is read past len).
- * stream: a hipStream_t (NULL = the context's own stream).  Calls only enqueue work; fetch the
- * outcome with sjgpu_result(), which waits for that stream.
+ * stream: the caller's hipStream_t (NULL = HIP's default stream, which is what PyTorch's default
+ * stream is); work is ordered with whatever else the caller enqueued there.  Calls only enqueue;
+ * fetch the outcome with sjgpu_result(), which waits for that stream.
  * sjgpu_stage1_device: regular-mode scan; writes idx_dev[0..n) ascending byte offsets and the three
  * sentinels idx_dev[n]=len, idx_dev[n+1]=len, idx_dev[n+2]=0 (json_structural_indexer.h:284-286);
  * needs idx_words >= n+3 (len+3 always suffices).  Error precedence is applied by the caller from

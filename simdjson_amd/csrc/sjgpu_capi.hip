@@ -103,7 +103,9 @@ void drop_events(sjgpu_ctx *ctx) {
   ctx->events.clear();
 }
 
-hipStream_t pick(sjgpu_ctx *ctx, void *stream) { return stream ? static_cast<hipStream_t>(stream) : ctx->stream; }
+// device-resident calls run on the CALLER's stream; NULL is HIP's default (null) stream, which is also
+// what torch.cuda.current_stream().cuda_stream reports for torch's default stream.
+hipStream_t pick(sjgpu_ctx *, void *stream) { return static_cast<hipStream_t>(stream); }
 
 } // namespace
 
