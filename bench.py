@@ -22,9 +22,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 measured copy
-KERNELS = {"stage1": ["k_stage1_summarize", "k_resolve_segments", "k_stage1_emit"],
-           "minify": ["k_minify_summarize", "k_resolve_segments", "k_minify_emit"],
-           "validate_utf8": ["k_validate_utf8"]}
+KERNELS = {("stage1", "split"): ["k_stage1_summarize", "k_resolve_segments", "k_stage1_emit"],
+           ("minify", "split"): ["k_minify_summarize", "k_resolve_segments", "k_minify_emit"],
+           ("stage1", "fused"): ["k_fused<0>"], ("minify", "fused"): ["k_fused<1>"],
+           ("validate_utf8", "split"): ["k_validate_utf8"], ("validate_utf8", "fused"): ["k_validate_utf8"]}
 
 
 def main():
@@ -32,9 +33,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--op", default="stage1", choices=list(KERNELS))
+    ap.add_argument("--op", default="stage1", choices=["stage1", "minify", "validate_utf8"])
     ap.add_argument("--workload", default="large_random", choices=["large_random", "amazon_ndjson", "twitter_like"])
     ap.add_argument("--size", type=int, default=1 << 30, help="bytes per GPU")
+    ap.add_argument("--pipeline", default=os.environ.get("SJGPU_PIPELINE", "fused"), choices=["fused", "split"])
     ap.add_argument("--cpu-iters", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -63,6 +65,7 @@ def main():
     host, units = getattr(corpus, args.workload)(args.size, 1000 + rank)
     L = len(host)
     parser = capi.DomParserImplementation(L, device=local_rank)
+    parser.set_pipeline(args.pipeline == "fused")
     buf = torch.from_numpy(host).cuda()
     stream = torch.cuda.current_stream().cuda_stream
     if args.op == "stage1":
@@ -87,6 +90,8 @@ def main():
     err = capi.stage1_error_from_flags(n, flags) if args.op == "stage1" else (15 if flags & 1 else 0)
     if args.op == "validate_utf8":
         err = 11 if flags & capi.F_UTF8_ERROR else 0
+    if flags & capi.F_INTERNAL:
+        raise SystemExit(f"rank {rank}: single-pass pipeline reported SJGPU_F_INTERNAL")
     if err != 0:
         raise SystemExit(f"rank {rank}: {args.op} returned error_code {err} on the synthetic buffer")
 
@@ -121,7 +126,8 @@ def main():
             alg = L + out_len
         else:
             alg = L
-        kms = [m / max(calls, 1) for m in ms_sum][: len(KERNELS[args.op])]
+        knames = KERNELS[(args.op, args.pipeline)]
+        kms = [m / max(calls, 1) for m in ms_sum][: len(knames)]
         gpu_ms = sum(kms)
         achieved = alg / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
         traffic = None
@@ -134,13 +140,13 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.workload} {L} B per GPU (seed 1000+rank), op={args.op}, regular mode, "
-                                   f"device-resident input and output", "bytes_per_gpu": L, "units_per_gpu": units,
+                                   f"device-resident input and output, {args.pipeline} pipeline", "bytes_per_gpu": L, "units_per_gpu": units,
                        "structurals": n if args.op == "stage1" else None, "out_bytes": out_len if args.op == "minify" else None,
                        "parallelism": f"{world} independent shard(s), one rank per GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg, "gpu_ms_per_step": round(gpu_ms, 4),
-                         "kernels_ms": dict(zip(KERNELS[args.op], [round(x, 4) for x in kms])),
+                         "kernels_ms": dict(zip(knames, [round(x, 4) for x in kms])),
                          "timing": "hipEvent pairs around each kernel on the launch stream, averaged over the timed steps"},
         }
         if world == 1 and not args.no_cpu_baseline:

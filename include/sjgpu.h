@@ -56,6 +56,7 @@ enum sjgpu_stage1_mode {
 #define SJGPU_F_UNESCAPED_CTRL  2u /* byte <= 0x1F inside a string */
 #define SJGPU_F_UTF8_ERROR      4u /* not well-formed UTF-8 */
 #define SJGPU_F_IDX_OVERFLOW    8u /* index buffer too small; indices beyond it were dropped */
+#define SJGPU_F_INTERNAL        16u /* single-pass pipeline gave up (bounded spin expired); result invalid */
 
 typedef struct sjgpu_ctx sjgpu_ctx;
 
@@ -102,6 +103,13 @@ int sjgpu_stage1_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *i
 int sjgpu_minify_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *dst_dev, void *stream);
 int sjgpu_validate_utf8_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *stream);
 int sjgpu_result(sjgpu_ctx *ctx, void *stream, sjgpu_scan_result *out);
+
+/* Pipeline selection (default: environment variable SJGPU_PIPELINE = "fused" | "split", else fused):
+ *   1 = single pass, one kernel, chained scan between 64 KiB tiles (reads every byte once);
+ *   0 = split: summarize -> resolve -> emit (three kernels, stage-1 masks round-trip through HBM).
+ * Both produce identical bytes; a single-pass call that raises SJGPU_F_INTERNAL is re-run split by the
+ * host-buffer entry points, device-resident callers see the flag in sjgpu_result(). */
+int sjgpu_set_pipeline(sjgpu_ctx *ctx, int fused);
 
 /* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).  While enabled,
  * each *_device call brackets every kernel it enqueues with events (up to 4096 calls are retained);

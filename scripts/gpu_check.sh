@@ -17,6 +17,8 @@ for s in $STAGES; do
       for op in stage1 minify validate_utf8; do
         timeout 600 python bench.py --op $op --steps 20 --warmup 3 > gpurun_out/bench_$op.json 2> gpurun_out/bench_$op.err; echo "bench $op rc=$?"; cat gpurun_out/bench_$op.json
       done
+      timeout 600 python bench.py --pipeline split --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_stage1_split.json 2> gpurun_out/bench_stage1_split.err; cat gpurun_out/bench_stage1_split.json
+      timeout 600 python bench.py --op minify --pipeline split --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_minify_split.json 2> gpurun_out/bench_minify_split.err; cat gpurun_out/bench_minify_split.json
       timeout 600 python bench.py --workload amazon_ndjson --steps 20 --warmup 3 > gpurun_out/bench_stage1_ndjson.json 2> gpurun_out/bench_stage1_ndjson.err; cat gpurun_out/bench_stage1_ndjson.json
       timeout 600 python bench.py --workload twitter_like --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_stage1_twitter.json 2> gpurun_out/bench_stage1_twitter.err; cat gpurun_out/bench_stage1_twitter.json
       ;;

@@ -45,8 +45,8 @@ def build_corpus(force=False):
 
 
 def build_sjgpu(force=False):
-    srcs = _csrc("sjgpu_kernels.hip", "sjgpu_capi.hip", "stage1_finish.cpp")
-    deps = srcs + _csrc("sj_block.h", "sjgpu_internal.h") + [os.path.join(_paths.INCLUDE_DIR, "sjgpu.h")]
+    srcs = _csrc("sjgpu_kernels.hip", "sjgpu_fused.hip", "sjgpu_capi.hip", "stage1_finish.cpp")
+    deps = srcs + _csrc("sj_block.h", "sjgpu_internal.h", "sjgpu_device.h") + [os.path.join(_paths.INCLUDE_DIR, "sjgpu.h")]
     if force or _stale(_paths.LIB_SJGPU, deps):
         os.makedirs(_paths.LIB_DIR, exist_ok=True)
         _run([HIPCC, f"--offload-arch={GFX_ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",

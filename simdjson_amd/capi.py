@@ -18,13 +18,13 @@ from . import _paths
 SUCCESS, CAPACITY, MEMALLOC, UTF8_ERROR, EMPTY, UNESCAPED_CHARS, UNCLOSED_STRING, UNEXPECTED_ERROR = 0, 1, 2, 11, 13, 14, 15, 24
 # simdjson::stage1_mode (internal/dom_parser_implementation.h:22-27)
 REGULAR, STREAMING_PARTIAL, STREAMING_FINAL, JSON_SEQUENCE_PARTIAL, JSON_SEQUENCE_FINAL, COMMA_DELIMITED_PARTIAL, COMMA_DELIMITED_FINAL = range(7)
-F_UNCLOSED_STRING, F_UNESCAPED_CTRL, F_UTF8_ERROR, F_IDX_OVERFLOW = 1, 2, 4, 8
+F_UNCLOSED_STRING, F_UNESCAPED_CTRL, F_UTF8_ERROR, F_IDX_OVERFLOW, F_INTERNAL = 1, 2, 4, 8, 16
 
 EXPORTS = [
     "sjgpu_device_count", "sjgpu_ctx_create", "sjgpu_ctx_destroy", "sjgpu_set_capacity", "sjgpu_capacity",
     "sjgpu_last_error", "sjgpu_stage1", "sjgpu_minify", "sjgpu_validate_utf8", "sjgpu_stage1_device",
     "sjgpu_minify_device", "sjgpu_validate_utf8_device", "sjgpu_result", "sjgpu_stage1_error_from_flags",
-    "sjgpu_stage1_finish_host", "sjgpu_trim_partial_utf8", "sjgpu_profile_enable", "sjgpu_profile_read",
+    "sjgpu_stage1_finish_host", "sjgpu_trim_partial_utf8", "sjgpu_profile_enable", "sjgpu_profile_read", "sjgpu_set_pipeline",
 ]
 
 
@@ -88,6 +88,8 @@ def load_library():
     L.sjgpu_stage1_error_from_flags.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
     L.sjgpu_stage1_finish_host.restype = ctypes.c_int
     L.sjgpu_stage1_finish_host.argtypes = [vp, sz, ctypes.c_int, vp, ctypes.c_uint32, ctypes.c_uint32, u32p]
+    L.sjgpu_set_pipeline.restype = ctypes.c_int
+    L.sjgpu_set_pipeline.argtypes = [vp, ctypes.c_int]
     L.sjgpu_profile_enable.restype = ctypes.c_int
     L.sjgpu_profile_enable.argtypes = [vp, ctypes.c_int]
     L.sjgpu_profile_read.restype = ctypes.c_int
@@ -195,6 +197,10 @@ class DomParserImplementation:
             raise SjgpuError(f"sjgpu_result error {rc}: {self.last_error()}")
         return int(r.n), int(r.flags), int(r.out_len)
 
+
+    def set_pipeline(self, fused=True):
+        """True: single-pass kernel (chained scan); False: split summarize/resolve/emit pipeline."""
+        return self.L.sjgpu_set_pipeline(self.h, 1 if fused else 0)
 
     def profile_enable(self, on=True):
         rc = self.L.sjgpu_profile_enable(self.h, 1 if on else 0)

@@ -5,6 +5,7 @@
 #include "sjgpu_internal.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -19,6 +20,9 @@ struct sjgpu_ctx {
   uint4 *masks = nullptr;
   seg_summary *summ = nullptr;
   seg_prefix *pref = nullptr;
+  uint64_t *desc = nullptr; // single-pass pipeline: tile descriptors + ticket
+  bool fused = true;
+  uint32_t max_workgroups = 2048;
   scan_result_dev *d_result = nullptr;
   scan_result_dev *h_result = nullptr; // pinned
   // staging for the host-buffer entry points (allocated on first use)
@@ -64,6 +68,7 @@ void release_workspace(sjgpu_ctx *ctx) {
   dev_free(ctx->masks);
   dev_free(ctx->summ);
   dev_free(ctx->pref);
+  dev_free(ctx->desc);
   dev_free(ctx->d_in);
   dev_free(ctx->d_idx);
   dev_free(ctx->d_out);
@@ -107,6 +112,16 @@ void drop_events(sjgpu_ctx *ctx) {
 // what torch.cuda.current_stream().cuda_stream reports for torch's default stream.
 hipStream_t pick(sjgpu_ctx *, void *stream) { return static_cast<hipStream_t>(stream); }
 
+void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint32_t *idx, size_t idx_words, hipStream_t s,
+                    hipEvent_t *ev) {
+  if (fused) { launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, ctx->max_workgroups, s, ev); }
+  else { launch_stage1(buf, len, ctx->masks, ctx->summ, ctx->pref, idx, idx_words, ctx->d_result, s, ev); }
+}
+void enqueue_minify(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint8_t *dst, hipStream_t s, hipEvent_t *ev) {
+  if (fused) { launch_minify_fused(buf, len, ctx->desc, dst, ctx->d_result, ctx->max_workgroups, s, ev); }
+  else { launch_minify(buf, len, ctx->summ, ctx->pref, dst, ctx->d_result, s, ev); }
+}
+
 } // namespace
 
 extern "C" {
@@ -125,7 +140,14 @@ int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out) {
   sjgpu_ctx *ctx = new (std::nothrow) sjgpu_ctx();
   if (!ctx) { return SJGPU_E_NOMEM; }
   ctx->device = device;
+  if (const char *pl = std::getenv("SJGPU_PIPELINE")) { ctx->fused = std::strcmp(pl, "split") != 0; }
   hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) {
+      ctx->max_workgroups = uint32_t(cus) * 8u; // more than can be resident; surplus workgroups just start later
+    }
+  }
   if (e == hipSuccess) { e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking); }
   if (e == hipSuccess) { e = hipMalloc(reinterpret_cast<void **>(&ctx->d_result), sizeof(scan_result_dev)); }
   if (e == hipSuccess) { e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_result), sizeof(scan_result_dev), hipHostMallocDefault); }
@@ -165,6 +187,7 @@ int sjgpu_set_capacity(sjgpu_ctx *ctx, size_t capacity) {
   SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->masks), nseg * (SEG_BYTES / BLOCK_BYTES) * sizeof(uint4)));
   SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->summ), nseg * sizeof(seg_summary)));
   SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->pref), nseg * sizeof(seg_prefix)));
+  SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->desc), (size_t(num_fused_tiles(capacity)) + 1) * sizeof(uint64_t)));
   ctx->capacity = capacity;
   return 0;
 }
@@ -180,8 +203,8 @@ int sjgpu_stage1_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *i
   if (len > ctx->capacity) { return E_CAPACITY; }
   if (len == 0) { return E_EMPTY; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
-  launch_stage1(static_cast<const uint8_t *>(buf_dev), len, ctx->masks, ctx->summ, ctx->pref, static_cast<uint32_t *>(idx_dev),
-                idx_words, ctx->d_result, pick(ctx, stream), next_events(ctx));
+  enqueue_stage1(ctx, ctx->fused, static_cast<const uint8_t *>(buf_dev), len, static_cast<uint32_t *>(idx_dev), idx_words,
+                 pick(ctx, stream), next_events(ctx));
   SJ_TRY(ctx, hipGetLastError());
   return 0;
 }
@@ -196,8 +219,8 @@ int sjgpu_minify_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *d
     SJ_TRY(ctx, hipMemsetAsync(ctx->d_result, 0, sizeof(scan_result_dev), pick(ctx, stream)));
     return 0;
   }
-  launch_minify(static_cast<const uint8_t *>(buf_dev), len, ctx->summ, ctx->pref, static_cast<uint8_t *>(dst_dev), ctx->d_result,
-                pick(ctx, stream), next_events(ctx));
+  enqueue_minify(ctx, ctx->fused, static_cast<const uint8_t *>(buf_dev), len, static_cast<uint8_t *>(dst_dev), pick(ctx, stream),
+                 next_events(ctx));
   SJ_TRY(ctx, hipGetLastError());
   return 0;
 }
@@ -218,6 +241,12 @@ int sjgpu_result(sjgpu_ctx *ctx, void *stream, sjgpu_scan_result *out) {
   if (!ctx || !out) { return SJGPU_E_BADARG; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
   return fetch_result(ctx, pick(ctx, stream), out);
+}
+
+int sjgpu_set_pipeline(sjgpu_ctx *ctx, int fused) {
+  if (!ctx) { return SJGPU_E_BADARG; }
+  ctx->fused = fused != 0;
+  return 0;
 }
 
 int sjgpu_profile_enable(sjgpu_ctx *ctx, int on) {
@@ -267,11 +296,15 @@ int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint3
   if (rc) { return rc; }
   hipStream_t s = ctx->stream;
   SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
-  launch_stage1(ctx->d_in, len, ctx->masks, ctx->summ, ctx->pref, ctx->d_idx, ctx->d_idx_words, ctx->d_result, s, nullptr);
-  SJ_TRY(ctx, hipGetLastError());
   sjgpu_scan_result res;
-  rc = fetch_result(ctx, s, &res);
-  if (rc) { return rc; }
+  for (int attempt = 0; attempt < 2; attempt++) { // a single-pass call that gives up is re-run on the split pipeline
+    enqueue_stage1(ctx, ctx->fused && attempt == 0, ctx->d_in, len, ctx->d_idx, ctx->d_idx_words, s, nullptr);
+    SJ_TRY(ctx, hipGetLastError());
+    rc = fetch_result(ctx, s, &res);
+    if (rc) { return rc; }
+    if (!(res.flags & SJGPU_F_INTERNAL)) { break; }
+  }
+  if (res.flags & SJGPU_F_INTERNAL) { return E_UNEXPECTED; }
   if (res.flags & SJGPU_F_IDX_OVERFLOW) { return E_UNEXPECTED; }
   // the two early exits of finish() need no index traffic (json_structural_indexer.h:255-263)
   if ((res.flags & SJGPU_F_UNCLOSED_STRING) && mode == SJGPU_REGULAR) { return E_UNCLOSED; }
@@ -295,11 +328,15 @@ int sjgpu_minify(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, uint8_t *dst, s
   if (rc) { return rc; }
   hipStream_t s = ctx->stream;
   SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
-  launch_minify(ctx->d_in, len, ctx->summ, ctx->pref, ctx->d_out, ctx->d_result, s, nullptr);
-  SJ_TRY(ctx, hipGetLastError());
   sjgpu_scan_result res;
-  rc = fetch_result(ctx, s, &res);
-  if (rc) { return rc; }
+  for (int attempt = 0; attempt < 2; attempt++) {
+    enqueue_minify(ctx, ctx->fused && attempt == 0, ctx->d_in, len, ctx->d_out, s, nullptr);
+    SJ_TRY(ctx, hipGetLastError());
+    rc = fetch_result(ctx, s, &res);
+    if (rc) { return rc; }
+    if (!(res.flags & SJGPU_F_INTERNAL)) { break; }
+  }
+  if (res.flags & SJGPU_F_INTERNAL) { return E_UNEXPECTED; }
   if (res.flags & SJGPU_F_UNCLOSED_STRING) { return E_UNCLOSED; }
   if (res.out_len > len) { return E_UNEXPECTED; }
   SJ_TRY(ctx, hipMemcpyAsync(dst, ctx->d_out, res.out_len, hipMemcpyDeviceToHost, s));

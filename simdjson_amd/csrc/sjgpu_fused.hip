@@ -1,0 +1,302 @@
+// simdjson_amd/csrc/sjgpu_fused.hip -- the SINGLE-PASS pipeline: stage 1 (and minify) in one kernel that reads
+// every input byte from HBM once and writes every output byte once (algorithmic traffic).
+//
+// The two true device-wide dependencies of the path -- in-string parity and output cursor -- are resolved
+// with a chained scan ("decoupled look-back"): a tile publishes its AGGREGATE (quote parity + the output
+// count for BOTH in-string hypotheses) as soon as it has scanned its bytes, then walks back over its
+// predecessors' descriptors until it meets one that already knows its INCLUSIVE prefix, composes, and
+// publishes its own inclusive prefix.  Everything else the reference carries from block to block
+// (escape parity, previous-scalar, UTF-8 look-back) is position-wise and is re-derived from the bytes in
+// front of each wave's span (sjgpu_device.h: segment_carry_in).
+//
+// MI355X specifics:
+//   * tile = 64 KiB = one 256-thread workgroup = 4 waves x 4 chunks.  Tiles must be big: descriptors live
+//     in other XCDs' L2s, a hand-off costs 1-3 us under load (MI355X_MICROARCH.md, handoff rows), and at
+//     ~5 TB/s a new 64 KiB tile becomes ready every ~13 ns, so the look-back window (256 descriptors per
+//     round trip, 4 coalesced 512-byte loads per wave) must cover "tiles per round trip" (~150).
+//   * descriptors are single naturally-aligned 8-byte granules written with ONE relaxed agent-scope
+//     atomic store (sc1 write-through) and read with relaxed agent-scope loads: the data is the flag, no
+//     fences (cdna_hip_programming.md G16, form R2).  Dispatch order is not assumed: tile ids come from an
+//     atomic ticket, so every predecessor of a running tile has already started.
+//   * every spin is bounded (wall-clock timeout); a timed-out tile poisons its descriptor, raises
+//     SJGPU_F_INTERNAL and the host re-runs the call on the split pipeline.
+//   * the per-chunk masks wait for the look-back in a 4-deep register FIFO (rolled loops, no dynamic
+//     register indexing, no LDS), offsets leave through the per-wave LDS window as 16-byte stores.
+#include "sjgpu_device.h"
+
+namespace sjgpu {
+namespace {
+
+constexpr u32 FUSED_WAVES = FUSED_TILE_BYTES / (FUSED_WAVE_CHUNKS * CHUNK_BYTES); // 4
+constexpr u32 FUSED_WAVE_BYTES = FUSED_WAVE_CHUNKS * CHUNK_BYTES;                 // 16 KiB
+constexpr u32 LOOKBACK_LOADS = 4;                                                // x64 descriptors per round trip
+constexpr u64 LOOKBACK_TIMEOUT_TICKS = 100ull * 1000 * 1000;                     // wall_clock64 is 100 MHz: 1 s
+
+// ---- descriptor encoding (one u64 per tile) -------------------------------------------------------------
+//   [63:62] status   0 invalid | 1 aggregate | 2 inclusive | 3 poison
+//   aggregate: [42] quote parity, [41:21] count if the tile starts inside a string, [20:0] count if outside
+//   inclusive: [32] in-string after the tile, [31:0] output cursor after the tile
+constexpr u64 ST_AGG = 1, ST_INCL = 2, ST_POISON = 3;
+__device__ __forceinline__ u64 make_agg(u32 q, u32 c_out, u32 c_in) {
+  return (ST_AGG << 62) | (u64(q & 1u) << 42) | (u64(c_in) << 21) | u64(c_out);
+}
+__device__ __forceinline__ u64 make_incl(u32 s, u32 base) { return (ST_INCL << 62) | (u64(s & 1u) << 32) | u64(base); }
+
+__device__ __forceinline__ u64 desc_load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void desc_store(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Wave-wide look-back for tile `tile` (all 64 lanes of ONE wave call this).  On success S = in-string at
+// the tile start, B = output cursor at the tile start.
+__device__ __forceinline__ bool lookback(const u64 *desc, u32 tile, u32 lane, u32 &S, u32 &B) {
+  // F = composition of the aggregates of tiles [end, tile): maps the state at `end` to (parity flip, count)
+  u32 fq = 0, fout = 0, fin = 0;
+  long long end = tile;
+  const u64 t_start = wall_clock64();
+  for (;;) {
+    u64 d[LOOKBACK_LOADS];
+#pragma unroll
+    for (u32 w = 0; w < LOOKBACK_LOADS; w++) {
+      const long long t = end - 1 - (long long)(w * 64 + lane);
+      d[w] = (t >= 0) ? desc_load(desc + t) : make_incl(0, 0); // in front of tile 0: outside strings, cursor 0
+    }
+    bool stalled = false;
+#pragma unroll
+    for (u32 w = 0; w < LOOKBACK_LOADS; w++) {
+      if (stalled) { break; }
+      const u32 st = u32(d[w] >> 62);
+      const u64 incl = __ballot(st == ST_INCL), valid = __ballot(st != 0), poison = __ballot(st == ST_POISON);
+      const u32 k = incl ? ctz64(incl) : 64u;                       // nearest inclusive predecessor in this window
+      const u64 below = (k == 64u) ? ~0ull : ((1ull << k) - 1ull);  // lanes nearer than it: must be aggregates
+      const u64 upto = (k == 64u) ? ~0ull : (below | (1ull << k));
+      if (poison & upto) { return false; }
+      if (~valid & below) { stalled = true; break; } // a needed aggregate is not published yet
+      // G = composition of the aggregates on lanes k-1 ... 0 (ascending tile order)
+      const bool mine = lane < k;
+      const u32 q = mine ? u32(d[w] >> 42) & 1u : 0u;
+      const u32 c_out = mine ? u32(d[w]) & 0x1FFFFFu : 0u;
+      const u32 c_in = mine ? u32(d[w] >> 21) & 0x1FFFFFu : 0u;
+      const u64 qm = __ballot(q != 0);
+      // parity already flipped, relative to the window start, when the walk reaches my tile: quotes of the
+      // farther lanes lane+1 .. k-1
+      const u32 flipped = u32(popc64(qm & ~((2ull << lane) - 1ull))) & 1u;
+      const u32 g_out = wave_sum(flipped ? c_in : c_out);
+      const u32 g_in = wave_sum(flipped ? c_out : c_in);
+      const u32 gq = u32(popc64(qm)) & 1u;
+      // F := G then F
+      const u32 nf_out = g_out + (gq ? fin : fout), nf_in = g_in + (gq ? fout : fin);
+      fout = nf_out;
+      fin = nf_in;
+      fq ^= gq;
+      if (k < 64u) {
+        const u32 lo = readlane_dyn(u32(d[w]), k), hi = readlane_dyn(u32(d[w] >> 32), k);
+        const u32 s_k = hi & 1u;
+        S = s_k ^ fq;
+        B = lo + (s_k ? fin : fout);
+        return true;
+      }
+      end -= 64;
+    }
+    if (wall_clock64() - t_start > LOOKBACK_TIMEOUT_TICKS) { return false; }
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+
+// what a wave tells its workgroup about its 16 KiB span
+constexpr u32 WF_CTRL_IF_OUT = 1u, WF_CTRL_IF_IN = 2u, WF_UTF8 = 4u;
+
+// OP 0: stage 1 (out = u32 structural offsets); OP 1: minify (out = bytes)
+template <int OP>
+__global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc,
+                                               u32 *__restrict__ ticket, u32 ntiles, void *__restrict__ out, u64 out_words,
+                                               scan_result_dev *__restrict__ result) {
+  constexpr u32 STAGE_WORDS = (OP == 0) ? EMIT_STAGE_WORDS : (MINIFY_STAGE_BYTES / 4);
+  __shared__ u32 sh_tile;
+  __shared__ u32 sh_wave[FUSED_WAVES][4]; // parity, count_if_out, count_if_in, flags
+  __shared__ u32 sh_prefix[4];            // S, B, ok
+  __shared__ __attribute__((aligned(16))) u32 sh_stage[FUSED_WAVES][STAGE_WORDS];
+
+  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+
+  for (;;) {
+    // Take the ticket only when we are ready to start the tile: a ticket claimed early would make every
+    // successor's look-back wait for a tile nobody is scanning yet.
+    if (threadIdx.x == 0) { sh_tile = atomicAdd(ticket, 1u); }
+    __syncthreads();
+    const u32 tile = sh_tile;
+    if (tile >= ntiles) { break; }
+
+    // ---- phase 1: scan my 4 chunks with a relative in-string state; masks go into the register FIFO ----
+    const u64 wave_start = u64(tile) * FUSED_TILE_BYTES + u64(wave) * FUSED_WAVE_BYTES;
+    u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0; // slot 3 = oldest chunk
+    u32 n_out = 0, n_in = 0;
+    u64 ctrl_in = 0, ctrl_out = 0, uerr = 0;
+    u32 parity = 0;
+    if (wave_start < len) { // wave-uniform
+      wave_carry wc = segment_carry_in(buf, wave_start, lane);
+#pragma unroll 1
+      for (u32 c = 0; c < FUSED_WAVE_CHUNKS; c++) {
+        const u64 cstart = wave_start + u64(c) * CHUNK_BYTES;
+        u64 a = 0, b = 0;
+        if (cstart < len) {
+          const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
+          u32 w[16];
+          load_block(buf, pos, len, w);
+          if (OP == 0) {
+            const chunk_masks m = scan_chunk<true, true>(w, wc, lane);
+            a = m.cand;
+            b = m.string_tail;
+            n_out += u32(popc64(a & ~b));
+            n_in += u32(popc64(a & b));
+            ctrl_in |= m.ctrl & m.in_string;
+            ctrl_out |= m.ctrl & ~m.in_string;
+            uerr |= m.utf8_err;
+          } else {
+            const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
+            const u64 valid = valid_mask(pos, len);
+            a = valid & m.ws; // drop candidates
+            b = m.in_string;
+            n_out += u32(popc64(valid & ~(a & ~b)));
+            n_in += u32(popc64(valid & ~(a & b)));
+          }
+        }
+        a3 = a2; a2 = a1; a1 = a0; a0 = a;
+        b3 = b2; b2 = b1; b1 = b0; b0 = b;
+      }
+      parity = wc.s;
+      // a multi-byte sequence still open at the very end of the input (utf8_lookup4_algorithm.h:164-171)
+      if (OP == 0 && wave_start + FUSED_WAVE_BYTES >= len && (wc.utf8 & UTF8_CARRY_OPEN)) { uerr |= 1; }
+    }
+    {
+      const u32 t_out = wave_sum(n_out), t_in = wave_sum(n_in);
+      u32 f = 0;
+      if (__ballot(ctrl_in != 0)) { f |= WF_CTRL_IF_OUT; }
+      if (__ballot(ctrl_out != 0)) { f |= WF_CTRL_IF_IN; }
+      if (__ballot(uerr != 0)) { f |= WF_UTF8; }
+      if (lane == 0) {
+        sh_wave[wave][0] = parity;
+        sh_wave[wave][1] = t_out;
+        sh_wave[wave][2] = t_in;
+        sh_wave[wave][3] = f;
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 2 (wave 0): publish the tile aggregate, look back, publish the inclusive prefix ----------
+    if (wave == 0) {
+      u32 tq = 0, tout = 0, tin = 0;
+#pragma unroll
+      for (u32 v = 0; v < FUSED_WAVES; v++) {
+        const u32 q = sh_wave[v][0], o = sh_wave[v][1], i = sh_wave[v][2];
+        const u32 no = tout + (tq ? i : o), ni = tin + (tq ? o : i);
+        tout = no;
+        tin = ni;
+        tq ^= q;
+      }
+      if (lane == 0) { desc_store(desc + tile, make_agg(tq, tout, tin)); }
+      u32 S = 0, B = 0;
+      const bool ok = lookback(desc, tile, lane, S, B);
+      if (lane == 0) {
+        if (ok) {
+          const u32 total = B + (S ? tin : tout), s_end = S ^ tq;
+          desc_store(desc + tile, make_incl(s_end, total));
+          if (tile == ntiles - 1) { // the last tile knows the totals: n / out_len, unclosed string, sentinels
+            u32 f = s_end ? SJGPU_F_UNCLOSED_STRING : 0u;
+            if (OP == 0) {
+              u32 *idx = static_cast<u32 *>(out);
+              if (u64(total) + 3 <= out_words) { // json_structural_indexer.h:284-286
+                idx[total] = u32(len);
+                idx[total + 1] = u32(len);
+                idx[total + 2] = 0;
+              } else {
+                f |= SJGPU_F_IDX_OVERFLOW;
+              }
+              result->n = total;
+            } else {
+              result->out_len = s_end ? 0ull : u64(total); // json_minifier.h:42-47
+            }
+            if (f) { atomicOr(&result->flags, f); }
+          }
+        } else {
+          desc_store(desc + tile, ST_POISON << 62);
+          atomicOr(&result->flags, SJGPU_F_INTERNAL);
+        }
+        sh_prefix[0] = S;
+        sh_prefix[1] = B;
+        sh_prefix[2] = ok ? 1u : 0u;
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 3: every wave derives its own carry-in from the tile prefix and emits ------------------------
+    if (sh_prefix[2] == 0u) { continue; } // poisoned chain: nothing to emit (workgroup-uniform)
+    u32 s = sh_prefix[0], base = sh_prefix[1];
+    for (u32 v = 0; v < wave; v++) {
+      base += s ? sh_wave[v][2] : sh_wave[v][1];
+      s ^= sh_wave[v][0];
+    }
+    if (wave_start >= len) { continue; }
+    {
+      const u32 f = sh_wave[wave][3];
+      u32 g = 0;
+      if (f & (s ? WF_CTRL_IF_IN : WF_CTRL_IF_OUT)) { g |= SJGPU_F_UNESCAPED_CTRL; }
+      if (f & WF_UTF8) { g |= SJGPU_F_UTF8_ERROR; }
+      if (g && lane == 0) { atomicOr(&result->flags, g); }
+    }
+    const u64 flip = s ? ~0ull : 0ull;
+    bool overflow = false;
+#pragma unroll 1
+    for (u32 c = 0; c < FUSED_WAVE_CHUNKS; c++) {
+      const u64 a = a3, b = b3;
+      a3 = a2; a2 = a1; a1 = a0;
+      b3 = b2; b2 = b1; b1 = b0;
+      const u64 cstart = wave_start + u64(c) * CHUNK_BYTES;
+      if (cstart >= len) { break; }
+      const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
+      if (OP == 0) {
+        emit_indices(a & ~(b ^ flip), u32(pos), lane, static_cast<u32 *>(out), out_words, base, sh_stage[wave], overflow);
+      } else {
+        u32 w[16];
+        load_block(buf, pos, len, w); // second touch of the same 4 KiB: served by L2 / Infinity Cache
+        emit_bytes(w, valid_mask(pos, len) & ~(a & ~(b ^ flip)), lane, static_cast<u8 *>(out), base,
+                   reinterpret_cast<u8 *>(sh_stage[wave]));
+      }
+    }
+    if (OP == 0 && __ballot(overflow) && lane == 0) { atomicOr(&result->flags, SJGPU_F_IDX_OVERFLOW); }
+  }
+}
+
+} // namespace
+
+// ---- launchers ----------------------------------------------------------------------------------------
+static inline void mark(hipEvent_t *ev, int k, hipStream_t stream) {
+  if (ev) { (void)hipEventRecord(ev[k], stream); }
+}
+
+static void launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *desc, void *out, uint64_t out_words,
+                         scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev) {
+  const u32 ntiles = num_fused_tiles(len);
+  u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles); // descriptors and ticket are cleared by ONE memset
+  (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
+  (void)hipMemsetAsync(desc, 0, (size_t(ntiles) + 1) * sizeof(u64), stream);
+  const u32 grid = ntiles < max_workgroups ? ntiles : max_workgroups;
+  mark(ev, 0, stream);
+  if (op == 0) {
+    hipLaunchKernelGGL(k_fused<0>, dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result);
+  } else {
+    hipLaunchKernelGGL(k_fused<1>, dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result);
+  }
+  mark(ev, 1, stream);
+  mark(ev, 2, stream);
+  mark(ev, 3, stream);
+}
+
+void launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
+                         scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev) {
+  launch_fused(0, buf, len, desc, idx, idx_words, result, max_workgroups, stream, ev);
+}
+void launch_minify_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint8_t *dst, scan_result_dev *result,
+                         uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev) {
+  launch_fused(1, buf, len, desc, dst, 0, result, max_workgroups, stream, ev);
+}
+
+} // namespace sjgpu

@@ -48,6 +48,12 @@ struct scan_result_dev {
 
 inline uint32_t num_segments(uint64_t len) { return uint32_t((len + SEG_BYTES - 1) / SEG_BYTES); }
 
+// single-pass pipeline (sjgpu_fused.hip): tile = one 256-thread workgroup = 4 waves x 4 chunks = 64 KiB;
+// workspace = one 8-byte descriptor per tile + the ticket word behind them.
+constexpr uint32_t FUSED_WAVE_CHUNKS = 4;
+constexpr uint32_t FUSED_TILE_BYTES = 4 * FUSED_WAVE_CHUNKS * CHUNK_BYTES;
+inline uint32_t num_fused_tiles(uint64_t len) { return uint32_t((len + FUSED_TILE_BYTES - 1) / FUSED_TILE_BYTES); }
+
 // ---- launchers (sjgpu_kernels.hip); every one only enqueues on `stream` ---------------------------------
 // ev: nullptr, or PROFILE_EVENTS events recorded around the kernels (ev[k], ev[k+1] bracket kernel k).
 constexpr int PROFILE_SLOTS = 3;
@@ -57,6 +63,11 @@ void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *
 void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_prefix *pref, uint8_t *dst,
                    scan_result_dev *result, hipStream_t stream, hipEvent_t *ev);
 void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *result, hipStream_t stream, hipEvent_t *ev);
+// single-pass variants: desc holds num_fused_tiles(capacity)+1 words; only profile slot 0 is used
+void launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
+                         scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev);
+void launch_minify_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint8_t *dst, scan_result_dev *result,
+                         uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev);
 
 } // namespace sjgpu
 #endif

@@ -17,10 +17,12 @@ pytestmark = pytest.mark.gpu
 CAP = 128 << 20
 
 
-@pytest.fixture(scope="module")
-def gpu():
+@pytest.fixture(scope="module", params=["fused", "split"])
+def gpu(request):
+    """Both device pipelines must be bit-exact: the single-pass kernel and the 3-kernel split pipeline."""
     build.build_sjgpu()
     p = capi.DomParserImplementation(CAP)  # raises loudly if the HIP library or the GPU is missing
+    p.set_pipeline(request.param == "fused")
     yield p
     p.close()
 
@@ -200,18 +202,21 @@ def test_reference_examples_if_present(gpu, orc):
 
 
 # ---- full size (BASELINE.json configs 2/3): device-resident path, 1 GiB ------------------------------------------
+@pytest.mark.parametrize("pipeline", ["fused", "split"])
 @pytest.mark.parametrize("kind", ["large_random", "amazon_ndjson"])
-def test_full_size_device_resident(orc, kind):
+def test_full_size_device_resident(orc, kind, pipeline):
     import torch
     size = int(os.environ.get("SJGPU_FULL_SIZE", str(1 << 30)))
     a, _ = getattr(corpus, kind)(size, 11)
     L = len(a)
     p = capi.DomParserImplementation(L)
+    p.set_pipeline(pipeline == "fused")
     buf = torch.from_numpy(a).cuda()
     idx = torch.empty(L + 3, dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     assert p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, stream) == 0
     n, flags, _ = p.result(stream)
+    assert flags & capi.F_INTERNAL == 0
     oerr, on, oidx = orc.stage1(a, 0)
     assert capi.stage1_error_from_flags(n, flags) == oerr == 0 and n == on
     # properties: strictly ascending, in range, sentinels
