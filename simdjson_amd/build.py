@@ -69,6 +69,22 @@ def build_plugin(force=False):
     return _paths.LIB_PLUGIN
 
 
+def build_plugin_test(force=False):
+    """tests/plugin/plugin_test.cpp -> simdjson_amd/lib/plugin_test: unmodified reference library + our shim.
+    Needs the reference (headers + oracle/_ref/simdjson_ref.o); the binary travels to the GPU box."""
+    out = os.path.join(_paths.LIB_DIR, "plugin_test")
+    src = os.path.join(_paths.REPO_ROOT, "tests", "plugin", "plugin_test.cpp")
+    ref_obj = os.path.join(_paths.ORACLE_OUT, "simdjson_ref.o")
+    hdr = os.path.join(_paths.REFERENCE_DIR, "include", "simdjson.h")
+    if not (os.path.exists(hdr) and os.path.exists(ref_obj) and os.path.exists(_paths.LIB_PLUGIN)):
+        return out if os.path.exists(out) else None
+    if force or _stale(out, [src, ref_obj, _paths.LIB_PLUGIN, _paths.LIB_CORPUS]):
+        _run(["g++", "-O2", "-std=c++17", "-I", os.path.join(_paths.REFERENCE_DIR, "include"),
+              "-I", os.path.join(_paths.CSRC_DIR, "plugin"), "-I", _paths.INCLUDE_DIR, src, ref_obj, "-o", out,
+              f"-L{_paths.LIB_DIR}", "-lsimdjson_mi355x", "-lsjgpu", "-lsjcorpus", "-lpthread", "-Wl,-rpath,$ORIGIN"])
+    return out
+
+
 def build_oracle():
     _run(["make", "-s", "-C", _paths.ORACLE_DIR, f"REFERENCE={_paths.REFERENCE_DIR}"])
 
@@ -76,8 +92,9 @@ def build_oracle():
 def build_all(force=False):
     build_corpus(force)
     build_sjgpu(force)
-    build_plugin(force)
     build_oracle()
+    build_plugin(force)
+    build_plugin_test(force)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,190 @@
+// simdjson_amd/csrc/plugin/mi355x_implementation.cpp -- see mi355x_implementation.h.
+#include "mi355x_implementation.h"
+
+#include "sjgpu.h"
+
+#include <atomic>
+#include <mutex>
+#include <new>
+
+namespace simdjson {
+namespace mi355x {
+namespace {
+
+using builtin_parser = simdjson::SIMDJSON_BUILTIN_IMPLEMENTATION::dom_parser_implementation;
+
+std::atomic<int> g_device{0};
+
+// libsjgpu's infrastructure codes -> simdjson::error_code (library must not abort or print,
+// /root/reference/src/implementation.cpp:307)
+error_code map_error(int rc) noexcept {
+  if (rc >= 0) { return error_code(rc); }
+  switch (rc) {
+  case SJGPU_E_NO_DEVICE: return UNSUPPORTED_ARCHITECTURE;
+  case SJGPU_E_NOMEM: return MEMALLOC;
+  case SJGPU_E_BADARG: return CAPACITY; // len > 0xFFFFFFFF or similar
+  default: return UNEXPECTED_ERROR;
+  }
+}
+
+// minify()/validate_utf8() have no parser object (include/simdjson/implementation.h:116,128): they use a
+// process-wide context that grows on demand, one call at a time.
+struct shared_ctx {
+  std::mutex m;
+  sjgpu_ctx *ctx = nullptr;
+  error_code ensure(size_t len) noexcept {
+    if (!ctx) {
+      int rc = sjgpu_ctx_create(g_device.load(), len < (1u << 20) ? (1u << 20) : len, &ctx);
+      if (rc != 0) { ctx = nullptr; return map_error(rc); }
+    } else if (sjgpu_capacity(ctx) < len) {
+      int rc = sjgpu_set_capacity(ctx, len);
+      if (rc != 0) { return map_error(rc); }
+    }
+    return SUCCESS;
+  }
+};
+shared_ctx &shared() noexcept {
+  static shared_ctx *s = new (std::nothrow) shared_ctx(); // intentionally leaked: no static-destruction order issues
+  return *s;
+}
+
+class dom_parser_implementation final : public internal::dom_parser_implementation {
+public:
+  dom_parser_implementation() noexcept = default;
+  ~dom_parser_implementation() override { sjgpu_ctx_destroy(ctx_); }
+
+  // stage 1 on the GPU, then the reference's own stage 2 (src/haswell.cpp:159-163 shape)
+  simdjson_warn_unused error_code parse(const uint8_t *buf, size_t len, dom::document &doc) noexcept final {
+    auto error = stage1(buf, len, stage1_mode::regular);
+    if (error) { return error; }
+    return stage2(doc);
+  }
+
+  simdjson_warn_unused error_code stage1(const uint8_t *buf, size_t len, stage1_mode mode) noexcept final {
+    buf_ = buf;
+    len_ = len;
+    if (!ctx_) { return UNINITIALIZED; }
+    // the array holds ROUNDUP(capacity,64)+9 words (generic/dom_parser_implementation.h:63-78)
+    const size_t words = SIMDJSON_ROUNDUP_N(_capacity, 64) + 9;
+    return map_error(sjgpu_stage1(ctx_, buf, len, int(mode), structural_indexes.get(), words, &n_structural_indexes));
+  }
+
+  simdjson_warn_unused error_code stage2(dom::document &doc) noexcept final { return with_inner([&] { return inner_->stage2(doc); }); }
+  simdjson_warn_unused error_code stage2_next(dom::document &doc) noexcept final {
+    return with_inner([&] { return inner_->stage2_next(doc); });
+  }
+  simdjson_warn_unused uint8_t *parse_string(const uint8_t *src, uint8_t *dst, bool allow_replacement) const noexcept final {
+    return inner_->parse_string(src, dst, allow_replacement);
+  }
+  simdjson_warn_unused uint8_t *parse_wobbly_string(const uint8_t *src, uint8_t *dst) const noexcept final {
+    return inner_->parse_wobbly_string(src, dst);
+  }
+
+  simdjson_warn_unused error_code set_capacity(size_t capacity) noexcept final {
+    if (capacity > SIMDJSON_MAXSIZE_BYTES) { return CAPACITY; }
+    const size_t words = SIMDJSON_ROUNDUP_N(capacity, 64) + 9;
+    structural_indexes.reset(new (std::nothrow) uint32_t[words]);
+    if (!structural_indexes) { _capacity = 0; return MEMALLOC; }
+    structural_indexes[0] = 0;
+    n_structural_indexes = 0;
+    int rc = ctx_ ? sjgpu_set_capacity(ctx_, capacity) : sjgpu_ctx_create(g_device.load(), capacity, &ctx_);
+    if (rc != 0) { _capacity = 0; return map_error(rc); }
+    if (inner_) {
+      auto error = inner_->set_capacity(capacity);
+      if (error) { _capacity = 0; return error; }
+    }
+    _capacity = capacity;
+    return SUCCESS;
+  }
+
+  simdjson_warn_unused error_code set_max_depth(size_t max_depth) noexcept final {
+    if (!inner_) { return UNINITIALIZED; }
+    auto error = inner_->set_max_depth(max_depth);
+    _max_depth = error ? 0 : max_depth;
+    return error;
+  }
+
+  // stage 2 / string parsing live in the reference's builtin CPU kernel
+  error_code create_inner(size_t capacity, size_t max_depth) noexcept {
+    return simdjson::builtin_implementation()->create_dom_parser_implementation(capacity, max_depth, inner_);
+  }
+
+private:
+  // Lend our stage-1 output to the CPU kernel object for the duration of one stage-2 call.
+  template <class F> error_code with_inner(F &&call) noexcept {
+    auto *in = static_cast<builtin_parser *>(inner_.get());
+    in->buf = buf_;
+    in->len = len_;
+    in->_number_as_string = _number_as_string;
+    in->_unpadded = _unpadded;
+    in->n_structural_indexes = n_structural_indexes;
+    in->next_structural_index = next_structural_index;
+    std::swap(in->structural_indexes, structural_indexes);
+    error_code error = call();
+    std::swap(in->structural_indexes, structural_indexes);
+    next_structural_index = in->next_structural_index;
+    return error;
+  }
+
+  sjgpu_ctx *ctx_ = nullptr;
+  std::unique_ptr<internal::dom_parser_implementation> inner_{};
+  const uint8_t *buf_ = nullptr;
+  size_t len_ = 0;
+};
+
+class implementation final : public simdjson::implementation {
+public:
+  implementation() noexcept
+      : simdjson::implementation("mi355x", "AMD Instinct MI355X (gfx950): stage 1 / minify / validate_utf8 in HIP via libsjgpu", 0) {}
+
+  // pattern of src/haswell.cpp:23-35: nothrow new, MEMALLOC on failure, then set_capacity / set_max_depth
+  simdjson_warn_unused error_code create_dom_parser_implementation(
+      size_t capacity, size_t max_depth, std::unique_ptr<internal::dom_parser_implementation> &dst) const noexcept final {
+    auto *p = new (std::nothrow) dom_parser_implementation();
+    if (!p) { return MEMALLOC; }
+    dst.reset(p);
+    if (auto err = p->create_inner(capacity, max_depth)) { dst.reset(); return err; }
+    if (auto err = p->set_capacity(capacity)) { dst.reset(); return err; }
+    if (auto err = p->set_max_depth(max_depth)) { dst.reset(); return err; }
+    return SUCCESS;
+  }
+
+  simdjson_warn_unused error_code minify(const uint8_t *buf, size_t len, uint8_t *dst, size_t &dst_len) const noexcept final {
+    auto &s = shared();
+    std::lock_guard<std::mutex> lock(s.m);
+    dst_len = 0;
+    if (auto err = s.ensure(len)) { return err; }
+    size_t n = 0;
+    const int rc = sjgpu_minify(s.ctx, buf, len, dst, &n);
+    dst_len = n;
+    return map_error(rc);
+  }
+
+  simdjson_warn_unused bool validate_utf8(const char *buf, size_t len) const noexcept final {
+    auto &s = shared();
+    std::lock_guard<std::mutex> lock(s.m);
+    if (s.ensure(len)) { return false; }
+    int ok = 0;
+    const int rc = sjgpu_validate_utf8(s.ctx, reinterpret_cast<const uint8_t *>(buf), len, &ok);
+    return rc == 0 && ok != 0;
+  }
+};
+
+} // namespace
+
+const simdjson::implementation *get_implementation() noexcept {
+  static const implementation *singleton = new (std::nothrow) implementation(); // never destroyed (protected non-virtual dtor)
+  return singleton;
+}
+
+bool available() noexcept { return sjgpu_device_count() > 0; }
+
+simdjson::error_code activate(int device) noexcept {
+  if (device < 0 || device >= sjgpu_device_count()) { return UNSUPPORTED_ARCHITECTURE; }
+  g_device.store(device);
+  simdjson::get_active_implementation() = get_implementation();
+  return SUCCESS;
+}
+
+} // namespace mi355x
+} // namespace simdjson

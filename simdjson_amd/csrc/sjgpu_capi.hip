@@ -185,7 +185,7 @@ int sjgpu_set_capacity(sjgpu_ctx *ctx, size_t capacity) {
   if (capacity == 0) { return 0; }
   const size_t nseg = num_segments(capacity);
   SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->masks), nseg * (SEG_BYTES / BLOCK_BYTES) * sizeof(uint4)));
-  SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->summ), nseg * sizeof(seg_summary)));
+  SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->summ), (nseg + num_groups(capacity)) * sizeof(seg_summary)));
   SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->pref), nseg * sizeof(seg_prefix)));
   SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->desc), (size_t(num_fused_tiles(capacity)) + 1) * sizeof(uint64_t)));
   ctx->capacity = capacity;

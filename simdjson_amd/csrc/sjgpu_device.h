@@ -127,9 +127,22 @@ struct chunk_masks {
 template <bool WANT_STRUCTURALS, bool WANT_UTF8>
 __device__ __forceinline__ chunk_masks scan_chunk(const u32 (&w)[16], wave_carry &wc, u32 lane) {
   const planes P = transpose64(w);
-  const classes c = classify(P);
   const u64 lt = lanemask_lt(lane);
   chunk_masks out;
+
+  // UTF-8 first, so that the bit planes are dead before the string algebra needs registers
+  out.utf8_err = 0;
+  if (WANT_UTF8) {
+    if (__ballot(P.b[7] != 0) | u64(wc.utf8)) { // wave-uniform ASCII fast path
+      const utf8_leads L = utf8_classify(P);
+      const u32 co = utf8_carry_out(L);
+      u32 ci = __shfl_up(co, 1);
+      if (lane == 0) { ci = wc.utf8; }
+      out.utf8_err = utf8_errors(P, L, ci);
+      wc.utf8 = readlane(co, 63);
+    }
+  }
+  const classes c = classify(P);
 
   // escapes: each block is "pass" (64 backslashes) or sets the carry by itself; a lane's carry-in is
   // the setting of the nearest non-pass lane below it (escape monoid).
@@ -165,17 +178,6 @@ __device__ __forceinline__ chunk_masks scan_chunk(const u32 (&w)[16], wave_carry
   out.ws = c.ws;
   out.ctrl = c.ctrl;
 
-  out.utf8_err = 0;
-  if (WANT_UTF8) {
-    if (__ballot(P.b[7] != 0) | u64(wc.utf8)) { // wave-uniform ASCII fast path
-      const utf8_leads L = utf8_classify(P);
-      const u32 co = utf8_carry_out(L);
-      u32 ci = __shfl_up(co, 1);
-      if (lane == 0) { ci = wc.utf8; }
-      out.utf8_err = utf8_errors(P, L, ci);
-      wc.utf8 = readlane(co, 63);
-    }
-  }
   return out;
 }
 
@@ -202,6 +204,7 @@ __device__ __forceinline__ void emit_indices(u64 structural, u32 pos32, u32 lane
   }
   u32 off = incl - cnt;
   const u32 skew = base & 3u;
+#pragma unroll 1
   for (u32 w0 = 0; w0 < total; w0 += EMIT_WINDOW) { // wave-uniform; one round unless the chunk is very dense
     const u32 lim = w0 + EMIT_WINDOW;
     const u32 rel = skew - w0; // stage slot of element e is e + rel (mod 2^32; e >= w0 whenever we store)
@@ -223,12 +226,14 @@ __device__ __forceinline__ void emit_indices(u64 structural, u32 pos32, u32 lane
     const u32 end = skew + here;                   // stage slots [skew, end) are live
     const u32 v_first = (skew + 3u) >> 2, v_last = end >> 2; // whole 4-word vectors [v_first, v_last)
     if (v_last > v_first) {
+#pragma unroll 1
       for (u32 v = v_first + lane; v < v_last; v += 64) {
         *reinterpret_cast<uint4 *>(g0 + 4u * v) = *reinterpret_cast<const uint4 *>(stage + 4u * v);
       }
       if (skew + lane < 4u * v_first) { g0[skew + lane] = stage[skew + lane]; }
       if (4u * v_last + lane < end) { g0[4u * v_last + lane] = stage[4u * v_last + lane]; }
     } else {
+#pragma unroll 1
       for (u32 i = skew + lane; i < end; i += 64) { g0[i] = stage[i]; }
     }
     wave_lds_fence();

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
     const u64 wave_start = u64(tile) * FUSED_TILE_BYTES + u64(wave) * FUSED_WAVE_BYTES;
     u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0; // slot 3 = oldest chunk
     u32 n_out = 0, n_in = 0;
-    u64 ctrl_in = 0, ctrl_out = 0, uerr = 0;
+    bool f_ci = false, f_co = false, f_ue = false; // wave-uniform error facts
     u32 parity = 0;
     if (wave_start < len) { // wave-uniform
       wave_carry wc = segment_carry_in(buf, wave_start, lane);
@@ -147,9 +147,9 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
             b = m.string_tail;
             n_out += u32(popc64(a & ~b));
             n_in += u32(popc64(a & b));
-            ctrl_in |= m.ctrl & m.in_string;
-            ctrl_out |= m.ctrl & ~m.in_string;
-            uerr |= m.utf8_err;
+            f_ci |= __ballot((m.ctrl & m.in_string) != 0) != 0;
+            f_co |= __ballot((m.ctrl & ~m.in_string) != 0) != 0;
+            f_ue |= __ballot(m.utf8_err != 0) != 0;
           } else {
             const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
             const u64 valid = valid_mask(pos, len);
@@ -164,14 +164,14 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
       }
       parity = wc.s;
       // a multi-byte sequence still open at the very end of the input (utf8_lookup4_algorithm.h:164-171)
-      if (OP == 0 && wave_start + FUSED_WAVE_BYTES >= len && (wc.utf8 & UTF8_CARRY_OPEN)) { uerr |= 1; }
+      if (OP == 0 && wave_start + FUSED_WAVE_BYTES >= len && (wc.utf8 & UTF8_CARRY_OPEN)) { f_ue = true; }
     }
     {
       const u32 t_out = wave_sum(n_out), t_in = wave_sum(n_in);
       u32 f = 0;
-      if (__ballot(ctrl_in != 0)) { f |= WF_CTRL_IF_OUT; }
-      if (__ballot(ctrl_out != 0)) { f |= WF_CTRL_IF_IN; }
-      if (__ballot(uerr != 0)) { f |= WF_UTF8; }
+      if (f_ci) { f |= WF_CTRL_IF_OUT; }
+      if (f_co) { f |= WF_CTRL_IF_IN; }
+      if (f_ue) { f |= WF_UTF8; }
       if (lane == 0) {
         sh_wave[wave][0] = parity;
         sh_wave[wave][1] = t_out;

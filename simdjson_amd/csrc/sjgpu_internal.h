@@ -7,9 +7,9 @@
 //
 // Device workspace per context (all sized from `capacity`, resident in HBM between calls):
 //   masks  [ceil(cap/64)] x uint4  {cand_lo, cand_hi, string_tail_lo, string_tail_hi} per block
-//   summ   [nseg] x seg_summary    per-segment carry summary (quote parity, counts for both in-string
-//                                  hypotheses, error bits)
-//   pref   [nseg] x seg_prefix     per-segment resolved carry-in (in-string bit, output base)
+//   summ   [nseg + ngroups] x seg_summary  per-segment carry summary (quote parity, counts for both
+//                                  in-string hypotheses, error bits), then the same per group of 64 segments
+//   pref   [ngroups] x seg_prefix  per-group resolved carry-in (in-string bit, output base)
 //   result                          one scan_result, mirrored to pinned host memory
 #ifndef SJGPU_INTERNAL_H
 #define SJGPU_INTERNAL_H
@@ -47,6 +47,9 @@ struct scan_result_dev {
 };
 
 inline uint32_t num_segments(uint64_t len) { return uint32_t((len + SEG_BYTES - 1) / SEG_BYTES); }
+// split pipeline's resolve is two-level: 64 segments (1 MiB of input) form a group
+constexpr uint32_t RESOLVE_GROUP = 64;
+inline uint32_t num_groups(uint64_t len) { return (num_segments(len) + RESOLVE_GROUP - 1) / RESOLVE_GROUP; }
 
 // single-pass pipeline (sjgpu_fused.hip): tile = one 256-thread workgroup = 4 waves x 4 chunks = 64 KiB;
 // workspace = one 8-byte descriptor per tile + the ticket word behind them.

@@ -66,8 +66,8 @@ __global__ __launch_bounds__(64) void k_stage1_summarize(const u8 *__restrict__ 
 }
 
 // =====================================================================================================
-// resolve: device-wide scan of (parity, count) over segments.  One workgroup; the summaries are
-// 16 B per 16 KiB of input, i.e. 0.1 % of the traffic.
+// resolve, level 2: scan of (parity, count) over at most a few thousand GROUP summaries in one workgroup
+// (level 1 = k_resolve_groups below folds 64 segment summaries into one group summary).
 // =====================================================================================================
 constexpr u32 RESOLVE_THREADS = 1024;
 
@@ -148,16 +148,62 @@ __global__ __launch_bounds__(RESOLVE_THREADS) void k_resolve_segments(const seg_
 }
 
 // =====================================================================================================
+// resolve, level 1: one wave per GROUP of 64 segments (1 MiB of input) folds the 64 summaries into one
+// summary of the same shape; level 2 (k_resolve_segments above, run over the group summaries) scans at
+// most 4096 of those in one workgroup; the emit kernels redo the in-group part themselves with one
+// coalesced 1 KiB load (segment_prefix below).  Replaces a 180 us single-workgroup scan by ~10 us.
+// =====================================================================================================
+__global__ __launch_bounds__(64) void k_resolve_groups(const seg_summary *__restrict__ summ, seg_summary *__restrict__ gsum,
+                                                       u32 nseg) {
+  const u32 lane = lane_id();
+  const u32 seg = blockIdx.x * RESOLVE_GROUP + lane;
+  seg_summary x{0u, 0u, 0u, 0u};
+  if (seg < nseg) { x = summ[seg]; }
+  const u64 qm = __ballot((x.flags & SF_PARITY) != 0);
+  const bool flipped = (popc64(qm & lanemask_lt(lane)) & 1) != 0; // in-string state, relative to the group start
+  const u32 g_out = wave_sum(flipped ? x.count_if_in : x.count_if_out);
+  const u32 g_in = wave_sum(flipped ? x.count_if_out : x.count_if_in);
+  u32 flags = (popc64(qm) & 1) ? SF_PARITY : 0u;
+  if (__ballot((x.flags & (flipped ? SF_CTRL_IF_IN : SF_CTRL_IF_OUT)) != 0)) { flags |= SF_CTRL_IF_OUT; }
+  if (__ballot((x.flags & (flipped ? SF_CTRL_IF_OUT : SF_CTRL_IF_IN)) != 0)) { flags |= SF_CTRL_IF_IN; }
+  if (__ballot((x.flags & SF_UTF8) != 0)) { flags |= SF_UTF8; }
+  if (lane == 0) {
+    seg_summary g;
+    g.count_if_out = g_out;
+    g.count_if_in = g_in;
+    g.flags = flags;
+    g.pad = 0;
+    gsum[blockIdx.x] = g;
+  }
+}
+
+// carry-in (in-string bit, output cursor) of segment `seg`: its group's prefix + the segments in front of
+// it inside the group
+__device__ __forceinline__ seg_prefix segment_prefix(const seg_summary *__restrict__ summ, const seg_prefix *__restrict__ gpref,
+                                                     u32 seg, u32 lane) {
+  const u32 group = seg / RESOLVE_GROUP, r = seg % RESOLVE_GROUP;
+  const seg_prefix gp = gpref[group];
+  seg_summary x{0u, 0u, 0u, 0u};
+  if (lane < r) { x = summ[group * RESOLVE_GROUP + lane]; }
+  const u64 qm = __ballot((x.flags & SF_PARITY) != 0);
+  const bool inside = ((popc64(qm & lanemask_lt(lane)) & 1) != 0) != (gp.in_string != 0);
+  seg_prefix p;
+  p.base = gp.base + wave_sum(inside ? x.count_if_in : x.count_if_out);
+  p.in_string = gp.in_string ^ (u32(popc64(qm)) & 1u);
+  return p;
+}
+
+// =====================================================================================================
 // stage 1, kernel 2: select the right hypothesis per segment, flatten bitmaps to ascending offsets
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_stage1_emit(const uint4 *__restrict__ masks, const seg_prefix *__restrict__ pref,
-                                                    u64 len, u32 *__restrict__ idx, u64 idx_words,
-                                                    scan_result_dev *__restrict__ result) {
+__global__ __launch_bounds__(64) void k_stage1_emit(const uint4 *__restrict__ masks, const seg_summary *__restrict__ summ,
+                                                    const seg_prefix *__restrict__ gpref, u64 len, u32 *__restrict__ idx,
+                                                    u64 idx_words, scan_result_dev *__restrict__ result) {
   __shared__ __attribute__((aligned(16))) u32 stage[EMIT_STAGE_WORDS];
   const u32 lane = lane_id();
   const u32 seg = blockIdx.x;
   const u64 seg_start = u64(seg) * SEG_BYTES;
-  const seg_prefix pf = pref[seg];
+  const seg_prefix pf = segment_prefix(summ, gpref, seg, lane);
   u32 base = pf.base;
   const u64 flip = pf.in_string ? ~0ull : 0ull;
   bool overflow = false;
@@ -203,13 +249,13 @@ __global__ __launch_bounds__(64) void k_minify_summarize(const u8 *__restrict__ 
   }
 }
 
-__global__ __launch_bounds__(64) void k_minify_emit(const u8 *__restrict__ buf, u64 len, const seg_prefix *__restrict__ pref,
-                                                    u8 *__restrict__ dst) {
+__global__ __launch_bounds__(64) void k_minify_emit(const u8 *__restrict__ buf, u64 len, const seg_summary *__restrict__ summ,
+                                                    const seg_prefix *__restrict__ gpref, u8 *__restrict__ dst) {
   __shared__ __attribute__((aligned(16))) u8 stage[MINIFY_STAGE_BYTES];
   const u32 lane = lane_id();
   const u32 seg = blockIdx.x;
   const u64 seg_start = u64(seg) * SEG_BYTES;
-  const seg_prefix pf = pref[seg];
+  const seg_prefix pf = segment_prefix(summ, gpref, seg, lane);
   wave_carry wc = segment_carry_in(buf, seg_start, lane);
   wc.s = pf.in_string; // absolute from here on
   u32 base = pf.base;
@@ -273,10 +319,13 @@ void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *
   mark(ev, 0, stream);
   hipLaunchKernelGGL(k_stage1_summarize, dim3(nseg), dim3(64), 0, stream, buf, len, masks, summ);
   mark(ev, 1, stream);
-  hipLaunchKernelGGL(k_resolve_segments, dim3(1), dim3(RESOLVE_THREADS), 0, stream, summ, pref, nseg, len, idx, idx_words,
+  const u32 ngroups = (nseg + RESOLVE_GROUP - 1) / RESOLVE_GROUP;
+  seg_summary *gsum = summ + nseg; // the group summaries live behind the segment summaries
+  hipLaunchKernelGGL(k_resolve_groups, dim3(ngroups), dim3(64), 0, stream, summ, gsum, nseg);
+  hipLaunchKernelGGL(k_resolve_segments, dim3(1), dim3(RESOLVE_THREADS), 0, stream, gsum, pref, ngroups, len, idx, idx_words,
                      result, 0);
   mark(ev, 2, stream);
-  hipLaunchKernelGGL(k_stage1_emit, dim3(nseg), dim3(64), 0, stream, masks, pref, len, idx, idx_words, result);
+  hipLaunchKernelGGL(k_stage1_emit, dim3(nseg), dim3(64), 0, stream, masks, summ, pref, len, idx, idx_words, result);
   mark(ev, 3, stream);
 }
 
@@ -287,10 +336,13 @@ void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_pref
   mark(ev, 0, stream);
   hipLaunchKernelGGL(k_minify_summarize, dim3(nseg), dim3(64), 0, stream, buf, len, summ);
   mark(ev, 1, stream);
-  hipLaunchKernelGGL(k_resolve_segments, dim3(1), dim3(RESOLVE_THREADS), 0, stream, summ, pref, nseg, len,
+  const u32 ngroups = (nseg + RESOLVE_GROUP - 1) / RESOLVE_GROUP;
+  seg_summary *gsum = summ + nseg;
+  hipLaunchKernelGGL(k_resolve_groups, dim3(ngroups), dim3(64), 0, stream, summ, gsum, nseg);
+  hipLaunchKernelGGL(k_resolve_segments, dim3(1), dim3(RESOLVE_THREADS), 0, stream, gsum, pref, ngroups, len,
                      static_cast<u32 *>(nullptr), u64(0), result, 1);
   mark(ev, 2, stream);
-  hipLaunchKernelGGL(k_minify_emit, dim3(nseg), dim3(64), 0, stream, buf, len, pref, dst);
+  hipLaunchKernelGGL(k_minify_emit, dim3(nseg), dim3(64), 0, stream, buf, len, summ, pref, dst);
   mark(ev, 3, stream);
 }
 

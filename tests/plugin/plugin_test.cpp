@@ -1,0 +1,171 @@
+// tests/plugin/plugin_test.cpp -- the drop-in boundary exercised the way a simdjson user would: the
+// UNMODIFIED reference library (dom::parser, ondemand::parser, parse_many, minify, validate_utf8) with
+// the MI355X backend activated, compared against the reference's own CPU kernel on the same inputs.
+// Mirrors the reference's per-implementation testing (tests/checkimplementation.cpp:5-22,
+// tests/dom/basictests.cpp -a <impl>).  Built in the build container (needs the reference headers and
+// oracle/_ref/simdjson_ref.o), run on the GPU box by tests/test_plugin.py.
+#include "mi355x_implementation.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" {
+size_t sjc_large_random(uint8_t *, size_t, size_t, uint64_t, uint64_t *);
+size_t sjc_amazon_ndjson(uint8_t *, size_t, size_t, uint64_t, uint64_t *);
+size_t sjc_twitter_like(uint8_t *, size_t, size_t, uint64_t, uint64_t *);
+}
+
+using namespace simdjson;
+
+#define CHECK(cond, ...) do { if (!(cond)) { std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); return 1; } } while (0)
+
+static padded_string gen(size_t (*fn)(uint8_t *, size_t, size_t, uint64_t, uint64_t *), size_t target, uint64_t seed) {
+  std::vector<uint8_t> tmp(target + 8192);
+  uint64_t units = 0;
+  size_t n = fn(tmp.data(), tmp.size(), target, seed, &units);
+  return padded_string(reinterpret_cast<const char *>(tmp.data()), n);
+}
+
+static const implementation *cpu_kernel() {
+  for (const char *name : {"icelake", "haswell", "westmere", "fallback"}) {
+    auto impl = get_available_implementations()[name];
+    if (impl && impl->supported_by_runtime_system()) { return impl; }
+  }
+  return nullptr;
+}
+
+static int compare_stage1(const implementation *cpu, const implementation *gpu, const padded_string &json, const char *tag) {
+  std::unique_ptr<internal::dom_parser_implementation> a, b;
+  CHECK(cpu->create_dom_parser_implementation(json.size(), 1024, a) == SUCCESS, "cpu parser");
+  CHECK(gpu->create_dom_parser_implementation(json.size(), 1024, b) == SUCCESS, "gpu parser");
+  for (int mode = 0; mode < 7; mode++) {
+    auto ea = a->stage1(reinterpret_cast<const uint8_t *>(json.data()), json.size(), stage1_mode(mode));
+    auto eb = b->stage1(reinterpret_cast<const uint8_t *>(json.data()), json.size(), stage1_mode(mode));
+    CHECK(ea == eb, "%s mode %d: error %d vs %d", tag, mode, int(ea), int(eb));
+    if (ea == UNCLOSED_STRING || ea == UNESCAPED_CHARS) { continue; }
+    CHECK(a->n_structural_indexes == b->n_structural_indexes, "%s mode %d: n %u vs %u", tag, mode, a->n_structural_indexes, b->n_structural_indexes);
+    CHECK(std::memcmp(a->structural_indexes.get(), b->structural_indexes.get(), (size_t(a->n_structural_indexes) + 3) * 4) == 0,
+          "%s mode %d: index words differ", tag, mode);
+  }
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  const implementation *before = get_active_implementation();
+  if (argc > 1 && std::strcmp(argv[1], "--expect-no-gpu") == 0) {
+    CHECK(!mi355x::available(), "a GPU is visible");
+    CHECK(mi355x::activate() == UNSUPPORTED_ARCHITECTURE, "activate() must refuse without a GPU");
+    CHECK(get_active_implementation() == before, "registry must be untouched");
+    std::printf("plugin refuses to activate without a GPU: OK\n");
+    return 0;
+  }
+  const implementation *cpu = cpu_kernel();
+  CHECK(cpu != nullptr, "no CPU kernel");
+  CHECK(mi355x::activate() == SUCCESS, "activate failed");
+  const implementation *gpu = get_active_implementation();
+  CHECK(gpu->name() == "mi355x", "active implementation is %s", std::string(gpu->name()).c_str());
+  std::printf("active: %s (%s); cpu reference kernel: %s\n", std::string(gpu->name()).c_str(),
+              std::string(gpu->description()).c_str(), std::string(cpu->name()).c_str());
+
+  padded_string twitter = gen(sjc_twitter_like, 3 << 20, 21), random = gen(sjc_large_random, 3 << 20, 22),
+                amazon = gen(sjc_amazon_ndjson, 3 << 20, 23);
+
+  // 1. raw stage-1 output through the plug-in boundary, all 7 modes, bit-exact
+  if (compare_stage1(cpu, gpu, twitter, "twitter_like")) { return 1; }
+  if (compare_stage1(cpu, gpu, random, "large_random")) { return 1; }
+  if (compare_stage1(cpu, gpu, amazon, "amazon_ndjson")) { return 1; }
+  padded_string unclosed(std::string("[\"abc")), badutf(std::string("[\"abc\xff\"]")), ctrl(std::string("[\"a\x01\"]"));
+  if (compare_stage1(cpu, gpu, unclosed, "unclosed")) { return 1; }
+  if (compare_stage1(cpu, gpu, badutf, "badutf")) { return 1; }
+  if (compare_stage1(cpu, gpu, ctrl, "ctrl")) { return 1; }
+
+  // 2. dom::parser::parse: GPU stage 1 + reference stage 2 == reference end to end
+  for (const padded_string *doc : {&twitter, &random}) {
+    get_active_implementation() = cpu;
+    dom::parser pc;
+    dom::element ec;
+    CHECK(pc.parse(*doc).get(ec) == SUCCESS, "cpu parse");
+    std::string sc = simdjson::minify(ec);
+    get_active_implementation() = gpu;
+    dom::parser pg;
+    dom::element eg;
+    CHECK(pg.parse(*doc).get(eg) == SUCCESS, "gpu parse");
+    CHECK(std::string(pg.implementation->structural_indexes ? "ok" : "") == "ok", "no index array");
+    std::string sg = simdjson::minify(eg);
+    CHECK(sc == sg, "DOM serialisations differ (%zu vs %zu bytes)", sc.size(), sg.size());
+  }
+  {
+    dom::parser p;
+    CHECK(p.parse(unclosed).error() == UNCLOSED_STRING, "unclosed -> UNCLOSED_STRING");
+    CHECK(p.parse(badutf).error() == UTF8_ERROR, "bad utf8 -> UTF8_ERROR");
+    CHECK(p.parse(ctrl).error() == UNESCAPED_CHARS, "ctrl -> UNESCAPED_CHARS");
+    CHECK(p.parse(padded_string(std::string("   "))).error() == EMPTY, "blank -> EMPTY");
+  }
+
+  // 3. ondemand::parser::iterate (stage 1 only; lazy access over our index)
+  {
+    uint64_t sums[2] = {0, 0}, counts[2] = {0, 0};
+    int k = 0;
+    for (const implementation *impl : {cpu, gpu}) {
+      get_active_implementation() = impl;
+      ondemand::parser parser;
+      ondemand::document d;
+      CHECK(parser.iterate(twitter).get(d) == SUCCESS, "iterate");
+      ondemand::array statuses;
+      CHECK(d["statuses"].get_array().get(statuses) == SUCCESS, "statuses");
+      for (auto st : statuses) {
+        uint64_t rc;
+        CHECK(st["retweet_count"].get_uint64().get(rc) == SUCCESS, "retweet_count");
+        sums[k] += rc;
+        counts[k]++;
+      }
+      k++;
+    }
+    CHECK(counts[0] == counts[1] && sums[0] == sums[1] && counts[0] > 100, "ondemand: %llu/%llu vs %llu/%llu",
+          (unsigned long long)counts[0], (unsigned long long)sums[0], (unsigned long long)counts[1], (unsigned long long)sums[1]);
+  }
+
+  // 4. parse_many over NDJSON (document_stream: streaming_partial / streaming_final batches, worker thread)
+  {
+    uint64_t docs[2] = {0, 0}, bytes[2] = {0, 0};
+    int k = 0;
+    for (const implementation *impl : {cpu, gpu}) {
+      get_active_implementation() = impl;
+      dom::parser parser;
+      dom::document_stream stream;
+      CHECK(parser.parse_many(amazon, 200000).get(stream) == SUCCESS, "parse_many");
+      for (auto it = stream.begin(); it != stream.end(); ++it) {
+        auto doc = *it;
+        CHECK(doc.error() == SUCCESS, "document %llu: %s", (unsigned long long)docs[k], error_message(doc.error()));
+        docs[k]++;
+        bytes[k] += it.source().size();
+      }
+      CHECK(stream.truncated_bytes() == 0, "truncated bytes");
+      k++;
+    }
+    CHECK(docs[0] == docs[1] && bytes[0] == bytes[1] && docs[0] > 1000, "parse_many: %llu/%llu vs %llu/%llu",
+          (unsigned long long)docs[0], (unsigned long long)bytes[0], (unsigned long long)docs[1], (unsigned long long)bytes[1]);
+  }
+
+  // 5. free functions minify() / validate_utf8() route to the active implementation
+  get_active_implementation() = gpu;
+  for (const padded_string *doc : {&twitter, &random, &amazon}) {
+    std::vector<char> a(doc->size() + 64), b(doc->size() + 64);
+    size_t la = 0, lb = 0;
+    CHECK(cpu->minify(reinterpret_cast<const uint8_t *>(doc->data()), doc->size(), reinterpret_cast<uint8_t *>(a.data()), la) == SUCCESS, "cpu minify");
+    CHECK(simdjson::minify(doc->data(), doc->size(), b.data(), lb) == SUCCESS, "gpu minify");
+    CHECK(la == lb && std::memcmp(a.data(), b.data(), la) == 0, "minify output differs");
+    CHECK(simdjson::validate_utf8(doc->data(), doc->size()), "validate_utf8");
+  }
+  CHECK(!simdjson::validate_utf8(badutf.data(), badutf.size()), "validate_utf8 must reject");
+  {
+    std::vector<char> out(16);
+    size_t n = 99;
+    CHECK(simdjson::minify(unclosed.data(), unclosed.size(), out.data(), n) == UNCLOSED_STRING && n == 0, "minify unclosed");
+  }
+  get_active_implementation() = before;
+  std::printf("plugin test OK\n");
+  return 0;
+}
