@@ -81,10 +81,11 @@ const char *sjgpu_last_error(const sjgpu_ctx *ctx); /* text of the last HIP fail
  * src/generic/stage1/buf_block_reader.h:99-104).
  * idx_out: the parser's structural_indexes array, idx_words >= len+3 words available
  * (include/simdjson/generic/dom_parser_implementation.h:63-78 allocates ROUNDUP(capacity,64)+9).
- * *n_io: the parser's n_structural_indexes, read-modify-written exactly where the reference does
- * (untouched on CAPACITY / len==0 / UNCLOSED_STRING(regular) / UNESCAPED_CHARS). */
+ * *n_io / *next_io: the parser's n_structural_indexes / next_structural_index, written exactly where
+ * the reference writes them (json_structural_indexer.h:264,287: n = count, next = 0 once the scan
+ * has passed the UNCLOSED_STRING / UNESCAPED_CHARS exits; untouched on the earlier exits). */
 int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint32_t *idx_out, size_t idx_words,
-                 uint32_t *n_io);
+                 uint32_t *n_io, uint32_t *next_io);
 /* dst: len writable bytes; never written beyond dst+len.  UNCLOSED_STRING => *dst_len = 0. */
 int sjgpu_minify(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, uint8_t *dst, size_t *dst_len);
 /* *ok = 1 iff buf[0..len) is well-formed UTF-8 (len == 0 => 1). */
@@ -111,6 +112,12 @@ int sjgpu_result(sjgpu_ctx *ctx, void *stream, sjgpu_scan_result *out);
  * host-buffer entry points, device-resident callers see the flag in sjgpu_result(). */
 int sjgpu_set_pipeline(sjgpu_ctx *ctx, int fused);
 
+/* Diagnostics: one single-pass stage-1 call whose first trace_tiles tiles record 8 wall-clock stamps each
+ * (100 MHz ticks: loop top, ticket, wave-0 scanned, all scanned, look-back done, prefix broadcast, wave-0
+ * emitted, unused) into trace_host[trace_tiles*8].  Synchronous. */
+int sjgpu_debug_trace_stage1(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *idx_dev, size_t idx_words,
+                             uint64_t *trace_host, uint32_t trace_tiles);
+
 /* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).  While enabled,
  * each *_device call brackets every kernel it enqueues with events (up to 4096 calls are retained);
  * sjgpu_profile_read waits for the stream, adds the elapsed milliseconds per kernel slot into
@@ -128,7 +135,7 @@ int sjgpu_stage1_error_from_flags(uint32_t n, uint32_t flags);
  * src/generic/stage1/find_next_document_index.h:39-369).  idx holds the n_raw raw structurals and
  * has room for n_raw+3 words; len is the (already trimmed) scanned length. */
 int sjgpu_stage1_finish_host(const uint8_t *buf, size_t len, int mode, uint32_t *idx, uint32_t n_raw, uint32_t flags,
-                             uint32_t *n_io);
+                             uint32_t *n_io, uint32_t *next_io);
 /* streaming modes: length after dropping a trailing partial UTF-8 character (…indexer.h:156-174) */
 size_t sjgpu_trim_partial_utf8(const uint8_t *buf, size_t len);
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "sjgpu_device_count", "sjgpu_ctx_create", "sjgpu_ctx_destroy", "sjgpu_set_capacity", "sjgpu_capacity",
     "sjgpu_last_error", "sjgpu_stage1", "sjgpu_minify", "sjgpu_validate_utf8", "sjgpu_stage1_device",
     "sjgpu_minify_device", "sjgpu_validate_utf8_device", "sjgpu_result", "sjgpu_stage1_error_from_flags",
-    "sjgpu_stage1_finish_host", "sjgpu_trim_partial_utf8", "sjgpu_profile_enable", "sjgpu_profile_read", "sjgpu_set_pipeline",
+    "sjgpu_stage1_finish_host", "sjgpu_trim_partial_utf8", "sjgpu_profile_enable", "sjgpu_profile_read", "sjgpu_set_pipeline", "sjgpu_debug_trace_stage1",
 ]
 
 
@@ -71,7 +71,7 @@ def load_library():
     L.sjgpu_last_error.restype = ctypes.c_char_p
     L.sjgpu_last_error.argtypes = [vp]
     L.sjgpu_stage1.restype = ctypes.c_int
-    L.sjgpu_stage1.argtypes = [vp, vp, sz, ctypes.c_int, vp, sz, u32p]
+    L.sjgpu_stage1.argtypes = [vp, vp, sz, ctypes.c_int, vp, sz, u32p, u32p]
     L.sjgpu_minify.restype = ctypes.c_int
     L.sjgpu_minify.argtypes = [vp, vp, sz, vp, ctypes.POINTER(sz)]
     L.sjgpu_validate_utf8.restype = ctypes.c_int
@@ -87,7 +87,9 @@ def load_library():
     L.sjgpu_stage1_error_from_flags.restype = ctypes.c_int
     L.sjgpu_stage1_error_from_flags.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
     L.sjgpu_stage1_finish_host.restype = ctypes.c_int
-    L.sjgpu_stage1_finish_host.argtypes = [vp, sz, ctypes.c_int, vp, ctypes.c_uint32, ctypes.c_uint32, u32p]
+    L.sjgpu_stage1_finish_host.argtypes = [vp, sz, ctypes.c_int, vp, ctypes.c_uint32, ctypes.c_uint32, u32p, u32p]
+    L.sjgpu_debug_trace_stage1.restype = ctypes.c_int
+    L.sjgpu_debug_trace_stage1.argtypes = [vp, vp, sz, vp, sz, vp, ctypes.c_uint32]
     L.sjgpu_set_pipeline.restype = ctypes.c_int
     L.sjgpu_set_pipeline.argtypes = [vp, ctypes.c_int]
     L.sjgpu_profile_enable.restype = ctypes.c_int
@@ -122,6 +124,7 @@ class DomParserImplementation:
         self.h = h
         self.device = device
         self.n_structural_indexes = 0
+        self.next_structural_index = 0
         self.structural_indexes = np.zeros(((int(capacity) + 63) // 64) * 64 + 9, dtype=np.uint32)
 
     def close(self):
@@ -147,9 +150,11 @@ class DomParserImplementation:
     def stage1(self, data, mode=REGULAR):
         a = _as_u8(data)
         n = ctypes.c_uint32(self.n_structural_indexes)
+        nxt = ctypes.c_uint32(self.next_structural_index)
         rc = self.L.sjgpu_stage1(self.h, a.ctypes.data, len(a), int(mode), self.structural_indexes.ctypes.data,
-                                 len(self.structural_indexes), ctypes.byref(n))
+                                 len(self.structural_indexes), ctypes.byref(n), ctypes.byref(nxt))
         self.n_structural_indexes = int(n.value)
+        self.next_structural_index = int(nxt.value)
         if rc < 0:
             raise SjgpuError(f"sjgpu_stage1 infrastructure error {rc}: {self.last_error()}")
         return rc
@@ -197,6 +202,14 @@ class DomParserImplementation:
             raise SjgpuError(f"sjgpu_result error {rc}: {self.last_error()}")
         return int(r.n), int(r.flags), int(r.out_len)
 
+
+    def debug_trace_stage1(self, buf_ptr, length, idx_ptr, idx_words, tiles):
+        """-> uint64[tiles, 8] wall-clock stamps (100 MHz) of the single-pass kernel's phases."""
+        out = np.zeros((int(tiles), 8), dtype=np.uint64)
+        rc = self.L.sjgpu_debug_trace_stage1(self.h, buf_ptr, int(length), idx_ptr, int(idx_words), out.ctypes.data, int(tiles))
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_debug_trace_stage1 error {rc}: {self.last_error()}")
+        return out
 
     def set_pipeline(self, fused=True):
         """True: single-pass kernel (chained scan); False: split summarize/resolve/emit pipeline."""

@@ -66,7 +66,8 @@ public:
     if (!ctx_) { return UNINITIALIZED; }
     // the array holds ROUNDUP(capacity,64)+9 words (generic/dom_parser_implementation.h:63-78)
     const size_t words = SIMDJSON_ROUNDUP_N(_capacity, 64) + 9;
-    return map_error(sjgpu_stage1(ctx_, buf, len, int(mode), structural_indexes.get(), words, &n_structural_indexes));
+    return map_error(sjgpu_stage1(ctx_, buf, len, int(mode), structural_indexes.get(), words, &n_structural_indexes,
+                                  &next_structural_index));
   }
 
   simdjson_warn_unused error_code stage2(dom::document &doc) noexcept final { return with_inner([&] { return inner_->stage2(doc); }); }

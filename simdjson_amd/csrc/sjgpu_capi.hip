@@ -243,6 +243,23 @@ int sjgpu_result(sjgpu_ctx *ctx, void *stream, sjgpu_scan_result *out) {
   return fetch_result(ctx, pick(ctx, stream), out);
 }
 
+int sjgpu_debug_trace_stage1(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *idx_dev, size_t idx_words,
+                             uint64_t *trace_host, uint32_t trace_tiles) {
+  if (!ctx || !buf_dev || !idx_dev || !trace_host || len == 0 || len > ctx->capacity) { return SJGPU_E_BADARG; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  uint64_t *d_trace = nullptr;
+  const size_t bytes = size_t(trace_tiles) * 8 * sizeof(uint64_t);
+  SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&d_trace), bytes));
+  (void)hipMemset(d_trace, 0, bytes);
+  launch_stage1_fused_traced(static_cast<const uint8_t *>(buf_dev), len, ctx->desc, static_cast<uint32_t *>(idx_dev), idx_words,
+                             ctx->d_result, ctx->max_workgroups, nullptr, d_trace, trace_tiles);
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) { e = hipMemcpy(trace_host, d_trace, bytes, hipMemcpyDeviceToHost); }
+  (void)hipFree(d_trace);
+  if (e != hipSuccess) { return fail(ctx, e, "debug_trace"); }
+  return 0;
+}
+
 int sjgpu_set_pipeline(sjgpu_ctx *ctx, int fused) {
   if (!ctx) { return SJGPU_E_BADARG; }
   ctx->fused = fused != 0;
@@ -278,7 +295,8 @@ int sjgpu_profile_read(sjgpu_ctx *ctx, double *ms_sum, uint32_t *calls) {
 }
 
 // ---- host-buffer entry points (the plug-in path: H2D, scan, D2H, host finish) ---------------------------
-int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint32_t *idx_out, size_t idx_words, uint32_t *n_io) {
+int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint32_t *idx_out, size_t idx_words, uint32_t *n_io,
+                 uint32_t *next_io) {
   if (!ctx || !n_io || mode < SJGPU_REGULAR || mode > SJGPU_COMMA_DELIMITED_FINAL) { return SJGPU_E_BADARG; }
   if (len > ctx->capacity) { return E_CAPACITY; } // json_structural_indexer.h:195
   if (len == 0) { return E_EMPTY; }               // :197
@@ -312,7 +330,7 @@ int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint3
   if (size_t(res.n) + 3 > idx_words) { return SJGPU_E_OVERFLOW; }
   SJ_TRY(ctx, hipMemcpyAsync(idx_out, ctx->d_idx, (size_t(res.n) + 3) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   SJ_TRY(ctx, hipStreamSynchronize(s));
-  return sjgpu_stage1_finish_host(buf, len, mode, idx_out, res.n, res.flags, n_io);
+  return sjgpu_stage1_finish_host(buf, len, mode, idx_out, res.n, res.flags, n_io, next_io);
 }
 
 int sjgpu_minify(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, uint8_t *dst, size_t *dst_len) {

@@ -105,10 +105,14 @@ __device__ __forceinline__ bool lookback(const u64 *desc, u32 tile, u32 lane, u3
 constexpr u32 WF_CTRL_IF_OUT = 1u, WF_CTRL_IF_IN = 2u, WF_UTF8 = 4u;
 
 // OP 0: stage 1 (out = u32 structural offsets); OP 1: minify (out = bytes)
-template <int OP>
+// TRACE: wave 0 / lane 0 of the first `trace_tiles` tiles records wall_clock64() at the phase boundaries
+// (8 stamps per tile) so the per-phase latency budget can be read off a real run (sjgpu_debug_trace_stage1).
+constexpr u32 TRACE_STAMPS = 8;
+template <int OP, bool TRACE>
 __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc,
                                                u32 *__restrict__ ticket, u32 ntiles, void *__restrict__ out, u64 out_words,
-                                               scan_result_dev *__restrict__ result) {
+                                               scan_result_dev *__restrict__ result, u64 *__restrict__ trace, u32 trace_tiles) {
+#define SJ_STAMP(k) do { if (TRACE && threadIdx.x == 0 && tile < trace_tiles) { trace[u64(tile) * TRACE_STAMPS + (k)] = wall_clock64(); } } while (0)
   constexpr u32 STAGE_WORDS = (OP == 0) ? EMIT_STAGE_WORDS : (MINIFY_STAGE_BYTES / 4);
   __shared__ u32 sh_tile;
   __shared__ u32 sh_wave[FUSED_WAVES][4]; // parity, count_if_out, count_if_in, flags
@@ -120,10 +124,13 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
   for (;;) {
     // Take the ticket only when we are ready to start the tile: a ticket claimed early would make every
     // successor's look-back wait for a tile nobody is scanning yet.
+    const u64 t_loop = TRACE ? wall_clock64() : 0;
     if (threadIdx.x == 0) { sh_tile = atomicAdd(ticket, 1u); }
     __syncthreads();
     const u32 tile = sh_tile;
     if (tile >= ntiles) { break; }
+    if (TRACE && threadIdx.x == 0 && tile < trace_tiles) { trace[u64(tile) * TRACE_STAMPS + 0] = t_loop; }
+    SJ_STAMP(1); // ticket known
 
     // ---- phase 1: scan my 4 chunks with a relative in-string state; masks go into the register FIFO ----
     const u64 wave_start = u64(tile) * FUSED_TILE_BYTES + u64(wave) * FUSED_WAVE_BYTES;
@@ -166,6 +173,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
       // a multi-byte sequence still open at the very end of the input (utf8_lookup4_algorithm.h:164-171)
       if (OP == 0 && wave_start + FUSED_WAVE_BYTES >= len && (wc.utf8 & UTF8_CARRY_OPEN)) { f_ue = true; }
     }
+    SJ_STAMP(2); // wave 0 finished scanning
     {
       const u32 t_out = wave_sum(n_out), t_in = wave_sum(n_in);
       u32 f = 0;
@@ -180,6 +188,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
       }
     }
     __syncthreads();
+    SJ_STAMP(3); // all waves finished scanning
 
     // ---- phase 2 (wave 0): publish the tile aggregate, look back, publish the inclusive prefix ----------
     if (wave == 0) {
@@ -195,6 +204,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
       if (lane == 0) { desc_store(desc + tile, make_agg(tq, tout, tin)); }
       u32 S = 0, B = 0;
       const bool ok = lookback(desc, tile, lane, S, B);
+      SJ_STAMP(4); // look-back done
       if (lane == 0) {
         if (ok) {
           const u32 total = B + (S ? tin : tout), s_end = S ^ tq;
@@ -226,6 +236,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
       }
     }
     __syncthreads();
+    SJ_STAMP(5);
 
     // ---- phase 3: every wave derives its own carry-in from the tile prefix and emits ------------------------
     if (sh_prefix[2] == 0u) { continue; } // poisoned chain: nothing to emit (workgroup-uniform)
@@ -262,7 +273,9 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
       }
     }
     if (OP == 0 && __ballot(overflow) && lane == 0) { atomicOr(&result->flags, SJGPU_F_IDX_OVERFLOW); }
+    SJ_STAMP(6); // wave 0 finished emitting
   }
+#undef SJ_STAMP
 }
 
 } // namespace
@@ -273,17 +286,24 @@ static inline void mark(hipEvent_t *ev, int k, hipStream_t stream) {
 }
 
 static void launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *desc, void *out, uint64_t out_words,
-                         scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev) {
+                         scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev,
+                         uint64_t *trace = nullptr, uint32_t trace_tiles = 0) {
   const u32 ntiles = num_fused_tiles(len);
   u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles); // descriptors and ticket are cleared by ONE memset
   (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
   (void)hipMemsetAsync(desc, 0, (size_t(ntiles) + 1) * sizeof(u64), stream);
   const u32 grid = ntiles < max_workgroups ? ntiles : max_workgroups;
   mark(ev, 0, stream);
-  if (op == 0) {
-    hipLaunchKernelGGL(k_fused<0>, dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result);
+  u64 *no_trace = nullptr;
+  if (trace) {
+    hipLaunchKernelGGL((k_fused<0, true>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result,
+                       trace, trace_tiles);
+  } else if (op == 0) {
+    hipLaunchKernelGGL((k_fused<0, false>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words,
+                       result, no_trace, 0u);
   } else {
-    hipLaunchKernelGGL(k_fused<1>, dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result);
+    hipLaunchKernelGGL((k_fused<1, false>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words,
+                       result, no_trace, 0u);
   }
   mark(ev, 1, stream);
   mark(ev, 2, stream);
@@ -293,6 +313,11 @@ static void launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *des
 void launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
                          scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev) {
   launch_fused(0, buf, len, desc, idx, idx_words, result, max_workgroups, stream, ev);
+}
+void launch_stage1_fused_traced(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
+                                scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, uint64_t *trace,
+                                uint32_t trace_tiles) {
+  launch_fused(0, buf, len, desc, idx, idx_words, result, max_workgroups, stream, nullptr, trace, trace_tiles);
 }
 void launch_minify_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint8_t *dst, scan_result_dev *result,
                          uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev) {

@@ -69,6 +69,9 @@ void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *res
 // single-pass variants: desc holds num_fused_tiles(capacity)+1 words; only profile slot 0 is used
 void launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
                          scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev);
+void launch_stage1_fused_traced(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
+                                scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, uint64_t *trace,
+                                uint32_t trace_tiles); // 8 wall_clock64 stamps (100 MHz) per tile
 void launch_minify_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint8_t *dst, scan_result_dev *result,
                          uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev);
 

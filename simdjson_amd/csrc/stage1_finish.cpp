@@ -134,7 +134,7 @@ extern "C" int sjgpu_stage1_error_from_flags(uint32_t n, uint32_t flags) {
 }
 
 extern "C" int sjgpu_stage1_finish_host(const uint8_t *buf, size_t len, int mode, uint32_t *idx, uint32_t n_raw,
-                                        uint32_t flags, uint32_t *n_io) {
+                                        uint32_t flags, uint32_t *n_io, uint32_t *next_io) {
   const bool streaming = mode != SJGPU_REGULAR;
   const bool unclosed = (flags & SJGPU_F_UNCLOSED_STRING) != 0;
   if (unclosed && !streaming) { return E_UNCLOSED; } // streaming tolerates it (…indexer.h:255-259)
@@ -144,6 +144,7 @@ extern "C" int sjgpu_stage1_finish_host(const uint8_t *buf, size_t len, int mode
   idx[n] = uint32_t(len); // the three sentinels (…indexer.h:284-287)
   idx[n + 1] = uint32_t(len);
   idx[n + 2] = 0;
+  if (next_io) { *next_io = 0; } // parser.next_structural_index = 0 (…indexer.h:287)
   if (n == 0) { return E_EMPTY; }
   if (idx[n - 1] > len) { return E_UNEXPECTED; }
   const view v{buf, idx};

@@ -41,9 +41,12 @@ static int compare_stage1(const implementation *cpu, const implementation *gpu, 
   CHECK(cpu->create_dom_parser_implementation(json.size(), 1024, a) == SUCCESS, "cpu parser");
   CHECK(gpu->create_dom_parser_implementation(json.size(), 1024, b) == SUCCESS, "gpu parser");
   for (int mode = 0; mode < 7; mode++) {
+    a->next_structural_index = b->next_structural_index = 12345; // must be reset by a completed scan
     auto ea = a->stage1(reinterpret_cast<const uint8_t *>(json.data()), json.size(), stage1_mode(mode));
     auto eb = b->stage1(reinterpret_cast<const uint8_t *>(json.data()), json.size(), stage1_mode(mode));
     CHECK(ea == eb, "%s mode %d: error %d vs %d", tag, mode, int(ea), int(eb));
+    CHECK(a->next_structural_index == b->next_structural_index, "%s mode %d: next_structural_index %u vs %u", tag, mode,
+          a->next_structural_index, b->next_structural_index);
     if (ea == UNCLOSED_STRING || ea == UNESCAPED_CHARS) { continue; }
     CHECK(a->n_structural_indexes == b->n_structural_indexes, "%s mode %d: n %u vs %u", tag, mode, a->n_structural_indexes, b->n_structural_indexes);
     CHECK(std::memcmp(a->structural_indexes.get(), b->structural_indexes.get(), (size_t(a->n_structural_indexes) + 3) * 4) == 0,

@@ -53,7 +53,9 @@ def host_stage1(lib, orc, data, mode):
             return capi.UTF8_ERROR, 0, idx[:3]
     raw, flags = orc.scan(a[:ln])
     idx[: len(raw)] = raw
-    err = lib.sjgpu_stage1_finish_host(a.ctypes.data, ln, mode, idx.ctypes.data, len(raw), flags, ctypes.byref(n_io))
+    nxt = ctypes.c_uint32(77)
+    err = lib.sjgpu_stage1_finish_host(a.ctypes.data, ln, mode, idx.ctypes.data, len(raw), flags, ctypes.byref(n_io), ctypes.byref(nxt))
+    assert nxt.value == (77 if err in checkers.EARLY else 0)  # next_structural_index reset exactly where finish() does
     return err, int(n_io.value), idx[: n_io.value + 3].copy()
 
 
