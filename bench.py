@@ -36,7 +36,9 @@ def main():
     ap.add_argument("--op", default="stage1", choices=["stage1", "minify", "validate_utf8"])
     ap.add_argument("--workload", default="large_random", choices=["large_random", "amazon_ndjson", "twitter_like"])
     ap.add_argument("--size", type=int, default=1 << 30, help="bytes per GPU")
-    ap.add_argument("--pipeline", default=os.environ.get("SJGPU_PIPELINE", "fused"), choices=["fused", "split"])
+    ap.add_argument("--pipeline", default=os.environ.get("SJGPU_PIPELINE", "split"), choices=["fused", "split"])
+    ap.add_argument("--ndjson-leg", type=int, default=-1, help="1: also time config 4 (amazon NDJSON shard per GPU, "
+                    "with and without the RCCL index concatenation); default: on when --gpus > 1")
     ap.add_argument("--cpu-iters", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -157,11 +159,79 @@ def main():
                 raise SystemExit(f"PARITY FAILURE: GPU n={n} vs CPU reference n={cb['n']}")
             line["cpu_baseline"] = {"value": round(cb["value"], 3), "unit": "GB/s", "cores": cb["cores"], "kind": cb["kind"],
                                     "sample": f"the same {L}-byte buffer, {cb['impl']} kernel, 1 thread, best of {args.cpu_iters}"}
+    # ---- optional second leg: BASELINE.json config 4 (parse_many-style NDJSON shards, RCCL concatenation) ----
+    ndjson = None
+    if (args.ndjson_leg == 1 or (args.ndjson_leg < 0 and world > 1)) and args.op == "stage1":
+        try:
+            ndjson = ndjson_leg(args, torch, dist, corpus, capi, rank, world, local_rank, fence)
+        except Exception as e:  # the primary line must survive a failure here
+            ndjson = {"error": repr(e)[:300]}
+    if rank == 0:
+        if ndjson is not None:
+            line["config4_ndjson"] = ndjson
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     parser.close()
+
+
+def ndjson_leg(args, torch, dist, corpus, capi, rank, world, local_rank, fence):
+    """amazon_cellphones-style NDJSON, one newline-aligned shard of --size bytes per GPU (weak scaling):
+    per-rank stage 1 with zero carry-in; then the same plus the all_gather that concatenates the index
+    arrays into global 64-bit positions (simdjson_amd.sharded)."""
+    import time as _t
+    from simdjson_amd import sharded
+    host, lines = corpus.amazon_ndjson(args.size, 2000 + rank)  # each rank's slice of the stream (ends in '\n')
+    L = len(host)
+    scanner = sharded.GpuShardScanner(L, local_rank)
+    scanner.parser.set_pipeline(args.pipeline == "fused")
+    buf = torch.from_numpy(host).cuda()
+    idx = torch.empty(L + 3, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    step = lambda: scanner.parser.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, stream)
+    for _ in range(2):
+        step()
+    n, flags, _ = scanner.parser.result(stream)
+    steps = max(4, args.steps // 2)
+    fence()
+    t0 = _t.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    dt_scan = _t.perf_counter() - t0
+    out = {"workload": f"amazon_ndjson {L} B per GPU, newline-aligned shards, zero carry-in", "structurals_rank0": n,
+           "lines_rank0": lines, "flags_rank0": flags}
+    if world > 1:
+        base = torch.tensor([L], dtype=torch.int64, device="cuda")
+        sizes = [torch.empty_like(base) for _ in range(world)]
+        dist.all_gather(sizes, base)
+        my_base = sum(int(x) for x in sizes[:rank])
+        local = sharded.ShardScan(my_base, L, n, flags, idx)
+        sharded.gather_global_indices(local)  # warm the communicator
+        fence()
+        t0 = _t.perf_counter()
+        for _ in range(steps):
+            step()
+            n2, f2, _ = scanner.parser.result(stream)
+            pos, counts, _ = sharded.gather_global_indices(sharded.ShardScan(my_base, L, n2, f2, idx))
+        fence()
+        dt_cat = _t.perf_counter() - t0
+        t = torch.tensor([dt_scan, dt_cat], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_scan, dt_cat = float(t[0]), float(t[1])
+        tot = torch.tensor([float(L)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot)
+        total = float(tot)
+        out["with_index_concat_GBps"] = round(total * steps / dt_cat / 1e9, 2)
+        out["total_structurals"] = int(sum(counts))
+        out["sorted_global_positions"] = bool((pos[1:] > pos[:-1]).all())
+    else:
+        total = float(L)
+    out["value_GBps"] = round(total * steps / dt_scan / 1e9, 2)
+    out["steps"] = steps
+    scanner.parser.close()
+    return out
 
 
 if __name__ == "__main__":

@@ -17,10 +17,15 @@ for s in $STAGES; do
       for op in stage1 minify validate_utf8; do
         timeout 600 python bench.py --op $op --steps 20 --warmup 3 > gpurun_out/bench_$op.json 2> gpurun_out/bench_$op.err; echo "bench $op rc=$?"; cat gpurun_out/bench_$op.json
       done
-      timeout 600 python bench.py --pipeline split --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_stage1_split.json 2> gpurun_out/bench_stage1_split.err; cat gpurun_out/bench_stage1_split.json
-      timeout 600 python bench.py --op minify --pipeline split --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_minify_split.json 2> gpurun_out/bench_minify_split.err; cat gpurun_out/bench_minify_split.json
+      timeout 600 python bench.py --pipeline fused --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_stage1_fused.json 2> gpurun_out/bench_stage1_fused.err; cat gpurun_out/bench_stage1_fused.json
+      timeout 600 python bench.py --op minify --pipeline fused --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_minify_fused.json 2> gpurun_out/bench_minify_fused.err; cat gpurun_out/bench_minify_fused.json
+      timeout 600 python bench.py --ndjson-leg 1 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/bench_ndjson_leg.json 2> gpurun_out/bench_ndjson_leg.err; cat gpurun_out/bench_ndjson_leg.json
       timeout 600 python bench.py --workload amazon_ndjson --steps 20 --warmup 3 > gpurun_out/bench_stage1_ndjson.json 2> gpurun_out/bench_stage1_ndjson.err; cat gpurun_out/bench_stage1_ndjson.json
       timeout 600 python bench.py --workload twitter_like --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_stage1_twitter.json 2> gpurun_out/bench_stage1_twitter.err; cat gpurun_out/bench_stage1_twitter.json
+      ;;
+    sweep)
+      timeout 900 python scripts/size_sweep.py twitter_like > gpurun_out/size_sweep_twitter.jsonl 2> gpurun_out/size_sweep.err; cat gpurun_out/size_sweep_twitter.jsonl
+      timeout 900 python scripts/size_sweep.py large_random > gpurun_out/size_sweep_large_random.jsonl 2>> gpurun_out/size_sweep.err; cat gpurun_out/size_sweep_large_random.jsonl
       ;;
     prof)
       for op in stage1 minify validate_utf8; do

@@ -100,24 +100,30 @@ SJ_HD planes transpose64(const u32 *w) {
 struct classes {
   u64 backslash, quote, ws, op, ctrl;
 };
+// a & ~b as ONE bit-field insert (v_bfi_b32 with a zero source): gfx950's VALU has no and-not, and spelling
+// the complement as a separate v_not doubles the cost of every negative literal below.
+SJ_HD u64 andn(u64 a, u64 b) {
+  return (u64(bfi(u32(b >> 32), 0u, u32(a >> 32))) << 32) | u64(bfi(u32(b), 0u, u32(a)));
+}
 SJ_HD classes classify(const planes &P) {
   const u64 b0 = P.b[0], b1 = P.b[1], b2 = P.b[2], b3 = P.b[3], b4 = P.b[4], b5 = P.b[5], b6 = P.b[6], b7 = P.b[7];
-  const u64 n0 = ~b0, n1 = ~b1, n2 = ~b2, n3 = ~b3, n4 = ~b4, n5 = ~b5, n6 = ~b6, n7 = ~b7;
   classes c;
-  const u64 hi_0 = n7 & n6 & n5 & n4;           // 0x0_
-  const u64 hi_2 = n7 & n6 & b5 & n4;           // 0x2_
-  const u64 lo_x0 = n3 & n2 & n0;               // low nibble 0000 or 0010
-  c.backslash = n7 & b6 & n5 & b4 & b3 & b2 & n1 & n0;                  // 0x5C
-  c.quote = hi_2 & lo_x0 & b1;                                          // 0x22
-  const u64 space = hi_2 & lo_x0 & n1;                                  // 0x20
-  const u64 tab_lf_cr = hi_0 & b3 & ((n2 & (b1 ^ b0)) | (b2 & n1 & b0)); // 09 0A | 0D
-  c.ws = space | tab_lf_cr;
-  const u64 comma = n6 & n4 & b2 & n1 & n0;     // x0x0 1100 : 2C (0C)
-  const u64 colon = n6 & b4 & n2 & b1 & n0;     // x0x1 1010 : 3A (1A)
-  const u64 open = b6 & b4 & n2 & b1 & b0;      // x1x1 1011 : 5B 7B
-  const u64 close = b6 & b4 & b2 & n1 & b0;     // x1x1 1101 : 5D 7D
-  c.op = n7 & b3 & (comma | colon | open | close);
-  c.ctrl = n7 & n6 & n5;                        // <= 0x1F
+  // every class is "these bits set, those bits clear" = AND of the set bits, and-not of the OR of the clear ones
+  const u64 hi765 = b7 | b6 | b5;                 // clear for 0x00..0x1F
+  c.ctrl = ~hi765;
+  const u64 hi764 = b7 | b6 | b4;                 // clear (with b5 set) for 0x2_
+  const u64 lo321 = b3 | b2 | b1;
+  const u64 space = andn(b5, hi764 | lo321 | b0);                        // 0x20
+  c.quote = andn(b5 & b1, hi764 | b3 | b2 | b0);                         // 0x22
+  // 0x09 0x0A 0x0D: high nibble 0, b3 set, then (b2 clear, b1 != b0) or (b2 set, b1 clear, b0 set)
+  const u64 tlc_low = andn(b1 ^ b0, b2) | andn(b2 & b0, b1);
+  c.ws = space | andn(b3 & tlc_low, hi765 | b4);
+  c.backslash = andn(b6 & b4 & b3 & b2, b7 | b5 | b1 | b0);              // 0x5C
+  // operators (b5 is "don't care": the x86 kernels compare b|0x20, which also admits 0x0C and 0x1A):
+  //   2C/0C x0x0 1100   3A/1A x0x1 1010   5B/7B x1x1 1011   5D/7D x1x1 1101
+  // all four have b3 set, b2 != b1; then either (b6 clear, b0 clear, b4 == b1) or (b6, b4, b0 all set)
+  const u64 low_pair = andn(b6 | b0 | (b4 ^ b1), b6 & b4 & b0); // = NOT of the bracketed alternative above
+  c.op = andn(b3 & (b2 ^ b1), b7 | low_pair);
   return c;
 }
 
