@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--op", default="stage1", choices=["stage1", "minify", "validate_utf8"])
     ap.add_argument("--workload", default="large_random", choices=["large_random", "amazon_ndjson", "twitter_like"])
     ap.add_argument("--size", type=int, default=1 << 30, help="bytes per GPU")
-    ap.add_argument("--pipeline", default=os.environ.get("SJGPU_PIPELINE", "split"), choices=["fused", "split"])
+    ap.add_argument("--pipeline", default=os.environ.get("SJGPU_PIPELINE", "auto"), choices=["auto", "fused", "split"])
     ap.add_argument("--ndjson-leg", type=int, default=-1, help="1: also time config 4 (amazon NDJSON shard per GPU, "
                     "with and without the RCCL index concatenation); default: on when --gpus > 1")
     ap.add_argument("--cpu-iters", type=int, default=12)
@@ -67,7 +67,9 @@ def main():
     host, units = getattr(corpus, args.workload)(args.size, 1000 + rank)
     L = len(host)
     parser = capi.DomParserImplementation(L, device=local_rank)
-    parser.set_pipeline(args.pipeline == "fused")
+    parser.set_pipeline(args.pipeline)
+    if args.pipeline == "auto":  # what AUTO resolves to for this size (sjgpu_capi.hip: AUTO_FUSED_BELOW)
+        args.pipeline = "fused" if L < (16 << 20) else "split"
     buf = torch.from_numpy(host).cuda()
     stream = torch.cuda.current_stream().cuda_stream
     if args.op == "stage1":
@@ -185,7 +187,7 @@ def ndjson_leg(args, torch, dist, corpus, capi, rank, world, local_rank, fence):
     host, lines = corpus.amazon_ndjson(args.size, 2000 + rank)  # each rank's slice of the stream (ends in '\n')
     L = len(host)
     scanner = sharded.GpuShardScanner(L, local_rank)
-    scanner.parser.set_pipeline(args.pipeline == "fused")
+    scanner.parser.set_pipeline(args.pipeline)
     buf = torch.from_numpy(host).cuda()
     idx = torch.empty(L + 3, dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream

@@ -105,12 +105,19 @@ int sjgpu_minify_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *d
 int sjgpu_validate_utf8_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *stream);
 int sjgpu_result(sjgpu_ctx *ctx, void *stream, sjgpu_scan_result *out);
 
-/* Pipeline selection (default: environment variable SJGPU_PIPELINE = "fused" | "split", else fused):
- *   1 = single pass, one kernel, chained scan between 64 KiB tiles (reads every byte once);
- *   0 = split: summarize -> resolve -> emit (three kernels, stage-1 masks round-trip through HBM).
- * Both produce identical bytes; a single-pass call that raises SJGPU_F_INTERNAL is re-run split by the
+/* Pipeline selection (default SJGPU_PIPELINE_AUTO; the environment variable SJGPU_PIPELINE = "split" |
+ * "fused" | "auto" sets the default of new contexts):
+ *   SPLIT  summarize -> resolve -> emit: four launches, stage-1 masks round-trip through HBM, every kernel
+ *          runs at full occupancy with no inter-workgroup waiting -- fastest on large inputs;
+ *   FUSED  one kernel, chained scan between 64 KiB tiles: reads every byte once, one launch -- fastest on
+ *          small inputs;
+ *   AUTO   FUSED below 16 MiB, SPLIT from there on.
+ * All produce identical bytes; a single-pass call that raises SJGPU_F_INTERNAL is re-run split by the
  * host-buffer entry points, device-resident callers see the flag in sjgpu_result(). */
-int sjgpu_set_pipeline(sjgpu_ctx *ctx, int fused);
+#define SJGPU_PIPELINE_SPLIT 0
+#define SJGPU_PIPELINE_FUSED 1
+#define SJGPU_PIPELINE_AUTO  2
+int sjgpu_set_pipeline(sjgpu_ctx *ctx, int pipeline);
 
 /* Diagnostics: one single-pass stage-1 call whose first trace_tiles tiles record 8 wall-clock stamps each
  * (100 MHz ticks: loop top, ticket, wave-0 scanned, all scanned, look-back done, prefix broadcast, wave-0

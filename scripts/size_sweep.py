@@ -25,7 +25,7 @@ for size in (64 << 10, 631515, 4 << 20, 32 << 20, 256 << 20, 1 << 30):
         dt = (time.perf_counter() - t0) / reps
         row[name + "_us"] = round(dt * 1e6, 1); row[name + "_GBps"] = round(L / dt / 1e9, 1)
     # host-buffer path (what the simdjson plug-in pays): pageable host memory in, pageable out
-    p.set_pipeline(L < (8 << 20))
+    p.set_pipeline("auto")
     for _ in range(2): p.stage1(a)
     reps = 50 if L < (64 << 20) else 3
     t0 = time.perf_counter()

@@ -211,9 +211,11 @@ class DomParserImplementation:
             raise SjgpuError(f"sjgpu_debug_trace_stage1 error {rc}: {self.last_error()}")
         return out
 
-    def set_pipeline(self, fused=True):
-        """True: single-pass kernel (chained scan); False: split summarize/resolve/emit pipeline."""
-        return self.L.sjgpu_set_pipeline(self.h, 1 if fused else 0)
+    def set_pipeline(self, pipeline="auto"):
+        """"split" | "fused" | "auto" (also accepts True = fused / False = split)."""
+        if isinstance(pipeline, bool):
+            pipeline = "fused" if pipeline else "split"
+        return self.L.sjgpu_set_pipeline(self.h, {"split": 0, "fused": 1, "auto": 2}[pipeline])
 
     def profile_enable(self, on=True):
         rc = self.L.sjgpu_profile_enable(self.h, 1 if on else 0)

@@ -21,7 +21,7 @@ struct sjgpu_ctx {
   seg_summary *summ = nullptr;
   seg_prefix *pref = nullptr;
   uint64_t *desc = nullptr; // single-pass pipeline: tile descriptors + ticket
-  bool fused = true;
+  int pipeline = 2; // 0 split, 1 single pass, 2 auto (single pass below AUTO_FUSED_BELOW bytes)
   uint32_t max_workgroups = 2048;
   scan_result_dev *d_result = nullptr;
   scan_result_dev *h_result = nullptr; // pinned
@@ -112,6 +112,11 @@ void drop_events(sjgpu_ctx *ctx) {
 // what torch.cuda.current_stream().cuda_stream reports for torch's default stream.
 hipStream_t pick(sjgpu_ctx *, void *stream) { return static_cast<hipStream_t>(stream); }
 
+// Measured on MI355X (profiles/r01_size_sweep.txt): one launch beats four up to a few MiB (20 us vs 24 us per
+// call), from ~32 MiB on the split pipeline's higher occupancy wins (1 GiB: 0.60 ms vs 0.73 ms).
+constexpr size_t AUTO_FUSED_BELOW = size_t(16) << 20;
+bool use_fused(const sjgpu_ctx *ctx, size_t len) { return ctx->pipeline == 1 || (ctx->pipeline == 2 && len < AUTO_FUSED_BELOW); }
+
 void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint32_t *idx, size_t idx_words, hipStream_t s,
                     hipEvent_t *ev) {
   if (fused) { launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, ctx->max_workgroups, s, ev); }
@@ -140,7 +145,9 @@ int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out) {
   sjgpu_ctx *ctx = new (std::nothrow) sjgpu_ctx();
   if (!ctx) { return SJGPU_E_NOMEM; }
   ctx->device = device;
-  if (const char *pl = std::getenv("SJGPU_PIPELINE")) { ctx->fused = std::strcmp(pl, "split") != 0; }
+  if (const char *pl = std::getenv("SJGPU_PIPELINE")) {
+    ctx->pipeline = std::strcmp(pl, "split") == 0 ? 0 : (std::strcmp(pl, "fused") == 0 ? 1 : 2);
+  }
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) {
     int cus = 0;
@@ -203,7 +210,7 @@ int sjgpu_stage1_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *i
   if (len > ctx->capacity) { return E_CAPACITY; }
   if (len == 0) { return E_EMPTY; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
-  enqueue_stage1(ctx, ctx->fused, static_cast<const uint8_t *>(buf_dev), len, static_cast<uint32_t *>(idx_dev), idx_words,
+  enqueue_stage1(ctx, use_fused(ctx, len), static_cast<const uint8_t *>(buf_dev), len, static_cast<uint32_t *>(idx_dev), idx_words,
                  pick(ctx, stream), next_events(ctx));
   SJ_TRY(ctx, hipGetLastError());
   return 0;
@@ -219,7 +226,7 @@ int sjgpu_minify_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *d
     SJ_TRY(ctx, hipMemsetAsync(ctx->d_result, 0, sizeof(scan_result_dev), pick(ctx, stream)));
     return 0;
   }
-  enqueue_minify(ctx, ctx->fused, static_cast<const uint8_t *>(buf_dev), len, static_cast<uint8_t *>(dst_dev), pick(ctx, stream),
+  enqueue_minify(ctx, use_fused(ctx, len), static_cast<const uint8_t *>(buf_dev), len, static_cast<uint8_t *>(dst_dev), pick(ctx, stream),
                  next_events(ctx));
   SJ_TRY(ctx, hipGetLastError());
   return 0;
@@ -260,9 +267,9 @@ int sjgpu_debug_trace_stage1(sjgpu_ctx *ctx, const void *buf_dev, size_t len, vo
   return 0;
 }
 
-int sjgpu_set_pipeline(sjgpu_ctx *ctx, int fused) {
-  if (!ctx) { return SJGPU_E_BADARG; }
-  ctx->fused = fused != 0;
+int sjgpu_set_pipeline(sjgpu_ctx *ctx, int pipeline) {
+  if (!ctx || pipeline < 0 || pipeline > 2) { return SJGPU_E_BADARG; }
+  ctx->pipeline = pipeline;
   return 0;
 }
 
@@ -316,7 +323,7 @@ int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint3
   SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
   sjgpu_scan_result res;
   for (int attempt = 0; attempt < 2; attempt++) { // a single-pass call that gives up is re-run on the split pipeline
-    enqueue_stage1(ctx, ctx->fused && attempt == 0, ctx->d_in, len, ctx->d_idx, ctx->d_idx_words, s, nullptr);
+    enqueue_stage1(ctx, use_fused(ctx, len) && attempt == 0, ctx->d_in, len, ctx->d_idx, ctx->d_idx_words, s, nullptr);
     SJ_TRY(ctx, hipGetLastError());
     rc = fetch_result(ctx, s, &res);
     if (rc) { return rc; }
@@ -348,7 +355,7 @@ int sjgpu_minify(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, uint8_t *dst, s
   SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
   sjgpu_scan_result res;
   for (int attempt = 0; attempt < 2; attempt++) {
-    enqueue_minify(ctx, ctx->fused && attempt == 0, ctx->d_in, len, ctx->d_out, s, nullptr);
+    enqueue_minify(ctx, use_fused(ctx, len) && attempt == 0, ctx->d_in, len, ctx->d_out, s, nullptr);
     SJ_TRY(ctx, hipGetLastError());
     rc = fetch_result(ctx, s, &res);
     if (rc) { return rc; }

@@ -22,7 +22,7 @@ def gpu(request):
     """Both device pipelines must be bit-exact: the single-pass kernel and the 3-kernel split pipeline."""
     build.build_sjgpu()
     p = capi.DomParserImplementation(CAP)  # raises loudly if the HIP library or the GPU is missing
-    p.set_pipeline(request.param == "fused")
+    p.set_pipeline(request.param)
     yield p
     p.close()
 
@@ -210,7 +210,7 @@ def test_full_size_device_resident(orc, kind, pipeline):
     a, _ = getattr(corpus, kind)(size, 11)
     L = len(a)
     p = capi.DomParserImplementation(L)
-    p.set_pipeline(pipeline == "fused")
+    p.set_pipeline(pipeline)
     buf = torch.from_numpy(a).cuda()
     idx = torch.empty(L + 3, dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
