@@ -6,7 +6,8 @@
 //   segment = SEG_CHUNKS chunks = 16 KiB    = one wave's (= one workgroup's) contiguous share
 //
 // Device workspace per context (all sized from `capacity`, resident in HBM between calls):
-//   masks  [ceil(cap/64)] x uint4  {cand_lo, cand_hi, string_tail_lo, string_tail_hi} per block
+//   masks  2 planes x [ceil(cap/64)] x u64  per block: plane 0 = final structural mask (resolved segments) or
+//                                  candidates; plane 1 = string_tail (unresolved segments only)
 //   summ   [nseg + ngroups] x seg_summary  per-segment carry summary (quote parity, counts for both
 //                                  in-string hypotheses, error bits), then the same per group of 64 segments
 //   pref   [ngroups] x seg_prefix  per-group resolved carry-in (in-string bit, output base)
@@ -29,6 +30,8 @@ constexpr uint32_t SF_PARITY = 1u;     // odd number of unescaped quotes in the 
 constexpr uint32_t SF_CTRL_IF_OUT = 2u; // control char inside a string if the segment starts OUTSIDE a string
 constexpr uint32_t SF_CTRL_IF_IN = 4u;  // ... if it starts INSIDE a string
 constexpr uint32_t SF_UTF8 = 8u;        // UTF-8 error in the segment
+constexpr uint32_t SF_RESOLVED = 16u;   // the segment fixed its own in-string carry-in (first control character): its
+                                        // mask plane 0 is final and both counts are equal
 
 struct seg_summary {
   uint32_t count_if_out; // structurals (stage1) / kept bytes (minify) if the segment starts outside a string

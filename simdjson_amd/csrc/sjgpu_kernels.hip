@@ -25,14 +25,25 @@ namespace {
 // =====================================================================================================
 // stage 1, kernel 1: scan every segment once, keep the per-block masks, publish the segment summary
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_stage1_summarize(const u8 *__restrict__ buf, u64 len, uint4 *__restrict__ masks,
-                                                         seg_summary *__restrict__ summ) {
+// Local resolution of the in-string state: a raw control character (<= 0x1F) inside a string is an error
+// (UNESCAPED_CHARS, json_structural_indexer.h:240,261-263) after which callers never look at the indexes, so
+// at the first control character of a segment the string state MUST be "outside" for any observable output.
+// That pins the segment's carry-in:  s_in = (relative in-string bit at that character).  When the first chunk
+// of a segment contains such a character (pretty-printed JSON, NDJSON, large_random: virtually always) the
+// segment is RESOLVED: it writes ONE final 64-bit mask per block instead of two and its count has a single
+// value.  The true parity chain is still scanned: a resolved segment whose true carry-in differs from the
+// derived one contains a control character inside a string and raises the same error the reference raises.
+__global__ __launch_bounds__(64) void k_stage1_summarize(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ mask0,
+                                                         u64 *__restrict__ mask1, seg_summary *__restrict__ summ) {
   const u32 lane = lane_id();
   const u32 seg = blockIdx.x;
   const u64 seg_start = u64(seg) * SEG_BYTES;
   wave_carry wc = segment_carry_in(buf, seg_start, lane);
-  u32 n_total = 0, n_in_tail = 0;
-  u64 ctrl_in = 0, ctrl_out = 0, uerr = 0;
+  u32 n_a = 0, n_b = 0; // resolved: n_a = final count; else n_a = candidates, n_b = candidates in a string tail
+  u64 ctrl_a = 0, ctrl_b = 0, uerr = 0;
+  bool resolved = false;
+  u32 derived = 0;
+  u64 flip = 0;
   for (u32 c = 0; c < SEG_CHUNKS; c++) {
     const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
     if (cstart >= len) { break; }
@@ -40,29 +51,58 @@ __global__ __launch_bounds__(64) void k_stage1_summarize(const u8 *__restrict__ 
     u32 w[16];
     load_block(buf, pos, len, w);
     const chunk_masks m = scan_chunk<true, true>(w, wc, lane);
-    n_total += u32(popc64(m.cand));
-    n_in_tail += u32(popc64(m.cand & m.string_tail));
-    ctrl_in |= m.ctrl & m.in_string;   // offends if the relative view is the true one
-    ctrl_out |= m.ctrl & ~m.in_string; // offends if the segment really starts inside a string
+    if (c == 0) {
+      const u64 cm = __ballot(m.ctrl != 0);
+      if (cm) { // wave-uniform
+        const u32 lc = ctz64(cm);
+        u32 v = 0;
+        if (lane == lc) { v = u32(m.in_string >> ctz64(m.ctrl)) & 1u; }
+        derived = readlane_dyn(v, lc);
+        resolved = true;
+        flip = derived ? ~0ull : 0ull;
+      }
+    }
     uerr |= m.utf8_err;
-    masks[pos / BLOCK_BYTES] = make_uint4(u32(m.cand), u32(m.cand >> 32), u32(m.string_tail), u32(m.string_tail >> 32));
+    if (resolved) {
+      const u64 structural = m.cand & ~(m.string_tail ^ flip);
+      n_a += u32(popc64(structural));
+      ctrl_a |= m.ctrl & (m.in_string ^ flip);
+      mask0[pos / BLOCK_BYTES] = structural;
+    } else {
+      n_a += u32(popc64(m.cand));
+      n_b += u32(popc64(m.cand & m.string_tail));
+      ctrl_a |= m.ctrl & m.in_string;  // offends if the relative view is the true one
+      ctrl_b |= m.ctrl & ~m.in_string; // offends if the segment really starts inside a string
+      mask0[pos / BLOCK_BYTES] = m.cand;
+      mask1[pos / BLOCK_BYTES] = m.string_tail;
+    }
   }
   // a multi-byte sequence still open at the very end of the input (utf8_lookup4_algorithm.h:164-171);
   // when len is not a multiple of the chunk the space padding has already flagged it.
   if (seg_start + SEG_BYTES >= len && (wc.utf8 & UTF8_CARRY_OPEN)) { uerr |= 1; }
-  const u32 tot = wave_sum(n_total), tail = wave_sum(n_in_tail);
+  const u32 ta = wave_sum(n_a), tb = wave_sum(n_b);
+  const bool any_a = __ballot(ctrl_a != 0) != 0, any_b = __ballot(ctrl_b != 0) != 0;
   u32 flags = wc.s ? SF_PARITY : 0u;
-  if (__ballot(ctrl_in != 0)) { flags |= SF_CTRL_IF_OUT; }
-  if (__ballot(ctrl_out != 0)) { flags |= SF_CTRL_IF_IN; }
   if (__ballot(uerr != 0)) { flags |= SF_UTF8; }
-  if (lane == 0) {
-    seg_summary s;
-    s.count_if_out = tot - tail; // structural = cand & ~string_tail
-    s.count_if_in = tail;        // starting inside a string flips string_tail
-    s.flags = flags;
-    s.pad = 0;
-    summ[seg] = s;
+  seg_summary s;
+  if (resolved) {
+    flags |= SF_RESOLVED;
+    s.count_if_out = ta;
+    s.count_if_in = ta;
+    // true carry-in == derived: error iff a control character sits inside a string in the resolved view;
+    // true carry-in != derived: the resolving control character itself is inside a string
+    const bool ok_view = !any_a;
+    if (derived ? true : !ok_view) { flags |= SF_CTRL_IF_OUT; }
+    if (derived ? !ok_view : true) { flags |= SF_CTRL_IF_IN; }
+  } else {
+    s.count_if_out = ta - tb; // structural = cand & ~string_tail
+    s.count_if_in = tb;       // starting inside a string flips string_tail
+    if (any_a) { flags |= SF_CTRL_IF_OUT; }
+    if (any_b) { flags |= SF_CTRL_IF_IN; }
   }
+  s.flags = flags;
+  s.pad = 0;
+  if (lane == 0) { summ[seg] = s; }
 }
 
 // =====================================================================================================
@@ -196,14 +236,16 @@ __device__ __forceinline__ seg_prefix segment_prefix(const seg_summary *__restri
 // =====================================================================================================
 // stage 1, kernel 2: select the right hypothesis per segment, flatten bitmaps to ascending offsets
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_stage1_emit(const uint4 *__restrict__ masks, const seg_summary *__restrict__ summ,
-                                                    const seg_prefix *__restrict__ gpref, u64 len, u32 *__restrict__ idx,
-                                                    u64 idx_words, scan_result_dev *__restrict__ result) {
+__global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask0, const u64 *__restrict__ mask1,
+                                                    const seg_summary *__restrict__ summ, const seg_prefix *__restrict__ gpref,
+                                                    u64 len, u32 *__restrict__ idx, u64 idx_words,
+                                                    scan_result_dev *__restrict__ result) {
   __shared__ __attribute__((aligned(16))) u32 stage[EMIT_STAGE_WORDS];
   const u32 lane = lane_id();
   const u32 seg = blockIdx.x;
   const u64 seg_start = u64(seg) * SEG_BYTES;
   const seg_prefix pf = segment_prefix(summ, gpref, seg, lane);
+  const bool resolved = (summ[seg].flags & SF_RESOLVED) != 0; // masks are already final
   u32 base = pf.base;
   const u64 flip = pf.in_string ? ~0ull : 0ull;
   bool overflow = false;
@@ -211,9 +253,9 @@ __global__ __launch_bounds__(64) void k_stage1_emit(const uint4 *__restrict__ ma
     const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
     if (cstart >= len) { break; }
     const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
-    const uint4 mk = masks[pos / BLOCK_BYTES];
-    const u64 cand = (u64(mk.y) << 32) | mk.x, tail = (u64(mk.w) << 32) | mk.z;
-    emit_indices(cand & ~(tail ^ flip), u32(pos), lane, idx, idx_words, base, stage, overflow);
+    u64 structural = mask0[pos / BLOCK_BYTES];
+    if (!resolved) { structural &= ~(mask1[pos / BLOCK_BYTES] ^ flip); }
+    emit_indices(structural, u32(pos), lane, idx, idx_words, base, stage, overflow);
   }
   if (__ballot(overflow) && lane == 0) { atomicOr(&result->flags, SJGPU_F_IDX_OVERFLOW); }
 }
@@ -317,7 +359,9 @@ void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *
   const u32 nseg = num_segments(len);
   (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
   mark(ev, 0, stream);
-  hipLaunchKernelGGL(k_stage1_summarize, dim3(nseg), dim3(64), 0, stream, buf, len, masks, summ);
+  u64 *mask0 = reinterpret_cast<u64 *>(masks);
+  u64 *mask1 = mask0 + size_t(nseg) * (SEG_BYTES / BLOCK_BYTES); // second plane, only written by unresolved segments
+  hipLaunchKernelGGL(k_stage1_summarize, dim3(nseg), dim3(64), 0, stream, buf, len, mask0, mask1, summ);
   mark(ev, 1, stream);
   const u32 ngroups = (nseg + RESOLVE_GROUP - 1) / RESOLVE_GROUP;
   seg_summary *gsum = summ + nseg; // the group summaries live behind the segment summaries
@@ -325,7 +369,7 @@ void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *
   hipLaunchKernelGGL(k_resolve_segments, dim3(1), dim3(RESOLVE_THREADS), 0, stream, gsum, pref, ngroups, len, idx, idx_words,
                      result, 0);
   mark(ev, 2, stream);
-  hipLaunchKernelGGL(k_stage1_emit, dim3(nseg), dim3(64), 0, stream, masks, summ, pref, len, idx, idx_words, result);
+  hipLaunchKernelGGL(k_stage1_emit, dim3(nseg), dim3(64), 0, stream, mask0, mask1, summ, pref, len, idx, idx_words, result);
   mark(ev, 3, stream);
 }
 

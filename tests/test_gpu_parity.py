@@ -168,6 +168,36 @@ def test_adversarial_shapes(gpu, orc):
         assert_same_all(gpu, orc, base[:n], tag=f"prefix {n}", modes=(0, 1, 2))
 
 
+def test_control_character_resolution(gpu, orc):
+    """Segments whose first chunk holds a control character fix their own in-string carry-in (one mask
+    plane); those without one keep both hypotheses.  Both kinds, valid and invalid, mixed in one buffer."""
+    seg = 16384
+    # minified (no control characters at all): every segment unresolved
+    a, _ = corpus.twitter_like(300_000, 3)
+    _, mini = orc.minify(a)
+    assert_same_all(gpu, orc, mini, tag="minified: unresolved segments", modes=(0, 2))
+    # a string that spans several segments with a raw newline at chosen places: UNESCAPED_CHARS, and the
+    # resolving character is the offender (derived carry-in != true carry-in)
+    for where in (seg + 5, seg + 4095, seg + 4096, 2 * seg + 100, 3 * seg - 1, 3 * seg):
+        body = bytearray(b'["' + b"k" * (4 * seg) + b'",1,2,3]' + b" \n" * 10)
+        body[where] = 0x0A
+        assert_same_all(gpu, orc, bytes(body), tag=f"newline inside long string at {where}", modes=(0, 1, 2))
+    # valid: long string without control characters (unresolved segments) followed by pretty-printed
+    # content (resolved segments); quote parity must carry across the boundary between the two kinds
+    for pad in (0, 1, 4095, 4096, 4097):
+        body = b'{"s":"' + b"z[]{}:," * 7000 + b"q" * pad + b'",\n  "t": [1, 2, 3],\n' + b'  "u": "a\\"b",\n' * 3000 + b'"v":0}'
+        assert_same_all(gpu, orc, body, tag=f"mixed resolved/unresolved pad {pad}", modes=(0,))
+    # control character in the first chunk but INSIDE a string that started in an earlier segment
+    body = b'["' + b"x" * (seg - 10) + b"\t" + b"y" * 100 + b'"]'
+    assert_same_all(gpu, orc, body, tag="tab inside string, first chunk of segment 1")
+    # 0x1E / 0x0C / 0x1A count as control characters too (they are also scalars / operators outside strings)
+    for c in (0x1E, 0x0C, 0x1A, 0x00):
+        body = b" " * (seg - 3) + bytes([c]) + b'{"a":"' + bytes([c]) + b'"}' + b" " * 50
+        assert_same_all(gpu, orc, body, tag=f"ctrl {c:#x} outside then inside")
+        body = b" " * (seg + 7) + bytes([c]) + b' {"a":"b"} ' * 2000
+        assert_same_all(gpu, orc, body, tag=f"ctrl {c:#x} resolves segment 1", modes=(0, 3, 4))
+
+
 def test_streaming_modes_on_bulk(gpu, orc):
     a, _ = corpus.amazon_ndjson(3 << 20, 5)
     cut = a[: len(a) - 777]  # ends inside a line
