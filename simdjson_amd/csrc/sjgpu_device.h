@@ -244,42 +244,83 @@ __device__ __forceinline__ void emit_indices(u64 structural, u32 pos32, u32 lane
 // =====================================================================================================
 // output: byte compaction (minify) of one chunk through a per-wave LDS window
 // =====================================================================================================
-constexpr u32 MINIFY_STAGE_BYTES = CHUNK_BYTES + 16;
+constexpr u32 MINIFY_STAGE_BYTES = CHUNK_BYTES + 32;
+constexpr u32 MINIFY_LUT_WORDS = 16;
+
+// v_perm_b32 selector that packs the bytes of a dword whose bit is set in k4 to the low end (0x0C = zero byte)
+__device__ __forceinline__ u32 compaction_selector(u32 k4) {
+  u32 sel = 0x0C0C0C0Cu, at = 0;
+#pragma unroll
+  for (u32 b = 0; b < 4; b++) {
+    if (k4 & (1u << b)) {
+      sel = (sel & ~(0xFFu << (8 * at))) | (b << (8 * at));
+      at++;
+    }
+  }
+  return sel;
+}
+// every wave that calls emit_bytes shares one 16-entry table in LDS (fill it once, then wave_lds_fence / barrier)
+__device__ __forceinline__ void init_compaction_lut(u32 *lut, u32 lane) {
+  if (lane < MINIFY_LUT_WORDS) { lut[lane] = compaction_selector(lane); }
+}
 
 // lane keeps the bytes of its block whose bit is set in `keep`; the wave appends them to dst[base...].
-// dst must be 16-byte aligned.
+// dst must be 16-byte aligned.  Dword-granular: each input dword is compacted with ONE v_perm_b32 (selector
+// from the LDS table), streamed through a 64-bit shift accumulator and OR-merged into the zeroed window, so a
+// lane issues <= 17 LDS operations per block instead of one per byte (and neighbouring lanes, whose output
+// ranges share a dword, need no ordering).  The stage must be all-zero on entry and is left all-zero.
 __device__ __forceinline__ void emit_bytes(const u32 (&w)[16], u64 keep, u32 lane, u8 *__restrict__ dst, u32 &base,
-                                           u8 *__restrict__ stage) {
+                                           u8 *__restrict__ stage, const u32 *__restrict__ lut) {
   const u32 cnt = u32(popc64(keep));
   const u32 incl = wave_incl_scan(cnt);
   const u32 total = readlane(incl, 63);
   if (total == 0) { return; }
   const u32 skew = base & 15u; // stage offset and destination address agree modulo 16
-  u32 o = skew + (incl - cnt);
+  const u32 o = skew + (incl - cnt);
+  u32 *const stage_w = reinterpret_cast<u32 *>(stage);
+  u32 dw = o >> 2, fill = o & 3u;
+  u64 acc = 0;
 #pragma unroll
   for (int j = 0; j < 16; j++) {
     const u32 k4 = u32(keep >> (4 * j)) & 0xFu;
-    const u32 x = w[j];
-    if (k4 & 1u) { stage[o] = u8(x); o++; }
-    if (k4 & 2u) { stage[o] = u8(x >> 8); o++; }
-    if (k4 & 4u) { stage[o] = u8(x >> 16); o++; }
-    if (k4 & 8u) { stage[o] = u8(x >> 24); o++; }
+    const u32 packed = byte_perm(0u, w[j], lut[k4]);
+    acc |= u64(packed) << (8u * fill);
+    fill += u32(__popc(k4));
+    if (fill >= 4u) {
+      atomicOr(&stage_w[dw], u32(acc)); // ds_or_b32, result unused
+      dw++;
+      acc >>= 32;
+      fill -= 4u;
+    }
   }
+  if (fill) { atomicOr(&stage_w[dw], u32(acc)); }
   wave_lds_fence();
   u8 *const g0 = dst + (u64(base) - skew);
   const u32 end = skew + total;
   const u32 v_first = (skew + 15u) >> 4, v_last = end >> 4; // whole 16-byte vectors [v_first, v_last)
   if (v_last > v_first) {
+#pragma unroll 1
     for (u32 v = v_first + lane; v < v_last; v += 64) {
       *reinterpret_cast<uint4 *>(g0 + 16u * v) = *reinterpret_cast<const uint4 *>(stage + 16u * v);
     }
     if (skew + lane < 16u * v_first) { g0[skew + lane] = stage[skew + lane]; }
     if (16u * v_last + lane < end) { g0[16u * v_last + lane] = stage[16u * v_last + lane]; }
   } else {
+#pragma unroll 1
     for (u32 i = skew + lane; i < end; i += 64) { g0[i] = stage[i]; }
   }
   wave_lds_fence();
+  // re-zero what was used: vectors [0, ceil(end/16))
+#pragma unroll 1
+  for (u32 v = lane; 16u * v < end; v += 64) { *reinterpret_cast<uint4 *>(stage + 16u * v) = make_uint4(0, 0, 0, 0); }
+  wave_lds_fence();
   base += total;
+}
+
+// zero a fresh per-wave minify window (call once before the first emit_bytes)
+__device__ __forceinline__ void clear_minify_stage(u8 *stage, u32 lane) {
+  for (u32 v = lane; 16u * v < MINIFY_STAGE_BYTES; v += 64) { *reinterpret_cast<uint4 *>(stage + 16u * v) = make_uint4(0, 0, 0, 0); }
+  wave_lds_fence();
 }
 
 } // namespace

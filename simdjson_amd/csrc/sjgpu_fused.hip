@@ -118,8 +118,13 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
   __shared__ u32 sh_wave[FUSED_WAVES][4]; // parity, count_if_out, count_if_in, flags
   __shared__ u32 sh_prefix[4];            // S, B, ok
   __shared__ __attribute__((aligned(16))) u32 sh_stage[FUSED_WAVES][STAGE_WORDS];
+  __shared__ u32 sh_lut[MINIFY_LUT_WORDS];
 
   const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  if (OP == 1) {
+    if (wave == 0) { init_compaction_lut(sh_lut, lane); }
+    clear_minify_stage(reinterpret_cast<u8 *>(sh_stage[wave]), lane);
+  }
 
   for (;;) {
     // Take the ticket only when we are ready to start the tile: a ticket claimed early would make every
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
         u32 w[16];
         load_block(buf, pos, len, w); // second touch of the same 4 KiB: served by L2 / Infinity Cache
         emit_bytes(w, valid_mask(pos, len) & ~(a & ~(b ^ flip)), lane, static_cast<u8 *>(out), base,
-                   reinterpret_cast<u8 *>(sh_stage[wave]));
+                   reinterpret_cast<u8 *>(sh_stage[wave]), sh_lut);
       }
     }
     if (OP == 0 && __ballot(overflow) && lane == 0) { atomicOr(&result->flags, SJGPU_F_IDX_OVERFLOW); }

@@ -294,7 +294,10 @@ __global__ __launch_bounds__(64) void k_minify_summarize(const u8 *__restrict__ 
 __global__ __launch_bounds__(64) void k_minify_emit(const u8 *__restrict__ buf, u64 len, const seg_summary *__restrict__ summ,
                                                     const seg_prefix *__restrict__ gpref, u8 *__restrict__ dst) {
   __shared__ __attribute__((aligned(16))) u8 stage[MINIFY_STAGE_BYTES];
+  __shared__ u32 lut[MINIFY_LUT_WORDS];
   const u32 lane = lane_id();
+  init_compaction_lut(lut, lane);
+  clear_minify_stage(stage, lane);
   const u32 seg = blockIdx.x;
   const u64 seg_start = u64(seg) * SEG_BYTES;
   const seg_prefix pf = segment_prefix(summ, gpref, seg, lane);
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(64) void k_minify_emit(const u8 *__restrict__ buf, 
     u32 w[16];
     load_block(buf, pos, len, w);
     const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
-    emit_bytes(w, valid_mask(pos, len) & ~(m.ws & ~m.in_string), lane, dst, base, stage);
+    emit_bytes(w, valid_mask(pos, len) & ~(m.ws & ~m.in_string), lane, dst, base, stage, lut);
   }
 }
 
