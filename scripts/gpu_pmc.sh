@@ -19,6 +19,8 @@ run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_A
 find gpurun_out/pmc_$TAG -name "*counter_collection.csv" | head
 python3 - <<PY
 import csv, glob, collections
+import json
+summary={}
 for f in sorted(glob.glob("gpurun_out/pmc_$TAG/*/*counter_collection.csv")+glob.glob("gpurun_out/pmc_$TAG/*/*/*counter_collection.csv")):
     rows=list(csv.DictReader(open(f)))
     agg=collections.defaultdict(lambda: collections.defaultdict(list))
@@ -29,4 +31,6 @@ for f in sorted(glob.glob("gpurun_out/pmc_$TAG/*/*counter_collection.csv")+glob.
     for k,v in agg.items():
         if "fill" in k or "copy" in k: continue
         print("  ", k, {c: round(sum(x)/len(x),1) for c,x in v.items()})
+        summary.setdefault(k, {}).update({c: sum(x)/len(x) for c,x in v.items()})
+json.dump(summary, open("gpurun_out/pmc_$TAG/summary.json","w"), indent=1)
 PY

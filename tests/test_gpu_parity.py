@@ -213,6 +213,37 @@ def test_streaming_modes_on_bulk(gpu, orc):
         assert_same_stage1(gpu, orc, com[:-300], mode, "comma_delimited cut")
 
 
+def test_three_gib_offsets_do_not_wrap(orc):
+    """Near the API's size limit (u32 offsets, len <= 0xFFFFFFFF): positions beyond 2^31 and segment / group
+    counts beyond 2^17 must not overflow anywhere.  3 GiB of NDJSON, exact digest against the oracle."""
+    import torch
+    size = int(os.environ.get("SJGPU_HUGE_SIZE", str(3 << 30)))
+    if size == 0:
+        pytest.skip("disabled")
+    a, _ = corpus.amazon_ndjson(size, 31)
+    L = len(a)
+    assert L > (1 << 31)
+    oerr, on, oidx = orc.stage1(a, 0)
+    for pipeline in ("split", "fused"):
+        p = capi.DomParserImplementation(L)
+        p.set_pipeline(pipeline)
+        buf = torch.from_numpy(a).cuda()
+        words = on + 1000
+        idx = torch.empty(words, dtype=torch.int32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        assert p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), words, stream) == 0
+        n, flags, _ = p.result(stream)
+        assert (n, flags) == (on, 0), (pipeline, n, on, flags)
+        host = idx[: n + 3].cpu().numpy().view(np.uint32)
+        assert orc.fnv(host) == orc.fnv(oidx), (pipeline, first_diff(host, oidx))
+        # too small an index array is reported, not overrun
+        small = torch.empty(1000, dtype=torch.int32, device="cuda")
+        assert p.stage1_device(buf.data_ptr(), L, small.data_ptr(), 1000, stream) == 0
+        assert p.result(stream)[1] & capi.F_IDX_OVERFLOW
+        del buf, idx, small
+        p.close()
+
+
 def test_capacity_and_empty_guards(gpu):
     small = capi.DomParserImplementation(16)
     assert small.stage1(b"[1,2,3,4,5,6,7,8,9,10]") == capi.CAPACITY
