@@ -68,7 +68,8 @@ void release_workspace(sjgpu_ctx *ctx) {
   dev_free(ctx->masks);
   dev_free(ctx->summ);
   dev_free(ctx->pref);
-  dev_free(ctx->desc);
+  dev_free(ctx->d_result); // also frees the descriptors behind it
+  ctx->desc = nullptr;
   dev_free(ctx->d_in);
   dev_free(ctx->d_idx);
   dev_free(ctx->d_out);
@@ -156,7 +157,6 @@ int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out) {
     }
   }
   if (e == hipSuccess) { e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking); }
-  if (e == hipSuccess) { e = hipMalloc(reinterpret_cast<void **>(&ctx->d_result), sizeof(scan_result_dev)); }
   if (e == hipSuccess) { e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_result), sizeof(scan_result_dev), hipHostMallocDefault); }
   if (e != hipSuccess) {
     int rc = fail(nullptr, e, "ctx_create");
@@ -178,7 +178,6 @@ void sjgpu_ctx_destroy(sjgpu_ctx *ctx) {
   if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
   release_workspace(ctx);
   drop_events(ctx);
-  dev_free(ctx->d_result);
   if (ctx->h_result) { (void)hipHostFree(ctx->h_result); }
   if (ctx->stream) { (void)hipStreamDestroy(ctx->stream); }
   delete ctx;
@@ -189,12 +188,15 @@ int sjgpu_set_capacity(sjgpu_ctx *ctx, size_t capacity) {
   SJ_TRY(ctx, hipSetDevice(ctx->device));
   if (ctx->stream) { SJ_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
   release_workspace(ctx);
+  // [result][tile descriptors][ticket]: one allocation, so that the single-pass launcher clears all of it at once
+  const size_t tiles = capacity ? num_fused_tiles(capacity) : 0;
+  SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_result), sizeof(scan_result_dev) + (tiles + 1) * sizeof(uint64_t)));
+  ctx->desc = reinterpret_cast<uint64_t *>(ctx->d_result + 1);
   if (capacity == 0) { return 0; }
   const size_t nseg = num_segments(capacity);
   SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->masks), nseg * (SEG_BYTES / BLOCK_BYTES) * sizeof(uint4)));
   SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->summ), (nseg + num_groups(capacity)) * sizeof(seg_summary)));
   SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->pref), nseg * sizeof(seg_prefix)));
-  SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->desc), (size_t(num_fused_tiles(capacity)) + 1) * sizeof(uint64_t)));
   ctx->capacity = capacity;
   return 0;
 }

@@ -67,6 +67,16 @@ __device__ __forceinline__ void load_block(const u8 *__restrict__ buf, u64 pos, 
     }
   }
 }
+// the same when the whole chunk is known to lie inside the input (wave-uniform fast path: four straight
+// 16-byte loads per lane, no per-lane control flow, so the compiler can keep them in flight across compute)
+__device__ __forceinline__ void load_block_full(const u8 *__restrict__ buf, u64 pos, u32 (&w)[16]) {
+  const uint4 *p = reinterpret_cast<const uint4 *>(buf + pos);
+  const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+  w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+  w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w;
+  w[12] = d.x; w[13] = d.y; w[14] = d.z; w[15] = d.w;
+}
 // bit i set iff byte pos+i is real input
 __device__ __forceinline__ u64 valid_mask(u64 pos, u64 len) {
   if (pos + BLOCK_BYTES <= len) { return ~0ull; }

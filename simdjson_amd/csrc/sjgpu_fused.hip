@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
         if (cstart < len) {
           const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
           u32 w[16];
-          load_block(buf, pos, len, w);
+          if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
+          else { load_block(buf, pos, len, w); }
           if (OP == 0) {
             const chunk_masks m = scan_chunk<true, true>(w, wc, lane);
             a = m.cand;
@@ -295,8 +296,13 @@ static void launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *des
                          uint64_t *trace = nullptr, uint32_t trace_tiles = 0) {
   const u32 ntiles = num_fused_tiles(len);
   u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles); // descriptors and ticket are cleared by ONE memset
-  (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
-  (void)hipMemsetAsync(desc, 0, (size_t(ntiles) + 1) * sizeof(u64), stream);
+  // result, descriptors and ticket are cleared by ONE memset when the context laid them out back to back
+  if (reinterpret_cast<uint64_t *>(result + 1) == desc) {
+    (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev) + (size_t(ntiles) + 1) * sizeof(u64), stream);
+  } else {
+    (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
+    (void)hipMemsetAsync(desc, 0, (size_t(ntiles) + 1) * sizeof(u64), stream);
+  }
   const u32 grid = ntiles < max_workgroups ? ntiles : max_workgroups;
   mark(ev, 0, stream);
   u64 *no_trace = nullptr;

@@ -44,12 +44,14 @@ __global__ __launch_bounds__(64) void k_stage1_summarize(const u8 *__restrict__ 
   bool resolved = false;
   u32 derived = 0;
   u64 flip = 0;
+  const u64 lane_off = u64(lane) * BLOCK_BYTES;
   for (u32 c = 0; c < SEG_CHUNKS; c++) {
     const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
     if (cstart >= len) { break; }
-    const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
+    const u64 pos = cstart + lane_off;
     u32 w[16];
-    load_block(buf, pos, len, w);
+    if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); } // interior chunk: branch-free loads
+    else { load_block(buf, pos, len, w); }
     const chunk_masks m = scan_chunk<true, true>(w, wc, lane);
     if (c == 0) {
       const u64 cm = __ballot(m.ctrl != 0);
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(RESOLVE_THREADS) void k_resolve_segments(const seg_
       result->n = 0;
       result->out_len = final_parity ? 0ull : u64(total); // unclosed string voids the output (json_minifier.h:42-47)
     }
-    atomicOr(&result->flags, f);
+    result->flags = f; // this kernel is the first writer of the call's result (the emit kernel only ORs into it)
   }
 }
 
@@ -360,7 +362,6 @@ static inline void mark(hipEvent_t *ev, int k, hipStream_t stream) {
 void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *summ, seg_prefix *pref, uint32_t *idx,
                    uint64_t idx_words, scan_result_dev *result, hipStream_t stream, hipEvent_t *ev) {
   const u32 nseg = num_segments(len);
-  (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
   mark(ev, 0, stream);
   u64 *mask0 = reinterpret_cast<u64 *>(masks);
   u64 *mask1 = mask0 + size_t(nseg) * (SEG_BYTES / BLOCK_BYTES); // second plane, only written by unresolved segments
@@ -379,7 +380,6 @@ void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *
 void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_prefix *pref, uint8_t *dst,
                    scan_result_dev *result, hipStream_t stream, hipEvent_t *ev) {
   const u32 nseg = num_segments(len);
-  (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
   mark(ev, 0, stream);
   hipLaunchKernelGGL(k_minify_summarize, dim3(nseg), dim3(64), 0, stream, buf, len, summ);
   mark(ev, 1, stream);
