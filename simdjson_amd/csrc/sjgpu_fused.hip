@@ -27,8 +27,7 @@
 namespace sjgpu {
 namespace {
 
-constexpr u32 FUSED_WAVES = FUSED_TILE_BYTES / (FUSED_WAVE_CHUNKS * CHUNK_BYTES); // 4
-constexpr u32 FUSED_WAVE_BYTES = FUSED_WAVE_CHUNKS * CHUNK_BYTES;                 // 16 KiB
+constexpr u32 FUSED_WAVES = 4; // waves per workgroup; each owns WC consecutive chunks of the tile
 constexpr u32 LOOKBACK_LOADS = 4;                                                // x64 descriptors per round trip
 constexpr u64 LOOKBACK_TIMEOUT_TICKS = 100ull * 1000 * 1000;                     // wall_clock64 is 100 MHz: 1 s
 
@@ -108,12 +107,18 @@ constexpr u32 WF_CTRL_IF_OUT = 1u, WF_CTRL_IF_IN = 2u, WF_UTF8 = 4u;
 // TRACE: wave 0 / lane 0 of the first `trace_tiles` tiles records wall_clock64() at the phase boundaries
 // (8 stamps per tile) so the per-phase latency budget can be read off a real run (sjgpu_debug_trace_stage1).
 constexpr u32 TRACE_STAMPS = 8;
-template <int OP, bool TRACE>
+// WC = chunks per wave: 4 (64 KiB tiles) for throughput, 1 (16 KiB tiles) for small inputs, where the serial
+// latency of one tile (WC loads + scans, then WC emits) is the whole call.
+template <int OP, bool TRACE, u32 WC>
 __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc,
                                                u32 *__restrict__ ticket, u32 ntiles, void *__restrict__ out, u64 out_words,
                                                scan_result_dev *__restrict__ result, u64 *__restrict__ trace, u32 trace_tiles) {
 #define SJ_STAMP(k) do { if (TRACE && threadIdx.x == 0 && tile < trace_tiles) { trace[u64(tile) * TRACE_STAMPS + (k)] = wall_clock64(); } } while (0)
   constexpr u32 STAGE_WORDS = (OP == 0) ? EMIT_STAGE_WORDS : (MINIFY_STAGE_BYTES / 4);
+  static_assert(WC == 1 || WC == 4, "the mask FIFO is written for 1 or 4 chunks per wave");
+  constexpr u32 FUSED_WAVE_CHUNKS = WC;
+  constexpr u32 FUSED_WAVE_BYTES = WC * CHUNK_BYTES;
+  constexpr u32 FUSED_TILE_BYTES = FUSED_WAVES * FUSED_WAVE_BYTES;
   __shared__ u32 sh_tile;
   __shared__ u32 sh_wave[FUSED_WAVES][4]; // parity, count_if_out, count_if_in, flags
   __shared__ u32 sh_prefix[4];            // S, B, ok
@@ -263,9 +268,12 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
     bool overflow = false;
 #pragma unroll 1
     for (u32 c = 0; c < FUSED_WAVE_CHUNKS; c++) {
-      const u64 a = a3, b = b3;
-      a3 = a2; a2 = a1; a1 = a0;
-      b3 = b2; b2 = b1; b1 = b0;
+      // oldest chunk first: after WC pushes chunk c sits in slot WC-1-c
+      const u64 a = (WC == 1) ? a0 : a3, b = (WC == 1) ? b0 : b3;
+      if (WC != 1) {
+        a3 = a2; a2 = a1; a1 = a0;
+        b3 = b2; b2 = b1; b1 = b0;
+      }
       const u64 cstart = wave_start + u64(c) * CHUNK_BYTES;
       if (cstart >= len) { break; }
       const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
@@ -291,11 +299,13 @@ static inline void mark(hipEvent_t *ev, int k, hipStream_t stream) {
   if (ev) { (void)hipEventRecord(ev[k], stream); }
 }
 
-static void launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *desc, void *out, uint64_t out_words,
-                         scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev,
-                         uint64_t *trace = nullptr, uint32_t trace_tiles = 0) {
-  const u32 ntiles = num_fused_tiles(len);
-  u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles); // descriptors and ticket are cleared by ONE memset
+template <u32 WC>
+static void launch_fused_wc(int op, const uint8_t *buf, uint64_t len, uint64_t *desc, void *out, uint64_t out_words,
+                            scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev,
+                            uint64_t *trace, uint32_t trace_tiles) {
+  constexpr u64 tile_bytes = u64(FUSED_WAVES) * WC * CHUNK_BYTES;
+  const u32 ntiles = u32((len + tile_bytes - 1) / tile_bytes);
+  u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles);
   // result, descriptors and ticket are cleared by ONE memset when the context laid them out back to back
   if (reinterpret_cast<uint64_t *>(result + 1) == desc) {
     (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev) + (size_t(ntiles) + 1) * sizeof(u64), stream);
@@ -304,21 +314,31 @@ static void launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *des
     (void)hipMemsetAsync(desc, 0, (size_t(ntiles) + 1) * sizeof(u64), stream);
   }
   const u32 grid = ntiles < max_workgroups ? ntiles : max_workgroups;
-  mark(ev, 0, stream);
   u64 *no_trace = nullptr;
+  mark(ev, 0, stream);
   if (trace) {
-    hipLaunchKernelGGL((k_fused<0, true>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result,
-                       trace, trace_tiles);
+    hipLaunchKernelGGL((k_fused<0, true, WC>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words,
+                       result, trace, trace_tiles);
   } else if (op == 0) {
-    hipLaunchKernelGGL((k_fused<0, false>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words,
+    hipLaunchKernelGGL((k_fused<0, false, WC>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words,
                        result, no_trace, 0u);
   } else {
-    hipLaunchKernelGGL((k_fused<1, false>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words,
+    hipLaunchKernelGGL((k_fused<1, false, WC>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words,
                        result, no_trace, 0u);
   }
   mark(ev, 1, stream);
   mark(ev, 2, stream);
   mark(ev, 3, stream);
+}
+
+static void launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *desc, void *out, uint64_t out_words,
+                         scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev,
+                         uint64_t *trace = nullptr, uint32_t trace_tiles = 0) {
+  if (len <= FUSED_SMALL_BELOW && !trace) {
+    launch_fused_wc<1>(op, buf, len, desc, out, out_words, result, max_workgroups, stream, ev, trace, trace_tiles);
+  } else {
+    launch_fused_wc<FUSED_WAVE_CHUNKS>(op, buf, len, desc, out, out_words, result, max_workgroups, stream, ev, trace, trace_tiles);
+  }
 }
 
 void launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,

@@ -58,7 +58,14 @@ inline uint32_t num_groups(uint64_t len) { return (num_segments(len) + RESOLVE_G
 // workspace = one 8-byte descriptor per tile + the ticket word behind them.
 constexpr uint32_t FUSED_WAVE_CHUNKS = 4;
 constexpr uint32_t FUSED_TILE_BYTES = 4 * FUSED_WAVE_CHUNKS * CHUNK_BYTES;
-inline uint32_t num_fused_tiles(uint64_t len) { return uint32_t((len + FUSED_TILE_BYTES - 1) / FUSED_TILE_BYTES); }
+// inputs up to FUSED_SMALL_BELOW use 16 KiB tiles (one chunk per wave): 4x the parallelism, 1/4 of the per-tile latency
+constexpr uint64_t FUSED_SMALL_BELOW = uint64_t(4) << 20;
+inline uint32_t num_fused_tiles(uint64_t len) { // descriptor words a context needs for documents up to len
+  const uint64_t big = (len + FUSED_TILE_BYTES - 1) / FUSED_TILE_BYTES;
+  const uint64_t small_len = len < FUSED_SMALL_BELOW ? len : FUSED_SMALL_BELOW;
+  const uint64_t small = (small_len + FUSED_TILE_BYTES / FUSED_WAVE_CHUNKS - 1) / (FUSED_TILE_BYTES / FUSED_WAVE_CHUNKS);
+  return uint32_t(big > small ? big : small);
+}
 
 // ---- launchers (sjgpu_kernels.hip); every one only enqueues on `stream` ---------------------------------
 // ev: nullptr, or PROFILE_EVENTS events recorded around the kernels (ev[k], ev[k+1] bracket kernel k).
