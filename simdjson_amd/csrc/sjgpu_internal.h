@@ -59,7 +59,7 @@ inline uint32_t num_groups(uint64_t len) { return (num_segments(len) + RESOLVE_G
 constexpr uint32_t FUSED_WAVE_CHUNKS = 4;
 constexpr uint32_t FUSED_TILE_BYTES = 4 * FUSED_WAVE_CHUNKS * CHUNK_BYTES;
 // inputs up to FUSED_SMALL_BELOW use 16 KiB tiles (one chunk per wave): 4x the parallelism, 1/4 of the per-tile latency
-constexpr uint64_t FUSED_SMALL_BELOW = uint64_t(4) << 20;
+constexpr uint64_t FUSED_SMALL_BELOW = uint64_t(8) << 20;
 inline uint32_t num_fused_tiles(uint64_t len) { // descriptor words a context needs for documents up to len
   const uint64_t big = (len + FUSED_TILE_BYTES - 1) / FUSED_TILE_BYTES;
   const uint64_t small_len = len < FUSED_SMALL_BELOW ? len : FUSED_SMALL_BELOW;
