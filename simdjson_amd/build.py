@@ -63,7 +63,7 @@ def build_plugin(force=False):
     deps = srcs + _csrc("plugin/mi355x_implementation.h") + [os.path.join(_paths.INCLUDE_DIR, "sjgpu.h")]
     if force or _stale(_paths.LIB_PLUGIN, deps):
         os.makedirs(_paths.LIB_DIR, exist_ok=True)
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared",
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DSIMDJSON_THREADS_ENABLED=1",
               "-I", os.path.join(_paths.REFERENCE_DIR, "include"), "-I", _paths.INCLUDE_DIR, "-I", _paths.CSRC_DIR,
               *srcs, "-o", _paths.LIB_PLUGIN, f"-L{_paths.LIB_DIR}", "-lsjgpu", "-Wl,-rpath,$ORIGIN"])
     return _paths.LIB_PLUGIN
@@ -79,10 +79,44 @@ def build_plugin_test(force=False):
     if not (os.path.exists(hdr) and os.path.exists(ref_obj) and os.path.exists(_paths.LIB_PLUGIN)):
         return out if os.path.exists(out) else None
     if force or _stale(out, [src, ref_obj, _paths.LIB_PLUGIN, _paths.LIB_CORPUS]):
-        _run(["g++", "-O2", "-std=c++17", "-I", os.path.join(_paths.REFERENCE_DIR, "include"),
+        _run(["g++", "-O2", "-std=c++17", "-DSIMDJSON_THREADS_ENABLED=1", "-I", os.path.join(_paths.REFERENCE_DIR, "include"),
               "-I", os.path.join(_paths.CSRC_DIR, "plugin"), "-I", _paths.INCLUDE_DIR, src, ref_obj, "-o", out,
               f"-L{_paths.LIB_DIR}", "-lsimdjson_mi355x", "-lsjgpu", "-lsjcorpus", "-lpthread", "-Wl,-rpath,$ORIGIN"])
     return out
+
+
+REFERENCE_TESTS = {  # reference test programs that need no external data files
+    "ref_unicode_tests": "tests/unicode_tests.cpp",
+    "ref_dom_document_stream_tests": "tests/dom/document_stream_tests.cpp",
+    "ref_dom_document_stream_fuzz_tests": "tests/dom/document_stream_fuzz_tests.cpp",
+    "ref_ondemand_document_stream_tests": "tests/ondemand/ondemand_document_stream_tests.cpp",
+    "ref_ondemand_document_stream_fuzz_tests": "tests/ondemand/ondemand_document_stream_fuzz_tests.cpp",
+}
+
+
+def build_reference_tests(force=False):
+    """The reference's OWN test programs, compiled in place from /root/reference/tests and linked with the
+    mi355x plug-in + an activator TU, so they exercise our backend unmodified.  Outputs simdjson_amd/lib/ref_*."""
+    ref = _paths.REFERENCE_DIR
+    ref_obj = os.path.join(_paths.ORACLE_OUT, "simdjson_ref.o")
+    act = os.path.join(_paths.REPO_ROOT, "tests", "plugin", "activate_mi355x.cpp")
+    built = []
+    for name, rel in REFERENCE_TESTS.items():
+        out = os.path.join(_paths.LIB_DIR, name)
+        src = os.path.join(ref, rel)
+        if not (os.path.exists(src) and os.path.exists(ref_obj) and os.path.exists(_paths.LIB_PLUGIN)):
+            if os.path.exists(out):
+                built.append(out)
+            continue
+        if force or _stale(out, [src, act, ref_obj, _paths.LIB_PLUGIN]):
+            _run(["g++", "-O1", "-std=c++17", "-w", "-DSIMDJSON_THREADS_ENABLED=1", "-I", os.path.join(ref, "include"), "-I", os.path.join(ref, "tests"),
+                  "-I", os.path.join(ref, "tests", "dom"), "-I", os.path.join(ref, "tests", "ondemand"),
+                  "-I", os.path.join(_paths.CSRC_DIR, "plugin"), "-I", _paths.INCLUDE_DIR,
+                  '-DSIMDJSON_BENCHMARK_DATA_DIR="' + os.path.join(ref, "jsonexamples") + '/"',
+                  src, act, ref_obj, "-o", out, f"-L{_paths.LIB_DIR}", "-lsimdjson_mi355x", "-lsjgpu", "-lpthread",
+                  "-Wl,-rpath,$ORIGIN"])
+        built.append(out)
+    return built
 
 
 def build_oracle():
@@ -95,6 +129,7 @@ def build_all(force=False):
     build_oracle()
     build_plugin(force)
     build_plugin_test(force)
+    build_reference_tests(force)
 
 
 if __name__ == "__main__":

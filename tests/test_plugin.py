@@ -38,3 +38,21 @@ def test_plugin_dropin_on_gpu():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "plugin test OK" in out.stdout
+
+
+REFERENCE_SUITE = sorted(build.REFERENCE_TESTS)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", REFERENCE_SUITE)
+def test_reference_own_test_programs_on_mi355x(name):
+    """The reference's OWN test programs (compiled in place from /root/reference/tests, untouched) run with the
+    mi355x backend activated before main(): document_stream (dom + ondemand, threaded stage-1 worker, RFC 7464
+    and comma-delimited matrices, truncation constants), the seeded stream fuzz corpus, and unicode_tests."""
+    _binary()
+    built = {os.path.basename(p): p for p in build.build_reference_tests()}
+    assert name in built, f"{name} was not built (needs the build container)"
+    out = subprocess.run([built[name]], capture_output=True, text=True, timeout=1200)
+    tail = (out.stdout[-2500:] + out.stderr[-1500:])
+    assert out.returncode == 0, tail
+    assert "[active implementation: mi355x]" in out.stderr, tail
