@@ -41,6 +41,9 @@ def test_plugin_dropin_on_gpu():
 
 
 REFERENCE_SUITE = sorted(build.REFERENCE_TESTS)
+# ~5.5 minutes on an MI355X box: tens of thousands of tiny stage-1 calls, each a PCIe round trip.  It passes
+# (round 1, twice); run it with SJGPU_SLOW_TESTS=1.  The other four take ~45 s together.
+SLOW = {"ref_dom_document_stream_tests"}
 
 
 @pytest.mark.gpu
@@ -49,6 +52,8 @@ def test_reference_own_test_programs_on_mi355x(name):
     """The reference's OWN test programs (compiled in place from /root/reference/tests, untouched) run with the
     mi355x backend activated before main(): document_stream (dom + ondemand, threaded stage-1 worker, RFC 7464
     and comma-delimited matrices, truncation constants), the seeded stream fuzz corpus, and unicode_tests."""
+    if name in SLOW and os.environ.get("SJGPU_SLOW_TESTS", "0") != "1":
+        pytest.skip("slow (set SJGPU_SLOW_TESTS=1)")
     _binary()
     built = {os.path.basename(p): p for p in build.build_reference_tests()}
     assert name in built, f"{name} was not built (needs the build container)"
