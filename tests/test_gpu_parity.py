@@ -198,6 +198,80 @@ def test_control_character_resolution(gpu, orc):
         assert_same_all(gpu, orc, body, tag=f"ctrl {c:#x} resolves segment 1", modes=(0, 3, 4))
 
 
+def _random_document(rng, target):
+    """Random JSON text (objects / arrays / strings with escapes and multi-byte UTF-8 / numbers / literals),
+    sometimes pretty-printed, sometimes minified, roughly `target` bytes."""
+    import json
+    words = ["a", "key", "\u00e9t\u00e9", "\u65e5\u672c\u8a9e", "\U0001f600", "q\"uote", "back\\slash", "tab\tnl\n", "x" * 70,
+             "\\" * 33, "{[,:]}", "\u0001ctrl", "", "\u2028", "~" * 130]
+
+    def value(depth):
+        r = rng.random()
+        if depth > 6 or r < 0.35:
+            k = rng.integers(0, 6)
+            return [None, True, False, int(rng.integers(-10**9, 10**9)), float(rng.random() * 1e6),
+                    " ".join(words[int(i)] for i in rng.integers(0, len(words), size=int(rng.integers(0, 6))))][int(k)]
+        if r < 0.65:
+            return [value(depth + 1) for _ in range(int(rng.integers(0, 8)))]
+        return {words[int(rng.integers(0, len(words)))] + str(i): value(depth + 1) for i in range(int(rng.integers(0, 8)))}
+
+    parts, size = [], 0
+    while size < target:
+        style = int(rng.integers(0, 3))
+        t = json.dumps(value(0), ensure_ascii=bool(rng.integers(0, 2)), indent=(None, 1, 4)[style],
+                       separators=(",", ":") if style == 0 else None)
+        parts.append(t)
+        size += len(t) + 1
+    return ("\n" if rng.integers(0, 2) else " ").join(parts).encode("utf-8")
+
+
+def test_differential_fuzz_structured_documents(gpu, orc):
+    """Cross-implementation differential fuzzing in the spirit of the reference's fuzz/fuzz_implementations.cpp
+    and fuzz/fuzz_minifyimpl.cpp: random structured documents, then random byte-level mutations, GPU vs oracle."""
+    rng = np.random.default_rng(20260921)
+    poison = np.frombuffer(b'"\\\\"\x00\x01\x1f\n\t{}[],: \xff\xc0\xe2\x82\xf0\x9f\x80\xed\xa0', dtype=np.uint8)
+    for it in range(60):
+        target = int(rng.choice([200, 5_000, 70_000, 300_000]))
+        doc = np.frombuffer(_random_document(rng, target), dtype=np.uint8).copy()
+        assert_same_all(gpu, orc, doc, tag=f"fuzz {it} pristine", modes=(0, 1, 2))
+        for mut in range(3):
+            b = doc.copy()
+            k = int(rng.integers(1, 6))
+            pos = rng.integers(0, len(b), size=k)
+            b[pos] = poison[rng.integers(0, len(poison), size=k)]
+            if mut == 2:  # truncate as a stream window would
+                b = b[: int(rng.integers(1, len(b) + 1))]
+            assert_same_all(gpu, orc, b, tag=f"fuzz {it} mutation {mut} at {pos.tolist()}", modes=(0, 1, 2, 5, 6))
+
+
+def test_two_contexts_on_two_threads(orc):
+    """One context per parser object, usable from any thread (document_stream's stage-1 worker pattern)."""
+    import threading
+    docs = [corpus.twitter_like(400_000, 50 + i)[0] for i in range(2)]
+    want = [orc.stage1(d, 0) for d in docs]
+    errors = []
+
+    def worker(i):
+        try:
+            p = capi.DomParserImplementation(1 << 20)
+            for _ in range(40):
+                err = p.stage1(docs[i], 0)
+                n = p.n_structural_indexes
+                if (err, n) != want[i][:2] or not np.array_equal(p.structural_indexes[: n + 3], want[i][2]):
+                    errors.append((i, err, n))
+                    break
+            p.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_streaming_modes_on_bulk(gpu, orc):
     a, _ = corpus.amazon_ndjson(3 << 20, 5)
     cut = a[: len(a) - 777]  # ends inside a line
