@@ -153,7 +153,8 @@ def main():
             "config": {"workload": f"{args.workload} {L} B per GPU (seed 1000+rank), op={args.op}, regular mode, "
                                    f"device-resident input and output, {args.pipeline} pipeline", "bytes_per_gpu": L, "units_per_gpu": units,
                        "structurals": n if args.op == "stage1" else None, "out_bytes": out_len if args.op == "minify" else None,
-                       "parallelism": f"{world} independent shard(s), one rank per GPU, no data-path collective"},
+                       "parallelism": f"{world} independent shard(s), one rank per GPU, no data-path collective",
+                       "library": os.path.basename(capi._paths.LIB_SJGPU)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg, "gpu_ms_per_step": round(gpu_ms, 4),

@@ -10,7 +10,7 @@ ORACLE_DIR = os.path.join(REPO_ROOT, "oracle")
 ORACLE_OUT = os.path.join(ORACLE_DIR, "_ref")
 REFERENCE_DIR = os.environ.get("SIMDJSON_REFERENCE", "/root/reference")
 
-LIB_SJGPU = os.path.join(LIB_DIR, "libsjgpu.so")          # HIP kernels + C-ABI (the product)
+LIB_SJGPU = os.environ.get("SJGPU_LIB") or os.path.join(LIB_DIR, "libsjgpu.so")  # HIP kernels + C-ABI (the product)
 LIB_CORPUS = os.path.join(LIB_DIR, "libsjcorpus.so")      # synthetic corpora (host tooling)
 LIB_PLUGIN = os.path.join(LIB_DIR, "libsimdjson_mi355x.so")  # simdjson::implementation shim (needs reference headers to build)
 LIB_ORACLE = os.path.join(ORACLE_OUT, "libsjoracle.so")   # test infrastructure

@@ -196,7 +196,8 @@ __device__ __forceinline__ chunk_masks scan_chunk(const u32 (&w)[16], wave_carry
 // output: bitmap -> ascending u32 offsets, through a per-wave LDS window, leaving as 16-byte stores
 // =====================================================================================================
 constexpr u32 EMIT_WINDOW = 1536;              // offsets per window (multiple of 4); denser chunks take several rounds
-constexpr u32 EMIT_STAGE_WORDS = EMIT_WINDOW + 4; // + skew so that LDS slot and destination agree modulo 16 bytes
+constexpr u32 EMIT_DUMP_SLOT = EMIT_WINDOW + 4;   // where empty extraction chains park their (ignored) stores
+constexpr u32 EMIT_STAGE_WORDS = EMIT_WINDOW + 8; // + skew so that LDS slot and destination agree modulo 16 bytes, + dump
 
 // One chunk: lane owns `structural` (64 bits) for the block at byte offset pos32; the wave appends the
 // set positions to idx[base...], advancing base.  idx must be 16-byte aligned.
@@ -216,6 +217,34 @@ __device__ __forceinline__ void emit_indices(u64 structural, u32 pos32, u32 lane
   const u32 skew = base & 3u;
 #pragma unroll 1
   for (u32 w0 = 0; w0 < total; w0 += EMIT_WINDOW) { // wave-uniform; one round unless the chunk is very dense
+    if (total <= EMIT_WINDOW) {
+      // Common case, everything fits one window: extract the low and the high half of every lane's mask in the
+      // SAME uniform loop (two independent ffs/clear chains per lane, trip count = the wave's largest half
+      // popcount).  A chain that has run dry keeps rewriting its last slot with the same value, a chain that
+      // was empty from the start writes to a dump slot, so there is no divergent control flow at all.
+      const u32 nlo = u32(__popc(lo)), nhi = u32(__popc(hi));
+      u32 mx = nlo > nhi ? nlo : nhi;
+      mx = max(mx, u32(__builtin_amdgcn_update_dpp(0, int(mx), 0x111, 0xf, 0xf, false)));
+      mx = max(mx, u32(__builtin_amdgcn_update_dpp(0, int(mx), 0x112, 0xf, 0xf, false)));
+      mx = max(mx, u32(__builtin_amdgcn_update_dpp(0, int(mx), 0x114, 0xf, 0xf, false)));
+      mx = max(mx, u32(__builtin_amdgcn_update_dpp(0, int(mx), 0x118, 0xf, 0xf, false)));
+      mx = max(mx, u32(__builtin_amdgcn_update_dpp(0, int(mx), 0x142, 0xa, 0xf, false)));
+      mx = max(mx, u32(__builtin_amdgcn_update_dpp(0, int(mx), 0x143, 0xc, 0xf, false)));
+      const u32 trips = readlane(mx, 63);
+      u32 a_lo = nlo ? (off + skew) : EMIT_DUMP_SLOT, a_hi = nhi ? (off + skew + nlo) : EMIT_DUMP_SLOT;
+      u32 v_lo = 0, v_hi = 0;
+#pragma unroll 2
+      for (u32 t = 0; t < trips; t++) {
+        if (lo) { v_lo = pos32 + u32(__ffs(int(lo)) - 1); }
+        if (hi) { v_hi = pos32 + 32u + u32(__ffs(int(hi)) - 1); }
+        stage[a_lo] = v_lo;
+        stage[a_hi] = v_hi;
+        lo &= lo - 1;
+        hi &= hi - 1;
+        a_lo += lo ? 1u : 0u; // stay on the last slot once the chain is exhausted
+        a_hi += hi ? 1u : 0u;
+      }
+    } else {
     const u32 lim = w0 + EMIT_WINDOW;
     const u32 rel = skew - w0; // stage slot of element e is e + rel (mod 2^32; e >= w0 whenever we store)
     while (lo && off < lim) {
@@ -229,6 +258,7 @@ __device__ __forceinline__ void emit_indices(u64 structural, u32 pos32, u32 lane
         hi &= hi - 1;
         off++;
       }
+    }
     }
     wave_lds_fence();
     const u32 here = min(EMIT_WINDOW, total - w0);

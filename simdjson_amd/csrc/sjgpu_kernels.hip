@@ -251,12 +251,23 @@ __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask
   u32 base = pf.base;
   const u64 flip = pf.in_string ? ~0ull : 0ull;
   bool overflow = false;
+  // all four chunks' masks are requested up front (8 bytes per lane each): one load latency per segment
+  // instead of one per chunk
+  u64 m0[SEG_CHUNKS], m1[SEG_CHUNKS];
+#pragma unroll
+  for (u32 c = 0; c < SEG_CHUNKS; c++) {
+    const u64 pos = seg_start + u64(c) * CHUNK_BYTES + u64(lane) * BLOCK_BYTES;
+    const bool live = seg_start + u64(c) * CHUNK_BYTES < len;
+    m0[c] = live ? mask0[pos / BLOCK_BYTES] : 0ull;
+    m1[c] = (live && !resolved) ? mask1[pos / BLOCK_BYTES] : 0ull;
+  }
+#pragma unroll
   for (u32 c = 0; c < SEG_CHUNKS; c++) {
     const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
     if (cstart >= len) { break; }
     const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
-    u64 structural = mask0[pos / BLOCK_BYTES];
-    if (!resolved) { structural &= ~(mask1[pos / BLOCK_BYTES] ^ flip); }
+    u64 structural = m0[c];
+    if (!resolved) { structural &= ~(m1[c] ^ flip); }
     emit_indices(structural, u32(pos), lane, idx, idx_words, base, stage, overflow);
   }
   if (__ballot(overflow) && lane == 0) { atomicOr(&result->flags, SJGPU_F_IDX_OVERFLOW); }
