@@ -45,13 +45,14 @@ def build_corpus(force=False):
 
 
 def build_sjgpu(force=False):
+    out = os.path.join(_paths.LIB_DIR, "libsjgpu.so")  # always the in-tree default, never an SJGPU_LIB override
     srcs = _csrc("sjgpu_kernels.hip", "sjgpu_fused.hip", "sjgpu_capi.hip", "stage1_finish.cpp")
     deps = srcs + _csrc("sj_block.h", "sjgpu_internal.h", "sjgpu_device.h") + [os.path.join(_paths.INCLUDE_DIR, "sjgpu.h")]
-    if force or _stale(_paths.LIB_SJGPU, deps):
+    if force or _stale(out, deps):
         os.makedirs(_paths.LIB_DIR, exist_ok=True)
         _run([HIPCC, f"--offload-arch={GFX_ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-              "-I", _paths.INCLUDE_DIR, "-I", _paths.CSRC_DIR, *srcs, "-o", _paths.LIB_SJGPU])
-    return _paths.LIB_SJGPU
+              "-I", _paths.INCLUDE_DIR, "-I", _paths.CSRC_DIR, *srcs, "-o", out])
+    return out
 
 
 def build_plugin(force=False):

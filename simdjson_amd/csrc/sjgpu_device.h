@@ -106,15 +106,27 @@ __device__ __forceinline__ u32 backslash_run_parity(const u8 *__restrict__ buf, 
 //   e = escaped[start]            = parity of the backslash run ending at start-1
 //   p = nonquote_scalar[start-1]  = scalar(b) unless b is '"', then "that quote is escaped"
 //   utf8 = demands of bytes start-3..start-1
-__device__ __forceinline__ wave_carry segment_carry_in(const u8 *__restrict__ buf, u64 start, u32 lane) {
+// Split in two so that the ONE byte load it normally needs can be issued before the segment's first chunk is
+// requested and consumed after: the two HBM latencies overlap instead of adding up.
+__device__ __forceinline__ u32 lookback_issue(const u8 *__restrict__ buf, u64 start, u32 lane) {
+  return (start > lane) ? u32(buf[start - 1 - lane]) : 0x20u; // lane i holds byte start-1-i (0x20 in front of the input)
+}
+// parity of the backslash run ending at byte start-1-skip, from m = ballot(lane's look-back byte is a backslash)
+__device__ __forceinline__ u32 run_parity_from_mask(const u8 *__restrict__ buf, u64 start, u32 lane, u64 m, u32 skip) {
+  const u64 inv = ~(m >> skip) & (~0ull >> skip); // bit i clear <=> byte start-1-skip-i is a backslash
+  if (inv) { return ctz64(inv) & 1u; }
+  // every byte we hold is a backslash (so start >= 64): keep walking from byte start-65
+  return ((64u - skip) + backslash_run_parity(buf, start - 64, lane)) & 1u;
+}
+__device__ __forceinline__ wave_carry segment_carry_from(const u8 *__restrict__ buf, u64 start, u32 lane, u32 byte) {
   wave_carry c{0u, 0u, 0u, 0u};
   if (start == 0) { return c; }
-  const u32 byte = (start > lane) ? u32(buf[start - 1 - lane]) : 0x20u;
   const u32 b1 = readlane(byte, 0), b2 = readlane(byte, 1), b3 = readlane(byte, 2);
   c.utf8 = utf8_carry_from_bytes(b3, b2, b1);
-  c.e = backslash_run_parity(buf, start, lane);
+  const u64 m = __ballot(byte == 0x5Cu);
+  c.e = run_parity_from_mask(buf, start, lane, m, 0);
   if (b1 == 0x22u) {
-    c.p = backslash_run_parity(buf, start - 1, lane);
+    c.p = run_parity_from_mask(buf, start, lane, m, 1);
   } else {
     const bool ws = b1 == 0x20u || b1 == 0x09u || b1 == 0x0Au || b1 == 0x0Du;
     const u32 cur = b1 | 0x20u;
@@ -122,6 +134,9 @@ __device__ __forceinline__ wave_carry segment_carry_in(const u8 *__restrict__ bu
     c.p = (ws || op) ? 0u : 1u;
   }
   return c;
+}
+__device__ __forceinline__ wave_carry segment_carry_in(const u8 *__restrict__ buf, u64 start, u32 lane) {
+  return segment_carry_from(buf, start, lane, lookback_issue(buf, start, lane));
 }
 
 // ---- one chunk (64 blocks) through the scanner -----------------------------------------------------------

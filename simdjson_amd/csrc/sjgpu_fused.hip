@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
     bool f_ci = false, f_co = false, f_ue = false; // wave-uniform error facts
     u32 parity = 0;
     if (wave_start < len) { // wave-uniform
-      wave_carry wc = segment_carry_in(buf, wave_start, lane);
+      const u32 lookback = lookback_issue(buf, wave_start, lane); // consumed after chunk 0 has been requested
+      wave_carry wc{0u, 0u, 0u, 0u};
 #pragma unroll 1
       for (u32 c = 0; c < FUSED_WAVE_CHUNKS; c++) {
         const u64 cstart = wave_start + u64(c) * CHUNK_BYTES;
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
           u32 w[16];
           if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
           else { load_block(buf, pos, len, w); }
+          if (c == 0) { wc = segment_carry_from(buf, wave_start, lane, lookback); }
           if (OP == 0) {
             const chunk_masks m = scan_chunk<true, true>(w, wc, lane);
             a = m.cand;

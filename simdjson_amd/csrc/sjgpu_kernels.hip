@@ -38,13 +38,14 @@ __global__ __launch_bounds__(64) void k_stage1_summarize(const u8 *__restrict__ 
   const u32 lane = lane_id();
   const u32 seg = blockIdx.x;
   const u64 seg_start = u64(seg) * SEG_BYTES;
-  wave_carry wc = segment_carry_in(buf, seg_start, lane);
+  const u64 lane_off = u64(lane) * BLOCK_BYTES;
+  const u32 lookback = lookback_issue(buf, seg_start, lane); // consumed after chunk 0 has been requested
+  wave_carry wc{0u, 0u, 0u, 0u};
   u32 n_a = 0, n_b = 0; // resolved: n_a = final count; else n_a = candidates, n_b = candidates in a string tail
   u64 ctrl_a = 0, ctrl_b = 0, uerr = 0;
   bool resolved = false;
   u32 derived = 0;
   u64 flip = 0;
-  const u64 lane_off = u64(lane) * BLOCK_BYTES;
   for (u32 c = 0; c < SEG_CHUNKS; c++) {
     const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
     if (cstart >= len) { break; }
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(64) void k_stage1_summarize(const u8 *__restrict__ 
     u32 w[16];
     if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); } // interior chunk: branch-free loads
     else { load_block(buf, pos, len, w); }
+    if (c == 0) { wc = segment_carry_from(buf, seg_start, lane, lookback); } // its latency hid behind the loads above
     const chunk_masks m = scan_chunk<true, true>(w, wc, lane);
     if (c == 0) {
       const u64 cm = __ballot(m.ctrl != 0);
@@ -246,13 +248,9 @@ __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask
   const u32 lane = lane_id();
   const u32 seg = blockIdx.x;
   const u64 seg_start = u64(seg) * SEG_BYTES;
-  const seg_prefix pf = segment_prefix(summ, gpref, seg, lane);
+  // Independent loads first, consumers later: the four chunks' masks (8 bytes per lane each) are requested before
+  // the group-prefix fold, so the segment pays ONE round trip to HBM, not one per chunk plus one for the prefix.
   const bool resolved = (summ[seg].flags & SF_RESOLVED) != 0; // masks are already final
-  u32 base = pf.base;
-  const u64 flip = pf.in_string ? ~0ull : 0ull;
-  bool overflow = false;
-  // all four chunks' masks are requested up front (8 bytes per lane each): one load latency per segment
-  // instead of one per chunk
   u64 m0[SEG_CHUNKS], m1[SEG_CHUNKS];
 #pragma unroll
   for (u32 c = 0; c < SEG_CHUNKS; c++) {
@@ -261,6 +259,10 @@ __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask
     m0[c] = live ? mask0[pos / BLOCK_BYTES] : 0ull;
     m1[c] = (live && !resolved) ? mask1[pos / BLOCK_BYTES] : 0ull;
   }
+  const seg_prefix pf = segment_prefix(summ, gpref, seg, lane);
+  u32 base = pf.base;
+  const u64 flip = pf.in_string ? ~0ull : 0ull;
+  bool overflow = false;
 #pragma unroll
   for (u32 c = 0; c < SEG_CHUNKS; c++) {
     const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
@@ -280,14 +282,17 @@ __global__ __launch_bounds__(64) void k_minify_summarize(const u8 *__restrict__ 
   const u32 lane = lane_id();
   const u32 seg = blockIdx.x;
   const u64 seg_start = u64(seg) * SEG_BYTES;
-  wave_carry wc = segment_carry_in(buf, seg_start, lane);
+  const u32 lookback = lookback_issue(buf, seg_start, lane);
+  wave_carry wc{0u, 0u, 0u, 0u};
   u32 kept_out = 0, kept_in = 0;
   for (u32 c = 0; c < SEG_CHUNKS; c++) {
     const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
     if (cstart >= len) { break; }
     const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
     u32 w[16];
-    load_block(buf, pos, len, w);
+    if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
+    else { load_block(buf, pos, len, w); }
+    if (c == 0) { wc = segment_carry_from(buf, seg_start, lane, lookback); }
     const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
     const u64 valid = valid_mask(pos, len);
     kept_out += u32(popc64(valid & ~(m.ws & ~m.in_string))); // dropped: whitespace outside strings (json_scanner.h:46)
@@ -313,16 +318,21 @@ __global__ __launch_bounds__(64) void k_minify_emit(const u8 *__restrict__ buf, 
   clear_minify_stage(stage, lane);
   const u32 seg = blockIdx.x;
   const u64 seg_start = u64(seg) * SEG_BYTES;
+  const u32 lookback = lookback_issue(buf, seg_start, lane);
   const seg_prefix pf = segment_prefix(summ, gpref, seg, lane);
-  wave_carry wc = segment_carry_in(buf, seg_start, lane);
-  wc.s = pf.in_string; // absolute from here on
+  wave_carry wc{0u, 0u, 0u, 0u};
   u32 base = pf.base;
   for (u32 c = 0; c < SEG_CHUNKS; c++) {
     const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
     if (cstart >= len) { break; }
     const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
     u32 w[16];
-    load_block(buf, pos, len, w);
+    if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
+    else { load_block(buf, pos, len, w); }
+    if (c == 0) {
+      wc = segment_carry_from(buf, seg_start, lane, lookback);
+      wc.s = pf.in_string; // absolute from here on
+    }
     const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
     emit_bytes(w, valid_mask(pos, len) & ~(m.ws & ~m.in_string), lane, dst, base, stage, lut);
   }
