@@ -210,14 +210,19 @@ __device__ __forceinline__ chunk_masks scan_chunk(const u32 (&w)[16], wave_carry
 // =====================================================================================================
 // output: bitmap -> ascending u32 offsets, through a per-wave LDS window, leaving as 16-byte stores
 // =====================================================================================================
-constexpr u32 EMIT_WINDOW = 1536;              // offsets per window (multiple of 4); denser chunks take several rounds
-constexpr u32 EMIT_DUMP_SLOT = EMIT_WINDOW + 4;   // where empty extraction chains park their (ignored) stores
-constexpr u32 EMIT_STAGE_WORDS = EMIT_WINDOW + 8; // + skew so that LDS slot and destination agree modulo 16 bytes, + dump
+constexpr u32 EMIT_WINDOW = 1536; // offsets per window (multiple of 4); denser chunks take several rounds
+// LDS words a window needs: + skew so that LDS slot and destination agree modulo 16 bytes, + a dump slot where
+// empty extraction chains park their (ignored) stores
+constexpr u32 emit_stage_words(u32 window) { return window + 8; }
+constexpr u32 EMIT_STAGE_WORDS = emit_stage_words(EMIT_WINDOW);
 
 // One chunk: lane owns `structural` (64 bits) for the block at byte offset pos32; the wave appends the
 // set positions to idx[base...], advancing base.  idx must be 16-byte aligned.
+template <u32 WINDOW = EMIT_WINDOW>
 __device__ __forceinline__ void emit_indices(u64 structural, u32 pos32, u32 lane, u32 *__restrict__ idx, u64 idx_words,
                                              u32 &base, u32 *__restrict__ stage, bool &overflow) {
+  constexpr u32 EMIT_WINDOW = WINDOW; // shadows the default inside this function
+  constexpr u32 EMIT_DUMP_SLOT = WINDOW + 4;
   u32 lo = u32(structural), hi = u32(structural >> 32);
   const u32 cnt = u32(__popc(lo) + __popc(hi));
   const u32 incl = wave_incl_scan(cnt);

@@ -24,6 +24,8 @@
 //     register indexing, no LDS), offsets leave through the per-wave LDS window as 16-byte stores.
 #include "sjgpu_device.h"
 
+#include <cstdlib>
+
 namespace sjgpu {
 namespace {
 
@@ -294,6 +296,207 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
 #undef SJ_STAMP
 }
 
+// =====================================================================================================
+// Pipelined variant (large inputs): a workgroup defers the look-back + emission of tile T(i-1) until it has
+// scanned and published tile T(i).  The in-kernel trace of the plain kernel showed 29 % of a tile's residency
+// spent waiting for the slowest of its ~150 predecessors to publish an aggregate; with one whole tile scan
+// (~15 us) between "publish my aggregate" and "ask for my prefix" that wait is over before it starts.
+// The pending tile's masks wait in LDS (16 KiB per workgroup), the tile being scanned uses the register FIFO.
+// Progress: a workgroup never waits before it has published the aggregate of every tile it holds, so every
+// wait is on an aggregate that some running workgroup will publish without waiting on anyone.
+// =====================================================================================================
+constexpr u32 PIPE_WINDOW = 1280; // 4 x 5 KiB of emission windows + 16 KiB of pending masks -> 4 workgroups per CU
+constexpr u32 NO_TILE = 0xFFFFFFFFu;
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc,
+                                                         u32 *__restrict__ ticket, u32 ntiles, void *__restrict__ out,
+                                                         u64 out_words, scan_result_dev *__restrict__ result) {
+  constexpr u32 WC = FUSED_WAVE_CHUNKS;
+  constexpr u32 STAGE_WORDS = (OP == 0) ? emit_stage_words(PIPE_WINDOW) : (MINIFY_STAGE_BYTES / 4);
+  constexpr u32 WAVE_BYTES = WC * CHUNK_BYTES;
+  __shared__ u32 sh_tile;
+  __shared__ u32 sh_wave[2][FUSED_WAVES][4]; // [iteration parity][wave]: parity, count_if_out, count_if_in, flags
+  __shared__ u32 sh_agg[2][4];               // tile aggregate of the same two tiles (tq, tout, tin)
+  __shared__ u32 sh_prefix[4];               // S, B, ok of the tile being emitted
+  __shared__ u64 sh_mask_a[FUSED_WAVES][WC][64], sh_mask_b[FUSED_WAVES][WC][64]; // the pending tile's masks
+  __shared__ __attribute__((aligned(16))) u32 sh_stage[FUSED_WAVES][STAGE_WORDS];
+  __shared__ u32 sh_lut[MINIFY_LUT_WORDS];
+
+  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  if (OP == 1) {
+    if (wave == 0) { init_compaction_lut(sh_lut, lane); }
+    clear_minify_stage(reinterpret_cast<u8 *>(sh_stage[wave]), lane);
+  }
+  u32 pend_tile = NO_TILE; // workgroup-uniform
+  for (u32 iter = 0;; iter++) {
+    const u32 cur = iter & 1u;
+    if (threadIdx.x == 0) { sh_tile = atomicAdd(ticket, 1u); }
+    __syncthreads();
+    const u32 tile = sh_tile;
+    const bool have = tile < ntiles;
+    const bool pend = pend_tile != NO_TILE;
+    if (!have && !pend) { break; }
+
+    // ---- scan the new tile into the register FIFO ------------------------------------------------------------
+    u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0; // slot 3 = oldest chunk
+    if (have) {
+      const u64 wave_start = u64(tile) * FUSED_TILE_BYTES + u64(wave) * WAVE_BYTES;
+      u32 n_out = 0, n_in = 0, parity = 0;
+      bool f_ci = false, f_co = false, f_ue = false;
+      if (wave_start < len) {
+        const u32 lookback = lookback_issue(buf, wave_start, lane);
+        wave_carry wc{0u, 0u, 0u, 0u};
+#pragma unroll 1
+        for (u32 c = 0; c < WC; c++) {
+          const u64 cstart = wave_start + u64(c) * CHUNK_BYTES;
+          u64 a = 0, b = 0;
+          if (cstart < len) {
+            const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
+            u32 w[16];
+            if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
+            else { load_block(buf, pos, len, w); }
+            if (c == 0) { wc = segment_carry_from(buf, wave_start, lane, lookback); }
+            if (OP == 0) {
+              const chunk_masks m = scan_chunk<true, true>(w, wc, lane);
+              a = m.cand;
+              b = m.string_tail;
+              n_out += u32(popc64(a & ~b));
+              n_in += u32(popc64(a & b));
+              f_ci |= __ballot((m.ctrl & m.in_string) != 0) != 0;
+              f_co |= __ballot((m.ctrl & ~m.in_string) != 0) != 0;
+              f_ue |= __ballot(m.utf8_err != 0) != 0;
+            } else {
+              const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
+              const u64 valid = valid_mask(pos, len);
+              a = valid & m.ws;
+              b = m.in_string;
+              n_out += u32(popc64(valid & ~(a & ~b)));
+              n_in += u32(popc64(valid & ~(a & b)));
+            }
+          }
+          a3 = a2; a2 = a1; a1 = a0; a0 = a;
+          b3 = b2; b2 = b1; b1 = b0; b0 = b;
+        }
+        parity = wc.s;
+        if (OP == 0 && wave_start + WAVE_BYTES >= len && (wc.utf8 & UTF8_CARRY_OPEN)) { f_ue = true; }
+      }
+      const u32 t_out = wave_sum(n_out), t_in = wave_sum(n_in);
+      u32 f = 0;
+      if (f_ci) { f |= WF_CTRL_IF_OUT; }
+      if (f_co) { f |= WF_CTRL_IF_IN; }
+      if (f_ue) { f |= WF_UTF8; }
+      if (lane == 0) {
+        sh_wave[cur][wave][0] = parity;
+        sh_wave[cur][wave][1] = t_out;
+        sh_wave[cur][wave][2] = t_in;
+        sh_wave[cur][wave][3] = f;
+      }
+    }
+    __syncthreads();
+
+    // ---- wave 0: publish the new tile's aggregate, then resolve the PENDING tile's prefix -------------------------
+    if (wave == 0) {
+      if (have) {
+        u32 tq = 0, tout = 0, tin = 0;
+#pragma unroll
+        for (u32 v = 0; v < FUSED_WAVES; v++) {
+          const u32 q = sh_wave[cur][v][0], o = sh_wave[cur][v][1], i = sh_wave[cur][v][2];
+          const u32 no = tout + (tq ? i : o), ni = tin + (tq ? o : i);
+          tout = no;
+          tin = ni;
+          tq ^= q;
+        }
+        if (lane == 0) {
+          desc_store(desc + tile, make_agg(tq, tout, tin));
+          sh_agg[cur][0] = tq;
+          sh_agg[cur][1] = tout;
+          sh_agg[cur][2] = tin;
+        }
+      }
+      if (pend) {
+        const u32 tq = sh_agg[cur ^ 1u][0], tout = sh_agg[cur ^ 1u][1], tin = sh_agg[cur ^ 1u][2];
+        u32 S = 0, B = 0;
+        const bool ok = lookback(desc, pend_tile, lane, S, B);
+        if (lane == 0) {
+          if (ok) {
+            const u32 total = B + (S ? tin : tout), s_end = S ^ tq;
+            desc_store(desc + pend_tile, make_incl(s_end, total));
+            if (pend_tile == ntiles - 1) { // the last tile knows the totals
+              u32 f = s_end ? SJGPU_F_UNCLOSED_STRING : 0u;
+              if (OP == 0) {
+                u32 *idx = static_cast<u32 *>(out);
+                if (u64(total) + 3 <= out_words) { // json_structural_indexer.h:284-286
+                  idx[total] = u32(len);
+                  idx[total + 1] = u32(len);
+                  idx[total + 2] = 0;
+                } else {
+                  f |= SJGPU_F_IDX_OVERFLOW;
+                }
+                result->n = total;
+              } else {
+                result->out_len = s_end ? 0ull : u64(total);
+              }
+              if (f) { atomicOr(&result->flags, f); }
+            }
+          } else {
+            desc_store(desc + pend_tile, ST_POISON << 62);
+            atomicOr(&result->flags, SJGPU_F_INTERNAL);
+          }
+          sh_prefix[0] = S;
+          sh_prefix[1] = B;
+          sh_prefix[2] = ok ? 1u : 0u;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- every wave: emit its share of the pending tile from the LDS masks -----------------------------------------
+    if (pend && sh_prefix[2] != 0u) {
+      const u64 wave_start = u64(pend_tile) * FUSED_TILE_BYTES + u64(wave) * WAVE_BYTES;
+      u32 s = sh_prefix[0], base = sh_prefix[1];
+      for (u32 v = 0; v < wave; v++) {
+        base += s ? sh_wave[cur ^ 1u][v][2] : sh_wave[cur ^ 1u][v][1];
+        s ^= sh_wave[cur ^ 1u][v][0];
+      }
+      if (wave_start < len) {
+        const u32 f = sh_wave[cur ^ 1u][wave][3];
+        u32 g = 0;
+        if (f & (s ? WF_CTRL_IF_IN : WF_CTRL_IF_OUT)) { g |= SJGPU_F_UNESCAPED_CTRL; }
+        if (f & WF_UTF8) { g |= SJGPU_F_UTF8_ERROR; }
+        if (g && lane == 0) { atomicOr(&result->flags, g); }
+        const u64 flip = s ? ~0ull : 0ull;
+        bool overflow = false;
+#pragma unroll 1
+        for (u32 c = 0; c < WC; c++) {
+          const u64 cstart = wave_start + u64(c) * CHUNK_BYTES;
+          if (cstart >= len) { break; }
+          const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
+          const u64 a = sh_mask_a[wave][c][lane], b = sh_mask_b[wave][c][lane];
+          if (OP == 0) {
+            emit_indices<PIPE_WINDOW>(a & ~(b ^ flip), u32(pos), lane, static_cast<u32 *>(out), out_words, base, sh_stage[wave],
+                                      overflow);
+          } else {
+            u32 w[16];
+            load_block(buf, pos, len, w);
+            emit_bytes(w, valid_mask(pos, len) & ~(a & ~(b ^ flip)), lane, static_cast<u8 *>(out), base,
+                       reinterpret_cast<u8 *>(sh_stage[wave]), sh_lut);
+          }
+        }
+        if (OP == 0 && __ballot(overflow) && lane == 0) { atomicOr(&result->flags, SJGPU_F_IDX_OVERFLOW); }
+      }
+    }
+    // ---- the tile scanned in this iteration becomes the pending one: park its masks in (this wave's rows of) LDS ----
+    if (have) {
+      sh_mask_a[wave][0][lane] = a3; sh_mask_b[wave][0][lane] = b3;
+      sh_mask_a[wave][1][lane] = a2; sh_mask_b[wave][1][lane] = b2;
+      sh_mask_a[wave][2][lane] = a1; sh_mask_b[wave][2][lane] = b1;
+      sh_mask_a[wave][3][lane] = a0; sh_mask_b[wave][3][lane] = b0;
+    }
+    pend_tile = have ? tile : NO_TILE;
+  }
+}
+
 } // namespace
 
 // ---- launchers ----------------------------------------------------------------------------------------
@@ -336,10 +539,32 @@ static void launch_fused_wc(int op, const uint8_t *buf, uint64_t len, uint64_t *
 static void launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *desc, void *out, uint64_t out_words,
                          scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev,
                          uint64_t *trace = nullptr, uint32_t trace_tiles = 0) {
+  static const bool plain = std::getenv("SJGPU_FUSED_PLAIN") != nullptr; // A/B switch: the non-pipelined large-input kernel
   if (len <= FUSED_SMALL_BELOW && !trace) {
     launch_fused_wc<1>(op, buf, len, desc, out, out_words, result, max_workgroups, stream, ev, trace, trace_tiles);
-  } else {
+  } else if (trace || plain) {
     launch_fused_wc<FUSED_WAVE_CHUNKS>(op, buf, len, desc, out, out_words, result, max_workgroups, stream, ev, trace, trace_tiles);
+  } else {
+    const u32 ntiles = u32((len + FUSED_TILE_BYTES - 1) / FUSED_TILE_BYTES);
+    u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles);
+    if (reinterpret_cast<uint64_t *>(result + 1) == desc) {
+      (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev) + (size_t(ntiles) + 1) * sizeof(u64), stream);
+    } else {
+      (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
+      (void)hipMemsetAsync(desc, 0, (size_t(ntiles) + 1) * sizeof(u64), stream);
+    }
+    // half as many workgroups as tiles at most: every workgroup should own >= 2 tiles for the deferral to work
+    const u32 cap = (ntiles + 1) / 2;
+    const u32 grid = cap < max_workgroups ? cap : max_workgroups;
+    mark(ev, 0, stream);
+    if (op == 0) {
+      hipLaunchKernelGGL(k_fused_pipelined<0>, dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result);
+    } else {
+      hipLaunchKernelGGL(k_fused_pipelined<1>, dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result);
+    }
+    mark(ev, 1, stream);
+    mark(ev, 2, stream);
+    mark(ev, 3, stream);
   }
 }
 
