@@ -48,55 +48,72 @@ __device__ __forceinline__ void desc_store(u64 *p, u64 v) { __hip_atomic_store(p
 
 // Wave-wide look-back for tile `tile` (all 64 lanes of ONE wave call this).  On success S = in-string at
 // the tile start, B = output cursor at the tile start.
-__device__ __forceinline__ bool lookback(const u64 *desc, u32 tile, u32 lane, u32 &S, u32 &B) {
-  // F = composition of the aggregates of tiles [end, tile): maps the state at `end` to (parity flip, count)
-  u32 fq = 0, fout = 0, fin = 0;
-  long long end = tile;
+// State of a walk: F = composition of the aggregates of tiles [end, tile): maps the state at `end` to
+// (parity flip, count).
+struct lookback_state {
+  u32 fq, fout, fin;
+  long long end;
+};
+__device__ __forceinline__ void lookback_load(const u64 *desc, long long end, u32 lane, u64 (&d)[LOOKBACK_LOADS]) {
+#pragma unroll
+  for (u32 w = 0; w < LOOKBACK_LOADS; w++) {
+    const long long t = end - 1 - (long long)(w * 64 + lane);
+    d[w] = (t >= 0) ? desc_load(desc + t) : make_incl(0, 0); // in front of tile 0: outside strings, cursor 0
+  }
+}
+// 1 = finished (S, B valid), 0 = a needed aggregate is not published yet (reload from st.end), -1 = poisoned chain
+__device__ __forceinline__ int lookback_consume(const u64 (&d)[LOOKBACK_LOADS], lookback_state &st, u32 lane, u32 &S, u32 &B) {
+#pragma unroll
+  for (u32 w = 0; w < LOOKBACK_LOADS; w++) {
+    const u32 status = u32(d[w] >> 62);
+    const u64 incl = __ballot(status == ST_INCL), valid = __ballot(status != 0), poison = __ballot(status == ST_POISON);
+    const u32 k = incl ? ctz64(incl) : 64u;                       // nearest inclusive predecessor in this window
+    const u64 below = (k == 64u) ? ~0ull : ((1ull << k) - 1ull);  // lanes nearer than it: must be aggregates
+    const u64 upto = (k == 64u) ? ~0ull : (below | (1ull << k));
+    if (poison & upto) { return -1; }
+    if (~valid & below) { return 0; }
+    // G = composition of the aggregates on lanes k-1 ... 0 (ascending tile order)
+    const bool mine = lane < k;
+    const u32 q = mine ? u32(d[w] >> 42) & 1u : 0u;
+    const u32 c_out = mine ? u32(d[w]) & 0x1FFFFFu : 0u;
+    const u32 c_in = mine ? u32(d[w] >> 21) & 0x1FFFFFu : 0u;
+    const u64 qm = __ballot(q != 0);
+    // parity already flipped, relative to the window start, when the walk reaches my tile: quotes of the
+    // farther lanes lane+1 .. k-1
+    const u32 flipped = u32(popc64(qm & ~((2ull << lane) - 1ull))) & 1u;
+    const u32 g_out = wave_sum(flipped ? c_in : c_out);
+    const u32 g_in = wave_sum(flipped ? c_out : c_in);
+    const u32 gq = u32(popc64(qm)) & 1u;
+    // F := G then F
+    const u32 nf_out = g_out + (gq ? st.fin : st.fout), nf_in = g_in + (gq ? st.fout : st.fin);
+    st.fout = nf_out;
+    st.fin = nf_in;
+    st.fq ^= gq;
+    if (k < 64u) {
+      const u32 lo = readlane_dyn(u32(d[w]), k), hi = readlane_dyn(u32(d[w] >> 32), k);
+      const u32 s_k = hi & 1u;
+      S = s_k ^ st.fq;
+      B = lo + (s_k ? st.fin : st.fout);
+      return 1;
+    }
+    st.end -= 64;
+  }
+  return 0; // whole batch consumed, no inclusive prefix yet: keep walking from st.end
+}
+// `preloaded`: descriptors already requested with lookback_load(desc, tile, ...) some time ago (may be null)
+__device__ __forceinline__ bool lookback(const u64 *desc, u32 tile, u32 lane, u32 &S, u32 &B,
+                                         const u64 (*preloaded)[LOOKBACK_LOADS] = nullptr) {
+  lookback_state st{0u, 0u, 0u, (long long)tile};
+  if (preloaded) {
+    const int r = lookback_consume(*preloaded, st, lane, S, B);
+    if (r != 0) { return r > 0; }
+  }
   const u64 t_start = wall_clock64();
   for (;;) {
     u64 d[LOOKBACK_LOADS];
-#pragma unroll
-    for (u32 w = 0; w < LOOKBACK_LOADS; w++) {
-      const long long t = end - 1 - (long long)(w * 64 + lane);
-      d[w] = (t >= 0) ? desc_load(desc + t) : make_incl(0, 0); // in front of tile 0: outside strings, cursor 0
-    }
-    bool stalled = false;
-#pragma unroll
-    for (u32 w = 0; w < LOOKBACK_LOADS; w++) {
-      if (stalled) { break; }
-      const u32 st = u32(d[w] >> 62);
-      const u64 incl = __ballot(st == ST_INCL), valid = __ballot(st != 0), poison = __ballot(st == ST_POISON);
-      const u32 k = incl ? ctz64(incl) : 64u;                       // nearest inclusive predecessor in this window
-      const u64 below = (k == 64u) ? ~0ull : ((1ull << k) - 1ull);  // lanes nearer than it: must be aggregates
-      const u64 upto = (k == 64u) ? ~0ull : (below | (1ull << k));
-      if (poison & upto) { return false; }
-      if (~valid & below) { stalled = true; break; } // a needed aggregate is not published yet
-      // G = composition of the aggregates on lanes k-1 ... 0 (ascending tile order)
-      const bool mine = lane < k;
-      const u32 q = mine ? u32(d[w] >> 42) & 1u : 0u;
-      const u32 c_out = mine ? u32(d[w]) & 0x1FFFFFu : 0u;
-      const u32 c_in = mine ? u32(d[w] >> 21) & 0x1FFFFFu : 0u;
-      const u64 qm = __ballot(q != 0);
-      // parity already flipped, relative to the window start, when the walk reaches my tile: quotes of the
-      // farther lanes lane+1 .. k-1
-      const u32 flipped = u32(popc64(qm & ~((2ull << lane) - 1ull))) & 1u;
-      const u32 g_out = wave_sum(flipped ? c_in : c_out);
-      const u32 g_in = wave_sum(flipped ? c_out : c_in);
-      const u32 gq = u32(popc64(qm)) & 1u;
-      // F := G then F
-      const u32 nf_out = g_out + (gq ? fin : fout), nf_in = g_in + (gq ? fout : fin);
-      fout = nf_out;
-      fin = nf_in;
-      fq ^= gq;
-      if (k < 64u) {
-        const u32 lo = readlane_dyn(u32(d[w]), k), hi = readlane_dyn(u32(d[w] >> 32), k);
-        const u32 s_k = hi & 1u;
-        S = s_k ^ fq;
-        B = lo + (s_k ? fin : fout);
-        return true;
-      }
-      end -= 64;
-    }
+    lookback_load(desc, st.end, lane, d);
+    const int r = lookback_consume(d, st, lane, S, B);
+    if (r != 0) { return r > 0; }
     if (wall_clock64() - t_start > LOOKBACK_TIMEOUT_TICKS) { return false; }
     __builtin_amdgcn_s_sleep(4);
   }
@@ -329,14 +346,21 @@ __global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ 
     clear_minify_stage(reinterpret_cast<u8 *>(sh_stage[wave]), lane);
   }
   u32 pend_tile = NO_TILE; // workgroup-uniform
+  u32 next_ticket = 0;     // thread 0 only: claimed while the previous tile was being emitted
+  if (threadIdx.x == 0) { next_ticket = atomicAdd(ticket, 1u); }
   for (u32 iter = 0;; iter++) {
     const u32 cur = iter & 1u;
-    if (threadIdx.x == 0) { sh_tile = atomicAdd(ticket, 1u); }
+    if (threadIdx.x == 0) { sh_tile = next_ticket; }
     __syncthreads();
     const u32 tile = sh_tile;
     const bool have = tile < ntiles;
     const bool pend = pend_tile != NO_TILE;
     if (!have && !pend) { break; }
+    // wave 0 requests the pending tile's predecessor descriptors NOW and looks at them after the scan below:
+    // by then they have arrived, and (the pending tile having been published a whole emission ago) they are
+    // almost always complete, so the look-back costs no round trip at all
+    u64 early[LOOKBACK_LOADS];
+    if (wave == 0 && pend) { lookback_load(desc, (long long)pend_tile, lane, early); }
 
     // ---- scan the new tile into the register FIFO ------------------------------------------------------------
     u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0; // slot 3 = oldest chunk
@@ -417,7 +441,7 @@ __global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ 
       if (pend) {
         const u32 tq = sh_agg[cur ^ 1u][0], tout = sh_agg[cur ^ 1u][1], tin = sh_agg[cur ^ 1u][2];
         u32 S = 0, B = 0;
-        const bool ok = lookback(desc, pend_tile, lane, S, B);
+        const bool ok = lookback(desc, pend_tile, lane, S, B, &early);
         if (lane == 0) {
           if (ok) {
             const u32 total = B + (S ? tin : tout), s_end = S ^ tq;
@@ -450,6 +474,9 @@ __global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ 
       }
     }
     __syncthreads();
+    // claim the next tile now: the atomic's latency hides behind the emission, and in this pipelined schedule a
+    // ticket held for one emission does not delay anybody (successors ask for prefixes a whole scan later)
+    if (threadIdx.x == 0) { next_ticket = have ? atomicAdd(ticket, 1u) : NO_TILE; }
 
     // ---- every wave: emit its share of the pending tile from the LDS masks -----------------------------------------
     if (pend && sh_prefix[2] != 0u) {
