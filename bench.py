@@ -76,7 +76,7 @@ def main():
     parser = capi.DomParserImplementation(L, device=local_rank)
     parser.set_pipeline(args.pipeline)
     if args.pipeline == "auto":  # what AUTO resolves to for this size (sjgpu_capi.hip: AUTO_FUSED_BELOW)
-        args.pipeline = "fused" if L < (16 << 20) else "split"
+        args.pipeline = "fused" if (L <= (8 << 20) or L >= (192 << 20)) else "split"
     buf = torch.from_numpy(host).cuda()
     stream = torch.cuda.current_stream().cuda_stream
     if args.op == "stage1":

@@ -107,11 +107,12 @@ int sjgpu_result(sjgpu_ctx *ctx, void *stream, sjgpu_scan_result *out);
 
 /* Pipeline selection (default SJGPU_PIPELINE_AUTO; the environment variable SJGPU_PIPELINE = "split" |
  * "fused" | "auto" sets the default of new contexts):
- *   SPLIT  summarize -> resolve -> emit: four launches, stage-1 masks round-trip through HBM, every kernel
- *          runs at full occupancy with no inter-workgroup waiting -- fastest on large inputs;
- *   FUSED  one kernel, chained scan between 64 KiB tiles: reads every byte once, one launch -- fastest on
- *          small inputs;
- *   AUTO   FUSED below 16 MiB, SPLIT from there on.
+ *   SPLIT  summarize -> resolve -> emit: four launches, a 64-bit mask per block round-trips through HBM, every
+ *          kernel runs at full occupancy with no inter-workgroup waiting -- fastest on medium inputs;
+ *   FUSED  one kernel, chained scan between tiles: reads every byte once, one launch -- fastest on small inputs
+ *          and, in its pipelined form (look-back + emission of a tile deferred behind the scan of the next), on
+ *          large ones;
+ *   AUTO   FUSED up to 8 MiB (16 KiB tiles) and from 192 MiB (pipelined 64 KiB tiles), SPLIT in between.
  * All produce identical bytes; a single-pass call that raises SJGPU_F_INTERNAL is re-run split by the
  * host-buffer entry points, device-resident callers see the flag in sjgpu_result(). */
 #define SJGPU_PIPELINE_SPLIT 0

@@ -113,10 +113,16 @@ void drop_events(sjgpu_ctx *ctx) {
 // what torch.cuda.current_stream().cuda_stream reports for torch's default stream.
 hipStream_t pick(sjgpu_ctx *, void *stream) { return static_cast<hipStream_t>(stream); }
 
-// Measured on MI355X (profiles/r01_size_sweep.txt): one launch beats four up to a few MiB (20 us vs 24 us per
-// call), from ~32 MiB on the split pipeline's higher occupancy wins (1 GiB: 0.60 ms vs 0.73 ms).
-constexpr size_t AUTO_FUSED_BELOW = size_t(16) << 20;
-bool use_fused(const sjgpu_ctx *ctx, size_t len) { return ctx->pipeline == 1 || (ctx->pipeline == 2 && len < AUTO_FUSED_BELOW); }
+// Measured on MI355X (profiles/r01_size_sweep.txt, large_random): the single-pass kernel with 16 KiB tiles wins up to
+// a few MiB (8-14 us vs 18-20 us per call: one launch instead of four); between ~8 and ~192 MiB the split pipeline
+// wins (its kernels fill the chip with 16 KiB work items, the 64 KiB-tile pipelined kernel needs >= 2 tiles per
+// workgroup); above that the pipelined single-pass kernel wins on dense output (1 GiB: 0.52 vs 0.58 ms) and is
+// within 5 % on sparse output.
+constexpr size_t AUTO_FUSED_BELOW = size_t(8) << 20;
+constexpr size_t AUTO_FUSED_FROM = size_t(192) << 20;
+bool use_fused(const sjgpu_ctx *ctx, size_t len) {
+  return ctx->pipeline == 1 || (ctx->pipeline == 2 && (len <= AUTO_FUSED_BELOW || len >= AUTO_FUSED_FROM));
+}
 
 void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint32_t *idx, size_t idx_words, hipStream_t s,
                     hipEvent_t *ev) {

@@ -346,21 +346,14 @@ __global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ 
     clear_minify_stage(reinterpret_cast<u8 *>(sh_stage[wave]), lane);
   }
   u32 pend_tile = NO_TILE; // workgroup-uniform
-  u32 next_ticket = 0;     // thread 0 only: claimed while the previous tile was being emitted
-  if (threadIdx.x == 0) { next_ticket = atomicAdd(ticket, 1u); }
   for (u32 iter = 0;; iter++) {
     const u32 cur = iter & 1u;
-    if (threadIdx.x == 0) { sh_tile = next_ticket; }
+    if (threadIdx.x == 0) { sh_tile = atomicAdd(ticket, 1u); }
     __syncthreads();
     const u32 tile = sh_tile;
     const bool have = tile < ntiles;
     const bool pend = pend_tile != NO_TILE;
     if (!have && !pend) { break; }
-    // wave 0 requests the pending tile's predecessor descriptors NOW and looks at them after the scan below:
-    // by then they have arrived, and (the pending tile having been published a whole emission ago) they are
-    // almost always complete, so the look-back costs no round trip at all
-    u64 early[LOOKBACK_LOADS];
-    if (wave == 0 && pend) { lookback_load(desc, (long long)pend_tile, lane, early); }
 
     // ---- scan the new tile into the register FIFO ------------------------------------------------------------
     u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0; // slot 3 = oldest chunk
@@ -441,7 +434,7 @@ __global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ 
       if (pend) {
         const u32 tq = sh_agg[cur ^ 1u][0], tout = sh_agg[cur ^ 1u][1], tin = sh_agg[cur ^ 1u][2];
         u32 S = 0, B = 0;
-        const bool ok = lookback(desc, pend_tile, lane, S, B, &early);
+        const bool ok = lookback(desc, pend_tile, lane, S, B);
         if (lane == 0) {
           if (ok) {
             const u32 total = B + (S ? tin : tout), s_end = S ^ tq;
@@ -474,9 +467,6 @@ __global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ 
       }
     }
     __syncthreads();
-    // claim the next tile now: the atomic's latency hides behind the emission, and in this pipelined schedule a
-    // ticket held for one emission does not delay anybody (successors ask for prefixes a whole scan later)
-    if (threadIdx.x == 0) { next_ticket = have ? atomicAdd(ticket, 1u) : NO_TILE; }
 
     // ---- every wave: emit its share of the pending tile from the LDS masks -----------------------------------------
     if (pend && sh_prefix[2] != 0u) {
