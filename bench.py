@@ -138,13 +138,15 @@ def main():
         else:
             alg = L
         knames = KERNELS[(args.op, args.pipeline)]
+        if args.pipeline == "fused" and args.op != "validate_utf8":  # which single-pass kernel this size gets (sjgpu_fused.hip)
+            knames = [("k_fused_pipelined" if L > (8 << 20) else "k_fused_16KiB_tiles") + ("<0>" if args.op == "stage1" else "<1>")]
         kms = [m / max(calls, 1) for m in ms_sum][: len(knames)]
         gpu_ms = sum(kms)
         achieved = alg / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(f"{args.op}:{args.workload}:{args.size}")
+            traffic = json.load(open(tpath)).get(f"{args.op}:{args.workload}:{args.size}:{args.pipeline}")
         line = {
             "metric": "stage1 GB/s (structural indexing)" if args.op == "stage1" else f"{args.op} GB/s",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
