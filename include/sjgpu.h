@@ -147,6 +147,27 @@ int sjgpu_stage1_finish_host(const uint8_t *buf, size_t len, int mode, uint32_t 
 /* streaming modes: length after dropping a trailing partial UTF-8 character (…indexer.h:156-174) */
 size_t sjgpu_trim_partial_utf8(const uint8_t *buf, size_t len);
 
+
+/* ---- one large document sharded across GPUs ("general inputs") -------------------------
+ * The reference has no counterpart: its stage 1 is one serial pass whose carries (json_escape_scanner.h:50-71
+ * next_is_escaped, json_string_scanner.h:62-85 prev_in_string, json_scanner.h:128-157 prev_scalar,
+ * utf8_lookup4_algorithm.h:164-171 prev_incomplete) run through the whole buffer.  Cut the buffer where all of
+ * them except the in-string bit are provably zero, exchange ONE bit per shard, and every shard scans alone:
+ *   1. host: cut k = sjgpu_clean_cut(buf, len, k*len/G)   (byte cut-1 is ASCII whitespace or , : [ ] { })
+ *   2. rank r: sjgpu_string_parity_device(shard r); sjgpu_result().n = 1 iff it holds an odd number of
+ *      unescaped quotes; all-gather the G bits; in_string(r) = XOR of the bits of shards < r
+ *   3. rank r: sjgpu_stage1_shard_device / sjgpu_minify_shard_device with in_string(r).
+ * sjgpu_result() after step 3: n / out_len of the shard; SJGPU_F_UNCLOSED_STRING = "the shard ENDS inside a
+ * string" (an error only for the last shard); the other flags as usual.  Offsets are shard-relative; the
+ * sentinels written behind them hold the shard's length.  Concatenating the shards' outputs in rank order
+ * gives exactly the whole-buffer result. */
+size_t sjgpu_clean_cut(const uint8_t *buf, size_t len, size_t target); /* first cut >= target, or len */
+int sjgpu_string_parity_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *stream);
+int sjgpu_stage1_shard_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, int in_string, void *idx_dev,
+                              size_t idx_words, void *stream);
+int sjgpu_minify_shard_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, int in_string, void *dst_dev,
+                              void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ EXPORTS = [
     "sjgpu_last_error", "sjgpu_stage1", "sjgpu_minify", "sjgpu_validate_utf8", "sjgpu_stage1_device",
     "sjgpu_minify_device", "sjgpu_validate_utf8_device", "sjgpu_result", "sjgpu_stage1_error_from_flags",
     "sjgpu_stage1_finish_host", "sjgpu_trim_partial_utf8", "sjgpu_profile_enable", "sjgpu_profile_read", "sjgpu_set_pipeline", "sjgpu_debug_trace_stage1",
+    "sjgpu_clean_cut", "sjgpu_string_parity_device", "sjgpu_stage1_shard_device", "sjgpu_minify_shard_device",
 ]
 
 
@@ -98,6 +99,14 @@ def load_library():
     L.sjgpu_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), u32p]
     L.sjgpu_trim_partial_utf8.restype = sz
     L.sjgpu_trim_partial_utf8.argtypes = [vp, sz]
+    L.sjgpu_clean_cut.restype = sz
+    L.sjgpu_clean_cut.argtypes = [vp, sz, sz]
+    L.sjgpu_string_parity_device.restype = ctypes.c_int
+    L.sjgpu_string_parity_device.argtypes = [vp, vp, sz, vp]
+    L.sjgpu_stage1_shard_device.restype = ctypes.c_int
+    L.sjgpu_stage1_shard_device.argtypes = [vp, vp, sz, ctypes.c_int, vp, sz, vp]
+    L.sjgpu_minify_shard_device.restype = ctypes.c_int
+    L.sjgpu_minify_shard_device.argtypes = [vp, vp, sz, ctypes.c_int, vp, vp]
     _lib = L
     return L
 
@@ -195,6 +204,24 @@ class DomParserImplementation:
             raise SjgpuError(f"sjgpu_validate_utf8_device error {rc}: {self.last_error()}")
         return rc
 
+    # ---- shards of one large document (sjgpu.h, "one large document sharded across GPUs") ----
+    def string_parity_device(self, buf_ptr, length, stream=0):
+        """-> 1 iff the shard holds an odd number of unescaped quotes (waits for `stream`)."""
+        rc = self.L.sjgpu_string_parity_device(self.h, buf_ptr, int(length), stream or None)
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_string_parity_device error {rc}: {self.last_error()}")
+        return self.result(stream)[0] & 1
+
+    def stage1_shard_device(self, buf_ptr, length, in_string, idx_ptr, idx_words, stream=0):
+        rc = self.L.sjgpu_stage1_shard_device(self.h, buf_ptr, int(length), int(in_string), idx_ptr, int(idx_words), stream or None)
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_stage1_shard_device error {rc}: {self.last_error()}")
+
+    def minify_shard_device(self, buf_ptr, length, in_string, dst_ptr, stream=0):
+        rc = self.L.sjgpu_minify_shard_device(self.h, buf_ptr, int(length), int(in_string), dst_ptr, stream or None)
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_minify_shard_device error {rc}: {self.last_error()}")
+
     def result(self, stream=0):  # waits for `stream`
         r = ScanResult()
         rc = self.L.sjgpu_result(self.h, stream or None, ctypes.byref(r))
@@ -234,6 +261,12 @@ class DomParserImplementation:
 
 def stage1_error_from_flags(n, flags):
     return int(load_library().sjgpu_stage1_error_from_flags(int(n), int(flags)))
+
+
+def clean_cut(buf, target):
+    """First cut >= target where only the in-string bit crosses (sjgpu_clean_cut), or len(buf)."""
+    a = _as_u8(buf)
+    return int(load_library().sjgpu_clean_cut(a.ctypes.data, len(a), int(target)))
 
 
 def device_count():

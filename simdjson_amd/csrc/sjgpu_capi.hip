@@ -125,13 +125,14 @@ bool use_fused(const sjgpu_ctx *ctx, size_t len) {
 }
 
 void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint32_t *idx, size_t idx_words, hipStream_t s,
-                    hipEvent_t *ev) {
-  if (fused) { launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, ctx->max_workgroups, s, ev); }
-  else { launch_stage1(buf, len, ctx->masks, ctx->summ, ctx->pref, idx, idx_words, ctx->d_result, s, ev); }
+                    hipEvent_t *ev, uint32_t carry = 0) {
+  if (fused) { launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, carry, ctx->max_workgroups, s, ev); }
+  else { launch_stage1(buf, len, ctx->masks, ctx->summ, ctx->pref, idx, idx_words, ctx->d_result, carry, s, ev); }
 }
-void enqueue_minify(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint8_t *dst, hipStream_t s, hipEvent_t *ev) {
-  if (fused) { launch_minify_fused(buf, len, ctx->desc, dst, ctx->d_result, ctx->max_workgroups, s, ev); }
-  else { launch_minify(buf, len, ctx->summ, ctx->pref, dst, ctx->d_result, s, ev); }
+void enqueue_minify(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint8_t *dst, hipStream_t s, hipEvent_t *ev,
+                    uint32_t carry = 0) {
+  if (fused) { launch_minify_fused(buf, len, ctx->desc, dst, ctx->d_result, carry, ctx->max_workgroups, s, ev); }
+  else { launch_minify(buf, len, ctx->summ, ctx->pref, dst, ctx->d_result, carry, s, ev); }
 }
 
 } // namespace
@@ -248,6 +249,45 @@ int sjgpu_validate_utf8_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
     return 0;
   }
   launch_validate_utf8(static_cast<const uint8_t *>(buf_dev), len, ctx->d_result, pick(ctx, stream), next_events(ctx));
+  SJ_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+// ---- shards of ONE large document across GPUs ("general inputs") -------------------------
+// Cuts come from sjgpu_clean_cut (host), so escapes, the previous-scalar bit and UTF-8 state are zero at
+// every cut; the in-string bit is the only carry and travels as an argument.
+int sjgpu_string_parity_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *stream) {
+  if (!ctx || (len && (!buf_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u)))) { return SJGPU_E_BADARG; }
+  if (len > ctx->capacity) { return E_CAPACITY; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  launch_string_parity(static_cast<const uint8_t *>(buf_dev), len, ctx->d_result, pick(ctx, stream));
+  SJ_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int sjgpu_stage1_shard_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, int in_string, void *idx_dev, size_t idx_words,
+                              void *stream) {
+  if (!ctx || !buf_dev || !idx_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u) || (reinterpret_cast<uintptr_t>(idx_dev) & 3u) ||
+      len == 0) {
+    return SJGPU_E_BADARG;
+  }
+  if (len > ctx->capacity) { return E_CAPACITY; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  enqueue_stage1(ctx, use_fused(ctx, len), static_cast<const uint8_t *>(buf_dev), len, static_cast<uint32_t *>(idx_dev), idx_words,
+                 pick(ctx, stream), next_events(ctx), CARRY_SHARD | (in_string ? CARRY_IN_STRING : 0u));
+  SJ_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int sjgpu_minify_shard_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, int in_string, void *dst_dev, void *stream) {
+  if (!ctx || !buf_dev || !dst_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u) || (reinterpret_cast<uintptr_t>(dst_dev) & 15u) ||
+      len == 0) {
+    return SJGPU_E_BADARG;
+  }
+  if (len > ctx->capacity) { return E_CAPACITY; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  enqueue_minify(ctx, use_fused(ctx, len), static_cast<const uint8_t *>(buf_dev), len, static_cast<uint8_t *>(dst_dev), pick(ctx, stream),
+                 next_events(ctx), CARRY_SHARD | (in_string ? CARRY_IN_STRING : 0u));
   SJ_TRY(ctx, hipGetLastError());
   return 0;
 }

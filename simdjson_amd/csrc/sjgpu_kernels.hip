@@ -135,7 +135,8 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *sh, bool use_xor, u32
 __global__ __launch_bounds__(RESOLVE_THREADS) void k_resolve_segments(const seg_summary *__restrict__ summ,
                                                                      seg_prefix *__restrict__ pref, u32 nseg, u64 len,
                                                                      u32 *__restrict__ idx, u64 idx_words,
-                                                                     scan_result_dev *__restrict__ result, int what) {
+                                                                     scan_result_dev *__restrict__ result, int what,
+                                                                     u32 carry) {
   __shared__ u32 sh[RESOLVE_THREADS];
   __shared__ u32 sh_flags;
   const u32 tid = threadIdx.x;
@@ -147,6 +148,8 @@ __global__ __launch_bounds__(RESOLVE_THREADS) void k_resolve_segments(const seg_
   for (u32 i = lo; i < hi; i++) { par ^= summ[i].flags & SF_PARITY; }
   u32 final_parity;
   u32 s = block_excl_scan(par, sh, true, final_parity);
+  s ^= carry & CARRY_IN_STRING; // a shard of a larger document may begin inside a string
+  final_parity ^= carry & CARRY_IN_STRING;
   // pass 2: counts under the now-known in-string state
   u32 cnt = 0, st = s, flags = 0;
   for (u32 i = lo; i < hi; i++) {
@@ -185,7 +188,8 @@ __global__ __launch_bounds__(RESOLVE_THREADS) void k_resolve_segments(const seg_
       result->out_len = 0;
     } else {
       result->n = 0;
-      result->out_len = final_parity ? 0ull : u64(total); // unclosed string voids the output (json_minifier.h:42-47)
+      // unclosed string voids the output (json_minifier.h:42-47) -- of a whole document, not of a shard
+      result->out_len = (final_parity && !(carry & CARRY_SHARD)) ? 0ull : u64(total);
     }
     result->flags = f; // this kernel is the first writer of the call's result (the emit kernel only ORs into it)
   }
@@ -373,6 +377,34 @@ __global__ __launch_bounds__(64) void k_validate_utf8(const u8 *__restrict__ buf
   if (__ballot(bad) && lane == 0) { atomicOr(&result->flags, SJGPU_F_UTF8_ERROR); }
 }
 
+
+// =====================================================================================================
+// string parity of a shard: 1 iff it holds an odd number of unescaped quotes (read-only pre-pass of the
+// general multi-GPU sharding, SURVEY 8(e): the ranks all-gather these bits, then scan with the right carry-in)
+// =====================================================================================================
+__global__ __launch_bounds__(64) void k_string_parity(const u8 *__restrict__ buf, u64 len, u32 nseg,
+                                                      scan_result_dev *__restrict__ result) {
+  const u32 lane = lane_id();
+  u32 parity = 0;
+  for (u32 seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    const u64 seg_start = u64(seg) * SEG_BYTES;
+    const u32 lookback = lookback_issue(buf, seg_start, lane);
+    wave_carry wc{0u, 0u, 0u, 0u};
+    for (u32 c = 0; c < SEG_CHUNKS; c++) {
+      const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
+      if (cstart >= len) { break; }
+      const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
+      u32 w[16];
+      if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
+      else { load_block(buf, pos, len, w); }
+      if (c == 0) { wc = segment_carry_from(buf, seg_start, lane, lookback); }
+      (void)scan_chunk<false, false>(w, wc, lane);
+    }
+    parity ^= wc.s;
+  }
+  if (parity && lane == 0) { atomicXor(&result->n, 1u); }
+}
+
 } // namespace
 
 // ---- launchers ----------------------------------------------------------------------------------------
@@ -381,7 +413,7 @@ static inline void mark(hipEvent_t *ev, int k, hipStream_t stream) {
 }
 
 void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *summ, seg_prefix *pref, uint32_t *idx,
-                   uint64_t idx_words, scan_result_dev *result, hipStream_t stream, hipEvent_t *ev) {
+                   uint64_t idx_words, scan_result_dev *result, uint32_t carry, hipStream_t stream, hipEvent_t *ev) {
   const u32 nseg = num_segments(len);
   mark(ev, 0, stream);
   u64 *mask0 = reinterpret_cast<u64 *>(masks);
@@ -392,14 +424,14 @@ void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *
   seg_summary *gsum = summ + nseg; // the group summaries live behind the segment summaries
   hipLaunchKernelGGL(k_resolve_groups, dim3(ngroups), dim3(64), 0, stream, summ, gsum, nseg);
   hipLaunchKernelGGL(k_resolve_segments, dim3(1), dim3(RESOLVE_THREADS), 0, stream, gsum, pref, ngroups, len, idx, idx_words,
-                     result, 0);
+                     result, 0, carry);
   mark(ev, 2, stream);
   hipLaunchKernelGGL(k_stage1_emit, dim3(nseg), dim3(64), 0, stream, mask0, mask1, summ, pref, len, idx, idx_words, result);
   mark(ev, 3, stream);
 }
 
 void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_prefix *pref, uint8_t *dst,
-                   scan_result_dev *result, hipStream_t stream, hipEvent_t *ev) {
+                   scan_result_dev *result, uint32_t carry, hipStream_t stream, hipEvent_t *ev) {
   const u32 nseg = num_segments(len);
   mark(ev, 0, stream);
   hipLaunchKernelGGL(k_minify_summarize, dim3(nseg), dim3(64), 0, stream, buf, len, summ);
@@ -408,7 +440,7 @@ void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_pref
   seg_summary *gsum = summ + nseg;
   hipLaunchKernelGGL(k_resolve_groups, dim3(ngroups), dim3(64), 0, stream, summ, gsum, nseg);
   hipLaunchKernelGGL(k_resolve_segments, dim3(1), dim3(RESOLVE_THREADS), 0, stream, gsum, pref, ngroups, len,
-                     static_cast<u32 *>(nullptr), u64(0), result, 1);
+                     static_cast<u32 *>(nullptr), u64(0), result, 1, carry);
   mark(ev, 2, stream);
   hipLaunchKernelGGL(k_minify_emit, dim3(nseg), dim3(64), 0, stream, buf, len, summ, pref, dst);
   mark(ev, 3, stream);
@@ -423,6 +455,14 @@ void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *res
   mark(ev, 1, stream);
   mark(ev, 2, stream);
   mark(ev, 3, stream);
+}
+
+void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *result, hipStream_t stream) {
+  (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
+  const u32 nseg = num_segments(len);
+  if (nseg == 0) { return; }
+  const u32 grid = nseg < 8192u ? nseg : 8192u;
+  hipLaunchKernelGGL(k_string_parity, dim3(grid), dim3(64), 0, stream, buf, len, nseg, result);
 }
 
 } // namespace sjgpu

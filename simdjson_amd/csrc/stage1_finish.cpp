@@ -126,6 +126,18 @@ extern "C" size_t sjgpu_trim_partial_utf8(const uint8_t *buf, size_t len) {
   return len;
 }
 
+// A cut is "clean" when the byte in front of it is ASCII whitespace or one of , : [ ] { } : not a backslash
+// (nothing is escaped across the cut), neither a scalar byte nor a quote (prev_scalar = 0), ASCII (no UTF-8
+// sequence is open).  Only the in-string bit survives such a cut.  Whitespace counts inside strings too.
+extern "C" size_t sjgpu_clean_cut(const uint8_t *buf, size_t len, size_t target) {
+  if (target == 0) { return 0; }
+  for (size_t c = target; c < len; c++) {
+    const uint8_t b = buf[c - 1];
+    if (b == ' ' || b == '\t' || b == '\n' || b == '\r' || opens(b) || closes(b) || separates(b)) { return c; }
+  }
+  return len;
+}
+
 extern "C" int sjgpu_stage1_error_from_flags(uint32_t n, uint32_t flags) {
   if (flags & SJGPU_F_UNCLOSED_STRING) { return E_UNCLOSED; }
   if (flags & SJGPU_F_UNESCAPED_CTRL) { return E_UNESCAPED; }

@@ -10,6 +10,11 @@ the scan itself.  The only exchange is optional: concatenating the per-rank inde
 all_gather of the counts, one padded all_gather of the offsets -- RCCL over xGMI on GPUs, gloo in the
 CPU tests).
 
+ONE LARGE DOCUMENT ("general inputs") shards too, with one tiny exchange: cut where every
+carry except the in-string bit is provably zero (`clean_cuts`, sjgpu_clean_cut), every rank computes the
+quote parity of its shard (a read-only pass), ONE all_gather of a bit per rank gives every rank its
+in-string carry-in, then every rank scans alone (`scan_document_shard`).
+
 `scan_fn` is the per-shard scan.  The product default is the HIP path (GpuShardScanner); the CPU test
 tier injects the oracle instead so that sharding, bases and the gather are covered without a GPU.
 """
@@ -30,6 +35,32 @@ def newline_cuts(buf: np.ndarray, parts: int):
         cuts.append(n if len(nl) == 0 else target + int(nl[0]) + 1)
     cuts.append(n)
     return cuts
+
+
+def clean_cuts(buf: np.ndarray, parts: int):
+    """parts+1 ascending cut offsets of ONE document: cut k is the first position at or after k*len/parts whose
+    previous byte is ASCII whitespace or one of , : [ ] { } (sjgpu_clean_cut) -- no escape, no scalar, no UTF-8
+    sequence crosses it.  A region without such a byte (one huge string without blanks) yields empty shards."""
+    from . import capi
+    a = np.ascontiguousarray(buf, dtype=np.uint8)
+    n = len(a)
+    cuts = [0]
+    for k in range(1, parts):
+        cuts.append(capi.clean_cut(a, max((k * n) // parts, cuts[-1])))
+    cuts.append(n)
+    return cuts
+
+
+F_UNCLOSED_STRING = 1  # SJGPU_F_UNCLOSED_STRING: for a shard, "ends inside a string"
+
+
+def document_flags(flags_per_rank):
+    """Flags of the whole document from the shards' flags: errors OR together, but only the LAST shard ending
+    inside a string is an unclosed string."""
+    out = 0
+    for f in flags_per_rank:
+        out |= f & ~F_UNCLOSED_STRING
+    return out | (flags_per_rank[-1] & F_UNCLOSED_STRING)
 
 
 @dataclass
@@ -63,6 +94,28 @@ class GpuShardScanner:
         n, flags, _ = self.parser.result(stream)
         return idx, n, flags
 
+    # shards of one document: quote parity (read-only pre-pass), then the scan with the exchanged carry-in
+    def _upload(self, shard):
+        return self.torch.from_numpy(np.ascontiguousarray(shard)).to(f"cuda:{self.device}")
+
+    def parity(self, shard: np.ndarray):
+        self._resident = self._upload(shard)  # stays in HBM for scan() of the same shard
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        return self.parser.string_parity_device(self._resident.data_ptr(), len(shard), stream)
+
+    def scan(self, shard: np.ndarray, in_string: int):
+        torch = self.torch
+        L = len(shard)
+        buf = getattr(self, "_resident", None)
+        if buf is None or buf.numel() != L:
+            buf = self._upload(shard)
+        self._resident = None
+        idx = torch.empty(L + 3, dtype=torch.int32, device=f"cuda:{self.device}")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.parser.stage1_shard_device(buf.data_ptr(), L, in_string, idx.data_ptr(), L + 3, stream)
+        n, flags, _ = self.parser.result(stream)
+        return idx, n, flags
+
 
 def scan_shard(buf: np.ndarray, rank: int, world: int, scan_fn) -> ShardScan:
     """Rank `rank`'s share of the stream: cut at newlines, scan with zero carry-in."""
@@ -74,11 +127,34 @@ def scan_shard(buf: np.ndarray, rank: int, world: int, scan_fn) -> ShardScan:
     return ShardScan(lo, hi - lo, n, flags, idx)
 
 
-def gather_global_indices(local: ShardScan, group=None):
+def scan_document_shard(buf: np.ndarray, rank: int, world: int, scanner, group=None) -> ShardScan:
+    """Rank `rank`'s share of ONE document.  `scanner` has parity(shard) -> 0/1 and scan(shard, in_string) ->
+    (idx, n, flags).  The only collective: all_gather of one int per rank (gloo / RCCL)."""
+    import torch
+    import torch.distributed as dist
+    cuts = clean_cuts(buf, world)
+    lo, hi = cuts[rank], cuts[rank + 1]
+    mine = torch.tensor([scanner.parity(buf[lo:hi]) if hi > lo else 0], dtype=torch.int32)
+    backend = dist.get_backend(group)
+    if backend == "nccl":
+        mine = mine.cuda()
+    bits = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(bits, mine, group=group)
+    in_string = 0
+    for r in range(rank):
+        in_string ^= int(bits[r]) & 1
+    if hi == lo:  # an empty shard passes the state through
+        return ShardScan(lo, 0, 0, F_UNCLOSED_STRING if in_string else 0, np.zeros(0, np.int32))
+    idx, n, flags = scanner.scan(buf[lo:hi], in_string)
+    return ShardScan(lo, hi - lo, n, flags, idx)
+
+
+def gather_global_indices(local: ShardScan, group=None, document=False):
     """Concatenate all ranks' structural positions as global int64 offsets (every rank gets the result).
 
     Collective: all_gather(counts, bases, flags) then ONE padded all_gather of the uint32 offsets.
-    Returns (positions int64 tensor [sum n], per-rank counts list, OR of flags)."""
+    Returns (positions int64 tensor [sum n], per-rank counts list, flags): flags = OR over the shards, or, with
+    document=True (shards of ONE document), document_flags()."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -94,6 +170,8 @@ def gather_global_indices(local: ShardScan, group=None):
     flags = 0
     for m in metas:
         flags |= int(m[2])
+    if document:
+        flags = document_flags([int(m[2]) for m in metas])
     width = max(max(counts), 1)
     mine = torch.zeros(width, dtype=torch.int32, device=dev)
     mine[: local.n] = idx[: local.n]

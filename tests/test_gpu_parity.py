@@ -336,6 +336,90 @@ def test_reference_examples_if_present(gpu, orc):
         assert_same_all(gpu, orc, np.fromfile(os.path.join(ex, fn), dtype=np.uint8), tag=fn, modes=(0, 2))
 
 
+# ---- shards of ONE document (sjgpu.h "one large document sharded across GPUs") ----------------------
+def _scan_in_shards(p, a, parts, with_minify=True):
+    """What G ranks do, replayed on one GPU: clean cuts, parity pre-pass per shard, XOR-prefix of the bits, shard
+    scans with the carried in-string bit.  -> (global offsets, per-shard flags, concatenated minified bytes)."""
+    import torch
+    from simdjson_amd import sharded
+    stream = torch.cuda.current_stream().cuda_stream
+    cuts = sharded.clean_cuts(a, parts)
+    assert cuts[0] == 0 and cuts[-1] == len(a) and cuts == sorted(cuts)
+    state, offs, flags, mini = 0, [], [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        if hi == lo:
+            flags.append(1 if state else 0)
+            continue
+        L = hi - lo
+        buf = torch.from_numpy(np.ascontiguousarray(a[lo:hi])).cuda()  # its own (aligned) allocation, like a rank's
+        parity = p.string_parity_device(buf.data_ptr(), L, stream)
+        idx = torch.empty(L + 3, dtype=torch.int32, device="cuda")
+        p.stage1_shard_device(buf.data_ptr(), L, state, idx.data_ptr(), L + 3, stream)
+        n, f, _ = p.result(stream)
+        assert f & (capi.F_INTERNAL | capi.F_IDX_OVERFLOW) == 0
+        assert (f & 1) == (state ^ parity), "carry-out = carry-in xor parity"
+        host = idx[: n + 3].cpu().numpy().view(np.uint32)
+        assert list(host[n:]) == [L, L, 0]
+        offs.append(host[:n].astype(np.int64) + lo)
+        flags.append(f)
+        if with_minify:
+            dst = torch.empty(L + 16, dtype=torch.uint8, device="cuda")
+            p.minify_shard_device(buf.data_ptr(), L, state, dst.data_ptr(), stream)
+            _, mf, mlen = p.result(stream)
+            assert (mf & 1) == (state ^ parity)
+            mini.append(dst[:mlen].cpu().numpy())
+        state ^= parity
+    cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
+    return cat(offs, np.int64), flags, cat(mini, np.uint8)
+
+
+def test_document_shards_equal_the_whole_scan(gpu, orc):
+    from simdjson_amd import sharded
+    rng = np.random.default_rng(5)
+    docs = {
+        "twitter_like 3 MiB": corpus.twitter_like(3 << 20, 3)[0],
+        "large_random 2 MiB": corpus.large_random(2 << 20, 3)[0],
+        "twitter_like 20 MiB": corpus.twitter_like(20 << 20, 4)[0],
+        "one long string with blanks": np.frombuffer(b'["' + b"lorem ipsum, {dolor}: [sit] \\\" amet " * 40000 + b'", 1]', np.uint8),
+        "no clean byte for a long stretch": np.frombuffer(b'["' + b"x" * 300000 + b'", "' + b"y" * 300000 + b'"]', np.uint8),
+        "ends inside a string": np.concatenate([corpus.twitter_like(1 << 20, 6)[0], np.frombuffer(b' "dangling text', np.uint8)]),
+    }
+    ctrl = corpus.twitter_like(1 << 20, 7)[0].copy()
+    quotes = np.flatnonzero(ctrl == ord('"'))
+    ctrl[int(quotes[len(quotes) // 2]) + 1] = 0x02
+    docs["control character inside a string"] = ctrl
+    bad = corpus.twitter_like(1 << 20, 8)[0].copy()
+    bad[len(bad) // 3] = 0xFF
+    docs["invalid UTF-8"] = bad
+    alphabet = np.frombuffer(b'"\\ ,:[]{}ab1\n\t\xc3\xa9\xe2\x82\xac', np.uint8)
+    docs["random soup"] = alphabet[rng.integers(0, len(alphabet), 200000)].copy()
+    for name, a in docs.items():
+        whole, wflags = orc.scan(a)
+        oerr, omin = orc.minify(a)
+        for parts in (2, 3, 8):
+            offs, flags, mini = _scan_in_shards(gpu, a, parts)
+            assert np.array_equal(offs, whole.astype(np.int64)), (name, parts, first_diff(offs, whole.astype(np.int64)))
+            assert sharded.document_flags(flags) == wflags, (name, parts, flags, wflags)
+            if oerr == 0:  # an unclosed string voids the whole document's output (json_minifier.h:42-47)
+                assert np.array_equal(mini, omin), (name, parts, first_diff(mini, omin))
+            else:
+                assert sharded.document_flags(flags) & 1
+
+
+def test_full_size_document_in_eight_shards(orc):
+    """BASELINE.json configs[1] cut into 8 shards (what 8 GPUs would hold), AUTO pipeline per shard."""
+    import torch
+    from simdjson_amd import sharded
+    size = int(os.environ.get("SJGPU_FULL_SIZE", str(1 << 30)))
+    a, _ = corpus.large_random(size, 11)
+    p = capi.DomParserImplementation(len(a) // 8 + (1 << 20))
+    offs, flags, _ = _scan_in_shards(p, a, 8, with_minify=False)
+    oerr, on, oidx = orc.stage1(a, 0)
+    assert oerr == 0 and sharded.document_flags(flags) == 0 and len(offs) == on
+    assert orc.fnv(offs.astype(np.uint32)) == orc.fnv(oidx[:on]), first_diff(offs, oidx[:on].astype(np.int64))
+    p.close()
+
+
 # ---- full size (BASELINE.json configs 2/3): device-resident path, 1 GiB ------------------------------------------
 @pytest.mark.parametrize("pipeline", ["fused", "split"])
 @pytest.mark.parametrize("kind", ["large_random", "amazon_ndjson"])
