@@ -168,6 +168,20 @@ int sjgpu_stage1_shard_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, i
 int sjgpu_minify_shard_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, int in_string, void *dst_dev,
                               void *stream);
 
+/* ---- ranges of ONE resident buffer, one after the other (overlap the upload of batch k+1 with
+ * the scan of batch k -- the GPU analogue of the reference's stage1_worker, dom/document_stream-inl.h:16-85).
+ * Scans bytes [begin, end) of buf_dev; bytes [0, begin) must already be resident (escapes, the previous-scalar bit
+ * and UTF-8 state are read from them), bytes beyond end need not be.  begin is a multiple of 1 MiB.  `more` != 0:
+ * more ranges follow (no end-of-input checks).  in_string and n_before / out_before come from sjgpu_result() of
+ * the previous range: (flags & SJGPU_F_UNCLOSED_STRING), n / out_len -- 0, 0 for the first range.  Offsets stay
+ * relative to byte 0 and are appended at idx_dev[n_before...]; result.n / out_len are running totals.
+ * sjgpu_stage1() and sjgpu_minify() drive exactly this for host buffers of 16 MiB and more (env
+ * SJGPU_STREAM_FROM_MB / SJGPU_STREAM_CHUNK_MB), with the device-to-host copies on a second thread. */
+int sjgpu_stage1_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin, size_t end, int more, int in_string,
+                              uint32_t n_before, void *idx_dev, size_t idx_words, void *stream);
+int sjgpu_minify_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin, size_t end, int more, int in_string,
+                              uint32_t out_before, void *dst_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

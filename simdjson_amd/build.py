@@ -50,7 +50,7 @@ def build_sjgpu(force=False):
     deps = srcs + _csrc("sj_block.h", "sjgpu_internal.h", "sjgpu_device.h") + [os.path.join(_paths.INCLUDE_DIR, "sjgpu.h")]
     if force or _stale(out, deps):
         os.makedirs(_paths.LIB_DIR, exist_ok=True)
-        _run([HIPCC, f"--offload-arch={GFX_ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+        _run([HIPCC, f"--offload-arch={GFX_ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
               "-I", _paths.INCLUDE_DIR, "-I", _paths.CSRC_DIR, *srcs, "-o", out])
     return out
 

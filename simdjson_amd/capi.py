@@ -26,6 +26,7 @@ EXPORTS = [
     "sjgpu_minify_device", "sjgpu_validate_utf8_device", "sjgpu_result", "sjgpu_stage1_error_from_flags",
     "sjgpu_stage1_finish_host", "sjgpu_trim_partial_utf8", "sjgpu_profile_enable", "sjgpu_profile_read", "sjgpu_set_pipeline", "sjgpu_debug_trace_stage1",
     "sjgpu_clean_cut", "sjgpu_string_parity_device", "sjgpu_stage1_shard_device", "sjgpu_minify_shard_device",
+    "sjgpu_stage1_range_device", "sjgpu_minify_range_device",
 ]
 
 
@@ -107,6 +108,10 @@ def load_library():
     L.sjgpu_stage1_shard_device.argtypes = [vp, vp, sz, ctypes.c_int, vp, sz, vp]
     L.sjgpu_minify_shard_device.restype = ctypes.c_int
     L.sjgpu_minify_shard_device.argtypes = [vp, vp, sz, ctypes.c_int, vp, vp]
+    L.sjgpu_stage1_range_device.restype = ctypes.c_int
+    L.sjgpu_stage1_range_device.argtypes = [vp, vp, sz, sz, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, vp, sz, vp]
+    L.sjgpu_minify_range_device.restype = ctypes.c_int
+    L.sjgpu_minify_range_device.argtypes = [vp, vp, sz, sz, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, vp, vp]
     _lib = L
     return L
 
@@ -221,6 +226,19 @@ class DomParserImplementation:
         rc = self.L.sjgpu_minify_shard_device(self.h, buf_ptr, int(length), int(in_string), dst_ptr, stream or None)
         if rc != 0:
             raise SjgpuError(f"sjgpu_minify_shard_device error {rc}: {self.last_error()}")
+
+    # ---- ranges of one resident buffer (sjgpu.h, "ranges of ONE resident buffer") ----
+    def stage1_range_device(self, buf_ptr, begin, end, more, in_string, n_before, idx_ptr, idx_words, stream=0):
+        rc = self.L.sjgpu_stage1_range_device(self.h, buf_ptr, int(begin), int(end), int(more), int(in_string), int(n_before),
+                                              idx_ptr, int(idx_words), stream or None)
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_stage1_range_device error {rc}: {self.last_error()}")
+
+    def minify_range_device(self, buf_ptr, begin, end, more, in_string, out_before, dst_ptr, stream=0):
+        rc = self.L.sjgpu_minify_range_device(self.h, buf_ptr, int(begin), int(end), int(more), int(in_string), int(out_before),
+                                              dst_ptr, stream or None)
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_minify_range_device error {rc}: {self.last_error()}")
 
     def result(self, stream=0):  # waits for `stream`
         r = ScanResult()

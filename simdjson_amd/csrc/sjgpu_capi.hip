@@ -4,13 +4,71 @@
 #include "sjgpu.h"
 #include "sjgpu_internal.h"
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 using namespace sjgpu;
+
+// Device-to-host copies of finished output ranges run on their own thread + stream, so that the host-buffer path can
+// upload range k+1 (a pageable hipMemcpyAsync blocks its caller) while range k's offsets travel the other way:
+// PCIe is full duplex, and measured on this box the two directions together move 97 GB/s against 56 GB/s for
+// either alone (profiles/r01_pcie_overlap.txt).  Works with plain malloc/new[] memory on both sides.
+struct copy_worker {
+  struct job { void *dst; const void *src; size_t bytes; };
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv_job, cv_idle;
+  std::deque<job> q;
+  bool stop = false;
+  size_t inflight = 0;
+  hipError_t err = hipSuccess;
+  int device = 0;
+  hipStream_t stream = nullptr;
+
+  void run() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      std::unique_lock<std::mutex> lk(m);
+      cv_job.wait(lk, [&] { return stop || !q.empty(); });
+      if (q.empty()) { return; }
+      const job j = q.front();
+      q.pop_front();
+      lk.unlock();
+      hipError_t e = hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost, stream);
+      if (e == hipSuccess) { e = hipStreamSynchronize(stream); }
+      lk.lock();
+      if (e != hipSuccess && err == hipSuccess) { err = e; }
+      if (--inflight == 0) { cv_idle.notify_all(); }
+    }
+  }
+  void submit(void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) { return; }
+    std::lock_guard<std::mutex> lk(m);
+    q.push_back(job{dst, src, bytes});
+    inflight++;
+    cv_job.notify_one();
+  }
+  hipError_t drain() { // returns the first error since the last drain
+    std::unique_lock<std::mutex> lk(m);
+    cv_idle.wait(lk, [&] { return inflight == 0; });
+    const hipError_t e = err;
+    err = hipSuccess;
+    return e;
+  }
+  void shutdown() {
+    if (!th.joinable()) { return; }
+    { std::lock_guard<std::mutex> lk(m); stop = true; cv_job.notify_one(); }
+    th.join();
+    if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+  }
+};
 
 struct sjgpu_ctx {
   int device = 0;
@@ -32,6 +90,12 @@ struct sjgpu_ctx {
   size_t d_idx_words = 0;
   uint8_t *d_out = nullptr;
   size_t d_out_bytes = 0;
+  // overlapped host-buffer path (large documents): upload stream + its two ping-pong events, D2H worker
+  hipStream_t s_in = nullptr;
+  hipEvent_t ev_in[2] = {nullptr, nullptr};
+  copy_worker *worker = nullptr;
+  size_t stream_from = size_t(16) << 20; // documents at least this long take the overlapped path (env SJGPU_STREAM_FROM_MB, 0 = never)
+  size_t stream_chunk = size_t(8) << 20; // range size, a multiple of RANGE_ALIGN (env SJGPU_STREAM_CHUNK_MB)
   // event profiling (sjgpu_profile_*)
   bool profile = false;
   std::vector<hipEvent_t> events; // PROFILE_EVENTS per recorded call
@@ -124,15 +188,98 @@ bool use_fused(const sjgpu_ctx *ctx, size_t len) {
   return ctx->pipeline == 1 || (ctx->pipeline == 2 && (len <= AUTO_FUSED_BELOW || len >= AUTO_FUSED_FROM));
 }
 
+// `len` is the END of the scan (bytes [org.begin, len) are scanned); a whole document has org = {0, 0, 0}
 void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint32_t *idx, size_t idx_words, hipStream_t s,
-                    hipEvent_t *ev, uint32_t carry = 0) {
-  if (fused) { launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, carry, ctx->max_workgroups, s, ev); }
-  else { launch_stage1(buf, len, ctx->masks, ctx->summ, ctx->pref, idx, idx_words, ctx->d_result, carry, s, ev); }
+                    hipEvent_t *ev, scan_origin org = scan_origin{0, 0, 0}) {
+  if (fused) { launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, org, ctx->max_workgroups, s, ev); }
+  else { launch_stage1(buf, len, ctx->masks, ctx->summ, ctx->pref, idx, idx_words, ctx->d_result, org, s, ev); }
 }
 void enqueue_minify(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint8_t *dst, hipStream_t s, hipEvent_t *ev,
-                    uint32_t carry = 0) {
-  if (fused) { launch_minify_fused(buf, len, ctx->desc, dst, ctx->d_result, carry, ctx->max_workgroups, s, ev); }
-  else { launch_minify(buf, len, ctx->summ, ctx->pref, dst, ctx->d_result, carry, s, ev); }
+                    scan_origin org = scan_origin{0, 0, 0}) {
+  if (fused) { launch_minify_fused(buf, len, ctx->desc, dst, ctx->d_result, org, ctx->max_workgroups, s, ev); }
+  else { launch_minify(buf, len, ctx->summ, ctx->pref, dst, ctx->d_result, org, s, ev); }
+}
+
+int ensure_streaming(sjgpu_ctx *ctx) {
+  if (ctx->worker) { return 0; }
+  if (!ctx->s_in) { SJ_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking)); }
+  for (hipEvent_t &e : ctx->ev_in) {
+    if (!e) { SJ_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+  }
+  copy_worker *w = new (std::nothrow) copy_worker();
+  if (!w) { return SJGPU_E_NOMEM; }
+  w->device = ctx->device;
+  hipError_t e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete w; return fail(ctx, e, "copy_worker stream"); }
+  w->th = std::thread([w] { w->run(); });
+  ctx->worker = w;
+  return 0;
+}
+
+// The overlapped host-buffer path (the GPU analogue of the reference's stage1_worker,
+// dom/document_stream-inl.h:16-85): the document is uploaded and scanned in ranges; while range k is scanned and
+// its output travels to the host on the worker's stream, range k+1 is already being uploaded.  The only state
+// between ranges is what one call's result holds: the output cursor and the in-string bit.
+//   op 0: stage 1, out = idx_out (u32 words, room for out_cap words); op 1: minify, out = dst (bytes, room for len)
+int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *out_host, size_t out_cap, sjgpu_scan_result *res_out) {
+  int rc = ensure_streaming(ctx);
+  if (rc) { return rc; }
+  const size_t chunk = ctx->stream_chunk;
+  const size_t unit = (op == 0) ? sizeof(uint32_t) : 1;
+  uint8_t *d_out = (op == 0) ? reinterpret_cast<uint8_t *>(ctx->d_idx) : ctx->d_out;
+  hipStream_t s = ctx->stream;
+  const size_t nranges = (len + chunk - 1) / chunk;
+  auto upload = [&](size_t k) -> hipError_t {
+    const size_t b = k * chunk, e = (b + chunk < len) ? b + chunk : len;
+    hipError_t err = hipMemcpyAsync(ctx->d_in + b, buf + b, e - b, hipMemcpyHostToDevice, ctx->s_in);
+    if (err == hipSuccess) { err = hipEventRecord(ctx->ev_in[k & 1], ctx->s_in); }
+    return err;
+  };
+  hipError_t he = upload(0);
+  uint32_t flags = 0, in_string = 0;
+  uint64_t cursor = 0; // output units produced by the ranges so far
+  sjgpu_scan_result res{0, 0, 0};
+  for (size_t k = 0; k < nranges && he == hipSuccess && rc == 0; k++) {
+    const size_t b = k * chunk, e = (b + chunk < len) ? b + chunk : len;
+    const bool last = (k + 1 == nranges);
+    const scan_origin org{uint64_t(b), uint32_t(cursor), (in_string ? CARRY_IN_STRING : 0u) | CARRY_SHARD | (last ? 0u : CARRY_MORE)};
+    he = hipStreamWaitEvent(s, ctx->ev_in[k & 1], 0);
+    if (he != hipSuccess) { break; }
+    for (int attempt = 0; attempt < 2; attempt++) { // a single-pass range that gives up is re-run on the split pipeline
+      const bool fused = use_fused(ctx, e - b) && attempt == 0;
+      if (op == 0) { enqueue_stage1(ctx, fused, ctx->d_in, e, ctx->d_idx, ctx->d_idx_words, s, nullptr, org); }
+      else { enqueue_minify(ctx, fused, ctx->d_in, e, ctx->d_out, s, nullptr, org); }
+      if (attempt == 0 && !last) { he = upload(k + 1); } // overlaps this range's scan and the previous range's D2H
+      if (he == hipSuccess) { he = hipGetLastError(); }
+      if (he != hipSuccess) { break; }
+      rc = fetch_result(ctx, s, &res);
+      if (rc || !(res.flags & SJGPU_F_INTERNAL)) { break; }
+    }
+    if (he != hipSuccess || rc) { break; }
+    flags |= res.flags & ~uint32_t(SJGPU_F_UNCLOSED_STRING);
+    if (res.flags & (SJGPU_F_INTERNAL | SJGPU_F_IDX_OVERFLOW)) { break; }
+    const uint64_t now = (op == 0) ? uint64_t(res.n) : res.out_len;
+    const uint64_t upto = now + ((op == 0 && last) ? 3 : 0); // the sentinels travel with the last range
+    if (now < cursor || upto > out_cap) { rc = SJGPU_E_OVERFLOW; break; }
+    ctx->worker->submit(static_cast<uint8_t *>(out_host) + cursor * unit, d_out + cursor * unit, size_t(upto - cursor) * unit);
+    cursor = now;
+    in_string = res.flags & SJGPU_F_UNCLOSED_STRING;
+  }
+  // nothing may be left in flight when we return: the caller owns buf and out_host
+  const hipError_t we = ctx->worker->drain();
+  const hipError_t ie = hipStreamSynchronize(ctx->s_in);
+  if (he != hipSuccess) { return fail(ctx, he, "streamed scan"); }
+  if (we != hipSuccess) { return fail(ctx, we, "streamed scan: device-to-host copy"); }
+  if (ie != hipSuccess) { return fail(ctx, ie, "streamed scan: upload"); }
+  if (rc) { return rc; }
+  res_out->n = (op == 0) ? uint32_t(cursor) : 0;
+  res_out->out_len = (op == 0) ? 0 : cursor;
+  res_out->flags = flags | in_string;
+  return 0;
+}
+
+bool take_streamed_path(const sjgpu_ctx *ctx, size_t len) {
+  return ctx->stream_from != 0 && len >= ctx->stream_from && len > ctx->stream_chunk;
 }
 
 } // namespace
@@ -155,6 +302,11 @@ int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out) {
   ctx->device = device;
   if (const char *pl = std::getenv("SJGPU_PIPELINE")) {
     ctx->pipeline = std::strcmp(pl, "split") == 0 ? 0 : (std::strcmp(pl, "fused") == 0 ? 1 : 2);
+  }
+  if (const char *v = std::getenv("SJGPU_STREAM_FROM_MB")) { ctx->stream_from = size_t(std::strtoull(v, nullptr, 10)) << 20; }
+  if (const char *v = std::getenv("SJGPU_STREAM_CHUNK_MB")) {
+    const size_t mb = size_t(std::strtoull(v, nullptr, 10));
+    if (mb >= 1 && mb <= 1024) { ctx->stream_chunk = mb << 20; }
   }
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) {
@@ -183,6 +335,15 @@ void sjgpu_ctx_destroy(sjgpu_ctx *ctx) {
   if (!ctx) { return; }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+  if (ctx->worker) {
+    ctx->worker->shutdown();
+    delete ctx->worker;
+    ctx->worker = nullptr;
+  }
+  for (hipEvent_t &ev : ctx->ev_in) {
+    if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+  }
+  if (ctx->s_in) { (void)hipStreamDestroy(ctx->s_in); ctx->s_in = nullptr; }
   release_workspace(ctx);
   drop_events(ctx);
   if (ctx->h_result) { (void)hipHostFree(ctx->h_result); }
@@ -274,7 +435,7 @@ int sjgpu_stage1_shard_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, i
   if (len > ctx->capacity) { return E_CAPACITY; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
   enqueue_stage1(ctx, use_fused(ctx, len), static_cast<const uint8_t *>(buf_dev), len, static_cast<uint32_t *>(idx_dev), idx_words,
-                 pick(ctx, stream), next_events(ctx), CARRY_SHARD | (in_string ? CARRY_IN_STRING : 0u));
+                 pick(ctx, stream), next_events(ctx), scan_origin{0, 0, CARRY_SHARD | (in_string ? CARRY_IN_STRING : 0u)});
   SJ_TRY(ctx, hipGetLastError());
   return 0;
 }
@@ -287,7 +448,42 @@ int sjgpu_minify_shard_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, i
   if (len > ctx->capacity) { return E_CAPACITY; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
   enqueue_minify(ctx, use_fused(ctx, len), static_cast<const uint8_t *>(buf_dev), len, static_cast<uint8_t *>(dst_dev), pick(ctx, stream),
-                 next_events(ctx), CARRY_SHARD | (in_string ? CARRY_IN_STRING : 0u));
+                 next_events(ctx), scan_origin{0, 0, CARRY_SHARD | (in_string ? CARRY_IN_STRING : 0u)});
+  SJ_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+// ---- ranges of ONE resident buffer, scanned one after the other (streaming upload) ---------
+static int check_range(const sjgpu_ctx *ctx, const void *buf_dev, size_t begin, size_t end) {
+  if (!ctx || !buf_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u) || begin >= end || (begin % RANGE_ALIGN) != 0 ||
+      end > 0xFFFFFFFFull) {
+    return SJGPU_E_BADARG;
+  }
+  return (end - begin > ctx->capacity) ? E_CAPACITY : 0;
+}
+
+int sjgpu_stage1_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin, size_t end, int more, int in_string,
+                              uint32_t n_before, void *idx_dev, size_t idx_words, void *stream) {
+  const int bad = check_range(ctx, buf_dev, begin, end);
+  if (bad) { return bad; }
+  if (!idx_dev || (reinterpret_cast<uintptr_t>(idx_dev) & 15u)) { return SJGPU_E_BADARG; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  const scan_origin org{uint64_t(begin), n_before, CARRY_SHARD | (in_string ? CARRY_IN_STRING : 0u) | (more ? CARRY_MORE : 0u)};
+  enqueue_stage1(ctx, use_fused(ctx, end - begin), static_cast<const uint8_t *>(buf_dev), end, static_cast<uint32_t *>(idx_dev), idx_words,
+                 pick(ctx, stream), next_events(ctx), org);
+  SJ_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int sjgpu_minify_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin, size_t end, int more, int in_string,
+                              uint32_t out_before, void *dst_dev, void *stream) {
+  const int bad = check_range(ctx, buf_dev, begin, end);
+  if (bad) { return bad; }
+  if (!dst_dev || (reinterpret_cast<uintptr_t>(dst_dev) & 15u)) { return SJGPU_E_BADARG; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  const scan_origin org{uint64_t(begin), out_before, CARRY_SHARD | (in_string ? CARRY_IN_STRING : 0u) | (more ? CARRY_MORE : 0u)};
+  enqueue_minify(ctx, use_fused(ctx, end - begin), static_cast<const uint8_t *>(buf_dev), end, static_cast<uint8_t *>(dst_dev),
+                 pick(ctx, stream), next_events(ctx), org);
   SJ_TRY(ctx, hipGetLastError());
   return 0;
 }
@@ -368,23 +564,31 @@ int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint3
   ctx->d_idx_words = idx_bytes / sizeof(uint32_t);
   if (rc) { return rc; }
   hipStream_t s = ctx->stream;
-  SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
   sjgpu_scan_result res;
-  for (int attempt = 0; attempt < 2; attempt++) { // a single-pass call that gives up is re-run on the split pipeline
-    enqueue_stage1(ctx, use_fused(ctx, len) && attempt == 0, ctx->d_in, len, ctx->d_idx, ctx->d_idx_words, s, nullptr);
-    SJ_TRY(ctx, hipGetLastError());
-    rc = fetch_result(ctx, s, &res);
+  const bool streamed = take_streamed_path(ctx, len);
+  if (streamed) { // large document: upload, scan and download overlap range by range; the offsets are on the host afterwards
+    rc = run_streamed(ctx, 0, buf, len, idx_out, idx_words, &res);
     if (rc) { return rc; }
-    if (!(res.flags & SJGPU_F_INTERNAL)) { break; }
+  } else {
+    SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
+    for (int attempt = 0; attempt < 2; attempt++) { // a single-pass call that gives up is re-run on the split pipeline
+      enqueue_stage1(ctx, use_fused(ctx, len) && attempt == 0, ctx->d_in, len, ctx->d_idx, ctx->d_idx_words, s, nullptr);
+      SJ_TRY(ctx, hipGetLastError());
+      rc = fetch_result(ctx, s, &res);
+      if (rc) { return rc; }
+      if (!(res.flags & SJGPU_F_INTERNAL)) { break; }
+    }
   }
   if (res.flags & SJGPU_F_INTERNAL) { return E_UNEXPECTED; }
   if (res.flags & SJGPU_F_IDX_OVERFLOW) { return E_UNEXPECTED; }
   // the two early exits of finish() need no index traffic (json_structural_indexer.h:255-263)
   if ((res.flags & SJGPU_F_UNCLOSED_STRING) && mode == SJGPU_REGULAR) { return E_UNCLOSED; }
   if (res.flags & SJGPU_F_UNESCAPED_CTRL) { return 14; }
-  if (size_t(res.n) + 3 > idx_words) { return SJGPU_E_OVERFLOW; }
-  SJ_TRY(ctx, hipMemcpyAsync(idx_out, ctx->d_idx, (size_t(res.n) + 3) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  SJ_TRY(ctx, hipStreamSynchronize(s));
+  if (!streamed) {
+    if (size_t(res.n) + 3 > idx_words) { return SJGPU_E_OVERFLOW; }
+    SJ_TRY(ctx, hipMemcpyAsync(idx_out, ctx->d_idx, (size_t(res.n) + 3) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    SJ_TRY(ctx, hipStreamSynchronize(s));
+  }
   return sjgpu_stage1_finish_host(buf, len, mode, idx_out, res.n, res.flags, n_io, next_io);
 }
 
@@ -400,20 +604,28 @@ int sjgpu_minify(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, uint8_t *dst, s
   rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_out), &ctx->d_out_bytes, ctx->capacity + 16);
   if (rc) { return rc; }
   hipStream_t s = ctx->stream;
-  SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
   sjgpu_scan_result res;
-  for (int attempt = 0; attempt < 2; attempt++) {
-    enqueue_minify(ctx, use_fused(ctx, len) && attempt == 0, ctx->d_in, len, ctx->d_out, s, nullptr);
-    SJ_TRY(ctx, hipGetLastError());
-    rc = fetch_result(ctx, s, &res);
+  const bool streamed = take_streamed_path(ctx, len);
+  if (streamed) {
+    rc = run_streamed(ctx, 1, buf, len, dst, len, &res);
     if (rc) { return rc; }
-    if (!(res.flags & SJGPU_F_INTERNAL)) { break; }
+  } else {
+    SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
+    for (int attempt = 0; attempt < 2; attempt++) {
+      enqueue_minify(ctx, use_fused(ctx, len) && attempt == 0, ctx->d_in, len, ctx->d_out, s, nullptr);
+      SJ_TRY(ctx, hipGetLastError());
+      rc = fetch_result(ctx, s, &res);
+      if (rc) { return rc; }
+      if (!(res.flags & SJGPU_F_INTERNAL)) { break; }
+    }
   }
   if (res.flags & SJGPU_F_INTERNAL) { return E_UNEXPECTED; }
   if (res.flags & SJGPU_F_UNCLOSED_STRING) { return E_UNCLOSED; }
   if (res.out_len > len) { return E_UNEXPECTED; }
-  SJ_TRY(ctx, hipMemcpyAsync(dst, ctx->d_out, res.out_len, hipMemcpyDeviceToHost, s));
-  SJ_TRY(ctx, hipStreamSynchronize(s));
+  if (!streamed) {
+    SJ_TRY(ctx, hipMemcpyAsync(dst, ctx->d_out, res.out_len, hipMemcpyDeviceToHost, s));
+    SJ_TRY(ctx, hipStreamSynchronize(s));
+  }
   *dst_len = res.out_len;
   return 0;
 }

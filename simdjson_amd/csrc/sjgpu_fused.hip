@@ -54,11 +54,11 @@ struct lookback_state {
   u32 fq, fout, fin;
   long long end;
 };
-__device__ __forceinline__ void lookback_load(const u64 *desc, long long end, u32 lane, u64 (&d)[LOOKBACK_LOADS], u32 carry) {
+__device__ __forceinline__ void lookback_load(const u64 *desc, long long end, u32 lane, u64 (&d)[LOOKBACK_LOADS], scan_origin org) {
 #pragma unroll
   for (u32 w = 0; w < LOOKBACK_LOADS; w++) {
     const long long t = end - 1 - (long long)(w * 64 + lane);
-    d[w] = (t >= 0) ? desc_load(desc + t) : make_incl(carry & CARRY_IN_STRING, 0); // in front of tile 0: the call's carry-in, cursor 0
+    d[w] = (t >= 0) ? desc_load(desc + t) : make_incl(org.carry & CARRY_IN_STRING, org.base0); // in front of tile 0: the call's carry-in and cursor
   }
 }
 // 1 = finished (S, B valid), 0 = a needed aggregate is not published yet (reload from st.end), -1 = poisoned chain
@@ -101,7 +101,7 @@ __device__ __forceinline__ int lookback_consume(const u64 (&d)[LOOKBACK_LOADS], 
   return 0; // whole batch consumed, no inclusive prefix yet: keep walking from st.end
 }
 // `preloaded`: descriptors already requested with lookback_load(desc, tile, ...) some time ago (may be null)
-__device__ __forceinline__ bool lookback(const u64 *desc, u32 tile, u32 lane, u32 &S, u32 &B, u32 carry,
+__device__ __forceinline__ bool lookback(const u64 *desc, u32 tile, u32 lane, u32 &S, u32 &B, scan_origin org,
                                          const u64 (*preloaded)[LOOKBACK_LOADS] = nullptr) {
   lookback_state st{0u, 0u, 0u, (long long)tile};
   if (preloaded) {
@@ -111,7 +111,7 @@ __device__ __forceinline__ bool lookback(const u64 *desc, u32 tile, u32 lane, u3
   const u64 t_start = wall_clock64();
   for (;;) {
     u64 d[LOOKBACK_LOADS];
-    lookback_load(desc, st.end, lane, d, carry);
+    lookback_load(desc, st.end, lane, d, org);
     const int r = lookback_consume(d, st, lane, S, B);
     if (r != 0) { return r > 0; }
     if (wall_clock64() - t_start > LOOKBACK_TIMEOUT_TICKS) { return false; }
@@ -132,7 +132,8 @@ template <int OP, bool TRACE, u32 WC>
 __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc,
                                                u32 *__restrict__ ticket, u32 ntiles, void *__restrict__ out, u64 out_words,
                                                scan_result_dev *__restrict__ result, u64 *__restrict__ trace, u32 trace_tiles,
-                                               u32 carry) {
+                                               scan_origin org) {
+  const u32 carry = org.carry;
 #define SJ_STAMP(k) do { if (TRACE && threadIdx.x == 0 && tile < trace_tiles) { trace[u64(tile) * TRACE_STAMPS + (k)] = wall_clock64(); } } while (0)
   constexpr u32 STAGE_WORDS = (OP == 0) ? EMIT_STAGE_WORDS : (MINIFY_STAGE_BYTES / 4);
   static_assert(WC == 1 || WC == 4, "the mask FIFO is written for 1 or 4 chunks per wave");
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
     SJ_STAMP(1); // ticket known
 
     // ---- phase 1: scan my 4 chunks with a relative in-string state; masks go into the register FIFO ----
-    const u64 wave_start = u64(tile) * FUSED_TILE_BYTES + u64(wave) * FUSED_WAVE_BYTES;
+    const u64 wave_start = org.begin + u64(tile) * FUSED_TILE_BYTES + u64(wave) * FUSED_WAVE_BYTES;
     u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0; // slot 3 = oldest chunk
     u32 n_out = 0, n_in = 0;
     bool f_ci = false, f_co = false, f_ue = false; // wave-uniform error facts
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
       }
       parity = wc.s;
       // a multi-byte sequence still open at the very end of the input (utf8_lookup4_algorithm.h:164-171)
-      if (OP == 0 && wave_start + FUSED_WAVE_BYTES >= len && (wc.utf8 & UTF8_CARRY_OPEN)) { f_ue = true; }
+      if (OP == 0 && wave_start + FUSED_WAVE_BYTES >= len && !(carry & CARRY_MORE) && (wc.utf8 & UTF8_CARRY_OPEN)) { f_ue = true; }
     }
     SJ_STAMP(2); // wave 0 finished scanning
     {
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
       }
       if (lane == 0) { desc_store(desc + tile, make_agg(tq, tout, tin)); }
       u32 S = 0, B = 0;
-      const bool ok = lookback(desc, tile, lane, S, B, carry);
+      const bool ok = lookback(desc, tile, lane, S, B, org);
       SJ_STAMP(4); // look-back done
       if (lane == 0) {
         if (ok) {
@@ -329,7 +330,8 @@ constexpr u32 NO_TILE = 0xFFFFFFFFu;
 template <int OP>
 __global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc,
                                                          u32 *__restrict__ ticket, u32 ntiles, void *__restrict__ out,
-                                                         u64 out_words, scan_result_dev *__restrict__ result, u32 carry) {
+                                                         u64 out_words, scan_result_dev *__restrict__ result, scan_origin org) {
+  const u32 carry = org.carry;
   constexpr u32 WC = FUSED_WAVE_CHUNKS;
   constexpr u32 STAGE_WORDS = (OP == 0) ? emit_stage_words(PIPE_WINDOW) : (MINIFY_STAGE_BYTES / 4);
   constexpr u32 WAVE_BYTES = WC * CHUNK_BYTES;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ 
     // ---- scan the new tile into the register FIFO ------------------------------------------------------------
     u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0; // slot 3 = oldest chunk
     if (have) {
-      const u64 wave_start = u64(tile) * FUSED_TILE_BYTES + u64(wave) * WAVE_BYTES;
+      const u64 wave_start = org.begin + u64(tile) * FUSED_TILE_BYTES + u64(wave) * WAVE_BYTES;
       u32 n_out = 0, n_in = 0, parity = 0;
       bool f_ci = false, f_co = false, f_ue = false;
       if (wave_start < len) {
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ 
           b3 = b2; b2 = b1; b1 = b0; b0 = b;
         }
         parity = wc.s;
-        if (OP == 0 && wave_start + WAVE_BYTES >= len && (wc.utf8 & UTF8_CARRY_OPEN)) { f_ue = true; }
+        if (OP == 0 && wave_start + WAVE_BYTES >= len && !(carry & CARRY_MORE) && (wc.utf8 & UTF8_CARRY_OPEN)) { f_ue = true; }
       }
       const u32 t_out = wave_sum(n_out), t_in = wave_sum(n_in);
       u32 f = 0;
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ 
       if (pend) {
         const u32 tq = sh_agg[cur ^ 1u][0], tout = sh_agg[cur ^ 1u][1], tin = sh_agg[cur ^ 1u][2];
         u32 S = 0, B = 0;
-        const bool ok = lookback(desc, pend_tile, lane, S, B, carry);
+        const bool ok = lookback(desc, pend_tile, lane, S, B, org);
         if (lane == 0) {
           if (ok) {
             const u32 total = B + (S ? tin : tout), s_end = S ^ tq;
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ 
 
     // ---- every wave: emit its share of the pending tile from the LDS masks -----------------------------------------
     if (pend && sh_prefix[2] != 0u) {
-      const u64 wave_start = u64(pend_tile) * FUSED_TILE_BYTES + u64(wave) * WAVE_BYTES;
+      const u64 wave_start = org.begin + u64(pend_tile) * FUSED_TILE_BYTES + u64(wave) * WAVE_BYTES;
       u32 s = sh_prefix[0], base = sh_prefix[1];
       for (u32 v = 0; v < wave; v++) {
         base += s ? sh_wave[cur ^ 1u][v][2] : sh_wave[cur ^ 1u][v][1];
@@ -524,10 +526,10 @@ static inline void mark(hipEvent_t *ev, int k, hipStream_t stream) {
 
 template <u32 WC>
 static void launch_fused_wc(int op, const uint8_t *buf, uint64_t len, uint64_t *desc, void *out, uint64_t out_words,
-                            scan_result_dev *result, uint32_t carry, uint32_t max_workgroups, hipStream_t stream,
+                            scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
                             hipEvent_t *ev, uint64_t *trace, uint32_t trace_tiles) {
   constexpr u64 tile_bytes = u64(FUSED_WAVES) * WC * CHUNK_BYTES;
-  const u32 ntiles = u32((len + tile_bytes - 1) / tile_bytes);
+  const u32 ntiles = u32((len - org.begin + tile_bytes - 1) / tile_bytes);
   u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles);
   // result, descriptors and ticket are cleared by ONE memset when the context laid them out back to back
   if (reinterpret_cast<uint64_t *>(result + 1) == desc) {
@@ -541,13 +543,13 @@ static void launch_fused_wc(int op, const uint8_t *buf, uint64_t len, uint64_t *
   mark(ev, 0, stream);
   if (trace) {
     hipLaunchKernelGGL((k_fused<0, true, WC>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words,
-                       result, trace, trace_tiles, carry);
+                       result, trace, trace_tiles, org);
   } else if (op == 0) {
     hipLaunchKernelGGL((k_fused<0, false, WC>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words,
-                       result, no_trace, 0u, carry);
+                       result, no_trace, 0u, org);
   } else {
     hipLaunchKernelGGL((k_fused<1, false, WC>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words,
-                       result, no_trace, 0u, carry);
+                       result, no_trace, 0u, org);
   }
   mark(ev, 1, stream);
   mark(ev, 2, stream);
@@ -555,15 +557,15 @@ static void launch_fused_wc(int op, const uint8_t *buf, uint64_t len, uint64_t *
 }
 
 static void launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *desc, void *out, uint64_t out_words,
-                         scan_result_dev *result, uint32_t carry, uint32_t max_workgroups, hipStream_t stream,
+                         scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
                          hipEvent_t *ev, uint64_t *trace = nullptr, uint32_t trace_tiles = 0) {
   static const bool plain = std::getenv("SJGPU_FUSED_PLAIN") != nullptr; // A/B switch: the non-pipelined large-input kernel
-  if (len <= FUSED_SMALL_BELOW && !trace) {
-    launch_fused_wc<1>(op, buf, len, desc, out, out_words, result, carry, max_workgroups, stream, ev, trace, trace_tiles);
+  if (len - org.begin <= FUSED_SMALL_BELOW && !trace) {
+    launch_fused_wc<1>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles);
   } else if (trace || plain) {
-    launch_fused_wc<FUSED_WAVE_CHUNKS>(op, buf, len, desc, out, out_words, result, carry, max_workgroups, stream, ev, trace, trace_tiles);
+    launch_fused_wc<FUSED_WAVE_CHUNKS>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles);
   } else {
-    const u32 ntiles = u32((len + FUSED_TILE_BYTES - 1) / FUSED_TILE_BYTES);
+    const u32 ntiles = u32((len - org.begin + FUSED_TILE_BYTES - 1) / FUSED_TILE_BYTES);
     u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles);
     if (reinterpret_cast<uint64_t *>(result + 1) == desc) {
       (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev) + (size_t(ntiles) + 1) * sizeof(u64), stream);
@@ -576,9 +578,9 @@ static void launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *des
     const u32 grid = cap < max_workgroups ? cap : max_workgroups;
     mark(ev, 0, stream);
     if (op == 0) {
-      hipLaunchKernelGGL(k_fused_pipelined<0>, dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result, carry);
+      hipLaunchKernelGGL(k_fused_pipelined<0>, dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result, org);
     } else {
-      hipLaunchKernelGGL(k_fused_pipelined<1>, dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result, carry);
+      hipLaunchKernelGGL(k_fused_pipelined<1>, dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result, org);
     }
     mark(ev, 1, stream);
     mark(ev, 2, stream);
@@ -587,17 +589,17 @@ static void launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *des
 }
 
 void launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
-                         scan_result_dev *result, uint32_t carry, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev) {
-  launch_fused(0, buf, len, desc, idx, idx_words, result, carry, max_workgroups, stream, ev);
+                         scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev) {
+  launch_fused(0, buf, len, desc, idx, idx_words, result, org, max_workgroups, stream, ev);
 }
 void launch_stage1_fused_traced(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
                                 scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, uint64_t *trace,
                                 uint32_t trace_tiles) {
-  launch_fused(0, buf, len, desc, idx, idx_words, result, 0u, max_workgroups, stream, nullptr, trace, trace_tiles);
+  launch_fused(0, buf, len, desc, idx, idx_words, result, scan_origin{0, 0, 0}, max_workgroups, stream, nullptr, trace, trace_tiles);
 }
 void launch_minify_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint8_t *dst, scan_result_dev *result,
-                         uint32_t carry, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev) {
-  launch_fused(1, buf, len, desc, dst, 0, result, carry, max_workgroups, stream, ev);
+                         scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev) {
+  launch_fused(1, buf, len, desc, dst, 0, result, org, max_workgroups, stream, ev);
 }
 
 } // namespace sjgpu

@@ -73,23 +73,33 @@ constexpr int PROFILE_SLOTS = 3;
 constexpr int PROFILE_EVENTS = PROFILE_SLOTS + 1;
 // carry: state in front of byte 0 when the buffer is a shard of a larger document; 0 for a whole document.
 // Shards are cut by sjgpu_clean_cut, so the in-string bit is the ONLY state that crosses a cut.
-constexpr uint32_t CARRY_IN_STRING = 1u; // byte 0 is inside a string
-constexpr uint32_t CARRY_SHARD = 2u;     // minify: report the shard's out_len even if the shard ends inside a string
+constexpr uint32_t CARRY_IN_STRING = 1u; // the first byte scanned is inside a string
+constexpr uint32_t CARRY_SHARD = 2u;     // minify: report out_len even if the scan ends inside a string
+constexpr uint32_t CARRY_MORE = 4u;      // the scan does not end at the end of the input: no "sequence open at EOF" check
+// A scan covers bytes [begin, len) of a buffer whose bytes [0, begin) are resident too (the look-back of escapes,
+// previous scalar and UTF-8 state reads them); begin is a multiple of RANGE_ALIGN.  Offsets stay relative to byte 0
+// and are appended at output slot base0.  A whole document is {0, 0, 0}.
+struct scan_origin {
+  uint64_t begin;
+  uint32_t base0;
+  uint32_t carry;
+};
+constexpr uint64_t RANGE_ALIGN = uint64_t(1) << 20; // one resolve group = 16 large tiles = 64 small tiles
 void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *summ, seg_prefix *pref, uint32_t *idx,
-                   uint64_t idx_words, scan_result_dev *result, uint32_t carry, hipStream_t stream, hipEvent_t *ev);
+                   uint64_t idx_words, scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev);
 void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_prefix *pref, uint8_t *dst,
-                   scan_result_dev *result, uint32_t carry, hipStream_t stream, hipEvent_t *ev);
+                   scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev);
 void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *result, hipStream_t stream); // result->n = parity
 void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *result, hipStream_t stream, hipEvent_t *ev);
 // single-pass variants: desc holds num_fused_tiles(capacity)+1 words; only profile slot 0 is used
 void launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
-                         scan_result_dev *result, uint32_t carry, uint32_t max_workgroups, hipStream_t stream,
+                         scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
                          hipEvent_t *ev);
 void launch_stage1_fused_traced(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
                                 scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, uint64_t *trace,
                                 uint32_t trace_tiles); // 8 wall_clock64 stamps (100 MHz) per tile
 void launch_minify_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint8_t *dst, scan_result_dev *result,
-                         uint32_t carry, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev);
+                         scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev);
 
 } // namespace sjgpu
 #endif

@@ -34,10 +34,11 @@ namespace {
 // value.  The true parity chain is still scanned: a resolved segment whose true carry-in differs from the
 // derived one contains a control character inside a string and raises the same error the reference raises.
 __global__ __launch_bounds__(64) void k_stage1_summarize(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ mask0,
-                                                         u64 *__restrict__ mask1, seg_summary *__restrict__ summ) {
+                                                         u64 *__restrict__ mask1, seg_summary *__restrict__ summ,
+                                                         scan_origin org) {
   const u32 lane = lane_id();
-  const u32 seg = blockIdx.x;
-  const u64 seg_start = u64(seg) * SEG_BYTES;
+  const u32 seg = blockIdx.x; // relative to the scan's origin: workspace index
+  const u64 seg_start = org.begin + u64(seg) * SEG_BYTES;
   const u64 lane_off = u64(lane) * BLOCK_BYTES;
   const u32 lookback = lookback_issue(buf, seg_start, lane); // consumed after chunk 0 has been requested
   wave_carry wc{0u, 0u, 0u, 0u};
@@ -71,19 +72,19 @@ __global__ __launch_bounds__(64) void k_stage1_summarize(const u8 *__restrict__ 
       const u64 structural = m.cand & ~(m.string_tail ^ flip);
       n_a += u32(popc64(structural));
       ctrl_a |= m.ctrl & (m.in_string ^ flip);
-      mask0[pos / BLOCK_BYTES] = structural;
+      mask0[(pos - org.begin) / BLOCK_BYTES] = structural;
     } else {
       n_a += u32(popc64(m.cand));
       n_b += u32(popc64(m.cand & m.string_tail));
       ctrl_a |= m.ctrl & m.in_string;  // offends if the relative view is the true one
       ctrl_b |= m.ctrl & ~m.in_string; // offends if the segment really starts inside a string
-      mask0[pos / BLOCK_BYTES] = m.cand;
-      mask1[pos / BLOCK_BYTES] = m.string_tail;
+      mask0[(pos - org.begin) / BLOCK_BYTES] = m.cand;
+      mask1[(pos - org.begin) / BLOCK_BYTES] = m.string_tail;
     }
   }
   // a multi-byte sequence still open at the very end of the input (utf8_lookup4_algorithm.h:164-171);
   // when len is not a multiple of the chunk the space padding has already flagged it.
-  if (seg_start + SEG_BYTES >= len && (wc.utf8 & UTF8_CARRY_OPEN)) { uerr |= 1; }
+  if (seg_start + SEG_BYTES >= len && !(org.carry & CARRY_MORE) && (wc.utf8 & UTF8_CARRY_OPEN)) { uerr |= 1; }
   const u32 ta = wave_sum(n_a), tb = wave_sum(n_b);
   const bool any_a = __ballot(ctrl_a != 0) != 0, any_b = __ballot(ctrl_b != 0) != 0;
   u32 flags = wc.s ? SF_PARITY : 0u;
@@ -136,7 +137,8 @@ __global__ __launch_bounds__(RESOLVE_THREADS) void k_resolve_segments(const seg_
                                                                      seg_prefix *__restrict__ pref, u32 nseg, u64 len,
                                                                      u32 *__restrict__ idx, u64 idx_words,
                                                                      scan_result_dev *__restrict__ result, int what,
-                                                                     u32 carry) {
+                                                                     scan_origin org) {
+  const u32 carry = org.carry;
   __shared__ u32 sh[RESOLVE_THREADS];
   __shared__ u32 sh_flags;
   const u32 tid = threadIdx.x;
@@ -160,7 +162,8 @@ __global__ __launch_bounds__(RESOLVE_THREADS) void k_resolve_segments(const seg_
     st ^= x.flags & SF_PARITY;
   }
   u32 total;
-  u32 base = block_excl_scan(cnt, sh, false, total);
+  u32 base = block_excl_scan(cnt, sh, false, total) + org.base0; // output continues where the previous range stopped
+  total += org.base0;
   if (flags) { atomicOr(&sh_flags, flags); }
   // pass 3: per-segment carry-in
   st = s;
@@ -247,11 +250,11 @@ __device__ __forceinline__ seg_prefix segment_prefix(const seg_summary *__restri
 __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask0, const u64 *__restrict__ mask1,
                                                     const seg_summary *__restrict__ summ, const seg_prefix *__restrict__ gpref,
                                                     u64 len, u32 *__restrict__ idx, u64 idx_words,
-                                                    scan_result_dev *__restrict__ result) {
+                                                    scan_result_dev *__restrict__ result, scan_origin org) {
   __shared__ __attribute__((aligned(16))) u32 stage[EMIT_STAGE_WORDS];
   const u32 lane = lane_id();
   const u32 seg = blockIdx.x;
-  const u64 seg_start = u64(seg) * SEG_BYTES;
+  const u64 seg_start = org.begin + u64(seg) * SEG_BYTES;
   // Independent loads first, consumers later: the four chunks' masks (8 bytes per lane each) are requested before
   // the group-prefix fold, so the segment pays ONE round trip to HBM, not one per chunk plus one for the prefix.
   const bool resolved = (summ[seg].flags & SF_RESOLVED) != 0; // masks are already final
@@ -260,8 +263,8 @@ __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask
   for (u32 c = 0; c < SEG_CHUNKS; c++) {
     const u64 pos = seg_start + u64(c) * CHUNK_BYTES + u64(lane) * BLOCK_BYTES;
     const bool live = seg_start + u64(c) * CHUNK_BYTES < len;
-    m0[c] = live ? mask0[pos / BLOCK_BYTES] : 0ull;
-    m1[c] = (live && !resolved) ? mask1[pos / BLOCK_BYTES] : 0ull;
+    m0[c] = live ? mask0[(pos - org.begin) / BLOCK_BYTES] : 0ull;
+    m1[c] = (live && !resolved) ? mask1[(pos - org.begin) / BLOCK_BYTES] : 0ull;
   }
   const seg_prefix pf = segment_prefix(summ, gpref, seg, lane);
   u32 base = pf.base;
@@ -282,10 +285,11 @@ __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask
 // =====================================================================================================
 // minify: summarize (kept-byte counts for both hypotheses) -> resolve -> re-scan + byte compaction
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_minify_summarize(const u8 *__restrict__ buf, u64 len, seg_summary *__restrict__ summ) {
+__global__ __launch_bounds__(64) void k_minify_summarize(const u8 *__restrict__ buf, u64 len, seg_summary *__restrict__ summ,
+                                                         scan_origin org) {
   const u32 lane = lane_id();
   const u32 seg = blockIdx.x;
-  const u64 seg_start = u64(seg) * SEG_BYTES;
+  const u64 seg_start = org.begin + u64(seg) * SEG_BYTES;
   const u32 lookback = lookback_issue(buf, seg_start, lane);
   wave_carry wc{0u, 0u, 0u, 0u};
   u32 kept_out = 0, kept_in = 0;
@@ -314,14 +318,14 @@ __global__ __launch_bounds__(64) void k_minify_summarize(const u8 *__restrict__ 
 }
 
 __global__ __launch_bounds__(64) void k_minify_emit(const u8 *__restrict__ buf, u64 len, const seg_summary *__restrict__ summ,
-                                                    const seg_prefix *__restrict__ gpref, u8 *__restrict__ dst) {
+                                                    const seg_prefix *__restrict__ gpref, u8 *__restrict__ dst, scan_origin org) {
   __shared__ __attribute__((aligned(16))) u8 stage[MINIFY_STAGE_BYTES];
   __shared__ u32 lut[MINIFY_LUT_WORDS];
   const u32 lane = lane_id();
   init_compaction_lut(lut, lane);
   clear_minify_stage(stage, lane);
   const u32 seg = blockIdx.x;
-  const u64 seg_start = u64(seg) * SEG_BYTES;
+  const u64 seg_start = org.begin + u64(seg) * SEG_BYTES;
   const u32 lookback = lookback_issue(buf, seg_start, lane);
   const seg_prefix pf = segment_prefix(summ, gpref, seg, lane);
   wave_carry wc{0u, 0u, 0u, 0u};
@@ -413,36 +417,37 @@ static inline void mark(hipEvent_t *ev, int k, hipStream_t stream) {
 }
 
 void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *summ, seg_prefix *pref, uint32_t *idx,
-                   uint64_t idx_words, scan_result_dev *result, uint32_t carry, hipStream_t stream, hipEvent_t *ev) {
-  const u32 nseg = num_segments(len);
+                   uint64_t idx_words, scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev) {
+  const u32 nseg = num_segments(len - org.begin);
   mark(ev, 0, stream);
   u64 *mask0 = reinterpret_cast<u64 *>(masks);
   u64 *mask1 = mask0 + size_t(nseg) * (SEG_BYTES / BLOCK_BYTES); // second plane, only written by unresolved segments
-  hipLaunchKernelGGL(k_stage1_summarize, dim3(nseg), dim3(64), 0, stream, buf, len, mask0, mask1, summ);
+  hipLaunchKernelGGL(k_stage1_summarize, dim3(nseg), dim3(64), 0, stream, buf, len, mask0, mask1, summ, org);
   mark(ev, 1, stream);
   const u32 ngroups = (nseg + RESOLVE_GROUP - 1) / RESOLVE_GROUP;
   seg_summary *gsum = summ + nseg; // the group summaries live behind the segment summaries
   hipLaunchKernelGGL(k_resolve_groups, dim3(ngroups), dim3(64), 0, stream, summ, gsum, nseg);
   hipLaunchKernelGGL(k_resolve_segments, dim3(1), dim3(RESOLVE_THREADS), 0, stream, gsum, pref, ngroups, len, idx, idx_words,
-                     result, 0, carry);
+                     result, 0, org);
   mark(ev, 2, stream);
-  hipLaunchKernelGGL(k_stage1_emit, dim3(nseg), dim3(64), 0, stream, mask0, mask1, summ, pref, len, idx, idx_words, result);
+  hipLaunchKernelGGL(k_stage1_emit, dim3(nseg), dim3(64), 0, stream, mask0, mask1, summ, pref, len, idx, idx_words, result,
+                     org);
   mark(ev, 3, stream);
 }
 
 void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_prefix *pref, uint8_t *dst,
-                   scan_result_dev *result, uint32_t carry, hipStream_t stream, hipEvent_t *ev) {
-  const u32 nseg = num_segments(len);
+                   scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev) {
+  const u32 nseg = num_segments(len - org.begin);
   mark(ev, 0, stream);
-  hipLaunchKernelGGL(k_minify_summarize, dim3(nseg), dim3(64), 0, stream, buf, len, summ);
+  hipLaunchKernelGGL(k_minify_summarize, dim3(nseg), dim3(64), 0, stream, buf, len, summ, org);
   mark(ev, 1, stream);
   const u32 ngroups = (nseg + RESOLVE_GROUP - 1) / RESOLVE_GROUP;
   seg_summary *gsum = summ + nseg;
   hipLaunchKernelGGL(k_resolve_groups, dim3(ngroups), dim3(64), 0, stream, summ, gsum, nseg);
   hipLaunchKernelGGL(k_resolve_segments, dim3(1), dim3(RESOLVE_THREADS), 0, stream, gsum, pref, ngroups, len,
-                     static_cast<u32 *>(nullptr), u64(0), result, 1, carry);
+                     static_cast<u32 *>(nullptr), u64(0), result, 1, org);
   mark(ev, 2, stream);
-  hipLaunchKernelGGL(k_minify_emit, dim3(nseg), dim3(64), 0, stream, buf, len, summ, pref, dst);
+  hipLaunchKernelGGL(k_minify_emit, dim3(nseg), dim3(64), 0, stream, buf, len, summ, pref, dst, org);
   mark(ev, 3, stream);
 }
 

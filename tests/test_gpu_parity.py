@@ -392,14 +392,18 @@ def test_document_shards_equal_the_whole_scan(gpu, orc):
     bad[len(bad) // 3] = 0xFF
     docs["invalid UTF-8"] = bad
     alphabet = np.frombuffer(b'"\\ ,:[]{}ab1\n\t\xc3\xa9\xe2\x82\xac', np.uint8)
+    docs["random soup (control characters in strings)"] = alphabet[rng.integers(0, len(alphabet), 200000)].copy()
+    alphabet = alphabet[(alphabet > 0x1F)]
     docs["random soup"] = alphabet[rng.integers(0, len(alphabet), 200000)].copy()
     for name, a in docs.items():
         whole, wflags = orc.scan(a)
         oerr, omin = orc.minify(a)
         for parts in (2, 3, 8):
             offs, flags, mini = _scan_in_shards(gpu, a, parts)
-            assert np.array_equal(offs, whole.astype(np.int64)), (name, parts, first_diff(offs, whole.astype(np.int64)))
             assert sharded.document_flags(flags) == wflags, (name, parts, flags, wflags)
+            if wflags & capi.F_UNESCAPED_CTRL:
+                continue  # UNESCAPED_CHARS: the reference returns before publishing n, the offsets are unobservable
+            assert np.array_equal(offs, whole.astype(np.int64)), (name, parts, first_diff(offs, whole.astype(np.int64)))
             if oerr == 0:  # an unclosed string voids the whole document's output (json_minifier.h:42-47)
                 assert np.array_equal(mini, omin), (name, parts, first_diff(mini, omin))
             else:
@@ -417,6 +421,89 @@ def test_full_size_document_in_eight_shards(orc):
     oerr, on, oidx = orc.stage1(a, 0)
     assert oerr == 0 and sharded.document_flags(flags) == 0 and len(offs) == on
     assert orc.fnv(offs.astype(np.uint32)) == orc.fnv(oidx[:on]), first_diff(offs, oidx[:on].astype(np.int64))
+    p.close()
+
+
+# ---- ranges of one resident buffer + the overlapped host-buffer path built on them --------------
+def _range_docs():
+    tw = corpus.twitter_like(5 << 20, 12)[0]
+    docs = {
+        "twitter_like 5 MiB (multi-byte UTF-8 and escapes at the range boundaries)": tw,
+        "large_random 3.5 MiB": corpus.large_random((7 << 20) // 2, 12)[0],
+        "ends inside a string": np.concatenate([tw[: 3 << 20], np.frombuffer(b' "dangling text', np.uint8)]),
+    }
+    # the 1 MiB boundary inside a string, inside a backslash run (odd and even), inside a 4-byte character
+    M = 1 << 20
+    for name, filler in (("backslash run across the boundary, odd", b"\\" * 7), ("backslash run across the boundary, even", b"\\" * 8),
+                         ("4-byte character across the boundary", "\U0001F600".encode()), ("quote exactly at the boundary", b'"')):
+        for shift in (0, 1, 2, 3):
+            head = b'["' + b"a" * (M - 2 - shift)
+            body = filler + (b"" if filler == b'"' else b'x"') + b', "tail", {"k": [1, 2, 3]}, "' + b"b" * (M + 77) + b'"]'
+            docs[f"{name} (-{shift})"] = np.frombuffer(head + body, np.uint8)
+    bad = tw.copy()
+    bad[(2 << 20) - 1] = 0xF0  # truncated 4-byte lead just before a range boundary
+    docs["invalid UTF-8 at a range boundary"] = bad
+    return docs
+
+
+def test_ranges_equal_the_whole_scan(gpu, orc):
+    import torch
+    stream = torch.cuda.current_stream().cuda_stream
+    for name, a in _range_docs().items():
+        L = len(a)
+        whole, wflags = orc.scan(a)
+        oerr, omin = orc.minify(a)
+        buf = torch.from_numpy(a.copy()).cuda()
+        for chunk in (1 << 20, 3 << 20):
+            idx = torch.full((L + 3,), -1, dtype=torch.int32, device="cuda")
+            dst = torch.zeros(L + 16, dtype=torch.uint8, device="cuda")
+            n = out = s_idx = s_min = flags = 0
+            for b in range(0, L, chunk):
+                e = min(b + chunk, L)
+                gpu.stage1_range_device(buf.data_ptr(), b, e, e < L, s_idx, n, idx.data_ptr(), L + 3, stream)
+                n, f, _ = gpu.result(stream)
+                assert f & (capi.F_INTERNAL | capi.F_IDX_OVERFLOW) == 0
+                flags |= f & ~1
+                s_idx = f & 1
+                gpu.minify_range_device(buf.data_ptr(), b, e, e < L, s_min, out, dst.data_ptr(), stream)
+                _, mf, out = gpu.result(stream)
+                s_min = mf & 1
+            assert (flags | s_idx) == wflags and s_min == (wflags & 1), (name, chunk, flags, s_idx, wflags)
+            if not (wflags & capi.F_UNESCAPED_CTRL):
+                host = idx[: n + 3].cpu().numpy().view(np.uint32)
+                assert n == len(whole) and np.array_equal(host[:n], whole), (name, chunk, first_diff(host[:n], whole))
+                assert list(host[n:]) == [L, L, 0]
+            if oerr == 0:
+                got = dst[:out].cpu().numpy()
+                assert np.array_equal(got, omin), (name, chunk, first_diff(got, omin))
+
+
+def test_overlapped_host_path(orc, monkeypatch):
+    """sjgpu_stage1 / sjgpu_minify with host buffers, forced through the range-by-range path with 1 MiB ranges
+    (and once with the defaults on a document large enough to take it by itself)."""
+    monkeypatch.setenv("SJGPU_STREAM_FROM_MB", "1")
+    monkeypatch.setenv("SJGPU_STREAM_CHUNK_MB", "1")
+    for pipeline in ("auto", "fused", "split"):
+        p = capi.DomParserImplementation(8 << 20)
+        p.set_pipeline(pipeline)
+        for name, a in _range_docs().items():
+            assert_same_all(p, orc, a, f"streamed {pipeline} {name}")
+        nd = corpus.amazon_ndjson(3 << 20, 5)[0]
+        for mode in checkers.MODES.values():
+            assert_same_stage1(p, orc, nd, mode, f"streamed {pipeline} ndjson")
+            assert_same_stage1(p, orc, nd[:-100], mode, f"streamed {pipeline} ndjson cut")
+        p.close()
+    monkeypatch.delenv("SJGPU_STREAM_FROM_MB")
+    monkeypatch.delenv("SJGPU_STREAM_CHUNK_MB")
+    a = corpus.twitter_like(40 << 20, 13)[0]
+    p = capi.DomParserImplementation(len(a))
+    assert_same_all(p, orc, a, "streamed, default thresholds, 40 MiB")
+    # too small an index array is reported, not overrun
+    import ctypes
+    small = np.zeros(1000, np.uint32)
+    n, nxt = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    rc = p.L.sjgpu_stage1(p.h, a.ctypes.data, len(a), 0, small.ctypes.data, len(small), ctypes.byref(n), ctypes.byref(nxt))
+    assert rc == -5  # SJGPU_E_OVERFLOW
     p.close()
 
 
