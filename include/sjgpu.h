@@ -175,7 +175,7 @@ int sjgpu_minify_shard_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, i
  * more ranges follow (no end-of-input checks).  in_string and n_before / out_before come from sjgpu_result() of
  * the previous range: (flags & SJGPU_F_UNCLOSED_STRING), n / out_len -- 0, 0 for the first range.  Offsets stay
  * relative to byte 0 and are appended at idx_dev[n_before...]; result.n / out_len are running totals.
- * sjgpu_stage1() and sjgpu_minify() drive exactly this for host buffers of 16 MiB and more (env
+ * sjgpu_stage1() and sjgpu_minify() drive exactly this for host buffers of 32 MiB and more (env
  * SJGPU_STREAM_FROM_MB / SJGPU_STREAM_CHUNK_MB), with the device-to-host copies on a second thread. */
 int sjgpu_stage1_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin, size_t end, int more, int in_string,
                               uint32_t n_before, void *idx_dev, size_t idx_words, void *stream);

@@ -174,8 +174,12 @@ class DomParserImplementation:
         return rc
 
     def minify(self, data):
+        """-> (error_code, minified bytes).  The bytes are a view of a buffer owned by this object (like
+        structural_indexes: allocated once, reused), valid until the next minify() call."""
         a = _as_u8(data)
-        dst = np.empty(max(len(a), 1), dtype=np.uint8)
+        if getattr(self, "_minify_out", None) is None or len(self._minify_out) < max(len(a), 1):
+            self._minify_out = np.zeros(max(len(a), 1), dtype=np.uint8)
+        dst = self._minify_out
         n = ctypes.c_size_t(0)
         rc = self.L.sjgpu_minify(self.h, a.ctypes.data, len(a), dst.ctypes.data, ctypes.byref(n))
         if rc < 0:

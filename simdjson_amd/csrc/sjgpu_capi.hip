@@ -94,8 +94,10 @@ struct sjgpu_ctx {
   hipStream_t s_in = nullptr;
   hipEvent_t ev_in[2] = {nullptr, nullptr};
   copy_worker *worker = nullptr;
-  size_t stream_from = size_t(16) << 20; // documents at least this long take the overlapped path (env SJGPU_STREAM_FROM_MB, 0 = never)
-  size_t stream_chunk = size_t(8) << 20; // range size, a multiple of RANGE_ALIGN (env SJGPU_STREAM_CHUNK_MB)
+  // Measured (profiles/r01_host_path_overlap.txt): ranges below 8 MiB are overhead-bound (a pageable 4 MiB upload runs at
+  // 40 GB/s, 16 MiB at 56), 16 MiB is best at 1 GiB, 8 MiB at 64 MiB; below ~32 MiB there is nothing to overlap.
+  size_t stream_from = size_t(32) << 20; // documents at least this long take the overlapped path (env SJGPU_STREAM_FROM_MB, 0 = never)
+  size_t stream_chunk = 0;               // range size, a multiple of RANGE_ALIGN; 0 = by length (env SJGPU_STREAM_CHUNK_MB)
   // event profiling (sjgpu_profile_*)
   bool profile = false;
   std::vector<hipEvent_t> events; // PROFILE_EVENTS per recorded call
@@ -200,6 +202,11 @@ void enqueue_minify(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, 
   else { launch_minify(buf, len, ctx->summ, ctx->pref, dst, ctx->d_result, org, s, ev); }
 }
 
+size_t stream_chunk_for(const sjgpu_ctx *ctx, size_t len) {
+  if (ctx->stream_chunk) { return ctx->stream_chunk; }
+  return (len < (size_t(256) << 20)) ? (size_t(8) << 20) : (size_t(16) << 20);
+}
+
 int ensure_streaming(sjgpu_ctx *ctx) {
   if (ctx->worker) { return 0; }
   if (!ctx->s_in) { SJ_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking)); }
@@ -224,7 +231,7 @@ int ensure_streaming(sjgpu_ctx *ctx) {
 int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *out_host, size_t out_cap, sjgpu_scan_result *res_out) {
   int rc = ensure_streaming(ctx);
   if (rc) { return rc; }
-  const size_t chunk = ctx->stream_chunk;
+  const size_t chunk = stream_chunk_for(ctx, len);
   const size_t unit = (op == 0) ? sizeof(uint32_t) : 1;
   uint8_t *d_out = (op == 0) ? reinterpret_cast<uint8_t *>(ctx->d_idx) : ctx->d_out;
   hipStream_t s = ctx->stream;
@@ -279,7 +286,7 @@ int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *o
 }
 
 bool take_streamed_path(const sjgpu_ctx *ctx, size_t len) {
-  return ctx->stream_from != 0 && len >= ctx->stream_from && len > ctx->stream_chunk;
+  return ctx->stream_from != 0 && len >= ctx->stream_from && len > stream_chunk_for(ctx, len);
 }
 
 } // namespace
