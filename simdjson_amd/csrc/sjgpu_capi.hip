@@ -16,20 +16,21 @@
 
 using namespace sjgpu;
 
-// Device-to-host copies of finished output ranges run on their own thread + stream, so that the host-buffer path can
-// upload range k+1 (a pageable hipMemcpyAsync blocks its caller) while range k's offsets travel the other way:
-// PCIe is full duplex, and measured on this box the two directions together move 97 GB/s against 56 GB/s for
-// either alone (profiles/r01_pcie_overlap.txt).  Works with plain malloc/new[] memory on both sides.
+// The host-buffer path of a large document moves its bytes on two helper threads, one per direction, each with its own
+// stream: a pageable hipMemcpyAsync blocks its caller, so only separate threads keep both directions of the (full
+// duplex) PCIe link busy while the calling thread launches scans.  Measured on this box: 56 GB/s either way alone,
+// 97 GB/s both ways together (profiles/r01_pcie_overlap.txt).  Works with plain malloc / new[] memory on both sides.
 struct copy_worker {
-  struct job { void *dst; const void *src; size_t bytes; };
+  struct job { void *dst; const void *src; size_t bytes; hipEvent_t record_after; };
   std::thread th;
   std::mutex m;
-  std::condition_variable cv_job, cv_idle;
+  std::condition_variable cv_job, cv_done;
   std::deque<job> q;
   bool stop = false;
-  size_t inflight = 0;
+  size_t submitted = 0, finished = 0; // jobs since the last drain
   hipError_t err = hipSuccess;
   int device = 0;
+  hipMemcpyKind kind = hipMemcpyDeviceToHost;
   hipStream_t stream = nullptr;
 
   void run() {
@@ -40,32 +41,48 @@ struct copy_worker {
       if (q.empty()) { return; }
       const job j = q.front();
       q.pop_front();
+      const bool skip = (err != hipSuccess); // after a failure the remaining jobs are only counted
       lk.unlock();
-      hipError_t e = hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost, stream);
-      if (e == hipSuccess) { e = hipStreamSynchronize(stream); }
+      hipError_t e = hipSuccess;
+      if (!skip) {
+        e = hipMemcpyAsync(j.dst, j.src, j.bytes, kind, stream);
+        if (e == hipSuccess && j.record_after) { e = hipEventRecord(j.record_after, stream); }
+        // device-to-host: the caller reads the bytes as soon as we report the job finished
+        if (e == hipSuccess && kind == hipMemcpyDeviceToHost) { e = hipStreamSynchronize(stream); }
+      }
       lk.lock();
       if (e != hipSuccess && err == hipSuccess) { err = e; }
-      if (--inflight == 0) { cv_idle.notify_all(); }
+      finished++;
+      cv_done.notify_all();
     }
   }
-  void submit(void *dst, const void *src, size_t bytes) {
-    if (bytes == 0) { return; }
+  void submit(void *dst, const void *src, size_t bytes, hipEvent_t record_after = nullptr) {
     std::lock_guard<std::mutex> lk(m);
-    q.push_back(job{dst, src, bytes});
-    inflight++;
+    q.push_back(job{dst, src, bytes, record_after});
+    submitted++;
     cv_job.notify_one();
+  }
+  // blocks until the first `count` jobs since the last drain have been issued (and their events recorded)
+  hipError_t wait_finished(size_t count) {
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return finished >= count; });
+    return err;
   }
   hipError_t drain() { // returns the first error since the last drain
     std::unique_lock<std::mutex> lk(m);
-    cv_idle.wait(lk, [&] { return inflight == 0; });
+    cv_done.wait(lk, [&] { return finished == submitted; });
     const hipError_t e = err;
     err = hipSuccess;
-    return e;
+    submitted = finished = 0;
+    lk.unlock();
+    const hipError_t se = hipStreamSynchronize(stream);
+    return e != hipSuccess ? e : se;
   }
   void shutdown() {
-    if (!th.joinable()) { return; }
-    { std::lock_guard<std::mutex> lk(m); stop = true; cv_job.notify_one(); }
-    th.join();
+    if (th.joinable()) {
+      { std::lock_guard<std::mutex> lk(m); stop = true; cv_job.notify_one(); }
+      th.join();
+    }
     if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
   }
 };
@@ -90,14 +107,15 @@ struct sjgpu_ctx {
   size_t d_idx_words = 0;
   uint8_t *d_out = nullptr;
   size_t d_out_bytes = 0;
-  // overlapped host-buffer path (large documents): upload stream + its two ping-pong events, D2H worker
-  hipStream_t s_in = nullptr;
-  hipEvent_t ev_in[2] = {nullptr, nullptr};
-  copy_worker *worker = nullptr;
-  // Measured (profiles/r01_host_path_overlap.txt): ranges below 8 MiB are overhead-bound (a pageable 4 MiB upload runs at
-  // 40 GB/s, 16 MiB at 56), 16 MiB is best at 1 GiB, 8 MiB at 64 MiB; below ~32 MiB there is nothing to overlap.
+  // overlapped host-buffer path (large documents): one copy thread per direction, one "range uploaded" event per range
+  copy_worker *up = nullptr, *down = nullptr;
+  std::vector<hipEvent_t> ev_in;
+  // Measured (profiles/r01_host_path_overlap.txt): 8 MiB ranges are within 2-10 % of the best size at every length and
+  // the only size that was fast in every context; with 16 and 32 MiB ranges the runtime's pageable-copy path sometimes
+  // serialises the two directions (44 ms instead of 28 ms per GiB) for several calls in a row.  Below ~32 MiB there is
+  // nothing to overlap.
   size_t stream_from = size_t(32) << 20; // documents at least this long take the overlapped path (env SJGPU_STREAM_FROM_MB, 0 = never)
-  size_t stream_chunk = 0;               // range size, a multiple of RANGE_ALIGN; 0 = by length (env SJGPU_STREAM_CHUNK_MB)
+  size_t stream_chunk = size_t(8) << 20; // range size, a multiple of RANGE_ALIGN (env SJGPU_STREAM_CHUNK_MB)
   // event profiling (sjgpu_profile_*)
   bool profile = false;
   std::vector<hipEvent_t> events; // PROFILE_EVENTS per recorded call
@@ -202,47 +220,47 @@ void enqueue_minify(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, 
   else { launch_minify(buf, len, ctx->summ, ctx->pref, dst, ctx->d_result, org, s, ev); }
 }
 
-size_t stream_chunk_for(const sjgpu_ctx *ctx, size_t len) {
-  if (ctx->stream_chunk) { return ctx->stream_chunk; }
-  return (len < (size_t(256) << 20)) ? (size_t(8) << 20) : (size_t(16) << 20);
+copy_worker *start_worker(sjgpu_ctx *ctx, hipMemcpyKind kind) {
+  copy_worker *w = new (std::nothrow) copy_worker();
+  if (!w) { return nullptr; }
+  w->device = ctx->device;
+  w->kind = kind;
+  if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
+  w->th = std::thread([w] { w->run(); });
+  return w;
 }
 
-int ensure_streaming(sjgpu_ctx *ctx) {
-  if (ctx->worker) { return 0; }
-  if (!ctx->s_in) { SJ_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_in, hipStreamNonBlocking)); }
-  for (hipEvent_t &e : ctx->ev_in) {
-    if (!e) { SJ_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+int ensure_streaming(sjgpu_ctx *ctx, size_t nranges) {
+  if (!ctx->up) { ctx->up = start_worker(ctx, hipMemcpyHostToDevice); }
+  if (!ctx->down) { ctx->down = start_worker(ctx, hipMemcpyDeviceToHost); }
+  if (!ctx->up || !ctx->down) { return SJGPU_E_NOMEM; }
+  while (ctx->ev_in.size() < nranges) {
+    hipEvent_t e;
+    SJ_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->ev_in.push_back(e);
   }
-  copy_worker *w = new (std::nothrow) copy_worker();
-  if (!w) { return SJGPU_E_NOMEM; }
-  w->device = ctx->device;
-  hipError_t e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
-  if (e != hipSuccess) { delete w; return fail(ctx, e, "copy_worker stream"); }
-  w->th = std::thread([w] { w->run(); });
-  ctx->worker = w;
   return 0;
 }
 
 // The overlapped host-buffer path (the GPU analogue of the reference's stage1_worker,
-// dom/document_stream-inl.h:16-85): the document is uploaded and scanned in ranges; while range k is scanned and
-// its output travels to the host on the worker's stream, range k+1 is already being uploaded.  The only state
-// between ranges is what one call's result holds: the output cursor and the in-string bit.
+// dom/document_stream-inl.h:16-85): the document is uploaded and scanned in ranges.  The upload thread streams the
+// ranges back to back; as soon as range k is resident this thread scans it (sjgpu_*_range_device's kernels), reads the
+// 16-byte result and hands the new output to the download thread.  The only state between ranges is what one call's
+// result holds: the output cursor and the in-string bit.
 //   op 0: stage 1, out = idx_out (u32 words, room for out_cap words); op 1: minify, out = dst (bytes, room for len)
 int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *out_host, size_t out_cap, sjgpu_scan_result *res_out) {
-  int rc = ensure_streaming(ctx);
+  const size_t chunk = ctx->stream_chunk;
+  const size_t nranges = (len + chunk - 1) / chunk;
+  int rc = ensure_streaming(ctx, nranges);
   if (rc) { return rc; }
-  const size_t chunk = stream_chunk_for(ctx, len);
   const size_t unit = (op == 0) ? sizeof(uint32_t) : 1;
   uint8_t *d_out = (op == 0) ? reinterpret_cast<uint8_t *>(ctx->d_idx) : ctx->d_out;
   hipStream_t s = ctx->stream;
-  const size_t nranges = (len + chunk - 1) / chunk;
-  auto upload = [&](size_t k) -> hipError_t {
+  for (size_t k = 0; k < nranges; k++) {
     const size_t b = k * chunk, e = (b + chunk < len) ? b + chunk : len;
-    hipError_t err = hipMemcpyAsync(ctx->d_in + b, buf + b, e - b, hipMemcpyHostToDevice, ctx->s_in);
-    if (err == hipSuccess) { err = hipEventRecord(ctx->ev_in[k & 1], ctx->s_in); }
-    return err;
-  };
-  hipError_t he = upload(0);
+    ctx->up->submit(ctx->d_in + b, buf + b, e - b, ctx->ev_in[k]);
+  }
+  hipError_t he = hipSuccess;
   uint32_t flags = 0, in_string = 0;
   uint64_t cursor = 0; // output units produced by the ranges so far
   sjgpu_scan_result res{0, 0, 0};
@@ -250,14 +268,14 @@ int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *o
     const size_t b = k * chunk, e = (b + chunk < len) ? b + chunk : len;
     const bool last = (k + 1 == nranges);
     const scan_origin org{uint64_t(b), uint32_t(cursor), (in_string ? CARRY_IN_STRING : 0u) | CARRY_SHARD | (last ? 0u : CARRY_MORE)};
-    he = hipStreamWaitEvent(s, ctx->ev_in[k & 1], 0);
+    he = ctx->up->wait_finished(k + 1); // the event of range k has been recorded (an unrecorded event would not be waited for)
+    if (he == hipSuccess) { he = hipStreamWaitEvent(s, ctx->ev_in[k], 0); }
     if (he != hipSuccess) { break; }
     for (int attempt = 0; attempt < 2; attempt++) { // a single-pass range that gives up is re-run on the split pipeline
       const bool fused = use_fused(ctx, e - b) && attempt == 0;
       if (op == 0) { enqueue_stage1(ctx, fused, ctx->d_in, e, ctx->d_idx, ctx->d_idx_words, s, nullptr, org); }
       else { enqueue_minify(ctx, fused, ctx->d_in, e, ctx->d_out, s, nullptr, org); }
-      if (attempt == 0 && !last) { he = upload(k + 1); } // overlaps this range's scan and the previous range's D2H
-      if (he == hipSuccess) { he = hipGetLastError(); }
+      he = hipGetLastError();
       if (he != hipSuccess) { break; }
       rc = fetch_result(ctx, s, &res);
       if (rc || !(res.flags & SJGPU_F_INTERNAL)) { break; }
@@ -268,16 +286,18 @@ int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *o
     const uint64_t now = (op == 0) ? uint64_t(res.n) : res.out_len;
     const uint64_t upto = now + ((op == 0 && last) ? 3 : 0); // the sentinels travel with the last range
     if (now < cursor || upto > out_cap) { rc = SJGPU_E_OVERFLOW; break; }
-    ctx->worker->submit(static_cast<uint8_t *>(out_host) + cursor * unit, d_out + cursor * unit, size_t(upto - cursor) * unit);
+    if (upto > cursor) {
+      ctx->down->submit(static_cast<uint8_t *>(out_host) + cursor * unit, d_out + cursor * unit, size_t(upto - cursor) * unit);
+    }
     cursor = now;
     in_string = res.flags & SJGPU_F_UNCLOSED_STRING;
   }
   // nothing may be left in flight when we return: the caller owns buf and out_host
-  const hipError_t we = ctx->worker->drain();
-  const hipError_t ie = hipStreamSynchronize(ctx->s_in);
+  const hipError_t ue = ctx->up->drain();
+  const hipError_t de = ctx->down->drain();
   if (he != hipSuccess) { return fail(ctx, he, "streamed scan"); }
-  if (we != hipSuccess) { return fail(ctx, we, "streamed scan: device-to-host copy"); }
-  if (ie != hipSuccess) { return fail(ctx, ie, "streamed scan: upload"); }
+  if (ue != hipSuccess) { return fail(ctx, ue, "streamed scan: upload"); }
+  if (de != hipSuccess) { return fail(ctx, de, "streamed scan: download"); }
   if (rc) { return rc; }
   res_out->n = (op == 0) ? uint32_t(cursor) : 0;
   res_out->out_len = (op == 0) ? 0 : cursor;
@@ -286,7 +306,7 @@ int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *o
 }
 
 bool take_streamed_path(const sjgpu_ctx *ctx, size_t len) {
-  return ctx->stream_from != 0 && len >= ctx->stream_from && len > stream_chunk_for(ctx, len);
+  return ctx->stream_from != 0 && len >= ctx->stream_from && len > ctx->stream_chunk;
 }
 
 } // namespace
@@ -342,15 +362,15 @@ void sjgpu_ctx_destroy(sjgpu_ctx *ctx) {
   if (!ctx) { return; }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
-  if (ctx->worker) {
-    ctx->worker->shutdown();
-    delete ctx->worker;
-    ctx->worker = nullptr;
+  for (copy_worker **w : {&ctx->up, &ctx->down}) {
+    if (*w) {
+      (*w)->shutdown();
+      delete *w;
+      *w = nullptr;
+    }
   }
-  for (hipEvent_t &ev : ctx->ev_in) {
-    if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
-  }
-  if (ctx->s_in) { (void)hipStreamDestroy(ctx->s_in); ctx->s_in = nullptr; }
+  for (hipEvent_t ev : ctx->ev_in) { (void)hipEventDestroy(ev); }
+  ctx->ev_in.clear();
   release_workspace(ctx);
   drop_events(ctx);
   if (ctx->h_result) { (void)hipHostFree(ctx->h_result); }
