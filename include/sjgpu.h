@@ -175,12 +175,24 @@ int sjgpu_minify_shard_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, i
  * more ranges follow (no end-of-input checks).  in_string and n_before / out_before come from sjgpu_result() of
  * the previous range: (flags & SJGPU_F_UNCLOSED_STRING), n / out_len -- 0, 0 for the first range.  Offsets stay
  * relative to byte 0 and are appended at idx_dev[n_before...]; result.n / out_len are running totals.
- * sjgpu_stage1() and sjgpu_minify() drive exactly this for host buffers of 32 MiB and more (env
+ * sjgpu_stage1() and sjgpu_minify() drive exactly this for host buffers of 64 MiB and more (env
  * SJGPU_STREAM_FROM_MB / SJGPU_STREAM_CHUNK_MB), with the device-to-host copies on a second thread. */
 int sjgpu_stage1_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin, size_t end, int more, int in_string,
                               uint32_t n_before, void *idx_dev, size_t idx_words, void *stream);
 int sjgpu_minify_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin, size_t end, int more, int in_string,
                               uint32_t out_before, void *dst_dev, void *stream);
+
+/* ---- page-locked host memory ("a pinned-memory padded_string allocator") ----------------------
+ * The host-buffer entry points accept any memory.  Ordinary (pageable) memory has to be pinned page by page by the
+ * runtime on every call it has not seen before -- measured here ~25 GB/s per direction, 47-57 GB/s when the pages
+ * are already locked (profiles/r01_host_path_overlap.txt).  An integrator who parses many documents allocates the
+ * document buffer (the reference's padded_string, include/simdjson/padded_string.h) with sjgpu_host_alloc, or
+ * registers long-lived arrays such as dom_parser_implementation::structural_indexes once with
+ * sjgpu_host_register (about 19 ms per GiB), and unregisters before freeing them. */
+void *sjgpu_host_alloc(size_t bytes);            /* NULL on failure */
+void sjgpu_host_free(void *p);
+int sjgpu_host_register(void *p, size_t bytes);  /* 0 or a negative SJGPU_E_* */
+int sjgpu_host_unregister(void *p);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,7 @@ EXPORTS = [
     "sjgpu_stage1_finish_host", "sjgpu_trim_partial_utf8", "sjgpu_profile_enable", "sjgpu_profile_read", "sjgpu_set_pipeline", "sjgpu_debug_trace_stage1",
     "sjgpu_clean_cut", "sjgpu_string_parity_device", "sjgpu_stage1_shard_device", "sjgpu_minify_shard_device",
     "sjgpu_stage1_range_device", "sjgpu_minify_range_device",
+    "sjgpu_host_alloc", "sjgpu_host_free", "sjgpu_host_register", "sjgpu_host_unregister",
 ]
 
 
@@ -112,6 +113,14 @@ def load_library():
     L.sjgpu_stage1_range_device.argtypes = [vp, vp, sz, sz, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, vp, sz, vp]
     L.sjgpu_minify_range_device.restype = ctypes.c_int
     L.sjgpu_minify_range_device.argtypes = [vp, vp, sz, sz, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, vp, vp]
+    L.sjgpu_host_alloc.restype = vp
+    L.sjgpu_host_alloc.argtypes = [sz]
+    L.sjgpu_host_free.restype = None
+    L.sjgpu_host_free.argtypes = [vp]
+    L.sjgpu_host_register.restype = ctypes.c_int
+    L.sjgpu_host_register.argtypes = [vp, sz]
+    L.sjgpu_host_unregister.restype = ctypes.c_int
+    L.sjgpu_host_unregister.argtypes = [vp]
     _lib = L
     return L
 
@@ -283,6 +292,17 @@ class DomParserImplementation:
 
 def stage1_error_from_flags(n, flags):
     return int(load_library().sjgpu_stage1_error_from_flags(int(n), int(flags)))
+
+
+def host_register(arr):
+    """Page-lock a long-lived numpy array (sjgpu_host_register); call host_unregister before dropping it."""
+    rc = load_library().sjgpu_host_register(arr.ctypes.data, arr.nbytes)
+    if rc != 0:
+        raise SjgpuError(f"sjgpu_host_register failed with {rc}")
+
+
+def host_unregister(arr):
+    load_library().sjgpu_host_unregister(arr.ctypes.data)
 
 
 def clean_cut(buf, target):

@@ -4,6 +4,7 @@
 #include "sjgpu.h"
 #include "sjgpu_internal.h"
 
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -13,6 +14,8 @@
 #include <new>
 #include <thread>
 #include <vector>
+
+#include <sched.h>
 
 using namespace sjgpu;
 
@@ -28,6 +31,8 @@ struct copy_worker {
   std::deque<job> q;
   bool stop = false;
   size_t submitted = 0, finished = 0; // jobs since the last drain
+  double busy_s = 0.0;                // time inside copies since the last drain (SJGPU_DEBUG_STREAM)
+  size_t busy_bytes = 0;
   hipError_t err = hipSuccess;
   int device = 0;
   hipMemcpyKind kind = hipMemcpyDeviceToHost;
@@ -35,6 +40,7 @@ struct copy_worker {
 
   void run() {
     (void)hipSetDevice(device);
+    if (std::getenv("SJGPU_DEBUG_STREAM")) { std::fprintf(stderr, "[sjgpu] %s thread on cpu %d\n", kind == hipMemcpyHostToDevice ? "upload" : "download", sched_getcpu()); }
     for (;;) {
       std::unique_lock<std::mutex> lk(m);
       cv_job.wait(lk, [&] { return stop || !q.empty(); });
@@ -44,13 +50,17 @@ struct copy_worker {
       const bool skip = (err != hipSuccess); // after a failure the remaining jobs are only counted
       lk.unlock();
       hipError_t e = hipSuccess;
+      const auto t0 = std::chrono::steady_clock::now();
       if (!skip) {
         e = hipMemcpyAsync(j.dst, j.src, j.bytes, kind, stream);
         if (e == hipSuccess && j.record_after) { e = hipEventRecord(j.record_after, stream); }
         // device-to-host: the caller reads the bytes as soon as we report the job finished
         if (e == hipSuccess && kind == hipMemcpyDeviceToHost) { e = hipStreamSynchronize(stream); }
       }
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       lk.lock();
+      busy_s += dt;
+      busy_bytes += j.bytes;
       if (e != hipSuccess && err == hipSuccess) { err = e; }
       finished++;
       cv_done.notify_all();
@@ -74,8 +84,16 @@ struct copy_worker {
     const hipError_t e = err;
     err = hipSuccess;
     submitted = finished = 0;
+    const double bs = busy_s;
+    const size_t bb = busy_bytes;
+    busy_s = 0.0;
+    busy_bytes = 0;
     lk.unlock();
     const hipError_t se = hipStreamSynchronize(stream);
+    if (bb && std::getenv("SJGPU_DEBUG_STREAM")) {
+      std::fprintf(stderr, "[sjgpu]   %s thread: %.1f MB in %.2f ms busy = %.1f GB/s\n", kind == hipMemcpyHostToDevice ? "upload" : "download",
+                   bb / 1e6, bs * 1e3, bb / bs / 1e9);
+    }
     return e != hipSuccess ? e : se;
   }
   void shutdown() {
@@ -108,14 +126,16 @@ struct sjgpu_ctx {
   uint8_t *d_out = nullptr;
   size_t d_out_bytes = 0;
   // overlapped host-buffer path (large documents): one copy thread per direction, one "range uploaded" event per range
-  copy_worker *up = nullptr, *down = nullptr;
+  std::vector<copy_worker *> up, down; // range k travels on up[k % up.size()]; output piece k on down[k % down.size()]
+  size_t copy_threads = 1;             // per direction (env SJGPU_COPY_THREADS)
   std::vector<hipEvent_t> ev_in;
-  // Measured (profiles/r01_host_path_overlap.txt): 8 MiB ranges are within 2-10 % of the best size at every length and
-  // the only size that was fast in every context; with 16 and 32 MiB ranges the runtime's pageable-copy path sometimes
-  // serialises the two directions (44 ms instead of 28 ms per GiB) for several calls in a row.  Below ~32 MiB there is
-  // nothing to overlap.
-  size_t stream_from = size_t(32) << 20; // documents at least this long take the overlapped path (env SJGPU_STREAM_FROM_MB, 0 = never)
-  size_t stream_chunk = size_t(8) << 20; // range size, a multiple of RANGE_ALIGN (env SJGPU_STREAM_CHUNK_MB)
+  // Measured (profiles/r01_host_path_overlap.txt), 1 GiB documents: with page-locked buffers 16 MiB ranges and ONE copy
+  // thread per direction give 27.1 ms (large_random) / 20.4 ms (twitter-like) in every context, against 42.1 / 28.3 ms
+  // for upload, scan, download one after the other; 8 MiB: 27.6 / 21.6; 4 MiB: 28.8 / 24.5; two threads per direction are
+  // slower and erratic (27-35 ms).  With pageable buffers the runtime has to pin every range it has not seen before, which
+  // halves the rate of the copy thread (25 instead of 47 GB/s); the overlap then roughly pays for the pinning.
+  size_t stream_from = size_t(64) << 20;  // documents at least this long take the overlapped path (env SJGPU_STREAM_FROM_MB, 0 = never)
+  size_t stream_chunk = size_t(16) << 20; // range size, a multiple of RANGE_ALIGN (env SJGPU_STREAM_CHUNK_MB)
   // event profiling (sjgpu_profile_*)
   bool profile = false;
   std::vector<hipEvent_t> events; // PROFILE_EVENTS per recorded call
@@ -231,9 +251,17 @@ copy_worker *start_worker(sjgpu_ctx *ctx, hipMemcpyKind kind) {
 }
 
 int ensure_streaming(sjgpu_ctx *ctx, size_t nranges) {
-  if (!ctx->up) { ctx->up = start_worker(ctx, hipMemcpyHostToDevice); }
-  if (!ctx->down) { ctx->down = start_worker(ctx, hipMemcpyDeviceToHost); }
-  if (!ctx->up || !ctx->down) { return SJGPU_E_NOMEM; }
+  if (ctx->up.empty() && std::getenv("SJGPU_DEBUG_STREAM")) { std::fprintf(stderr, "[sjgpu] caller on cpu %d\n", sched_getcpu()); }
+  while (ctx->up.size() < ctx->copy_threads) {
+    copy_worker *w = start_worker(ctx, hipMemcpyHostToDevice);
+    if (!w) { return SJGPU_E_NOMEM; }
+    ctx->up.push_back(w);
+  }
+  while (ctx->down.size() < ctx->copy_threads) {
+    copy_worker *w = start_worker(ctx, hipMemcpyDeviceToHost);
+    if (!w) { return SJGPU_E_NOMEM; }
+    ctx->down.push_back(w);
+  }
   while (ctx->ev_in.size() < nranges) {
     hipEvent_t e;
     SJ_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -258,17 +286,24 @@ int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *o
   hipStream_t s = ctx->stream;
   for (size_t k = 0; k < nranges; k++) {
     const size_t b = k * chunk, e = (b + chunk < len) ? b + chunk : len;
-    ctx->up->submit(ctx->d_in + b, buf + b, e - b, ctx->ev_in[k]);
+    ctx->up[k % ctx->up.size()]->submit(ctx->d_in + b, buf + b, e - b, ctx->ev_in[k]);
   }
   hipError_t he = hipSuccess;
   uint32_t flags = 0, in_string = 0;
   uint64_t cursor = 0; // output units produced by the ranges so far
+  const bool debug = std::getenv("SJGPU_DEBUG_STREAM") != nullptr;
+  double wait_upload_s = 0.0, wait_scan_s = 0.0;
+  const auto t_begin = std::chrono::steady_clock::now();
   sjgpu_scan_result res{0, 0, 0};
   for (size_t k = 0; k < nranges && he == hipSuccess && rc == 0; k++) {
     const size_t b = k * chunk, e = (b + chunk < len) ? b + chunk : len;
     const bool last = (k + 1 == nranges);
     const scan_origin org{uint64_t(b), uint32_t(cursor), (in_string ? CARRY_IN_STRING : 0u) | CARRY_SHARD | (last ? 0u : CARRY_MORE)};
-    he = ctx->up->wait_finished(k + 1); // the event of range k has been recorded (an unrecorded event would not be waited for)
+    // the event of range k has been recorded (an unrecorded event would not be waited for): it is job k / T of thread k % T
+    const auto tw0 = std::chrono::steady_clock::now();
+    he = ctx->up[k % ctx->up.size()]->wait_finished(k / ctx->up.size() + 1);
+    const auto tw1 = std::chrono::steady_clock::now();
+    wait_upload_s += std::chrono::duration<double>(tw1 - tw0).count();
     if (he == hipSuccess) { he = hipStreamWaitEvent(s, ctx->ev_in[k], 0); }
     if (he != hipSuccess) { break; }
     for (int attempt = 0; attempt < 2; attempt++) { // a single-pass range that gives up is re-run on the split pipeline
@@ -280,6 +315,7 @@ int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *o
       rc = fetch_result(ctx, s, &res);
       if (rc || !(res.flags & SJGPU_F_INTERNAL)) { break; }
     }
+    wait_scan_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw1).count();
     if (he != hipSuccess || rc) { break; }
     flags |= res.flags & ~uint32_t(SJGPU_F_UNCLOSED_STRING);
     if (res.flags & (SJGPU_F_INTERNAL | SJGPU_F_IDX_OVERFLOW)) { break; }
@@ -287,14 +323,29 @@ int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *o
     const uint64_t upto = now + ((op == 0 && last) ? 3 : 0); // the sentinels travel with the last range
     if (now < cursor || upto > out_cap) { rc = SJGPU_E_OVERFLOW; break; }
     if (upto > cursor) {
-      ctx->down->submit(static_cast<uint8_t *>(out_host) + cursor * unit, d_out + cursor * unit, size_t(upto - cursor) * unit);
+      ctx->down[k % ctx->down.size()]->submit(static_cast<uint8_t *>(out_host) + cursor * unit, d_out + cursor * unit,
+                                              size_t(upto - cursor) * unit);
     }
     cursor = now;
     in_string = res.flags & SJGPU_F_UNCLOSED_STRING;
   }
   // nothing may be left in flight when we return: the caller owns buf and out_host
-  const hipError_t ue = ctx->up->drain();
-  const hipError_t de = ctx->down->drain();
+  const auto t_loop = std::chrono::steady_clock::now();
+  hipError_t ue = hipSuccess, de = hipSuccess;
+  for (copy_worker *w : ctx->up) {
+    const hipError_t e = w->drain();
+    if (ue == hipSuccess) { ue = e; }
+  }
+  for (copy_worker *w : ctx->down) {
+    const hipError_t e = w->drain();
+    if (de == hipSuccess) { de = e; }
+  }
+  if (debug) {
+    const auto t_end = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[sjgpu] streamed call: %zu ranges, %.2f ms total = %.2f waiting for uploads + %.2f launching/waiting for scans + %.2f draining downloads\n",
+                 nranges, std::chrono::duration<double>(t_end - t_begin).count() * 1e3, wait_upload_s * 1e3, wait_scan_s * 1e3,
+                 std::chrono::duration<double>(t_end - t_loop).count() * 1e3);
+  }
   if (he != hipSuccess) { return fail(ctx, he, "streamed scan"); }
   if (ue != hipSuccess) { return fail(ctx, ue, "streamed scan: upload"); }
   if (de != hipSuccess) { return fail(ctx, de, "streamed scan: download"); }
@@ -319,6 +370,25 @@ int sjgpu_device_count(void) {
   return n;
 }
 
+void *sjgpu_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { return nullptr; }
+  return p;
+}
+void sjgpu_host_free(void *p) {
+  if (p) { (void)hipHostFree(p); }
+}
+int sjgpu_host_register(void *p, size_t bytes) {
+  if (!p || bytes == 0) { return SJGPU_E_BADARG; }
+  const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+  return e == hipSuccess ? 0 : fail(nullptr, e, "hipHostRegister");
+}
+int sjgpu_host_unregister(void *p) {
+  if (!p) { return SJGPU_E_BADARG; }
+  const hipError_t e = hipHostUnregister(p);
+  return e == hipSuccess ? 0 : fail(nullptr, e, "hipHostUnregister");
+}
+
 int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out) {
   if (!out) { return SJGPU_E_BADARG; }
   *out = nullptr;
@@ -331,6 +401,10 @@ int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out) {
     ctx->pipeline = std::strcmp(pl, "split") == 0 ? 0 : (std::strcmp(pl, "fused") == 0 ? 1 : 2);
   }
   if (const char *v = std::getenv("SJGPU_STREAM_FROM_MB")) { ctx->stream_from = size_t(std::strtoull(v, nullptr, 10)) << 20; }
+  if (const char *v = std::getenv("SJGPU_COPY_THREADS")) {
+    const size_t t = size_t(std::strtoull(v, nullptr, 10));
+    if (t >= 1 && t <= 8) { ctx->copy_threads = t; }
+  }
   if (const char *v = std::getenv("SJGPU_STREAM_CHUNK_MB")) {
     const size_t mb = size_t(std::strtoull(v, nullptr, 10));
     if (mb >= 1 && mb <= 1024) { ctx->stream_chunk = mb << 20; }
@@ -362,12 +436,12 @@ void sjgpu_ctx_destroy(sjgpu_ctx *ctx) {
   if (!ctx) { return; }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
-  for (copy_worker **w : {&ctx->up, &ctx->down}) {
-    if (*w) {
-      (*w)->shutdown();
-      delete *w;
-      *w = nullptr;
+  for (std::vector<copy_worker *> *ws : {&ctx->up, &ctx->down}) {
+    for (copy_worker *w : *ws) {
+      w->shutdown();
+      delete w;
     }
+    ws->clear();
   }
   for (hipEvent_t ev : ctx->ev_in) { (void)hipEventDestroy(ev); }
   ctx->ev_in.clear();
