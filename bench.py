@@ -2,7 +2,7 @@
 """bench.py -- stage-1 structural indexing throughput on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--op stage1|minify|validate_utf8]
-                    [--workload large_random|amazon_ndjson|twitter_like] [--size BYTES]
+                    [--workload large_random|amazon_ndjson|twitter_like|deep_nesting|escape_heavy] [--size BYTES]
 
 A "step" = one pass of the hot path (sjgpu_*_device through the C-ABI) over one synthetic buffer that
 is already resident in HBM.  N = 1: BASELINE.json configs[1] -- 1 GiB large_random-style JSON.
@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--op", default="stage1", choices=["stage1", "minify", "validate_utf8"])
-    ap.add_argument("--workload", default="large_random", choices=["large_random", "amazon_ndjson", "twitter_like"])
+    ap.add_argument("--workload", default="large_random", choices=["large_random", "amazon_ndjson", "twitter_like", "deep_nesting", "escape_heavy"])
     ap.add_argument("--size", type=int, default=1 << 30, help="bytes per GPU")
     ap.add_argument("--pipeline", default=os.environ.get("SJGPU_PIPELINE", "auto"), choices=["auto", "fused", "split"])
     ap.add_argument("--ndjson-leg", type=int, default=-1, help="1: also time config 4 (amazon NDJSON shard per GPU, "
@@ -71,7 +71,8 @@ def main():
         dist.barrier()
 
     # ---- workload: one synthetic buffer per rank, resident in HBM before anything is timed ----
-    host, units = getattr(corpus, args.workload)(args.size, 1000 + rank)
+    gen = {"deep_nesting": corpus.deep_nesting_doc}.get(args.workload) or getattr(corpus, args.workload)
+    host, units = gen(args.size, 1000 + rank)
     L = len(host)
     parser = capi.DomParserImplementation(L, device=local_rank)
     parser.set_pipeline(args.pipeline)

@@ -22,6 +22,11 @@ for s in $STAGES; do
       timeout 600 python bench.py --ndjson-leg 1 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/bench_ndjson_leg.json 2> gpurun_out/bench_ndjson_leg.err; cat gpurun_out/bench_ndjson_leg.json
       timeout 600 python bench.py --workload amazon_ndjson --steps 20 --warmup 3 > gpurun_out/bench_stage1_ndjson.json 2> gpurun_out/bench_stage1_ndjson.err; cat gpurun_out/bench_stage1_ndjson.json
       timeout 600 python bench.py --workload twitter_like --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_stage1_twitter.json 2> gpurun_out/bench_stage1_twitter.err; cat gpurun_out/bench_stage1_twitter.json
+      for wl in deep_nesting escape_heavy; do
+        for pl in fused split; do
+          timeout 600 python bench.py --workload $wl --pipeline $pl --steps 10 --warmup 2 > gpurun_out/bench_stage1_${wl}_${pl}.json 2> gpurun_out/bench_stage1_${wl}_${pl}.err; cat gpurun_out/bench_stage1_${wl}_${pl}.json
+        done
+      done
       ;;
     sweep)
       timeout 900 python scripts/size_sweep.py twitter_like > gpurun_out/size_sweep_twitter.jsonl 2> gpurun_out/size_sweep.err; cat gpurun_out/size_sweep_twitter.jsonl

@@ -72,6 +72,29 @@ def backslash_runs(run_lengths, lead_pad=0):
     return np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
 
 
+def deep_nesting_doc(target_bytes, seed=1):
+    """bench workload (BASELINE configs[4]): target_bytes of '[' * k + ']' * k.  Returns (array, k)."""
+    k = (int(target_bytes) + 1) // 2
+    return deep_nesting(k), k
+
+
+ESCAPE_RUNS = (1, 2, 3, 4, 7, 8, 62, 63, 64, 65, 66, 126, 127, 128, 129, 130, 1, 1, 2, 2, 4094, 4095, 4096, 4097, 4098,
+               16382, 16383, 16384, 16385, 16386, 65535, 65536, 65537, 3, 5, 9, 17, 33, 1, 2, 1, 2)
+
+
+def escape_heavy(target_bytes, seed=1):
+    """bench workload (BASELINE configs[4]): an array of strings that are almost nothing but backslash runs -- odd and
+    even lengths from 1 to 64 KiB + 1, so escape carries cross blocks, chunks, segments and tiles -- >= target_bytes.
+    Returns (array, n_strings)."""
+    rot = int(seed) % len(ESCAPE_RUNS)
+    runs = ESCAPE_RUNS[rot:] + ESCAPE_RUNS[:rot]
+    block = backslash_runs(runs)[1:-1]  # without the enclosing brackets
+    reps = max(1, -(-int(target_bytes) // (len(block) + 1)))
+    body = np.tile(np.concatenate([block, np.frombuffer(b",", np.uint8)]), reps)
+    body[-1] = ord("]")
+    return np.concatenate([np.frombuffer(b"[", np.uint8), body]), reps * len(runs)
+
+
 def boundary_straddle(payload: bytes, boundary: int, offset_before: int, total: int, filler=b" "):
     """Places `payload` so that it starts `offset_before` bytes before a multiple of `boundary`."""
     start = boundary - offset_before

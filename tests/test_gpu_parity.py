@@ -560,3 +560,32 @@ def test_full_size_device_resident(orc, kind, pipeline):
         assert p.result(stream)[1] & capi.F_UTF8_ERROR, pos
         buf[pos] = old
     p.close()
+
+
+@pytest.mark.parametrize("kind", ["deep_nesting", "escape_heavy"])
+def test_full_size_adversarial(orc, kind):
+    """BASELINE.json configs[4] at full size: density 1.0 (4 bytes out per byte in) and escape carries across every
+    boundary type; exact digest of all n+3 words against the oracle, both pipelines."""
+    import torch
+    size = int(os.environ.get("SJGPU_FULL_SIZE", str(1 << 30)))
+    gen = corpus.deep_nesting_doc if kind == "deep_nesting" else corpus.escape_heavy
+    a, _ = gen(size, 1000)
+    L = len(a)
+    oerr, on, oidx = orc.stage1(a, 0)
+    assert oerr == 0
+    want = orc.fnv(oidx)
+    del oidx
+    buf = torch.from_numpy(a).cuda()
+    idx = torch.empty(L + 3, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for pipeline in ("fused", "split"):
+        p = capi.DomParserImplementation(L)
+        p.set_pipeline(pipeline)
+        idx.zero_()
+        assert p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, stream) == 0
+        n, flags, _ = p.result(stream)
+        assert (n, flags) == (on, 0), (pipeline, n, on, flags)
+        host = idx[: n + 3].cpu().numpy().view(np.uint32)
+        assert orc.fnv(host) == want, pipeline
+        del host
+        p.close()
