@@ -114,6 +114,7 @@ struct sjgpu_ctx {
   seg_summary *summ = nullptr;
   seg_prefix *pref = nullptr;
   uint64_t *desc = nullptr; // single-pass pipeline: tile descriptors + ticket
+  uint8_t *esc_tab = nullptr; // escape table (launch_escape_table), ESC_TABLE_BYTES whatever the capacity
   int pipeline = 2; // 0 split, 1 single pass, 2 auto (single pass below AUTO_FUSED_BELOW bytes)
   uint32_t max_workgroups = 2048;
   scan_result_dev *d_result = nullptr;
@@ -229,13 +230,23 @@ bool use_fused(const sjgpu_ctx *ctx, size_t len) {
 }
 
 // `len` is the END of the scan (bytes [org.begin, len) are scanned); a whole document has org = {0, 0, 0}
+// Scans longer than the small-tile limit get the escape table first: it bounds the look-back over backslash runs
+// (sjgpu_kernels.hip, k_escape_local).  Shorter ones walk; their worst case is bounded by their size.
+void prepare_escapes(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, scan_origin &org, hipStream_t s) {
+  if (len - org.begin <= FUSED_SMALL_BELOW) { return; }
+  launch_escape_table(buf, org.begin, len, ctx->esc_tab, s);
+  org.esc = ctx->esc_tab;
+}
+
 void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint32_t *idx, size_t idx_words, hipStream_t s,
                     hipEvent_t *ev, scan_origin org = scan_origin{0, 0, 0}) {
+  prepare_escapes(ctx, buf, len, org, s);
   if (fused) { launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, org, ctx->max_workgroups, s, ev); }
   else { launch_stage1(buf, len, ctx->masks, ctx->summ, ctx->pref, idx, idx_words, ctx->d_result, org, s, ev); }
 }
 void enqueue_minify(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint8_t *dst, hipStream_t s, hipEvent_t *ev,
                     scan_origin org = scan_origin{0, 0, 0}) {
+  prepare_escapes(ctx, buf, len, org, s);
   if (fused) { launch_minify_fused(buf, len, ctx->desc, dst, ctx->d_result, org, ctx->max_workgroups, s, ev); }
   else { launch_minify(buf, len, ctx->summ, ctx->pref, dst, ctx->d_result, org, s, ev); }
 }
@@ -418,6 +429,8 @@ int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out) {
   }
   if (e == hipSuccess) { e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking); }
   if (e == hipSuccess) { e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_result), sizeof(scan_result_dev), hipHostMallocDefault); }
+  if (e == hipSuccess) { e = hipMalloc(reinterpret_cast<void **>(&ctx->esc_tab), ESC_TABLE_BYTES); }
+  if (e == hipSuccess) { e = hipMemset(ctx->esc_tab, 0, ESC_TABLE_BYTES); } // entry 0 and the pass flag start at zero
   if (e != hipSuccess) {
     int rc = fail(nullptr, e, "ctx_create");
     sjgpu_ctx_destroy(ctx);
@@ -448,6 +461,7 @@ void sjgpu_ctx_destroy(sjgpu_ctx *ctx) {
   release_workspace(ctx);
   drop_events(ctx);
   if (ctx->h_result) { (void)hipHostFree(ctx->h_result); }
+  dev_free(ctx->esc_tab);
   if (ctx->stream) { (void)hipStreamDestroy(ctx->stream); }
   delete ctx;
 }
@@ -522,7 +536,9 @@ int sjgpu_string_parity_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
   if (!ctx || (len && (!buf_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u)))) { return SJGPU_E_BADARG; }
   if (len > ctx->capacity) { return E_CAPACITY; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
-  launch_string_parity(static_cast<const uint8_t *>(buf_dev), len, ctx->d_result, pick(ctx, stream));
+  scan_origin org{0, 0, 0};
+  prepare_escapes(ctx, static_cast<const uint8_t *>(buf_dev), len, org, pick(ctx, stream));
+  launch_string_parity(static_cast<const uint8_t *>(buf_dev), len, ctx->d_result, org.esc, pick(ctx, stream));
   SJ_TRY(ctx, hipGetLastError());
   return 0;
 }

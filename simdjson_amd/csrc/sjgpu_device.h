@@ -92,9 +92,14 @@ struct wave_carry {
   u32 utf8; // utf8 carry word (sj_block.h)
 };
 
-// parity of the maximal backslash run ending at byte end-1 (0 if end == 0 or no run)
-__device__ __forceinline__ u32 backslash_run_parity(const u8 *__restrict__ buf, u64 end, u32 lane) {
+// parity of the maximal backslash run ending at byte end-1 (0 if end == 0 or no run).
+// esc (may be null): the escape table of the call, esc[s] = that parity for end = s * SEG_BYTES, computed exactly by
+// k_escape_local / k_escape_resolve before the scan.  With it the walk stops at the first segment boundary it reaches
+// (<= 256 steps); without it the walk is as long as the run -- quadratic over a document that is one long backslash run,
+// which is why every call beyond FUSED_SMALL_BELOW bytes gets the table.  `end` is a multiple of 64 at every call site.
+__device__ __forceinline__ u32 backslash_run_parity(const u8 *__restrict__ buf, u64 end, u32 lane, const u8 *__restrict__ esc) {
   for (;;) {
+    if (esc && (end % SEG_BYTES) == 0) { return u32(esc[end / SEG_BYTES]) & 1u; } // wave-uniform
     const u32 byte = (end > lane) ? u32(buf[end - 1 - lane]) : 0u;
     const u64 m = __ballot(byte == 0x5Cu);
     if (~m) { return ctz64(~m) & 1u; }
@@ -112,21 +117,23 @@ __device__ __forceinline__ u32 lookback_issue(const u8 *__restrict__ buf, u64 st
   return (start > lane) ? u32(buf[start - 1 - lane]) : 0x20u; // lane i holds byte start-1-i (0x20 in front of the input)
 }
 // parity of the backslash run ending at byte start-1-skip, from m = ballot(lane's look-back byte is a backslash)
-__device__ __forceinline__ u32 run_parity_from_mask(const u8 *__restrict__ buf, u64 start, u32 lane, u64 m, u32 skip) {
+__device__ __forceinline__ u32 run_parity_from_mask(const u8 *__restrict__ buf, u64 start, u32 lane, u64 m, u32 skip,
+                                                    const u8 *__restrict__ esc) {
   const u64 inv = ~(m >> skip) & (~0ull >> skip); // bit i clear <=> byte start-1-skip-i is a backslash
   if (inv) { return ctz64(inv) & 1u; }
   // every byte we hold is a backslash (so start >= 64): keep walking from byte start-65
-  return ((64u - skip) + backslash_run_parity(buf, start - 64, lane)) & 1u;
+  return ((64u - skip) + backslash_run_parity(buf, start - 64, lane, esc)) & 1u;
 }
-__device__ __forceinline__ wave_carry segment_carry_from(const u8 *__restrict__ buf, u64 start, u32 lane, u32 byte) {
+__device__ __forceinline__ wave_carry segment_carry_from(const u8 *__restrict__ buf, u64 start, u32 lane, u32 byte,
+                                                         const u8 *__restrict__ esc) {
   wave_carry c{0u, 0u, 0u, 0u};
   if (start == 0) { return c; }
   const u32 b1 = readlane(byte, 0), b2 = readlane(byte, 1), b3 = readlane(byte, 2);
   c.utf8 = utf8_carry_from_bytes(b3, b2, b1);
   const u64 m = __ballot(byte == 0x5Cu);
-  c.e = run_parity_from_mask(buf, start, lane, m, 0);
+  c.e = run_parity_from_mask(buf, start, lane, m, 0, esc);
   if (b1 == 0x22u) {
-    c.p = run_parity_from_mask(buf, start, lane, m, 1);
+    c.p = run_parity_from_mask(buf, start, lane, m, 1, esc);
   } else {
     const bool ws = b1 == 0x20u || b1 == 0x09u || b1 == 0x0Au || b1 == 0x0Du;
     const u32 cur = b1 | 0x20u;
@@ -135,8 +142,8 @@ __device__ __forceinline__ wave_carry segment_carry_from(const u8 *__restrict__ 
   }
   return c;
 }
-__device__ __forceinline__ wave_carry segment_carry_in(const u8 *__restrict__ buf, u64 start, u32 lane) {
-  return segment_carry_from(buf, start, lane, lookback_issue(buf, start, lane));
+__device__ __forceinline__ wave_carry segment_carry_in(const u8 *__restrict__ buf, u64 start, u32 lane, const u8 *__restrict__ esc) {
+  return segment_carry_from(buf, start, lane, lookback_issue(buf, start, lane), esc);
 }
 
 // ---- one chunk (64 blocks) through the scanner -----------------------------------------------------------

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
           u32 w[16];
           if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
           else { load_block(buf, pos, len, w); }
-          if (c == 0) { wc = segment_carry_from(buf, wave_start, lane, lookback); }
+          if (c == 0) { wc = segment_carry_from(buf, wave_start, lane, lookback, org.esc); }
           if (OP == 0) {
             const chunk_masks m = scan_chunk<true, true>(w, wc, lane);
             a = m.cand;
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ 
             u32 w[16];
             if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
             else { load_block(buf, pos, len, w); }
-            if (c == 0) { wc = segment_carry_from(buf, wave_start, lane, lookback); }
+            if (c == 0) { wc = segment_carry_from(buf, wave_start, lane, lookback, org.esc); }
             if (OP == 0) {
               const chunk_masks m = scan_chunk<true, true>(w, wc, lane);
               a = m.cand;

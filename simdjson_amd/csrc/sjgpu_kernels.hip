@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64) void k_stage1_summarize(const u8 *__restrict__ 
     u32 w[16];
     if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); } // interior chunk: branch-free loads
     else { load_block(buf, pos, len, w); }
-    if (c == 0) { wc = segment_carry_from(buf, seg_start, lane, lookback); } // its latency hid behind the loads above
+    if (c == 0) { wc = segment_carry_from(buf, seg_start, lane, lookback, org.esc); } // its latency hid behind the loads above
     const chunk_masks m = scan_chunk<true, true>(w, wc, lane);
     if (c == 0) {
       const u64 cm = __ballot(m.ctrl != 0);
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64) void k_minify_summarize(const u8 *__restrict__ 
     u32 w[16];
     if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
     else { load_block(buf, pos, len, w); }
-    if (c == 0) { wc = segment_carry_from(buf, seg_start, lane, lookback); }
+    if (c == 0) { wc = segment_carry_from(buf, seg_start, lane, lookback, org.esc); }
     const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
     const u64 valid = valid_mask(pos, len);
     kept_out += u32(popc64(valid & ~(m.ws & ~m.in_string))); // dropped: whitespace outside strings (json_scanner.h:46)
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64) void k_minify_emit(const u8 *__restrict__ buf, 
     if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
     else { load_block(buf, pos, len, w); }
     if (c == 0) {
-      wc = segment_carry_from(buf, seg_start, lane, lookback);
+      wc = segment_carry_from(buf, seg_start, lane, lookback, org.esc);
       wc.s = pf.in_string; // absolute from here on
     }
     const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(64) void k_validate_utf8(const u8 *__restrict__ buf
 // general multi-GPU sharding, SURVEY 8(e): the ranks all-gather these bits, then scan with the right carry-in)
 // =====================================================================================================
 __global__ __launch_bounds__(64) void k_string_parity(const u8 *__restrict__ buf, u64 len, u32 nseg,
-                                                      scan_result_dev *__restrict__ result) {
+                                                      scan_result_dev *__restrict__ result, const u8 *__restrict__ esc) {
   const u32 lane = lane_id();
   u32 parity = 0;
   for (u32 seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
@@ -401,12 +401,76 @@ __global__ __launch_bounds__(64) void k_string_parity(const u8 *__restrict__ buf
       u32 w[16];
       if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
       else { load_block(buf, pos, len, w); }
-      if (c == 0) { wc = segment_carry_from(buf, seg_start, lane, lookback); }
+      if (c == 0) { wc = segment_carry_from(buf, seg_start, lane, lookback, esc); }
       (void)scan_chunk<false, false>(w, wc, lane);
     }
     parity ^= wc.s;
   }
   if (parity && lane == 0) { atomicXor(&result->n, 1u); }
+}
+
+
+// =====================================================================================================
+// escape table: esc[s] = "byte s * SEG_BYTES is escaped" = parity of the backslash run ending in front of it.
+// The scan kernels derive a segment's escape carry-in by looking back over the bytes in front of it; over one long
+// backslash run that walk would be as long as the run, for EVERY segment inside it (quadratic: a 1 GiB document of
+// backslashes would take minutes).  Here every boundary walks at most ONE segment back (k_escape_local); a segment
+// that is nothing but backslashes passes its own carry-in through (16 KiB is even), and those rare entries are
+// resolved by one small scan (k_escape_resolve).  Ordinary input: one 64-byte read per segment, no pass entries.
+// =====================================================================================================
+constexpr u8 ESC_PASS = 2;
+constexpr size_t ESC_FLAG_OFFSET = (ESC_TABLE_ENTRIES + 3) & ~size_t(3); // u32: "this call wrote a pass entry"
+
+__global__ __launch_bounds__(256) void k_escape_local(const u8 *__restrict__ buf, u64 s0, u32 nseg, u8 *__restrict__ esc) {
+  const u32 lane = threadIdx.x & 63u;
+  const u32 r = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (r >= nseg) { return; }
+  const u64 s = s0 + r;
+  u32 state = 0; // in front of byte 0 there is nothing
+  if (s > 0) {
+    u64 end = s * SEG_BYTES;
+    state = ESC_PASS;
+    for (u32 k = 0; k < SEG_BYTES / 64; k++, end -= 64) {
+      const u32 byte = u32(buf[end - 1 - lane]);
+      const u64 m = __ballot(byte == 0x5Cu);
+      if (~m) {
+        state = ctz64(~m) & 1u; // the 64 k bytes behind are backslashes: an even number
+        break;
+      }
+    }
+  }
+  if (lane == 0) {
+    esc[s] = u8(state);
+    if (state == ESC_PASS) { atomicOr(reinterpret_cast<u32 *>(esc + ESC_FLAG_OFFSET), 1u); }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_escape_resolve(u64 s0, u32 nseg, u8 *__restrict__ esc) {
+  u32 *flag = reinterpret_cast<u32 *>(esc + ESC_FLAG_OFFSET);
+  if (*flag == 0) { return; } // no pass entry: the table is final (workgroup-uniform)
+  __shared__ u8 sh[1024];
+  const u32 tid = threadIdx.x;
+  const u32 per = (nseg + 1023u) / 1024u;
+  const u32 lo = min(tid * per, nseg), hi = min(lo + per, nseg);
+  u32 last = ESC_PASS;
+  for (u32 i = lo; i < hi; i++) {
+    const u32 v = esc[s0 + i];
+    if (v != ESC_PASS) { last = v; }
+  }
+  sh[tid] = u8(last);
+  __syncthreads();
+  // state in front of my slice: the nearest setting slice below me, else what the previous range of this buffer left
+  u32 cur = ESC_PASS;
+  for (int t = int(tid) - 1; t >= 0 && cur == ESC_PASS; t--) { cur = sh[t]; }
+  if (cur == ESC_PASS) { cur = (s0 > 0) ? (u32(esc[s0 - 1]) & 1u) : 0u; }
+  __syncthreads(); // everybody has read esc[s0 - 1 ...] before anybody rewrites entries
+  for (u32 i = lo; i < hi; i++) {
+    const u32 v = esc[s0 + i];
+    if (v == ESC_PASS) { esc[s0 + i] = u8(cur); }
+    else { cur = v; }
+  }
+  __syncthreads();
+  if (tid == 0) { *flag = 0; } // ready for the next call
 }
 
 } // namespace
@@ -462,12 +526,20 @@ void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *res
   mark(ev, 3, stream);
 }
 
-void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *result, hipStream_t stream) {
+void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *result, const uint8_t *esc, hipStream_t stream) {
   (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
   const u32 nseg = num_segments(len);
   if (nseg == 0) { return; }
   const u32 grid = nseg < 8192u ? nseg : 8192u;
-  hipLaunchKernelGGL(k_string_parity, dim3(grid), dim3(64), 0, stream, buf, len, nseg, result);
+  hipLaunchKernelGGL(k_string_parity, dim3(grid), dim3(64), 0, stream, buf, len, nseg, result, esc);
+}
+
+void launch_escape_table(const uint8_t *buf, uint64_t begin, uint64_t len, uint8_t *esc, hipStream_t stream) {
+  const u32 nseg = num_segments(len - begin);
+  if (nseg == 0) { return; }
+  const u64 s0 = begin / SEG_BYTES;
+  hipLaunchKernelGGL(k_escape_local, dim3((nseg + 3) / 4), dim3(256), 0, stream, buf, s0, nseg, esc);
+  hipLaunchKernelGGL(k_escape_resolve, dim3(1), dim3(1024), 0, stream, s0, nseg, esc);
 }
 
 } // namespace sjgpu

@@ -589,3 +589,72 @@ def test_full_size_adversarial(orc, kind):
         assert orc.fnv(host) == want, pipeline
         del host
         p.close()
+
+
+# ---- long backslash runs: the escape table (k_escape_local / k_escape_resolve) --------------------------------------------
+def _long_run_document(rng, total):
+    """Strings that are backslash runs of 16 KiB-ish to MiB-ish lengths, each placed at a chosen distance from a 16 KiB
+    segment boundary (so runs start / end exactly on, just before and just after boundaries, and some segments are
+    nothing but backslashes), separated by ordinary small values."""
+    SEG = 16384
+    parts, at = [b"["], 1
+    lengths = [SEG - 1, SEG, SEG + 1, 2 * SEG - 1, 2 * SEG, 2 * SEG + 1, 3 * SEG, 5 * SEG + 1, 100000, 100001,
+               (1 << 20) + 1, 1 << 20, 4 << 20, (4 << 20) + 1, 63, 64, 65, 4095, 4096, 4097]
+    k = 0
+    while at < total:
+        r = lengths[k % len(lengths)]
+        k += 1
+        # pad so that the run starts at (boundary + delta)
+        delta = int(rng.choice([-2, -1, 0, 1, 2, 63, 64, 4095, 8000]))
+        pad = (-(at + 1) + delta) % SEG
+        body = b" " * pad + b'"' + b"\\" * r + (b'"' if r % 2 == 0 else b'""') + b', {"k": [1, 2]}, "x\\"y", '
+        parts.append(body)
+        at += len(body)
+    parts.append(b"0]")
+    return np.frombuffer(b"".join(parts), np.uint8)
+
+
+def test_long_backslash_runs_use_the_escape_table(orc, monkeypatch):
+    import time
+    import torch
+    rng = np.random.default_rng(99)
+    docs = {"runs around segment boundaries, 40 MiB": _long_run_document(rng, 40 << 20),
+            "escape_heavy 24 MiB": corpus.escape_heavy(24 << 20, 3)[0],
+            "one 32 MiB backslash run in a string": np.frombuffer(b'["' + b"\\" * (32 << 20) + b'", 1]', np.uint8),
+            "odd 32 MiB run: the string stays open": np.frombuffer(b'["' + b"\\" * ((32 << 20) + 1) + b'", 1]', np.uint8)}
+    for pipeline in ("fused", "split"):
+        p = capi.DomParserImplementation(64 << 20)
+        p.set_pipeline(pipeline)
+        for name, a in docs.items():
+            assert_same_all(p, orc, a, f"{pipeline} {name}")
+        p.close()
+    # range by range with ranges above the small-tile limit: the table of range k continues the table of range k-1
+    monkeypatch.setenv("SJGPU_STREAM_FROM_MB", "1")
+    monkeypatch.setenv("SJGPU_STREAM_CHUNK_MB", "9")
+    p = capi.DomParserImplementation(64 << 20)
+    for name, a in docs.items():
+        assert_same_all(p, orc, a, f"streamed {name}")
+    p.close()
+    monkeypatch.delenv("SJGPU_STREAM_FROM_MB")
+    monkeypatch.delenv("SJGPU_STREAM_CHUNK_MB")
+    # the point of the table: one huge run must not cost a look-back per segment that is as long as the run
+    a = np.frombuffer(b'["' + b"\\" * (256 << 20) + b'"]', np.uint8)
+    L = len(a)
+    want, wflags = orc.scan(a)
+    assert wflags == 0 and list(want) == [0, 1, L - 1]
+    buf = torch.from_numpy(a.copy()).cuda()
+    idx = torch.empty(1024, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for pipeline in ("fused", "split"):
+        p = capi.DomParserImplementation(L)
+        p.set_pipeline(pipeline)
+        p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), 1024, stream)
+        assert p.result(stream)[:2] == (3, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), 1024, stream)
+        n, flags, _ = p.result(stream)
+        dt = time.perf_counter() - t0
+        assert (n, flags) == (3, 0) and [int(x) for x in idx[:3]] == [0, 1, L - 1]
+        assert dt < 0.05, f"{pipeline}: 256 MiB of backslashes took {dt * 1e3:.1f} ms"
+        p.close()
