@@ -131,7 +131,8 @@ __device__ __forceinline__ wave_carry segment_carry_from(const u8 *__restrict__ 
   const u32 b1 = readlane(byte, 0), b2 = readlane(byte, 1), b3 = readlane(byte, 2);
   c.utf8 = utf8_carry_from_bytes(b3, b2, b1);
   const u64 m = __ballot(byte == 0x5Cu);
-  c.e = run_parity_from_mask(buf, start, lane, m, 0, esc);
+  // a span that starts on a segment boundary reads its escape carry-in straight from the table (no walk at all)
+  c.e = (esc && (start % SEG_BYTES) == 0) ? (u32(esc[start / SEG_BYTES]) & 1u) : run_parity_from_mask(buf, start, lane, m, 0, esc);
   if (b1 == 0x22u) {
     c.p = run_parity_from_mask(buf, start, lane, m, 1, esc);
   } else {

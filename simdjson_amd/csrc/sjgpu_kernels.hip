@@ -428,13 +428,20 @@ __global__ __launch_bounds__(256) void k_escape_local(const u8 *__restrict__ buf
   const u64 s = s0 + r;
   u32 state = 0; // in front of byte 0 there is nothing
   if (s > 0) {
-    u64 end = s * SEG_BYTES;
+    // walk back over segment s-1 in steps of 1 KiB (16 bytes per lane, lane 0 nearest to the boundary)
+    const u8 *top = buf + s * SEG_BYTES;
     state = ESC_PASS;
-    for (u32 k = 0; k < SEG_BYTES / 64; k++, end -= 64) {
-      const u32 byte = u32(buf[end - 1 - lane]);
-      const u64 m = __ballot(byte == 0x5Cu);
-      if (~m) {
-        state = ctz64(~m) & 1u; // the 64 k bytes behind are backslashes: an even number
+    for (u32 k = 0; k < SEG_BYTES / 1024; k++, top -= 1024) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(top - 16u * (lane + 1u));
+      const u32 x[4] = {v.x ^ 0x5C5C5C5Cu, v.y ^ 0x5C5C5C5Cu, v.z ^ 0x5C5C5C5Cu, v.w ^ 0x5C5C5C5Cu}; // zero bytes = backslashes
+      const u64 other = __ballot((x[0] | x[1] | x[2] | x[3]) != 0);
+      if (other) {
+        // the nearest lane that holds something else: its backslashes above that byte end the run; everything
+        // nearer to the boundary is 16-byte groups of backslashes (an even number)
+        const u32 f = ctz64(other);
+        const u32 hi = x[3] ? x[3] : (x[2] ? x[2] : (x[1] ? x[1] : x[0])); // highest-addressed dword that is not all backslashes
+        const u32 above = u32(__clz(int(hi))) >> 3;                        // backslashes above its last other byte (0..3)
+        state = readlane_dyn(above, f) & 1u;                               // whole dwords above it add 4 each: parity unchanged
         break;
       }
     }
