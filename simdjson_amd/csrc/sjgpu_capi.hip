@@ -231,7 +231,7 @@ bool use_fused(const sjgpu_ctx *ctx, size_t len) {
 
 // `len` is the END of the scan (bytes [org.begin, len) are scanned); a whole document has org = {0, 0, 0}
 // Scans longer than the small-tile limit get the escape table first: it bounds the look-back over backslash runs
-// (sjgpu_kernels.hip, k_escape_table).  Shorter ones walk; their worst case is bounded by their size.
+// (sjgpu_kernels.hip, k_escape_local).  Shorter ones walk; their worst case is bounded by their size.
 void prepare_escapes(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, scan_origin &org, hipStream_t s) {
   if (len - org.begin <= FUSED_SMALL_BELOW) { return; }
   launch_escape_table(buf, org.begin, len, ctx->esc_tab, s);

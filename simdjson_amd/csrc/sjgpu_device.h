@@ -94,7 +94,7 @@ struct wave_carry {
 
 // parity of the maximal backslash run ending at byte end-1 (0 if end == 0 or no run).
 // esc (may be null): the escape table of the call, esc[s] = that parity for end = s * SEG_BYTES, computed exactly by
-// k_escape_table before the scan.  With it the walk stops at the first segment boundary it reaches
+// k_escape_local / k_escape_resolve before the scan.  With it the walk stops at the first segment boundary it reaches
 // (<= 256 steps); without it the walk is as long as the run -- quadratic over a document that is one long backslash run,
 // which is why every call beyond FUSED_SMALL_BELOW bytes gets the table.  `end` is a multiple of 64 at every call site.
 __device__ __forceinline__ u32 backslash_run_parity(const u8 *__restrict__ buf, u64 end, u32 lane, const u8 *__restrict__ esc) {

@@ -414,21 +414,54 @@ __global__ __launch_bounds__(64) void k_string_parity(const u8 *__restrict__ buf
 // escape table: esc[s] = "byte s * SEG_BYTES is escaped" = parity of the backslash run ending in front of it.
 // The scan kernels derive a segment's escape carry-in by looking back over the bytes in front of it; over one long
 // backslash run that walk would be as long as the run, for EVERY segment inside it (quadratic: a 1 GiB document of
-// backslashes would take minutes).  Here every boundary walks at most ONE segment back (k_escape_table); a segment
+// backslashes would take minutes).  Here every boundary walks at most ONE segment back (k_escape_local); a segment
 // that is nothing but backslashes passes its own carry-in through (16 KiB is even), and those rare entries are
-// resolved by one small scan (escape_resolve, run by the workgroup that finishes last).  Ordinary input: one 1 KiB read per segment.
+// resolved by one small scan (k_escape_resolve).  Ordinary input: one 64-byte read per segment, no pass entries.
 // =====================================================================================================
 constexpr u8 ESC_PASS = 2;
-constexpr size_t ESC_FLAG_OFFSET = (ESC_TABLE_ENTRIES + 3) & ~size_t(3); // two u32 state words behind the entries
+constexpr size_t ESC_FLAG_OFFSET = (ESC_TABLE_ENTRIES + 3) & ~size_t(3); // u32: "this call wrote a pass entry"
 
-// state word behind the entries: [0] "this call wrote a pass entry", [1] workgroups of k_escape_table that have finished
-__device__ __forceinline__ void escape_resolve(u64 s0, u32 nseg, u8 *__restrict__ esc, u8 *sh) {
-  const u32 tid = threadIdx.x, nthreads = blockDim.x;
-  const u32 per = (nseg + nthreads - 1u) / nthreads;
+__global__ __launch_bounds__(256) void k_escape_local(const u8 *__restrict__ buf, u64 s0, u32 nseg, u8 *__restrict__ esc) {
+  const u32 lane = threadIdx.x & 63u;
+  const u32 r = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (r >= nseg) { return; }
+  const u64 s = s0 + r;
+  u32 state = 0; // in front of byte 0 there is nothing
+  if (s > 0) {
+    // walk back over segment s-1 in steps of 1 KiB (16 bytes per lane, lane 0 nearest to the boundary)
+    const u8 *top = buf + s * SEG_BYTES;
+    state = ESC_PASS;
+    for (u32 k = 0; k < SEG_BYTES / 1024; k++, top -= 1024) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(top - 16u * (lane + 1u));
+      const u32 x[4] = {v.x ^ 0x5C5C5C5Cu, v.y ^ 0x5C5C5C5Cu, v.z ^ 0x5C5C5C5Cu, v.w ^ 0x5C5C5C5Cu}; // zero bytes = backslashes
+      const u64 other = __ballot((x[0] | x[1] | x[2] | x[3]) != 0);
+      if (other) {
+        // the nearest lane that holds something else: its backslashes above that byte end the run; everything
+        // nearer to the boundary is 16-byte groups of backslashes (an even number)
+        const u32 f = ctz64(other);
+        const u32 hi = x[3] ? x[3] : (x[2] ? x[2] : (x[1] ? x[1] : x[0])); // highest-addressed dword that is not all backslashes
+        const u32 above = u32(__clz(int(hi))) >> 3;                        // backslashes above its last other byte (0..3)
+        state = readlane_dyn(above, f) & 1u;                               // whole dwords above it add 4 each: parity unchanged
+        break;
+      }
+    }
+  }
+  if (lane == 0) {
+    esc[s] = u8(state);
+    if (state == ESC_PASS) { atomicOr(reinterpret_cast<u32 *>(esc + ESC_FLAG_OFFSET), 1u); }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_escape_resolve(u64 s0, u32 nseg, u8 *__restrict__ esc) {
+  u32 *flag = reinterpret_cast<u32 *>(esc + ESC_FLAG_OFFSET);
+  if (*flag == 0) { return; } // no pass entry: the table is final (workgroup-uniform)
+  __shared__ u8 sh[1024];
+  const u32 tid = threadIdx.x;
+  const u32 per = (nseg + 1023u) / 1024u;
   const u32 lo = min(tid * per, nseg), hi = min(lo + per, nseg);
   u32 last = ESC_PASS;
   for (u32 i = lo; i < hi; i++) {
-    const u32 v = __hip_atomic_load(esc + s0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 v = esc[s0 + i];
     if (v != ESC_PASS) { last = v; }
   }
   sh[tid] = u8(last);
@@ -439,62 +472,12 @@ __device__ __forceinline__ void escape_resolve(u64 s0, u32 nseg, u8 *__restrict_
   if (cur == ESC_PASS) { cur = (s0 > 0) ? (u32(esc[s0 - 1]) & 1u) : 0u; }
   __syncthreads(); // everybody has read esc[s0 - 1 ...] before anybody rewrites entries
   for (u32 i = lo; i < hi; i++) {
-    const u32 v = __hip_atomic_load(esc + s0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 v = esc[s0 + i];
     if (v == ESC_PASS) { esc[s0 + i] = u8(cur); }
     else { cur = v; }
   }
-}
-
-// One launch: every wave settles one boundary; the workgroup that finishes LAST resolves the pass entries, if any.
-__global__ __launch_bounds__(256) void k_escape_table(const u8 *__restrict__ buf, u64 s0, u32 nseg, u8 *__restrict__ esc) {
-  __shared__ u8 sh[256];
-  __shared__ u32 sh_last;
-  u32 *state_words = reinterpret_cast<u32 *>(esc + ESC_FLAG_OFFSET);
-  const u32 lane = threadIdx.x & 63u;
-  const u32 r = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (r < nseg) { // wave-uniform
-    const u64 s = s0 + r;
-    u32 state = 0; // in front of byte 0 there is nothing
-    if (s > 0) {
-      // walk back over segment s-1 in steps of 1 KiB (16 bytes per lane, lane 0 nearest to the boundary)
-      const u8 *top = buf + s * SEG_BYTES;
-      state = ESC_PASS;
-      for (u32 k = 0; k < SEG_BYTES / 1024; k++, top -= 1024) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(top - 16u * (lane + 1u));
-        const u32 x[4] = {v.x ^ 0x5C5C5C5Cu, v.y ^ 0x5C5C5C5Cu, v.z ^ 0x5C5C5C5Cu, v.w ^ 0x5C5C5C5Cu}; // zero bytes = backslashes
-        const u64 other = __ballot((x[0] | x[1] | x[2] | x[3]) != 0);
-        if (other) {
-          // the nearest lane that holds something else: its backslashes above that byte end the run; everything
-          // nearer to the boundary is 16-byte groups of backslashes (an even number)
-          const u32 f = ctz64(other);
-          const u32 hi = x[3] ? x[3] : (x[2] ? x[2] : (x[1] ? x[1] : x[0])); // highest-addressed dword that is not all backslashes
-          const u32 above = u32(__clz(int(hi))) >> 3;                        // backslashes above its last other byte (0..3)
-          state = readlane_dyn(above, f) & 1u;                               // whole dwords above it add 4 each: parity unchanged
-          break;
-        }
-      }
-    }
-    if (lane == 0) {
-      __hip_atomic_store(esc + s, u8(state), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (state == ESC_PASS) { atomicOr(&state_words[0], 1u); }
-    }
-  }
-  // "last workgroup out" hand-over: entries and flag are released before the count, acquired after it
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    sh_last = (atomicAdd(&state_words[1], 1u) == gridDim.x - 1u) ? 1u : 0u;
-  }
-  __syncthreads();
-  if (sh_last == 0u) { return; }
-  __threadfence();
-  const u32 any_pass = __hip_atomic_load(&state_words[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (any_pass) { escape_resolve(s0, nseg, esc, sh); } // workgroup-uniform
-  __syncthreads();
-  if (threadIdx.x == 0) { // ready for the next call
-    state_words[0] = 0;
-    state_words[1] = 0;
-  }
+  if (tid == 0) { *flag = 0; } // ready for the next call
 }
 
 } // namespace
@@ -562,7 +545,8 @@ void launch_escape_table(const uint8_t *buf, uint64_t begin, uint64_t len, uint8
   const u32 nseg = num_segments(len - begin);
   if (nseg == 0) { return; }
   const u64 s0 = begin / SEG_BYTES;
-  hipLaunchKernelGGL(k_escape_table, dim3((nseg + 3) / 4), dim3(256), 0, stream, buf, s0, nseg, esc);
+  hipLaunchKernelGGL(k_escape_local, dim3((nseg + 3) / 4), dim3(256), 0, stream, buf, s0, nseg, esc);
+  hipLaunchKernelGGL(k_escape_resolve, dim3(1), dim3(1024), 0, stream, s0, nseg, esc);
 }
 
 } // namespace sjgpu

@@ -591,7 +591,7 @@ def test_full_size_adversarial(orc, kind):
         p.close()
 
 
-# ---- long backslash runs: the escape table (k_escape_table) --------------------------------------------
+# ---- long backslash runs: the escape table (k_escape_local / k_escape_resolve) --------------------------------------------
 def _long_run_document(rng, total):
     """Strings that are backslash runs of 16 KiB-ish to MiB-ish lengths, each placed at a chosen distance from a 16 KiB
     segment boundary (so runs start / end exactly on, just before and just after boundaries, and some segments are
