@@ -272,6 +272,23 @@ __device__ __forceinline__ void emit_indices(u64 structural, u32 pos32, u32 lane
         a_lo += lo ? 1u : 0u; // stay on the last slot once the chain is exhausted
         a_hi += hi ? 1u : 0u;
       }
+    } else if (total > 2u * EMIT_WINDOW) {
+      // Dense chunk (minified small objects, arrays of digits, nesting: up to one offset per byte).  The per-lane
+      // extraction below would run 64 iterations per window with only the window's ~20 source lanes active; here
+      // the wave walks over the source blocks whose offsets fall into the window and expands ONE block per step
+      // with all 64 lanes: lane j owns bit j, its slot is the block's first slot + the number of set bits below j.
+      const u32 lim = w0 + EMIT_WINDOW;
+      const u32 rel = skew - w0;
+      const u32 first = incl - cnt;                 // my block's first element
+      const u32 value0 = pos32 - 63u * lane;         // + 64 * L = (byte offset of block L) + lane
+      const u32 mlo_mine = u32(structural), mhi_mine = u32(structural >> 32);
+      for (u64 rem = __ballot(cnt != 0 && incl > w0 && first < lim); rem; rem &= rem - 1) { // wave-uniform
+        const u32 L = ctz64(rem);
+        const u32 mlo = readlane_dyn(mlo_mine, L), mhi = readlane_dyn(mhi_mine, L);
+        const u32 e = readlane_dyn(first, L) + __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+        const bool mine = ((lane < 32u ? mlo >> lane : mhi >> (lane - 32u)) & 1u) != 0;
+        if (mine && e >= w0 && e < lim) { stage[e + rel] = value0 + 64u * L; }
+      }
     } else {
     const u32 lim = w0 + EMIT_WINDOW;
     const u32 rel = skew - w0; // stage slot of element e is e + rel (mod 2^32; e >= w0 whenever we store)

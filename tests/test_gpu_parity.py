@@ -155,6 +155,13 @@ def test_quote_parity_and_escape_carry_across_segments(gpu, orc):
 def test_adversarial_shapes(gpu, orc):
     for k in (1, 31, 32, 33, 2047, 2048, 2049, 8191, 8192, 8193, 100_000, 1 << 20):
         assert_same_all(gpu, orc, corpus.deep_nesting(k), tag=f"deep_nesting {k}")
+    # every emission regime of a 4 KiB chunk: one window, two windows (per-lane extraction), dense (block expansion);
+    # densities from 0.05 to 1.0 in one document so that neighbouring chunks take different paths
+    rng = np.random.default_rng(17)
+    units = [b"1,", b"[],", b'{"a":1},', b'"k":12,', b"1234567,", b'"some text here",', b"              1,", b"[[[[]]]],"]
+    for weights in ([1] * len(units), [8, 4, 1, 0, 0, 0, 0, 4], [0, 0, 1, 2, 4, 4, 2, 0], [1, 0, 0, 0, 0, 0, 0, 0]):
+        pick = rng.choice(len(units), size=200000, p=np.array(weights) / sum(weights))
+        assert_same_all(gpu, orc, b"[" + b"".join(units[i] for i in pick) + b"0]", tag=f"mixed density {weights}")
     runs = [1, 2, 63, 64, 65, 127, 128, 129, 4095, 4096, 4097, 16383, 16384, 16385, (1 << 20) - 1, 1 << 20, (1 << 20) + 1]
     for pad in (0, 1, 37, 63):
         assert_same_all(gpu, orc, corpus.backslash_runs(runs, pad), tag=f"backslash_runs pad {pad}")
