@@ -92,6 +92,31 @@ struct wave_carry {
   u32 utf8; // utf8 carry word (sj_block.h)
 };
 
+// ---- escape table (k_escape_table, sjgpu_kernels.hip) -------------------------------------------------------
+// esc[s] = 0 / 1: byte s * SEG_BYTES is not / is escaped; ESC_PASS: the segment in front of it is nothing but backslashes,
+// so the answer is that of esc[s - 1].  Pass entries only exist inside backslash runs of 16 KiB and more; readers
+// resolve them here, 256 entries per step (entry 0 is always 0, so the walk ends).  All lanes call with the same s.
+constexpr u32 ESC_PASS = 2;
+__device__ __forceinline__ u32 escape_lookup(const u8 *__restrict__ esc, u64 s, u32 lane) {
+  const u32 v = esc[s];
+  if (v != ESC_PASS) { return v & 1u; } // wave-uniform; the only path ordinary documents take
+  u64 top = s; // entries [0, top) are still candidates
+  while (top > 0) {
+    const u64 base = (top - 1) & ~u64(255);
+    const u32 w = *reinterpret_cast<const u32 *>(esc + base + 4u * lane); // entries base + 4 lane .. + 3
+    u32 found = 0, val = 0;
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) { // ascending, so the highest setting entry below top wins
+      const u32 e = (w >> (8u * j)) & 0xFFu;
+      if (base + 4u * lane + j < top && e != ESC_PASS) { found = 1; val = e; }
+    }
+    const u64 m = __ballot(found != 0);
+    if (m) { return readlane_dyn(val, 63u - clz64(m)) & 1u; }
+    top = base;
+  }
+  return 0u;
+}
+
 // parity of the maximal backslash run ending at byte end-1 (0 if end == 0 or no run).
 // esc (may be null): the escape table of the call, esc[s] = that parity for end = s * SEG_BYTES, computed exactly by
 // k_escape_local / k_escape_resolve before the scan.  With it the walk stops at the first segment boundary it reaches
@@ -99,7 +124,7 @@ struct wave_carry {
 // which is why every call beyond FUSED_SMALL_BELOW bytes gets the table.  `end` is a multiple of 64 at every call site.
 __device__ __forceinline__ u32 backslash_run_parity(const u8 *__restrict__ buf, u64 end, u32 lane, const u8 *__restrict__ esc) {
   for (;;) {
-    if (esc && (end % SEG_BYTES) == 0) { return u32(esc[end / SEG_BYTES]) & 1u; } // wave-uniform
+    if (esc && (end % SEG_BYTES) == 0) { return escape_lookup(esc, end / SEG_BYTES, lane); } // wave-uniform
     const u32 byte = (end > lane) ? u32(buf[end - 1 - lane]) : 0u;
     const u64 m = __ballot(byte == 0x5Cu);
     if (~m) { return ctz64(~m) & 1u; }
@@ -132,7 +157,7 @@ __device__ __forceinline__ wave_carry segment_carry_from(const u8 *__restrict__ 
   c.utf8 = utf8_carry_from_bytes(b3, b2, b1);
   const u64 m = __ballot(byte == 0x5Cu);
   // a span that starts on a segment boundary reads its escape carry-in straight from the table (no walk at all)
-  c.e = (esc && (start % SEG_BYTES) == 0) ? (u32(esc[start / SEG_BYTES]) & 1u) : run_parity_from_mask(buf, start, lane, m, 0, esc);
+  c.e = (esc && (start % SEG_BYTES) == 0) ? escape_lookup(esc, start / SEG_BYTES, lane) : run_parity_from_mask(buf, start, lane, m, 0, esc);
   if (b1 == 0x22u) {
     c.p = run_parity_from_mask(buf, start, lane, m, 1, esc);
   } else {

@@ -96,7 +96,7 @@ void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *res
 // front of byte s * SEG_BYTES, i.e. "that byte is escaped".  One 64-byte read per segment for ordinary input.  esc holds
 // ESC_TABLE_BYTES bytes; entry begin / SEG_BYTES - 1 must be valid (from the previous range of the same buffer) if begin > 0.
 constexpr size_t ESC_TABLE_ENTRIES = (uint64_t(1) << 32) / SEG_BYTES + 1;
-constexpr size_t ESC_TABLE_BYTES = ESC_TABLE_ENTRIES + 64; // + the "a pass entry exists" flag word behind the entries
+constexpr size_t ESC_TABLE_BYTES = (ESC_TABLE_ENTRIES + 1023) & ~size_t(1023); // readers load whole aligned dwords
 void launch_escape_table(const uint8_t *buf, uint64_t begin, uint64_t len, uint8_t *esc, hipStream_t stream);
 void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *result, hipStream_t stream, hipEvent_t *ev);
 // single-pass variants: desc holds num_fused_tiles(capacity)+1 words; only profile slot 0 is used

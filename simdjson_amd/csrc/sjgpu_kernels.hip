@@ -412,72 +412,47 @@ __global__ __launch_bounds__(64) void k_string_parity(const u8 *__restrict__ buf
 
 // =====================================================================================================
 // escape table: esc[s] = "byte s * SEG_BYTES is escaped" = parity of the backslash run ending in front of it.
-// The scan kernels derive a segment's escape carry-in by looking back over the bytes in front of it; over one long
-// backslash run that walk would be as long as the run, for EVERY segment inside it (quadratic: a 1 GiB document of
-// backslashes would take minutes).  Here every boundary walks at most ONE segment back (k_escape_local); a segment
-// that is nothing but backslashes passes its own carry-in through (16 KiB is even), and those rare entries are
-// resolved by one small scan (k_escape_resolve).  Ordinary input: one 64-byte read per segment, no pass entries.
+// The scan kernels derive a span's escape carry-in by looking back over the bytes in front of it; over one long
+// backslash run that walk would be as long as the run, for EVERY span inside it (quadratic: a 1 GiB document of
+// backslashes would take minutes).  Here every boundary looks back over at most ONE segment, 1 KiB per step; a
+// segment that is nothing but backslashes hands its own carry-in on (16 KiB is even) and is recorded as ESC_PASS,
+// which the readers resolve on demand (escape_lookup, sjgpu_device.h).  Ordinary input: one 1 KiB read per segment.
 // =====================================================================================================
-constexpr u8 ESC_PASS = 2;
-constexpr size_t ESC_FLAG_OFFSET = (ESC_TABLE_ENTRIES + 3) & ~size_t(3); // u32: "this call wrote a pass entry"
+constexpr u32 ESC_PER_WAVE = 8; // boundaries per wave: fewer, fatter workgroups (the kernel is dispatch-bound otherwise)
 
-__global__ __launch_bounds__(256) void k_escape_local(const u8 *__restrict__ buf, u64 s0, u32 nseg, u8 *__restrict__ esc) {
-  const u32 lane = threadIdx.x & 63u;
-  const u32 r = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (r >= nseg) { return; }
-  const u64 s = s0 + r;
-  u32 state = 0; // in front of byte 0 there is nothing
-  if (s > 0) {
-    // walk back over segment s-1 in steps of 1 KiB (16 bytes per lane, lane 0 nearest to the boundary)
-    const u8 *top = buf + s * SEG_BYTES;
-    state = ESC_PASS;
-    for (u32 k = 0; k < SEG_BYTES / 1024; k++, top -= 1024) {
-      const uint4 v = *reinterpret_cast<const uint4 *>(top - 16u * (lane + 1u));
-      const u32 x[4] = {v.x ^ 0x5C5C5C5Cu, v.y ^ 0x5C5C5C5Cu, v.z ^ 0x5C5C5C5Cu, v.w ^ 0x5C5C5C5Cu}; // zero bytes = backslashes
-      const u64 other = __ballot((x[0] | x[1] | x[2] | x[3]) != 0);
-      if (other) {
-        // the nearest lane that holds something else: its backslashes above that byte end the run; everything
-        // nearer to the boundary is 16-byte groups of backslashes (an even number)
-        const u32 f = ctz64(other);
-        const u32 hi = x[3] ? x[3] : (x[2] ? x[2] : (x[1] ? x[1] : x[0])); // highest-addressed dword that is not all backslashes
-        const u32 above = u32(__clz(int(hi))) >> 3;                        // backslashes above its last other byte (0..3)
-        state = readlane_dyn(above, f) & 1u;                               // whole dwords above it add 4 each: parity unchanged
-        break;
-      }
-    }
-  }
-  if (lane == 0) {
-    esc[s] = u8(state);
-    if (state == ESC_PASS) { atomicOr(reinterpret_cast<u32 *>(esc + ESC_FLAG_OFFSET), 1u); }
-  }
+// state of the boundary in front of which `top` points, from the 1 KiB below it; ESC_PASS if those are all backslashes
+__device__ __forceinline__ u32 escape_step(const u8 *top, u32 lane) {
+  const uint4 v = *reinterpret_cast<const uint4 *>(top - 16u * (lane + 1u)); // lane 0 nearest to the boundary
+  const u32 x[4] = {v.x ^ 0x5C5C5C5Cu, v.y ^ 0x5C5C5C5Cu, v.z ^ 0x5C5C5C5Cu, v.w ^ 0x5C5C5C5Cu}; // zero bytes = backslashes
+  const u64 other = __ballot((x[0] | x[1] | x[2] | x[3]) != 0);
+  if (other == 0) { return ESC_PASS; }
+  // the nearest lane that holds something else: its backslashes above that byte end the run; everything nearer to
+  // the boundary is 16-byte groups of backslashes (an even number)
+  const u32 f = ctz64(other);
+  const u32 hi = x[3] ? x[3] : (x[2] ? x[2] : (x[1] ? x[1] : x[0])); // highest-addressed dword that is not all backslashes
+  const u32 above = u32(__clz(int(hi))) >> 3;                        // backslashes above its last other byte (0..3)
+  return readlane_dyn(above, f) & 1u;                                // whole dwords above it add 4 each: parity unchanged
 }
 
-__global__ __launch_bounds__(1024) void k_escape_resolve(u64 s0, u32 nseg, u8 *__restrict__ esc) {
-  u32 *flag = reinterpret_cast<u32 *>(esc + ESC_FLAG_OFFSET);
-  if (*flag == 0) { return; } // no pass entry: the table is final (workgroup-uniform)
-  __shared__ u8 sh[1024];
-  const u32 tid = threadIdx.x;
-  const u32 per = (nseg + 1023u) / 1024u;
-  const u32 lo = min(tid * per, nseg), hi = min(lo + per, nseg);
-  u32 last = ESC_PASS;
-  for (u32 i = lo; i < hi; i++) {
-    const u32 v = esc[s0 + i];
-    if (v != ESC_PASS) { last = v; }
+__global__ __launch_bounds__(256) void k_escape_table(const u8 *__restrict__ buf, u64 s0, u32 nseg, u8 *__restrict__ esc) {
+  const u32 lane = threadIdx.x & 63u;
+  const u32 r0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * ESC_PER_WAVE;
+  u32 state[ESC_PER_WAVE];
+#pragma unroll
+  for (u32 i = 0; i < ESC_PER_WAVE; i++) { // the first step of all boundaries: independent loads, in flight together
+    const u64 s = s0 + r0 + i;
+    state[i] = (r0 + i < nseg && s > 0) ? escape_step(buf + s * SEG_BYTES, lane) : 0u; // nothing in front of byte 0
   }
-  sh[tid] = u8(last);
-  __syncthreads();
-  // state in front of my slice: the nearest setting slice below me, else what the previous range of this buffer left
-  u32 cur = ESC_PASS;
-  for (int t = int(tid) - 1; t >= 0 && cur == ESC_PASS; t--) { cur = sh[t]; }
-  if (cur == ESC_PASS) { cur = (s0 > 0) ? (u32(esc[s0 - 1]) & 1u) : 0u; }
-  __syncthreads(); // everybody has read esc[s0 - 1 ...] before anybody rewrites entries
-  for (u32 i = lo; i < hi; i++) {
-    const u32 v = esc[s0 + i];
-    if (v == ESC_PASS) { esc[s0 + i] = u8(cur); }
-    else { cur = v; }
+#pragma unroll
+  for (u32 i = 0; i < ESC_PER_WAVE; i++) {
+    if (r0 + i >= nseg) { break; }
+    const u64 s = s0 + r0 + i;
+    u32 st = state[i];
+    for (u32 k = 1; st == ESC_PASS && k < SEG_BYTES / 1024; k++) { // rare: the run is longer than 1 KiB
+      st = escape_step(buf + s * SEG_BYTES - u64(k) * 1024u, lane);
+    }
+    if (lane == 0) { esc[s] = u8(st); }
   }
-  __syncthreads();
-  if (tid == 0) { *flag = 0; } // ready for the next call
 }
 
 } // namespace
@@ -545,8 +520,8 @@ void launch_escape_table(const uint8_t *buf, uint64_t begin, uint64_t len, uint8
   const u32 nseg = num_segments(len - begin);
   if (nseg == 0) { return; }
   const u64 s0 = begin / SEG_BYTES;
-  hipLaunchKernelGGL(k_escape_local, dim3((nseg + 3) / 4), dim3(256), 0, stream, buf, s0, nseg, esc);
-  hipLaunchKernelGGL(k_escape_resolve, dim3(1), dim3(1024), 0, stream, s0, nseg, esc);
+  const u32 per_wg = 4u * ESC_PER_WAVE;
+  hipLaunchKernelGGL(k_escape_table, dim3((nseg + per_wg - 1) / per_wg), dim3(256), 0, stream, buf, s0, nseg, esc);
 }
 
 } // namespace sjgpu
