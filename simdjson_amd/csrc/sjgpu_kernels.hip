@@ -416,7 +416,7 @@ __global__ __launch_bounds__(64) void k_string_parity(const u8 *__restrict__ buf
 // backslash run that walk would be as long as the run, for EVERY span inside it (quadratic: a 1 GiB document of
 // backslashes would take minutes).  Here every boundary looks back over at most ONE segment, 1 KiB per step; a
 // segment that is nothing but backslashes hands its own carry-in on (16 KiB is even) and is recorded as ESC_PASS,
-// which the readers resolve on demand (escape_lookup, sjgpu_device.h).  Ordinary input: one 1 KiB read per segment.
+// which the readers resolve on demand (escape_lookup, sjgpu_device.h).  Ordinary input: one 64-byte read per segment.
 // =====================================================================================================
 constexpr u32 ESC_PER_WAVE = 8; // boundaries per wave: fewer, fatter workgroups (the kernel is dispatch-bound otherwise)
 
@@ -439,16 +439,20 @@ __global__ __launch_bounds__(256) void k_escape_table(const u8 *__restrict__ buf
   const u32 r0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * ESC_PER_WAVE;
   u32 state[ESC_PER_WAVE];
 #pragma unroll
-  for (u32 i = 0; i < ESC_PER_WAVE; i++) { // the first step of all boundaries: independent loads, in flight together
+  for (u32 i = 0; i < ESC_PER_WAVE; i++) { // the last 64 bytes in front of every boundary: independent loads, in flight together
     const u64 s = s0 + r0 + i;
-    state[i] = (r0 + i < nseg && s > 0) ? escape_step(buf + s * SEG_BYTES, lane) : 0u; // nothing in front of byte 0
+    state[i] = 0u; // nothing in front of byte 0
+    if (r0 + i < nseg && s > 0) {
+      const u64 m = __ballot(buf[s * SEG_BYTES - 1u - lane] == 0x5Cu);
+      state[i] = ~m ? (ctz64(~m) & 1u) : ESC_PASS;
+    }
   }
 #pragma unroll
   for (u32 i = 0; i < ESC_PER_WAVE; i++) {
     if (r0 + i >= nseg) { break; }
     const u64 s = s0 + r0 + i;
     u32 st = state[i];
-    for (u32 k = 1; st == ESC_PASS && k < SEG_BYTES / 1024; k++) { // rare: the run is longer than 1 KiB
+    for (u32 k = 0; st == ESC_PASS && k < SEG_BYTES / 1024; k++) { // rare: a run of 64 backslashes and more, 1 KiB per step
       st = escape_step(buf + s * SEG_BYTES - u64(k) * 1024u, lane);
     }
     if (lane == 0) { esc[s] = u8(st); }
