@@ -230,23 +230,17 @@ bool use_fused(const sjgpu_ctx *ctx, size_t len) {
 }
 
 // `len` is the END of the scan (bytes [org.begin, len) are scanned); a whole document has org = {0, 0, 0}
-// Scans longer than the small-tile limit get the escape table first: it bounds the look-back over backslash runs
-// (sjgpu_kernels.hip, k_escape_local).  Shorter ones walk; their worst case is bounded by their size.
-void prepare_escapes(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, scan_origin &org, hipStream_t s) {
-  if (len - org.begin <= FUSED_SMALL_BELOW) { return; }
-  launch_escape_table(buf, org.begin, len, ctx->esc_tab, s);
-  org.esc = ctx->esc_tab;
-}
-
+// Every scan is handed the context's escape-table workspace; the launchers fill and use it for scans beyond the
+// small-tile limit (launch_escape_table, sjgpu_kernels.hip) and ignore it below.
 void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint32_t *idx, size_t idx_words, hipStream_t s,
                     hipEvent_t *ev, scan_origin org = scan_origin{0, 0, 0}) {
-  prepare_escapes(ctx, buf, len, org, s);
+  org.esc = ctx->esc_tab;
   if (fused) { launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, org, ctx->max_workgroups, s, ev); }
   else { launch_stage1(buf, len, ctx->masks, ctx->summ, ctx->pref, idx, idx_words, ctx->d_result, org, s, ev); }
 }
 void enqueue_minify(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint8_t *dst, hipStream_t s, hipEvent_t *ev,
                     scan_origin org = scan_origin{0, 0, 0}) {
-  prepare_escapes(ctx, buf, len, org, s);
+  org.esc = ctx->esc_tab;
   if (fused) { launch_minify_fused(buf, len, ctx->desc, dst, ctx->d_result, org, ctx->max_workgroups, s, ev); }
   else { launch_minify(buf, len, ctx->summ, ctx->pref, dst, ctx->d_result, org, s, ev); }
 }
@@ -536,9 +530,7 @@ int sjgpu_string_parity_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
   if (!ctx || (len && (!buf_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u)))) { return SJGPU_E_BADARG; }
   if (len > ctx->capacity) { return E_CAPACITY; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
-  scan_origin org{0, 0, 0};
-  prepare_escapes(ctx, static_cast<const uint8_t *>(buf_dev), len, org, pick(ctx, stream));
-  launch_string_parity(static_cast<const uint8_t *>(buf_dev), len, ctx->d_result, org.esc, pick(ctx, stream));
+  launch_string_parity(static_cast<const uint8_t *>(buf_dev), len, ctx->d_result, ctx->esc_tab, pick(ctx, stream));
   SJ_TRY(ctx, hipGetLastError());
   return 0;
 }

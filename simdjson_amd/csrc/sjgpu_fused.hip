@@ -560,18 +560,29 @@ static void launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *des
                          scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
                          hipEvent_t *ev, uint64_t *trace = nullptr, uint32_t trace_tiles = 0) {
   static const bool plain = std::getenv("SJGPU_FUSED_PLAIN") != nullptr; // A/B switch: the non-pipelined large-input kernel
+  uint8_t *const esc_workspace = const_cast<uint8_t *>(org.esc);
+  if (!wants_escape_table(len - org.begin) || !esc_workspace) { org.esc = nullptr; }
   if (len - org.begin <= FUSED_SMALL_BELOW && !trace) {
     launch_fused_wc<1>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles);
   } else if (trace || plain) {
+    if (org.esc) { launch_escape_table(buf, org.begin, len, esc_workspace, stream); }
     launch_fused_wc<FUSED_WAVE_CHUNKS>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles);
   } else {
     const u32 ntiles = u32((len - org.begin + FUSED_TILE_BYTES - 1) / FUSED_TILE_BYTES);
     u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles);
-    if (reinterpret_cast<uint64_t *>(result + 1) == desc) {
-      (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev) + (size_t(ntiles) + 1) * sizeof(u64), stream);
+    // result, descriptors and ticket lie back to back (sjgpu_capi.hip): the escape-table launch zeroes them on the side
+    const bool contiguous = reinterpret_cast<uint64_t *>(result + 1) == desc;
+    const size_t clear_bytes = sizeof(scan_result_dev) + (size_t(ntiles) + 1) * sizeof(u64);
+    if (org.esc && contiguous) {
+      launch_escape_table(buf, org.begin, len, esc_workspace, stream, result, clear_bytes);
     } else {
-      (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
-      (void)hipMemsetAsync(desc, 0, (size_t(ntiles) + 1) * sizeof(u64), stream);
+      if (org.esc) { launch_escape_table(buf, org.begin, len, esc_workspace, stream); }
+      if (contiguous) {
+        (void)hipMemsetAsync(result, 0, clear_bytes, stream);
+      } else {
+        (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
+        (void)hipMemsetAsync(desc, 0, (size_t(ntiles) + 1) * sizeof(u64), stream);
+      }
     }
     // half as many workgroups as tiles at most: every workgroup should own >= 2 tiles for the deferral to work
     const u32 cap = (ntiles + 1) / 2;

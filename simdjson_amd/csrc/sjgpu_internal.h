@@ -83,21 +83,26 @@ struct scan_origin {
   uint64_t begin;
   uint32_t base0;
   uint32_t carry;
-  const uint8_t *esc; // escape table (launch_escape_table) or nullptr: esc[s] = "byte s * SEG_BYTES is escaped"
+  const uint8_t *esc; // callers of the launchers: the table workspace (ESC_TABLE_BYTES); kernels: the filled table or nullptr
 };
 constexpr uint64_t RANGE_ALIGN = uint64_t(1) << 20; // one resolve group = 16 large tiles = 64 small tiles
 void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *summ, seg_prefix *pref, uint32_t *idx,
                    uint64_t idx_words, scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev);
 void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_prefix *pref, uint8_t *dst,
                    scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev);
-void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *result, const uint8_t *esc,
+void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *result, uint8_t *esc_workspace,
                           hipStream_t stream); // result->n = parity
 // Escape table for bytes [begin, len) of buf: esc[s] (s = absolute segment index) = parity of the backslash run that ends in
 // front of byte s * SEG_BYTES, i.e. "that byte is escaped".  One 64-byte read per segment for ordinary input.  esc holds
 // ESC_TABLE_BYTES bytes; entry begin / SEG_BYTES - 1 must be valid (from the previous range of the same buffer) if begin > 0.
 constexpr size_t ESC_TABLE_ENTRIES = (uint64_t(1) << 32) / SEG_BYTES + 1;
 constexpr size_t ESC_TABLE_BYTES = (ESC_TABLE_ENTRIES + 1023) & ~size_t(1023); // readers load whole aligned dwords
-void launch_escape_table(const uint8_t *buf, uint64_t begin, uint64_t len, uint8_t *esc, hipStream_t stream);
+// clear / clear_bytes (optional, a multiple of 8): memory the same launch zeroes, so that the single-pass pipeline's
+// result + descriptors + ticket need no memset of their own.
+void launch_escape_table(const uint8_t *buf, uint64_t begin, uint64_t len, uint8_t *esc, hipStream_t stream,
+                         void *clear = nullptr, size_t clear_bytes = 0);
+// scans up to FUSED_SMALL_BELOW bytes walk over backslash runs (bounded by their size); longer ones get the table
+inline bool wants_escape_table(uint64_t scanned_bytes) { return scanned_bytes > FUSED_SMALL_BELOW; }
 void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *result, hipStream_t stream, hipEvent_t *ev);
 // single-pass variants: desc holds num_fused_tiles(capacity)+1 words; only profile slot 0 is used
 void launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,

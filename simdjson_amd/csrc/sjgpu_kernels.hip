@@ -434,7 +434,9 @@ __device__ __forceinline__ u32 escape_step(const u8 *top, u32 lane) {
   return readlane_dyn(above, f) & 1u;                                // whole dwords above it add 4 each: parity unchanged
 }
 
-__global__ __launch_bounds__(256) void k_escape_table(const u8 *__restrict__ buf, u64 s0, u32 nseg, u8 *__restrict__ esc) {
+__global__ __launch_bounds__(256) void k_escape_table(const u8 *__restrict__ buf, u64 s0, u32 nseg, u8 *__restrict__ esc,
+                                                      u64 *__restrict__ clear, u32 clear_words) {
+  for (u32 i = blockIdx.x * 256u + threadIdx.x; i < clear_words; i += gridDim.x * 256u) { clear[i] = 0; }
   const u32 lane = threadIdx.x & 63u;
   const u32 r0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * ESC_PER_WAVE;
   u32 state[ESC_PER_WAVE];
@@ -469,6 +471,8 @@ static inline void mark(hipEvent_t *ev, int k, hipStream_t stream) {
 void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *summ, seg_prefix *pref, uint32_t *idx,
                    uint64_t idx_words, scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev) {
   const u32 nseg = num_segments(len - org.begin);
+  if (wants_escape_table(len - org.begin) && org.esc) { launch_escape_table(buf, org.begin, len, const_cast<uint8_t *>(org.esc), stream); }
+  else { org.esc = nullptr; }
   mark(ev, 0, stream);
   u64 *mask0 = reinterpret_cast<u64 *>(masks);
   u64 *mask1 = mask0 + size_t(nseg) * (SEG_BYTES / BLOCK_BYTES); // second plane, only written by unresolved segments
@@ -488,6 +492,8 @@ void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *
 void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_prefix *pref, uint8_t *dst,
                    scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev) {
   const u32 nseg = num_segments(len - org.begin);
+  if (wants_escape_table(len - org.begin) && org.esc) { launch_escape_table(buf, org.begin, len, const_cast<uint8_t *>(org.esc), stream); }
+  else { org.esc = nullptr; }
   mark(ev, 0, stream);
   hipLaunchKernelGGL(k_minify_summarize, dim3(nseg), dim3(64), 0, stream, buf, len, summ, org);
   mark(ev, 1, stream);
@@ -512,20 +518,27 @@ void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *res
   mark(ev, 3, stream);
 }
 
-void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *result, const uint8_t *esc, hipStream_t stream) {
+void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *result, uint8_t *esc_workspace, hipStream_t stream) {
   (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
   const u32 nseg = num_segments(len);
   if (nseg == 0) { return; }
+  const uint8_t *esc = nullptr;
+  if (wants_escape_table(len)) {
+    launch_escape_table(buf, 0, len, esc_workspace, stream);
+    esc = esc_workspace;
+  }
   const u32 grid = nseg < 8192u ? nseg : 8192u;
   hipLaunchKernelGGL(k_string_parity, dim3(grid), dim3(64), 0, stream, buf, len, nseg, result, esc);
 }
 
-void launch_escape_table(const uint8_t *buf, uint64_t begin, uint64_t len, uint8_t *esc, hipStream_t stream) {
+void launch_escape_table(const uint8_t *buf, uint64_t begin, uint64_t len, uint8_t *esc, hipStream_t stream, void *clear,
+                         size_t clear_bytes) {
   const u32 nseg = num_segments(len - begin);
   if (nseg == 0) { return; }
   const u64 s0 = begin / SEG_BYTES;
   const u32 per_wg = 4u * ESC_PER_WAVE;
-  hipLaunchKernelGGL(k_escape_table, dim3((nseg + per_wg - 1) / per_wg), dim3(256), 0, stream, buf, s0, nseg, esc);
+  hipLaunchKernelGGL(k_escape_table, dim3((nseg + per_wg - 1) / per_wg), dim3(256), 0, stream, buf, s0, nseg, esc,
+                     static_cast<u64 *>(clear), u32(clear_bytes / 8));
 }
 
 } // namespace sjgpu
