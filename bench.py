@@ -244,6 +244,17 @@ def ndjson_leg(args, torch, dist, corpus, capi, rank, world, local_rank, fence):
     out["value_GBps"] = round(total * steps / dt_scan / 1e9, 2)
     out["steps"] = steps
     scanner.parser.close()
+    if world == 1 and not args.no_cpu_baseline:
+        # the same NDJSON on T independent host threads, each with its own reference parser
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import cpu_baseline
+        threads = os.cpu_count() or 1
+        cb = cpu_baseline.time_cpu_ndjson_threads(host, threads, max(2, args.cpu_iters // 4))
+        if cb is not None:
+            out["cpu_baseline_threads"] = {"value": round(cb["value"], 2), "unit": "GB/s", "cores": cb["cores"], "kind": cb["kind"],
+                                           "sample": f"the same {L}-byte NDJSON buffer cut at newlines into {cb['cores']} slices, "
+                                                     f"{cb['impl']} kernel, one parser per thread, {threads} hardware threads on the box",
+                                           "structurals": cb["n"]}
     return out
 
 

@@ -19,7 +19,7 @@ for s in $STAGES; do
       done
       timeout 600 python bench.py --pipeline fused --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_stage1_fused.json 2> gpurun_out/bench_stage1_fused.err; cat gpurun_out/bench_stage1_fused.json
       timeout 600 python bench.py --op minify --pipeline fused --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_minify_fused.json 2> gpurun_out/bench_minify_fused.err; cat gpurun_out/bench_minify_fused.json
-      timeout 600 python bench.py --ndjson-leg 1 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/bench_ndjson_leg.json 2> gpurun_out/bench_ndjson_leg.err; cat gpurun_out/bench_ndjson_leg.json
+      timeout 600 python bench.py --ndjson-leg 1 --steps 10 --warmup 2 > gpurun_out/bench_ndjson_leg.json 2> gpurun_out/bench_ndjson_leg.err; cat gpurun_out/bench_ndjson_leg.json
       timeout 600 python bench.py --workload amazon_ndjson --steps 20 --warmup 3 > gpurun_out/bench_stage1_ndjson.json 2> gpurun_out/bench_stage1_ndjson.err; cat gpurun_out/bench_stage1_ndjson.json
       timeout 600 python bench.py --workload twitter_like --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_stage1_twitter.json 2> gpurun_out/bench_stage1_twitter.err; cat gpurun_out/bench_stage1_twitter.json
       for wl in deep_nesting escape_heavy; do
