@@ -1,9 +1,10 @@
 #!/bin/bash
 # scripts/gpu_pmc.sh -- PMC passes (each counter set in its own rocprofv3 run, kernel-trace only).
-# Usage: bash scripts/gpu_pmc.sh "<bench args>" tag
+# Usage: bash scripts/gpu_pmc.sh "<bench args>" tag ["fetch write sq1 sq2"]
 set -u
 ARGS=${1:-"--op stage1"}
 TAG=${2:-stage1}
+SETS=${3:-"fetch write sq1 sq2"}
 mkdir -p gpurun_out/pmc_$TAG
 export TMPDIR=/tmp
 run() { # name, counters...
@@ -12,10 +13,14 @@ run() { # name, counters...
      python $GRAFT_REPO_ROOT/bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG/$name.log 2>&1)
   echo "pmc $name rc=$?"
 }
-run fetch FETCH_SIZE
-run write WRITE_SIZE
-run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
-run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM GRBM_GUI_ACTIVE
+for set in $SETS; do
+  case $set in
+    fetch) run fetch FETCH_SIZE ;;
+    write) run write WRITE_SIZE ;;
+    sq1) run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR ;;
+    sq2) run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM GRBM_GUI_ACTIVE ;;
+  esac
+done
 find gpurun_out/pmc_$TAG -name "*counter_collection.csv" | head
 python3 - <<PY
 import csv, glob, collections
