@@ -28,6 +28,8 @@ for s in $STAGES; do
         done
       done
       ;;
+    multi) # the N > 1 code path on a 1-GPU box: two ranks over gloo sharing the device (the driver's real runs use RCCL, one GPU per rank)
+      timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --share-device --size 268435456 > gpurun_out/bench_2ranks_shared.json 2> gpurun_out/bench_2ranks_shared.err; echo "multi rc=$?"; cat gpurun_out/bench_2ranks_shared.json ;;
     sweep)
       timeout 900 python scripts/size_sweep.py twitter_like > gpurun_out/size_sweep_twitter.jsonl 2> gpurun_out/size_sweep.err; cat gpurun_out/size_sweep_twitter.jsonl
       timeout 900 python scripts/size_sweep.py large_random > gpurun_out/size_sweep_large_random.jsonl 2>> gpurun_out/size_sweep.err; cat gpurun_out/size_sweep_large_random.jsonl
