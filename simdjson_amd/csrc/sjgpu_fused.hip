@@ -560,7 +560,7 @@ static void launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *des
                          scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
                          hipEvent_t *ev, uint64_t *trace = nullptr, uint32_t trace_tiles = 0) {
   static const bool plain = std::getenv("SJGPU_FUSED_PLAIN") != nullptr; // A/B switch: the non-pipelined large-input kernel
-  uint8_t *const esc_workspace = const_cast<uint8_t *>(org.esc);
+  uint8_t *const esc_workspace = org.esc;
   if (!wants_escape_table(len - org.begin) || !esc_workspace) { org.esc = nullptr; }
   if (len - org.begin <= FUSED_SMALL_BELOW && !trace) {
     launch_fused_wc<1>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles);

@@ -83,7 +83,8 @@ struct scan_origin {
   uint64_t begin;
   uint32_t base0;
   uint32_t carry;
-  const uint8_t *esc; // callers of the launchers: the table workspace (ESC_TABLE_BYTES); kernels: the filled table or nullptr
+  uint8_t *esc; // escape table: the launchers get the context's workspace (ESC_TABLE_BYTES), fill it for scans beyond
+                // FUSED_SMALL_BELOW bytes and hand nullptr to the kernels of shorter ones; kernels only read it
 };
 constexpr uint64_t RANGE_ALIGN = uint64_t(1) << 20; // one resolve group = 16 large tiles = 64 small tiles
 void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *summ, seg_prefix *pref, uint32_t *idx,

@@ -471,7 +471,7 @@ static inline void mark(hipEvent_t *ev, int k, hipStream_t stream) {
 void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *summ, seg_prefix *pref, uint32_t *idx,
                    uint64_t idx_words, scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev) {
   const u32 nseg = num_segments(len - org.begin);
-  if (wants_escape_table(len - org.begin) && org.esc) { launch_escape_table(buf, org.begin, len, const_cast<uint8_t *>(org.esc), stream); }
+  if (wants_escape_table(len - org.begin) && org.esc) { launch_escape_table(buf, org.begin, len, org.esc, stream); }
   else { org.esc = nullptr; }
   mark(ev, 0, stream);
   u64 *mask0 = reinterpret_cast<u64 *>(masks);
@@ -492,7 +492,7 @@ void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *
 void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_prefix *pref, uint8_t *dst,
                    scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev) {
   const u32 nseg = num_segments(len - org.begin);
-  if (wants_escape_table(len - org.begin) && org.esc) { launch_escape_table(buf, org.begin, len, const_cast<uint8_t *>(org.esc), stream); }
+  if (wants_escape_table(len - org.begin) && org.esc) { launch_escape_table(buf, org.begin, len, org.esc, stream); }
   else { org.esc = nullptr; }
   mark(ev, 0, stream);
   hipLaunchKernelGGL(k_minify_summarize, dim3(nseg), dim3(64), 0, stream, buf, len, summ, org);
