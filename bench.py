@@ -76,8 +76,8 @@ def main():
     L = len(host)
     parser = capi.DomParserImplementation(L, device=local_rank)
     parser.set_pipeline(args.pipeline)
-    if args.pipeline == "auto":  # what AUTO resolves to for this size (sjgpu_capi.hip: AUTO_FUSED_BELOW)
-        args.pipeline = "fused" if (L <= (8 << 20) or L >= (192 << 20)) else "split"
+    auto = args.pipeline == "auto"
+    args.requested_pipeline = args.pipeline
     buf = torch.from_numpy(host).cuda()
     stream = torch.cuda.current_stream().cuda_stream
     if args.op == "stage1":
@@ -107,6 +107,10 @@ def main():
     if err != 0:
         raise SystemExit(f"rank {rank}: {args.op} returned error_code {err} on the synthetic buffer")
 
+    if auto:  # what AUTO settled on after the warm-up scans (size and, for stage 1, the density it saw)
+        assert step() == 0
+        parser.result(stream)
+        args.pipeline = "fused" if args.op == "validate_utf8" else parser.last_pipeline()
     parser.profile_enable(True)
     fence()
     t0 = time.perf_counter()
@@ -198,7 +202,7 @@ def ndjson_leg(args, torch, dist, corpus, capi, rank, world, local_rank, fence):
     host, lines = corpus.amazon_ndjson(args.size, 2000 + rank)  # each rank's slice of the stream (ends in '\n')
     L = len(host)
     scanner = sharded.GpuShardScanner(L, local_rank)
-    scanner.parser.set_pipeline(args.pipeline)
+    scanner.parser.set_pipeline(args.requested_pipeline)  # AUTO learns the density from the warm-up scans
     buf = torch.from_numpy(host).cuda()
     idx = torch.empty(L + 3, dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream

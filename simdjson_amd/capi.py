@@ -27,7 +27,7 @@ EXPORTS = [
     "sjgpu_stage1_finish_host", "sjgpu_trim_partial_utf8", "sjgpu_profile_enable", "sjgpu_profile_read", "sjgpu_set_pipeline", "sjgpu_debug_trace_stage1",
     "sjgpu_clean_cut", "sjgpu_string_parity_device", "sjgpu_stage1_shard_device", "sjgpu_minify_shard_device",
     "sjgpu_stage1_range_device", "sjgpu_minify_range_device",
-    "sjgpu_host_alloc", "sjgpu_host_free", "sjgpu_host_register", "sjgpu_host_unregister",
+    "sjgpu_host_alloc", "sjgpu_host_free", "sjgpu_host_register", "sjgpu_host_unregister", "sjgpu_last_pipeline",
 ]
 
 
@@ -113,6 +113,8 @@ def load_library():
     L.sjgpu_stage1_range_device.argtypes = [vp, vp, sz, sz, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, vp, sz, vp]
     L.sjgpu_minify_range_device.restype = ctypes.c_int
     L.sjgpu_minify_range_device.argtypes = [vp, vp, sz, sz, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, vp, vp]
+    L.sjgpu_last_pipeline.restype = ctypes.c_int
+    L.sjgpu_last_pipeline.argtypes = [vp]
     L.sjgpu_host_alloc.restype = vp
     L.sjgpu_host_alloc.argtypes = [sz]
     L.sjgpu_host_free.restype = None
@@ -274,6 +276,10 @@ class DomParserImplementation:
         if isinstance(pipeline, bool):
             pipeline = "fused" if pipeline else "split"
         return self.L.sjgpu_set_pipeline(self.h, {"split": 0, "fused": 1, "auto": 2}[pipeline])
+
+    def last_pipeline(self):
+        """"fused" | "split": what the last enqueued scan used (AUTO decides by size and, for stage 1, output density)."""
+        return "fused" if self.L.sjgpu_last_pipeline(self.h) == 1 else "split"
 
     def profile_enable(self, on=True):
         rc = self.L.sjgpu_profile_enable(self.h, 1 if on else 0)

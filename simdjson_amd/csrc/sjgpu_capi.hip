@@ -115,7 +115,12 @@ struct sjgpu_ctx {
   seg_prefix *pref = nullptr;
   uint64_t *desc = nullptr; // single-pass pipeline: tile descriptors + ticket
   uint8_t *esc_tab = nullptr; // escape table (launch_escape_table), ESC_TABLE_BYTES whatever the capacity
-  int pipeline = 2; // 0 split, 1 single pass, 2 auto (single pass below AUTO_FUSED_BELOW bytes)
+  int pipeline = 2; // 0 split, 1 single pass, 2 auto (use_fused below)
+  // AUTO remembers how dense the output of the last large stage-1 scan was (offsets per 1000 input bytes): on sparse
+  // output the split pipeline is the faster one, and streams of documents / batches look like their predecessors
+  uint32_t density_permille = 1000; // unknown: assume dense
+  uint64_t pending_scan_bytes = 0;  // length of the stage-1 scan whose result has not been fetched yet (0: none / a range)
+  int last_pipeline = 0;            // pipeline of the last enqueued scan (sjgpu_last_pipeline)
   uint32_t max_workgroups = 2048;
   scan_result_dev *d_result = nullptr;
   scan_result_dev *h_result = nullptr; // pinned
@@ -189,6 +194,10 @@ int fetch_result(sjgpu_ctx *ctx, hipStream_t s, sjgpu_scan_result *out) {
   out->n = ctx->h_result->n;
   out->flags = ctx->h_result->flags;
   out->out_len = ctx->h_result->out_len;
+  if (ctx->pending_scan_bytes) {
+    ctx->density_permille = uint32_t(uint64_t(out->n) * 1000u / ctx->pending_scan_bytes);
+    ctx->pending_scan_bytes = 0;
+  }
   return 0;
 }
 
@@ -222,11 +231,15 @@ hipStream_t pick(sjgpu_ctx *, void *stream) { return static_cast<hipStream_t>(st
 // a few MiB (8-14 us vs 18-20 us per call: one launch instead of four); between ~8 and ~192 MiB the split pipeline
 // wins (its kernels fill the chip with 16 KiB work items, the 64 KiB-tile pipelined kernel needs >= 2 tiles per
 // workgroup); above that the pipelined single-pass kernel wins on dense output (1 GiB: 0.52 vs 0.58 ms) and is
-// within 5 % on sparse output.
+// loses 3-8 % on sparse output (twitter-like 0.12 offsets per byte: 2 180-2 250 vs 2 260-2 320 GB/s; amazon NDJSON 0.06:
+// 2 290-2 440 vs 2 580-2 620), so for stage 1 AUTO goes by the density the previous large scan of this context saw.
 constexpr size_t AUTO_FUSED_BELOW = size_t(8) << 20;
 constexpr size_t AUTO_FUSED_FROM = size_t(192) << 20;
-bool use_fused(const sjgpu_ctx *ctx, size_t len) {
-  return ctx->pipeline == 1 || (ctx->pipeline == 2 && (len <= AUTO_FUSED_BELOW || len >= AUTO_FUSED_FROM));
+constexpr uint32_t AUTO_DENSE_PERMILLE = 200;
+bool use_fused(const sjgpu_ctx *ctx, size_t len, int op = 1) { // op 0: stage 1, 1: minify
+  if (ctx->pipeline != 2) { return ctx->pipeline == 1; }
+  if (len <= AUTO_FUSED_BELOW) { return true; }
+  return len >= AUTO_FUSED_FROM && (op != 0 || ctx->density_permille >= AUTO_DENSE_PERMILLE);
 }
 
 // `len` is the END of the scan (bytes [org.begin, len) are scanned); a whole document has org = {0, 0, 0}
@@ -235,12 +248,16 @@ bool use_fused(const sjgpu_ctx *ctx, size_t len) {
 void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint32_t *idx, size_t idx_words, hipStream_t s,
                     hipEvent_t *ev, scan_origin org = scan_origin{0, 0, 0}) {
   org.esc = ctx->esc_tab;
+  ctx->last_pipeline = fused ? 1 : 0;
+  ctx->pending_scan_bytes = (org.begin == 0 && org.base0 == 0 && len >= AUTO_FUSED_FROM) ? len : 0;
   if (fused) { launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, org, ctx->max_workgroups, s, ev); }
   else { launch_stage1(buf, len, ctx->masks, ctx->summ, ctx->pref, idx, idx_words, ctx->d_result, org, s, ev); }
 }
 void enqueue_minify(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint8_t *dst, hipStream_t s, hipEvent_t *ev,
                     scan_origin org = scan_origin{0, 0, 0}) {
   org.esc = ctx->esc_tab;
+  ctx->last_pipeline = fused ? 1 : 0;
+  ctx->pending_scan_bytes = 0;
   if (fused) { launch_minify_fused(buf, len, ctx->desc, dst, ctx->d_result, org, ctx->max_workgroups, s, ev); }
   else { launch_minify(buf, len, ctx->summ, ctx->pref, dst, ctx->d_result, org, s, ev); }
 }
@@ -312,7 +329,7 @@ int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *o
     if (he == hipSuccess) { he = hipStreamWaitEvent(s, ctx->ev_in[k], 0); }
     if (he != hipSuccess) { break; }
     for (int attempt = 0; attempt < 2; attempt++) { // a single-pass range that gives up is re-run on the split pipeline
-      const bool fused = use_fused(ctx, e - b) && attempt == 0;
+      const bool fused = use_fused(ctx, e - b, op) && attempt == 0;
       if (op == 0) { enqueue_stage1(ctx, fused, ctx->d_in, e, ctx->d_idx, ctx->d_idx_words, s, nullptr, org); }
       else { enqueue_minify(ctx, fused, ctx->d_in, e, ctx->d_out, s, nullptr, org); }
       he = hipGetLastError();
@@ -489,7 +506,7 @@ int sjgpu_stage1_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *i
   if (len > ctx->capacity) { return E_CAPACITY; }
   if (len == 0) { return E_EMPTY; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
-  enqueue_stage1(ctx, use_fused(ctx, len), static_cast<const uint8_t *>(buf_dev), len, static_cast<uint32_t *>(idx_dev), idx_words,
+  enqueue_stage1(ctx, use_fused(ctx, len, 0), static_cast<const uint8_t *>(buf_dev), len, static_cast<uint32_t *>(idx_dev), idx_words,
                  pick(ctx, stream), next_events(ctx));
   SJ_TRY(ctx, hipGetLastError());
   return 0;
@@ -543,7 +560,7 @@ int sjgpu_stage1_shard_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, i
   }
   if (len > ctx->capacity) { return E_CAPACITY; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
-  enqueue_stage1(ctx, use_fused(ctx, len), static_cast<const uint8_t *>(buf_dev), len, static_cast<uint32_t *>(idx_dev), idx_words,
+  enqueue_stage1(ctx, use_fused(ctx, len, 0), static_cast<const uint8_t *>(buf_dev), len, static_cast<uint32_t *>(idx_dev), idx_words,
                  pick(ctx, stream), next_events(ctx), scan_origin{0, 0, CARRY_SHARD | (in_string ? CARRY_IN_STRING : 0u)});
   SJ_TRY(ctx, hipGetLastError());
   return 0;
@@ -578,7 +595,7 @@ int sjgpu_stage1_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin,
   if (!idx_dev || (reinterpret_cast<uintptr_t>(idx_dev) & 15u)) { return SJGPU_E_BADARG; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
   const scan_origin org{uint64_t(begin), n_before, CARRY_SHARD | (in_string ? CARRY_IN_STRING : 0u) | (more ? CARRY_MORE : 0u)};
-  enqueue_stage1(ctx, use_fused(ctx, end - begin), static_cast<const uint8_t *>(buf_dev), end, static_cast<uint32_t *>(idx_dev), idx_words,
+  enqueue_stage1(ctx, use_fused(ctx, end - begin, 0), static_cast<const uint8_t *>(buf_dev), end, static_cast<uint32_t *>(idx_dev), idx_words,
                  pick(ctx, stream), next_events(ctx), org);
   SJ_TRY(ctx, hipGetLastError());
   return 0;
@@ -625,6 +642,8 @@ int sjgpu_set_pipeline(sjgpu_ctx *ctx, int pipeline) {
   ctx->pipeline = pipeline;
   return 0;
 }
+
+int sjgpu_last_pipeline(const sjgpu_ctx *ctx) { return ctx ? ctx->last_pipeline : SJGPU_E_BADARG; }
 
 int sjgpu_profile_enable(sjgpu_ctx *ctx, int on) {
   if (!ctx) { return SJGPU_E_BADARG; }
@@ -681,7 +700,7 @@ int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint3
   } else {
     SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
     for (int attempt = 0; attempt < 2; attempt++) { // a single-pass call that gives up is re-run on the split pipeline
-      enqueue_stage1(ctx, use_fused(ctx, len) && attempt == 0, ctx->d_in, len, ctx->d_idx, ctx->d_idx_words, s, nullptr);
+      enqueue_stage1(ctx, use_fused(ctx, len, 0) && attempt == 0, ctx->d_in, len, ctx->d_idx, ctx->d_idx_words, s, nullptr);
       SJ_TRY(ctx, hipGetLastError());
       rc = fetch_result(ctx, s, &res);
       if (rc) { return rc; }
