@@ -535,6 +535,7 @@ int sjgpu_validate_utf8_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
     SJ_TRY(ctx, hipMemsetAsync(ctx->d_result, 0, sizeof(scan_result_dev), pick(ctx, stream)));
     return 0;
   }
+  ctx->pending_scan_bytes = 0;
   launch_validate_utf8(static_cast<const uint8_t *>(buf_dev), len, ctx->d_result, pick(ctx, stream), next_events(ctx));
   SJ_TRY(ctx, hipGetLastError());
   return 0;
@@ -547,6 +548,7 @@ int sjgpu_string_parity_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
   if (!ctx || (len && (!buf_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u)))) { return SJGPU_E_BADARG; }
   if (len > ctx->capacity) { return E_CAPACITY; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
+  ctx->pending_scan_bytes = 0;
   launch_string_parity(static_cast<const uint8_t *>(buf_dev), len, ctx->d_result, ctx->esc_tab, pick(ctx, stream));
   SJ_TRY(ctx, hipGetLastError());
   return 0;
@@ -769,6 +771,7 @@ int sjgpu_validate_utf8(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int *ok)
   if (rc) { return rc; }
   hipStream_t s = ctx->stream;
   SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
+  ctx->pending_scan_bytes = 0;
   launch_validate_utf8(ctx->d_in, len, ctx->d_result, s, nullptr);
   SJ_TRY(ctx, hipGetLastError());
   sjgpu_scan_result res;
