@@ -500,6 +500,15 @@ def test_overlapped_host_path(orc, monkeypatch):
             assert_same_stage1(p, orc, nd, mode, f"streamed {pipeline} ndjson")
             assert_same_stage1(p, orc, nd[:-100], mode, f"streamed {pipeline} ndjson cut")
         p.close()
+    # ranges above the small-tile limit with the single-pass pipeline forced: the pipelined kernel with begin > 0
+    monkeypatch.setenv("SJGPU_STREAM_CHUNK_MB", "9")
+    big = corpus.twitter_like(30 << 20, 14)[0]
+    for pipeline in ("fused", "split"):
+        p = capi.DomParserImplementation(len(big))
+        p.set_pipeline(pipeline)
+        assert_same_all(p, orc, big, f"streamed {pipeline}, 9 MiB ranges")
+        assert_same_all(p, orc, np.concatenate([big[: 20 << 20], np.frombuffer(b' "dangling', np.uint8)]), f"streamed {pipeline}, unclosed")
+        p.close()
     monkeypatch.delenv("SJGPU_STREAM_FROM_MB")
     monkeypatch.delenv("SJGPU_STREAM_CHUNK_MB")
     a = corpus.twitter_like(40 << 20, 13)[0]
