@@ -183,14 +183,63 @@ def main():
             ndjson = ndjson_leg(args, torch, dist, corpus, capi, rank, world, local_rank, fence)
         except Exception as e:  # the primary line must survive a failure here
             ndjson = {"error": repr(e)[:300]}
+    # ---- optional third leg (N > 1 only): ONE document cut into one shard per GPU (general inputs) ----
+    docshards = None
+    if world > 1 and args.op == "stage1" and args.ndjson_leg != 0:
+        try:
+            docshards = document_leg(args, torch, dist, capi, rank, world, buf, L, out, fence)
+        except Exception as e:
+            docshards = {"error": repr(e)[:300]}
     if rank == 0:
         if ndjson is not None:
             line["config4_ndjson"] = ndjson
+        if docshards is not None:
+            line["one_document_shards"] = docshards
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     parser.close()
+
+
+def document_leg(args, torch, dist, capi, rank, world, buf, L, idx, fence):
+    """Every rank's resident buffer taken as its shard of ONE document of world x --size bytes (the large_random
+    buffers end in a newline, so the cuts between them are clean cuts): string-parity pre-pass, all_gather of one
+    integer per rank, shard scan with the carried in-string bit (include/sjgpu.h, "one large document sharded
+    across GPUs").  Timed like the primary leg: barrier + synchronize, MAX over ranks."""
+    import time as _t
+    dev = buf.device
+    parser = capi.DomParserImplementation(L, device=dev.index or 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    bits = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(world)]
+    mine = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def step():
+        mine[0] = parser.string_parity_device(buf.data_ptr(), L, stream)
+        dist.all_gather(bits, mine)
+        carry = 0
+        for r in range(rank):
+            carry ^= int(bits[r]) & 1
+        parser.stage1_shard_device(buf.data_ptr(), L, carry, idx.data_ptr(), L + 3, stream)
+        return parser.result(stream)
+
+    for _ in range(2):
+        n, flags, _ = step()
+    steps = max(4, args.steps // 2)
+    fence()
+    t0 = _t.perf_counter()
+    for _ in range(steps):
+        n, flags, _ = step()
+    fence()
+    dt = _t.perf_counter() - t0
+    t = torch.tensor([dt, float(L), float(n)], dtype=torch.float64, device=dev)
+    tmax = t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t)
+    parser.close()
+    return {"workload": f"one document of {int(t[1])} B in {world} shards (clean cuts), parity pre-pass + all_gather of {world} integers + shard scan",
+            "value_GBps": round(float(t[1]) * steps / float(tmax[0]) / 1e9, 2), "total_structurals": int(t[2]),
+            "flags_rank0": flags, "steps": steps}
 
 
 def ndjson_leg(args, torch, dist, corpus, capi, rank, world, local_rank, fence):
