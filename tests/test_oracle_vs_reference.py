@@ -60,3 +60,35 @@ def test_bulk_corpora(both, kind):
             b[pos] = val
             assert checkers.observable(b, 0, *ref.stage1(impl, b, 0)) == checkers.observable(b, 0, *orc.stage1(b, 0)), (pos, val)
             assert ref.validate_utf8(impl, b) == orc.validate_utf8(b)
+
+
+def test_worst_case_generators_against_the_reference(both):
+    """The shapes bench.py --workload deep_nesting / escape_heavy and the escape-table tests are built from: backslash
+    runs of 16 KiB +- 1 and more at chosen distances from 16 KiB boundaries, one offset per byte, one long run."""
+    orc, ref = both
+    impls = [i for i in ("icelake", "haswell", "westmere") if ref.available(i)]
+    rng = np.random.default_rng(99)
+    SEG = 16384
+    parts, at, k = [b"["], 1, 0
+    lengths = [SEG - 1, SEG, SEG + 1, 2 * SEG - 1, 2 * SEG + 1, 3 * SEG, 100001, 63, 64, 65, 4095, 4097]
+    while at < (3 << 20):
+        r = lengths[k % len(lengths)]
+        k += 1
+        pad = (-(at + 1) + int(rng.choice([-2, -1, 0, 1, 2, 63, 64, 4095]))) % SEG
+        body = b" " * pad + b'"' + b"\\" * r + (b'"' if r % 2 == 0 else b'""') + b', {"k": [1, 2]}, "x\\"y", '
+        parts.append(body)
+        at += len(body)
+    parts.append(b"0]")
+    docs = {"runs around segment boundaries": np.frombuffer(b"".join(parts), np.uint8),
+            "escape_heavy": corpus.escape_heavy(2 << 20, 7)[0],
+            "deep_nesting": corpus.deep_nesting_doc(1 << 20, 1)[0],
+            "one long even run": np.frombuffer(b'["' + b"\\" * (1 << 20) + b'", 1]', np.uint8),
+            "one long odd run": np.frombuffer(b'["' + b"\\" * ((1 << 20) + 1) + b'", 1]', np.uint8)}
+    for name, a in docs.items():
+        for impl in impls:
+            for mode in (0, 2):
+                assert checkers.observable(a, mode, *orc.stage1(a, mode)) == checkers.observable(a, mode, *ref.stage1(impl, a, mode)), \
+                    (name, impl, mode)
+            assert orc.validate_utf8(a) == ref.validate_utf8(impl, a), (name, impl)
+            om, rm = orc.minify(a), ref.minify(impl, a)
+            assert om[0] == rm[0] and np.array_equal(om[1], rm[1]), (name, impl)
