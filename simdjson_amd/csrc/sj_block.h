@@ -46,6 +46,31 @@ SJ_HD u32 byte_perm(u32 hi, u32 lo, u32 sel) {
 // v_bfi_b32: bits of a where mask is 1, bits of b elsewhere.
 SJ_HD u32 bfi(u32 mask, u32 a, u32 b) { return (a & mask) | (b & ~mask); }
 
+// Any boolean function of three inputs as ONE instruction: gfx950's v_bitop3_b32 takes the function's truth table as an
+// immediate.  TT is the function evaluated on the constants A3, B3, C3 below (operand a, b, c), which is the encoding the
+// hardware uses.  The character classes further down are trees of these instead of two-input and / or / and-not chains.
+constexpr u32 A3 = 0xF0u, B3 = 0xCCu, C3 = 0xAAu;
+#define SJ_TT3(expr) ((expr) & 0xFFu)
+template <u32 TT> SJ_HD u32 lut3(u32 a, u32 b, u32 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+#else
+  u32 r = 0;
+  if (TT & 0x80u) { r |= a & b & c; }
+  if (TT & 0x40u) { r |= a & b & ~c; }
+  if (TT & 0x20u) { r |= a & ~b & c; }
+  if (TT & 0x10u) { r |= a & ~b & ~c; }
+  if (TT & 0x08u) { r |= ~a & b & c; }
+  if (TT & 0x04u) { r |= ~a & b & ~c; }
+  if (TT & 0x02u) { r |= ~a & ~b & c; }
+  if (TT & 0x01u) { r |= ~a & ~b & ~c; }
+  return r;
+#endif
+}
+template <u32 TT> SJ_HD u64 lut3(u64 a, u64 b, u64 c) {
+  return (u64(lut3<TT>(u32(a >> 32), u32(b >> 32), u32(c >> 32))) << 32) | u64(lut3<TT>(u32(a), u32(b), u32(c)));
+}
+
 SJ_HD int popc64(u64 x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __popcll(x);
@@ -108,22 +133,27 @@ SJ_HD u64 andn(u64 a, u64 b) {
 SJ_HD classes classify(const planes &P) {
   const u64 b0 = P.b[0], b1 = P.b[1], b2 = P.b[2], b3 = P.b[3], b4 = P.b[4], b5 = P.b[5], b6 = P.b[6], b7 = P.b[7];
   classes c;
-  // every class is "these bits set, those bits clear" = AND of the set bits, and-not of the OR of the clear ones
-  const u64 hi765 = b7 | b6 | b5;                 // clear for 0x00..0x1F
-  c.ctrl = ~hi765;
-  const u64 hi764 = b7 | b6 | b4;                 // clear (with b5 set) for 0x2_
-  const u64 lo321 = b3 | b2 | b1;
-  const u64 space = andn(b5, hi764 | lo321 | b0);                        // 0x20
-  c.quote = andn(b5 & b1, hi764 | b3 | b2 | b0);                         // 0x22
-  // 0x09 0x0A 0x0D: high nibble 0, b3 set, then (b2 clear, b1 != b0) or (b2 set, b1 clear, b0 set)
-  const u64 tlc_low = andn(b1 ^ b0, b2) | andn(b2 & b0, b1);
-  c.ws = space | andn(b3 & tlc_low, hi765 | b4);
-  c.backslash = andn(b6 & b4 & b3 & b2, b7 | b5 | b1 | b0);              // 0x5C
+  // 20 three-input functions per 32-bit half for the five classes (the two-input formulation took ~60)
+  c.ctrl = lut3<SJ_TT3(~(A3 | B3 | C3))>(b7, b6, b5);                       // 0x00..0x1F
+  const u64 g = lut3<SJ_TT3(~(A3 | B3 | C3))>(b7, b6, b4);                  // high nibble 0x0_ or 0x2_
+  const u64 b5_not0 = andn(b5, b0);                                         // 0x2_ / 0x3_ ... with an even low nibble
+  const u64 n321 = lut3<SJ_TT3(~(A3 | B3 | C3))>(b3, b2, b1);
+  const u64 space = lut3<SJ_TT3(A3 & B3 & C3)>(g, b5_not0, n321);           // 0x20
+  const u64 low_001x = lut3<SJ_TT3(~A3 & ~B3 & C3)>(b3, b2, b1);
+  c.quote = lut3<SJ_TT3(A3 & B3 & C3)>(g, b5_not0, low_001x);               // 0x22
+  // 0x09 0x0A 0x0D: high nibble 0, b3 set, low three bits 001, 010 or 101
+  const u64 tlc_low = lut3<SJ_TT3((~A3 & (B3 ^ C3)) | (A3 & ~B3 & C3))>(b2, b1, b0);
+  const u64 high0_b3 = lut3<SJ_TT3(A3 & ~B3 & C3)>(g, b5, b3);
+  c.ws = lut3<SJ_TT3(A3 | (B3 & C3))>(space, high0_b3, tlc_low);
+  const u64 high_010 = lut3<SJ_TT3(~A3 & B3 & ~C3)>(b7, b6, b5);
+  const u64 mid_111 = lut3<SJ_TT3(A3 & B3 & C3)>(b4, b3, b2);
+  c.backslash = lut3<SJ_TT3(A3 & B3 & ~C3)>(high_010, mid_111, b1 | b0);    // 0x5C
   // operators (b5 is "don't care": the x86 kernels compare b|0x20, which also admits 0x0C and 0x1A):
   //   2C/0C x0x0 1100   3A/1A x0x1 1010   5B/7B x1x1 1011   5D/7D x1x1 1101
-  // all four have b3 set, b2 != b1; then either (b6 clear, b0 clear, b4 == b1) or (b6, b4, b0 all set)
-  const u64 low_pair = andn(b6 | b0 | (b4 ^ b1), b6 & b4 & b0); // = NOT of the bracketed alternative above
-  c.op = andn(b3 & (b2 ^ b1), b7 | low_pair);
+  // all four: b7 clear, b3 set, b2 != b1; then b6 clear: b0 clear and b4 == b1; b6 set: b4 and b0 set
+  const u64 if_b6_clear = lut3<SJ_TT3(~C3 & ~(A3 ^ B3))>(b4, b1, b0);
+  const u64 by_b6 = lut3<SJ_TT3((A3 & B3) | (~A3 & C3))>(b6, b4 & b0, if_b6_clear);
+  c.op = lut3<SJ_TT3(~A3 & B3 & C3)>(b7, b3, b2 ^ b1) & by_b6;
   return c;
 }
 
@@ -229,9 +259,9 @@ struct quote_scalar {
 };
 SJ_HD quote_scalar quotes_and_scalars(const classes &c, u64 escaped) {
   quote_scalar q;
-  q.quote = c.quote & ~escaped;
+  q.quote = andn(c.quote, escaped);
   q.scalar = ~(c.ws | c.op);
-  q.nonquote_scalar = q.scalar & ~q.quote;
+  q.nonquote_scalar = lut3<SJ_TT3(~(A3 | B3 | C3))>(c.ws, c.op, q.quote);
   return q;
 }
 // Step 2 (needs the two 1-bit carries of the lane).
@@ -239,7 +269,7 @@ SJ_HD block_masks finish_block(const classes &c, const quote_scalar &q, u32 in_s
   block_masks m;
   m.in_string = prefix_xor(q.quote) ^ (0 - u64(in_string_carry));
   const u64 follows = (q.nonquote_scalar << 1) | prev_scalar_carry;
-  m.cand = c.op | (q.scalar & ~follows);
+  m.cand = lut3<SJ_TT3(A3 | (~B3 & ~C3))>(c.op, c.ws, follows); // op | (scalar & ~follows), scalar = ~(ws | op)
   m.string_tail = m.in_string ^ q.quote;
   return m;
 }
