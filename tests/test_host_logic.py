@@ -82,3 +82,18 @@ def test_error_from_flags(lib):
     f = capi.stage1_error_from_flags
     assert f(5, 0) == capi.SUCCESS and f(0, 0) == capi.EMPTY and f(5, 4) == capi.UTF8_ERROR
     assert f(5, 1 | 2 | 4) == capi.UNCLOSED_STRING and f(5, 2 | 4) == capi.UNESCAPED_CHARS and f(0, 4) == capi.EMPTY
+
+
+def test_clean_cut_definition(lib):
+    """sjgpu_clean_cut(buf, len, target) = the first c >= target whose previous byte is ASCII whitespace or one of
+    , : [ ] { } (0 stays 0, len when there is none)."""
+    import numpy as np
+    clean = set(b" \t\n\r,:[]{}")
+    rng = np.random.default_rng(3)
+    alphabet = np.frombuffer(b'ab"\\ ,:[]{}\n\t\r\x01\xc3\xa9', np.uint8)
+    for _ in range(300):
+        n = int(rng.integers(0, 200))
+        a = alphabet[rng.integers(0, len(alphabet), n)].copy() if n else np.zeros(0, np.uint8)
+        for target in sorted({0, 1, n // 2, max(n - 1, 0), n}):
+            want = 0 if target == 0 else next((c for c in range(target, n) if int(a[c - 1]) in clean), n)
+            assert capi.clean_cut(a, target) == want, (bytes(a), target)
