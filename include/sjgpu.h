@@ -98,7 +98,8 @@ int sjgpu_validate_utf8(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int *ok)
  * fetch the outcome with sjgpu_result(), which waits for that stream.
  * sjgpu_stage1_device: regular-mode scan; writes idx_dev[0..n) ascending byte offsets and the three
  * sentinels idx_dev[n]=len, idx_dev[n+1]=len, idx_dev[n+2]=0 (json_structural_indexer.h:284-286);
- * needs idx_words >= n+3 (len+3 always suffices).  Error precedence is applied by the caller from
+ * needs idx_words >= n+3 (len+3 always suffices).  idx_dev and dst_dev must be 16-byte aligned like buf_dev (the
+ * offsets leave as 16-byte stores); a misaligned pointer is SJGPU_E_BADARG.  Error precedence is applied by the caller from
  * `flags` (helper below). */
 int sjgpu_stage1_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *idx_dev, size_t idx_words, void *stream);
 int sjgpu_minify_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *dst_dev, void *stream);
@@ -129,13 +130,22 @@ int sjgpu_last_pipeline(const sjgpu_ctx *ctx); /* SJGPU_PIPELINE_SPLIT / _FUSED:
 int sjgpu_debug_trace_stage1(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *idx_dev, size_t idx_words,
                              uint64_t *trace_host, uint32_t trace_tiles);
 
+/* The same for the pipelined single-pass kernel (the large-input one): thread 0 of every workgroup stamps the first 32
+ * iterations of its loop -- loop top, ticket known, wave 0 scanned, all waves scanned, aggregate published + look-back
+ * done, prefix broadcast, wave 0 emitted, masks parked -- into trace_host[workgroup][32][8] (zero = not reached);
+ * max_records >= 32 x workgroups (2048 workgroups at most).  Synchronous. */
+int sjgpu_debug_trace_pipelined(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *idx_dev, size_t idx_words,
+                                uint64_t *trace_host, uint32_t max_records, uint32_t *workgroups_out);
+
 /* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).  While enabled,
  * each *_device call brackets every kernel it enqueues with events (up to 4096 calls are retained);
  * sjgpu_profile_read waits for the stream, adds the elapsed milliseconds per kernel slot into
- * ms_sum[0..3] (stage1: summarize, resolve, emit; minify: summarize, resolve, emit; validate_utf8:
- * slot 0), stores the number of calls accumulated and resets. */
+ * ms_sum[0..2] (split pipeline: [escape table +] summarize, resolve, emit; single pass: slot 0 = everything the
+ * call enqueues -- escape table, workspace clears, the scan kernel; validate_utf8: slot 0), stores the number of
+ * calls accumulated and resets.  sjgpu_profile_kernel names the dominant kernel of the last enqueued call. */
 int sjgpu_profile_enable(sjgpu_ctx *ctx, int on);
 int sjgpu_profile_read(sjgpu_ctx *ctx, double *ms_sum, uint32_t *calls);
+const char *sjgpu_profile_kernel(const sjgpu_ctx *ctx); /* e.g. "k_fused_pipelined<0>", "k_stage1_summarize+k_stage1_emit" */
 
 /* regular-mode error_code from a scan result (json_structural_indexer.h:249-294,395-396):
  * UNCLOSED_STRING > UNESCAPED_CHARS > EMPTY > UTF8_ERROR > SUCCESS. */

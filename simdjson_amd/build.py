@@ -1,14 +1,20 @@
-"""In-tree native builds (explicit compiler invocations; outputs under simdjson_amd/lib/ and oracle/_ref/).
+"""In-tree native builds (explicit compiler invocations; outputs under simdjson_amd/lib/, build/tests/ and oracle/_ref/).
 
     libsjgpu.so            hipcc --offload-arch=gfx950   HIP kernels + C-ABI (include/sjgpu.h)   [product]
     libsjcorpus.so         gcc                           synthetic corpora                         [tooling]
     libsimdjson_mi355x.so  g++ against the reference's public headers: the simdjson::implementation
                            plug-in shim.  Needs /root/reference at BUILD time only; the built file travels.
     oracle/_ref/*.so       make -C oracle                CPU checkers                              [tests]
+    build/tests/*          g++                           test programs that link the reference (plugin_test, the reference's
+                           own test programs): test infrastructure, git-ignored, never under simdjson_amd/.  They are
+                           built where /root/reference exists and travel prebuilt; build/tests/STAMP.json records the
+                           hashes of the sources they were built from, and tests refuse a stale binary.
 
 Run `python -m simdjson_amd.build` or call build_all(); each target is rebuilt only when a source
 is newer than its output.
 """
+import hashlib
+import json
 import os
 import shutil
 import subprocess
@@ -70,19 +76,56 @@ def build_plugin(force=False):
     return _paths.LIB_PLUGIN
 
 
+TEST_BIN_DIR = os.path.join(_paths.REPO_ROOT, "build", "tests")
+_RPATH = "-Wl,-rpath,$ORIGIN/../../simdjson_amd/lib"
+
+
+def _stamp_sources():
+    """Everything of OURS a prebuilt test binary embeds (libsjgpu.so / the plug-in .so are linked dynamically)."""
+    plug = os.path.join(_paths.REPO_ROOT, "tests", "plugin")
+    files = [os.path.join(_paths.INCLUDE_DIR, "sjgpu.h"), *_csrc("plugin/mi355x_implementation.h")]
+    files += sorted(os.path.join(plug, f) for f in os.listdir(plug) if f.endswith((".cpp", ".h")))
+    return files
+
+
+def source_stamp():
+    h = hashlib.sha256()
+    for f in _stamp_sources():
+        h.update(os.path.relpath(f, _paths.REPO_ROOT).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def _write_stamp(name):
+    path = os.path.join(TEST_BIN_DIR, "STAMP.json")
+    d = json.load(open(path)) if os.path.exists(path) else {}
+    d[name] = source_stamp()
+    json.dump(d, open(path, "w"), indent=1, sort_keys=True)
+
+
+def binary_is_current(name):
+    """True iff build/tests/<name> exists and was built from the sources as they are now."""
+    path = os.path.join(TEST_BIN_DIR, "STAMP.json")
+    if not (os.path.exists(path) and os.path.exists(os.path.join(TEST_BIN_DIR, name))):
+        return False
+    return json.load(open(path)).get(name) == source_stamp()
+
+
 def build_plugin_test(force=False):
-    """tests/plugin/plugin_test.cpp -> simdjson_amd/lib/plugin_test: unmodified reference library + our shim.
+    """tests/plugin/plugin_test.cpp -> build/tests/plugin_test: unmodified reference library + our shim.
     Needs the reference (headers + oracle/_ref/simdjson_ref.o); the binary travels to the GPU box."""
-    out = os.path.join(_paths.LIB_DIR, "plugin_test")
+    out = os.path.join(TEST_BIN_DIR, "plugin_test")
     src = os.path.join(_paths.REPO_ROOT, "tests", "plugin", "plugin_test.cpp")
     ref_obj = os.path.join(_paths.ORACLE_OUT, "simdjson_ref.o")
     hdr = os.path.join(_paths.REFERENCE_DIR, "include", "simdjson.h")
     if not (os.path.exists(hdr) and os.path.exists(ref_obj) and os.path.exists(_paths.LIB_PLUGIN)):
         return out if os.path.exists(out) else None
-    if force or _stale(out, [src, ref_obj, _paths.LIB_PLUGIN, _paths.LIB_CORPUS]):
+    if force or not binary_is_current("plugin_test") or _stale(out, [src, ref_obj, _paths.LIB_PLUGIN, _paths.LIB_CORPUS]):
+        os.makedirs(TEST_BIN_DIR, exist_ok=True)
         _run(["g++", "-O2", "-std=c++17", "-DSIMDJSON_THREADS_ENABLED=1", "-I", os.path.join(_paths.REFERENCE_DIR, "include"),
               "-I", os.path.join(_paths.CSRC_DIR, "plugin"), "-I", _paths.INCLUDE_DIR, src, ref_obj, "-o", out,
-              f"-L{_paths.LIB_DIR}", "-lsimdjson_mi355x", "-lsjgpu", "-lsjcorpus", "-lpthread", "-Wl,-rpath,$ORIGIN"])
+              f"-L{_paths.LIB_DIR}", "-lsimdjson_mi355x", "-lsjgpu", "-lsjcorpus", "-lpthread", _RPATH])
+        _write_stamp("plugin_test")
     return out
 
 
@@ -97,25 +140,28 @@ REFERENCE_TESTS = {  # reference test programs that need no external data files 
 
 def build_reference_tests(force=False):
     """The reference's OWN test programs, compiled in place from /root/reference/tests and linked with the
-    mi355x plug-in + an activator TU, so they exercise our backend unmodified.  Outputs simdjson_amd/lib/ref_*."""
+    mi355x plug-in + an activator TU, so they exercise our backend unmodified.  Outputs build/tests/ref_*."""
     ref = _paths.REFERENCE_DIR
     ref_obj = os.path.join(_paths.ORACLE_OUT, "simdjson_ref.o")
     act = os.path.join(_paths.REPO_ROOT, "tests", "plugin", "activate_mi355x.cpp")
     built = []
     for name, rel in REFERENCE_TESTS.items():
-        out = os.path.join(_paths.LIB_DIR, name)
+        out = os.path.join(TEST_BIN_DIR, name)
         src = os.path.join(ref, rel)
         if not (os.path.exists(src) and os.path.exists(ref_obj) and os.path.exists(_paths.LIB_PLUGIN)):
             if os.path.exists(out):
                 built.append(out)
             continue
-        if force or _stale(out, [src, act, ref_obj, _paths.LIB_PLUGIN]):
+        if force or not binary_is_current(name) or _stale(out, [src, act, ref_obj, _paths.LIB_PLUGIN]):
+            os.makedirs(TEST_BIN_DIR, exist_ok=True)
             _run(["g++", "-O1", "-std=c++17", "-w", "-DSIMDJSON_THREADS_ENABLED=1", "-I", os.path.join(ref, "include"), "-I", os.path.join(ref, "tests"),
                   "-I", os.path.join(ref, "tests", "dom"), "-I", os.path.join(ref, "tests", "ondemand"),
                   "-I", os.path.join(_paths.CSRC_DIR, "plugin"), "-I", _paths.INCLUDE_DIR,
-                  '-DSIMDJSON_BENCHMARK_DATA_DIR="' + os.path.join(ref, "jsonexamples") + '/"',
+                  # data files come from the committed fixtures: /root/repo/... exists here AND on the GPU box (symlink)
+                  '-DSIMDJSON_BENCHMARK_DATA_DIR="/root/repo/tests/golden/jsonexamples/"',
                   src, act, ref_obj, "-o", out, f"-L{_paths.LIB_DIR}", "-lsimdjson_mi355x", "-lsjgpu", "-lpthread",
-                  "-Wl,-rpath,$ORIGIN"])
+                  _RPATH])
+            _write_stamp(name)
         built.append(out)
     return built
 

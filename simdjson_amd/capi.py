@@ -28,6 +28,7 @@ EXPORTS = [
     "sjgpu_clean_cut", "sjgpu_string_parity_device", "sjgpu_stage1_shard_device", "sjgpu_minify_shard_device",
     "sjgpu_stage1_range_device", "sjgpu_minify_range_device",
     "sjgpu_host_alloc", "sjgpu_host_free", "sjgpu_host_register", "sjgpu_host_unregister", "sjgpu_last_pipeline",
+    "sjgpu_profile_kernel", "sjgpu_debug_trace_pipelined",
 ]
 
 
@@ -93,6 +94,8 @@ def load_library():
     L.sjgpu_stage1_finish_host.argtypes = [vp, sz, ctypes.c_int, vp, ctypes.c_uint32, ctypes.c_uint32, u32p, u32p]
     L.sjgpu_debug_trace_stage1.restype = ctypes.c_int
     L.sjgpu_debug_trace_stage1.argtypes = [vp, vp, sz, vp, sz, vp, ctypes.c_uint32]
+    L.sjgpu_debug_trace_pipelined.restype = ctypes.c_int
+    L.sjgpu_debug_trace_pipelined.argtypes = [vp, vp, sz, vp, sz, vp, ctypes.c_uint32, u32p]
     L.sjgpu_set_pipeline.restype = ctypes.c_int
     L.sjgpu_set_pipeline.argtypes = [vp, ctypes.c_int]
     L.sjgpu_profile_enable.restype = ctypes.c_int
@@ -115,6 +118,8 @@ def load_library():
     L.sjgpu_minify_range_device.argtypes = [vp, vp, sz, sz, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, vp, vp]
     L.sjgpu_last_pipeline.restype = ctypes.c_int
     L.sjgpu_last_pipeline.argtypes = [vp]
+    L.sjgpu_profile_kernel.restype = ctypes.c_char_p
+    L.sjgpu_profile_kernel.argtypes = [vp]
     L.sjgpu_host_alloc.restype = vp
     L.sjgpu_host_alloc.argtypes = [sz]
     L.sjgpu_host_free.restype = None
@@ -280,6 +285,10 @@ class DomParserImplementation:
     def last_pipeline(self):
         """"fused" | "split": what the last enqueued scan used (AUTO decides by size and, for stage 1, output density)."""
         return "fused" if self.L.sjgpu_last_pipeline(self.h) == 1 else "split"
+
+    def profile_kernel(self):
+        """Name(s) of the scan kernel(s) the last enqueued call launched, as the launcher reported them."""
+        return self.L.sjgpu_profile_kernel(self.h).decode()
 
     def profile_enable(self, on=True):
         rc = self.L.sjgpu_profile_enable(self.h, 1 if on else 0)

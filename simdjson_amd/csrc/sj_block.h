@@ -186,20 +186,22 @@ SJ_HD u64 escaped_mask(u64 backslash, u64 first_is_escaped, u64 &next_is_escaped
 //   bits 1-2   byte[-2], byte[-1] is a 3/4-byte lead
 //   bits 3-5   byte[-3], byte[-2], byte[-1] is a 4-byte lead
 //   bit 6..9   byte[-1] is E0 / ED / F0 / F4
-struct utf8_leads {
-  u64 cont, l234, l34, l4, e0, ed, f0, f4, bad;
+template <class T> struct utf8_leads_t {
+  T cont, l234, l34, l4, e0, ed, f0, f4, bad;
 };
-SJ_HD utf8_leads utf8_classify(const planes &P) {
-  const u64 b0 = P.b[0], b1 = P.b[1], b2 = P.b[2], b3 = P.b[3], b4 = P.b[4], b5 = P.b[5], b6 = P.b[6], b7 = P.b[7];
-  utf8_leads L;
+typedef utf8_leads_t<u64> utf8_leads;
+// b[k] = plane k of a group of 32 (T = u32) or 64 (T = u64) consecutive bytes
+template <class T> SJ_HD utf8_leads_t<T> utf8_classify_planes(const T *b) {
+  const T b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5], b6 = b[6], b7 = b[7];
+  utf8_leads_t<T> L;
   L.cont = b7 & ~b6;
-  const u64 l2 = b7 & b6 & ~b5;                 // C0..DF
-  const u64 l3 = b7 & b6 & b5 & ~b4;            // E0..EF
-  L.l4 = b7 & b6 & b5 & b4 & ~b3;               // F0..F7
-  L.bad = (b7 & b6 & b5 & b4 & b3)              // F8..FF
-          | (l2 & ~b4 & ~b3 & ~b2 & ~b1)        // C0, C1 (overlong 2-byte)
-          | (L.l4 & b2 & (b1 | b0));            // F5..F7 (> U+10FFFF)
-  const u64 lowz = ~b2 & ~b1 & ~b0;
+  const T l2 = b7 & b6 & ~b5;                 // C0..DF
+  const T l3 = b7 & b6 & b5 & ~b4;            // E0..EF
+  L.l4 = b7 & b6 & b5 & b4 & ~b3;             // F0..F7
+  L.bad = (b7 & b6 & b5 & b4 & b3)            // F8..FF
+          | (l2 & ~b4 & ~b3 & ~b2 & ~b1)      // C0, C1 (overlong 2-byte)
+          | (L.l4 & b2 & (b1 | b0));          // F5..F7 (> U+10FFFF)
+  const T lowz = ~b2 & ~b1 & ~b0;
   L.e0 = l3 & ~b3 & lowz;
   L.ed = l3 & b3 & b2 & ~b1 & b0;
   L.f0 = L.l4 & lowz;
@@ -208,26 +210,29 @@ SJ_HD utf8_leads utf8_classify(const planes &P) {
   L.l234 = l2 | L.l34;
   return L;
 }
-// What this block demands of the next one (independent of its own carry-in).
-SJ_HD u32 utf8_carry_out(const utf8_leads &L) {
-  return u32(L.l234 >> 63) | (u32(L.l34 >> 62) << 1) | (u32(L.l4 >> 61) << 3) | (u32(L.e0 >> 63) << 6) |
-         (u32(L.ed >> 63) << 7) | (u32(L.f0 >> 63) << 8) | (u32(L.f4 >> 63) << 9);
+SJ_HD utf8_leads utf8_classify(const planes &P) { return utf8_classify_planes<u64>(P.b); }
+// What this group demands of the next one (independent of its own carry-in).
+template <class T> SJ_HD u32 utf8_carry_out(const utf8_leads_t<T> &L) {
+  constexpr int W = int(sizeof(T)) * 8;
+  return u32(L.l234 >> (W - 1)) | (u32(L.l34 >> (W - 2)) << 1) | (u32(L.l4 >> (W - 3)) << 3) | (u32(L.e0 >> (W - 1)) << 6) |
+         (u32(L.ed >> (W - 1)) << 7) | (u32(L.f0 >> (W - 1)) << 8) | (u32(L.f4 >> (W - 1)) << 9);
 }
-// Mask of offending positions given the previous block's demands.
-SJ_HD u64 utf8_errors(const planes &P, const utf8_leads &L, u32 carry_in) {
-  const u64 b4 = P.b[4], b5 = P.b[5];
-  const u64 expect = ((L.l234 << 1) | (carry_in & 1u)) | ((L.l34 << 2) | ((carry_in >> 1) & 3u)) |
-                     ((L.l4 << 3) | ((carry_in >> 3) & 7u));
-  const u64 after_e0 = (L.e0 << 1) | ((carry_in >> 6) & 1u);
-  const u64 after_ed = (L.ed << 1) | ((carry_in >> 7) & 1u);
-  const u64 after_f0 = (L.f0 << 1) | ((carry_in >> 8) & 1u);
-  const u64 after_f4 = (L.f4 << 1) | ((carry_in >> 9) & 1u);
-  const u64 second = (after_e0 & ~b5)          // E0 80..9F : overlong 3-byte
-                     | (after_ed & b5)         // ED A0..BF : surrogate
-                     | (after_f0 & ~b5 & ~b4)  // F0 80..8F : overlong 4-byte
-                     | (after_f4 & (b5 | b4)); // F4 90..BF : > U+10FFFF
+// Mask of offending positions given the previous group's demands.
+template <class T> SJ_HD T utf8_errors_planes(const T *b, const utf8_leads_t<T> &L, u32 carry_in) {
+  const T b4 = b[4], b5 = b[5];
+  const T expect = ((L.l234 << 1) | T(carry_in & 1u)) | ((L.l34 << 2) | T((carry_in >> 1) & 3u)) |
+                   ((L.l4 << 3) | T((carry_in >> 3) & 7u));
+  const T after_e0 = (L.e0 << 1) | T((carry_in >> 6) & 1u);
+  const T after_ed = (L.ed << 1) | T((carry_in >> 7) & 1u);
+  const T after_f0 = (L.f0 << 1) | T((carry_in >> 8) & 1u);
+  const T after_f4 = (L.f4 << 1) | T((carry_in >> 9) & 1u);
+  const T second = (after_e0 & ~b5)          // E0 80..9F : overlong 3-byte
+                   | (after_ed & b5)         // ED A0..BF : surrogate
+                   | (after_f0 & ~b5 & ~b4)  // F0 80..8F : overlong 4-byte
+                   | (after_f4 & (b5 | b4)); // F4 90..BF : > U+10FFFF
   return (expect ^ L.cont) | L.bad | second;
 }
+SJ_HD u64 utf8_errors(const planes &P, const utf8_leads &L, u32 carry_in) { return utf8_errors_planes<u64>(P.b, L, carry_in); }
 
 // The same carry word computed from three raw bytes (used once per segment for the look-back).
 SJ_HD u32 utf8_carry_from_bytes(u32 p3, u32 p2, u32 p1) {

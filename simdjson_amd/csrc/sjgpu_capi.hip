@@ -121,6 +121,7 @@ struct sjgpu_ctx {
   uint32_t density_permille = 1000; // unknown: assume dense
   uint64_t pending_scan_bytes = 0;  // length of the stage-1 scan whose result has not been fetched yet (0: none / a range)
   int last_pipeline = 0;            // pipeline of the last enqueued scan (sjgpu_last_pipeline)
+  const char *last_kernel = "";     // its dominant kernel(s), as the launcher reported them (sjgpu_profile_kernel)
   uint32_t max_workgroups = 2048;
   scan_result_dev *d_result = nullptr;
   scan_result_dev *h_result = nullptr; // pinned
@@ -250,16 +251,22 @@ void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, 
   org.esc = ctx->esc_tab;
   ctx->last_pipeline = fused ? 1 : 0;
   ctx->pending_scan_bytes = (org.begin == 0 && org.base0 == 0 && len >= AUTO_FUSED_FROM) ? len : 0;
-  if (fused) { launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, org, ctx->max_workgroups, s, ev); }
-  else { launch_stage1(buf, len, ctx->masks, ctx->summ, ctx->pref, idx, idx_words, ctx->d_result, org, s, ev); }
+  if (fused) { ctx->last_kernel = launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, org, ctx->max_workgroups, s, ev); }
+  else {
+    launch_stage1(buf, len, ctx->masks, ctx->summ, ctx->pref, idx, idx_words, ctx->d_result, org, s, ev);
+    ctx->last_kernel = "k_stage1_summarize+k_resolve_groups+k_resolve_segments+k_stage1_emit";
+  }
 }
 void enqueue_minify(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint8_t *dst, hipStream_t s, hipEvent_t *ev,
                     scan_origin org = scan_origin{0, 0, 0}) {
   org.esc = ctx->esc_tab;
   ctx->last_pipeline = fused ? 1 : 0;
   ctx->pending_scan_bytes = 0;
-  if (fused) { launch_minify_fused(buf, len, ctx->desc, dst, ctx->d_result, org, ctx->max_workgroups, s, ev); }
-  else { launch_minify(buf, len, ctx->summ, ctx->pref, dst, ctx->d_result, org, s, ev); }
+  if (fused) { ctx->last_kernel = launch_minify_fused(buf, len, ctx->desc, dst, ctx->d_result, org, ctx->max_workgroups, s, ev); }
+  else {
+    launch_minify(buf, len, ctx->summ, ctx->pref, dst, ctx->d_result, org, s, ev);
+    ctx->last_kernel = "k_minify_summarize+k_resolve_groups+k_resolve_segments+k_minify_emit";
+  }
 }
 
 copy_worker *start_worker(sjgpu_ctx *ctx, hipMemcpyKind kind) {
@@ -500,7 +507,7 @@ const char *sjgpu_last_error(const sjgpu_ctx *ctx) { return ctx ? ctx->err : "";
 
 // ---- device-resident entry points ------------------------------------------------------------------
 int sjgpu_stage1_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *idx_dev, size_t idx_words, void *stream) {
-  if (!ctx || !buf_dev || !idx_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u) || (reinterpret_cast<uintptr_t>(idx_dev) & 3u)) {
+  if (!ctx || !buf_dev || !idx_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u) || (reinterpret_cast<uintptr_t>(idx_dev) & 15u)) {
     return SJGPU_E_BADARG;
   }
   if (len > ctx->capacity) { return E_CAPACITY; }
@@ -536,6 +543,7 @@ int sjgpu_validate_utf8_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
     return 0;
   }
   ctx->pending_scan_bytes = 0;
+  ctx->last_kernel = "k_validate_utf8";
   launch_validate_utf8(static_cast<const uint8_t *>(buf_dev), len, ctx->d_result, pick(ctx, stream), next_events(ctx));
   SJ_TRY(ctx, hipGetLastError());
   return 0;
@@ -556,7 +564,7 @@ int sjgpu_string_parity_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
 
 int sjgpu_stage1_shard_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, int in_string, void *idx_dev, size_t idx_words,
                               void *stream) {
-  if (!ctx || !buf_dev || !idx_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u) || (reinterpret_cast<uintptr_t>(idx_dev) & 3u) ||
+  if (!ctx || !buf_dev || !idx_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u) || (reinterpret_cast<uintptr_t>(idx_dev) & 15u) ||
       len == 0) {
     return SJGPU_E_BADARG;
   }
@@ -624,7 +632,10 @@ int sjgpu_result(sjgpu_ctx *ctx, void *stream, sjgpu_scan_result *out) {
 
 int sjgpu_debug_trace_stage1(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *idx_dev, size_t idx_words,
                              uint64_t *trace_host, uint32_t trace_tiles) {
-  if (!ctx || !buf_dev || !idx_dev || !trace_host || len == 0 || len > ctx->capacity) { return SJGPU_E_BADARG; }
+  if (!ctx || !buf_dev || !idx_dev || !trace_host || len == 0 || len > ctx->capacity || (reinterpret_cast<uintptr_t>(buf_dev) & 15u) ||
+      (reinterpret_cast<uintptr_t>(idx_dev) & 15u)) {
+    return SJGPU_E_BADARG;
+  }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
   uint64_t *d_trace = nullptr;
   const size_t bytes = size_t(trace_tiles) * 8 * sizeof(uint64_t);
@@ -639,6 +650,26 @@ int sjgpu_debug_trace_stage1(sjgpu_ctx *ctx, const void *buf_dev, size_t len, vo
   return 0;
 }
 
+int sjgpu_debug_trace_pipelined(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *idx_dev, size_t idx_words, uint64_t *trace_host,
+                                uint32_t max_records, uint32_t *workgroups_out) {
+  if (!ctx || !buf_dev || !idx_dev || !trace_host || !workgroups_out || len == 0 || len > ctx->capacity ||
+      (reinterpret_cast<uintptr_t>(buf_dev) & 15u) || (reinterpret_cast<uintptr_t>(idx_dev) & 15u)) {
+    return SJGPU_E_BADARG;
+  }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  uint64_t *d_trace = nullptr;
+  const size_t bytes = size_t(max_records) * 8 * sizeof(uint64_t);
+  SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&d_trace), bytes));
+  (void)hipMemset(d_trace, 0, bytes);
+  *workgroups_out = launch_stage1_pipelined_traced(static_cast<const uint8_t *>(buf_dev), len, ctx->desc, static_cast<uint32_t *>(idx_dev), idx_words,
+                                                  ctx->d_result, ctx->esc_tab, ctx->max_workgroups, nullptr, d_trace, max_records);
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) { e = hipMemcpy(trace_host, d_trace, bytes, hipMemcpyDeviceToHost); }
+  (void)hipFree(d_trace);
+  if (e != hipSuccess) { return fail(ctx, e, "debug_trace_pipelined"); }
+  return *workgroups_out ? 0 : SJGPU_E_BADARG;
+}
+
 int sjgpu_set_pipeline(sjgpu_ctx *ctx, int pipeline) {
   if (!ctx || pipeline < 0 || pipeline > 2) { return SJGPU_E_BADARG; }
   ctx->pipeline = pipeline;
@@ -646,6 +677,7 @@ int sjgpu_set_pipeline(sjgpu_ctx *ctx, int pipeline) {
 }
 
 int sjgpu_last_pipeline(const sjgpu_ctx *ctx) { return ctx ? ctx->last_pipeline : SJGPU_E_BADARG; }
+const char *sjgpu_profile_kernel(const sjgpu_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
 
 int sjgpu_profile_enable(sjgpu_ctx *ctx, int on) {
   if (!ctx) { return SJGPU_E_BADARG; }

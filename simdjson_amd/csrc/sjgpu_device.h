@@ -89,7 +89,6 @@ struct wave_carry {
   u32 e;    // first byte of the next block is escaped
   u32 s;    // inside a string (relative or absolute, caller's choice)
   u32 p;    // previous byte is a non-quote scalar
-  u32 utf8; // utf8 carry word (sj_block.h)
 };
 
 // ---- escape table (k_escape_table, sjgpu_kernels.hip) -------------------------------------------------------
@@ -135,7 +134,7 @@ __device__ __forceinline__ u32 backslash_run_parity(const u8 *__restrict__ buf, 
 // Carry-in of a segment starting at byte `start`, from the bytes in front of it:
 //   e = escaped[start]            = parity of the backslash run ending at start-1
 //   p = nonquote_scalar[start-1]  = scalar(b) unless b is '"', then "that quote is escaped"
-//   utf8 = demands of bytes start-3..start-1
+// (UTF-8 needs no carry: blocks are validated one by one from the bytes in memory, see utf8_queue below)
 // Split in two so that the ONE byte load it normally needs can be issued before the segment's first chunk is
 // requested and consumed after: the two HBM latencies overlap instead of adding up.
 __device__ __forceinline__ u32 lookback_issue(const u8 *__restrict__ buf, u64 start, u32 lane) {
@@ -151,10 +150,9 @@ __device__ __forceinline__ u32 run_parity_from_mask(const u8 *__restrict__ buf, 
 }
 __device__ __forceinline__ wave_carry segment_carry_from(const u8 *__restrict__ buf, u64 start, u32 lane, u32 byte,
                                                          const u8 *__restrict__ esc) {
-  wave_carry c{0u, 0u, 0u, 0u};
+  wave_carry c{0u, 0u, 0u};
   if (start == 0) { return c; }
-  const u32 b1 = readlane(byte, 0), b2 = readlane(byte, 1), b3 = readlane(byte, 2);
-  c.utf8 = utf8_carry_from_bytes(b3, b2, b1);
+  const u32 b1 = readlane(byte, 0);
   const u64 m = __ballot(byte == 0x5Cu);
   // a span that starts on a segment boundary reads its escape carry-in straight from the table (no walk at all)
   c.e = (esc && (start % SEG_BYTES) == 0) ? escape_lookup(esc, start / SEG_BYTES, lane) : run_parity_from_mask(buf, start, lane, m, 0, esc);
@@ -179,27 +177,130 @@ struct chunk_masks {
   u64 in_string;   // includes opening quotes, excludes closing quotes
   u64 ws;          // whitespace bytes
   u64 ctrl;        // bytes <= 0x1F
-  u64 utf8_err;    // offending positions (0 if WANT_UTF8 is false)
 };
 
+// =====================================================================================================
+// UTF-8: sparse and deferred.  Well-formedness of a 64-byte block is a function of its bytes and the three bytes in
+// front of it, all of which sit in memory -- so blocks need not be validated in stream order, nor by the lane that
+// scans them.  The scan only NOTES which blocks need a look: those that hold a non-ASCII byte, and those that
+// follow a block whose last three bytes hold one (an open sequence ending in ASCII must be caught, too).  Their
+// indexes queue up in a small per-wave LDS list; whenever 64 have gathered, the wave validates them with ALL lanes
+// busy (utf8_drain: one block per lane, re-read through L2, 32 bytes at a time to keep the register footprint small).
+// Mostly-ASCII text (one or two such blocks per 4 KiB chunk: NDJSON, twitter.json) pays ~10 VALU per chunk instead
+// of the ~124 an in-line check of every chunk that holds any non-ASCII byte costs; pure ASCII pays one compare.
+// Decides exactly what the reference's lookup algorithm decides (utf8_lookup4_algorithm.h:16-202), incl. the
+// "sequence open at the end of the input" rule (:164-171).
+// =====================================================================================================
+constexpr u32 UTF8Q_SLOTS = 128; // < 64 left over + <= 64 noted by one chunk
+struct utf8_queue {
+  u32 *slots;  // LDS, UTF8Q_SLOTS words owned by this wave
+  u32 count;   // wave-uniform
+  u32 pending; // wave-uniform: the last three bytes in front of the next block hold a non-ASCII byte
+  u32 error;   // wave-uniform, sticky
+};
+// state at the start of a span, from the look-back bytes (lane i holds byte start-1-i)
+__device__ __forceinline__ u32 utf8_pending_from(u32 lookback_byte, u32 lane) {
+  return (__ballot(lane < 3u && lookback_byte >= 0x80u) != 0) ? 1u : 0u;
+}
+// one chunk: b7 = the lane's plane 7 (non-ASCII positions), w15 = its last dword, block0 = index of lane 0's block
+__device__ __forceinline__ void utf8_note_chunk(utf8_queue &uq, u64 b7, u32 w15, u32 block0, u32 lane) {
+  const u64 m = __ballot(b7 != 0);
+  if (m | u64(uq.pending)) { // wave-uniform; ASCII chunks stop here
+    const u64 t = __ballot((w15 & 0x80808000u) != 0); // bytes 61..63 of the block
+    const u64 need = m | (t << 1) | u64(uq.pending);
+    uq.pending = u32(t >> 63);
+    const u32 k = __builtin_amdgcn_mbcnt_hi(u32(need >> 32), __builtin_amdgcn_mbcnt_lo(u32(need), 0u));
+    if ((need >> lane) & 1ull) { uq.slots[uq.count + k] = block0 + lane; }
+    uq.count += u32(popc64(need));
+  }
+}
+// 32 bytes at p (a multiple of 32) as 8 dwords; bytes at or beyond len read as 0x20, nothing past len is touched
+__device__ __forceinline__ void load_half(const u8 *__restrict__ buf, u64 p, u64 len, u32 (&w)[8]) {
+  if (p + 32 <= len) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(buf + p);
+    const uint4 a = q[0], b = q[1];
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+    w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+  } else {
+    const u32 rem = p < len ? u32(len - p) : 0u; // 0..31 real bytes
+#pragma unroll 1
+    for (u32 j = 0; j < 8; j++) {
+      u32 v = 0x20202020u;
+      for (u32 k = 0; k < 4; k++) {
+        if (4 * j + k < rem) { v = (v & ~(0xFFu << (8 * k))) | (u32(buf[p + 4 * j + k]) << (8 * k)); }
+      }
+      w[j] = v;
+    }
+  }
+}
+// true iff block `block` (64 bytes at block * 64) is ill-formed given the three bytes in front of it; `more`: the
+// input continues behind len (no end-of-input rule)
+__device__ __forceinline__ bool utf8_check_block(const u8 *__restrict__ buf, u64 len, bool more, u32 block) {
+  const u64 pos = u64(block) * BLOCK_BYTES;
+  if (pos >= len) { return false; } // nothing but padding (noted because the block in front ends in a non-ASCII byte)
+  u32 prev = 0x20202020u; // the dword in front of the half being checked
+  if (pos >= 4) { prev = *reinterpret_cast<const u32 *>(buf + pos - 4); }
+  u32 bad = 0;
+#pragma unroll 1
+  for (u32 h = 0; h < 2; h++) {
+    const u64 p = pos + 32u * h;
+    u32 w[8], q[8];
+    load_half(buf, p, len, w);
+    s2p32(w, q);
+    const utf8_leads_t<u32> L = utf8_classify_planes<u32>(q);
+    bad |= utf8_errors_planes<u32>(q, L, utf8_carry_from_bytes((prev >> 8) & 0xFFu, (prev >> 16) & 0xFFu, prev >> 24));
+    // a sequence still open where the input ends (when len is not a multiple of 32 the padding has flagged it)
+    if (!more && p + 32 >= len && (utf8_carry_out(L) & UTF8_CARRY_OPEN)) { bad |= 1u; }
+    prev = w[7];
+  }
+  return bad != 0;
+}
+// validate the n oldest queued blocks (n <= 64 and n <= count), one per lane
+__device__ __forceinline__ void utf8_drain(utf8_queue &uq, const u8 *__restrict__ buf, u64 len, bool more, u32 lane, u32 n) {
+  wave_lds_fence();
+  bool bad = false;
+  if (lane < n) { bad = utf8_check_block(buf, len, more, uq.slots[lane]); }
+  if (__ballot(bad)) { uq.error = 1u; }
+  const u32 rest = uq.count - n; // < 64
+  u32 v = 0;
+  if (lane < rest) { v = uq.slots[n + lane]; }
+  wave_lds_fence();
+  if (lane < rest) { uq.slots[lane] = v; }
+  wave_lds_fence();
+  uq.count = rest;
+}
+// after every chunk: keep the list below 64 entries
+__device__ __forceinline__ void utf8_drain_if_full(utf8_queue &uq, const u8 *__restrict__ buf, u64 len, bool more, u32 lane) {
+  if (uq.count >= 64u) { utf8_drain(uq, buf, len, more, lane, 64u); }
+}
+// Kernels whose LDS is tight keep only the < 64 left-over entries between scans (`park`, 64 words per wave) and let
+// the list grow in memory that is idle while the wave scans (its output window): utf8_resume before a span's first
+// chunk, utf8_settle behind its last one (where few registers are live), no draining in between -- `room` must
+// hold 63 + 64 entries per chunk of the span.
+__device__ __forceinline__ void utf8_resume(utf8_queue &uq, u32 *room, const u32 *park, u32 lane) {
+  if (lane < uq.count) { room[lane] = park[lane]; }
+  uq.slots = room;
+}
+__device__ __forceinline__ void utf8_settle(utf8_queue &uq, u32 *park, const u8 *__restrict__ buf, u64 len, bool more, u32 lane) {
+  while (uq.count >= 64u) { utf8_drain(uq, buf, len, more, lane, 64u); }
+  wave_lds_fence();
+  if (lane < uq.count) { park[lane] = uq.slots[lane]; }
+  wave_lds_fence();
+  uq.slots = park;
+}
+// at the end of the wave's work
+__device__ __forceinline__ void utf8_drain_rest(utf8_queue &uq, const u8 *__restrict__ buf, u64 len, bool more, u32 lane) {
+  utf8_drain_if_full(uq, buf, len, more, lane);
+  if (uq.count) { utf8_drain(uq, buf, len, more, lane, uq.count); }
+}
+
+// uq (WANT_UTF8 only): the wave's UTF-8 list; block0 = index of lane 0's block (byte offset of the chunk / 64)
 template <bool WANT_STRUCTURALS, bool WANT_UTF8>
-__device__ __forceinline__ chunk_masks scan_chunk(const u32 (&w)[16], wave_carry &wc, u32 lane) {
+__device__ __forceinline__ chunk_masks scan_chunk(const u32 (&w)[16], wave_carry &wc, u32 lane, utf8_queue *uq = nullptr, u32 block0 = 0) {
   const planes P = transpose64(w);
   const u64 lt = lanemask_lt(lane);
   chunk_masks out;
-
-  // UTF-8 first, so that the bit planes are dead before the string algebra needs registers
-  out.utf8_err = 0;
-  if (WANT_UTF8) {
-    if (__ballot(P.b[7] != 0) | u64(wc.utf8)) { // wave-uniform ASCII fast path
-      const utf8_leads L = utf8_classify(P);
-      const u32 co = utf8_carry_out(L);
-      u32 ci = __shfl_up(co, 1);
-      if (lane == 0) { ci = wc.utf8; }
-      out.utf8_err = utf8_errors(P, L, ci);
-      wc.utf8 = readlane(co, 63);
-    }
-  }
+  if (WANT_UTF8) { utf8_note_chunk(*uq, P.b[7], w[15], block0, lane); }
   const classes c = classify(P);
 
   // escapes: each block is "pass" (64 backslashes) or sets the carry by itself; a lane's carry-in is

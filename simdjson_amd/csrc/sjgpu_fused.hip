@@ -119,8 +119,8 @@ __device__ __forceinline__ bool lookback(const u64 *desc, u32 tile, u32 lane, u3
   }
 }
 
-// what a wave tells its workgroup about its 16 KiB span
-constexpr u32 WF_CTRL_IF_OUT = 1u, WF_CTRL_IF_IN = 2u, WF_UTF8 = 4u;
+// what a wave tells its workgroup about its 16 KiB span (UTF-8 verdicts go straight to the result: utf8_queue)
+constexpr u32 WF_CTRL_IF_OUT = 1u, WF_CTRL_IF_IN = 2u;
 
 // OP 0: stage 1 (out = u32 structural offsets); OP 1: minify (out = bytes)
 // TRACE: wave 0 / lane 0 of the first `trace_tiles` tiles records wall_clock64() at the phase boundaries
@@ -145,12 +145,15 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
   __shared__ u32 sh_prefix[4];            // S, B, ok
   __shared__ __attribute__((aligned(16))) u32 sh_stage[FUSED_WAVES][STAGE_WORDS];
   __shared__ u32 sh_lut[MINIFY_LUT_WORDS];
+  __shared__ u32 sh_uq[(OP == 0) ? FUSED_WAVES : 1][(OP == 0) ? 64 : 1]; // left-over UTF-8 list entries between tiles
 
   const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   if (OP == 1) {
     if (wave == 0) { init_compaction_lut(sh_lut, lane); }
     clear_minify_stage(reinterpret_cast<u8 *>(sh_stage[wave]), lane);
   }
+  const bool more = (carry & CARRY_MORE) != 0;
+  utf8_queue uq{sh_uq[(OP == 0) ? wave : 0], 0u, 0u, 0u}; // lives across tiles: blocks are validated 64 at a time
 
   for (;;) {
     // Take the ticket only when we are ready to start the tile: a ticket claimed early would make every
@@ -167,11 +170,12 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
     const u64 wave_start = org.begin + u64(tile) * FUSED_TILE_BYTES + u64(wave) * FUSED_WAVE_BYTES;
     u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0; // slot 3 = oldest chunk
     u32 n_out = 0, n_in = 0;
-    bool f_ci = false, f_co = false, f_ue = false; // wave-uniform error facts
+    bool f_ci = false, f_co = false; // wave-uniform error facts
     u32 parity = 0;
     if (wave_start < len) { // wave-uniform
       const u32 lookback = lookback_issue(buf, wave_start, lane); // consumed after chunk 0 has been requested
-      wave_carry wc{0u, 0u, 0u, 0u};
+      wave_carry wc{0u, 0u, 0u};
+      if (OP == 0) { utf8_resume(uq, sh_stage[wave], sh_uq[wave], lane); } // the output window is idle while we scan
 #pragma unroll 1
       for (u32 c = 0; c < FUSED_WAVE_CHUNKS; c++) {
         const u64 cstart = wave_start + u64(c) * CHUNK_BYTES;
@@ -181,16 +185,18 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
           u32 w[16];
           if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
           else { load_block(buf, pos, len, w); }
-          if (c == 0) { wc = segment_carry_from(buf, wave_start, lane, lookback, org.esc); }
+          if (c == 0) {
+            wc = segment_carry_from(buf, wave_start, lane, lookback, org.esc);
+            uq.pending = utf8_pending_from(lookback, lane);
+          }
           if (OP == 0) {
-            const chunk_masks m = scan_chunk<true, true>(w, wc, lane);
+            const chunk_masks m = scan_chunk<true, true>(w, wc, lane, &uq, u32(cstart / BLOCK_BYTES));
             a = m.cand;
             b = m.string_tail;
             n_out += u32(popc64(a & ~b));
             n_in += u32(popc64(a & b));
             f_ci |= __ballot((m.ctrl & m.in_string) != 0) != 0;
             f_co |= __ballot((m.ctrl & ~m.in_string) != 0) != 0;
-            f_ue |= __ballot(m.utf8_err != 0) != 0;
           } else {
             const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
             const u64 valid = valid_mask(pos, len);
@@ -204,8 +210,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
         b3 = b2; b2 = b1; b1 = b0; b0 = b;
       }
       parity = wc.s;
-      // a multi-byte sequence still open at the very end of the input (utf8_lookup4_algorithm.h:164-171)
-      if (OP == 0 && wave_start + FUSED_WAVE_BYTES >= len && !(carry & CARRY_MORE) && (wc.utf8 & UTF8_CARRY_OPEN)) { f_ue = true; }
+      if (OP == 0) { utf8_settle(uq, sh_uq[wave], buf, len, more, lane); }
     }
     SJ_STAMP(2); // wave 0 finished scanning
     {
@@ -213,7 +218,6 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
       u32 f = 0;
       if (f_ci) { f |= WF_CTRL_IF_OUT; }
       if (f_co) { f |= WF_CTRL_IF_IN; }
-      if (f_ue) { f |= WF_UTF8; }
       if (lane == 0) {
         sh_wave[wave][0] = parity;
         sh_wave[wave][1] = t_out;
@@ -284,7 +288,6 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
       const u32 f = sh_wave[wave][3];
       u32 g = 0;
       if (f & (s ? WF_CTRL_IF_IN : WF_CTRL_IF_OUT)) { g |= SJGPU_F_UNESCAPED_CTRL; }
-      if (f & WF_UTF8) { g |= SJGPU_F_UTF8_ERROR; }
       if (g && lane == 0) { atomicOr(&result->flags, g); }
     }
     const u64 flip = s ? ~0ull : 0ull;
@@ -312,6 +315,10 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
     if (OP == 0 && __ballot(overflow) && lane == 0) { atomicOr(&result->flags, SJGPU_F_IDX_OVERFLOW); }
     SJ_STAMP(6); // wave 0 finished emitting
   }
+  if (OP == 0) { // what is left of the wave's UTF-8 list, then its verdict
+    utf8_drain_rest(uq, buf, len, more, lane);
+    if (uq.error && lane == 0) { atomicOr(&result->flags, SJGPU_F_UTF8_ERROR); }
+  }
 #undef SJ_STAMP
 }
 
@@ -327,85 +334,132 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
 constexpr u32 PIPE_WINDOW = 1280; // 4 x 5 KiB of emission windows + 16 KiB of pending masks -> 4 workgroups per CU
 constexpr u32 NO_TILE = 0xFFFFFFFFu;
 
-template <int OP>
-__global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc,
+// PF: spans that lie wholly inside the input are scanned with the loads of chunk c+1 in flight while chunk c is
+// classified (two register sets, the four chunks unrolled).  Measured round 2 (profiles/r02_*): nothing on dense output,
+// where the kernel moves bytes at the rate a plain copy of them reaches, but sparse output (NDJSON, pretty-printed text)
+// is bound by how many loads 16 waves per CU keep in flight.
+// TRACE: thread 0 of every workgroup stamps wall_clock64() at 8 phase boundaries of its first PIPE_TRACE_ITERS iterations
+// (sjgpu_debug_trace_pipelined): 0 loop top, 1 ticket known, 2 wave 0 scanned, 3 all scanned, 4 wave 0 published +
+// looked back, 5 prefix broadcast, 6 wave 0 emitted, 7 masks parked.
+constexpr u32 PIPE_TRACE_ITERS = 32;
+template <int OP, bool PF, bool TRACE = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fused_pipelined(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc,
                                                          u32 *__restrict__ ticket, u32 ntiles, void *__restrict__ out,
-                                                         u64 out_words, scan_result_dev *__restrict__ result, scan_origin org) {
+                                                         u64 out_words, scan_result_dev *__restrict__ result, scan_origin org,
+                                                         u64 *__restrict__ trace = nullptr) {
+#define SJ_PSTAMP(k) do { if (TRACE && threadIdx.x == 0 && iter < PIPE_TRACE_ITERS) { trace[(u64(blockIdx.x) * PIPE_TRACE_ITERS + iter) * TRACE_STAMPS + (k)] = wall_clock64(); } } while (0)
   const u32 carry = org.carry;
   constexpr u32 WC = FUSED_WAVE_CHUNKS;
   constexpr u32 STAGE_WORDS = (OP == 0) ? emit_stage_words(PIPE_WINDOW) : (MINIFY_STAGE_BYTES / 4);
   constexpr u32 WAVE_BYTES = WC * CHUNK_BYTES;
-  __shared__ u32 sh_tile;
+  __shared__ u32 sh_tile[2];                 // [iteration parity]: the ticket of an iteration is drawn one iteration ahead
   __shared__ u32 sh_wave[2][FUSED_WAVES][4]; // [iteration parity][wave]: parity, count_if_out, count_if_in, flags
   __shared__ u32 sh_agg[2][4];               // tile aggregate of the same two tiles (tq, tout, tin)
   __shared__ u32 sh_prefix[4];               // S, B, ok of the tile being emitted
   __shared__ u64 sh_mask_a[FUSED_WAVES][WC][64], sh_mask_b[FUSED_WAVES][WC][64]; // the pending tile's masks
   __shared__ __attribute__((aligned(16))) u32 sh_stage[FUSED_WAVES][STAGE_WORDS];
   __shared__ u32 sh_lut[MINIFY_LUT_WORDS];
+  __shared__ u32 sh_uq[(OP == 0) ? FUSED_WAVES : 1][(OP == 0) ? 64 : 1]; // left-over UTF-8 list entries between tiles
 
   const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   if (OP == 1) {
     if (wave == 0) { init_compaction_lut(sh_lut, lane); }
     clear_minify_stage(reinterpret_cast<u8 *>(sh_stage[wave]), lane);
   }
+  const bool more = (carry & CARRY_MORE) != 0;
+  utf8_queue uq{sh_uq[(OP == 0) ? wave : 0], 0u, 0u, 0u}; // lives across tiles: blocks are validated 64 at a time
   u32 pend_tile = NO_TILE; // workgroup-uniform
+  // Tickets are drawn one iteration AHEAD (the atomic's round trip, 1.4-2 us of an iteration of 21-27, hides behind
+  // the scan): thread 0 keeps the next ticket in a register and hands it over through LDS at the end of the iteration.
+  // Progress: a workgroup still publishes the aggregate of every tile it holds before it waits for anyone, and all its
+  // waits are on smaller tile numbers; the owner of the smallest unpublished tile is therefore never blocked.
+  u32 next_ticket = 0;
+  if (threadIdx.x == 0) { sh_tile[0] = atomicAdd(ticket, 1u); }
   for (u32 iter = 0;; iter++) {
     const u32 cur = iter & 1u;
-    if (threadIdx.x == 0) { sh_tile = atomicAdd(ticket, 1u); }
+    SJ_PSTAMP(0);
     __syncthreads();
-    const u32 tile = sh_tile;
+    const u32 tile = sh_tile[cur];
     const bool have = tile < ntiles;
     const bool pend = pend_tile != NO_TILE;
     if (!have && !pend) { break; }
+    if (threadIdx.x == 0 && have) { next_ticket = atomicAdd(ticket, 1u); } // consumed at the end of this iteration
+    SJ_PSTAMP(1);
 
     // ---- scan the new tile into the register FIFO ------------------------------------------------------------
     u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0; // slot 3 = oldest chunk
     if (have) {
       const u64 wave_start = org.begin + u64(tile) * FUSED_TILE_BYTES + u64(wave) * WAVE_BYTES;
       u32 n_out = 0, n_in = 0, parity = 0;
-      bool f_ci = false, f_co = false, f_ue = false;
+      bool f_ci = false, f_co = false;
       if (wave_start < len) {
         const u32 lookback = lookback_issue(buf, wave_start, lane);
-        wave_carry wc{0u, 0u, 0u, 0u};
-#pragma unroll 1
-        for (u32 c = 0; c < WC; c++) {
-          const u64 cstart = wave_start + u64(c) * CHUNK_BYTES;
-          u64 a = 0, b = 0;
-          if (cstart < len) {
-            const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
-            u32 w[16];
-            if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
-            else { load_block(buf, pos, len, w); }
-            if (c == 0) { wc = segment_carry_from(buf, wave_start, lane, lookback, org.esc); }
-            if (OP == 0) {
-              const chunk_masks m = scan_chunk<true, true>(w, wc, lane);
-              a = m.cand;
-              b = m.string_tail;
-              n_out += u32(popc64(a & ~b));
-              n_in += u32(popc64(a & b));
-              f_ci |= __ballot((m.ctrl & m.in_string) != 0) != 0;
-              f_co |= __ballot((m.ctrl & ~m.in_string) != 0) != 0;
-              f_ue |= __ballot(m.utf8_err != 0) != 0;
-            } else {
-              const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
-              const u64 valid = valid_mask(pos, len);
-              a = valid & m.ws;
-              b = m.in_string;
-              n_out += u32(popc64(valid & ~(a & ~b)));
-              n_in += u32(popc64(valid & ~(a & b)));
-            }
+        wave_carry wc{0u, 0u, 0u};
+        if (OP == 0) { utf8_resume(uq, sh_stage[wave], sh_uq[wave], lane); } // the output window is idle while we scan
+        // one chunk through the scanner; its masks enter the FIFO
+        auto scan_one = [&](const u32 (&w)[16], u64 cstart) {
+          const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
+          u64 a, b;
+          if (OP == 0) {
+            const chunk_masks m = scan_chunk<true, true>(w, wc, lane, &uq, u32(cstart / BLOCK_BYTES));
+            a = m.cand;
+            b = m.string_tail;
+            n_out += u32(popc64(a & ~b));
+            n_in += u32(popc64(a & b));
+            f_ci |= __ballot((m.ctrl & m.in_string) != 0) != 0;
+            f_co |= __ballot((m.ctrl & ~m.in_string) != 0) != 0;
+          } else {
+            const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
+            const u64 valid = valid_mask(pos, len);
+            a = valid & m.ws;
+            b = m.in_string;
+            n_out += u32(popc64(valid & ~(a & ~b)));
+            n_in += u32(popc64(valid & ~(a & b)));
           }
           a3 = a2; a2 = a1; a1 = a0; a0 = a;
           b3 = b2; b2 = b1; b1 = b0; b0 = b;
+        };
+        if (PF && wave_start + WAVE_BYTES <= len) { // wave-uniform: the whole span is input
+          const u64 lane_pos = wave_start + u64(lane) * BLOCK_BYTES;
+          u32 wa[16], wb[16];
+          load_block_full(buf, lane_pos, wa);
+          load_block_full(buf, lane_pos + CHUNK_BYTES, wb);
+          wc = segment_carry_from(buf, wave_start, lane, lookback, org.esc);
+          uq.pending = utf8_pending_from(lookback, lane);
+          scan_one(wa, wave_start);
+          load_block_full(buf, lane_pos + 2 * CHUNK_BYTES, wa);
+          scan_one(wb, wave_start + CHUNK_BYTES);
+          load_block_full(buf, lane_pos + 3 * CHUNK_BYTES, wb);
+          scan_one(wa, wave_start + 2 * CHUNK_BYTES);
+          scan_one(wb, wave_start + 3 * CHUNK_BYTES);
+        } else {
+#pragma unroll 1
+          for (u32 c = 0; c < WC; c++) {
+            const u64 cstart = wave_start + u64(c) * CHUNK_BYTES;
+            if (cstart < len) {
+              const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
+              u32 w[16];
+              if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
+              else { load_block(buf, pos, len, w); }
+              if (c == 0) {
+                wc = segment_carry_from(buf, wave_start, lane, lookback, org.esc);
+                uq.pending = utf8_pending_from(lookback, lane);
+              }
+              scan_one(w, cstart);
+            } else {
+              a3 = a2; a2 = a1; a1 = a0; a0 = 0;
+              b3 = b2; b2 = b1; b1 = b0; b0 = 0;
+            }
+          }
         }
         parity = wc.s;
-        if (OP == 0 && wave_start + WAVE_BYTES >= len && !(carry & CARRY_MORE) && (wc.utf8 & UTF8_CARRY_OPEN)) { f_ue = true; }
+        if (OP == 0) { utf8_settle(uq, sh_uq[wave], buf, len, more, lane); }
       }
+      SJ_PSTAMP(2);
       const u32 t_out = wave_sum(n_out), t_in = wave_sum(n_in);
       u32 f = 0;
       if (f_ci) { f |= WF_CTRL_IF_OUT; }
       if (f_co) { f |= WF_CTRL_IF_IN; }
-      if (f_ue) { f |= WF_UTF8; }
       if (lane == 0) {
         sh_wave[cur][wave][0] = parity;
         sh_wave[cur][wave][1] = t_out;
@@ -414,6 +468,7 @@ __global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ 
       }
     }
     __syncthreads();
+    SJ_PSTAMP(3);
 
     // ---- wave 0: publish the new tile's aggregate, then resolve the PENDING tile's prefix -------------------------
     if (wave == 0) {
@@ -468,8 +523,10 @@ __global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ 
           sh_prefix[2] = ok ? 1u : 0u;
         }
       }
+      SJ_PSTAMP(4);
     }
     __syncthreads();
+    SJ_PSTAMP(5);
 
     // ---- every wave: emit its share of the pending tile from the LDS masks -----------------------------------------
     if (pend && sh_prefix[2] != 0u) {
@@ -483,7 +540,6 @@ __global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ 
         const u32 f = sh_wave[cur ^ 1u][wave][3];
         u32 g = 0;
         if (f & (s ? WF_CTRL_IF_IN : WF_CTRL_IF_OUT)) { g |= SJGPU_F_UNESCAPED_CTRL; }
-        if (f & WF_UTF8) { g |= SJGPU_F_UTF8_ERROR; }
         if (g && lane == 0) { atomicOr(&result->flags, g); }
         const u64 flip = s ? ~0ull : 0ull;
         bool overflow = false;
@@ -506,6 +562,7 @@ __global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ 
         if (OP == 0 && __ballot(overflow) && lane == 0) { atomicOr(&result->flags, SJGPU_F_IDX_OVERFLOW); }
       }
     }
+    SJ_PSTAMP(6);
     // ---- the tile scanned in this iteration becomes the pending one: park its masks in (this wave's rows of) LDS ----
     if (have) {
       sh_mask_a[wave][0][lane] = a3; sh_mask_b[wave][0][lane] = b3;
@@ -514,7 +571,14 @@ __global__ __launch_bounds__(256) void k_fused_pipelined(const u8 *__restrict__ 
       sh_mask_a[wave][3][lane] = a0; sh_mask_b[wave][3][lane] = b0;
     }
     pend_tile = have ? tile : NO_TILE;
+    if (threadIdx.x == 0) { sh_tile[cur ^ 1u] = have ? next_ticket : NO_TILE; } // visible behind the barrier at the loop top
+    SJ_PSTAMP(7);
   }
+  if (OP == 0) { // what is left of the wave's UTF-8 list, then its verdict
+    utf8_drain_rest(uq, buf, len, more, lane);
+    if (uq.error && lane == 0) { atomicOr(&result->flags, SJGPU_F_UTF8_ERROR); }
+  }
+#undef SJ_PSTAMP
 }
 
 } // namespace
@@ -540,7 +604,6 @@ static void launch_fused_wc(int op, const uint8_t *buf, uint64_t len, uint64_t *
   }
   const u32 grid = ntiles < max_workgroups ? ntiles : max_workgroups;
   u64 *no_trace = nullptr;
-  mark(ev, 0, stream);
   if (trace) {
     hipLaunchKernelGGL((k_fused<0, true, WC>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words,
                        result, trace, trace_tiles, org);
@@ -556,17 +619,22 @@ static void launch_fused_wc(int op, const uint8_t *buf, uint64_t len, uint64_t *
   mark(ev, 3, stream);
 }
 
-static void launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *desc, void *out, uint64_t out_words,
-                         scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
-                         hipEvent_t *ev, uint64_t *trace = nullptr, uint32_t trace_tiles = 0) {
+// returns the name of the scan kernel it launched (sjgpu_profile_kernel)
+static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *desc, void *out, uint64_t out_words,
+                                scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
+                                hipEvent_t *ev, uint64_t *trace = nullptr, uint32_t trace_tiles = 0) {
   static const bool plain = std::getenv("SJGPU_FUSED_PLAIN") != nullptr; // A/B switch: the non-pipelined large-input kernel
   uint8_t *const esc_workspace = org.esc;
-  if (!wants_escape_table(len - org.begin) || !esc_workspace) { org.esc = nullptr; }
+  if (!wants_escape_table(len - org.begin, org) || !esc_workspace) { org.esc = nullptr; }
+  mark(ev, 0, stream); // slot 0 = everything this call enqueues (table, clears, the scan kernel)
   if (len - org.begin <= FUSED_SMALL_BELOW && !trace) {
+    if (org.esc) { launch_escape_table(buf, org.begin, len, esc_workspace, stream); } // a range of a larger buffer
     launch_fused_wc<1>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles);
+    return op == 0 ? "k_fused<0> (16 KiB tiles)" : "k_fused<1> (16 KiB tiles)";
   } else if (trace || plain) {
     if (org.esc) { launch_escape_table(buf, org.begin, len, esc_workspace, stream); }
     launch_fused_wc<FUSED_WAVE_CHUNKS>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles);
+    return op == 0 ? "k_fused<0> (64 KiB tiles)" : "k_fused<1> (64 KiB tiles)";
   } else {
     const u32 ntiles = u32((len - org.begin + FUSED_TILE_BYTES - 1) / FUSED_TILE_BYTES);
     u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles);
@@ -587,30 +655,55 @@ static void launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *des
     // half as many workgroups as tiles at most: every workgroup should own >= 2 tiles for the deferral to work
     const u32 cap = (ntiles + 1) / 2;
     const u32 grid = cap < max_workgroups ? cap : max_workgroups;
-    mark(ev, 0, stream);
-    if (op == 0) {
-      hipLaunchKernelGGL(k_fused_pipelined<0>, dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result, org);
+    static const bool prefetch = []() { const char *v = std::getenv("SJGPU_PREFETCH"); return !v || v[0] != '0'; }(); // A/B switch
+    if (op == 0 && prefetch) {
+      hipLaunchKernelGGL((k_fused_pipelined<0, true>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result, org);
+    } else if (op == 0) {
+      hipLaunchKernelGGL((k_fused_pipelined<0, false>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result, org);
     } else {
-      hipLaunchKernelGGL(k_fused_pipelined<1>, dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result, org);
+      hipLaunchKernelGGL((k_fused_pipelined<1, false>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result, org);
     }
     mark(ev, 1, stream);
     mark(ev, 2, stream);
     mark(ev, 3, stream);
+    return op == 0 ? "k_fused_pipelined<0>" : "k_fused_pipelined<1>";
   }
 }
 
-void launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
-                         scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev) {
-  launch_fused(0, buf, len, desc, idx, idx_words, result, org, max_workgroups, stream, ev);
+const char *launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
+                                scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev) {
+  return launch_fused(0, buf, len, desc, idx, idx_words, result, org, max_workgroups, stream, ev);
 }
+// one traced run of the pipelined stage-1 kernel; trace holds *grid_out x PIPE_TRACE_ITERS x 8 stamps (zero = not reached)
+uint32_t launch_stage1_pipelined_traced(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
+                                        scan_result_dev *result, uint8_t *esc_workspace, uint32_t max_workgroups, hipStream_t stream,
+                                        uint64_t *trace, uint32_t max_records) {
+  scan_origin org{0, 0, 0, esc_workspace};
+  const u32 ntiles = u32((len + FUSED_TILE_BYTES - 1) / FUSED_TILE_BYTES);
+  u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles);
+  launch_escape_table(buf, 0, len, esc_workspace, stream);
+  (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
+  (void)hipMemsetAsync(desc, 0, (size_t(ntiles) + 1) * sizeof(u64), stream);
+  const u32 cap = (ntiles + 1) / 2;
+  u32 grid = cap < max_workgroups ? cap : max_workgroups;
+  if (grid > max_records / PIPE_TRACE_ITERS) { return 0; }
+  static const bool prefetch = []() { const char *v = std::getenv("SJGPU_PREFETCH"); return !v || v[0] != '0'; }();
+  if (prefetch) {
+    hipLaunchKernelGGL((k_fused_pipelined<0, true, true>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, idx, idx_words, result, org, trace);
+  } else {
+    hipLaunchKernelGGL((k_fused_pipelined<0, false, true>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, idx, idx_words, result, org, trace);
+  }
+  return grid;
+}
+
 void launch_stage1_fused_traced(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
                                 scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, uint64_t *trace,
                                 uint32_t trace_tiles) {
   launch_fused(0, buf, len, desc, idx, idx_words, result, scan_origin{0, 0, 0}, max_workgroups, stream, nullptr, trace, trace_tiles);
 }
-void launch_minify_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint8_t *dst, scan_result_dev *result,
-                         scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev) {
-  launch_fused(1, buf, len, desc, dst, 0, result, org, max_workgroups, stream, ev);
+const char *launch_minify_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint8_t *dst, scan_result_dev *result,
+                                scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev) {
+  return launch_fused(1, buf, len, desc, dst, 0, result, org, max_workgroups, stream, ev);
 }
 
 } // namespace sjgpu

@@ -68,7 +68,8 @@ inline uint32_t num_fused_tiles(uint64_t len) { // descriptor words a context ne
 }
 
 // ---- launchers (sjgpu_kernels.hip); every one only enqueues on `stream` ---------------------------------
-// ev: nullptr, or PROFILE_EVENTS events recorded around the kernels (ev[k], ev[k+1] bracket kernel k).
+// ev: nullptr, or PROFILE_EVENTS events recorded around the kernels: ev[k], ev[k+1] bracket slot k (slot 0 includes the
+// escape-table launch and the workspace clears in front of the first scan kernel; unused slots measure zero).
 constexpr int PROFILE_SLOTS = 3;
 constexpr int PROFILE_EVENTS = PROFILE_SLOTS + 1;
 // carry: state in front of byte 0 when the buffer is a shard of a larger document; 0 for a whole document.
@@ -102,18 +103,27 @@ constexpr size_t ESC_TABLE_BYTES = (ESC_TABLE_ENTRIES + 1023) & ~size_t(1023); /
 // result + descriptors + ticket need no memset of their own.
 void launch_escape_table(const uint8_t *buf, uint64_t begin, uint64_t len, uint8_t *esc, hipStream_t stream,
                          void *clear = nullptr, size_t clear_bytes = 0);
-// scans up to FUSED_SMALL_BELOW bytes walk over backslash runs (bounded by their size); longer ones get the table
+// whole documents up to FUSED_SMALL_BELOW bytes walk over backslash runs (bounded by their size); longer ones get the
+// table -- and so does EVERY range of a larger buffer, however short: the walk of a short range would otherwise run
+// back over all earlier ranges, and a later range resolves its pass entries through the entries of the ranges in
+// front of it, which must therefore all have been written
 inline bool wants_escape_table(uint64_t scanned_bytes) { return scanned_bytes > FUSED_SMALL_BELOW; }
+inline bool wants_escape_table(uint64_t scanned_bytes, const scan_origin &org) {
+  return scanned_bytes > FUSED_SMALL_BELOW || org.begin > 0 || (org.carry & CARRY_MORE) != 0;
+}
 void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *result, hipStream_t stream, hipEvent_t *ev);
 // single-pass variants: desc holds num_fused_tiles(capacity)+1 words; only profile slot 0 is used
-void launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
-                         scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
-                         hipEvent_t *ev);
+const char *launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
+                                scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
+                                hipEvent_t *ev); // -> name of the scan kernel launched
 void launch_stage1_fused_traced(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
                                 scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, uint64_t *trace,
                                 uint32_t trace_tiles); // 8 wall_clock64 stamps (100 MHz) per tile
-void launch_minify_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint8_t *dst, scan_result_dev *result,
-                         scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev);
+uint32_t launch_stage1_pipelined_traced(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
+                                        scan_result_dev *result, uint8_t *esc_workspace, uint32_t max_workgroups, hipStream_t stream,
+                                        uint64_t *trace, uint32_t max_records); // -> workgroups launched (32 records of 8 stamps each)
+const char *launch_minify_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint8_t *dst, scan_result_dev *result,
+                                scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev);
 
 } // namespace sjgpu
 #endif

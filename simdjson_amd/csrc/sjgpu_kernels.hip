@@ -40,13 +40,21 @@ __global__ __launch_bounds__(64) void k_stage1_summarize(const u8 *__restrict__ 
   const u32 seg = blockIdx.x; // relative to the scan's origin: workspace index
   const u64 seg_start = org.begin + u64(seg) * SEG_BYTES;
   const u64 lane_off = u64(lane) * BLOCK_BYTES;
+  __shared__ u32 uq_slots[UTF8Q_SLOTS];
+  const bool more = (org.carry & CARRY_MORE) != 0;
   const u32 lookback = lookback_issue(buf, seg_start, lane); // consumed after chunk 0 has been requested
-  wave_carry wc{0u, 0u, 0u, 0u};
+  wave_carry wc{0u, 0u, 0u};
+  utf8_queue uq{uq_slots, 0u, 0u, 0u};
   u32 n_a = 0, n_b = 0; // resolved: n_a = final count; else n_a = candidates, n_b = candidates in a string tail
-  u64 ctrl_a = 0, ctrl_b = 0, uerr = 0;
+  u64 ctrl_a = 0, ctrl_b = 0;
   bool resolved = false;
   u32 derived = 0;
   u64 flip = 0;
+  // The segment's masks leave in ONE burst behind the last chunk (32 bytes per lane and plane, lane-major), not chunk
+  // by chunk: an 8-byte store in front of the next chunk's loads sits in the same in-order counter those loads are
+  // waited on, so every chunk paid the store's round trip (loads + OR + such a store: 4.6 TB/s, without: 5.9).
+  u64 keep0[SEG_CHUNKS] = {0, 0, 0, 0}, keep1[SEG_CHUNKS] = {0, 0, 0, 0};
+#pragma unroll
   for (u32 c = 0; c < SEG_CHUNKS; c++) {
     const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
     if (cstart >= len) { break; }
@@ -54,8 +62,11 @@ __global__ __launch_bounds__(64) void k_stage1_summarize(const u8 *__restrict__ 
     u32 w[16];
     if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); } // interior chunk: branch-free loads
     else { load_block(buf, pos, len, w); }
-    if (c == 0) { wc = segment_carry_from(buf, seg_start, lane, lookback, org.esc); } // its latency hid behind the loads above
-    const chunk_masks m = scan_chunk<true, true>(w, wc, lane);
+    if (c == 0) { // the look-back's latency hid behind the loads above
+      wc = segment_carry_from(buf, seg_start, lane, lookback, org.esc);
+      uq.pending = utf8_pending_from(lookback, lane);
+    }
+    const chunk_masks m = scan_chunk<true, true>(w, wc, lane, &uq, u32(cstart / BLOCK_BYTES));
     if (c == 0) {
       const u64 cm = __ballot(m.ctrl != 0);
       if (cm) { // wave-uniform
@@ -67,28 +78,37 @@ __global__ __launch_bounds__(64) void k_stage1_summarize(const u8 *__restrict__ 
         flip = derived ? ~0ull : 0ull;
       }
     }
-    uerr |= m.utf8_err;
     if (resolved) {
       const u64 structural = m.cand & ~(m.string_tail ^ flip);
       n_a += u32(popc64(structural));
       ctrl_a |= m.ctrl & (m.in_string ^ flip);
-      mask0[(pos - org.begin) / BLOCK_BYTES] = structural;
+      keep0[c] = structural;
     } else {
       n_a += u32(popc64(m.cand));
       n_b += u32(popc64(m.cand & m.string_tail));
       ctrl_a |= m.ctrl & m.in_string;  // offends if the relative view is the true one
       ctrl_b |= m.ctrl & ~m.in_string; // offends if the segment really starts inside a string
-      mask0[(pos - org.begin) / BLOCK_BYTES] = m.cand;
-      mask1[(pos - org.begin) / BLOCK_BYTES] = m.string_tail;
+      keep0[c] = m.cand;
+      keep1[c] = m.string_tail;
+    }
+    utf8_drain_if_full(uq, buf, len, more, lane);
+  }
+  {
+    const size_t at = (size_t(seg) * 64 + lane) * 2; // in 16-byte units: [segment][lane][chunk]
+    uint4 *p0 = reinterpret_cast<uint4 *>(mask0) + at;
+    p0[0] = make_uint4(u32(keep0[0]), u32(keep0[0] >> 32), u32(keep0[1]), u32(keep0[1] >> 32));
+    p0[1] = make_uint4(u32(keep0[2]), u32(keep0[2] >> 32), u32(keep0[3]), u32(keep0[3] >> 32));
+    if (!resolved) {
+      uint4 *p1 = reinterpret_cast<uint4 *>(mask1) + at;
+      p1[0] = make_uint4(u32(keep1[0]), u32(keep1[0] >> 32), u32(keep1[1]), u32(keep1[1] >> 32));
+      p1[1] = make_uint4(u32(keep1[2]), u32(keep1[2] >> 32), u32(keep1[3]), u32(keep1[3] >> 32));
     }
   }
-  // a multi-byte sequence still open at the very end of the input (utf8_lookup4_algorithm.h:164-171);
-  // when len is not a multiple of the chunk the space padding has already flagged it.
-  if (seg_start + SEG_BYTES >= len && !(org.carry & CARRY_MORE) && (wc.utf8 & UTF8_CARRY_OPEN)) { uerr |= 1; }
+  utf8_drain_rest(uq, buf, len, more, lane); // incl. a sequence still open at the very end of the input
   const u32 ta = wave_sum(n_a), tb = wave_sum(n_b);
   const bool any_a = __ballot(ctrl_a != 0) != 0, any_b = __ballot(ctrl_b != 0) != 0;
   u32 flags = wc.s ? SF_PARITY : 0u;
-  if (__ballot(uerr != 0)) { flags |= SF_UTF8; }
+  if (uq.error) { flags |= SF_UTF8; }
   seg_summary s;
   if (resolved) {
     flags |= SF_RESOLVED;
@@ -258,13 +278,19 @@ __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask
   // Independent loads first, consumers later: the four chunks' masks (8 bytes per lane each) are requested before
   // the group-prefix fold, so the segment pays ONE round trip to HBM, not one per chunk plus one for the prefix.
   const bool resolved = (summ[seg].flags & SF_RESOLVED) != 0; // masks are already final
-  u64 m0[SEG_CHUNKS], m1[SEG_CHUNKS];
-#pragma unroll
-  for (u32 c = 0; c < SEG_CHUNKS; c++) {
-    const u64 pos = seg_start + u64(c) * CHUNK_BYTES + u64(lane) * BLOCK_BYTES;
-    const bool live = seg_start + u64(c) * CHUNK_BYTES < len;
-    m0[c] = live ? mask0[(pos - org.begin) / BLOCK_BYTES] : 0ull;
-    m1[c] = (live && !resolved) ? mask1[(pos - org.begin) / BLOCK_BYTES] : 0ull;
+  u64 m0[SEG_CHUNKS], m1[SEG_CHUNKS] = {0, 0, 0, 0};
+  {
+    const size_t at = (size_t(seg) * 64 + lane) * 2; // [segment][lane][chunk]; chunks beyond len hold zero masks
+    const uint4 *p0 = reinterpret_cast<const uint4 *>(mask0) + at;
+    const uint4 x = p0[0], y = p0[1];
+    m0[0] = (u64(x.y) << 32) | x.x; m0[1] = (u64(x.w) << 32) | x.z;
+    m0[2] = (u64(y.y) << 32) | y.x; m0[3] = (u64(y.w) << 32) | y.z;
+    if (!resolved) {
+      const uint4 *p1 = reinterpret_cast<const uint4 *>(mask1) + at;
+      const uint4 u = p1[0], v = p1[1];
+      m1[0] = (u64(u.y) << 32) | u.x; m1[1] = (u64(u.w) << 32) | u.z;
+      m1[2] = (u64(v.y) << 32) | v.x; m1[3] = (u64(v.w) << 32) | v.z;
+    }
   }
   const seg_prefix pf = segment_prefix(summ, gpref, seg, lane);
   u32 base = pf.base;
@@ -291,7 +317,7 @@ __global__ __launch_bounds__(64) void k_minify_summarize(const u8 *__restrict__ 
   const u32 seg = blockIdx.x;
   const u64 seg_start = org.begin + u64(seg) * SEG_BYTES;
   const u32 lookback = lookback_issue(buf, seg_start, lane);
-  wave_carry wc{0u, 0u, 0u, 0u};
+  wave_carry wc{0u, 0u, 0u};
   u32 kept_out = 0, kept_in = 0;
   for (u32 c = 0; c < SEG_CHUNKS; c++) {
     const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
@@ -328,7 +354,7 @@ __global__ __launch_bounds__(64) void k_minify_emit(const u8 *__restrict__ buf, 
   const u64 seg_start = org.begin + u64(seg) * SEG_BYTES;
   const u32 lookback = lookback_issue(buf, seg_start, lane);
   const seg_prefix pf = segment_prefix(summ, gpref, seg, lane);
-  wave_carry wc{0u, 0u, 0u, 0u};
+  wave_carry wc{0u, 0u, 0u};
   u32 base = pf.base;
   for (u32 c = 0; c < SEG_CHUNKS; c++) {
     const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
@@ -393,7 +419,7 @@ __global__ __launch_bounds__(64) void k_string_parity(const u8 *__restrict__ buf
   for (u32 seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const u64 seg_start = u64(seg) * SEG_BYTES;
     const u32 lookback = lookback_issue(buf, seg_start, lane);
-    wave_carry wc{0u, 0u, 0u, 0u};
+    wave_carry wc{0u, 0u, 0u};
     for (u32 c = 0; c < SEG_CHUNKS; c++) {
       const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
       if (cstart >= len) { break; }
@@ -471,9 +497,9 @@ static inline void mark(hipEvent_t *ev, int k, hipStream_t stream) {
 void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *summ, seg_prefix *pref, uint32_t *idx,
                    uint64_t idx_words, scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev) {
   const u32 nseg = num_segments(len - org.begin);
-  if (wants_escape_table(len - org.begin) && org.esc) { launch_escape_table(buf, org.begin, len, org.esc, stream); }
+  mark(ev, 0, stream); // slot 0 = table + summarize
+  if (wants_escape_table(len - org.begin, org) && org.esc) { launch_escape_table(buf, org.begin, len, org.esc, stream); }
   else { org.esc = nullptr; }
-  mark(ev, 0, stream);
   u64 *mask0 = reinterpret_cast<u64 *>(masks);
   u64 *mask1 = mask0 + size_t(nseg) * (SEG_BYTES / BLOCK_BYTES); // second plane, only written by unresolved segments
   hipLaunchKernelGGL(k_stage1_summarize, dim3(nseg), dim3(64), 0, stream, buf, len, mask0, mask1, summ, org);
@@ -492,9 +518,9 @@ void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *
 void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_prefix *pref, uint8_t *dst,
                    scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev) {
   const u32 nseg = num_segments(len - org.begin);
-  if (wants_escape_table(len - org.begin) && org.esc) { launch_escape_table(buf, org.begin, len, org.esc, stream); }
+  mark(ev, 0, stream); // slot 0 = table + summarize
+  if (wants_escape_table(len - org.begin, org) && org.esc) { launch_escape_table(buf, org.begin, len, org.esc, stream); }
   else { org.esc = nullptr; }
-  mark(ev, 0, stream);
   hipLaunchKernelGGL(k_minify_summarize, dim3(nseg), dim3(64), 0, stream, buf, len, summ, org);
   mark(ev, 1, stream);
   const u32 ngroups = (nseg + RESOLVE_GROUP - 1) / RESOLVE_GROUP;
@@ -508,10 +534,10 @@ void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_pref
 }
 
 void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *result, hipStream_t stream, hipEvent_t *ev) {
+  mark(ev, 0, stream);
   (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
   const u64 nchunks = (len + CHUNK_BYTES - 1) / CHUNK_BYTES;
   const u32 grid = u32(nchunks < 8192 ? nchunks : 8192); // 256 CUs x 32 single-wave workgroups, grid-stride beyond
-  mark(ev, 0, stream);
   hipLaunchKernelGGL(k_validate_utf8, dim3(grid), dim3(64), 0, stream, buf, len, result);
   mark(ev, 1, stream);
   mark(ev, 2, stream);

@@ -55,6 +55,58 @@ static int compare_stage1(const implementation *cpu, const implementation *gpu, 
   return 0;
 }
 
+static uint64_t fnv1a64(const void *p, size_t n) {
+  const uint8_t *b = static_cast<const uint8_t *>(p);
+  uint64_t h = 0xCBF29CE484222325ull;
+  for (size_t i = 0; i < n; i++) { h = (h ^ b[i]) * 0x100000001B3ull; }
+  return h;
+}
+
+// BASELINE.json configs[0]: the reference's real example files through dom::parser with the mi355x backend; the
+// known answers are the reference's own: n and the minified length as in SURVEY.md App. B, the FNV-1a-64 of the n+3
+// index words as tests/golden/corpora.json records it (made from the reference's x86 kernels by make_golden.py).
+static int check_jsonexamples(const implementation *cpu, const implementation *gpu, const std::string &dir) {
+  struct known { const char *file; uint32_t n; uint64_t fnv; size_t minified; };
+  const known files[] = {{"twitter.json", 55263u, 9964107509431273939ull, 466906}, {"citm_catalog.json", 135990u, 5599721547797733565ull, 500299}};
+  for (const known &k : files) {
+    padded_string json;
+    CHECK(padded_string::load(dir + "/" + k.file).get(json) == SUCCESS, "cannot load %s/%s", dir.c_str(), k.file);
+    get_active_implementation() = gpu;
+    dom::parser parser;
+    dom::element doc;
+    CHECK(parser.parse(json).get(doc) == SUCCESS, "%s: dom::parser::parse on mi355x", k.file);
+    const auto &impl = *parser.implementation;
+    CHECK(impl.n_structural_indexes == k.n, "%s: n = %u, expected %u", k.file, impl.n_structural_indexes, k.n);
+    const uint64_t h = fnv1a64(impl.structural_indexes.get(), (size_t(k.n) + 3) * sizeof(uint32_t));
+    CHECK(h == k.fnv, "%s: fnv of idx[0..n+2] = %llu, expected %llu", k.file, (unsigned long long)h, (unsigned long long)k.fnv);
+    std::vector<char> out(json.size());
+    size_t out_len = 0;
+    CHECK(simdjson::minify(json.data(), json.size(), out.data(), out_len) == SUCCESS && out_len == k.minified, "%s: minified length %zu, expected %zu",
+          k.file, out_len, k.minified);
+    CHECK(simdjson::validate_utf8(json.data(), json.size()), "%s: validate_utf8", k.file);
+    if (compare_stage1(cpu, gpu, json, k.file)) { return 1; }
+    std::printf("configs[0] %s: n = %u, fnv = %llu, minified %zu: OK\n", k.file, k.n, (unsigned long long)h, out_len);
+  }
+  padded_string nd;
+  CHECK(padded_string::load(dir + "/amazon_cellphones.ndjson").get(nd) == SUCCESS, "cannot load amazon_cellphones.ndjson");
+  size_t docs[2] = {0, 0};
+  int k = 0;
+  for (const implementation *impl : {cpu, gpu}) {
+    get_active_implementation() = impl;
+    dom::parser parser;
+    dom::document_stream stream;
+    CHECK(parser.parse_many(nd, 20000).get(stream) == SUCCESS, "parse_many");
+    for (auto doc : stream) {
+      CHECK(doc.error() == SUCCESS, "amazon_cellphones.ndjson document %zu: %s", docs[k], error_message(doc.error()));
+      docs[k]++;
+    }
+    k++;
+  }
+  CHECK(docs[0] == docs[1] && docs[0] == 793, "amazon_cellphones.ndjson: %zu vs %zu documents (expected 793)", docs[0], docs[1]);
+  std::printf("configs[0] amazon_cellphones.ndjson: %zu documents through parse_many: OK\n", docs[1]);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   const implementation *before = get_active_implementation();
   if (argc > 1 && std::strcmp(argv[1], "--expect-no-gpu") == 0) {
@@ -71,6 +123,13 @@ int main(int argc, char **argv) {
   CHECK(gpu->name() == "mi355x", "active implementation is %s", std::string(gpu->name()).c_str());
   std::printf("active: %s (%s); cpu reference kernel: %s\n", std::string(gpu->name()).c_str(),
               std::string(gpu->description()).c_str(), std::string(cpu->name()).c_str());
+
+  std::string examples = "tests/golden/jsonexamples";
+  for (int i = 1; i + 1 < argc; i++) {
+    if (std::strcmp(argv[i], "--jsonexamples") == 0) { examples = argv[i + 1]; }
+  }
+  if (check_jsonexamples(cpu, gpu, examples)) { return 1; }
+  get_active_implementation() = gpu;
 
   padded_string twitter = gen(sjc_twitter_like, 3 << 20, 21), random = gen(sjc_large_random, 3 << 20, 22),
                 amazon = gen(sjc_amazon_ndjson, 3 << 20, 23);
