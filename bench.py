@@ -3,12 +3,24 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--op stage1|minify|validate_utf8]
                     [--workload large_random|amazon_ndjson|twitter_like|deep_nesting|escape_heavy] [--size BYTES]
+                    [--legs all|none|name,name]
 
-A "step" = one pass of the hot path (sjgpu_*_device through the C-ABI) over one synthetic buffer that
-is already resident in HBM.  N = 1: BASELINE.json configs[1] -- 1 GiB large_random-style JSON.
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank scans its OWN 1 GiB shard
-(independent documents, SURVEY 8(e): no data-path collective), weak scaling; value = bytes all ranks
-scanned / max-over-ranks time.  Prints ONE JSON line on rank 0.
+A "step" = one pass of the hot path (sjgpu_*_device through the C-ABI) over one synthetic buffer that is already
+resident in HBM.  The TOP-LEVEL fields of the one JSON line are BASELINE.json configs[1]: stage 1 on 1 GiB of
+large_random-style JSON on one MI355X.  N = 1 additionally carries, under "legs", every other configuration of
+BASELINE.json measured the same way (each with its own `roofline` and `cpu_baseline`):
+
+    config0_twitter_json      the reference's real twitter.json: exact index check + device-resident and host-buffer timing
+    config2_minify            1 GiB large_random, minify          config2_validate_utf8   the same, validate_utf8
+    config3_amazon_ndjson     1 GiB amazon_cellphones-style NDJSON, stage 1 (+ the reference on all host threads)
+    config4_deep_nesting      1 GiB of brackets (one offset per byte)   config4_escape_heavy   backslash runs up to 64 KiB + 1
+    plugin_host_path          sjgpu_stage1 with HOST buffers (PCIe both ways): 1 GiB document, 1 MB
+                              parse_many-sized batches next to the reference's icelake kernel, sjgpu_stage1_many
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank scans its OWN 1 GiB shard (independent
+documents, SURVEY 8(e): no data-path collective), weak scaling; value = bytes all ranks scanned / max-over-ranks time;
+"config4_ndjson" / "one_document_shards" carry the NDJSON shards with the index concatenation and the one-document path.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -22,10 +34,289 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 measured copy
-KERNELS = {("stage1", "split"): ["k_stage1_summarize", "k_resolve_segments", "k_stage1_emit"],
-           ("minify", "split"): ["k_minify_summarize", "k_resolve_segments", "k_minify_emit"],
-           ("stage1", "fused"): ["k_fused<0>"], ("minify", "fused"): ["k_fused<1>"],
-           ("validate_utf8", "split"): ["k_validate_utf8"], ("validate_utf8", "fused"): ["k_validate_utf8"]}
+ALL_LEGS = ["config0_twitter_json", "config2_minify", "config2_validate_utf8", "config3_amazon_ndjson", "config4_deep_nesting",
+            "config4_escape_heavy", "plugin_host_path"]
+
+
+def position_digest_host(words):
+    """Order-sensitive digest of an index list: sum of (i + 1) * idx[i] modulo 2^64 (wraps like the int64 torch computes)."""
+    w = np.asarray(words, dtype=np.uint64)
+    return int((w * np.arange(1, len(w) + 1, dtype=np.uint64)).sum(dtype=np.uint64))
+
+
+def position_digest_device(torch, idx, count):
+    w = idx[:count].to(torch.int64) & 0xFFFFFFFF
+    return int((w * torch.arange(1, count + 1, dtype=torch.int64, device=idx.device)).sum().item()) & 0xFFFFFFFFFFFFFFFF
+
+
+def byte_digest_host(b):
+    w = np.asarray(b, dtype=np.uint64)
+    return int((w * (np.arange(1, len(w) + 1, dtype=np.uint64) | np.uint64(1))).sum(dtype=np.uint64))
+
+
+def byte_digest_device(torch, dst, count):
+    w = dst[:count].to(torch.int64)
+    return int((w * (torch.arange(1, count + 1, dtype=torch.int64, device=dst.device) | 1)).sum().item()) & 0xFFFFFFFFFFFFFFFF
+
+
+class Ctx:
+    """What every leg needs: torch, the C-ABI mirror, the corpus generators, the reference (CPU side of the comparison)."""
+
+    def __init__(self, args, torch, capi, corpus, local_rank):
+        self.args, self.torch, self.capi, self.corpus, self.local_rank = args, torch, capi, corpus, local_rank
+        self.traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            self.traffic = json.load(open(tpath))
+        self._ref = None
+
+    def cpu(self):
+        if self._ref is None:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import cpu_baseline  # test infrastructure: the CPU side of the comparison only
+            self._ref = cpu_baseline
+        return self._ref
+
+
+def make_workload(corpus, workload, size, seed):
+    gen = {"deep_nesting": corpus.deep_nesting_doc}.get(workload) or getattr(corpus, workload)
+    return gen(size, seed)
+
+
+def device_leg(cx, op, workload, host, units, steps, warmup, pipeline, fence=None, cpu_iters=None, with_cpu=True):
+    """One op over one resident buffer: K timed steps bracketed by synchronize (+ barrier), HIP-event kernel time from
+    libsjgpu, exact parity of the timed buffer's output against the reference (count AND an order-sensitive digest)."""
+    torch, capi = cx.torch, cx.capi
+    L = len(host)
+    parser = capi.DomParserImplementation(L, device=cx.local_rank)
+    parser.set_pipeline(pipeline)
+    buf = torch.from_numpy(host).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    out = None
+    if op == "stage1":
+        out = torch.empty(L + 16, dtype=torch.int32, device="cuda")
+        step = lambda: parser.stage1_device(buf.data_ptr(), L, out.data_ptr(), L + 3, stream)
+    elif op == "minify":
+        out = torch.empty(L + 64, dtype=torch.uint8, device="cuda")
+        step = lambda: parser.minify_device(buf.data_ptr(), L, out.data_ptr(), stream)
+    else:
+        step = lambda: parser.validate_utf8_device(buf.data_ptr(), L, stream)
+    sync = fence or torch.cuda.synchronize
+    for _ in range(max(warmup, 1)):
+        assert step() == 0
+    n, flags, out_len = parser.result(stream)
+    if flags & capi.F_INTERNAL:
+        raise SystemExit(f"{op}/{workload}: single-pass pipeline reported SJGPU_F_INTERNAL")
+    err = capi.stage1_error_from_flags(n, flags) if op == "stage1" else ((15 if flags & 1 else 0) if op == "minify" else (11 if flags & capi.F_UTF8_ERROR else 0))
+    if err != 0:
+        raise SystemExit(f"{op}/{workload}: error_code {err} on the synthetic buffer")
+    assert step() == 0  # AUTO has settled (size and, for stage 1, the density the warm-up scans saw)
+    parser.result(stream)
+    used = "-" if op == "validate_utf8" else parser.last_pipeline()
+    kernel = parser.profile_kernel()
+    parser.profile_enable(True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    ms_sum, calls = parser.profile_read()
+    parser.profile_enable(False)
+    gpu_ms = sum(ms_sum) / max(calls, 1)
+    alg = L + (4 * (n + 3) if op == "stage1" else (out_len if op == "minify" else 0))
+    achieved = alg / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
+    tkey = f"{op}:{workload}:{cx.args.size}:{used if used != '-' else 'fused'}"
+    leg = {
+        "value": round(L * steps / dt / 1e9, 2), "unit": "GB/s", "ms_per_step": round(dt / steps * 1e3, 4), "bytes": L, "units": units,
+        "pipeline": used, "structurals": n if op == "stage1" else None, "out_bytes": out_len if op == "minify" else None,
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "algorithmic_bytes_per_launch": alg, "gpu_ms_per_step": round(gpu_ms, 4), "kernel": kernel,
+                     "kernel_ms_slots": [round(m / max(calls, 1), 4) for m in ms_sum],
+                     "traffic": cx.traffic.get(tkey), "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this "
+                     "command, separate passes (scripts/gpu_pmc.sh); null = not collected for this workload",
+                     "timing": "hipEvent pair around everything one call enqueues (escape table, clears, scan kernels) on the launch stream, mean over the timed steps"},
+    }
+    if with_cpu:
+        cb = cx.cpu().time_cpu(host, op, cpu_iters or cx.args.cpu_iters)
+        leg["cpu_baseline"] = {"value": round(cb["value"], 3), "unit": "GB/s", "cores": cb["cores"], "kind": cb["kind"],
+                               "sample": f"the same {L}-byte buffer, {cb['impl']} kernel, 1 thread, best of {cpu_iters or cx.args.cpu_iters}"}
+        leg["parity"] = parity_check(cx, op, host, parser, n, out_len, flags, out)
+    parser.close()
+    del buf, out
+    return leg
+
+
+def parity_check(cx, op, host, parser, n, out_len, flags, out):
+    """The output of the TIMED buffer against the real reference: count, error code and an order-sensitive digest of
+    every word / byte (the exact full compare lives in tests/test_gpu_parity.py::test_full_size_*)."""
+    import ctypes
+    torch = cx.torch
+    L = len(host)
+    cpu = cx.cpu()
+    if not os.path.exists(cpu.LIB_REF):
+        return {"checked": False, "why": "oracle/_ref/libsjref.so absent"}
+    R = ctypes.CDLL(cpu.LIB_REF)
+    R.sjref_available.argtypes = [ctypes.c_char_p]
+    impl = next((i for i in (b"icelake", b"haswell", b"westmere") if R.sjref_available(i)), None)
+    if op == "stage1":
+        R.sjref_stage1.restype = ctypes.c_int
+        R.sjref_stage1.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+        ridx = np.zeros(L + 80, dtype=np.uint32)
+        rn = ctypes.c_uint32(0)
+        rerr = R.sjref_stage1(impl, host.ctypes.data, L, 0, 0, ridx.ctypes.data, ctypes.byref(rn))
+        want = position_digest_host(ridx[: rn.value + 3])
+        got = position_digest_device(torch, out, n + 3)
+        ok = rerr == 0 and rn.value == n and want == got
+        if not ok:
+            raise SystemExit(f"PARITY FAILURE stage1: n {n} vs {rn.value}, digest {got} vs {want}, reference error {rerr}")
+        return {"checked": True, "n": n, "digest_sum_i_times_idx_mod_2_64": got, "reference": impl.decode()}
+    if op == "minify":
+        R.sjref_minify.restype = ctypes.c_int
+        R.sjref_minify.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+        rout = np.zeros(L + 64, dtype=np.uint8)
+        rl = ctypes.c_size_t(0)
+        rerr = R.sjref_minify(impl, host.ctypes.data, L, rout.ctypes.data, ctypes.byref(rl))
+        want = byte_digest_host(rout[: rl.value])
+        got = byte_digest_device(torch, out, out_len)
+        if not (rerr == 0 and rl.value == out_len and want == got):
+            raise SystemExit(f"PARITY FAILURE minify: len {out_len} vs {rl.value}, digest {got} vs {want}")
+        return {"checked": True, "out_bytes": out_len, "digest": got, "reference": impl.decode()}
+    R.sjref_validate_utf8.restype = ctypes.c_int
+    R.sjref_validate_utf8.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
+    want = R.sjref_validate_utf8(impl, host.ctypes.data, L)
+    got = 0 if flags & cx.capi.F_UTF8_ERROR else 1
+    if want != got:
+        raise SystemExit("PARITY FAILURE validate_utf8")
+    return {"checked": True, "verdict": got, "reference": impl.decode()}
+
+
+def leg_twitter_json(cx):
+    """BASELINE.json configs[0]: the reference's twitter.json (fixture), plumbing + bit-exact index check."""
+    import ctypes
+    torch, capi = cx.torch, cx.capi
+    path = os.path.join(ROOT, "tests", "golden", "jsonexamples", "twitter.json")
+    host = np.fromfile(path, dtype=np.uint8)
+    L = len(host)
+    cpu = cx.cpu()
+    R = ctypes.CDLL(cpu.LIB_REF)
+    R.sjref_available.argtypes = [ctypes.c_char_p]
+    impl = next((i for i in (b"icelake", b"haswell", b"westmere") if R.sjref_available(i)), None)
+    R.sjref_stage1.restype = ctypes.c_int
+    R.sjref_stage1.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+    ridx = np.zeros(L + 80, dtype=np.uint32)
+    rn = ctypes.c_uint32(0)
+    assert R.sjref_stage1(impl, host.ctypes.data, L, 0, 0, ridx.ctypes.data, ctypes.byref(rn)) == 0
+    p = capi.DomParserImplementation(1 << 20, device=cx.local_rank)
+    err = p.stage1(host, capi.REGULAR)  # host buffers: what dom::parser drives through the plug-in
+    n = p.n_structural_indexes
+    exact = err == 0 and n == rn.value and np.array_equal(p.structural_indexes[: n + 3], ridx[: n + 3])
+    if not exact:
+        raise SystemExit(f"PARITY FAILURE twitter.json: err {err}, n {n} vs {rn.value}")
+    reps = 200
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        p.stage1(host, capi.REGULAR)
+    host_us = (time.perf_counter() - t0) / reps * 1e6
+    buf = torch.from_numpy(host).cuda()
+    idx = torch.empty(L + 16, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(5):
+        p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, stream)
+    p.result(stream)
+    kernel = p.profile_kernel()
+    p.profile_enable(True)
+    for _ in range(reps):
+        p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, stream)
+    ms, calls = p.profile_read()
+    p.profile_enable(False)
+    gpu_ms = sum(ms) / max(calls, 1)
+    dn, dflags, _ = p.result(stream)
+    assert dn == n and position_digest_device(torch, idx, n + 3) == position_digest_host(ridx[: n + 3])
+    cb = cpu.time_cpu(host, "stage1", 200)
+    alg = L + 4 * (n + 3)
+    p.close()
+    return {"workload": "tests/golden/jsonexamples/twitter.json (the reference's file, 631 515 B)", "n": n, "exact_vs_reference": True,
+            "known_answer": {"n": 55263, "matches": n == 55263},
+            "device_resident": {"gpu_us_per_call": round(gpu_ms * 1e3, 2), "value": round(L / gpu_ms / 1e6, 2), "unit": "GB/s", "kernel": kernel,
+                                "roofline": {"bound": "launch latency (10 tiles of 64 KiB)", "achieved": round(alg / gpu_ms / 1e6, 1), "peak": HBM_PEAK_GBS,
+                                             "unit": "GB/s", "frac": round(alg / gpu_ms / 1e6 / HBM_PEAK_GBS, 5)}},
+            "host_buffers": {"us_per_call": round(host_us, 1), "value": round(L / host_us / 1e3, 2), "unit": "GB/s",
+                             "note": "sjgpu_stage1: upload, scan, download, finish -- PCIe both ways, what dom::parser::parse sees"},
+            "cpu_baseline": {"value": round(cb["value"], 3), "unit": "GB/s", "cores": 1, "kind": cb["kind"],
+                             "sample": f"twitter.json, {cb['impl']} kernel, 1 thread, best of 200 ({cb['seconds'] * 1e6:.1f} us per call)"}}
+
+
+def leg_plugin_host_path(cx, host_large):
+    """the end-to-end plug-in number, PCIe included -- never `value`."""
+    import ctypes
+    capi = cx.capi
+    cpu = cx.cpu()
+    out = {}
+    L = len(host_large)
+    p = capi.DomParserImplementation(L, device=cx.local_rank)
+    p.stage1(host_large, capi.REGULAR)  # first call: workspace + the runtime pins the pages it meets
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        err = p.stage1(host_large, capi.REGULAR)
+        times.append(time.perf_counter() - t0)
+    assert err == 0
+    out["document_1GiB_pageable"] = {"ms_per_call": round(min(times) * 1e3, 2), "value": round(L / min(times) / 1e9, 2), "unit": "GB/s",
+                                     "note": "large_random through sjgpu_stage1 with ordinary host memory: overlapped upload / scan / download in 16 MiB ranges"}
+    p.close()
+    # parse_many-sized batches: 1 MB windows of NDJSON, streaming_partial, as document_stream issues them
+    nd, _ = cx.corpus.amazon_ndjson(64 << 20, 77)
+    B = 1_000_000  # dom::DEFAULT_BATCH_SIZE
+    windows = [nd[k: k + B] for k in range(0, len(nd) - B, B)][:48]
+    q = capi.DomParserImplementation(B, device=cx.local_rank)
+    for w in windows[:4]:
+        q.stage1(w, capi.STREAMING_PARTIAL)
+    t0 = time.perf_counter()
+    for w in windows:
+        q.stage1(w, capi.STREAMING_PARTIAL)
+    gpu_us = (time.perf_counter() - t0) / len(windows) * 1e6
+    q.close()
+    R = ctypes.CDLL(cpu.LIB_REF)
+    R.sjref_available.argtypes = [ctypes.c_char_p]
+    impl = next((i for i in (b"icelake", b"haswell", b"westmere") if R.sjref_available(i)), None)
+    R.sjref_parser_create.restype = ctypes.c_void_p
+    R.sjref_parser_create.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    R.sjref_parser_stage1.restype = ctypes.c_int
+    R.sjref_parser_stage1.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    R.sjref_parser_destroy.argtypes = [ctypes.c_void_p]
+    h = R.sjref_parser_create(impl, B)
+    nn = ctypes.c_uint32(0)
+    for w in windows[:4]:
+        R.sjref_parser_stage1(h, w.ctypes.data, len(w), 1, None, ctypes.byref(nn), None)
+    t0 = time.perf_counter()
+    for w in windows:
+        R.sjref_parser_stage1(h, w.ctypes.data, len(w), 1, None, ctypes.byref(nn), None)
+    cpu_us = (time.perf_counter() - t0) / len(windows) * 1e6
+    R.sjref_parser_destroy(h)
+    out["parse_many_window_1MB"] = {"mi355x_us_per_window": round(gpu_us, 1), "reference_us_per_window": round(cpu_us, 1), "reference_kernel": impl.decode(),
+                                    "mi355x_GBps": round(B / gpu_us / 1e3, 2), "reference_GBps": round(B / cpu_us / 1e3, 2),
+                                    "note": "sjgpu_stage1(streaming_partial) per 1 000 000-byte window of amazon NDJSON (dom::DEFAULT_BATCH_SIZE), host buffers, "
+                                            "next to the reference's stage1 on one host thread; document_stream hides either behind stage 2 of the previous window"}
+    # many small documents per launch
+    lines = [bytes(l) for l in bytes(nd[: 4 << 20]).split(b"\n") if l][:8192]
+    r = capi.DomParserImplementation(1 << 20, device=cx.local_rank)
+    r.stage1_many(lines[:64])
+    t0 = time.perf_counter()
+    res = r.stage1_many(lines)
+    dt_many = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for l in lines[:512]:
+        r.stage1(l, capi.REGULAR)
+    dt_single = (time.perf_counter() - t0) / 512
+    r.close()
+    assert all(e == 0 for e, _, _ in res)
+    nbytes = sum(len(l) for l in lines)
+    out["small_documents"] = {"documents": len(lines), "mean_bytes": round(nbytes / len(lines), 1),
+                              "one_launch_us_per_document": round(dt_many / len(lines) * 1e6, 3), "one_launch_GBps": round(nbytes / dt_many / 1e9, 3),
+                              "one_call_each_us_per_document": round(dt_single * 1e6, 2),
+                              "note": "sjgpu_stage1_many (one workgroup per document, one launch, incl. the Python-side marshalling) vs sjgpu_stage1 per document"}
+    return out
 
 
 def main():
@@ -37,8 +328,9 @@ def main():
     ap.add_argument("--workload", default="large_random", choices=["large_random", "amazon_ndjson", "twitter_like", "deep_nesting", "escape_heavy"])
     ap.add_argument("--size", type=int, default=1 << 30, help="bytes per GPU")
     ap.add_argument("--pipeline", default=os.environ.get("SJGPU_PIPELINE", "auto"), choices=["auto", "fused", "split"])
-    ap.add_argument("--ndjson-leg", type=int, default=-1, help="1: also time config 4 (amazon NDJSON shard per GPU, "
-                    "with and without the RCCL index concatenation); default: on when --gpus > 1")
+    ap.add_argument("--legs", default="all", help="N = 1: which of the other BASELINE configs to measure into the same line: all | none | comma list of "
+                    + ",".join(ALL_LEGS))
+    ap.add_argument("--ndjson-leg", type=int, default=-1, help="N > 1: 0 switches the NDJSON / one-document legs off")
     ap.add_argument("--cpu-iters", type=int, default=12)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--share-device", action="store_true", help="dry run: every rank uses cuda:0 (needs --backend gloo)")
@@ -69,26 +361,7 @@ def main():
         build.build_sjgpu()
     if world > 1:
         dist.barrier()
-
-    # ---- workload: one synthetic buffer per rank, resident in HBM before anything is timed ----
-    gen = {"deep_nesting": corpus.deep_nesting_doc}.get(args.workload) or getattr(corpus, args.workload)
-    host, units = gen(args.size, 1000 + rank)
-    L = len(host)
-    parser = capi.DomParserImplementation(L, device=local_rank)
-    parser.set_pipeline(args.pipeline)
-    auto = args.pipeline == "auto"
-    args.requested_pipeline = args.pipeline
-    buf = torch.from_numpy(host).cuda()
-    stream = torch.cuda.current_stream().cuda_stream
-    if args.op == "stage1":
-        out = torch.empty(L + 3, dtype=torch.int32, device="cuda")
-        step = lambda: parser.stage1_device(buf.data_ptr(), L, out.data_ptr(), L + 3, stream)
-    elif args.op == "minify":
-        out = torch.empty(L + 16, dtype=torch.uint8, device="cuda")
-        step = lambda: parser.minify_device(buf.data_ptr(), L, out.data_ptr(), stream)
-    else:
-        out = None
-        step = lambda: parser.validate_utf8_device(buf.data_ptr(), L, stream)
+    cx = Ctx(args, torch, capi, corpus, local_rank)
 
     def fence():
         torch.cuda.synchronize()
@@ -96,31 +369,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        assert step() == 0
-    n, flags, out_len = parser.result(stream)
-    err = capi.stage1_error_from_flags(n, flags) if args.op == "stage1" else (15 if flags & 1 else 0)
-    if args.op == "validate_utf8":
-        err = 11 if flags & capi.F_UTF8_ERROR else 0
-    if flags & capi.F_INTERNAL:
-        raise SystemExit(f"rank {rank}: single-pass pipeline reported SJGPU_F_INTERNAL")
-    if err != 0:
-        raise SystemExit(f"rank {rank}: {args.op} returned error_code {err} on the synthetic buffer")
-
-    if auto:  # what AUTO settled on after the warm-up scans (size and, for stage 1, the density it saw)
-        assert step() == 0
-        parser.result(stream)
-        args.pipeline = "fused" if args.op == "validate_utf8" else parser.last_pipeline()
-    parser.profile_enable(True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    ms_sum, calls = parser.profile_read()
-    parser.profile_enable(False)
-
+    # ---- the headline: one synthetic buffer per rank, resident in HBM before anything is timed ----
+    host, units = make_workload(corpus, args.workload, args.size, 1000 + rank)
+    L = len(host)
+    with_cpu = world == 1 and not args.no_cpu_baseline
+    leg = device_leg(cx, args.op, args.workload, host, units, args.steps, args.warmup, args.pipeline, fence=fence, with_cpu=with_cpu)
+    dt = leg["ms_per_step"] * 1e-3 * args.steps
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -130,64 +384,74 @@ def main():
         total_bytes = float(tot.item())
     else:
         total_bytes = float(L)
-
+    line = None
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        value = total_bytes * args.steps / dt / 1e9
-        # roofline: algorithmic bytes per launch over the GPU time of the kernels of one
-        # step, measured with HIP events on the launch stream inside the timed region
-        if args.op == "stage1":
-            alg = L + 4 * (n + 3)
-        elif args.op == "minify":
-            alg = L + out_len
-        else:
-            alg = L
-        knames = KERNELS[(args.op, args.pipeline)]
-        if args.pipeline == "fused" and args.op != "validate_utf8":  # which single-pass kernel this size gets (sjgpu_fused.hip)
-            knames = [("k_fused_pipelined" if L > (8 << 20) else "k_fused_16KiB_tiles") + ("<0>" if args.op == "stage1" else "<1>")]
-        kms = [m / max(calls, 1) for m in ms_sum][: len(knames)]
-        gpu_ms = sum(kms)
-        achieved = alg / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(f"{args.op}:{args.workload}:{args.size}:{args.pipeline}")
         line = {
             "metric": "stage1 GB/s (structural indexing)" if args.op == "stage1" else f"{args.op} GB/s",
-            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": round(total_bytes * args.steps / dt / 1e9, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.workload} {L} B per GPU (seed 1000+rank), op={args.op}, regular mode, "
-                                   f"device-resident input and output, {args.pipeline} pipeline", "bytes_per_gpu": L, "units_per_gpu": units,
-                       "structurals": n if args.op == "stage1" else None, "out_bytes": out_len if args.op == "minify" else None,
-                       "parallelism": f"{world} independent shard(s), one rank per GPU, no data-path collective",
+            "config": {"workload": f"{args.workload} {L} B per GPU (seed 1000+rank), op={args.op}, regular mode, device-resident input and output, "
+                                   f"{leg['pipeline']} pipeline", "bytes_per_gpu": L, "units_per_gpu": units, "structurals": leg["structurals"],
+                       "out_bytes": leg["out_bytes"], "parallelism": f"{world} independent shard(s), one rank per GPU, no data-path collective",
                        "library": os.path.basename(capi._paths.LIB_SJGPU)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg, "gpu_ms_per_step": round(gpu_ms, 4),
-                         "kernels_ms": dict(zip(knames, [round(x, 4) for x in kms])),
-                         "timing": "hipEvent pairs around each kernel on the launch stream, averaged over the timed steps"},
+            "roofline": leg["roofline"],
         }
-        if world == 1 and not args.no_cpu_baseline:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import cpu_baseline  # test infrastructure: the CPU side of the comparison only
-            cb = cpu_baseline.time_cpu(host, args.op, args.cpu_iters)
-            if args.op == "stage1" and cb["n"] is not None and cb["n"] != n:
-                raise SystemExit(f"PARITY FAILURE: GPU n={n} vs CPU reference n={cb['n']}")
-            line["cpu_baseline"] = {"value": round(cb["value"], 3), "unit": "GB/s", "cores": cb["cores"], "kind": cb["kind"],
-                                    "sample": f"the same {L}-byte buffer, {cb['impl']} kernel, 1 thread, best of {args.cpu_iters}"}
-    # ---- optional second leg: BASELINE.json config 4 (parse_many-style NDJSON shards, RCCL concatenation) ----
-    ndjson = None
-    if (args.ndjson_leg == 1 or (args.ndjson_leg < 0 and world > 1)) and args.op == "stage1":
+        for k in ("cpu_baseline", "parity"):
+            if k in leg:
+                line[k] = leg[k]
+
+    # ---- N = 1: the other BASELINE configs, same method, into the same line ----
+    if world == 1 and args.op == "stage1" and args.workload == "large_random" and args.legs != "none":
+        wanted = ALL_LEGS if args.legs == "all" else [x for x in args.legs.split(",") if x]
+        legs = {}
+        sub_steps, sub_warm = max(5, args.steps // 2), 2
+
+        def guarded(name, fn):
+            if name not in wanted:
+                return
+            try:
+                legs[name] = fn()
+            except SystemExit:
+                raise  # parity failures must fail the bench
+            except Exception as e:  # an infrastructure hiccup in one leg must not cost the headline line
+                legs[name] = {"error": repr(e)[:300]}
+
+        guarded("config0_twitter_json", lambda: leg_twitter_json(cx))
+        guarded("config2_minify", lambda: device_leg(cx, "minify", "large_random", host, units, sub_steps, sub_warm, args.pipeline, with_cpu=with_cpu))
+        guarded("config2_validate_utf8", lambda: device_leg(cx, "validate_utf8", "large_random", host, units, sub_steps, sub_warm, args.pipeline, with_cpu=with_cpu))
+        guarded("plugin_host_path", lambda: leg_plugin_host_path(cx, host))
+        del host
+
+        def ndjson():
+            h, u = make_workload(corpus, "amazon_ndjson", args.size, 2000)
+            out = device_leg(cx, "stage1", "amazon_ndjson", h, u, sub_steps, sub_warm, args.pipeline, with_cpu=with_cpu)
+            if with_cpu:  # the same NDJSON on T independent host threads, one reference parser each
+                threads = os.cpu_count() or 1
+                cb = cx.cpu().time_cpu_ndjson_threads(h, threads, 3)
+                if cb is not None:
+                    out["cpu_baseline_threads"] = {"value": round(cb["value"], 2), "unit": "GB/s", "cores": cb["cores"], "kind": cb["kind"],
+                                                   "sample": f"the same NDJSON buffer cut at newlines into {cb['cores']} slices, {cb['impl']} kernel, one parser per thread, "
+                                                             f"{threads} hardware threads on the box", "structurals": cb["n"]}
+            return out
+
+        guarded("config3_amazon_ndjson", ndjson)
+        for wl in ("deep_nesting", "escape_heavy"):
+            def adversarial(wl=wl):
+                h, u = make_workload(corpus, wl, args.size, 1000)
+                return device_leg(cx, "stage1", wl, h, u, sub_steps, sub_warm, args.pipeline, with_cpu=with_cpu, cpu_iters=4)
+            guarded(f"config4_{wl}", adversarial)
+        line["legs"] = legs
+
+    # ---- N > 1: BASELINE.json config 4 (parse_many-style NDJSON shards, RCCL concatenation) and the one-document path ----
+    ndjson = docshards = None
+    if world > 1 and args.op == "stage1" and args.ndjson_leg != 0:
         try:
             ndjson = ndjson_leg(args, torch, dist, corpus, capi, rank, world, local_rank, fence)
         except Exception as e:  # the primary line must survive a failure here
             ndjson = {"error": repr(e)[:300]}
-    # ---- optional third leg (N > 1 only): ONE document cut into one shard per GPU (general inputs) ----
-    docshards = None
-    if world > 1 and args.op == "stage1" and args.ndjson_leg != 0:
         try:
-            docshards = document_leg(args, torch, dist, capi, rank, world, buf, L, out, fence)
+            docshards = document_leg(args, torch, dist, capi, corpus, rank, world, local_rank, fence)
         except Exception as e:
             docshards = {"error": repr(e)[:300]}
     if rank == 0:
@@ -199,15 +463,18 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    parser.close()
 
 
-def document_leg(args, torch, dist, capi, rank, world, buf, L, idx, fence):
+def document_leg(args, torch, dist, capi, corpus, rank, world, local_rank, fence):
     """Every rank's resident buffer taken as its shard of ONE document of world x --size bytes (the large_random
     buffers end in a newline, so the cuts between them are clean cuts): string-parity pre-pass, all_gather of one
     integer per rank, shard scan with the carried in-string bit (include/sjgpu.h, "one large document sharded
     across GPUs").  Timed like the primary leg: barrier + synchronize, MAX over ranks."""
     import time as _t
+    host, _ = corpus.large_random(args.size, 1000 + rank)
+    L = len(host)
+    buf = torch.from_numpy(host).cuda()
+    idx = torch.empty(L + 16, dtype=torch.int32, device="cuda")
     dev = buf.device
     parser = capi.DomParserImplementation(L, device=dev.index or 0)
     stream = torch.cuda.current_stream().cuda_stream
@@ -244,16 +511,16 @@ def document_leg(args, torch, dist, capi, rank, world, buf, L, idx, fence):
 
 def ndjson_leg(args, torch, dist, corpus, capi, rank, world, local_rank, fence):
     """amazon_cellphones-style NDJSON, one newline-aligned shard of --size bytes per GPU (weak scaling):
-    per-rank stage 1 with zero carry-in; then the same plus the all_gather that concatenates the index
+    per-rank stage 1 with zero carry-in; then the same plus the gather that concatenates the index
     arrays into global 64-bit positions (simdjson_amd.sharded)."""
     import time as _t
     from simdjson_amd import sharded
     host, lines = corpus.amazon_ndjson(args.size, 2000 + rank)  # each rank's slice of the stream (ends in '\n')
     L = len(host)
     scanner = sharded.GpuShardScanner(L, local_rank)
-    scanner.parser.set_pipeline(args.requested_pipeline)  # AUTO learns the density from the warm-up scans
+    scanner.parser.set_pipeline(args.pipeline)  # AUTO learns the density from the warm-up scans
     buf = torch.from_numpy(host).cuda()
-    idx = torch.empty(L + 3, dtype=torch.int32, device="cuda")
+    idx = torch.empty(L + 16, dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     step = lambda: scanner.parser.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, stream)
     for _ in range(2):
@@ -268,46 +535,34 @@ def ndjson_leg(args, torch, dist, corpus, capi, rank, world, local_rank, fence):
     dt_scan = _t.perf_counter() - t0
     out = {"workload": f"amazon_ndjson {L} B per GPU, newline-aligned shards, zero carry-in", "structurals_rank0": n,
            "lines_rank0": lines, "flags_rank0": flags}
-    if world > 1:
-        base = torch.tensor([L], dtype=torch.int64, device="cuda")
-        sizes = [torch.empty_like(base) for _ in range(world)]
-        dist.all_gather(sizes, base)
-        my_base = sum(int(x) for x in sizes[:rank])
-        local = sharded.ShardScan(my_base, L, n, flags, idx)
-        sharded.gather_global_indices(local)  # warm the communicator
-        fence()
-        t0 = _t.perf_counter()
-        for _ in range(steps):
-            step()
-            n2, f2, _ = scanner.parser.result(stream)
-            pos, counts, _ = sharded.gather_global_indices(sharded.ShardScan(my_base, L, n2, f2, idx))
-        fence()
-        dt_cat = _t.perf_counter() - t0
-        t = torch.tensor([dt_scan, dt_cat], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_scan, dt_cat = float(t[0]), float(t[1])
-        tot = torch.tensor([float(L)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tot)
-        total = float(tot)
-        out["with_index_concat_GBps"] = round(total * steps / dt_cat / 1e9, 2)
+    base = torch.tensor([L], dtype=torch.int64, device="cuda")
+    sizes = [torch.empty_like(base) for _ in range(world)]
+    dist.all_gather(sizes, base)
+    my_base = sum(int(x) for x in sizes[:rank])
+    local = sharded.ShardScan(my_base, L, n, flags, idx)
+    sharded.gather_to_root(local)  # warm the communicator
+    fence()
+    t0 = _t.perf_counter()
+    for _ in range(steps):
+        step()
+        n2, f2, _ = scanner.parser.result(stream)
+        pos, counts = sharded.gather_to_root(sharded.ShardScan(my_base, L, n2, f2, idx))
+    fence()
+    dt_cat = _t.perf_counter() - t0
+    t = torch.tensor([dt_scan, dt_cat], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_scan, dt_cat = float(t[0]), float(t[1])
+    tot = torch.tensor([float(L)], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tot)
+    total = float(tot)
+    out["with_index_concat_GBps"] = round(total * steps / dt_cat / 1e9, 2)
+    out["index_concat"] = "variable-length gather to rank 0: all_gather of the counts, then each rank sends exactly its n offsets (64-bit global positions)"
+    if rank == 0:
         out["total_structurals"] = int(sum(counts))
-        out["sorted_global_positions"] = bool((pos[1:] > pos[:-1]).all())
-    else:
-        total = float(L)
+        out["sorted_global_positions"] = bool((pos[1:] > pos[:-1]).all()) if len(pos) > 1 else True
     out["value_GBps"] = round(total * steps / dt_scan / 1e9, 2)
     out["steps"] = steps
     scanner.parser.close()
-    if world == 1 and not args.no_cpu_baseline:
-        # the same NDJSON on T independent host threads, each with its own reference parser
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import cpu_baseline
-        threads = os.cpu_count() or 1
-        cb = cpu_baseline.time_cpu_ndjson_threads(host, threads, max(2, args.cpu_iters // 4))
-        if cb is not None:
-            out["cpu_baseline_threads"] = {"value": round(cb["value"], 2), "unit": "GB/s", "cores": cb["cores"], "kind": cb["kind"],
-                                           "sample": f"the same {L}-byte NDJSON buffer cut at newlines into {cb['cores']} slices, "
-                                                     f"{cb['impl']} kernel, one parser per thread, {threads} hardware threads on the box",
-                                           "structurals": cb["n"]}
     return out
 
 

@@ -161,6 +161,43 @@ int sjgpu_stage1_finish_host(const uint8_t *buf, size_t len, int mode, uint32_t 
 size_t sjgpu_trim_partial_utf8(const uint8_t *buf, size_t len);
 
 
+/* ---- many small documents in one launch ---------------------------------------------------------------------------
+ * The reference scans one document per stage1() call (dom::parser::parse, ondemand::parser::iterate); a caller with a
+ * batch of small documents (log lines, API payloads, one NDJSON record each) pays a launch and a PCIe round trip per
+ * document that way.  sjgpu_stage1_many scans them all in ONE launch, one workgroup per document (regular mode): the
+ * documents are gathered into one page-locked block, the kernel reads and writes that block across PCIe (blocks beyond
+ * 2 MiB are staged through HBM with one copy each way), and every document gets its own error code, n and list --
+ * exactly what sjgpu_stage1(..., SJGPU_REGULAR, ...) would have produced for it.  Documents of up to a few hundred KiB;
+ * longer ones belong to sjgpu_stage1.  sjgpu_stage1 itself takes the same one-workgroup kernel for documents up to
+ * 64 KiB (one launch, one wait, no device-side staging; SJGPU_SMALL_DOCS=0 turns that off). */
+typedef struct sjgpu_doc {
+  const uint8_t *buf;  /* in: the document */
+  size_t len;
+  uint32_t *idx_out;   /* in: room for len + 3 words; out: idx[0..n+2] */
+  size_t idx_words;
+  uint32_t n;          /* out: n_structural_indexes (0 when error is UNCLOSED_STRING / UNESCAPED_CHARS / EMPTY / CAPACITY) */
+  int error;           /* out: simdjson::error_code of this document */
+} sjgpu_doc;
+int sjgpu_stage1_many(sjgpu_ctx *ctx, sjgpu_doc *docs, size_t count);
+
+/* ---- the structural list after the scan, on the device -------------------------------------------------------------
+ * sjgpu_stage1_finish_device: finish() of a streaming mode (json_structural_indexer.h:295-394 with
+ * find_next_document_index.h:39-369) for a list that lives in HBM: idx_dev[0..n_raw) are the raw structurals of
+ * buf_dev[0..len) as sjgpu_stage1_device left them (sentinels behind them), flags the scan's flags; len is the length
+ * after sjgpu_trim_partial_utf8.  Record separators / root commas are filtered out of idx_dev in place, the last complete
+ * document is found with a reduction and a bracket balance instead of the reference's backward walk, and idx_dev ends up
+ * holding exactly the words sjgpu_stage1() would have delivered (idx[0 .. *n_io + 2]).  Returns the error_code of the
+ * mode (SUCCESS, EMPTY, CAPACITY, UTF8_ERROR, UNESCAPED_CHARS); *next_start_out = where the next batch begins for the
+ * partial json_sequence / comma_delimited modes.  Waits for the stream (it reads one small state back).
+ * sjgpu_stage1() uses the same kernels for streaming-mode documents beyond the small-document path (SJGPU_FINISH=host
+ * keeps the host walk of stage1_finish.cpp, =device forces the device path).
+ * sjgpu_depth_scan_device: depth_dev[i] (int32, n + 1 entries) = number of containers open in front of structural i --
+ * the `depth` the reference's stage 2 carries while it walks the list (src/generic/stage2/json_iterator.h), as a
+ * bracket prefix scan; depth_dev[n] = depth behind the last structural (0 for a balanced document).  Asynchronous. */
+int sjgpu_stage1_finish_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, int mode, void *idx_dev, uint32_t n_raw,
+                               uint32_t flags, void *stream, uint32_t *n_io, uint32_t *next_start_out);
+int sjgpu_depth_scan_device(sjgpu_ctx *ctx, const void *buf_dev, const void *idx_dev, uint32_t n, void *depth_dev, void *stream);
+
 /* ---- one large document sharded across GPUs ("general inputs") -------------------------
  * The reference has no counterpart: its stage 1 is one serial pass whose carries (json_escape_scanner.h:50-71
  * next_is_escaped, json_string_scanner.h:62-85 prev_in_string, json_scanner.h:128-157 prev_scalar,

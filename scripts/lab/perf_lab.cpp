@@ -78,6 +78,7 @@ int main(int argc, char **argv) {
   std::vector<int> pipelines = {SJGPU_PIPELINE_FUSED, SJGPU_PIPELINE_SPLIT};
   int reps = 10;
   bool check = true, trace = false;
+  int stress = 0;
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
     if (a == "--size" && i + 1 < argc) { target = std::strtoull(argv[++i], nullptr, 10); }
@@ -88,6 +89,7 @@ int main(int argc, char **argv) {
     else if (a == "--reps" && i + 1 < argc) { reps = std::atoi(argv[++i]); }
     else if (a == "--no-check") { check = false; }
     else if (a == "--trace") { trace = true; }
+    else if (a == "--stress" && i + 1 < argc) { stress = std::atoi(argv[++i]); }
   }
   const char *impl = sjref_available("icelake") ? "icelake" : "haswell";
   sjgpu_ctx *ctx = nullptr;
@@ -155,6 +157,33 @@ int main(int argc, char **argv) {
           return sjgpu_validate_utf8_device(ctx, d_buf, L, nullptr);
         };
         sjgpu_scan_result res{};
+        if (stress && check && op != "validate_utf8") { // every repetition compared in full: is the kernel deterministic?
+          int bad = 0;
+          for (int r = 0; r < stress; r++) {
+            rc = call();
+            sjgpu_result(ctx, nullptr, &res);
+            bool ok = rc == 0;
+            if (ok && op == "stage1") {
+              ok = res.n == ref_n && (res.flags & ~SJGPU_F_UTF8_ERROR) == 0;
+              if (ok) {
+                got_idx.resize(size_t(res.n) + 3);
+                CK(hipMemcpy(got_idx.data(), d_idx, got_idx.size() * 4, hipMemcpyDeviceToHost));
+                ok = std::memcmp(got_idx.data(), ref_idx.data(), got_idx.size() * 4) == 0;
+              }
+            } else if (ok) {
+              ok = res.out_len == ref_mlen && res.flags == 0;
+              if (ok) {
+                got_out.resize(res.out_len);
+                CK(hipMemcpy(got_out.data(), d_out, res.out_len, hipMemcpyDeviceToHost));
+                ok = std::memcmp(got_out.data(), ref_out.data(), res.out_len) == 0;
+              }
+            }
+            if (!ok) { bad++; std::printf("  stress %s %s rep %d: MISMATCH n %u out_len %llu flags %u\n", kind.c_str(), op.c_str(), r, res.n, (unsigned long long)res.out_len, res.flags); }
+          }
+          std::printf("%-18s %-14s %-6s stress: %d of %d repetitions wrong\n", kind.c_str(), op.c_str(), pl == SJGPU_PIPELINE_FUSED ? "fused" : "split", bad, stress);
+          failures += bad;
+          continue;
+        }
         for (int w = 0; w < 2; w++) { rc = call(); sjgpu_result(ctx, nullptr, &res); }
         if (rc != 0) { std::printf("%-18s %-14s call failed: %d (%s)\n", kind.c_str(), op.c_str(), rc, sjgpu_last_error(ctx)); failures++; continue; }
         const int used = sjgpu_last_pipeline(ctx);
@@ -194,7 +223,7 @@ int main(int argc, char **argv) {
               CK(hipMemcpy(got_out.data(), d_out, res.out_len, hipMemcpyDeviceToHost));
               ok = std::memcmp(got_out.data(), ref_out.data(), res.out_len) == 0;
             }
-            verdict = ok ? "exact (" + std::to_string(res.out_len) + " bytes)" : "MISMATCH: len " + std::to_string(res.out_len) + " vs " + std::to_string(ref_mlen);
+            verdict = ok ? "exact (" + std::to_string(res.out_len) + " bytes)" : "MISMATCH: len " + std::to_string(res.out_len) + " vs " + std::to_string(ref_mlen) + ", flags " + std::to_string(res.flags);
             if (!ok) { failures++; }
           }
         } else if (check) {

@@ -332,7 +332,7 @@ int main(int argc, char **argv) {
     time("G0 loads + transposition", [&] { hipLaunchKernelGGL((k_lane_math<0>), dim3(nseg), dim3(64), 0, nullptr, buf, u64(L), mask0, nseg); });
     time("G1 loads + transposition + classify", [&] { hipLaunchKernelGGL((k_lane_math<1>), dim3(nseg), dim3(64), 0, nullptr, buf, u64(L), mask0, nseg); });
     time("G2 loads + transposition + classify + per-lane string algebra", [&] { hipLaunchKernelGGL((k_lane_math<2>), dim3(nseg), dim3(64), 0, nullptr, buf, u64(L), mask0, nseg); });
-    time("H  k_validate_utf8 (product)", [&] { hipLaunchKernelGGL(k_validate_utf8, dim3(8192), dim3(64), 0, nullptr, buf, u64(L), reinterpret_cast<scan_result_dev *>(summ)); });
+    time("H  k_validate_utf8 (product)", [&] { hipLaunchKernelGGL(k_validate_utf8, dim3(8192), dim3(64), 0, nullptr, buf, u64(L), reinterpret_cast<scan_result_dev *>(summ), u64(0), 0u); });
   }
   return 0;
 }

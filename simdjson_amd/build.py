@@ -52,7 +52,7 @@ def build_corpus(force=False):
 
 def build_sjgpu(force=False):
     out = os.path.join(_paths.LIB_DIR, "libsjgpu.so")  # always the in-tree default, never an SJGPU_LIB override
-    srcs = _csrc("sjgpu_kernels.hip", "sjgpu_fused.hip", "sjgpu_capi.hip", "stage1_finish.cpp")
+    srcs = _csrc("sjgpu_kernels.hip", "sjgpu_fused.hip", "sjgpu_small.hip", "sjgpu_finish.hip", "sjgpu_capi.hip", "stage1_finish.cpp")
     deps = srcs + _csrc("sj_block.h", "sjgpu_internal.h", "sjgpu_device.h") + [os.path.join(_paths.INCLUDE_DIR, "sjgpu.h")]
     if force or _stale(out, deps):
         os.makedirs(_paths.LIB_DIR, exist_ok=True)
@@ -83,7 +83,7 @@ _RPATH = "-Wl,-rpath,$ORIGIN/../../simdjson_amd/lib"
 def _stamp_sources():
     """Everything of OURS a prebuilt test binary embeds (libsjgpu.so / the plug-in .so are linked dynamically)."""
     plug = os.path.join(_paths.REPO_ROOT, "tests", "plugin")
-    files = [os.path.join(_paths.INCLUDE_DIR, "sjgpu.h"), *_csrc("plugin/mi355x_implementation.h")]
+    files = [os.path.join(_paths.INCLUDE_DIR, "sjgpu.h"), *_csrc("plugin/mi355x_implementation.h", "plugin/intree/simdjson_mi355x.patch")]
     files += sorted(os.path.join(plug, f) for f in os.listdir(plug) if f.endswith((".cpp", ".h")))
     return files
 
@@ -166,6 +166,49 @@ def build_reference_tests(force=False):
     return built
 
 
+INTREE_DIR = os.path.join(_paths.REPO_ROOT, "build", "intree")
+INTREE_PATCH = os.path.join(_paths.CSRC_DIR, "plugin", "intree", "simdjson_mi355x.patch")
+INTREE_TESTS = {"intree_basictests": "tests/dom/basictests.cpp", "intree_errortests": "tests/dom/errortests.cpp"}
+
+
+def build_intree(force=False):
+    """In-tree registration: a SCRATCH copy of the reference's src/ and include/ under build/intree/
+    (git-ignored, never committed) gets simdjson_mi355x.patch -- an `mi355x` entry in the compile-time kernel list of
+    src/implementation.cpp -- and is compiled with -DSIMDJSON_IMPLEMENTATION_MI355X=1; the reference's own basictests /
+    errortests are then built against THAT library, so `-a mi355x` and SIMDJSON_FORCE_IMPLEMENTATION=mi355x select the
+    backend by name, without any activation code in the program.  Outputs build/tests/intree_*."""
+    ref = _paths.REFERENCE_DIR
+    if not (os.path.exists(os.path.join(ref, "src", "simdjson.cpp")) and os.path.exists(_paths.LIB_PLUGIN)):
+        return [os.path.join(TEST_BIN_DIR, n) for n in INTREE_TESTS if os.path.exists(os.path.join(TEST_BIN_DIR, n))]
+    tree = os.path.join(INTREE_DIR, "simdjson")
+    obj = os.path.join(INTREE_DIR, "simdjson_mi355x.o")
+    if force or _stale(obj, [INTREE_PATCH, os.path.join(ref, "src", "implementation.cpp")]):
+        shutil.rmtree(tree, ignore_errors=True)
+        os.makedirs(tree, exist_ok=True)
+        for sub in ("src", "include"):
+            shutil.copytree(os.path.join(ref, sub), os.path.join(tree, sub))
+        for dirpath, _, files in os.walk(tree):  # the reference tree is read-only; the scratch copy must not be
+            os.chmod(dirpath, 0o755)
+            for f in files:
+                os.chmod(os.path.join(dirpath, f), 0o644)
+        _run(["patch", "-p1", "-s", "-i", INTREE_PATCH], cwd=tree)
+        _run(["g++", "-O2", "-std=c++17", "-DSIMDJSON_THREADS_ENABLED=1", "-DSIMDJSON_IMPLEMENTATION_MI355X=1", "-I", os.path.join(tree, "include"),
+              "-I", os.path.join(tree, "src"), "-c", os.path.join(tree, "src", "simdjson.cpp"), "-o", obj])
+    built = []
+    for name, rel in INTREE_TESTS.items():
+        out = os.path.join(TEST_BIN_DIR, name)
+        src = os.path.join(ref, rel)
+        if force or not binary_is_current(name) or _stale(out, [src, obj, _paths.LIB_PLUGIN]):
+            os.makedirs(TEST_BIN_DIR, exist_ok=True)
+            _run(["g++", "-O1", "-std=c++17", "-w", "-DSIMDJSON_THREADS_ENABLED=1", "-DSIMDJSON_IMPLEMENTATION_MI355X=1", "-I", os.path.join(tree, "include"),
+                  "-I", os.path.join(ref, "tests"), "-I", os.path.join(ref, "tests", "dom"),
+                  '-DSIMDJSON_BENCHMARK_DATA_DIR="/root/repo/tests/golden/jsonexamples/"', src, obj, "-o", out,
+                  f"-L{_paths.LIB_DIR}", "-lsimdjson_mi355x", "-lsjgpu", "-lpthread", _RPATH])
+            _write_stamp(name)
+        built.append(out)
+    return built
+
+
 def build_oracle():
     _run(["make", "-s", "-C", _paths.ORACLE_DIR, f"REFERENCE={_paths.REFERENCE_DIR}"])
 
@@ -177,6 +220,7 @@ def build_all(force=False):
     build_plugin(force)
     build_plugin_test(force)
     build_reference_tests(force)
+    build_intree(force)
 
 
 if __name__ == "__main__":

@@ -28,12 +28,19 @@ EXPORTS = [
     "sjgpu_clean_cut", "sjgpu_string_parity_device", "sjgpu_stage1_shard_device", "sjgpu_minify_shard_device",
     "sjgpu_stage1_range_device", "sjgpu_minify_range_device",
     "sjgpu_host_alloc", "sjgpu_host_free", "sjgpu_host_register", "sjgpu_host_unregister", "sjgpu_last_pipeline",
-    "sjgpu_profile_kernel", "sjgpu_debug_trace_pipelined",
+    "sjgpu_profile_kernel", "sjgpu_debug_trace_pipelined", "sjgpu_stage1_many", "sjgpu_stage1_finish_device",
+    "sjgpu_depth_scan_device",
 ]
 
 
 class SjgpuError(RuntimeError):
     pass
+
+
+class Doc(ctypes.Structure):
+    """sjgpu_doc (include/sjgpu.h): one document of a sjgpu_stage1_many batch."""
+    _fields_ = [("buf", ctypes.c_void_p), ("len", ctypes.c_size_t), ("idx_out", ctypes.c_void_p), ("idx_words", ctypes.c_size_t),
+                ("n", ctypes.c_uint32), ("error", ctypes.c_int)]
 
 
 class ScanResult(ctypes.Structure):
@@ -96,6 +103,12 @@ def load_library():
     L.sjgpu_debug_trace_stage1.argtypes = [vp, vp, sz, vp, sz, vp, ctypes.c_uint32]
     L.sjgpu_debug_trace_pipelined.restype = ctypes.c_int
     L.sjgpu_debug_trace_pipelined.argtypes = [vp, vp, sz, vp, sz, vp, ctypes.c_uint32, u32p]
+    L.sjgpu_stage1_many.restype = ctypes.c_int
+    L.sjgpu_stage1_many.argtypes = [vp, ctypes.POINTER(Doc), sz]
+    L.sjgpu_stage1_finish_device.restype = ctypes.c_int
+    L.sjgpu_stage1_finish_device.argtypes = [vp, vp, sz, ctypes.c_int, vp, ctypes.c_uint32, ctypes.c_uint32, vp, u32p, u32p]
+    L.sjgpu_depth_scan_device.restype = ctypes.c_int
+    L.sjgpu_depth_scan_device.argtypes = [vp, vp, vp, ctypes.c_uint32, vp, vp]
     L.sjgpu_set_pipeline.restype = ctypes.c_int
     L.sjgpu_set_pipeline.argtypes = [vp, ctypes.c_int]
     L.sjgpu_profile_enable.restype = ctypes.c_int
@@ -259,6 +272,35 @@ class DomParserImplementation:
                                               dst_ptr, stream or None)
         if rc != 0:
             raise SjgpuError(f"sjgpu_minify_range_device error {rc}: {self.last_error()}")
+
+    # ---- many small documents in one launch (sjgpu.h, "many small documents in one launch") ----
+    def stage1_many(self, documents):
+        """documents: list of bytes-like.  -> list of (error_code, n, idx[0..n+2]) as stage1(doc, REGULAR) would give."""
+        arrays = [_as_u8(d) for d in documents]
+        outs = [np.zeros(len(a) + 3, dtype=np.uint32) for a in arrays]
+        docs = (Doc * len(arrays))()
+        for k, (a, o) in enumerate(zip(arrays, outs)):
+            docs[k] = Doc(a.ctypes.data if len(a) else 1, len(a), o.ctypes.data, len(o), 0, 0)
+        rc = self.L.sjgpu_stage1_many(self.h, docs, len(arrays))
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_stage1_many error {rc}: {self.last_error()}")
+        return [(int(d.error), int(d.n), o[: d.n + 3].copy()) for d, o in zip(docs, outs)]
+
+    # ---- the structural list after the scan, on the device ----
+    def stage1_finish_device(self, buf_ptr, length, mode, idx_ptr, n_raw, flags, stream=0):
+        """-> (error_code, n, next_start); idx (device) is left holding what stage1(mode) would have delivered."""
+        n = ctypes.c_uint32(0)
+        nxt = ctypes.c_uint32(0)
+        rc = self.L.sjgpu_stage1_finish_device(self.h, buf_ptr, int(length), int(mode), idx_ptr, int(n_raw), int(flags), stream or None,
+                                               ctypes.byref(n), ctypes.byref(nxt))
+        if rc < 0:
+            raise SjgpuError(f"sjgpu_stage1_finish_device error {rc}: {self.last_error()}")
+        return rc, int(n.value), int(nxt.value)
+
+    def depth_scan_device(self, buf_ptr, idx_ptr, n, depth_ptr, stream=0):
+        rc = self.L.sjgpu_depth_scan_device(self.h, buf_ptr, idx_ptr, int(n), depth_ptr, stream or None)
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_depth_scan_device error {rc}: {self.last_error()}")
 
     def result(self, stream=0):  # waits for `stream`
         r = ScanResult()

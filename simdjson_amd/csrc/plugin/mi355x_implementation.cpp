@@ -27,26 +27,17 @@ error_code map_error(int rc) noexcept {
   }
 }
 
-// minify()/validate_utf8() have no parser object (include/simdjson/implementation.h:116,128): they use a
-// process-wide context that grows on demand, one call at a time.
-struct shared_ctx {
-  std::mutex m;
+// minify() / validate_utf8() have no parser object (include/simdjson/implementation.h:116,128) and the reference's are
+// re-entrant: every call borrows a context from libsjgpu's pool (sjgpu_ctx_create takes a parked one: microseconds),
+// so concurrent callers never wait for each other, and a context only ever allocates what its operation uses.
+struct borrowed_ctx {
   sjgpu_ctx *ctx = nullptr;
-  error_code ensure(size_t len) noexcept {
-    if (!ctx) {
-      int rc = sjgpu_ctx_create(g_device.load(), len < (1u << 20) ? (1u << 20) : len, &ctx);
-      if (rc != 0) { ctx = nullptr; return map_error(rc); }
-    } else if (sjgpu_capacity(ctx) < len) {
-      int rc = sjgpu_set_capacity(ctx, len);
-      if (rc != 0) { return map_error(rc); }
-    }
-    return SUCCESS;
-  }
+  int rc;
+  borrowed_ctx() noexcept { rc = sjgpu_ctx_create(g_device.load(), 0xFFFFFFFFu, &ctx); }
+  ~borrowed_ctx() { sjgpu_ctx_destroy(ctx); }
+  borrowed_ctx(const borrowed_ctx &) = delete;
+  borrowed_ctx &operator=(const borrowed_ctx &) = delete;
 };
-shared_ctx &shared() noexcept {
-  static shared_ctx *s = new (std::nothrow) shared_ctx(); // intentionally leaked: no static-destruction order issues
-  return *s;
-}
 
 class dom_parser_implementation final : public internal::dom_parser_implementation {
 public:
@@ -151,22 +142,20 @@ public:
   }
 
   simdjson_warn_unused error_code minify(const uint8_t *buf, size_t len, uint8_t *dst, size_t &dst_len) const noexcept final {
-    auto &s = shared();
-    std::lock_guard<std::mutex> lock(s.m);
     dst_len = 0;
-    if (auto err = s.ensure(len)) { return err; }
+    borrowed_ctx b;
+    if (b.rc != 0) { return map_error(b.rc); }
     size_t n = 0;
-    const int rc = sjgpu_minify(s.ctx, buf, len, dst, &n);
+    const int rc = sjgpu_minify(b.ctx, buf, len, dst, &n); // any length: beyond 4 GiB - 1 it goes piece by piece
     dst_len = n;
     return map_error(rc);
   }
 
   simdjson_warn_unused bool validate_utf8(const char *buf, size_t len) const noexcept final {
-    auto &s = shared();
-    std::lock_guard<std::mutex> lock(s.m);
-    if (s.ensure(len)) { return false; }
+    borrowed_ctx b;
+    if (b.rc != 0) { return false; }
     int ok = 0;
-    const int rc = sjgpu_validate_utf8(s.ctx, reinterpret_cast<const uint8_t *>(buf), len, &ok);
+    const int rc = sjgpu_validate_utf8(b.ctx, reinterpret_cast<const uint8_t *>(buf), len, &ok);
     return rc == 0 && ok != 0;
   }
 };

@@ -107,9 +107,10 @@ struct copy_worker {
 
 struct sjgpu_ctx {
   int device = 0;
-  size_t capacity = 0;
+  size_t capacity = 0;    // the caller's limit on document length (CAPACITY beyond it); costs nothing by itself
+  size_t ws_capacity = 0; // what the scan workspace below is sized for: grown by the first call that needs more
   hipStream_t stream = nullptr;
-  // scan workspace (sized by capacity)
+  // scan workspace (sized by ws_capacity)
   uint4 *masks = nullptr;
   seg_summary *summ = nullptr;
   seg_prefix *pref = nullptr;
@@ -132,6 +133,15 @@ struct sjgpu_ctx {
   size_t d_idx_words = 0;
   uint8_t *d_out = nullptr;
   size_t d_out_bytes = 0;
+  // small documents (sjgpu_small.hip): one page-locked block the one-workgroup kernel reads and writes across PCIe
+  uint8_t *h_small = nullptr; // [result 64 B][descriptors][input][output]
+  size_t h_small_bytes = 0;
+  bool small_docs = true;     // env SJGPU_SMALL_DOCS=0 sends small documents through the tile pipelines (A/B, tests)
+  int enqueue_rc = 0;         // failure of the workspace allocation inside the last enqueue_* (checked by SJ_ENQUEUED)
+  int device_finish = 1;      // streaming-mode finish: 0 host, 1 device beyond the small-document path, 2 always device
+  // scratch of the device-side finish / depth scan (sjgpu_finish.hip), grown on demand
+  uint8_t *d_tmp = nullptr;
+  size_t d_tmp_bytes = 0;
   // overlapped host-buffer path (large documents): one copy thread per direction, one "range uploaded" event per range
   std::vector<copy_worker *> up, down; // range k travels on up[k % up.size()]; output piece k on down[k % down.size()]
   size_t copy_threads = 1;             // per direction (env SJGPU_COPY_THREADS)
@@ -163,6 +173,13 @@ int fail(sjgpu_ctx *ctx, hipError_t e, const char *what) {
     if (e_ != hipSuccess) { return fail((ctx), e_, #call); } \
   } while (0)
 
+// behind every enqueue_stage1 / enqueue_minify: workspace allocation failures, then launch failures
+#define SJ_ENQUEUED(ctx)                                                    \
+  do {                                                                      \
+    if ((ctx)->enqueue_rc) { const int r_ = (ctx)->enqueue_rc; (ctx)->enqueue_rc = 0; return r_; } \
+    SJ_TRY((ctx), hipGetLastError());                                       \
+  } while (0)
+
 template <class T> void dev_free(T *&p) {
   if (p) { (void)hipFree(p); p = nullptr; }
 }
@@ -175,19 +192,58 @@ int grow(sjgpu_ctx *ctx, void **p, size_t *have, size_t want) {
   return 0;
 }
 
-void release_workspace(sjgpu_ctx *ctx) {
+void release_scan_workspace(sjgpu_ctx *ctx) {
   dev_free(ctx->masks);
   dev_free(ctx->summ);
   dev_free(ctx->pref);
   dev_free(ctx->d_result); // also frees the descriptors behind it
   ctx->desc = nullptr;
+  ctx->ws_capacity = 0;
+}
+void release_staging(sjgpu_ctx *ctx) {
   dev_free(ctx->d_in);
   dev_free(ctx->d_idx);
   dev_free(ctx->d_out);
   ctx->d_in_bytes = ctx->d_out_bytes = 0;
   ctx->d_idx_words = 0;
-  ctx->capacity = 0;
 }
+
+// [result][tile descriptors][ticket]: one allocation, so that the single-pass launcher clears all of it at once
+int alloc_result(sjgpu_ctx *ctx, size_t for_len) {
+  const size_t tiles = for_len ? num_fused_tiles(for_len) : 0;
+  SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_result), sizeof(scan_result_dev) + (tiles + 1) * sizeof(uint64_t)));
+  ctx->desc = reinterpret_cast<uint64_t *>(ctx->d_result + 1);
+  return 0;
+}
+
+// Device workspace is allocated by the call that first needs it, for what THAT call needs: a context made for
+// validate_utf8 or for small documents never pays for the masks of the split pipeline, and sjgpu_set_capacity only
+// moves a limit.  Sizes grow geometrically so that a stream of ever larger documents re-allocates O(log) times.
+size_t grown(size_t want) {
+  size_t g = size_t(1) << 20;
+  while (g < want) { g <<= 1; }
+  return g > 0xFFFFFFFFull ? 0xFFFFFFFFull : g;
+}
+// what a scan of `len` bytes needs; split: the masks / summaries of the split pipeline too
+int ensure_scan_workspace(sjgpu_ctx *ctx, size_t len, bool split) {
+  if (ctx->ws_capacity >= len && ctx->d_result && (!split || ctx->masks)) { return 0; }
+  if (ctx->stream) { SJ_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
+  const size_t cap = ctx->ws_capacity >= len ? ctx->ws_capacity : grown(len);
+  if (cap != ctx->ws_capacity || !ctx->d_result) {
+    release_scan_workspace(ctx);
+    const int rc = alloc_result(ctx, cap);
+    if (rc) { return rc; }
+    ctx->ws_capacity = cap;
+  }
+  if (split && !ctx->masks) {
+    const size_t nseg = num_segments(cap);
+    SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->masks), nseg * (SEG_BYTES / BLOCK_BYTES) * sizeof(uint4)));
+    SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->summ), (nseg + num_groups(cap)) * sizeof(seg_summary)));
+    SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->pref), nseg * sizeof(seg_prefix)));
+  }
+  return 0;
+}
+int ensure_result_only(sjgpu_ctx *ctx) { return ctx->d_result ? 0 : alloc_result(ctx, 0); }
 
 int fetch_result(sjgpu_ctx *ctx, hipStream_t s, sjgpu_scan_result *out) {
   SJ_TRY(ctx, hipMemcpyAsync(ctx->h_result, ctx->d_result, sizeof(scan_result_dev), hipMemcpyDeviceToHost, s));
@@ -249,6 +305,8 @@ bool use_fused(const sjgpu_ctx *ctx, size_t len, int op = 1) { // op 0: stage 1,
 void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint32_t *idx, size_t idx_words, hipStream_t s,
                     hipEvent_t *ev, scan_origin org = scan_origin{0, 0, 0}) {
   org.esc = ctx->esc_tab;
+  ctx->enqueue_rc = ensure_scan_workspace(ctx, len - org.begin, !fused);
+  if (ctx->enqueue_rc) { return; }
   ctx->last_pipeline = fused ? 1 : 0;
   ctx->pending_scan_bytes = (org.begin == 0 && org.base0 == 0 && len >= AUTO_FUSED_FROM) ? len : 0;
   if (fused) { ctx->last_kernel = launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, org, ctx->max_workgroups, s, ev); }
@@ -260,6 +318,8 @@ void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, 
 void enqueue_minify(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint8_t *dst, hipStream_t s, hipEvent_t *ev,
                     scan_origin org = scan_origin{0, 0, 0}) {
   org.esc = ctx->esc_tab;
+  ctx->enqueue_rc = ensure_scan_workspace(ctx, len - org.begin, !fused);
+  if (ctx->enqueue_rc) { return; }
   ctx->last_pipeline = fused ? 1 : 0;
   ctx->pending_scan_bytes = 0;
   if (fused) { ctx->last_kernel = launch_minify_fused(buf, len, ctx->desc, dst, ctx->d_result, org, ctx->max_workgroups, s, ev); }
@@ -304,8 +364,11 @@ int ensure_streaming(sjgpu_ctx *ctx, size_t nranges) {
 // ranges back to back; as soon as range k is resident this thread scans it (sjgpu_*_range_device's kernels), reads the
 // 16-byte result and hands the new output to the download thread.  The only state between ranges is what one call's
 // result holds: the output cursor and the in-string bit.
-//   op 0: stage 1, out = idx_out (u32 words, room for out_cap words); op 1: minify, out = dst (bytes, room for len)
-int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *out_host, size_t out_cap, sjgpu_scan_result *res_out) {
+//   op 0: stage 1, out = idx_out (u32 words, room for out_cap words); op 1: minify, out = dst (bytes, room for len);
+//   op 2: validate_utf8 (no output: the upload of range k+1 runs under the check of range k, the verdict is fetched once)
+//   carry_in: CARRY_IN_STRING if the buffer is a piece of a larger document that begins inside a string (minify)
+int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *out_host, size_t out_cap, sjgpu_scan_result *res_out,
+                 uint32_t carry_in = 0) {
   const size_t chunk = ctx->stream_chunk;
   const size_t nranges = (len + chunk - 1) / chunk;
   int rc = ensure_streaming(ctx, nranges);
@@ -318,7 +381,7 @@ int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *o
     ctx->up[k % ctx->up.size()]->submit(ctx->d_in + b, buf + b, e - b, ctx->ev_in[k]);
   }
   hipError_t he = hipSuccess;
-  uint32_t flags = 0, in_string = 0;
+  uint32_t flags = 0, in_string = carry_in & CARRY_IN_STRING;
   uint64_t cursor = 0; // output units produced by the ranges so far
   const bool debug = std::getenv("SJGPU_DEBUG_STREAM") != nullptr;
   double wait_upload_s = 0.0, wait_scan_s = 0.0;
@@ -335,10 +398,16 @@ int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *o
     wait_upload_s += std::chrono::duration<double>(tw1 - tw0).count();
     if (he == hipSuccess) { he = hipStreamWaitEvent(s, ctx->ev_in[k], 0); }
     if (he != hipSuccess) { break; }
+    if (op == 2) { // stateless but for the three bytes in front of the range, which are resident; flags accumulate on the device
+      launch_validate_utf8(ctx->d_in, e, ctx->d_result, s, nullptr, b, !last);
+      he = hipGetLastError();
+      continue;
+    }
     for (int attempt = 0; attempt < 2; attempt++) { // a single-pass range that gives up is re-run on the split pipeline
       const bool fused = use_fused(ctx, e - b, op) && attempt == 0;
       if (op == 0) { enqueue_stage1(ctx, fused, ctx->d_in, e, ctx->d_idx, ctx->d_idx_words, s, nullptr, org); }
       else { enqueue_minify(ctx, fused, ctx->d_in, e, ctx->d_out, s, nullptr, org); }
+      if (ctx->enqueue_rc) { rc = ctx->enqueue_rc; ctx->enqueue_rc = 0; break; }
       he = hipGetLastError();
       if (he != hipSuccess) { break; }
       rc = fetch_result(ctx, s, &res);
@@ -379,6 +448,7 @@ int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *o
   if (ue != hipSuccess) { return fail(ctx, ue, "streamed scan: upload"); }
   if (de != hipSuccess) { return fail(ctx, de, "streamed scan: download"); }
   if (rc) { return rc; }
+  if (op == 2) { return fetch_result(ctx, s, res_out); }
   res_out->n = (op == 0) ? uint32_t(cursor) : 0;
   res_out->out_len = (op == 0) ? 0 : cursor;
   res_out->flags = flags | in_string;
@@ -418,14 +488,23 @@ int sjgpu_host_unregister(void *p) {
   return e == hipSuccess ? 0 : fail(nullptr, e, "hipHostUnregister");
 }
 
-int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out) {
-  if (!out) { return SJGPU_E_BADARG; }
-  *out = nullptr;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) { return SJGPU_E_NO_DEVICE; }
-  sjgpu_ctx *ctx = new (std::nothrow) sjgpu_ctx();
-  if (!ctx) { return SJGPU_E_NOMEM; }
-  ctx->device = device;
+} // extern "C"
+
+// Contexts are recycled: creating one costs a stream, two page-locked blocks and the escape table (~0.5 ms, 3 ms with
+// the workspace the first call allocates), and the reference creates a dom_parser_implementation per parser object --
+// its document_stream tests make 106 000 of them.  sjgpu_ctx_destroy parks the context (with whatever small workspace
+// it has grown) and sjgpu_ctx_create takes a parked one of the same device; large workspaces are released on parking.
+namespace {
+constexpr size_t POOL_MAX = 64;                          // parked contexts per process
+constexpr size_t POOL_KEEP_BYTES = size_t(32) << 20;     // workspace / staging for documents beyond this is freed on parking
+std::mutex g_pool_m;
+std::vector<sjgpu_ctx *> g_pool;
+
+void apply_environment(sjgpu_ctx *ctx) {
+  ctx->pipeline = 2;
+  ctx->stream_from = size_t(64) << 20;
+  ctx->stream_chunk = size_t(16) << 20;
+  ctx->copy_threads = 1;
   if (const char *pl = std::getenv("SJGPU_PIPELINE")) {
     ctx->pipeline = std::strcmp(pl, "split") == 0 ? 0 : (std::strcmp(pl, "fused") == 0 ? 1 : 2);
   }
@@ -438,6 +517,68 @@ int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out) {
     const size_t mb = size_t(std::strtoull(v, nullptr, 10));
     if (mb >= 1 && mb <= 1024) { ctx->stream_chunk = mb << 20; }
   }
+  ctx->small_docs = true;
+  if (const char *v = std::getenv("SJGPU_SMALL_DOCS")) { ctx->small_docs = v[0] != '0'; }
+  ctx->device_finish = 1; // streaming-mode finish on the device for documents beyond the small-document path
+  if (const char *v = std::getenv("SJGPU_FINISH")) { ctx->device_finish = std::strcmp(v, "host") == 0 ? 0 : (std::strcmp(v, "device") == 0 ? 2 : 1); }
+}
+
+void really_destroy(sjgpu_ctx *ctx) {
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+  for (std::vector<copy_worker *> *ws : {&ctx->up, &ctx->down}) {
+    for (copy_worker *w : *ws) {
+      w->shutdown();
+      delete w;
+    }
+    ws->clear();
+  }
+  for (hipEvent_t ev : ctx->ev_in) { (void)hipEventDestroy(ev); }
+  ctx->ev_in.clear();
+  release_scan_workspace(ctx);
+  release_staging(ctx);
+  drop_events(ctx);
+  if (ctx->h_result) { (void)hipHostFree(ctx->h_result); }
+  if (ctx->h_small) { (void)hipHostFree(ctx->h_small); }
+  dev_free(ctx->esc_tab);
+  dev_free(ctx->d_tmp);
+  if (ctx->stream) { (void)hipStreamDestroy(ctx->stream); }
+  delete ctx;
+}
+} // namespace
+
+extern "C" int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out) {
+  if (!out) { return SJGPU_E_BADARG; }
+  *out = nullptr;
+  if (capacity > 0xFFFFFFFFull) { return SJGPU_E_BADARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) { return SJGPU_E_NO_DEVICE; }
+  sjgpu_ctx *ctx = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_m);
+    for (size_t i = g_pool.size(); i-- > 0;) {
+      if (g_pool[i]->device == device) {
+        ctx = g_pool[i];
+        g_pool.erase(g_pool.begin() + long(i));
+        break;
+      }
+    }
+  }
+  if (ctx) { // a parked context: same stream, same page-locked blocks, whatever workspace it kept
+    apply_environment(ctx);
+    ctx->capacity = capacity;
+    ctx->density_permille = 1000;
+    ctx->pending_scan_bytes = 0;
+    ctx->last_pipeline = 0;
+    ctx->last_kernel = "";
+    ctx->err[0] = 0;
+    *out = ctx;
+    return 0;
+  }
+  ctx = new (std::nothrow) sjgpu_ctx();
+  if (!ctx) { return SJGPU_E_NOMEM; }
+  ctx->device = device;
+  apply_environment(ctx);
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) {
     int cus = 0;
@@ -451,56 +592,42 @@ int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out) {
   if (e == hipSuccess) { e = hipMemset(ctx->esc_tab, 0, ESC_TABLE_BYTES); } // entry 0 and the pass flag start at zero
   if (e != hipSuccess) {
     int rc = fail(nullptr, e, "ctx_create");
-    sjgpu_ctx_destroy(ctx);
+    really_destroy(ctx);
     return rc;
   }
-  int rc = sjgpu_set_capacity(ctx, capacity);
-  if (rc != 0) {
-    sjgpu_ctx_destroy(ctx);
-    return rc;
-  }
+  ctx->capacity = capacity;
   *out = ctx;
   return 0;
 }
 
-void sjgpu_ctx_destroy(sjgpu_ctx *ctx) {
+extern "C" void sjgpu_ctx_destroy(sjgpu_ctx *ctx) {
   if (!ctx) { return; }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
-  for (std::vector<copy_worker *> *ws : {&ctx->up, &ctx->down}) {
-    for (copy_worker *w : *ws) {
-      w->shutdown();
-      delete w;
-    }
-    ws->clear();
-  }
-  for (hipEvent_t ev : ctx->ev_in) { (void)hipEventDestroy(ev); }
-  ctx->ev_in.clear();
-  release_workspace(ctx);
   drop_events(ctx);
-  if (ctx->h_result) { (void)hipHostFree(ctx->h_result); }
-  dev_free(ctx->esc_tab);
-  if (ctx->stream) { (void)hipStreamDestroy(ctx->stream); }
-  delete ctx;
+  ctx->profile = false;
+  if (ctx->ws_capacity > POOL_KEEP_BYTES) { release_scan_workspace(ctx); }
+  if (ctx->d_in_bytes > POOL_KEEP_BYTES || ctx->d_idx_words * sizeof(uint32_t) > 4 * POOL_KEEP_BYTES || ctx->d_out_bytes > POOL_KEEP_BYTES) {
+    release_staging(ctx);
+  }
+  if (ctx->d_tmp_bytes > 4 * POOL_KEEP_BYTES) { dev_free(ctx->d_tmp); ctx->d_tmp_bytes = 0; }
+  {
+    std::lock_guard<std::mutex> lk(g_pool_m);
+    if (g_pool.size() < POOL_MAX) {
+      g_pool.push_back(ctx);
+      return;
+    }
+  }
+  really_destroy(ctx);
 }
 
-int sjgpu_set_capacity(sjgpu_ctx *ctx, size_t capacity) {
+extern "C" int sjgpu_set_capacity(sjgpu_ctx *ctx, size_t capacity) {
   if (!ctx || capacity > 0xFFFFFFFFull) { return SJGPU_E_BADARG; }
-  SJ_TRY(ctx, hipSetDevice(ctx->device));
-  if (ctx->stream) { SJ_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
-  release_workspace(ctx);
-  // [result][tile descriptors][ticket]: one allocation, so that the single-pass launcher clears all of it at once
-  const size_t tiles = capacity ? num_fused_tiles(capacity) : 0;
-  SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_result), sizeof(scan_result_dev) + (tiles + 1) * sizeof(uint64_t)));
-  ctx->desc = reinterpret_cast<uint64_t *>(ctx->d_result + 1);
-  if (capacity == 0) { return 0; }
-  const size_t nseg = num_segments(capacity);
-  SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->masks), nseg * (SEG_BYTES / BLOCK_BYTES) * sizeof(uint4)));
-  SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->summ), (nseg + num_groups(capacity)) * sizeof(seg_summary)));
-  SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->pref), nseg * sizeof(seg_prefix)));
-  ctx->capacity = capacity;
+  ctx->capacity = capacity; // device memory follows the documents actually scanned (ensure_scan_workspace)
   return 0;
 }
+
+extern "C" {
 
 size_t sjgpu_capacity(const sjgpu_ctx *ctx) { return ctx ? ctx->capacity : 0; }
 const char *sjgpu_last_error(const sjgpu_ctx *ctx) { return ctx ? ctx->err : ""; }
@@ -515,7 +642,7 @@ int sjgpu_stage1_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *i
   SJ_TRY(ctx, hipSetDevice(ctx->device));
   enqueue_stage1(ctx, use_fused(ctx, len, 0), static_cast<const uint8_t *>(buf_dev), len, static_cast<uint32_t *>(idx_dev), idx_words,
                  pick(ctx, stream), next_events(ctx));
-  SJ_TRY(ctx, hipGetLastError());
+  SJ_ENQUEUED(ctx);
   return 0;
 }
 
@@ -525,19 +652,21 @@ int sjgpu_minify_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *d
   }
   if (len > ctx->capacity) { return E_CAPACITY; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
+  if (const int wrc = ensure_result_only(ctx)) { return wrc; }
   if (len == 0) { // SUCCESS with zero bytes (json_minifier.h:68-97 with an empty reader)
     SJ_TRY(ctx, hipMemsetAsync(ctx->d_result, 0, sizeof(scan_result_dev), pick(ctx, stream)));
     return 0;
   }
   enqueue_minify(ctx, use_fused(ctx, len), static_cast<const uint8_t *>(buf_dev), len, static_cast<uint8_t *>(dst_dev), pick(ctx, stream),
                  next_events(ctx));
-  SJ_TRY(ctx, hipGetLastError());
+  SJ_ENQUEUED(ctx);
   return 0;
 }
 
 int sjgpu_validate_utf8_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *stream) {
   if (!ctx || (len && (!buf_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u)))) { return SJGPU_E_BADARG; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
+  if (const int wrc = ensure_result_only(ctx)) { return wrc; }
   if (len == 0) {
     SJ_TRY(ctx, hipMemsetAsync(ctx->d_result, 0, sizeof(scan_result_dev), pick(ctx, stream)));
     return 0;
@@ -556,6 +685,7 @@ int sjgpu_string_parity_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
   if (!ctx || (len && (!buf_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u)))) { return SJGPU_E_BADARG; }
   if (len > ctx->capacity) { return E_CAPACITY; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
+  if (const int wrc = ensure_result_only(ctx)) { return wrc; }
   ctx->pending_scan_bytes = 0;
   launch_string_parity(static_cast<const uint8_t *>(buf_dev), len, ctx->d_result, ctx->esc_tab, pick(ctx, stream));
   SJ_TRY(ctx, hipGetLastError());
@@ -572,7 +702,7 @@ int sjgpu_stage1_shard_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, i
   SJ_TRY(ctx, hipSetDevice(ctx->device));
   enqueue_stage1(ctx, use_fused(ctx, len, 0), static_cast<const uint8_t *>(buf_dev), len, static_cast<uint32_t *>(idx_dev), idx_words,
                  pick(ctx, stream), next_events(ctx), scan_origin{0, 0, CARRY_SHARD | (in_string ? CARRY_IN_STRING : 0u)});
-  SJ_TRY(ctx, hipGetLastError());
+  SJ_ENQUEUED(ctx);
   return 0;
 }
 
@@ -585,7 +715,7 @@ int sjgpu_minify_shard_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, i
   SJ_TRY(ctx, hipSetDevice(ctx->device));
   enqueue_minify(ctx, use_fused(ctx, len), static_cast<const uint8_t *>(buf_dev), len, static_cast<uint8_t *>(dst_dev), pick(ctx, stream),
                  next_events(ctx), scan_origin{0, 0, CARRY_SHARD | (in_string ? CARRY_IN_STRING : 0u)});
-  SJ_TRY(ctx, hipGetLastError());
+  SJ_ENQUEUED(ctx);
   return 0;
 }
 
@@ -607,7 +737,7 @@ int sjgpu_stage1_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin,
   const scan_origin org{uint64_t(begin), n_before, CARRY_SHARD | (in_string ? CARRY_IN_STRING : 0u) | (more ? CARRY_MORE : 0u)};
   enqueue_stage1(ctx, use_fused(ctx, end - begin, 0), static_cast<const uint8_t *>(buf_dev), end, static_cast<uint32_t *>(idx_dev), idx_words,
                  pick(ctx, stream), next_events(ctx), org);
-  SJ_TRY(ctx, hipGetLastError());
+  SJ_ENQUEUED(ctx);
   return 0;
 }
 
@@ -620,7 +750,7 @@ int sjgpu_minify_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin,
   const scan_origin org{uint64_t(begin), out_before, CARRY_SHARD | (in_string ? CARRY_IN_STRING : 0u) | (more ? CARRY_MORE : 0u)};
   enqueue_minify(ctx, use_fused(ctx, end - begin), static_cast<const uint8_t *>(buf_dev), end, static_cast<uint8_t *>(dst_dev),
                  pick(ctx, stream), next_events(ctx), org);
-  SJ_TRY(ctx, hipGetLastError());
+  SJ_ENQUEUED(ctx);
   return 0;
 }
 
@@ -637,6 +767,7 @@ int sjgpu_debug_trace_stage1(sjgpu_ctx *ctx, const void *buf_dev, size_t len, vo
     return SJGPU_E_BADARG;
   }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
+  if (const int wrc = ensure_scan_workspace(ctx, len, false)) { return wrc; }
   uint64_t *d_trace = nullptr;
   const size_t bytes = size_t(trace_tiles) * 8 * sizeof(uint64_t);
   SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&d_trace), bytes));
@@ -657,6 +788,7 @@ int sjgpu_debug_trace_pipelined(sjgpu_ctx *ctx, const void *buf_dev, size_t len,
     return SJGPU_E_BADARG;
   }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
+  if (const int wrc = ensure_scan_workspace(ctx, len, false)) { return wrc; }
   uint64_t *d_trace = nullptr;
   const size_t bytes = size_t(max_records) * 8 * sizeof(uint64_t);
   SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&d_trace), bytes));
@@ -708,6 +840,228 @@ int sjgpu_profile_read(sjgpu_ctx *ctx, double *ms_sum, uint32_t *calls) {
 }
 
 // ---- host-buffer entry points (the plug-in path: H2D, scan, D2H, host finish) ---------------------------
+} // extern "C"
+
+namespace {
+
+constexpr size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+// Streaming-mode documents at least this long are finished on the device (a dozen small launches, ~60 us, against
+// downloading and walking a list of millions of offsets); shorter ones keep the host walk, which is O(last document).
+constexpr size_t DEVICE_FINISH_FROM = size_t(4) << 20;
+
+int ensure_small(sjgpu_ctx *ctx, size_t bytes) {
+  if (ctx->h_small_bytes >= bytes) { return 0; }
+  if (ctx->h_small) { (void)hipHostFree(ctx->h_small); ctx->h_small = nullptr; ctx->h_small_bytes = 0; }
+  size_t want = size_t(256) << 10;
+  while (want < bytes) { want <<= 1; }
+  SJ_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_small), want, hipHostMallocDefault));
+  ctx->h_small_bytes = want;
+  return 0;
+}
+
+// ONE small document through the one-workgroup kernel (sjgpu_small.hip): the document is copied into the context's
+// page-locked block, the kernel reads it and writes offsets / bytes and the result back across PCIe, the host waits once.
+// *out = where the kernel left the output (inside the block, valid until the context's next call).
+int small_single(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, sjgpu_scan_result *res, const void **out) {
+  const size_t in_at = 64, out_at = in_at + round_up(len, 64) + 64;
+  const size_t out_bytes = op == 0 ? (len + 3) * sizeof(uint32_t) : (op == 1 ? len + 16 : 0);
+  int rc = ensure_small(ctx, out_at + out_bytes + 64);
+  if (rc) { return rc; }
+  std::memcpy(ctx->h_small + in_at, buf, len);
+  scan_result_dev *r = reinterpret_cast<scan_result_dev *>(ctx->h_small);
+  ctx->pending_scan_bytes = 0;
+  ctx->last_kernel = op == 0 ? "k_docs<0>" : (op == 1 ? "k_docs<1>" : "k_docs<2>");
+  launch_docs(op, ctx->h_small + in_at, nullptr, doc_desc{0, 0, uint32_t(len), 0}, 1, ctx->h_small + out_at, r, ctx->stream);
+  SJ_TRY(ctx, hipGetLastError());
+  SJ_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  res->n = r->n;
+  res->flags = r->flags;
+  res->out_len = r->out_len;
+  if (out) { *out = ctx->h_small + out_at; }
+  return 0;
+}
+
+int ensure_staging_in(sjgpu_ctx *ctx, size_t len) { return grow(ctx, reinterpret_cast<void **>(&ctx->d_in), &ctx->d_in_bytes, grown(len) + 64); }
+
+// pieces of inputs beyond what one scan addresses (32-bit offsets); env SJGPU_PIECE_MB for tests
+size_t piece_bytes() {
+  size_t mb = 1024;
+  if (const char *v = std::getenv("SJGPU_PIECE_MB")) {
+    const size_t x = size_t(std::strtoull(v, nullptr, 10));
+    if (x >= 1 && x <= 2048) { mb = x; }
+  }
+  return mb << 20;
+}
+
+// one buffer that is well-formed or not by itself (a whole input, or a piece cut at a character boundary)
+int validate_piece(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int *ok) {
+  sjgpu_scan_result res{0, 0, 0};
+  int rc = 0;
+  if (ctx->small_docs && len <= DOCS_SINGLE_MAX) {
+    rc = small_single(ctx, 2, buf, len, &res, nullptr);
+  } else {
+    rc = ensure_result_only(ctx);
+    if (!rc) { rc = ensure_staging_in(ctx, len); }
+    if (rc) { return rc; }
+    ctx->pending_scan_bytes = 0;
+    ctx->last_kernel = "k_validate_utf8";
+    if (take_streamed_path(ctx, len)) {
+      rc = run_streamed(ctx, 2, buf, len, nullptr, 0, &res);
+    } else {
+      hipStream_t s = ctx->stream;
+      SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
+      launch_validate_utf8(ctx->d_in, len, ctx->d_result, s, nullptr);
+      SJ_TRY(ctx, hipGetLastError());
+      rc = fetch_result(ctx, s, &res);
+    }
+  }
+  if (rc) { return rc; }
+  *ok = (res.flags & SJGPU_F_UTF8_ERROR) ? 0 : 1;
+  return 0;
+}
+
+// one buffer of at most 4 GiB - 1 bytes; in_string / shard: it is a piece of a larger document (sjgpu_clean_cut)
+int minify_piece(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, bool shard, uint32_t in_string, uint8_t *dst, sjgpu_scan_result *res) {
+  int rc = 0;
+  if (ctx->small_docs && len <= DOCS_SINGLE_MAX && !shard) {
+    const void *out = nullptr;
+    rc = small_single(ctx, 1, buf, len, res, &out);
+    if (rc) { return rc; }
+    if (res->out_len > len) { return E_UNEXPECTED; }
+    std::memcpy(dst, out, res->out_len);
+    return 0;
+  }
+  rc = ensure_staging_in(ctx, len);
+  if (!rc) { rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_out), &ctx->d_out_bytes, grown(len) + 64); }
+  if (rc) { return rc; }
+  hipStream_t s = ctx->stream;
+  const uint32_t carry = (shard ? CARRY_SHARD : 0u) | (in_string ? CARRY_IN_STRING : 0u);
+  const bool streamed = take_streamed_path(ctx, len);
+  if (streamed) {
+    rc = run_streamed(ctx, 1, buf, len, dst, len, res, carry);
+    if (rc) { return rc; }
+  } else {
+    SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
+    for (int attempt = 0; attempt < 2; attempt++) { // a single-pass call that gives up is re-run on the split pipeline
+      enqueue_minify(ctx, use_fused(ctx, len) && attempt == 0, ctx->d_in, len, ctx->d_out, s, nullptr, scan_origin{0, 0, carry});
+      SJ_ENQUEUED(ctx);
+      rc = fetch_result(ctx, s, res);
+      if (rc) { return rc; }
+      if (!(res->flags & SJGPU_F_INTERNAL)) { break; }
+    }
+  }
+  if (res->flags & SJGPU_F_INTERNAL) { return E_UNEXPECTED; }
+  if (res->out_len > len) { return E_UNEXPECTED; }
+  if (!streamed && res->out_len && !((res->flags & SJGPU_F_UNCLOSED_STRING) && !shard)) {
+    SJ_TRY(ctx, hipMemcpyAsync(dst, ctx->d_out, res->out_len, hipMemcpyDeviceToHost, s));
+    SJ_TRY(ctx, hipStreamSynchronize(s));
+  }
+  return 0;
+}
+
+
+int ensure_tmp(sjgpu_ctx *ctx, size_t bytes) { return grow(ctx, reinterpret_cast<void **>(&ctx->d_tmp), &ctx->d_tmp_bytes, bytes); }
+
+// What finish() decides for a streaming mode (json_structural_indexer.h:295-394), with the list still on the device:
+// the filters and the boundary search run there (sjgpu_finish.hip), the host reads back one small state and applies the
+// same scalar edits stage1_finish.cpp applies.  `edit(pos, value)` stores one word of the caller's copy of the list,
+// `word(pos)` reads one (device or host copy -- the caller decides where the list lives).
+struct finish_decision {
+  int error;
+  uint32_t n_io;
+  bool write_next_start; // idx[n_io] = next_start                     (partial filter modes)
+  bool shift_sentinel;   // idx[n_io + 1] = idx[n_io]; idx[n_io] = len (final modes)
+  uint32_t next_start;
+  bool need_first_word;  // streaming_partial with nothing complete: CAPACITY iff idx[0] == 0, else EMPTY with n_io = 0
+};
+
+// Runs the device part for the n_raw structurals of dev_idx and returns the decision; `n_after_unclosed` is filled with
+// the list length the reference works on (the dangling opening quote of an unclosed string is dropped first).
+int decide_on_device(sjgpu_ctx *ctx, const uint8_t *dev_buf, size_t len, int mode, uint32_t *dev_idx, uint32_t n_raw, uint32_t flags,
+                     hipStream_t s, finish_decision *d) {
+  const bool partial = mode == SJGPU_STREAMING_PARTIAL || mode == SJGPU_JSON_SEQUENCE_PARTIAL || mode == SJGPU_COMMA_DELIMITED_PARTIAL;
+  const bool final_mode = !partial;
+  *d = finish_decision{0, n_raw, false, false, uint32_t(len), false};
+  if (n_raw == 0) { d->error = E_EMPTY; return 0; }
+  uint32_t n = n_raw;
+  if (flags & SJGPU_F_UNCLOSED_STRING) { // the last structural is the dangling opening quote
+    d->n_io = --n;
+    if (partial && n == 0) { d->error = E_CAPACITY; return 0; }
+  }
+  finish_state st{};
+  st.n_report = n;
+  if (n > 0) {
+    int rc = ensure_tmp(ctx, finish_workspace_bytes(n));
+    if (rc) { return rc; }
+    launch_finish(mode, dev_buf, len, dev_idx, n, ctx->d_tmp, s);
+    SJ_TRY(ctx, hipGetLastError());
+    SJ_TRY(ctx, hipMemcpyAsync(&st, ctx->d_tmp, sizeof st, hipMemcpyDeviceToHost, s));
+    SJ_TRY(ctx, hipStreamSynchronize(s));
+  }
+  const uint32_t utf8 = (flags & SJGPU_F_UTF8_ERROR) ? E_UTF8 : 0;
+  if (mode == SJGPU_STREAMING_PARTIAL) {
+    if (st.keep == 0 && n > 0) { d->need_first_word = true; d->n_io = n; d->error = 0; return 0; } // resolved by the caller
+    d->n_io = st.keep;
+    d->error = int(utf8);
+    return 0;
+  }
+  if (mode == SJGPU_STREAMING_FINAL) {
+    d->n_io = st.keep;
+    d->shift_sentinel = true;
+    d->error = st.keep == 0 ? E_EMPTY : int(utf8);
+    return 0;
+  }
+  // json_sequence / comma_delimited
+  d->next_start = st.next_start;
+  if (partial) {
+    d->n_io = st.n_report;
+    if (st.verdict == FIN_TOO_LARGE) { d->error = E_CAPACITY; return 0; }
+    if (st.keep == 0) { d->n_io = 0; d->error = E_EMPTY; return 0; }
+    d->n_io = st.keep;
+    d->write_next_start = true;
+    d->error = int(utf8);
+    return 0;
+  }
+  (void)final_mode;
+  d->n_io = st.keep;
+  d->shift_sentinel = true;
+  d->error = st.keep == 0 ? E_EMPTY : int(utf8);
+  return 0;
+}
+
+// sjgpu_stage1's tail for the streaming modes when the list is on the device: decide there, fetch only what is kept
+int finish_on_device_and_fetch(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint32_t *idx_out, size_t idx_words,
+                               const sjgpu_scan_result &res, uint32_t *n_io, uint32_t *next_io) {
+  (void)buf;
+  hipStream_t s = ctx->stream;
+  finish_decision d;
+  int rc = decide_on_device(ctx, ctx->d_in, len, mode, ctx->d_idx, res.n, res.flags, s, &d);
+  if (rc) { return rc; }
+  *n_io = d.n_io;
+  if (next_io) { *next_io = 0; }
+  // the words a caller may look at: idx[0 .. n_io + 2] (never beyond the raw list and its three sentinels)
+  size_t words = size_t(d.n_io) + 3;
+  if (words > size_t(res.n) + 3) { words = size_t(res.n) + 3; }
+  if (words > idx_words) { return SJGPU_E_OVERFLOW; }
+  SJ_TRY(ctx, hipMemcpyAsync(idx_out, ctx->d_idx, words * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  SJ_TRY(ctx, hipStreamSynchronize(s));
+  if (d.need_first_word) {
+    if (idx_out[0] == 0) { return E_CAPACITY; } // one document fills the whole window
+    *n_io = 0;
+    return E_EMPTY; // leading whitespace only; the document may fit the next window
+  }
+  if (d.write_next_start) { idx_out[d.n_io] = d.next_start; }
+  if (d.shift_sentinel) {
+    idx_out[d.n_io + 1] = idx_out[d.n_io]; // lets the stream compute truncated_bytes (json_structural_indexer.h:334-337)
+    idx_out[d.n_io] = uint32_t(len);
+  }
+  return d.error;
+}
+
+} // namespace
+
+extern "C" {
+
 int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint32_t *idx_out, size_t idx_words, uint32_t *n_io,
                  uint32_t *next_io) {
   if (!ctx || !n_io || mode < SJGPU_REGULAR || mode > SJGPU_COMMA_DELIMITED_FINAL) { return SJGPU_E_BADARG; }
@@ -719,14 +1073,26 @@ int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint3
     if (len == 0) { return E_UTF8; }
   }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
-  int rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_in), &ctx->d_in_bytes, ctx->capacity);
+  sjgpu_scan_result res;
+  int rc = 0;
+  if (ctx->small_docs && len <= DOCS_SINGLE_MAX) { // one launch, one wait, no staging copies on the device
+    const void *out = nullptr;
+    rc = small_single(ctx, 0, buf, len, &res, &out);
+    if (rc) { return rc; }
+    if (res.flags & SJGPU_F_IDX_OVERFLOW) { return E_UNEXPECTED; }
+    if ((res.flags & SJGPU_F_UNCLOSED_STRING) && mode == SJGPU_REGULAR) { return E_UNCLOSED; }
+    if (res.flags & SJGPU_F_UNESCAPED_CTRL) { return 14; }
+    if (size_t(res.n) + 3 > idx_words) { return SJGPU_E_OVERFLOW; }
+    std::memcpy(idx_out, out, (size_t(res.n) + 3) * sizeof(uint32_t));
+    return sjgpu_stage1_finish_host(buf, len, mode, idx_out, res.n, res.flags, n_io, next_io);
+  }
+  rc = ensure_staging_in(ctx, len);
   if (rc) { return rc; }
   size_t idx_bytes = ctx->d_idx_words * sizeof(uint32_t);
-  rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_idx), &idx_bytes, (ctx->capacity + 3) * sizeof(uint32_t));
+  rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_idx), &idx_bytes, (grown(len) + 16) * sizeof(uint32_t));
   ctx->d_idx_words = idx_bytes / sizeof(uint32_t);
   if (rc) { return rc; }
   hipStream_t s = ctx->stream;
-  sjgpu_scan_result res;
   const bool streamed = take_streamed_path(ctx, len);
   if (streamed) { // large document: upload, scan and download overlap range by range; the offsets are on the host afterwards
     rc = run_streamed(ctx, 0, buf, len, idx_out, idx_words, &res);
@@ -735,7 +1101,7 @@ int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint3
     SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
     for (int attempt = 0; attempt < 2; attempt++) { // a single-pass call that gives up is re-run on the split pipeline
       enqueue_stage1(ctx, use_fused(ctx, len, 0) && attempt == 0, ctx->d_in, len, ctx->d_idx, ctx->d_idx_words, s, nullptr);
-      SJ_TRY(ctx, hipGetLastError());
+      SJ_ENQUEUED(ctx);
       rc = fetch_result(ctx, s, &res);
       if (rc) { return rc; }
       if (!(res.flags & SJGPU_F_INTERNAL)) { break; }
@@ -748,68 +1114,186 @@ int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint3
   if (res.flags & SJGPU_F_UNESCAPED_CTRL) { return 14; }
   if (!streamed) {
     if (size_t(res.n) + 3 > idx_words) { return SJGPU_E_OVERFLOW; }
+    if (mode != SJGPU_REGULAR && (ctx->device_finish == 2 || (ctx->device_finish == 1 && len >= DEVICE_FINISH_FROM))) {
+      // streaming modes: find the last complete document / filter the list where it lies, then fetch only what is kept
+      return finish_on_device_and_fetch(ctx, buf, len, mode, idx_out, idx_words, res, n_io, next_io);
+    }
     SJ_TRY(ctx, hipMemcpyAsync(idx_out, ctx->d_idx, (size_t(res.n) + 3) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     SJ_TRY(ctx, hipStreamSynchronize(s));
   }
   return sjgpu_stage1_finish_host(buf, len, mode, idx_out, res.n, res.flags, n_io, next_io);
 }
 
+// ---- the list after the scan, for device-resident callers (sjgpu_finish.hip) --------------------------------------------------
+int sjgpu_stage1_finish_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, int mode, void *idx_dev, uint32_t n_raw, uint32_t flags,
+                               void *stream, uint32_t *n_io, uint32_t *next_start_out) {
+  if (!ctx || !buf_dev || !idx_dev || !n_io || mode < SJGPU_STREAMING_PARTIAL || mode > SJGPU_COMMA_DELIMITED_FINAL || len == 0 ||
+      len > 0xFFFFFFFFull) {
+    return SJGPU_E_BADARG;
+  }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  if ((flags & SJGPU_F_UNCLOSED_STRING) == 0 && (flags & SJGPU_F_UNESCAPED_CTRL)) { return 14; }
+  if (flags & SJGPU_F_UNESCAPED_CTRL) { return 14; }
+  hipStream_t s = pick(ctx, stream);
+  uint32_t *idx = static_cast<uint32_t *>(idx_dev);
+  finish_decision d;
+  int rc = decide_on_device(ctx, static_cast<const uint8_t *>(buf_dev), len, mode, idx, n_raw, flags, s, &d);
+  if (rc) { return rc; }
+  *n_io = d.n_io;
+  if (next_start_out) { *next_start_out = d.next_start; }
+  if (d.need_first_word) {
+    uint32_t first = 0;
+    SJ_TRY(ctx, hipMemcpyAsync(&first, idx, sizeof first, hipMemcpyDeviceToHost, s));
+    SJ_TRY(ctx, hipStreamSynchronize(s));
+    if (first == 0) { return E_CAPACITY; }
+    *n_io = 0;
+    return E_EMPTY;
+  }
+  if (d.write_next_start) { SJ_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(idx + d.n_io), int(d.next_start), 1, s)); }
+  if (d.shift_sentinel) {
+    SJ_TRY(ctx, hipMemcpyAsync(idx + d.n_io + 1, idx + d.n_io, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    SJ_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(idx + d.n_io), int(uint32_t(len)), 1, s));
+  }
+  return d.error;
+}
+
+int sjgpu_depth_scan_device(sjgpu_ctx *ctx, const void *buf_dev, const void *idx_dev, uint32_t n, void *depth_dev, void *stream) {
+  if (!ctx || !buf_dev || !idx_dev || !depth_dev) { return SJGPU_E_BADARG; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_tmp(ctx, 64 + 4 * (size_t(n) / 4096 + 8));
+  if (rc) { return rc; }
+  launch_depth_scan(static_cast<const uint8_t *>(buf_dev), static_cast<const uint32_t *>(idx_dev), n, static_cast<int32_t *>(depth_dev), ctx->d_tmp,
+                    pick(ctx, stream));
+  SJ_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+// ---- many small documents per launch (sjgpu_small.hip) -----------------------------------------------------------------------
+int sjgpu_stage1_many(sjgpu_ctx *ctx, sjgpu_doc *docs, size_t count) {
+  if (!ctx || (count && !docs) || count > 0xFFFFFFu) { return SJGPU_E_BADARG; }
+  if (count == 0) { return 0; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  // block layout: [results: 16 B each][descriptors: 24 B each][inputs, each rounded to 64 B + 64 B of slack][outputs, 16-byte aligned]
+  size_t in_bytes = 0, out_words = 0;
+  for (size_t i = 0; i < count; i++) {
+    docs[i].n = 0;
+    docs[i].error = 0;
+    if (!docs[i].buf || !docs[i].idx_out || docs[i].len > 0xFFFFFFFFull) { return SJGPU_E_BADARG; }
+    if (docs[i].len == 0) { docs[i].error = E_EMPTY; continue; }
+    if (docs[i].len > ctx->capacity) { docs[i].error = E_CAPACITY; continue; }
+    if (docs[i].idx_words < docs[i].len + 3) { return SJGPU_E_OVERFLOW; }
+    in_bytes += round_up(docs[i].len, 64) + 64;
+    out_words += round_up(docs[i].len + 3, 4);
+  }
+  const size_t res_at = 0, desc_at = round_up(count * sizeof(scan_result_dev), 64), in_at = desc_at + round_up(count * sizeof(doc_desc), 64);
+  const size_t out_at = in_at + in_bytes, total = out_at + out_words * sizeof(uint32_t) + 64;
+  int rc = ensure_small(ctx, total);
+  if (rc) { return rc; }
+  scan_result_dev *results = reinterpret_cast<scan_result_dev *>(ctx->h_small + res_at);
+  doc_desc *descs = reinterpret_cast<doc_desc *>(ctx->h_small + desc_at);
+  size_t in_off = 0, out_off = 0;
+  uint32_t live = 0;
+  for (size_t i = 0; i < count; i++) {
+    if (docs[i].error) { continue; }
+    std::memcpy(ctx->h_small + in_at + in_off, docs[i].buf, docs[i].len);
+    descs[live] = doc_desc{in_off, out_off, uint32_t(docs[i].len), 0};
+    in_off += round_up(docs[i].len, 64) + 64;
+    out_off += round_up(docs[i].len + 3, 4);
+    live++;
+  }
+  if (live == 0) { return 0; }
+  hipStream_t s = ctx->stream;
+  // Small batches are read and written by the kernel across PCIe (no copies at all); larger ones are staged through
+  // HBM with ONE copy in and ONE copy out, so that the workgroups do not all wait on the link at once.
+  const bool zero_copy = total <= (size_t(2) << 20);
+  uint8_t *base = ctx->h_small;
+  if (!zero_copy) {
+    rc = ensure_tmp(ctx, total);
+    if (rc) { return rc; }
+    SJ_TRY(ctx, hipMemcpyAsync(ctx->d_tmp, ctx->h_small, out_at, hipMemcpyHostToDevice, s));
+    base = ctx->d_tmp;
+  }
+  ctx->pending_scan_bytes = 0;
+  ctx->last_kernel = "k_docs<0>";
+  launch_docs(0, base + in_at, reinterpret_cast<const doc_desc *>(base + desc_at), doc_desc{0, 0, 0, 0}, live, base + out_at,
+              reinterpret_cast<scan_result_dev *>(base + res_at), s);
+  SJ_TRY(ctx, hipGetLastError());
+  if (!zero_copy) {
+    SJ_TRY(ctx, hipMemcpyAsync(ctx->h_small + res_at, ctx->d_tmp + res_at, desc_at, hipMemcpyDeviceToHost, s));
+    SJ_TRY(ctx, hipMemcpyAsync(ctx->h_small + out_at, ctx->d_tmp + out_at, out_words * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  }
+  SJ_TRY(ctx, hipStreamSynchronize(s));
+  const uint32_t *out = reinterpret_cast<const uint32_t *>(ctx->h_small + out_at);
+  live = 0;
+  for (size_t i = 0; i < count; i++) {
+    if (docs[i].error) { continue; }
+    const scan_result_dev r = results[live];
+    const doc_desc d = descs[live];
+    live++;
+    docs[i].error = sjgpu_stage1_error_from_flags(r.n, r.flags);
+    if (r.flags & SJGPU_F_IDX_OVERFLOW) { docs[i].error = E_UNEXPECTED; continue; }
+    if (docs[i].error == E_UNCLOSED || docs[i].error == 14) { continue; } // the reference leaves n and the list alone on these two
+    docs[i].n = r.n;
+    std::memcpy(docs[i].idx_out, out + d.out_off, (size_t(r.n) + 3) * sizeof(uint32_t));
+  }
+  return 0;
+}
+
+// No length limit (include/simdjson/implementation.h:116 has none): inputs beyond 4 GiB - 1 go piece by piece, cut where
+// only the in-string bit crosses (sjgpu_clean_cut), exactly like the shards of a document spread over several GPUs.
 int sjgpu_minify(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, uint8_t *dst, size_t *dst_len) {
   if (!ctx || !dst_len) { return SJGPU_E_BADARG; }
   *dst_len = 0;
   if (len == 0) { return 0; }
   if (!buf || !dst) { return SJGPU_E_BADARG; }
-  if (len > ctx->capacity) { return E_CAPACITY; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
-  int rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_in), &ctx->d_in_bytes, ctx->capacity);
-  if (rc) { return rc; }
-  rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_out), &ctx->d_out_bytes, ctx->capacity + 16);
-  if (rc) { return rc; }
-  hipStream_t s = ctx->stream;
-  sjgpu_scan_result res;
-  const bool streamed = take_streamed_path(ctx, len);
-  if (streamed) {
-    rc = run_streamed(ctx, 1, buf, len, dst, len, &res);
+  const size_t piece = piece_bytes();
+  sjgpu_scan_result res{0, 0, 0};
+  if (len <= piece) {
+    const int rc = minify_piece(ctx, buf, len, false, 0, dst, &res);
     if (rc) { return rc; }
-  } else {
-    SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
-    for (int attempt = 0; attempt < 2; attempt++) {
-      enqueue_minify(ctx, use_fused(ctx, len) && attempt == 0, ctx->d_in, len, ctx->d_out, s, nullptr);
-      SJ_TRY(ctx, hipGetLastError());
-      rc = fetch_result(ctx, s, &res);
-      if (rc) { return rc; }
-      if (!(res.flags & SJGPU_F_INTERNAL)) { break; }
-    }
+    if (res.flags & SJGPU_F_UNCLOSED_STRING) { return E_UNCLOSED; }
+    *dst_len = res.out_len;
+    return 0;
   }
-  if (res.flags & SJGPU_F_INTERNAL) { return E_UNEXPECTED; }
-  if (res.flags & SJGPU_F_UNCLOSED_STRING) { return E_UNCLOSED; }
-  if (res.out_len > len) { return E_UNEXPECTED; }
-  if (!streamed) {
-    SJ_TRY(ctx, hipMemcpyAsync(dst, ctx->d_out, res.out_len, hipMemcpyDeviceToHost, s));
-    SJ_TRY(ctx, hipStreamSynchronize(s));
+  size_t at = 0, out = 0;
+  uint32_t in_string = 0;
+  while (at < len) {
+    size_t cut = (len - at <= piece) ? len : sjgpu_clean_cut(buf, len, at + piece);
+    if (cut - at > 0xFFFFFFF0ull) { return E_CAPACITY; } // no clean byte within 4 GiB: not JSON anyone could parse
+    const int rc = minify_piece(ctx, buf + at, cut - at, true, in_string, dst + out, &res);
+    if (rc) { return rc; }
+    out += res.out_len;
+    in_string = res.flags & SJGPU_F_UNCLOSED_STRING;
+    at = cut;
   }
-  *dst_len = res.out_len;
+  if (in_string) { return E_UNCLOSED; } // json_minifier.h:42-47: dst_len stays 0
+  *dst_len = out;
   return 0;
 }
 
+// No length limit either (include/simdjson/implementation.h:128): pieces are cut in front of a character's first byte, so
+// each piece is well-formed or not by itself.
 int sjgpu_validate_utf8(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int *ok) {
   if (!ctx || !ok) { return SJGPU_E_BADARG; }
   *ok = 1;
   if (len == 0) { return 0; }
   if (!buf) { return SJGPU_E_BADARG; }
-  if (len > ctx->capacity) { return E_CAPACITY; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
-  int rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_in), &ctx->d_in_bytes, ctx->capacity);
-  if (rc) { return rc; }
-  hipStream_t s = ctx->stream;
-  SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
-  ctx->pending_scan_bytes = 0;
-  launch_validate_utf8(ctx->d_in, len, ctx->d_result, s, nullptr);
-  SJ_TRY(ctx, hipGetLastError());
-  sjgpu_scan_result res;
-  rc = fetch_result(ctx, s, &res);
-  if (rc) { return rc; }
-  *ok = (res.flags & SJGPU_F_UTF8_ERROR) ? 0 : 1;
+  const size_t piece = piece_bytes();
+  size_t at = 0;
+  while (at < len) {
+    size_t cut = len;
+    if (len - at > piece) {
+      cut = at + piece;
+      int back = 0;
+      while (back < 4 && (buf[cut] & 0xC0u) == 0x80u) { cut--; back++; } // continuation bytes belong to the piece in front
+      if (back == 4) { *ok = 0; return 0; }                                // four in a row: ill-formed whatever precedes them
+    }
+    const int rc = validate_piece(ctx, buf + at, cut - at, ok);
+    if (rc || !*ok) { return rc; }
+    at = cut;
+  }
   return 0;
 }
 

@@ -255,19 +255,14 @@ __device__ __forceinline__ bool utf8_check_block(const u8 *__restrict__ buf, u64
   }
   return bad != 0;
 }
-// validate the n oldest queued blocks (n <= 64 and n <= count), one per lane
+// validate the n NEWEST queued blocks (n <= 64 and n <= count), one per lane; the order of validation is immaterial, and
+// taking them off the end means nothing has to move however long the list has grown
 __device__ __forceinline__ void utf8_drain(utf8_queue &uq, const u8 *__restrict__ buf, u64 len, bool more, u32 lane, u32 n) {
   wave_lds_fence();
   bool bad = false;
-  if (lane < n) { bad = utf8_check_block(buf, len, more, uq.slots[lane]); }
+  if (lane < n) { bad = utf8_check_block(buf, len, more, uq.slots[uq.count - n + lane]); }
   if (__ballot(bad)) { uq.error = 1u; }
-  const u32 rest = uq.count - n; // < 64
-  u32 v = 0;
-  if (lane < rest) { v = uq.slots[n + lane]; }
-  wave_lds_fence();
-  if (lane < rest) { uq.slots[lane] = v; }
-  wave_lds_fence();
-  uq.count = rest;
+  uq.count -= n;
 }
 // after every chunk: keep the list below 64 entries
 __device__ __forceinline__ void utf8_drain_if_full(utf8_queue &uq, const u8 *__restrict__ buf, u64 len, bool more, u32 lane) {

@@ -1,0 +1,382 @@
+// simdjson_amd/csrc/sjgpu_finish.hip -- what the reference does with the structural list AFTER the scan, on the device:
+//
+//   * document boundaries of the streaming modes: "the last value that directly follows another value", and whether the
+//     brackets behind it balance            (/root/reference/src/generic/stage1/find_next_document_index.h:39-98)
+//   * RFC 7464 record separators: drop them, re-insert the scalar starts the scanner glued to them, cut at the last one
+//                                            (find_next_document_index.h:126-267)
+//   * comma-delimited documents: drop the commas at nesting depth 0, cut behind the last one   (:288-369)
+//   * the nesting depth in front of every structural (bracket prefix scan): the first data-parallel slice of stage 2 --
+//     what the reference's tape builder carries as `depth` while it walks the list serially
+//                                            (/root/reference/src/generic/stage2/json_iterator.h, tape_builder.h:108-123)
+//
+// The reference walks the list backwards / compacts it in place on one core.  Here every step is a map over the list, a
+// prefix scan (depth, output slot) or a reduction (last boundary, last separator) -- so it runs where the list lies, needs
+// no PCIe round trip per batch, and an NDJSON / RS / comma stream sharded over several GPUs can find its own cuts.
+// Behaviour is pinned by stage1_finish.cpp (the host implementation, itself pinned against the reference): the two must
+// leave the same words in the index array (tests/test_gpu_parity.py::test_device_finish_*).
+#include "sjgpu_device.h"
+
+namespace sjgpu {
+namespace {
+
+constexpr u32 FIN_THREADS = 256, FIN_PER_THREAD = 16, FIN_BLOCK = FIN_THREADS * FIN_PER_THREAD; // 4096 structurals per workgroup
+
+// structural classes
+enum : u32 { C_OTHER = 0, C_OBJ_OPEN = 1, C_ARR_OPEN = 2, C_OBJ_CLOSE = 3, C_ARR_CLOSE = 4, C_COLON = 5, C_COMMA = 6, C_RS = 7 };
+__device__ __forceinline__ u32 classify_byte(u32 c) {
+  switch (c) {
+  case '{': return C_OBJ_OPEN;
+  case '[': return C_ARR_OPEN;
+  case '}': return C_OBJ_CLOSE;
+  case ']': return C_ARR_CLOSE;
+  case ':': return C_COLON;
+  case ',': return C_COMMA;
+  case 0x1E: return C_RS;
+  default: return C_OTHER;
+  }
+}
+__device__ __forceinline__ bool is_open(u32 k) { return k == C_OBJ_OPEN || k == C_ARR_OPEN; }
+__device__ __forceinline__ bool is_close(u32 k) { return k == C_OBJ_CLOSE || k == C_ARR_CLOSE; }
+__device__ __forceinline__ bool is_sep(u32 k) { return k == C_COLON || k == C_COMMA; }
+__device__ __forceinline__ bool is_ws_byte(u32 c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r'; }
+
+// ---- block-level exclusive scan of one int per thread (256 threads) ----------------------------------------------------
+__device__ __forceinline__ int block_excl_scan256(int v, int *sh /*[8]*/, int &total) {
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const int incl = int(wave_incl_scan(u32(v)));
+  if (lane == 63) { sh[wave] = incl; }
+  __syncthreads();
+  int base = 0;
+  for (u32 w = 0; w < wave; w++) { base += sh[w]; }
+  total = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return base + incl - v;
+}
+
+// ---- generic in-place exclusive scan of an int array, three kernels per level --------------------------------------------
+__global__ __launch_bounds__(FIN_THREADS) void k_scan_blocks(int *__restrict__ a, const u32 *__restrict__ n_ptr, int *__restrict__ partial) {
+  __shared__ int sh[8];
+  const u32 n = *n_ptr;
+  const u64 base = u64(blockIdx.x) * FIN_BLOCK + u64(threadIdx.x) * FIN_PER_THREAD;
+  if (u64(blockIdx.x) * FIN_BLOCK >= n) { if (threadIdx.x == 0) { partial[blockIdx.x] = 0; } return; }
+  int v[FIN_PER_THREAD], sum = 0;
+#pragma unroll
+  for (u32 j = 0; j < FIN_PER_THREAD; j++) {
+    v[j] = (base + j < n) ? a[base + j] : 0;
+    sum += v[j];
+  }
+  int total;
+  int run = block_excl_scan256(sum, sh, total);
+#pragma unroll
+  for (u32 j = 0; j < FIN_PER_THREAD; j++) {
+    if (base + j < n) { a[base + j] = run; }
+    run += v[j];
+  }
+  if (threadIdx.x == 0) { partial[blockIdx.x] = total; }
+}
+// one workgroup: exclusive scan of up to 2^20 partials in place (a second level on top would follow the same pattern;
+// 2^20 blocks of 4096 cover the whole 32-bit index range)
+__global__ __launch_bounds__(1024) void k_scan_partials(int *__restrict__ partial, u32 nblocks) {
+  __shared__ int sh[1024];
+  const u32 per = (nblocks + 1023) / 1024;
+  const u32 lo = min(threadIdx.x * per, nblocks), hi = min(lo + per, nblocks);
+  int sum = 0;
+  for (u32 i = lo; i < hi; i++) { sum += partial[i]; }
+  sh[threadIdx.x] = sum;
+  __syncthreads();
+  for (u32 d = 1; d < 1024; d <<= 1) {
+    const int t = (threadIdx.x >= d) ? sh[threadIdx.x - d] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  int run = sh[threadIdx.x] - sum;
+  for (u32 i = lo; i < hi; i++) {
+    const int x = partial[i];
+    partial[i] = run;
+    run += x;
+  }
+}
+__global__ __launch_bounds__(FIN_THREADS) void k_scan_add(int *__restrict__ a, const u32 *__restrict__ n_ptr, const int *__restrict__ partial) {
+  const u32 n = *n_ptr;
+  const int add = partial[blockIdx.x];
+  const u64 base = u64(blockIdx.x) * FIN_BLOCK + u64(threadIdx.x) * FIN_PER_THREAD;
+#pragma unroll
+  for (u32 j = 0; j < FIN_PER_THREAD; j++) {
+    if (base + j < n) { a[base + j] += add; }
+  }
+}
+
+// ---- maps ---------------------------------------------------------------------------------------------------------------
+// delta[i] = +1 / -1 / 0 for an opening / closing bracket / anything else (nesting depth as ONE counter, the way the
+// reference's comma filter and the tape builder count it)
+__global__ __launch_bounds__(FIN_THREADS) void k_bracket_delta(const u8 *__restrict__ buf, const u32 *__restrict__ idx, const u32 *__restrict__ n_ptr,
+                                                             int *__restrict__ delta) {
+  const u32 n = *n_ptr;
+  const u64 i = u64(blockIdx.x) * FIN_THREADS + threadIdx.x;
+  if (i >= n) { return; }
+  const u32 k = classify_byte(buf[idx[i]]);
+  delta[i] = is_open(k) ? 1 : (is_close(k) ? -1 : 0);
+}
+
+// Last "value directly following a value" among structurals [1, n): atomicMax of its list index + 1 (0 = none).
+__global__ __launch_bounds__(FIN_THREADS) void k_last_boundary(const u8 *__restrict__ buf, const u32 *__restrict__ idx, const u32 *__restrict__ n_ptr,
+                                                             finish_state *__restrict__ st) {
+  const u32 n = *n_ptr;
+  const u64 i = u64(blockIdx.x) * FIN_THREADS + threadIdx.x;
+  bool b = false;
+  if (i >= 1 && i < n) {
+    const u32 cur = classify_byte(buf[idx[i]]), before = classify_byte(buf[idx[i - 1]]);
+    b = !is_sep(cur) && !is_close(cur) && !is_open(before) && !is_sep(before);
+  }
+  const u64 m = __ballot(b);
+  if (m && (threadIdx.x & 63u) == 0) { atomicMax(&st->boundary_plus1, u32(u64(blockIdx.x) * FIN_THREADS + (threadIdx.x & ~63u) + 63u - clz64(m)) + 1u); }
+}
+// Bracket balance of the structurals from the last boundary (or 0) to n, braces and square brackets separately.
+__global__ __launch_bounds__(FIN_THREADS) void k_tail_balance(const u8 *__restrict__ buf, const u32 *__restrict__ idx, const u32 *__restrict__ n_ptr,
+                                                            finish_state *__restrict__ st) {
+  const u32 n = *n_ptr;
+  const u32 from = st->boundary_plus1 ? st->boundary_plus1 - 1 : 0;
+  const u64 i = u64(from) + u64(blockIdx.x) * FIN_THREADS + threadIdx.x;
+  int o = 0, a = 0;
+  if (i < n) {
+    const u32 k = classify_byte(buf[idx[i]]);
+    o = (k == C_OBJ_OPEN) - (k == C_OBJ_CLOSE);
+    a = (k == C_ARR_OPEN) - (k == C_ARR_CLOSE);
+  }
+  const int so = int(wave_sum(u32(o))), sa = int(wave_sum(u32(a)));
+  if ((threadIdx.x & 63u) == 0) {
+    if (so) { atomicAdd(&st->obj_balance, so); }
+    if (sa) { atomicAdd(&st->arr_balance, sa); }
+  }
+}
+// complete_prefix(v, n) of stage1_finish.cpp from the two reductions above
+__global__ void k_resolve_prefix(finish_state *__restrict__ st, const u32 *__restrict__ n_ptr) {
+  if (st->verdict != FIN_SEARCH) { return; } // the filter has already decided (k_after_filter / k_count_below)
+  const u32 n = *n_ptr;
+  const bool balanced = st->obj_balance == 0 && st->arr_balance == 0;
+  st->keep = (n == 0) ? 0u : (balanced ? n : (st->boundary_plus1 ? st->boundary_plus1 - 1 : 0u));
+}
+
+// ---- comma-delimited: keep flag per structural, last root comma ------------------------------------------------------------
+// depth[i] = nesting depth in front of structural i (exclusive scan of k_bracket_delta); keep[i] = 0 for a comma at depth 0
+__global__ __launch_bounds__(FIN_THREADS) void k_comma_flags(const u8 *__restrict__ buf, const u32 *__restrict__ idx, const u32 *__restrict__ n_ptr,
+                                                           const int *__restrict__ depth, int *__restrict__ keep, finish_state *__restrict__ st) {
+  const u32 n = *n_ptr;
+  const u64 i = u64(blockIdx.x) * FIN_THREADS + threadIdx.x;
+  bool root = false;
+  if (i < n) {
+    root = buf[idx[i]] == ',' && depth[i] == 0;
+    keep[i] = root ? 0 : 1;
+  }
+  const u64 m = __ballot(root);
+  if (m && (threadIdx.x & 63u) == 0) {
+    atomicAdd(&st->separators, u32(popc64(m)));
+    atomicMax(&st->last_sep_index_plus1, u32(u64(blockIdx.x) * FIN_THREADS + (threadIdx.x & ~63u) + 63u - clz64(m)) + 1u);
+  }
+}
+
+// ---- record separators -----------------------------------------------------------------------------------------------------
+// first byte behind p that is neither whitespace nor RS (or len); counts the RS bytes passed and remembers the last one
+__device__ __forceinline__ u32 value_behind(const u8 *__restrict__ buf, u32 len, u32 p, u32 &rs_passed, u32 &last_rs) {
+  u32 v = p + 1;
+  for (; v < len; v++) {
+    const u32 c = buf[v];
+    if (c == 0x1E) { rs_passed++; last_rs = v; }
+    else if (!is_ws_byte(c)) { break; }
+  }
+  return v;
+}
+// keep[i] = 1 if list slot i yields an output entry, out_pos[i] = the entry: a non-RS structural as it is; the head of a
+// run of record separators yields the start of the value behind the run when the scanner glued that value to the RS
+__global__ __launch_bounds__(FIN_THREADS) void k_rs_flags(const u8 *__restrict__ buf, u32 len, const u32 *__restrict__ idx, const u32 *__restrict__ n_ptr,
+                                                        int *__restrict__ keep, u32 *__restrict__ out_pos, finish_state *__restrict__ st) {
+  const u32 n = *n_ptr;
+  const u64 i = u64(blockIdx.x) * FIN_THREADS + threadIdx.x;
+  if (i >= n) { return; }
+  const u32 pos = idx[i];
+  if (buf[pos] != 0x1E) {
+    keep[i] = 1;
+    out_pos[i] = pos;
+    return;
+  }
+  keep[i] = 0;
+  out_pos[i] = 0;
+  // absorbed: the record separator in front of this one reaches past it (only whitespace / RS in between)
+  if (i > 0) {
+    const u32 prev = idx[i - 1];
+    if (buf[prev] == 0x1E) {
+      bool only_blank = true;
+      for (u32 q = prev + 1; q < pos; q++) {
+        const u32 c = buf[q];
+        if (c != 0x1E && !is_ws_byte(c)) { only_blank = false; break; }
+      }
+      if (only_blank) { return; }
+    }
+  }
+  u32 rs = 1, last_rs = pos;
+  const u32 value = value_behind(buf, len, pos, rs, last_rs);
+  atomicAdd(&st->separators, rs);
+  atomicMax(&st->last_sep_pos_plus1, last_rs + 1u);
+  if (value < len) {
+    const u32 k = classify_byte(buf[value]);
+    const bool is_operator = k != C_OTHER && k != C_RS;
+    u64 m = i + 1;
+    while (m < n && idx[m] < value) { m++; } // the separators this run absorbed
+    const bool scanner_has_it = m < n && idx[m] == value;
+    if (!is_operator && !scanner_has_it) {
+      keep[i] = 1;
+      out_pos[i] = value;
+    }
+  }
+}
+
+// ---- compaction ------------------------------------------------------------------------------------------------------------
+// slot[i] = exclusive scan of keep; src = the entries (idx itself or k_rs_flags' out_pos); tmp[slot[i]] = src[i] for kept i.
+// keep_flags holds the flags as they were BEFORE the scan turned the array into slots (a copy).
+__global__ __launch_bounds__(FIN_THREADS) void k_scatter(const u32 *__restrict__ src, const int *__restrict__ slot, const u8 *__restrict__ keep_flags,
+                                                       const u32 *__restrict__ n_ptr, u32 *__restrict__ tmp) {
+  const u32 n = *n_ptr;
+  const u64 i = u64(blockIdx.x) * FIN_THREADS + threadIdx.x;
+  if (i < n && keep_flags[i]) { tmp[slot[i]] = src[i]; }
+}
+__global__ __launch_bounds__(FIN_THREADS) void k_flags_to_bytes(const int *__restrict__ keep, const u32 *__restrict__ n_ptr, u8 *__restrict__ flags) {
+  const u32 n = *n_ptr;
+  const u64 i = u64(blockIdx.x) * FIN_THREADS + threadIdx.x;
+  if (i < n) { flags[i] = u8(keep[i]); }
+}
+__global__ __launch_bounds__(FIN_THREADS) void k_copy_back(const u32 *__restrict__ tmp, const u32 *__restrict__ count_ptr, u32 *__restrict__ idx) {
+  const u32 n = *count_ptr;
+  const u64 i = u64(blockIdx.x) * FIN_THREADS + threadIdx.x;
+  if (i < n) { idx[i] = tmp[i]; }
+}
+// kept = slot[n-1] + keep[n-1]; then what filter_root_commas / filter_record_separators decide from the reductions
+// (stage1_finish.cpp).  mode_final: 1 for the *_FINAL modes.  Leaves st->n_cur = the list length the boundary search runs on.
+__global__ void k_after_filter(finish_state *__restrict__ st, const int *__restrict__ slot, const u8 *__restrict__ keep_flags, const u32 *__restrict__ idx,
+                               const u32 *__restrict__ src, u32 len, int is_rs, int mode_final) {
+  const u32 n = st->n_in;
+  const u32 kept = n ? u32(slot[n - 1]) + u32(keep_flags[n - 1]) : 0u;
+  st->kept = kept;
+  st->next_start = len;
+  st->verdict = FIN_SEARCH; // run the boundary search on n_cur entries
+  st->n_cur = kept;
+  st->n_report = kept;
+  if (kept == 0) { st->verdict = FIN_KEEP_GIVEN; st->keep = 0; return; }
+  if (is_rs) {
+    if (st->separators == 0) {
+      if (!mode_final) { st->verdict = FIN_KEEP_GIVEN; st->keep = 0; }
+      return;
+    }
+    if (mode_final) { st->verdict = FIN_KEEP_GIVEN; st->keep = kept; return; }
+    st->next_start = st->last_sep_pos_plus1 - 1;
+    if (st->separators < 2) { st->verdict = FIN_TOO_LARGE; return; }
+    st->verdict = FIN_COUNT_BELOW; // keep = entries of the compacted list in front of the last record separator
+    return;
+  }
+  if (mode_final) { return; }
+  if (st->separators == 0) { st->verdict = FIN_TOO_LARGE; return; }
+  const u32 li = st->last_sep_index_plus1 - 1; // list index of the last root comma
+  st->next_start = idx[li] + 1; // idx is still the un-compacted list here
+  const u32 k = u32(slot[li]);  // kept entries in front of it
+  (void)src;
+  if (k == 0) { st->verdict = FIN_KEEP_GIVEN; st->keep = 0; return; }
+  st->n_cur = k;
+  st->n_report = k;
+}
+// entries of the compacted list (tmp) below a position: the list is ascending, so a count is a search
+__global__ __launch_bounds__(FIN_THREADS) void k_count_below(const u32 *__restrict__ tmp, finish_state *__restrict__ st) {
+  if (st->verdict != FIN_COUNT_BELOW) { return; }
+  const u32 n = st->kept, limit = st->next_start;
+  const u64 i = u64(blockIdx.x) * FIN_THREADS + threadIdx.x;
+  const bool below = i < n && tmp[i] < limit;
+  const u64 m = __ballot(below);
+  if (m && (threadIdx.x & 63u) == 0) { atomicAdd(&st->keep, u32(popc64(m))); }
+}
+
+} // namespace
+
+// ---- host side: enqueue the kernels of one finish ------------------------------------------------------------------------------
+static inline u32 blocks_for(u64 n, u32 per) { return u32((n + per - 1) / per); }
+
+static void enqueue_scan(int *a, u32 n_max, const u32 *n_ptr, int *partial, hipStream_t s) {
+  const u32 nb = blocks_for(n_max, FIN_BLOCK);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(FIN_THREADS), 0, s, a, n_ptr, partial);
+  if (nb > 1) {
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partial, nb);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(FIN_THREADS), 0, s, a, n_ptr, partial);
+  }
+}
+
+size_t finish_workspace_bytes(uint32_t n) {
+  const size_t nn = size_t(n) + 64;
+  // state | scan array (int) | out_pos / tmp (u32) x2 | keep flags (u8) | partials
+  return 256 + nn * 4 + nn * 4 + nn * 4 + nn + (size_t(blocks_for(nn, FIN_BLOCK)) + 64) * 4 + 256;
+}
+
+// boundary search over the first st->n_cur entries of `list`
+static void enqueue_prefix_search(const uint8_t *buf, const uint32_t *list, uint32_t n_max, finish_state *st, hipStream_t s) {
+  const u32 nb = blocks_for(n_max, FIN_THREADS);
+  if (nb == 0) { return; }
+  hipLaunchKernelGGL(k_last_boundary, dim3(nb), dim3(FIN_THREADS), 0, s, buf, list, &st->n_cur, st);
+  hipLaunchKernelGGL(k_tail_balance, dim3(nb), dim3(FIN_THREADS), 0, s, buf, list, &st->n_cur, st);
+  hipLaunchKernelGGL(k_resolve_prefix, dim3(1), dim3(1), 0, s, st, &st->n_cur);
+}
+
+void launch_finish(int mode, const uint8_t *buf, uint64_t len, uint32_t *idx, uint32_t n, void *workspace, hipStream_t s) {
+  uint8_t *w = static_cast<uint8_t *>(workspace);
+  finish_state *st = reinterpret_cast<finish_state *>(w);
+  const size_t nn = size_t(n) + 64;
+  int *scan = reinterpret_cast<int *>(w + 256);
+  u32 *out_pos = reinterpret_cast<u32 *>(w + 256 + nn * 4);
+  u32 *tmp = reinterpret_cast<u32 *>(w + 256 + nn * 8);
+  u8 *flags = w + 256 + nn * 12;
+  int *partial = reinterpret_cast<int *>(w + 256 + nn * 12 + ((nn + 255) & ~size_t(255)));
+  (void)hipMemsetAsync(st, 0, sizeof(finish_state), s); // verdict = FIN_SEARCH, all reductions at their identity
+  (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&st->n_in), int(n), 3, s); // n_in, n_cur, n_report
+  (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&st->next_start), int(u32(len)), 1, s);
+  const bool rs = mode == SJGPU_JSON_SEQUENCE_PARTIAL || mode == SJGPU_JSON_SEQUENCE_FINAL;
+  const bool comma = mode == SJGPU_COMMA_DELIMITED_PARTIAL || mode == SJGPU_COMMA_DELIMITED_FINAL;
+  const bool final_batch = mode == SJGPU_STREAMING_FINAL || mode == SJGPU_JSON_SEQUENCE_FINAL || mode == SJGPU_COMMA_DELIMITED_FINAL;
+  const u32 nb = blocks_for(n, FIN_THREADS);
+  if (!rs && !comma) {
+    enqueue_prefix_search(buf, idx, n, st, s);
+    return;
+  }
+  if (comma) {
+    hipLaunchKernelGGL(k_bracket_delta, dim3(nb), dim3(FIN_THREADS), 0, s, buf, idx, &st->n_in, scan);
+    enqueue_scan(scan, n, &st->n_in, partial, s);
+    int *keep = reinterpret_cast<int *>(out_pos); // the slot array of the compaction (out_pos is unused in this mode)
+    hipLaunchKernelGGL(k_comma_flags, dim3(nb), dim3(FIN_THREADS), 0, s, buf, idx, &st->n_in, scan, keep, st);
+    hipLaunchKernelGGL(k_flags_to_bytes, dim3(nb), dim3(FIN_THREADS), 0, s, keep, &st->n_in, flags);
+    enqueue_scan(keep, n, &st->n_in, partial, s);
+    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(FIN_THREADS), 0, s, idx, keep, flags, &st->n_in, tmp);
+    hipLaunchKernelGGL(k_after_filter, dim3(1), dim3(1), 0, s, st, keep, flags, idx, idx, u32(len), 0, final_batch ? 1 : 0);
+  } else {
+    int *keep = scan;
+    hipLaunchKernelGGL(k_rs_flags, dim3(nb), dim3(FIN_THREADS), 0, s, buf, u32(len), idx, &st->n_in, keep, out_pos, st);
+    hipLaunchKernelGGL(k_flags_to_bytes, dim3(nb), dim3(FIN_THREADS), 0, s, keep, &st->n_in, flags);
+    enqueue_scan(keep, n, &st->n_in, partial, s);
+    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(FIN_THREADS), 0, s, out_pos, keep, flags, &st->n_in, tmp);
+    hipLaunchKernelGGL(k_after_filter, dim3(1), dim3(1), 0, s, st, keep, flags, idx, out_pos, u32(len), 1, final_batch ? 1 : 0);
+    hipLaunchKernelGGL(k_count_below, dim3(nb), dim3(FIN_THREADS), 0, s, tmp, st);
+  }
+  hipLaunchKernelGGL(k_copy_back, dim3(nb), dim3(FIN_THREADS), 0, s, tmp, &st->kept, idx);
+  // the boundary search of the modes that still need one runs on the compacted list; k_resolve_prefix's answer is only
+  // taken when the verdict says so (finish_state::verdict)
+  enqueue_prefix_search(buf, idx, n, st, s);
+}
+
+// depth[i] = nesting depth in front of structural i, i in [0, n]  (depth[n] = depth behind the last one); scratch holds
+// blocks_for(n + 1) + 1 ints and one u32
+void launch_depth_scan(const uint8_t *buf, const uint32_t *idx, uint32_t n, int32_t *depth, void *scratch, hipStream_t s) {
+  u32 *n_ptr = static_cast<u32 *>(scratch);
+  int *partial = reinterpret_cast<int *>(n_ptr + 4);
+  const u32 n1 = n + 1;
+  (void)hipMemsetAsync(depth + n, 0, sizeof(int32_t), s); // the extra slot carries no delta
+  (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(n_ptr), int(n), 1, s);
+  (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(n_ptr + 1), int(n1), 1, s);
+  if (n) { hipLaunchKernelGGL(k_bracket_delta, dim3(blocks_for(n, FIN_THREADS)), dim3(FIN_THREADS), 0, s, buf, idx, n_ptr, depth); }
+  enqueue_scan(depth, n1, n_ptr + 1, partial, s);
+}
+
+} // namespace sjgpu

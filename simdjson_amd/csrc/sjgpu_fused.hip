@@ -374,16 +374,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // Progress: a workgroup still publishes the aggregate of every tile it holds before it waits for anyone, and all its
   // waits are on smaller tile numbers; the owner of the smallest unpublished tile is therefore never blocked.
   u32 next_ticket = 0;
-  if (threadIdx.x == 0) { sh_tile[0] = atomicAdd(ticket, 1u); }
+  const bool early = (org.carry & CARRY_DEBUG_LATE_TICKET) == 0;
+  if (threadIdx.x == 0 && early) { sh_tile[0] = atomicAdd(ticket, 1u); }
   for (u32 iter = 0;; iter++) {
     const u32 cur = iter & 1u;
     SJ_PSTAMP(0);
+    if (!early && threadIdx.x == 0) { sh_tile[cur] = atomicAdd(ticket, 1u); }
     __syncthreads();
     const u32 tile = sh_tile[cur];
     const bool have = tile < ntiles;
     const bool pend = pend_tile != NO_TILE;
     if (!have && !pend) { break; }
-    if (threadIdx.x == 0 && have) { next_ticket = atomicAdd(ticket, 1u); } // consumed at the end of this iteration
+    if (threadIdx.x == 0 && have && early) { next_ticket = atomicAdd(ticket, 1u); } // consumed at the end of this iteration
     SJ_PSTAMP(1);
 
     // ---- scan the new tile into the register FIFO ------------------------------------------------------------
@@ -571,7 +573,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       sh_mask_a[wave][3][lane] = a0; sh_mask_b[wave][3][lane] = b0;
     }
     pend_tile = have ? tile : NO_TILE;
-    if (threadIdx.x == 0) { sh_tile[cur ^ 1u] = have ? next_ticket : NO_TILE; } // visible behind the barrier at the loop top
+    if (threadIdx.x == 0 && early) { sh_tile[cur ^ 1u] = have ? next_ticket : NO_TILE; } // visible behind the barrier at the loop top
     SJ_PSTAMP(7);
   }
   if (OP == 0) { // what is left of the wave's UTF-8 list, then its verdict
@@ -656,6 +658,8 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
     const u32 cap = (ntiles + 1) / 2;
     const u32 grid = cap < max_workgroups ? cap : max_workgroups;
     static const bool prefetch = []() { const char *v = std::getenv("SJGPU_PREFETCH"); return !v || v[0] != '0'; }(); // A/B switch
+    static const bool late_ticket = std::getenv("SJGPU_LATE_TICKET") != nullptr;                                       // A/B switch
+    if (late_ticket) { org.carry |= CARRY_DEBUG_LATE_TICKET; }
     if (op == 0 && prefetch) {
       hipLaunchKernelGGL((k_fused_pipelined<0, true>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result, org);
     } else if (op == 0) {

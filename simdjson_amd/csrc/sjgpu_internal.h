@@ -77,6 +77,7 @@ constexpr int PROFILE_EVENTS = PROFILE_SLOTS + 1;
 constexpr uint32_t CARRY_IN_STRING = 1u; // the first byte scanned is inside a string
 constexpr uint32_t CARRY_SHARD = 2u;     // minify: report out_len even if the scan ends inside a string
 constexpr uint32_t CARRY_MORE = 4u;      // the scan does not end at the end of the input: no "sequence open at EOF" check
+constexpr uint32_t CARRY_DEBUG_LATE_TICKET = 0x100u; // A/B switch of the pipelined kernel (env SJGPU_LATE_TICKET)
 // A scan covers bytes [begin, len) of a buffer whose bytes [0, begin) are resident too (the look-back of escapes,
 // previous scalar and UTF-8 state reads them); begin is a multiple of RANGE_ALIGN.  Offsets stay relative to byte 0
 // and are appended at output slot base0.  A whole document is {0, 0, 0}.
@@ -111,7 +112,10 @@ inline bool wants_escape_table(uint64_t scanned_bytes) { return scanned_bytes > 
 inline bool wants_escape_table(uint64_t scanned_bytes, const scan_origin &org) {
   return scanned_bytes > FUSED_SMALL_BELOW || org.begin > 0 || (org.carry & CARRY_MORE) != 0;
 }
-void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *result, hipStream_t stream, hipEvent_t *ev);
+// bytes [begin, len) of buf; begin > 0 (a multiple of 4 KiB): a later range of a resident buffer, the flags add up in *result;
+// more: the input continues behind len
+void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *result, hipStream_t stream, hipEvent_t *ev,
+                          uint64_t begin = 0, bool more = false);
 // single-pass variants: desc holds num_fused_tiles(capacity)+1 words; only profile slot 0 is used
 const char *launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
                                 scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
@@ -119,6 +123,41 @@ const char *launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc
 void launch_stage1_fused_traced(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
                                 scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, uint64_t *trace,
                                 uint32_t trace_tiles); // 8 wall_clock64 stamps (100 MHz) per tile
+// ---- the structural list after the scan (sjgpu_finish.hip) ----------------------------------------------------------------
+enum : uint32_t { FIN_SEARCH = 0, FIN_KEEP_GIVEN = 1, FIN_TOO_LARGE = 2, FIN_COUNT_BELOW = 3 };
+struct finish_state {            // device-resident, zero-initialised; read back by the host once the kernels are done
+  uint32_t n_in, n_cur, n_report; // structurals handed in / the boundary search runs on / the reference's `n` after the filter
+  uint32_t next_start;            // where the next batch begins (len unless a separator says otherwise)
+  uint32_t kept, keep, verdict;   // compacted length; structurals of complete documents; FIN_*
+  uint32_t separators, last_sep_index_plus1, last_sep_pos_plus1; // root commas / record separators seen
+  uint32_t boundary_plus1;        // list index + 1 of the last value that directly follows a value
+  int32_t obj_balance, arr_balance;
+  uint32_t pad[3];
+};
+size_t finish_workspace_bytes(uint32_t n);
+// modes 1..6 of sjgpu_stage1_mode on the n raw structurals idx[0..n) (n > 0) of buf[0..len): filters the list in place
+// (json_sequence / comma_delimited) and leaves the decision in the finish_state at the start of `workspace`
+void launch_finish(int mode, const uint8_t *buf, uint64_t len, uint32_t *idx, uint32_t n, void *workspace, hipStream_t stream);
+// depth[i] = nesting depth in front of structural i for i in [0, n], depth[n] = behind the last; scratch: 64 + 4 * (n / 4096 + 2) bytes
+void launch_depth_scan(const uint8_t *buf, const uint32_t *idx, uint32_t n, int32_t *depth, void *scratch, hipStream_t stream);
+
+// ---- one workgroup per document (sjgpu_small.hip) ---------------------------------------------------------------------
+// in_off: byte offset of the document in the input block (a multiple of 64); out_off: first output unit of the document in
+// the output block (stage 1: words, a multiple of 4, room for len + 3; minify: bytes, a multiple of 16, room for len)
+struct doc_desc {
+  uint64_t in_off;
+  uint64_t out_off;
+  uint32_t len;
+  uint32_t flags;
+};
+constexpr uint32_t DOC_KEEP_UNCLOSED = 1u; // minify: report out_len even if the document ends inside a string
+// documents up to this size take the one-workgroup kernel when they come one by one (sjgpu_stage1 & co.)
+constexpr size_t DOCS_SINGLE_MAX = size_t(64) << 10;
+// op 0 stage 1, 1 minify, 2 validate_utf8; docs == nullptr: one document, described by `single`.  in_base / out_base /
+// results may be device memory or page-locked host memory (the kernel then moves the bytes across PCIe itself).
+void launch_docs(int op, const uint8_t *in_base, const doc_desc *docs, doc_desc single, uint32_t count, void *out_base,
+                 scan_result_dev *results, hipStream_t stream);
+
 uint32_t launch_stage1_pipelined_traced(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
                                         scan_result_dev *result, uint8_t *esc_workspace, uint32_t max_workgroups, hipStream_t stream,
                                         uint64_t *trace, uint32_t max_records); // -> workgroups launched (32 records of 8 stamps each)

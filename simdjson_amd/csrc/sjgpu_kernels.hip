@@ -375,11 +375,14 @@ __global__ __launch_bounds__(64) void k_minify_emit(const u8 *__restrict__ buf, 
 // =====================================================================================================
 // validate_utf8: stateless (3-byte look-back), pure HBM read
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_validate_utf8(const u8 *__restrict__ buf, u64 len, scan_result_dev *__restrict__ result) {
+// Bytes [begin, len) of buf (begin a multiple of the chunk size; the bytes in front of it are resident and were checked
+// by an earlier launch); `more`: the input continues behind len, no end-of-input rule.
+__global__ __launch_bounds__(64) void k_validate_utf8(const u8 *__restrict__ buf, u64 len, scan_result_dev *__restrict__ result, u64 begin,
+                                                      u32 more) {
   const u32 lane = lane_id();
   const u64 nchunks = (len + CHUNK_BYTES - 1) / CHUNK_BYTES;
   bool bad = false;
-  for (u64 ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+  for (u64 ch = begin / CHUNK_BYTES + blockIdx.x; ch < nchunks; ch += gridDim.x) {
     const u64 cstart = ch * CHUNK_BYTES;
     const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
     u32 w[16];
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(64) void k_validate_utf8(const u8 *__restrict__ buf
     u32 ci = __shfl_up(co, 1);
     if (lane == 0) { ci = c0; }
     if (utf8_errors(P, L, ci) != 0) { bad = true; }
-    if (ch == nchunks - 1 && (readlane(co, 63) & UTF8_CARRY_OPEN)) { bad = true; } // sequence open at EOF
+    if (ch == nchunks - 1 && !more && (readlane(co, 63) & UTF8_CARRY_OPEN)) { bad = true; } // sequence open at EOF
   }
   if (__ballot(bad) && lane == 0) { atomicOr(&result->flags, SJGPU_F_UTF8_ERROR); }
 }
@@ -533,12 +536,13 @@ void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_pref
   mark(ev, 3, stream);
 }
 
-void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *result, hipStream_t stream, hipEvent_t *ev) {
+void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *result, hipStream_t stream, hipEvent_t *ev, uint64_t begin,
+                          bool more) {
   mark(ev, 0, stream);
-  (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
-  const u64 nchunks = (len + CHUNK_BYTES - 1) / CHUNK_BYTES;
+  if (begin == 0) { (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream); } // later ranges add to the flags
+  const u64 nchunks = (len - begin + CHUNK_BYTES - 1) / CHUNK_BYTES;
   const u32 grid = u32(nchunks < 8192 ? nchunks : 8192); // 256 CUs x 32 single-wave workgroups, grid-stride beyond
-  hipLaunchKernelGGL(k_validate_utf8, dim3(grid), dim3(64), 0, stream, buf, len, result);
+  hipLaunchKernelGGL(k_validate_utf8, dim3(grid), dim3(64), 0, stream, buf, len, result, begin, more ? 1u : 0u);
   mark(ev, 1, stream);
   mark(ev, 2, stream);
   mark(ev, 3, stream);

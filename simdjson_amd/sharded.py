@@ -149,6 +149,47 @@ def scan_document_shard(buf: np.ndarray, rank: int, world: int, scanner, group=N
     return ShardScan(lo, hi - lo, n, flags, idx)
 
 
+def gather_to_root(local: ShardScan, root=0, group=None):
+    """Concatenate all ranks' structural positions on ONE rank, moving exactly the offsets that exist ("one
+    variable-length gather of index arrays"): an all_gather of (count, base) -- 16 bytes per rank -- then every rank
+    sends its n uint32 offsets to `root`, which receives them straight into their final place and widens them to global
+    64-bit positions there (base + offset, document_stream-inl.h:250's convention).  Nothing is padded, nobody but the
+    root materialises the list, and the wire carries 4 bytes per structural, not 8.
+    Returns (positions int64 [sum n] on the root, None elsewhere; per-rank counts)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    idx = local.idx
+    if isinstance(idx, np.ndarray):
+        idx = torch.from_numpy(idx.astype(np.int64).astype(np.int32) if idx.dtype != np.int32 else idx)
+    dev = idx.device
+    meta = torch.tensor([local.n, local.base], dtype=torch.int64, device=dev)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    counts = [int(m[0]) for m in metas]
+    bases = [int(m[1]) for m in metas]
+    if rank != root:
+        if local.n:
+            dist.send(idx[: local.n].contiguous(), dst=root, group=group)
+        return None, counts
+    total = sum(counts)
+    raw = torch.empty(total, dtype=torch.int32, device=dev)
+    at = 0
+    pending = []
+    for r in range(world):
+        if counts[r]:
+            if r == root:
+                raw[at: at + counts[r]] = idx[: counts[r]]
+            else:
+                pending.append(dist.irecv(raw[at: at + counts[r]], src=r, group=group))
+        at += counts[r]
+    for w in pending:
+        w.wait()
+    base_of = torch.repeat_interleave(torch.tensor(bases, dtype=torch.int64, device=dev), torch.tensor(counts, dtype=torch.int64, device=dev))
+    return (raw.to(torch.int64) & 0xFFFFFFFF) + base_of, counts
+
+
 def gather_global_indices(local: ShardScan, group=None, document=False):
     """Concatenate all ranks' structural positions as global int64 offsets (every rank gets the result).
 

@@ -17,12 +17,34 @@ pytestmark = pytest.mark.gpu
 CAP = 128 << 20
 
 
-@pytest.fixture(scope="module", params=["fused", "split"])
+def _parser(kind, capacity=CAP):
+    """kind: "fused" / "split" = that tile pipeline for EVERY document (the one-workgroup kernel for small documents
+    switched off, streaming modes finished on the host); "docs" = the defaults (documents up to 64 KiB take the
+    one-workgroup kernel, sjgpu_small.hip); "device_finish" = tile pipelines + every streaming-mode call finished on
+    the device (sjgpu_finish.hip).  The switches are read when the context is made."""
+    env = {"fused": {"SJGPU_SMALL_DOCS": "0", "SJGPU_FINISH": "host"}, "split": {"SJGPU_SMALL_DOCS": "0", "SJGPU_FINISH": "host"},
+           "docs": {}, "device_finish": {"SJGPU_SMALL_DOCS": "0", "SJGPU_FINISH": "device"}}[kind]
+    old = {k: os.environ.get(k) for k in ("SJGPU_SMALL_DOCS", "SJGPU_FINISH")}
+    for k in old:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    try:
+        p = capi.DomParserImplementation(capacity)  # raises loudly if the HIP library or the GPU is missing
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    p.set_pipeline({"fused": "fused", "split": "split"}.get(kind, "auto"))
+    return p
+
+
+@pytest.fixture(scope="module", params=["fused", "split", "docs", "device_finish"])
 def gpu(request):
-    """Both device pipelines must be bit-exact: the single-pass kernel and the 3-kernel split pipeline."""
+    """Every route a document can take must be bit-exact: the single-pass kernels, the 3-kernel split pipeline, the
+    one-workgroup kernel for small documents, and the device-side finish of the streaming modes."""
     build.build_sjgpu()
-    p = capi.DomParserImplementation(CAP)  # raises loudly if the HIP library or the GPU is missing
-    p.set_pipeline(request.param)
+    p = _parser(request.param)
     yield p
     p.close()
 
@@ -323,6 +345,253 @@ def test_three_gib_offsets_do_not_wrap(orc):
         p.close()
 
 
+def test_dense_non_ascii_text_with_errors(orc):
+    """Every block holds multi-byte characters (the UTF-8 list fills up several times per span and is drained 64 blocks at
+    a time); one broken byte anywhere must be found, by every route."""
+    rng = np.random.default_rng(123)
+    unit = ('"' + "\u65e5\u672c\u8a9e\u30c6\u30ad\u30b9\u30c8 \U0001F600 caf\u00e9 " * 40 + '",\n').encode()
+    doc = np.frombuffer(b"[" + unit * (24 << 20 // len(unit) // 1) + b"0]", np.uint8) if False else np.frombuffer(b"[" + unit * ((24 << 20) // len(unit)) + b"0]", np.uint8)
+    for kind in ("fused", "split", "docs"):
+        p = _parser(kind, 32 << 20)
+        assert_same_all(p, orc, doc, f"{kind}: dense non-ASCII, valid")
+        for trial in range(6):
+            bad = doc.copy()
+            pos = int(rng.integers(2, len(bad) - 2))
+            bad[pos] = [0xFF, 0xC0, 0x80, 0xED, 0xF5, 0xE0][trial]
+            assert_same_all(p, orc, bad, f"{kind}: dense non-ASCII, byte {pos} broken")
+        small = doc[: 50_000].copy()  # the one-workgroup kernel / 16 KiB tiles
+        small[-1] = ord("]")
+        small[37_001] = 0xFF
+        assert_same_all(p, orc, small, f"{kind}: dense non-ASCII, 50 KB")
+        p.close()
+
+
+def test_pipelined_kernels_are_deterministic(orc):
+    """Tile order, ticket order and look-back timing vary from run to run; the output must not."""
+    import torch
+    a = corpus.twitter_like(300 << 20, 17)[0]
+    _, mini = orc.minify(a)
+    L = len(mini)
+    oerr, on, oidx = orc.stage1(mini, 0)
+    want_idx = orc.fnv(oidx)
+    p = capi.DomParserImplementation(L)
+    p.set_pipeline("fused")
+    buf = torch.from_numpy(mini.copy()).cuda()
+    idx = torch.empty(L + 16, dtype=torch.int32, device="cuda")
+    dst = torch.empty(L + 64, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for rep in range(12):
+        assert p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, stream) == 0
+        n, flags, _ = p.result(stream)
+        assert (n, flags) == (on, 0), (rep, n, on, flags)
+        assert orc.fnv(idx[: n + 3].cpu().numpy().view(np.uint32)) == want_idx, rep
+        assert p.minify_device(buf.data_ptr(), L, dst.data_ptr(), stream) == 0
+        _, mflags, mlen = p.result(stream)
+        assert (mlen, mflags) == (L, 0), (rep, mlen, L, mflags)  # minified text is its own minification
+        assert bool((dst[:L] == buf).all()), rep
+    p.close()
+
+
+# ---- many small documents in one launch (sjgpu_small.hip, sjgpu_stage1_many) --------------------------------------------------
+def test_many_small_documents_in_one_launch(orc):
+    rng = np.random.default_rng(77)
+    p = capi.DomParserImplementation(1 << 20)
+    tw = corpus.twitter_like(400_000, 9)[0]
+    docs = [b"", b"[1]", b'{"a":"b"}', b'["unclosed', b'["ctrl \x01 inside"]', b"\xff", b'["bad utf8 \xff"]', b"   ", bytes(tw[:70_000]), bytes(tw[:16384]),
+            bytes(tw[:16385]), bytes(tw[:4096]), bytes(tw[:4095]), b'"' + b"\\" * 5000 + b'"', b'["' + "\u65e5\u672c\u8a9e".encode() * 3000 + b'"]']
+    for k in range(200):
+        n = int(rng.integers(1, 3000))
+        docs.append(bytes(corpus.random_adversarial(n, 9000 + k, ascii_only=bool(k % 2), p_backslash=(0.0, 0.2)[k % 2])))
+    for k in range(40):
+        docs.append(_random_document(rng, int(rng.choice([100, 3000, 40000]))))
+    docs.append(b"x" * (2 << 20))  # beyond the capacity of this context
+    for batch in (docs, docs[:5], docs[8:9] * 40):  # the middle one travels zero-copy, the others are staged through HBM
+        got = p.stage1_many(batch)
+        assert len(got) == len(batch)
+        for d, (err, n, idx) in zip(batch, got):
+            if len(d) > (1 << 20):
+                assert err == capi.CAPACITY
+                continue
+            oerr, on, oidx = orc.stage1(d, 0)
+            assert err == oerr, (d[:40], err, oerr)
+            if checkers.observable(d, 0, oerr, on, oidx)[1:]:
+                assert n == on and np.array_equal(idx, oidx), (d[:40], n, on)
+    p.close()
+
+
+def test_contexts_are_cheap_to_make(orc):
+    """The reference makes a dom_parser_implementation per parser object (its document_stream tests: 106 000 of them):
+    contexts come from a pool, and a small document is one launch and one wait."""
+    import time
+    doc = b'{"k":[1,2,3],"s":"text"}'
+    want = orc.stage1(doc, 0)
+    p = capi.DomParserImplementation(1000)
+    p.stage1(doc, 0)
+    p.close()
+    t0 = time.perf_counter()
+    for _ in range(3000):
+        p = capi.DomParserImplementation(1000)
+        err = p.stage1(doc, 0)
+        assert err == want[0] and p.n_structural_indexes == want[1]
+        p.close()
+    dt = time.perf_counter() - t0
+    assert dt < 3.0, f"3000 x (make a context, scan 24 bytes, drop it) took {dt:.2f} s"
+
+
+# ---- the list after the scan, on the device (sjgpu_finish.hip) --------------------------------------------------------------------
+def _stream_shapes():
+    nd = corpus.amazon_ndjson(2 << 20, 5)[0]
+    lines = [bytes(l) for l in bytes(nd[:300_000]).split(b"\n") if l]
+    tw = corpus.twitter_like(300_000, 3)[0]
+    shapes = {
+        "ndjson": bytes(nd), "ndjson cut inside a line": bytes(nd[:-777]), "ndjson cut inside a string": bytes(nd[: len(nd) - 60]) + b' "dangling',
+        "one big document": bytes(tw), "one big document, truncated": bytes(tw[:-500]), "leading blanks then a truncated document": b"   \n " + bytes(tw[:-500]),
+        "rs": b"".join(b"\x1e" + l + b"\n" for l in lines), "rs cut": b"".join(b"\x1e" + l + b"\n" for l in lines)[:-300],
+        "rs runs": b"\x1e \x1e\x1e\n".join(lines[:200]) + b"\x1e", "rs glued scalars": b"\x1e1 \x1e true\x1e\x1e\"s\" \x1e[1]\x1e 2.5",
+        "rs single": b"\x1e" + lines[0], "no rs at all": b" ".join(lines[:50]),
+        "commas": b",".join(lines), "commas cut": b",".join(lines)[:-300], "commas nested only": b"[" + b",".join(lines[:50]) + b"]",
+        "commas and blanks": b" , ".join(lines[:300]) + b" ,", "single value": b"12345", "two scalars": b"1 2", "unbalanced": b"{[}] 1",
+        "closers first": b"]} {\"a\":1} [", "bad utf8": b'{"a":"\xff"} {"b":1} {"c"',
+    }
+    return shapes
+
+
+def test_device_finish_equals_host_finish(orc):
+    """All six streaming modes: the device-side filters / boundary search against the oracle (= the reference's finish()),
+    through sjgpu_stage1 with SJGPU_FINISH=device and through the device-resident sjgpu_stage1_finish_device."""
+    import torch
+    p = _parser("device_finish", 8 << 20)
+    q = _parser("fused", 8 << 20)  # raw scans for the device-resident API
+    stream = torch.cuda.current_stream().cuda_stream
+    for name, data in _stream_shapes().items():
+        a = checkers.as_u8(data)
+        for mode in range(1, 7):
+            assert_same_stage1(p, orc, a, mode, f"device finish: {name}")
+            # device-resident: scan, then finish where the list lies
+            ln = checkers.trim_partial_utf8_len(a)
+            if ln == 0:
+                continue
+            buf = torch.from_numpy(a[:ln].copy()).cuda()
+            idx = torch.zeros(ln + 16, dtype=torch.int32, device="cuda")
+            assert q.stage1_device(buf.data_ptr(), ln, idx.data_ptr(), ln + 3, stream) == 0
+            n_raw, flags, _ = q.result(stream)
+            want = checkers.observable(a, mode, *orc.stage1(a, mode))
+            if flags & capi.F_UNESCAPED_CTRL:
+                continue
+            err, n, nxt = q.stage1_finish_device(buf.data_ptr(), ln, mode, idx.data_ptr(), n_raw, flags, stream)
+            got = (err,) if err in checkers.EARLY else (err, n, tuple(int(x) & 0xFFFFFFFF for x in idx[: n + 3].cpu().numpy()))
+            assert got == want, (name, mode, got[:2], want[:2])
+    p.close()
+    q.close()
+
+
+def test_depth_scan(orc):
+    """depth[i] = containers open in front of structural i (the `depth` of the reference's stage 2), as a prefix scan on
+    the device; checked against a running count over the reference's own structural list."""
+    import torch
+    p = capi.DomParserImplementation(64 << 20)
+    stream = torch.cuda.current_stream().cuda_stream
+    ex = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jsonexamples")
+    docs = {"twitter.json": np.fromfile(os.path.join(ex, "twitter.json"), dtype=np.uint8), "citm": np.fromfile(os.path.join(ex, "citm_catalog.json"), dtype=np.uint8),
+            "large_random 20 MiB": corpus.large_random(20 << 20, 4)[0], "deep_nesting": corpus.deep_nesting(1 << 20),
+            "unbalanced": np.frombuffer(b"]]}{[[ 1, 2 ]", np.uint8), "scalar": np.frombuffer(b"17", np.uint8)}
+    for name, a in docs.items():
+        L = len(a)
+        buf = torch.from_numpy(a.copy()).cuda()
+        idx = torch.empty(L + 16, dtype=torch.int32, device="cuda")
+        assert p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, stream) == 0
+        n, flags, _ = p.result(stream)
+        oidx, _ = orc.scan(a)
+        assert n == len(oidx)
+        depth = torch.full((n + 1,), -99, dtype=torch.int32, device="cuda")
+        p.depth_scan_device(buf.data_ptr(), idx.data_ptr(), n, depth.data_ptr(), stream)
+        got = depth.cpu().numpy()
+        c = a[oidx]
+        delta = np.isin(c, [ord("{"), ord("[")]).astype(np.int64) - np.isin(c, [ord("}"), ord("]")]).astype(np.int64)
+        want = np.concatenate([[0], np.cumsum(delta)])
+        assert np.array_equal(got, want), (name, first_diff(got, want))
+        if name in ("twitter.json", "citm", "large_random 20 MiB", "deep_nesting"):
+            assert want[-1] == 0 and want.min() == 0  # a valid document closes what it opens
+    p.close()
+
+
+# ---- inputs beyond one scan: pieces (sjgpu_minify / sjgpu_validate_utf8 have no length limit) -----------------------------------
+def test_minify_and_validate_in_pieces(orc, monkeypatch):
+    """What inputs of 4 GiB and more go through, forced onto small inputs with 1 MiB pieces: minify cut where only the
+    in-string bit crosses, validate_utf8 cut in front of a character's first byte."""
+    monkeypatch.setenv("SJGPU_PIECE_MB", "1")
+    p = capi.DomParserImplementation(64 << 20)
+    tw = corpus.twitter_like(5 << 20, 21)[0]
+    M = 1 << 20
+    docs = {"twitter_like 5 MiB": tw, "ends inside a string": np.concatenate([tw[: 3 << 20], np.frombuffer(b' "dangling', np.uint8)]),
+            "one string across three pieces": np.frombuffer(b'["' + b"lorem ipsum \\\" dolor " * 150000 + b'", 1]', np.uint8),
+            "no clean byte for two pieces": np.frombuffer(b'["' + b"x" * (2 * M + 17) + b'"] ' * 3, np.uint8)}
+    for shift in range(0, 5):  # multi-byte characters straddling the piece boundary at every phase
+        docs[f"4-byte characters at the boundary (-{shift})"] = np.frombuffer(b'["' + b"a" * (M - 2 - shift) + "\U0001F600".encode() * 50000 + b'"]', np.uint8)
+    bad = tw.copy()
+    bad[M - 1] = 0xF0
+    docs["truncated lead at a piece boundary"] = bad
+    bad2 = tw.copy()
+    bad2[2 * M - 2: 2 * M + 3] = 0x80
+    docs["five continuation bytes across a boundary"] = bad2
+    for name, a in docs.items():
+        gerr, gout = p.minify(a)
+        oerr, oout = orc.minify(a)
+        assert gerr == oerr and np.array_equal(gout, oout), (name, gerr, oerr, len(gout), len(oout))
+        assert p.validate_utf8(a) == orc.validate_utf8(a), name
+    p.close()
+
+
+def test_huge_inputs_have_no_length_limit(orc):
+    """validate_utf8 / minify of more than 4 GiB - 1 bytes (the reference's free functions take any size_t)."""
+    size = int(os.environ.get("SJGPU_HUGE_FREE_SIZE", str((4 << 30) + (64 << 20))))
+    if size == 0:
+        pytest.skip("disabled")
+    a = corpus.amazon_ndjson(size, 41)[0]
+    assert len(a) > 0xFFFFFFFF
+    p = capi.DomParserImplementation(1 << 20)  # the parser's capacity does not bound the free functions
+    assert p.validate_utf8(a)
+    gerr, gout = p.minify(a)
+    assert gerr == 0
+    step = 1 << 30
+    at = 0
+    for b in range(0, len(a), step):  # the oracle piece by piece at line boundaries (NDJSON: every line is a document)
+        e = min(b + step, len(a))
+        while e < len(a) and a[e - 1] != 0x0A:
+            e += 1
+        if b > 0:
+            while a[b - 1] != 0x0A:
+                b += 1
+        oerr, oout = orc.minify(a[b:e])
+        assert oerr == 0 and np.array_equal(gout[at: at + len(oout)], oout), b
+        at += len(oout)
+    assert at == len(gout)
+    a[len(a) // 2] = 0xFF
+    assert not p.validate_utf8(a)
+    p.close()
+
+
+def test_page_locked_host_memory():
+    """sjgpu_host_alloc / sjgpu_host_register: documents and index arrays in page-locked memory (include/sjgpu.h)."""
+    import ctypes
+    L = capi.load_library()
+    a, _ = corpus.twitter_like(3 << 20, 5)
+    n = len(a)
+    ptr = L.sjgpu_host_alloc(n)
+    assert ptr
+    ctypes.memmove(ptr, a.ctypes.data, n)
+    pinned = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(n,))
+    p = capi.DomParserImplementation(n)
+    capi.host_register(p.structural_indexes)
+    err = p.stage1(pinned, 0)
+    want = checkers.Oracle().stage1(a, 0)
+    assert (err, p.n_structural_indexes) == want[:2] and np.array_equal(p.structural_indexes[: want[1] + 3], want[2])
+    capi.host_unregister(p.structural_indexes)
+    p.close()
+    L.sjgpu_host_free(ptr)
+    assert L.sjgpu_host_register(None, 10) == -4 and L.sjgpu_host_unregister(None) == -4
+
+
 def test_capacity_and_empty_guards(gpu):
     small = capi.DomParserImplementation(16)
     assert small.stage1(b"[1,2,3,4,5,6,7,8,9,10]") == capi.CAPACITY
@@ -489,6 +758,47 @@ def test_ranges_equal_the_whole_scan(gpu, orc):
                 assert np.array_equal(got, omin), (name, chunk, first_diff(got, omin))
 
 
+def test_short_ranges_get_the_escape_table(orc, monkeypatch):
+    """A backslash run that crosses a short-then-long range boundary, and a streamed document whose tail range is short:
+    every range of a larger buffer builds the escape table (a short range used to skip it, its look-back then
+    walked over all earlier ranges, and a later range could resolve a pass entry through an entry nobody had written)."""
+    import time
+    import torch
+    stream = torch.cuda.current_stream().cuda_stream
+    M = 1 << 20
+    # ranges of 2 MiB (short: no table of their own before the fix) then 10 MiB; a 96 KiB backslash run straddles the cut
+    head = b'["' + b"a" * (2 * M - 2 - 40000)
+    body = b"\\" * 98305 + b'x", "tail", ' + b'{"k": [1, 2, 3]}, ' * 600000 + b'"end"]'
+    a = np.frombuffer(head + body, np.uint8)
+    L = len(a)
+    whole, wflags = orc.scan(a)
+    buf = torch.from_numpy(a.copy()).cuda()
+    for pipeline in ("fused", "split"):
+        p = _parser(pipeline, 16 << 20)
+        idx = torch.full((L + 16,), -1, dtype=torch.int32, device="cuda")
+        n = s = flags = 0
+        for b, e in ((0, 2 * M), (2 * M, L)):
+            p.stage1_range_device(buf.data_ptr(), b, e, e < L, s, n, idx.data_ptr(), L + 3, stream)
+            n, f, _ = p.result(stream)
+            flags |= f & ~1
+            s = f & 1
+        assert (flags | s) == wflags and n == len(whole)
+        assert np.array_equal(idx[:n].cpu().numpy().view(np.uint32), whole), pipeline
+        p.close()
+    # a 72 MiB document that is one backslash run, streamed in 16 MiB ranges: the 8 MiB tail range must not walk
+    monkeypatch.setenv("SJGPU_STREAM_FROM_MB", "1")
+    doc = np.frombuffer(b'["' + b"\\" * ((72 << 20) - 8) + b'", 7]', np.uint8)
+    want = orc.stage1(doc, 0)
+    p = capi.DomParserImplementation(len(doc))
+    p.stage1(doc, 0)
+    t0 = time.perf_counter()
+    err = p.stage1(doc, 0)
+    dt = time.perf_counter() - t0
+    assert (err, p.n_structural_indexes) == want[:2] and np.array_equal(p.structural_indexes[: want[1] + 3], want[2])
+    assert dt < 0.5, f"72 MiB of backslashes through the streamed path took {dt * 1e3:.0f} ms"
+    p.close()
+
+
 def test_overlapped_host_path(orc, monkeypatch):
     """sjgpu_stage1 / sjgpu_minify with host buffers, forced through the range-by-range path with 1 MiB ranges
     (and once with the defaults on a document large enough to take it by itself)."""
@@ -564,8 +874,8 @@ def test_full_size_device_resident(orc, kind, pipeline):
     dst2 = torch.empty(L + 16, dtype=torch.uint8, device="cuda")
     mbuf = dst[:mlen].clone()
     assert p.minify_device(mbuf.data_ptr(), mlen, dst2.data_ptr(), stream) == 0
-    _, _, mlen2 = p.result(stream)
-    assert mlen2 == mlen and bool((dst2[:mlen] == mbuf).all())
+    _, mflags2, mlen2 = p.result(stream)
+    assert (mlen2, mflags2) == (mlen, 0) and bool((dst2[:mlen] == mbuf).all()), (mlen2, mlen, mflags2)
     idx2 = torch.empty(mlen + 3, dtype=torch.int32, device="cuda")
     assert p.stage1_device(mbuf.data_ptr(), mlen, idx2.data_ptr(), mlen + 3, stream) == 0
     n2, flags2, _ = p.result(stream)

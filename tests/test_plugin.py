@@ -62,3 +62,51 @@ def test_reference_own_test_programs_on_mi355x(name):
     tail = (out.stdout[-2500:] + out.stderr[-1500:])
     assert out.returncode == 0, tail
     assert "[active implementation: mi355x]" in out.stderr, tail
+
+
+# ---- in-tree registration: the backend selected BY NAME, the way the reference selects its own kernels ----------
+INTREE_SUITE = sorted(build.INTREE_TESTS)
+
+
+def _intree(name):
+    _binary()
+    built = {os.path.basename(p): p for p in build.build_intree()}
+    assert name in built, f"{name} was not built (needs the build container)"
+    assert build.binary_is_current(name), f"build/tests/{name} is stale (sources changed since it was built)"
+    return built[name]
+
+
+def test_intree_registration_keeps_the_cpu_kernels_and_lists_mi355x():
+    """The patched library (simdjson_mi355x.patch applied to a scratch copy, -DSIMDJSON_IMPLEMENTATION_MI355X=1) still passes
+    the reference's basictests on its CPU kernel, and knows the name `mi355x`: without a GPU the programs run and every
+    parser creation answers UNSUPPORTED_ARCHITECTURE -- no abort, no CPU stand-in."""
+    import torch
+    exe = _intree("intree_basictests")
+    out = subprocess.run([exe, "-a", "haswell"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "Basic tests are ok." in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+    if not torch.cuda.is_available():
+        out = subprocess.run([exe, "-a", "mi355x"], capture_output=True, text=True, timeout=600)
+        assert "Unsupported architecture value" not in out.stderr
+        assert "Running tests against this implementation: mi355x" in out.stdout
+        assert out.returncode != 0 and "UNSUPPORTED_ARCHITECTURE" in (out.stdout + out.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", INTREE_SUITE)
+@pytest.mark.parametrize("how", ["-a mi355x", "SIMDJSON_FORCE_IMPLEMENTATION"])
+def test_intree_reference_tests_select_mi355x_by_name(name, how):
+    """tests/dom/basictests.cpp and errortests.cpp of the reference, untouched, against the patched library:
+    `-a mi355x` (tests/dom/basictests.cpp:2461-2470) and SIMDJSON_FORCE_IMPLEMENTATION=mi355x (src/implementation.cpp:296-312)."""
+    exe = _intree(name)
+    env = dict(os.environ)
+    args = [exe]
+    if how == "-a mi355x":
+        args += ["-a", "mi355x"]
+    else:
+        env["SIMDJSON_FORCE_IMPLEMENTATION"] = "mi355x"
+    out = subprocess.run(args, capture_output=True, text=True, timeout=900, env=env)
+    tail = out.stdout[-2500:] + out.stderr[-1500:]
+    assert out.returncode == 0, tail
+    if name == "intree_basictests":
+        assert "Running tests against this implementation: mi355x" in out.stdout, tail
+        assert "Basic tests are ok." in out.stdout, tail

@@ -34,11 +34,15 @@ def _worker(rank, world, port, size, seed, q):
 
     local = sharded.scan_shard(buf, rank, world, scan_fn)
     positions, counts, flags = sharded.gather_global_indices(local)
+    rooted, rcounts = sharded.gather_to_root(local)  # the variable-length gather bench.py --gpus N times
     if rank == 0:
         whole, wflags = orc.scan(buf)
         ok = (flags == wflags == 0 and sum(counts) == len(whole)
-              and np.array_equal(positions.numpy(), whole.astype(np.int64)))
+              and np.array_equal(positions.numpy(), whole.astype(np.int64))
+              and rcounts == counts and np.array_equal(rooted.numpy(), whole.astype(np.int64)))
         q.put((ok, counts, len(whole)))
+    else:
+        assert rooted is None and rcounts == counts
     dist.barrier()
     dist.destroy_process_group()
 
