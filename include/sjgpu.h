@@ -218,6 +218,24 @@ int sjgpu_stage1_shard_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, i
 int sjgpu_minify_shard_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, int in_string, void *dst_dev,
                               void *stream);
 
+/* ---- ONE host buffer, SEVERAL GPUs of the node, one process (sjgpu_mgpu.hip) ------------------------------------------
+ * The C++ face of SURVEY.md 8(e) for callers whose document and index array live in host memory (the simdjson plug-in,
+ * dom::parser / parse_many windows of hundreds of megabytes): the buffer is cut at clean cuts into one shard per
+ * listed device, every device uploads, scans and downloads its own shard over its own PCIe link (one host thread per
+ * device), and the shards exchange exactly one bit each -- through host memory, no collective.  Results are
+ * bit-identical to sjgpu_stage1 / sjgpu_minify / sjgpu_validate_utf8 on one device, for every stage1_mode.
+ * devices[]: HIP device numbers, one shard per entry (an entry may repeat: that is how a one-GPU box tests this).
+ * The plug-in uses it when the environment lists devices: SJGPU_DEVICES=0,1,2,3 (documents of SJGPU_MGPU_FROM_MB
+ * megabytes and more, default 256).  Shards that STAY in HBM are one process per GPU: simdjson_amd/sharded.py. */
+typedef struct sjgpu_mgpu sjgpu_mgpu;
+int sjgpu_mgpu_create(const int *devices, int count, sjgpu_mgpu **out);
+void sjgpu_mgpu_destroy(sjgpu_mgpu *m);
+int sjgpu_mgpu_count(const sjgpu_mgpu *m);
+int sjgpu_mgpu_stage1(sjgpu_mgpu *m, const uint8_t *buf, size_t len, int mode, uint32_t *idx_out, size_t idx_words,
+                      uint32_t *n_io, uint32_t *next_io);
+int sjgpu_mgpu_minify(sjgpu_mgpu *m, const uint8_t *buf, size_t len, uint8_t *dst, size_t *dst_len);
+int sjgpu_mgpu_validate_utf8(sjgpu_mgpu *m, const uint8_t *buf, size_t len, int *ok);
+
 /* ---- ranges of ONE resident buffer, one after the other (overlap the upload of batch k+1 with
  * the scan of batch k -- the GPU analogue of the reference's stage1_worker, dom/document_stream-inl.h:16-85).
  * Scans bytes [begin, end) of buf_dev; bytes [0, begin) must already be resident (escapes, the previous-scalar bit

@@ -231,8 +231,10 @@ int main(int argc, char **argv) {
           verdict = okv == ref_utf8 ? "same verdict (" + std::to_string(okv) + ")" : "MISMATCH";
           if (okv != ref_utf8) { failures++; }
         }
-        std::printf("%-18s %-14s %-6s %9.4f %9.1f %9.1f %7.4f  %s\n", kind.c_str(), op.c_str(), used == 1 ? "fused" : "split", gpu_ms, L / gpu_ms / 1e6,
+        std::printf("%-18s %-14s %-6s %9.4f %9.1f %9.1f %7.4f  %s", kind.c_str(), op.c_str(), used == 1 ? "fused" : "split", gpu_ms, L / gpu_ms / 1e6,
                     alg / gpu_ms / 1e6, alg / gpu_ms / 1e6 / 8000.0, verdict.c_str());
+        if (used != 1 && op != "validate_utf8") { std::printf("  [slots %.4f %.4f %.4f]", ms[0] / calls, ms[1] / calls, ms[2] / calls); }
+        std::printf("\n");
         std::fflush(stdout);
       }
     }

@@ -308,8 +308,8 @@ int main(int argc, char **argv) {
     };
     scan_origin org{0, 0, 0, esc};
     scan_origin org_noesc{0, 0, 0, nullptr};
-    time("A0 k_stage1_summarize (product), escape table", [&] { hipLaunchKernelGGL(k_stage1_summarize, dim3(nseg), dim3(64), 0, nullptr, buf, u64(L), mask0, mask1, summ, org); });
-    time("A1 k_stage1_summarize (product), no table (byte walk)", [&] { hipLaunchKernelGGL(k_stage1_summarize, dim3(nseg), dim3(64), 0, nullptr, buf, u64(L), mask0, mask1, summ, org_noesc); });
+    time("A0 k_stage1_summarize (product), escape table", [&] { hipLaunchKernelGGL(k_stage1_summarize, dim3((nseg + 3) / 4), dim3(256), 0, nullptr, buf, u64(L), mask0, mask1, summ, org, nseg); });
+    time("A1 k_stage1_summarize (product), no table (byte walk)", [&] { hipLaunchKernelGGL(k_stage1_summarize, dim3((nseg + 3) / 4), dim3(256), 0, nullptr, buf, u64(L), mask0, mask1, summ, org_noesc, nseg); });
     time("B1 esc byte hoisted, 64-thread WGs", [&] { hipLaunchKernelGGL((k_scan<1, 0, 64>), dim3(nseg), dim3(64), 0, nullptr, buf, u64(L), mask0, mask1, summ, esc, nseg); });
     time("B2 esc byte hoisted, 256-thread WGs (4 segments each)", [&] { hipLaunchKernelGGL((k_scan<1, 0, 256>), dim3((nseg + 3) / 4), dim3(256), 0, nullptr, buf, u64(L), mask0, mask1, summ, esc, nseg); });
     time("C1 + next chunk prefetched (double buffer), 64-thread WGs", [&] { hipLaunchKernelGGL((k_scan<2, 0, 64>), dim3(nseg), dim3(64), 0, nullptr, buf, u64(L), mask0, mask1, summ, esc, nseg); });

@@ -29,7 +29,8 @@ EXPORTS = [
     "sjgpu_stage1_range_device", "sjgpu_minify_range_device",
     "sjgpu_host_alloc", "sjgpu_host_free", "sjgpu_host_register", "sjgpu_host_unregister", "sjgpu_last_pipeline",
     "sjgpu_profile_kernel", "sjgpu_debug_trace_pipelined", "sjgpu_stage1_many", "sjgpu_stage1_finish_device",
-    "sjgpu_depth_scan_device",
+    "sjgpu_depth_scan_device", "sjgpu_mgpu_create", "sjgpu_mgpu_destroy", "sjgpu_mgpu_count", "sjgpu_mgpu_stage1", "sjgpu_mgpu_minify",
+    "sjgpu_mgpu_validate_utf8",
 ]
 
 
@@ -109,6 +110,18 @@ def load_library():
     L.sjgpu_stage1_finish_device.argtypes = [vp, vp, sz, ctypes.c_int, vp, ctypes.c_uint32, ctypes.c_uint32, vp, u32p, u32p]
     L.sjgpu_depth_scan_device.restype = ctypes.c_int
     L.sjgpu_depth_scan_device.argtypes = [vp, vp, vp, ctypes.c_uint32, vp, vp]
+    L.sjgpu_mgpu_create.restype = ctypes.c_int
+    L.sjgpu_mgpu_create.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(vp)]
+    L.sjgpu_mgpu_destroy.restype = None
+    L.sjgpu_mgpu_destroy.argtypes = [vp]
+    L.sjgpu_mgpu_count.restype = ctypes.c_int
+    L.sjgpu_mgpu_count.argtypes = [vp]
+    L.sjgpu_mgpu_stage1.restype = ctypes.c_int
+    L.sjgpu_mgpu_stage1.argtypes = [vp, vp, sz, ctypes.c_int, vp, sz, u32p, u32p]
+    L.sjgpu_mgpu_minify.restype = ctypes.c_int
+    L.sjgpu_mgpu_minify.argtypes = [vp, vp, sz, vp, ctypes.POINTER(sz)]
+    L.sjgpu_mgpu_validate_utf8.restype = ctypes.c_int
+    L.sjgpu_mgpu_validate_utf8.argtypes = [vp, vp, sz, ctypes.POINTER(ctypes.c_int)]
     L.sjgpu_set_pipeline.restype = ctypes.c_int
     L.sjgpu_set_pipeline.argtypes = [vp, ctypes.c_int]
     L.sjgpu_profile_enable.restype = ctypes.c_int
@@ -345,6 +358,60 @@ class DomParserImplementation:
         if rc != 0:
             raise SjgpuError(f"sjgpu_profile_read error {rc}: {self.last_error()}")
         return [float(x) for x in ms], int(calls.value)
+
+
+class MultiGpu:
+    """sjgpu_mgpu (include/sjgpu.h): one host buffer, one shard per listed device, one process.  Same member names as
+    DomParserImplementation for the host-buffer calls."""
+
+    def __init__(self, devices):
+        self.L = load_library()
+        arr = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        rc = self.L.sjgpu_mgpu_create(arr, len(devices), ctypes.byref(h))
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_mgpu_create({list(devices)}) failed with {rc}")
+        self.h = h
+        self.n_structural_indexes = 0
+        self.next_structural_index = 0
+        self.structural_indexes = np.zeros(0, dtype=np.uint32)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sjgpu_mgpu_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def stage1(self, data, mode=REGULAR):
+        a = _as_u8(data)
+        if len(self.structural_indexes) < len(a) + 3:
+            self.structural_indexes = np.zeros(len(a) + 64, dtype=np.uint32)
+        n = ctypes.c_uint32(self.n_structural_indexes)
+        nxt = ctypes.c_uint32(self.next_structural_index)
+        rc = self.L.sjgpu_mgpu_stage1(self.h, a.ctypes.data, len(a), int(mode), self.structural_indexes.ctypes.data, len(self.structural_indexes),
+                                      ctypes.byref(n), ctypes.byref(nxt))
+        self.n_structural_indexes, self.next_structural_index = int(n.value), int(nxt.value)
+        if rc < 0:
+            raise SjgpuError(f"sjgpu_mgpu_stage1 infrastructure error {rc}")
+        return rc
+
+    def minify(self, data):
+        a = _as_u8(data)
+        dst = np.zeros(max(len(a), 1), dtype=np.uint8)
+        n = ctypes.c_size_t(0)
+        rc = self.L.sjgpu_mgpu_minify(self.h, a.ctypes.data, len(a), dst.ctypes.data, ctypes.byref(n))
+        if rc < 0:
+            raise SjgpuError(f"sjgpu_mgpu_minify infrastructure error {rc}")
+        return rc, dst[: n.value]
+
+    def validate_utf8(self, data):
+        a = _as_u8(data)
+        ok = ctypes.c_int(0)
+        rc = self.L.sjgpu_mgpu_validate_utf8(self.h, a.ctypes.data, len(a), ctypes.byref(ok))
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_mgpu_validate_utf8 error {rc}")
+        return bool(ok.value)
 
 
 def stage1_error_from_flags(n, flags):

@@ -4,8 +4,9 @@
 #include "sjgpu.h"
 
 #include <atomic>
-#include <mutex>
+#include <cstdlib>
 #include <new>
+#include <vector>
 
 namespace simdjson {
 namespace mi355x {
@@ -39,10 +40,37 @@ struct borrowed_ctx {
   borrowed_ctx &operator=(const borrowed_ctx &) = delete;
 };
 
+// SJGPU_DEVICES=0,1,2,3: documents of SJGPU_MGPU_FROM_MB megabytes and more (default 256) are cut into one shard per listed
+// device and scanned by all of them at once, each over its own PCIe link (sjgpu_mgpu_*, include/sjgpu.h).  Read once.
+struct device_list {
+  std::vector<int> devices;
+  size_t from_bytes = size_t(256) << 20;
+  device_list() noexcept {
+    if (const char *v = std::getenv("SJGPU_DEVICES")) {
+      for (const char *p = v; *p;) {
+        char *end = nullptr;
+        const long d = std::strtol(p, &end, 10);
+        if (end == p) { break; }
+        devices.push_back(int(d));
+        p = (*end == ',') ? end + 1 : end;
+      }
+    }
+    if (const char *v = std::getenv("SJGPU_MGPU_FROM_MB")) { from_bytes = size_t(std::strtoull(v, nullptr, 10)) << 20; }
+    if (devices.size() < 2) { devices.clear(); }
+  }
+};
+const device_list &listed_devices() noexcept {
+  static const device_list *l = new (std::nothrow) device_list();
+  return *l;
+}
+
 class dom_parser_implementation final : public internal::dom_parser_implementation {
 public:
   dom_parser_implementation() noexcept = default;
-  ~dom_parser_implementation() override { sjgpu_ctx_destroy(ctx_); }
+  ~dom_parser_implementation() override {
+    sjgpu_mgpu_destroy(mgpu_);
+    sjgpu_ctx_destroy(ctx_);
+  }
 
   // stage 1 on the GPU, then the reference's own stage 2 (src/haswell.cpp:159-163 shape)
   simdjson_warn_unused error_code parse(const uint8_t *buf, size_t len, dom::document &doc) noexcept final {
@@ -57,6 +85,14 @@ public:
     if (!ctx_) { return UNINITIALIZED; }
     // the array holds ROUNDUP(capacity,64)+9 words (generic/dom_parser_implementation.h:63-78)
     const size_t words = SIMDJSON_ROUNDUP_N(_capacity, 64) + 9;
+    if (len > _capacity) { return CAPACITY; }
+    const device_list &dl = listed_devices();
+    if (!dl.devices.empty() && len >= dl.from_bytes) { // every listed GPU takes a shard
+      if (!mgpu_ && sjgpu_mgpu_create(dl.devices.data(), int(dl.devices.size()), &mgpu_) != 0) { mgpu_ = nullptr; }
+      if (mgpu_) {
+        return map_error(sjgpu_mgpu_stage1(mgpu_, buf, len, int(mode), structural_indexes.get(), words, &n_structural_indexes, &next_structural_index));
+      }
+    }
     return map_error(sjgpu_stage1(ctx_, buf, len, int(mode), structural_indexes.get(), words, &n_structural_indexes,
                                   &next_structural_index));
   }
@@ -119,6 +155,7 @@ private:
   }
 
   sjgpu_ctx *ctx_ = nullptr;
+  sjgpu_mgpu *mgpu_ = nullptr; // made on the first document long enough for SJGPU_DEVICES
   std::unique_ptr<internal::dom_parser_implementation> inner_{};
   const uint8_t *buf_ = nullptr;
   size_t len_ = 0;

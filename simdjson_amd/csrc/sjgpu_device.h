@@ -447,6 +447,119 @@ __device__ __forceinline__ void emit_indices(u64 structural, u32 pos32, u32 lane
   base += total;
 }
 
+// A wave's whole SPAN at once: FOUR consecutive chunks whose offsets fit one window together (sparse output: NDJSON,
+// pretty-printed text).  One prefix scan over packed counts, ONE extraction loop with eight independent chains per lane
+// (two halves x four chunks), one hand-over to the store loop -- instead of four scans, four loops and four hand-overs
+// whose fixed latencies dominated the emission of sparse chunks (profiles/r02_pipelined_phase_trace.txt: 1.6 us per
+// chunk of ~245 offsets).  Returns false without touching anything when the span does not fit the window (the caller
+// then emits chunk by chunk).  m[c] = lane's structural bits of chunk c, pos0 = byte offset of lane 0's block in chunk 0.
+template <u32 WINDOW, u32 NCH>
+__device__ __forceinline__ bool emit_span(const u64 *m, u32 pos0, u32 lane, u32 *__restrict__ idx, u64 idx_words, u32 &base,
+                                          u32 *__restrict__ stage, bool &overflow) {
+  static_assert(NCH == 2 || NCH == 4, "two or four chunks");
+  constexpr u32 DUMP = WINDOW + 4;
+  constexpr u32 NH = 2 * NCH;
+  u32 h[NH], n[NH];
+#pragma unroll
+  for (u32 c = 0; c < NCH; c++) {
+    h[2 * c] = u32(m[c]);
+    h[2 * c + 1] = u32(m[c] >> 32);
+    n[2 * c] = u32(__popc(h[2 * c]));
+    n[2 * c + 1] = u32(__popc(h[2 * c + 1]));
+  }
+  // scans over pairs of 16-bit fields (a chunk holds at most 4096 offsets)
+  const u32 p01 = (n[0] + n[1]) | ((n[2] + n[3]) << 16);
+  const u32 i01 = wave_incl_scan(p01);
+  const u32 t01 = readlane(i01, 63);
+  u32 T[4] = {t01 & 0xFFFFu, t01 >> 16, 0u, 0u};
+  u32 p23 = 0, i23 = 0;
+  if (NCH == 4) {
+    p23 = (n[NH - 4] + n[NH - 3]) | ((n[NH - 2] + n[NH - 1]) << 16);
+    i23 = wave_incl_scan(p23);
+    const u32 t23 = readlane(i23, 63);
+    T[2] = t23 & 0xFFFFu;
+    T[3] = t23 >> 16;
+  }
+  const u32 total = T[0] + T[1] + T[2] + T[3];
+  if (total > WINDOW) { return false; }
+  if (total == 0) { return true; }
+  if (u64(base) + total > idx_words) {
+    overflow = true;
+    base += total;
+    return true;
+  }
+  const u32 skew = base & 3u;
+  const u32 e01 = i01 - p01, e23 = i23 - p23; // exclusive, per field
+  u32 a[NH];
+  a[0] = skew + (e01 & 0xFFFFu);
+  a[2] = skew + T[0] + (e01 >> 16);
+  if (NCH == 4) {
+    a[NH - 4] = skew + T[0] + T[1] + (e23 & 0xFFFFu);
+    a[NH - 2] = skew + T[0] + T[1] + T[2] + (e23 >> 16);
+  }
+  u32 mx = 0;
+#pragma unroll
+  for (u32 c = 0; c < NCH; c++) {
+    a[2 * c + 1] = a[2 * c] + n[2 * c];
+    mx = max(mx, max(n[2 * c], n[2 * c + 1]));
+  }
+#pragma unroll
+  for (u32 k = 0; k < NH; k++) { a[k] = n[k] ? a[k] : DUMP; } // an empty chain parks its (ignored) stores in the dump slot
+  mx = max(mx, u32(__builtin_amdgcn_update_dpp(0, int(mx), 0x111, 0xf, 0xf, false)));
+  mx = max(mx, u32(__builtin_amdgcn_update_dpp(0, int(mx), 0x112, 0xf, 0xf, false)));
+  mx = max(mx, u32(__builtin_amdgcn_update_dpp(0, int(mx), 0x114, 0xf, 0xf, false)));
+  mx = max(mx, u32(__builtin_amdgcn_update_dpp(0, int(mx), 0x118, 0xf, 0xf, false)));
+  mx = max(mx, u32(__builtin_amdgcn_update_dpp(0, int(mx), 0x142, 0xa, 0xf, false)));
+  mx = max(mx, u32(__builtin_amdgcn_update_dpp(0, int(mx), 0x143, 0xc, 0xf, false)));
+  const u32 trips = readlane(mx, 63);
+  const u32 lane_pos = pos0 + lane * BLOCK_BYTES;
+  u32 v[NH];
+#pragma unroll
+  for (u32 k = 0; k < NH; k++) { v[k] = 0; }
+#pragma unroll 1
+  for (u32 t = 0; t < trips; t++) {
+#pragma unroll
+    for (u32 k = 0; k < NH; k++) {
+      if (h[k]) { v[k] = lane_pos + (k >> 1) * CHUNK_BYTES + (k & 1u) * 32u + u32(__ffs(int(h[k])) - 1); }
+      stage[a[k]] = v[k];
+      h[k] &= h[k] - 1;
+      a[k] += h[k] ? 1u : 0u; // stay on the last slot once the chain is exhausted
+    }
+  }
+  wave_lds_fence();
+  u32 *const g0 = idx + (u64(base) - skew); // 16-byte aligned
+  const u32 end = skew + total;            // stage slots [skew, end) are live
+  const u32 v_first = (skew + 3u) >> 2, v_last = end >> 2;
+  if (v_last > v_first) {
+#pragma unroll 1
+    for (u32 q = v_first + lane; q < v_last; q += 64) {
+      *reinterpret_cast<uint4 *>(g0 + 4u * q) = *reinterpret_cast<const uint4 *>(stage + 4u * q);
+    }
+    if (skew + lane < 4u * v_first) { g0[skew + lane] = stage[skew + lane]; }
+    if (4u * v_last + lane < end) { g0[4u * v_last + lane] = stage[4u * v_last + lane]; }
+  } else {
+#pragma unroll 1
+    for (u32 i = skew + lane; i < end; i += 64) { g0[i] = stage[i]; }
+  }
+  wave_lds_fence();
+  base += total;
+  return true;
+}
+// a span of four chunks: in one piece, else as two pairs, else chunk by chunk (st[c] = lane's structural bits of chunk c,
+// zero for chunks beyond the input; span_pos = byte offset of the span)
+template <u32 WINDOW>
+__device__ __forceinline__ void emit_span4_adaptive(const u64 (&st)[4], u32 span_pos, u32 lane, u32 *__restrict__ idx, u64 idx_words, u32 &base,
+                                                    u32 *__restrict__ stage, bool &overflow) {
+  if (emit_span<WINDOW, 4>(st, span_pos, lane, idx, idx_words, base, stage, overflow)) { return; }
+#pragma unroll
+  for (u32 half = 0; half < 2; half++) {
+    const u32 pos = span_pos + half * 2u * CHUNK_BYTES;
+    if (emit_span<WINDOW, 2>(st + 2 * half, pos, lane, idx, idx_words, base, stage, overflow)) { continue; }
+    emit_indices<WINDOW>(st[2 * half], pos + lane * BLOCK_BYTES, lane, idx, idx_words, base, stage, overflow);
+    emit_indices<WINDOW>(st[2 * half + 1], pos + CHUNK_BYTES + lane * BLOCK_BYTES, lane, idx, idx_words, base, stage, overflow);
+  }
+}
+
 // =====================================================================================================
 // output: byte compaction (minify) of one chunk through a per-wave LDS window
 // =====================================================================================================

@@ -545,16 +545,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (g && lane == 0) { atomicOr(&result->flags, g); }
         const u64 flip = s ? ~0ull : 0ull;
         bool overflow = false;
+        if (OP == 0) { // sparse spans leave in one piece, medium ones as two pairs of chunks, dense ones chunk by chunk
+          u64 st[4];
+#pragma unroll
+          for (u32 c = 0; c < WC; c++) { st[c] = sh_mask_a[wave][c][lane] & ~(sh_mask_b[wave][c][lane] ^ flip); } // zero beyond len
+          emit_span4_adaptive<PIPE_WINDOW>(st, u32(wave_start), lane, static_cast<u32 *>(out), out_words, base, sh_stage[wave], overflow);
+        } else {
 #pragma unroll 1
-        for (u32 c = 0; c < WC; c++) {
-          const u64 cstart = wave_start + u64(c) * CHUNK_BYTES;
-          if (cstart >= len) { break; }
-          const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
-          const u64 a = sh_mask_a[wave][c][lane], b = sh_mask_b[wave][c][lane];
-          if (OP == 0) {
-            emit_indices<PIPE_WINDOW>(a & ~(b ^ flip), u32(pos), lane, static_cast<u32 *>(out), out_words, base, sh_stage[wave],
-                                      overflow);
-          } else {
+          for (u32 c = 0; c < WC; c++) {
+            const u64 cstart = wave_start + u64(c) * CHUNK_BYTES;
+            if (cstart >= len) { break; }
+            const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
+            const u64 a = sh_mask_a[wave][c][lane], b = sh_mask_b[wave][c][lane];
             u32 w[16];
             load_block(buf, pos, len, w);
             emit_bytes(w, valid_mask(pos, len) & ~(a & ~(b ^ flip)), lane, static_cast<u8 *>(out), base,

@@ -33,18 +33,33 @@ namespace {
 // segment is RESOLVED: it writes ONE final 64-bit mask per block instead of two and its count has a single
 // value.  The true parity chain is still scanned: a resolved segment whose true carry-in differs from the
 // derived one contains a control character inside a string and raises the same error the reference raises.
-__global__ __launch_bounds__(64) void k_stage1_summarize(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ mask0,
-                                                         u64 *__restrict__ mask1, seg_summary *__restrict__ summ,
-                                                         scan_origin org) {
+// Four independent waves (four consecutive segments) share a workgroup for ONE reason: the UTF-8 blocks they have
+// noted but not yet validated when their segments end.  A wave of its own would validate a handful of blocks with a
+// handful of lanes (one or two non-ASCII blocks per chunk is what NDJSON / pretty-printed text hold) -- ~75 of its
+// ~415 VALU instructions per chunk (profiles/r02_pmc_ndjson.txt: this kernel issues 81 % of the time).  The four
+// hand their left-overs to wave 0 through LDS and leave; wave 0 validates them together.
+constexpr u32 SUMM_WAVES = 4;
+__global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_stage1_summarize(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ mask0,
+                                                                     u64 *__restrict__ mask1, seg_summary *__restrict__ summ,
+                                                                     scan_origin org, u32 nseg) {
   const u32 lane = lane_id();
-  const u32 seg = blockIdx.x; // relative to the scan's origin: workspace index
+  const u32 wave = threadIdx.x >> 6;
+  const u32 seg = blockIdx.x * SUMM_WAVES + wave; // relative to the scan's origin: workspace index
+  __shared__ u32 uq_slots[SUMM_WAVES][UTF8Q_SLOTS];
+  __shared__ u32 sh_left[SUMM_WAVES * 64];
+  __shared__ u32 sh_left_count;
+  if (threadIdx.x == 0) { sh_left_count = 0; }
+  const bool more = (org.carry & CARRY_MORE) != 0;
+  if (seg >= nseg) { // past the last segment (wave-uniform; wave 0 always has one): only the rendezvous below
+    __syncthreads();
+    __syncthreads();
+    return;
+  }
   const u64 seg_start = org.begin + u64(seg) * SEG_BYTES;
   const u64 lane_off = u64(lane) * BLOCK_BYTES;
-  __shared__ u32 uq_slots[UTF8Q_SLOTS];
-  const bool more = (org.carry & CARRY_MORE) != 0;
   const u32 lookback = lookback_issue(buf, seg_start, lane); // consumed after chunk 0 has been requested
   wave_carry wc{0u, 0u, 0u};
-  utf8_queue uq{uq_slots, 0u, 0u, 0u};
+  utf8_queue uq{uq_slots[wave], 0u, 0u, 0u};
   u32 n_a = 0, n_b = 0; // resolved: n_a = final count; else n_a = candidates, n_b = candidates in a string tail
   u64 ctrl_a = 0, ctrl_b = 0;
   bool resolved = false;
@@ -104,7 +119,24 @@ __global__ __launch_bounds__(64) void k_stage1_summarize(const u8 *__restrict__ 
       p1[1] = make_uint4(u32(keep1[2]), u32(keep1[2] >> 32), u32(keep1[3]), u32(keep1[3] >> 32));
     }
   }
-  utf8_drain_rest(uq, buf, len, more, lane); // incl. a sequence still open at the very end of the input
+  // left-overs (fewer than 64 after the last utf8_drain_if_full) go to wave 0, which validates them with full lanes
+  __syncthreads(); // sh_left_count is zero
+  {
+    wave_lds_fence();
+    u32 at = 0;
+    if (lane == 0 && uq.count) { at = atomicAdd(&sh_left_count, uq.count); }
+    at = readlane(at, 0);
+    if (lane < uq.count) { sh_left[at + lane] = uq.slots[lane]; }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const u32 total = sh_left_count;
+    for (u32 done = 0; done < total; done += 64) {
+      bool bad = false;
+      if (done + lane < total) { bad = utf8_check_block(buf, len, more, sh_left[done + lane]); } // incl. a sequence open at the end of the input
+      if (__ballot(bad)) { uq.error = 1u; }
+    }
+  }
   const u32 ta = wave_sum(n_a), tb = wave_sum(n_b);
   const bool any_a = __ballot(ctrl_a != 0) != 0, any_b = __ballot(ctrl_b != 0) != 0;
   u32 flags = wc.s ? SF_PARITY : 0u;
@@ -296,15 +328,10 @@ __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask
   u32 base = pf.base;
   const u64 flip = pf.in_string ? ~0ull : 0ull;
   bool overflow = false;
+  u64 st[SEG_CHUNKS];
 #pragma unroll
-  for (u32 c = 0; c < SEG_CHUNKS; c++) {
-    const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
-    if (cstart >= len) { break; }
-    const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
-    u64 structural = m0[c];
-    if (!resolved) { structural &= ~(m1[c] ^ flip); }
-    emit_indices(structural, u32(pos), lane, idx, idx_words, base, stage, overflow);
-  }
+  for (u32 c = 0; c < SEG_CHUNKS; c++) { st[c] = resolved ? m0[c] : (m0[c] & ~(m1[c] ^ flip)); } // chunks beyond len hold zero masks
+  emit_span4_adaptive<EMIT_WINDOW>(st, u32(seg_start), lane, idx, idx_words, base, stage, overflow); // sparse segments go out in one piece
   if (__ballot(overflow) && lane == 0) { atomicOr(&result->flags, SJGPU_F_IDX_OVERFLOW); }
 }
 
@@ -505,7 +532,8 @@ void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *
   else { org.esc = nullptr; }
   u64 *mask0 = reinterpret_cast<u64 *>(masks);
   u64 *mask1 = mask0 + size_t(nseg) * (SEG_BYTES / BLOCK_BYTES); // second plane, only written by unresolved segments
-  hipLaunchKernelGGL(k_stage1_summarize, dim3(nseg), dim3(64), 0, stream, buf, len, mask0, mask1, summ, org);
+  hipLaunchKernelGGL(k_stage1_summarize, dim3((nseg + SUMM_WAVES - 1) / SUMM_WAVES), dim3(64 * SUMM_WAVES), 0, stream, buf, len, mask0, mask1, summ,
+                     org, nseg);
   mark(ev, 1, stream);
   const u32 ngroups = (nseg + RESOLVE_GROUP - 1) / RESOLVE_GROUP;
   seg_summary *gsum = summ + nseg; // the group summaries live behind the segment summaries

@@ -988,3 +988,33 @@ def test_long_backslash_runs_use_the_escape_table(orc, monkeypatch):
         assert (n, flags) == (3, 0) and [int(x) for x in idx[:3]] == [0, 1, L - 1]
         assert dt < 0.05, f"{pipeline}: 256 MiB of backslashes took {dt * 1e3:.1f} ms"
         p.close()
+
+
+# ---- one host buffer, several GPUs, one process (sjgpu_mgpu.hip; a device may be listed more than once) ------------------------
+def test_mgpu_shards_equal_the_single_scan(orc):
+    tw = corpus.twitter_like(6 << 20, 31)[0]
+    docs = {"twitter_like 6 MiB": tw, "amazon_ndjson 5 MiB": corpus.amazon_ndjson(5 << 20, 31)[0],
+            "ends inside a string": np.concatenate([tw[: 2 << 20], np.frombuffer(b' "dangling text', np.uint8)]),
+            "no clean byte for a long stretch": np.frombuffer(b'["' + b"x" * 3000000 + b'", "' + b"y" * 300000 + b'"]', np.uint8),
+            "tiny": np.frombuffer(b'{"a":[1,2,3]}', np.uint8), "one byte": np.frombuffer(b"7", np.uint8)}
+    bad = tw.copy()
+    bad[len(bad) // 2] = 0xFF
+    docs["invalid UTF-8"] = bad
+    ctrl = tw.copy()
+    quotes = np.flatnonzero(ctrl == ord('"'))
+    ctrl[int(quotes[len(quotes) // 3]) + 1] = 0x01
+    docs["control character inside a string"] = ctrl
+    for shards in (2, 3, 8):
+        m = capi.MultiGpu([0] * shards)
+        for name, a in docs.items():
+            modes = range(7) if len(a) < (3 << 20) or shards == 3 else (0, 1, 2)
+            for mode in modes:
+                err = m.stage1(a, mode)
+                got = checkers.observable(a, mode, err, m.n_structural_indexes, m.structural_indexes[: m.n_structural_indexes + 3])
+                want = checkers.observable(a, mode, *orc.stage1(a, mode))
+                assert got == want, (name, shards, mode, got[:2], want[:2])
+            gerr, gout = m.minify(a)
+            oerr, oout = orc.minify(a)
+            assert gerr == oerr and np.array_equal(gout, oout), (name, shards, gerr, oerr)
+            assert m.validate_utf8(a) == orc.validate_utf8(a), (name, shards)
+        m.close()

@@ -110,3 +110,24 @@ def test_intree_reference_tests_select_mi355x_by_name(name, how):
     if name == "intree_basictests":
         assert "Running tests against this implementation: mi355x" in out.stdout, tail
         assert "Basic tests are ok." in out.stdout, tail
+
+
+@pytest.mark.gpu
+def test_sanitizers_over_the_host_shim():
+    """AddressSanitizer and ThreadSanitizer builds of libsjgpu's host code + the plug-in + plugin_test (scripts/sanitize.sh):
+    dom::parser, ondemand, threaded parse_many (the stage-1 worker thread), minify / validate_utf8, all seven stage1 modes
+    on the GPU, and not one report.  The binaries are built in the build container and travel."""
+    exe = {s: os.path.join(_paths.REPO_ROOT, "build", "san", f"plugin_test_{s}") for s in ("address", "thread")}
+    if not all(os.path.exists(p) for p in exe.values()):
+        pytest.skip("build/san/* not built (bash scripts/sanitize.sh build, needs the reference)")
+    base = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0",
+                TSAN_OPTIONS="report_signal_unsafe=0:halt_on_error=0:suppressions=" + os.path.join(_paths.REPO_ROOT, "scripts", "tsan.supp"))
+    routes = [{}, {"SJGPU_STREAM_FROM_MB": "1", "SJGPU_STREAM_CHUNK_MB": "1"},  # the overlapped path: copy threads, 1 MiB ranges
+              {"SJGPU_DEVICES": "0,0", "SJGPU_MGPU_FROM_MB": "1"}]              # two shard threads per document (the one device twice)
+    for san, path in exe.items():
+        for route in routes:
+            out = subprocess.run([path, "--jsonexamples", EXAMPLES], capture_output=True, text=True, timeout=900, env=dict(base, **route))
+            text = out.stdout + out.stderr
+            assert "plugin test OK" in out.stdout, (san, route, text[-3000:])
+            assert "ERROR: AddressSanitizer" not in text and "WARNING: ThreadSanitizer" not in text, (san, route, text[-4000:])
+            assert out.returncode == 0, (san, route, text[-2000:])
