@@ -40,6 +40,18 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// "My LDS writes have been performed": s_waitcnt lgkmcnt(0).  __syncthreads() is a release fence + s_barrier, and on
+// gfx950 the barrier itself does not wait for anything; the wait comes from the fence -- but hipcc 7.2 dropped it at
+// the loop-top barrier of k_minify_onchip (the ticket written to LDS at the end of an iteration was not waited for
+// across the back edge, three waves read the slot before the write had landed: scripts/lab/minify_debug.cpp found it,
+// tests/test_build.py::test_every_barrier_waits_for_lds keeps looking).  Stores whose visibility a barrier at a loop
+// top has to guarantee are followed by this.
+__device__ __forceinline__ void lds_writes_done() {
+#ifndef SJGPU_SELFTEST_DROP_LDS_WAIT // scripts/check_barriers.py must find the barriers this leaves unguarded
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+}
+
 // ---- loads ----------------------------------------------------------------------------------------
 // A lane's 64 bytes as 16 dwords.  Bytes at or beyond len read as 0x20, exactly the reference's
 // space-padded last block (/root/reference/src/generic/stage1/buf_block_reader.h:99-104); nothing
@@ -96,6 +108,15 @@ struct wave_carry {
 // so the answer is that of esc[s - 1].  Pass entries only exist inside backslash runs of 16 KiB and more; readers
 // resolve them here, 256 entries per step (entry 0 is always 0, so the walk ends).  All lanes call with the same s.
 constexpr u32 ESC_PASS = 2;
+// The table a kernel was handed plus the spacing of its entries (2^shift bytes): 16 KiB for the stage-1 kernels, whose
+// waves start on 16 KiB boundaries, 8 KiB for the minify kernels (k_minify_onchip's waves own 8 KiB).  A bare pointer
+// converts to the 16 KiB flavour; null = no table for this call.
+struct esc_ref {
+  const u8 *tab;
+  u32 shift;
+  __device__ __forceinline__ esc_ref(const u8 *t = nullptr, u32 sh = ESC_SHIFT_STAGE1) : tab(t), shift(sh) {}
+  __device__ __forceinline__ bool at_entry(u64 pos) const { return tab && (pos & ((u64(1) << shift) - 1)) == 0; }
+};
 __device__ __forceinline__ u32 escape_lookup(const u8 *__restrict__ esc, u64 s, u32 lane) {
   const u32 v = esc[s];
   if (v != ESC_PASS) { return v & 1u; } // wave-uniform; the only path ordinary documents take
@@ -121,9 +142,9 @@ __device__ __forceinline__ u32 escape_lookup(const u8 *__restrict__ esc, u64 s, 
 // k_escape_local / k_escape_resolve before the scan.  With it the walk stops at the first segment boundary it reaches
 // (<= 256 steps); without it the walk is as long as the run -- quadratic over a document that is one long backslash run,
 // which is why every call beyond FUSED_SMALL_BELOW bytes gets the table.  `end` is a multiple of 64 at every call site.
-__device__ __forceinline__ u32 backslash_run_parity(const u8 *__restrict__ buf, u64 end, u32 lane, const u8 *__restrict__ esc) {
+__device__ __forceinline__ u32 backslash_run_parity(const u8 *__restrict__ buf, u64 end, u32 lane, esc_ref esc) {
   for (;;) {
-    if (esc && (end % SEG_BYTES) == 0) { return escape_lookup(esc, end / SEG_BYTES, lane); } // wave-uniform
+    if (esc.at_entry(end)) { return escape_lookup(esc.tab, end >> esc.shift, lane); } // wave-uniform
     const u32 byte = (end > lane) ? u32(buf[end - 1 - lane]) : 0u;
     const u64 m = __ballot(byte == 0x5Cu);
     if (~m) { return ctz64(~m) & 1u; }
@@ -142,20 +163,20 @@ __device__ __forceinline__ u32 lookback_issue(const u8 *__restrict__ buf, u64 st
 }
 // parity of the backslash run ending at byte start-1-skip, from m = ballot(lane's look-back byte is a backslash)
 __device__ __forceinline__ u32 run_parity_from_mask(const u8 *__restrict__ buf, u64 start, u32 lane, u64 m, u32 skip,
-                                                    const u8 *__restrict__ esc) {
+                                                    esc_ref esc) {
   const u64 inv = ~(m >> skip) & (~0ull >> skip); // bit i clear <=> byte start-1-skip-i is a backslash
   if (inv) { return ctz64(inv) & 1u; }
   // every byte we hold is a backslash (so start >= 64): keep walking from byte start-65
   return ((64u - skip) + backslash_run_parity(buf, start - 64, lane, esc)) & 1u;
 }
 __device__ __forceinline__ wave_carry segment_carry_from(const u8 *__restrict__ buf, u64 start, u32 lane, u32 byte,
-                                                         const u8 *__restrict__ esc) {
+                                                         esc_ref esc) {
   wave_carry c{0u, 0u, 0u};
   if (start == 0) { return c; }
   const u32 b1 = readlane(byte, 0);
   const u64 m = __ballot(byte == 0x5Cu);
   // a span that starts on a segment boundary reads its escape carry-in straight from the table (no walk at all)
-  c.e = (esc && (start % SEG_BYTES) == 0) ? escape_lookup(esc, start / SEG_BYTES, lane) : run_parity_from_mask(buf, start, lane, m, 0, esc);
+  c.e = esc.at_entry(start) ? escape_lookup(esc.tab, start >> esc.shift, lane) : run_parity_from_mask(buf, start, lane, m, 0, esc);
   if (b1 == 0x22u) {
     c.p = run_parity_from_mask(buf, start, lane, m, 1, esc);
   } else {
@@ -166,7 +187,7 @@ __device__ __forceinline__ wave_carry segment_carry_from(const u8 *__restrict__ 
   }
   return c;
 }
-__device__ __forceinline__ wave_carry segment_carry_in(const u8 *__restrict__ buf, u64 start, u32 lane, const u8 *__restrict__ esc) {
+__device__ __forceinline__ wave_carry segment_carry_in(const u8 *__restrict__ buf, u64 start, u32 lane, esc_ref esc) {
   return segment_carry_from(buf, start, lane, lookback_issue(buf, start, lane), esc);
 }
 
@@ -588,6 +609,8 @@ __device__ __forceinline__ void init_compaction_lut(u32 *lut, u32 lane) {
 // from the LDS table), streamed through a 64-bit shift accumulator and OR-merged into the zeroed window, so a
 // lane issues <= 17 LDS operations per block instead of one per byte (and neighbouring lanes, whose output
 // ranges share a dword, need no ordering).  The stage must be all-zero on entry and is left all-zero.
+// REZERO = false: the caller overwrites the window before its next use (k_minify_onchip parks input bytes in it).
+template <bool REZERO = true>
 __device__ __forceinline__ void emit_bytes(const u32 (&w)[16], u64 keep, u32 lane, u8 *__restrict__ dst, u32 &base,
                                            u8 *__restrict__ stage, const u32 *__restrict__ lut) {
   const u32 cnt = u32(popc64(keep));
@@ -629,10 +652,11 @@ __device__ __forceinline__ void emit_bytes(const u32 (&w)[16], u64 keep, u32 lan
     for (u32 i = skew + lane; i < end; i += 64) { g0[i] = stage[i]; }
   }
   wave_lds_fence();
-  // re-zero what was used: vectors [0, ceil(end/16))
+  if (REZERO) { // what was used: vectors [0, ceil(end/16))
 #pragma unroll 1
-  for (u32 v = lane; 16u * v < end; v += 64) { *reinterpret_cast<uint4 *>(stage + 16u * v) = make_uint4(0, 0, 0, 0); }
-  wave_lds_fence();
+    for (u32 v = lane; 16u * v < end; v += 64) { *reinterpret_cast<uint4 *>(stage + 16u * v) = make_uint4(0, 0, 0, 0); }
+    wave_lds_fence();
+  }
   base += total;
 }
 

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
           if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
           else { load_block(buf, pos, len, w); }
           if (c == 0) {
-            wc = segment_carry_from(buf, wave_start, lane, lookback, org.esc);
+            wc = segment_carry_from(buf, wave_start, lane, lookback, esc_ref(org.esc, OP == 1 ? ESC_SHIFT_MINIFY : ESC_SHIFT_STAGE1));
             uq.pending = utf8_pending_from(lookback, lane);
           }
           if (OP == 0) {
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           u32 wa[16], wb[16];
           load_block_full(buf, lane_pos, wa);
           load_block_full(buf, lane_pos + CHUNK_BYTES, wb);
-          wc = segment_carry_from(buf, wave_start, lane, lookback, org.esc);
+          wc = segment_carry_from(buf, wave_start, lane, lookback, esc_ref(org.esc, OP == 1 ? ESC_SHIFT_MINIFY : ESC_SHIFT_STAGE1));
           uq.pending = utf8_pending_from(lookback, lane);
           scan_one(wa, wave_start);
           load_block_full(buf, lane_pos + 2 * CHUNK_BYTES, wa);
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
               if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
               else { load_block(buf, pos, len, w); }
               if (c == 0) {
-                wc = segment_carry_from(buf, wave_start, lane, lookback, org.esc);
+                wc = segment_carry_from(buf, wave_start, lane, lookback, esc_ref(org.esc, OP == 1 ? ESC_SHIFT_MINIFY : ESC_SHIFT_STAGE1));
                 uq.pending = utf8_pending_from(lookback, lane);
               }
               scan_one(w, cstart);
@@ -576,6 +576,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     pend_tile = have ? tile : NO_TILE;
     if (threadIdx.x == 0 && early) { sh_tile[cur ^ 1u] = have ? next_ticket : NO_TILE; } // visible behind the barrier at the loop top
+    lds_writes_done();
     SJ_PSTAMP(7);
   }
   if (OP == 0) { // what is left of the wave's UTF-8 list, then its verdict
@@ -583,6 +584,191 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (uq.error && lane == 0) { atomicOr(&result->flags, SJGPU_F_UTF8_ERROR); }
   }
 #undef SJ_PSTAMP
+}
+
+
+// =====================================================================================================
+// k_minify_onchip: the pipelined minifier with the pending tile's BYTES kept on the chip.
+// k_fused_pipelined<1> defers the compaction of a tile by one iteration and then loads the tile a second time; with
+// ~130 MiB of tiles between the two reads (1024 workgroups x 2 x 64 KiB) the second read misses the 4 MiB L2s, so the
+// kernel moves 2 x len + dst_len through the fabric (profiles/traffic.json: FETCH_SIZE = 2.0 x len) and sits at the
+// rate a copy of THAT many bytes reaches.  Here a wave scans TWO chunks per tile, keeps their 2 x 16 input dwords in
+// registers until the pending tile has left, and parks them in LDS ([16-byte piece][lane]: conflict-free b128 accesses)
+// where the next iteration's compaction finds them.  The 4 KiB + 32 B of a parked chunk double as that chunk's
+// compaction window (emit_bytes wants a zeroed window: the chunk is read into registers, its rows are zeroed, the
+// kept bytes are OR-merged back in and leave from there), so a workgroup of NW waves needs NW x 2 x 4128 B of LDS:
+// 33 KiB for 4 waves (4 workgroups per CU, 32 KiB tiles) or 66 KiB for 8 waves (2 per CU, 64 KiB tiles).
+// The masks of the pending tile (2 x 2 x u64 per lane) stay in registers.  Protocol = k_fused_pipelined's.
+// =====================================================================================================
+constexpr u32 ONCHIP_REGION_BYTES = MINIFY_STAGE_BYTES; // 4 KiB of input + the 32 bytes of skew/slack the window needs
+static_assert(ONCHIP_REGION_BYTES % 16 == 0, "regions are accessed with b128 operations");
+
+template <u32 NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_minify_onchip(
+    const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc, u32 *__restrict__ ticket, u32 ntiles, u8 *__restrict__ out,
+    scan_result_dev *__restrict__ result, scan_origin org) {
+  constexpr u32 WC = ONCHIP_WAVE_CHUNKS;
+  static_assert(WC == 2, "two register sets, two parked chunks");
+  constexpr u32 WAVE_BYTES = WC * CHUNK_BYTES;
+  constexpr u32 TILE_BYTES = NW * WAVE_BYTES;
+  const u32 carry = org.carry;
+  __shared__ u32 sh_tile[2];
+  __shared__ u32 sh_wave[2][NW][4]; // [iteration parity][wave]: quote parity, kept if out, kept if in
+  __shared__ u32 sh_agg[2][4];
+  __shared__ u32 sh_prefix[4];
+  __shared__ __attribute__((aligned(16))) u8 sh_bytes[NW][WC][ONCHIP_REGION_BYTES];
+  __shared__ u32 sh_lut[MINIFY_LUT_WORDS];
+
+  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  if (wave == 0) { init_compaction_lut(sh_lut, lane); }
+  u32 pend_tile = NO_TILE;
+  u64 pa0 = 0, pa1 = 0, pb0 = 0, pb1 = 0; // the pending tile's masks: droppable-if-outside-a-string, in-string (relative)
+  u32 next_ticket = 0;
+  if (threadIdx.x == 0) { sh_tile[0] = atomicAdd(ticket, 1u); }
+  for (u32 iter = 0;; iter++) {
+    const u32 cur = iter & 1u;
+    __syncthreads();
+    const u32 tile = sh_tile[cur];
+    const bool have = tile < ntiles;
+    const bool pend = pend_tile != NO_TILE;
+    if (!have && !pend) { break; }
+    if (threadIdx.x == 0 && have) { next_ticket = atomicAdd(ticket, 1u); }
+
+    // ---- scan the new tile; its bytes stay in wa / wb until the pending tile has left the LDS ------------------------
+    u32 wa[16], wb[16];
+    u64 a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    bool park = false;
+    if (have) {
+      const u64 wave_start = org.begin + u64(tile) * TILE_BYTES + u64(wave) * WAVE_BYTES;
+      u32 n_out = 0, n_in = 0, parity = 0;
+      if (wave_start < len) {
+        park = true;
+        const u32 lookback = lookback_issue(buf, wave_start, lane);
+        const u64 pos0 = wave_start + u64(lane) * BLOCK_BYTES, pos1 = pos0 + CHUNK_BYTES;
+        if (wave_start + WAVE_BYTES <= len) { // wave-uniform: the whole span is input
+          load_block_full(buf, pos0, wa);
+          load_block_full(buf, pos1, wb);
+        } else {
+          load_block(buf, pos0, len, wa); // zero beyond the end
+          load_block(buf, pos1, len, wb);
+        }
+        wave_carry wc = segment_carry_from(buf, wave_start, lane, lookback, esc_ref(org.esc, ESC_SHIFT_MINIFY));
+        {
+          const chunk_masks m = scan_chunk<false, false>(wa, wc, lane);
+          const u64 valid = valid_mask(pos0, len);
+          a0 = valid & m.ws;
+          b0 = m.in_string;
+          n_out += u32(popc64(valid & ~(a0 & ~b0))); // dropped: whitespace outside strings (json_scanner.h:46)
+          n_in += u32(popc64(valid & ~(a0 & b0)));
+        }
+        {
+          const chunk_masks m = scan_chunk<false, false>(wb, wc, lane);
+          const u64 valid = valid_mask(pos1, len);
+          a1 = valid & m.ws;
+          b1 = m.in_string;
+          n_out += u32(popc64(valid & ~(a1 & ~b1)));
+          n_in += u32(popc64(valid & ~(a1 & b1)));
+        }
+        parity = wc.s;
+      }
+      const u32 t_out = wave_sum(n_out), t_in = wave_sum(n_in);
+      if (lane == 0) {
+        sh_wave[cur][wave][0] = parity;
+        sh_wave[cur][wave][1] = t_out;
+        sh_wave[cur][wave][2] = t_in;
+      }
+    }
+    __syncthreads();
+
+    // ---- wave 0: publish the new tile's aggregate, then resolve the PENDING tile's prefix -------------------------
+    if (wave == 0) {
+      if (have) {
+        u32 tq = 0, tout = 0, tin = 0;
+#pragma unroll
+        for (u32 v = 0; v < NW; v++) {
+          const u32 q = sh_wave[cur][v][0], o = sh_wave[cur][v][1], i = sh_wave[cur][v][2];
+          const u32 no = tout + (tq ? i : o), ni = tin + (tq ? o : i);
+          tout = no;
+          tin = ni;
+          tq ^= q;
+        }
+        if (lane == 0) {
+          desc_store(desc + tile, make_agg(tq, tout, tin));
+          sh_agg[cur][0] = tq;
+          sh_agg[cur][1] = tout;
+          sh_agg[cur][2] = tin;
+
+        }
+      }
+      if (pend) {
+        const u32 tq = sh_agg[cur ^ 1u][0], tout = sh_agg[cur ^ 1u][1], tin = sh_agg[cur ^ 1u][2];
+        u32 S = 0, B = 0;
+        const bool ok = lookback(desc, pend_tile, lane, S, B, org);
+        if (lane == 0) {
+          if (ok) {
+            const u32 total = B + (S ? tin : tout), s_end = S ^ tq;
+            desc_store(desc + pend_tile, make_incl(s_end, total));
+            if (pend_tile == ntiles - 1) { // the last tile knows the totals
+              if (s_end) { atomicOr(&result->flags, SJGPU_F_UNCLOSED_STRING); }
+              result->out_len = (s_end && !(carry & CARRY_SHARD)) ? 0ull : u64(total); // json_minifier.h:42-47
+            }
+          } else {
+            desc_store(desc + pend_tile, ST_POISON << 62);
+            atomicOr(&result->flags, SJGPU_F_INTERNAL);
+          }
+          sh_prefix[0] = S;
+          sh_prefix[1] = B;
+          sh_prefix[2] = ok ? 1u : 0u;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- every wave: compact its two parked chunks of the pending tile ----------------------------------------------
+    if (pend && sh_prefix[2] != 0u) {
+      const u64 wave_start = org.begin + u64(pend_tile) * TILE_BYTES + u64(wave) * WAVE_BYTES;
+      u32 s = sh_prefix[0], base = sh_prefix[1];
+      for (u32 v = 0; v < wave; v++) {
+        base += s ? sh_wave[cur ^ 1u][v][2] : sh_wave[cur ^ 1u][v][1];
+        s ^= sh_wave[cur ^ 1u][v][0];
+      }
+      const u64 flip = s ? ~0ull : 0ull;
+#pragma unroll
+      for (u32 c = 0; c < WC; c++) {
+        const u64 cstart = wave_start + u64(c) * CHUNK_BYTES;
+        if (cstart < len) { // wave-uniform
+          const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
+          const u64 a = c ? pa1 : pa0, b = c ? pb1 : pb0;
+          uint4 *const region = reinterpret_cast<uint4 *>(sh_bytes[wave][c]);
+          u32 w[16];
+#pragma unroll
+          for (u32 j = 0; j < 4; j++) {
+            const uint4 q = region[j * 64 + lane];
+            w[4 * j] = q.x; w[4 * j + 1] = q.y; w[4 * j + 2] = q.z; w[4 * j + 3] = q.w;
+          }
+          wave_lds_fence();
+#pragma unroll
+          for (u32 j = 0; j < 4; j++) { region[j * 64 + lane] = make_uint4(0, 0, 0, 0); }
+          if (lane < (ONCHIP_REGION_BYTES - CHUNK_BYTES) / 16) { region[256 + lane] = make_uint4(0, 0, 0, 0); }
+          wave_lds_fence();
+          emit_bytes<false>(w, valid_mask(pos, len) & ~(a & ~(b ^ flip)), lane, out, base, sh_bytes[wave][c], sh_lut);
+        }
+      }
+    }
+    // ---- the tile scanned in this iteration becomes the pending one: park its bytes, keep its masks ----------------
+    if (park) {
+      uint4 *const r0 = reinterpret_cast<uint4 *>(sh_bytes[wave][0]), *const r1 = reinterpret_cast<uint4 *>(sh_bytes[wave][1]);
+#pragma unroll
+      for (u32 j = 0; j < 4; j++) {
+        r0[j * 64 + lane] = make_uint4(wa[4 * j], wa[4 * j + 1], wa[4 * j + 2], wa[4 * j + 3]);
+        r1[j * 64 + lane] = make_uint4(wb[4 * j], wb[4 * j + 1], wb[4 * j + 2], wb[4 * j + 3]);
+      }
+    }
+    pa0 = a0; pa1 = a1; pb0 = b0; pb1 = b1;
+    pend_tile = have ? tile : NO_TILE;
+    if (threadIdx.x == 0) { sh_tile[cur ^ 1u] = have ? next_ticket : NO_TILE; }
+    lds_writes_done(); // see the comment there: the barrier at the loop top must find the ticket in LDS
+  }
 }
 
 } // namespace
@@ -629,26 +815,30 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
                                 hipEvent_t *ev, uint64_t *trace = nullptr, uint32_t trace_tiles = 0) {
   static const bool plain = std::getenv("SJGPU_FUSED_PLAIN") != nullptr; // A/B switch: the non-pipelined large-input kernel
   uint8_t *const esc_workspace = org.esc;
+  const u32 esc_shift = op == 1 ? ESC_SHIFT_MINIFY : ESC_SHIFT_STAGE1;
   if (!wants_escape_table(len - org.begin, org) || !esc_workspace) { org.esc = nullptr; }
   mark(ev, 0, stream); // slot 0 = everything this call enqueues (table, clears, the scan kernel)
   if (len - org.begin <= FUSED_SMALL_BELOW && !trace) {
-    if (org.esc) { launch_escape_table(buf, org.begin, len, esc_workspace, stream); } // a range of a larger buffer
+    if (org.esc) { launch_escape_table(buf, org.begin, len, esc_workspace, stream, nullptr, 0, esc_shift); } // a range of a larger buffer
     launch_fused_wc<1>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles);
     return op == 0 ? "k_fused<0> (16 KiB tiles)" : "k_fused<1> (16 KiB tiles)";
   } else if (trace || plain) {
-    if (org.esc) { launch_escape_table(buf, org.begin, len, esc_workspace, stream); }
+    if (org.esc) { launch_escape_table(buf, org.begin, len, esc_workspace, stream, nullptr, 0, esc_shift); }
     launch_fused_wc<FUSED_WAVE_CHUNKS>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles);
     return op == 0 ? "k_fused<0> (64 KiB tiles)" : "k_fused<1> (64 KiB tiles)";
   } else {
-    const u32 ntiles = u32((len - org.begin + FUSED_TILE_BYTES - 1) / FUSED_TILE_BYTES);
+    static const int onchip = []() { const char *v = std::getenv("SJGPU_MINIFY_ONCHIP"); return v ? std::atoi(v) : 4; }(); // A/B: 0 = re-reading kernel, 4 / 8 waves
+    const u32 onchip_waves = (op == 1 && onchip != 0) ? (onchip == 8 ? 8u : 4u) : 0u;
+    const u64 tile_bytes = onchip_waves ? u64(onchip_waves) * ONCHIP_WAVE_CHUNKS * CHUNK_BYTES : u64(FUSED_TILE_BYTES);
+    const u32 ntiles = u32((len - org.begin + tile_bytes - 1) / tile_bytes);
     u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles);
     // result, descriptors and ticket lie back to back (sjgpu_capi.hip): the escape-table launch zeroes them on the side
     const bool contiguous = reinterpret_cast<uint64_t *>(result + 1) == desc;
     const size_t clear_bytes = sizeof(scan_result_dev) + (size_t(ntiles) + 1) * sizeof(u64);
     if (org.esc && contiguous) {
-      launch_escape_table(buf, org.begin, len, esc_workspace, stream, result, clear_bytes);
+      launch_escape_table(buf, org.begin, len, esc_workspace, stream, result, clear_bytes, esc_shift);
     } else {
-      if (org.esc) { launch_escape_table(buf, org.begin, len, esc_workspace, stream); }
+      if (org.esc) { launch_escape_table(buf, org.begin, len, esc_workspace, stream, nullptr, 0, esc_shift); }
       if (contiguous) {
         (void)hipMemsetAsync(result, 0, clear_bytes, stream);
       } else {
@@ -662,6 +852,16 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
     static const bool prefetch = []() { const char *v = std::getenv("SJGPU_PREFETCH"); return !v || v[0] != '0'; }(); // A/B switch
     static const bool late_ticket = std::getenv("SJGPU_LATE_TICKET") != nullptr;                                       // A/B switch
     if (late_ticket) { org.carry |= CARRY_DEBUG_LATE_TICKET; }
+    if (onchip_waves) {
+      const u32 resident = max_workgroups / (onchip_waves == 8 ? 4u : 2u); // max_workgroups = 8 per CU
+      const u32 g = cap < resident ? cap : resident;
+      if (onchip_waves == 8) { hipLaunchKernelGGL((k_minify_onchip<8>), dim3(g), dim3(512), 0, stream, buf, len, desc, ticket, ntiles, static_cast<u8 *>(out), result, org); }
+      else { hipLaunchKernelGGL((k_minify_onchip<4>), dim3(g), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, static_cast<u8 *>(out), result, org); }
+      mark(ev, 1, stream);
+      mark(ev, 2, stream);
+      mark(ev, 3, stream);
+      return onchip_waves == 8 ? "k_minify_onchip<8>" : "k_minify_onchip<4>";
+    }
     if (op == 0 && prefetch) {
       hipLaunchKernelGGL((k_fused_pipelined<0, true>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result, org);
     } else if (op == 0) {

@@ -58,10 +58,13 @@ inline uint32_t num_groups(uint64_t len) { return (num_segments(len) + RESOLVE_G
 // workspace = one 8-byte descriptor per tile + the ticket word behind them.
 constexpr uint32_t FUSED_WAVE_CHUNKS = 4;
 constexpr uint32_t FUSED_TILE_BYTES = 4 * FUSED_WAVE_CHUNKS * CHUNK_BYTES;
+// k_minify_onchip (bytes of the pending tile wait in LDS): two chunks per wave, 4 or 8 waves per workgroup
+constexpr uint32_t ONCHIP_WAVE_CHUNKS = 2;
+constexpr uint32_t ONCHIP_TILE_BYTES = 4 * ONCHIP_WAVE_CHUNKS * CHUNK_BYTES;
 // inputs up to FUSED_SMALL_BELOW use 16 KiB tiles (one chunk per wave): 4x the parallelism, 1/4 of the per-tile latency
 constexpr uint64_t FUSED_SMALL_BELOW = uint64_t(8) << 20;
 inline uint32_t num_fused_tiles(uint64_t len) { // descriptor words a context needs for documents up to len
-  const uint64_t big = (len + FUSED_TILE_BYTES - 1) / FUSED_TILE_BYTES;
+  const uint64_t big = (len + ONCHIP_TILE_BYTES - 1) / ONCHIP_TILE_BYTES; // the smallest tile any large-input kernel uses
   const uint64_t small_len = len < FUSED_SMALL_BELOW ? len : FUSED_SMALL_BELOW;
   const uint64_t small = (small_len + FUSED_TILE_BYTES / FUSED_WAVE_CHUNKS - 1) / (FUSED_TILE_BYTES / FUSED_WAVE_CHUNKS);
   return uint32_t(big > small ? big : small);
@@ -98,12 +101,17 @@ void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *res
 // Escape table for bytes [begin, len) of buf: esc[s] (s = absolute segment index) = parity of the backslash run that ends in
 // front of byte s * SEG_BYTES, i.e. "that byte is escaped".  One 64-byte read per segment for ordinary input.  esc holds
 // ESC_TABLE_BYTES bytes; entry begin / SEG_BYTES - 1 must be valid (from the previous range of the same buffer) if begin > 0.
-constexpr size_t ESC_TABLE_ENTRIES = (uint64_t(1) << 32) / SEG_BYTES + 1;
+// Entries are 2^shift bytes apart: ESC_SHIFT_STAGE1 for every stage-1 kernel (waves start on 16 KiB boundaries),
+// ESC_SHIFT_MINIFY for every minify kernel (k_minify_onchip's waves start on 8 KiB boundaries).  One operation uses one
+// spacing for all ranges of a buffer, so the "previous range" entries it reads are its own.
+constexpr uint32_t ESC_SHIFT_STAGE1 = 14, ESC_SHIFT_MINIFY = 13;
+static_assert((uint64_t(1) << ESC_SHIFT_STAGE1) == SEG_BYTES, "stage-1 waves start on segment boundaries");
+constexpr size_t ESC_TABLE_ENTRIES = ((uint64_t(1) << 32) >> ESC_SHIFT_MINIFY) + 1;
 constexpr size_t ESC_TABLE_BYTES = (ESC_TABLE_ENTRIES + 1023) & ~size_t(1023); // readers load whole aligned dwords
 // clear / clear_bytes (optional, a multiple of 8): memory the same launch zeroes, so that the single-pass pipeline's
 // result + descriptors + ticket need no memset of their own.
 void launch_escape_table(const uint8_t *buf, uint64_t begin, uint64_t len, uint8_t *esc, hipStream_t stream,
-                         void *clear = nullptr, size_t clear_bytes = 0);
+                         void *clear = nullptr, size_t clear_bytes = 0, uint32_t shift = ESC_SHIFT_STAGE1);
 // whole documents up to FUSED_SMALL_BELOW bytes walk over backslash runs (bounded by their size); longer ones get the
 // table -- and so does EVERY range of a larger buffer, however short: the walk of a short range would otherwise run
 // back over all earlier ranges, and a later range resolves its pass entries through the entries of the ranges in

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64) void k_minify_summarize(const u8 *__restrict__ 
     u32 w[16];
     if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
     else { load_block(buf, pos, len, w); }
-    if (c == 0) { wc = segment_carry_from(buf, seg_start, lane, lookback, org.esc); }
+    if (c == 0) { wc = segment_carry_from(buf, seg_start, lane, lookback, esc_ref(org.esc, ESC_SHIFT_MINIFY)); }
     const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
     const u64 valid = valid_mask(pos, len);
     kept_out += u32(popc64(valid & ~(m.ws & ~m.in_string))); // dropped: whitespace outside strings (json_scanner.h:46)
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64) void k_minify_emit(const u8 *__restrict__ buf, 
     if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
     else { load_block(buf, pos, len, w); }
     if (c == 0) {
-      wc = segment_carry_from(buf, seg_start, lane, lookback, org.esc);
+      wc = segment_carry_from(buf, seg_start, lane, lookback, esc_ref(org.esc, ESC_SHIFT_MINIFY));
       wc.s = pf.in_string; // absolute from here on
     }
     const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
@@ -491,7 +491,7 @@ __device__ __forceinline__ u32 escape_step(const u8 *top, u32 lane) {
 }
 
 __global__ __launch_bounds__(256) void k_escape_table(const u8 *__restrict__ buf, u64 s0, u32 nseg, u8 *__restrict__ esc,
-                                                      u64 *__restrict__ clear, u32 clear_words) {
+                                                      u64 *__restrict__ clear, u32 clear_words, u32 shift) {
   for (u32 i = blockIdx.x * 256u + threadIdx.x; i < clear_words; i += gridDim.x * 256u) { clear[i] = 0; }
   const u32 lane = threadIdx.x & 63u;
   const u32 r0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * ESC_PER_WAVE;
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void k_escape_table(const u8 *__restrict__ buf
     const u64 s = s0 + r0 + i;
     state[i] = 0u; // nothing in front of byte 0
     if (r0 + i < nseg && s > 0) {
-      const u64 m = __ballot(buf[s * SEG_BYTES - 1u - lane] == 0x5Cu);
+      const u64 m = __ballot(buf[(s << shift) - 1u - lane] == 0x5Cu);
       state[i] = ~m ? (ctz64(~m) & 1u) : ESC_PASS;
     }
   }
@@ -510,8 +510,8 @@ __global__ __launch_bounds__(256) void k_escape_table(const u8 *__restrict__ buf
     if (r0 + i >= nseg) { break; }
     const u64 s = s0 + r0 + i;
     u32 st = state[i];
-    for (u32 k = 0; st == ESC_PASS && k < SEG_BYTES / 1024; k++) { // rare: a run of 64 backslashes and more, 1 KiB per step
-      st = escape_step(buf + s * SEG_BYTES - u64(k) * 1024u, lane);
+    for (u32 k = 0; st == ESC_PASS && k < (1u << shift) / 1024u; k++) { // rare: a run of 64 backslashes and more, 1 KiB per step
+      st = escape_step(buf + (s << shift) - u64(k) * 1024u, lane);
     }
     if (lane == 0) { esc[s] = u8(st); }
   }
@@ -550,7 +550,7 @@ void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_pref
                    scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev) {
   const u32 nseg = num_segments(len - org.begin);
   mark(ev, 0, stream); // slot 0 = table + summarize
-  if (wants_escape_table(len - org.begin, org) && org.esc) { launch_escape_table(buf, org.begin, len, org.esc, stream); }
+  if (wants_escape_table(len - org.begin, org) && org.esc) { launch_escape_table(buf, org.begin, len, org.esc, stream, nullptr, 0, ESC_SHIFT_MINIFY); }
   else { org.esc = nullptr; }
   hipLaunchKernelGGL(k_minify_summarize, dim3(nseg), dim3(64), 0, stream, buf, len, summ, org);
   mark(ev, 1, stream);
@@ -590,13 +590,13 @@ void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *res
 }
 
 void launch_escape_table(const uint8_t *buf, uint64_t begin, uint64_t len, uint8_t *esc, hipStream_t stream, void *clear,
-                         size_t clear_bytes) {
-  const u32 nseg = num_segments(len - begin);
+                         size_t clear_bytes, uint32_t shift) {
+  const u32 nseg = u32((len - begin + (u64(1) << shift) - 1) >> shift); // entries: one per 2^shift bytes of the range
   if (nseg == 0) { return; }
-  const u64 s0 = begin / SEG_BYTES;
+  const u64 s0 = begin >> shift;
   const u32 per_wg = 4u * ESC_PER_WAVE;
   hipLaunchKernelGGL(k_escape_table, dim3((nseg + per_wg - 1) / per_wg), dim3(256), 0, stream, buf, s0, nseg, esc,
-                     static_cast<u64 *>(clear), u32(clear_bytes / 8));
+                     static_cast<u64 *>(clear), u32(clear_bytes / 8), shift);
 }
 
 } // namespace sjgpu

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void k_docs(const u8 *__restrict__ in_base, co
   const u64 out_room = (OP == 0) ? u64(d.len) + 3 : u64(d.len);
   bool overflow = false;
   u32 my_flags = 0;
+  lds_writes_done();
   __syncthreads();
 
   for (u64 step_start = 0, step = 0; step_start < len; step_start += DOC_STEP_BYTES, step++) {

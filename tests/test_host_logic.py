@@ -28,6 +28,21 @@ def test_exports_match_header(lib):
         assert hasattr(lib, name), name
 
 
+def test_every_barrier_waits_for_lds(lib):
+    """Round 2: hipcc dropped the `s_waitcnt lgkmcnt(0)` of a __syncthreads() at a loop header (k_minify_onchip); the
+    workgroup's next ticket, stored to LDS at the end of an iteration, was read before the store had been performed
+    and one run in two of a 1 GiB minify came out wrong.  The kernels now wait explicitly (lds_writes_done); this walks
+    the control flow of every kernel in the built library and fails if any s_barrier can be reached from an LDS store
+    without that wait."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_barriers", os.path.join(_paths.REPO_ROOT, "scripts", "check_barriers.py"))
+    cb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cb)
+    objects, found = cb.check(os.path.join(_paths.LIB_DIR, "libsjgpu.so"))
+    assert objects >= 5          # one code object per .hip source
+    assert found == []
+
+
 def test_no_gpu_means_loud_failure(lib):
     import torch
     if torch.cuda.is_available():
