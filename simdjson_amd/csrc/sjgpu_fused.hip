@@ -771,6 +771,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
   }
 }
 
+
 } // namespace
 
 // ---- launchers ----------------------------------------------------------------------------------------
