@@ -15,16 +15,16 @@ for s in $STAGES; do
     tests) timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/pytest_gpu.log ;;
     bench)
       for op in stage1 minify validate_utf8; do
-        timeout 600 python bench.py --op $op --steps 20 --warmup 3 > gpurun_out/bench_$op.json 2> gpurun_out/bench_$op.err; echo "bench $op rc=$?"; cat gpurun_out/bench_$op.json
+        timeout 600 python bench.py --legs none --op $op --steps 20 --warmup 3 > gpurun_out/bench_$op.json 2> gpurun_out/bench_$op.err; echo "bench $op rc=$?"; cat gpurun_out/bench_$op.json
       done
-      timeout 600 python bench.py --pipeline fused --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_stage1_fused.json 2> gpurun_out/bench_stage1_fused.err; cat gpurun_out/bench_stage1_fused.json
-      timeout 600 python bench.py --op minify --pipeline fused --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_minify_fused.json 2> gpurun_out/bench_minify_fused.err; cat gpurun_out/bench_minify_fused.json
+      timeout 600 python bench.py --legs none --pipeline fused --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_stage1_fused.json 2> gpurun_out/bench_stage1_fused.err; cat gpurun_out/bench_stage1_fused.json
+      timeout 600 python bench.py --legs none --op minify --pipeline fused --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_minify_fused.json 2> gpurun_out/bench_minify_fused.err; cat gpurun_out/bench_minify_fused.json
       timeout 600 python bench.py --ndjson-leg 1 --steps 10 --warmup 2 > gpurun_out/bench_ndjson_leg.json 2> gpurun_out/bench_ndjson_leg.err; cat gpurun_out/bench_ndjson_leg.json
-      timeout 600 python bench.py --workload amazon_ndjson --steps 20 --warmup 3 > gpurun_out/bench_stage1_ndjson.json 2> gpurun_out/bench_stage1_ndjson.err; cat gpurun_out/bench_stage1_ndjson.json
-      timeout 600 python bench.py --workload twitter_like --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_stage1_twitter.json 2> gpurun_out/bench_stage1_twitter.err; cat gpurun_out/bench_stage1_twitter.json
+      timeout 600 python bench.py --legs none --workload amazon_ndjson --steps 20 --warmup 3 > gpurun_out/bench_stage1_ndjson.json 2> gpurun_out/bench_stage1_ndjson.err; cat gpurun_out/bench_stage1_ndjson.json
+      timeout 600 python bench.py --legs none --workload twitter_like --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_stage1_twitter.json 2> gpurun_out/bench_stage1_twitter.err; cat gpurun_out/bench_stage1_twitter.json
       for wl in deep_nesting escape_heavy; do
         for pl in fused split; do
-          timeout 600 python bench.py --workload $wl --pipeline $pl --steps 10 --warmup 2 > gpurun_out/bench_stage1_${wl}_${pl}.json 2> gpurun_out/bench_stage1_${wl}_${pl}.err; cat gpurun_out/bench_stage1_${wl}_${pl}.json
+          timeout 600 python bench.py --legs none --workload $wl --pipeline $pl --steps 10 --warmup 2 > gpurun_out/bench_stage1_${wl}_${pl}.json 2> gpurun_out/bench_stage1_${wl}_${pl}.err; cat gpurun_out/bench_stage1_${wl}_${pl}.json
         done
       done
       ;;
@@ -36,7 +36,7 @@ for s in $STAGES; do
       ;;
     prof)
       for op in stage1 minify validate_utf8; do
-        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_$op -o $op -- python $GRAFT_REPO_ROOT/bench.py --op $op --steps 10 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_$op.log 2>&1); echo "prof $op rc=$?"
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_$op -o $op -- python $GRAFT_REPO_ROOT/bench.py --legs none --op $op --steps 10 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_$op.log 2>&1); echo "prof $op rc=$?"
       done
       find gpurun_out -name "*kernel_stats*" | head; for f in $(find gpurun_out -name "*kernel_stats.csv"); do echo "== $f"; head -12 $f; done
       ;;

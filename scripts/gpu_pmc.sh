@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 run() { # name, counters...
   local name=$1; shift
   (cd /tmp && timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG/$name -o $name -- \
-     python $GRAFT_REPO_ROOT/bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG/$name.log 2>&1)
+     python $GRAFT_REPO_ROOT/bench.py --legs none $ARGS --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG/$name.log 2>&1)
   echo "pmc $name rc=$?"
 }
 for set in $SETS; do
