@@ -91,6 +91,55 @@ int sjref_validate_utf8(const char *impl_name, const uint8_t *buf, size_t len) {
   return impl->validate_utf8(reinterpret_cast<const char *>(buf), len) ? 1 : 0;
 }
 
+// ---- strings ---------------------------------------------------------------------------------------------
+// dom_parser_implementation::parse_string (/root/reference/include/simdjson/internal/dom_parser_implementation.h:124) of the
+// named kernel: src behind the opening quote, inside a buffer with SIMDJSON_PADDING readable bytes behind the closing quote;
+// dst with room for the string + SIMDJSON_PADDING.  Returns the unescaped length, or -1 for nullptr.
+long sjref_parse_string(const char *impl_name, const uint8_t *src, uint8_t *dst, int allow_replacement) {
+  auto impl = find_impl(impl_name);
+  if (!impl) { return -2; }
+  std::unique_ptr<dom_parser_implementation> p;
+  if (impl->create_dom_parser_implementation(64, 16, p) != simdjson::SUCCESS) { return -2; }
+  uint8_t *end = p->parse_string(src, dst, allow_replacement != 0);
+  return end ? long(end - dst) : -1;
+}
+
+// A full dom parse (stage 1 + stage 2) with the named kernel; copies document::string_buf -- [u32 length][bytes][0] per
+// string, document order (src/generic/stage2/tape_builder.h:415-433) -- up to the end of the last record the tape points
+// at.  buf must be padded.  Returns the parse's error_code; *used_out / *strings_out from the tape walk.
+int sjref_dom_string_buf(const char *impl_name, const uint8_t *buf, size_t len, uint8_t *out, size_t out_cap, uint64_t *used_out,
+                         uint32_t *strings_out) {
+  auto impl = find_impl(impl_name);
+  if (!impl) { return -1; }
+  std::unique_ptr<dom_parser_implementation> p;
+  if (impl->create_dom_parser_implementation(len ? len : 1, 1024, p) != simdjson::SUCCESS) { return -2; }
+  simdjson::dom::document doc;
+  if (doc.allocate(len) != simdjson::SUCCESS) { return -2; }
+  auto err = p->parse(buf, len, doc);
+  uint64_t used = 0;
+  uint32_t strings = 0;
+  if (err == simdjson::SUCCESS) {
+    const uint64_t end = doc.tape[0] & 0xFFFFFFFFFFFFFFull; // the root entry points behind the last entry
+    for (uint64_t i = 1; i + 1 < end; i++) {
+      const uint64_t v = doc.tape[i];
+      const char type = char(v >> 56);
+      if (type == '"') {
+        const uint64_t at = v & 0xFFFFFFFFFFFFFFull;
+        uint32_t l;
+        std::memcpy(&l, doc.string_buf.get() + at, 4);
+        if (at + 5 + l > used) { used = at + 5 + l; }
+        strings++;
+      } else if (type == 'l' || type == 'u' || type == 'd') {
+        i++; // the value sits in the next slot
+      }
+    }
+    if (used <= out_cap && out) { std::memcpy(out, doc.string_buf.get(), used); }
+  }
+  if (used_out) { *used_out = used; }
+  if (strings_out) { *strings_out = strings; }
+  return int(err);
+}
+
 // ---- timing legs for bench.py's cpu_baseline (reference convention: best-of-N, input bytes only,
 // ---- /root/reference/benchmark/benchmarker.h:315-346,418) -------------------------------------
 static double now_s() {

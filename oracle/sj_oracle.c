@@ -264,6 +264,112 @@ int sjo_minify(const uint8_t *buf, size_t len, uint8_t *dst, size_t *dst_len) {
   return SJO_SUCCESS;
 }
 
+/* ---- strings ------------------------------------------------------------------------------------------ */
+static unsigned str_byte(const uint8_t *p, const uint8_t *end) { return p < end ? *p : 0x20u; }
+
+/* jsoncharutils::hex_to_u32_nocheck (/root/reference/include/simdjson/generic/jsoncharutils.h:31-38): four hex digits,
+ * or a value with bits above 16 set when any of them is not one */
+static uint32_t hex4(const uint8_t *p, const uint8_t *end) {
+  uint32_t v = 0;
+  for (int k = 0; k < 4; k++) {
+    const unsigned c = str_byte(p + k, end);
+    uint32_t d;
+    if (c >= '0' && c <= '9') { d = c - '0'; }
+    else if (c >= 'a' && c <= 'f') { d = c - 'a' + 10; }
+    else if (c >= 'A' && c <= 'F') { d = c - 'A' + 10; }
+    else { return 0xFFFFFFFFu; }
+    v = (v << 4) | d;
+  }
+  return v;
+}
+
+/* jsoncharutils::codepoint_to_utf8 (:52-80): 0 bytes = not a code point */
+static size_t put_utf8(uint32_t cp, uint8_t *c) {
+  if (cp <= 0x7F) { if (c) { c[0] = (uint8_t)cp; } return 1; }
+  if (cp <= 0x7FF) { if (c) { c[0] = (uint8_t)((cp >> 6) + 192); c[1] = (uint8_t)((cp & 63) + 128); } return 2; }
+  if (cp <= 0xFFFF) { if (c) { c[0] = (uint8_t)((cp >> 12) + 224); c[1] = (uint8_t)(((cp >> 6) & 63) + 128); c[2] = (uint8_t)((cp & 63) + 128); } return 3; }
+  if (cp <= 0x10FFFF) {
+    if (c) { c[0] = (uint8_t)((cp >> 18) + 240); c[1] = (uint8_t)(((cp >> 12) & 63) + 128); c[2] = (uint8_t)(((cp >> 6) & 63) + 128); c[3] = (uint8_t)((cp & 63) + 128); }
+    return 4;
+  }
+  return 0;
+}
+
+static uint8_t escape_value(unsigned c) { /* escape_map, stringparsing.h:22-43 */
+  switch (c) {
+  case '"': return 0x22; case '/': return 0x2f; case '\\': return 0x5c;
+  case 'b': return 0x08; case 'f': return 0x0c; case 'n': return 0x0a; case 'r': return 0x0d; case 't': return 0x09;
+  default: return 0;
+  }
+}
+
+long sjo_parse_string(const uint8_t *src, const uint8_t *end, uint8_t *dst, int allow_replacement) {
+  size_t o = 0;
+  for (;;) {
+    if (src >= end) { return -1; } /* no closing quote: stage 1 would have said UNCLOSED_STRING */
+    const unsigned c = *src;
+    if (c == '"') { return (long)o; }
+    if (c != '\\') { if (dst) { dst[o] = (uint8_t)c; } o++; src++; continue; }
+    const unsigned e = str_byte(src + 1, end);
+    if (e != 'u') {
+      const uint8_t v = escape_value(e);
+      if (!v) { return -1; }
+      if (dst) { dst[o] = v; }
+      o++;
+      src += 2;
+      continue;
+    }
+    /* handle_unicode_codepoint (stringparsing.h:50-96) */
+    uint32_t cp = hex4(src + 2, end);
+    src += 6;
+    if (cp >= 0xd800 && cp < 0xdc00) {
+      if (str_byte(src, end) != '\\' || str_byte(src + 1, end) != 'u') {
+        if (!allow_replacement) { return -1; }
+        cp = 0xfffd;
+      } else {
+        const uint32_t low = hex4(src + 2, end) - 0xdc00;
+        if (low >> 10) {
+          if (!allow_replacement) { return -1; }
+          cp = 0xfffd; /* the second escape is NOT consumed: it is looked at again on its own */
+        } else {
+          cp = (((cp - 0xd800) << 10) | low) + 0x10000;
+          src += 6;
+        }
+      }
+    } else if (cp >= 0xdc00 && cp <= 0xdfff) {
+      if (!allow_replacement) { return -1; }
+      cp = 0xfffd;
+    }
+    const size_t k = put_utf8(cp, dst ? dst + o : NULL);
+    if (k == 0) { return -1; }
+    o += k;
+  }
+}
+
+int sjo_string_buffer(const uint8_t *buf, size_t len, const uint32_t *idx, uint32_t n, int allow_replacement, uint8_t *out,
+                      size_t out_cap, uint32_t *offsets, uint64_t *bytes, uint32_t *strings, uint32_t *first_bad) {
+  uint64_t at = 0;
+  uint32_t count = 0, bad = 0xFFFFFFFFu;
+  for (uint32_t i = 0; i < n; i++) {
+    if (offsets) { offsets[i] = 0xFFFFFFFFu; }
+    if (idx[i] >= len || buf[idx[i]] != '"') { continue; }
+    const long l = sjo_parse_string(buf + idx[i] + 1, buf + len, NULL, allow_replacement);
+    if (l < 0) { if (bad == 0xFFFFFFFFu) { bad = i; } continue; }
+    if (at + 5 + (uint64_t)l > out_cap) { return SJO_CAPACITY; }
+    const uint32_t l32 = (uint32_t)l;
+    out[at] = (uint8_t)l32; out[at + 1] = (uint8_t)(l32 >> 8); out[at + 2] = (uint8_t)(l32 >> 16); out[at + 3] = (uint8_t)(l32 >> 24);
+    (void)sjo_parse_string(buf + idx[i] + 1, buf + len, out + at + 4, allow_replacement);
+    out[at + 4 + l32] = 0;
+    if (offsets) { offsets[i] = (uint32_t)at; }
+    at += 5 + (uint64_t)l32;
+    count++;
+  }
+  if (bytes) { *bytes = at; }
+  if (strings) { *strings = count; }
+  if (first_bad) { *first_bad = bad; }
+  return bad == 0xFFFFFFFFu ? SJO_SUCCESS : SJO_STRING_ERROR;
+}
+
 uint64_t sjo_fnv1a64(const void *data, size_t nbytes) {
   const uint8_t *p = (const uint8_t *)data;
   uint64_t h = 0xcbf29ce484222325ull;

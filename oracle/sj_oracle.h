@@ -20,6 +20,7 @@ extern "C" {
 enum {
   SJO_SUCCESS = 0,
   SJO_CAPACITY = 1,
+  SJO_STRING_ERROR = 5,
   SJO_UTF8_ERROR = 11,
   SJO_EMPTY = 13,
   SJO_UNESCAPED_CHARS = 14,
@@ -56,6 +57,22 @@ int sjo_validate_utf8(const uint8_t *buf, size_t len);
 /* host-side helpers of finish(), exposed so tests can pin them one by one */
 size_t sjo_trim_partial_utf8(const uint8_t *buf, size_t len);
 uint32_t sjo_find_next_document_index(const uint8_t *buf, const uint32_t *idx, uint32_t n);
+
+/* ---- the strings of a document, unescaped (stage 2's string work) ------------------------------------
+ * sjo_parse_string: byte-at-a-time restatement of stringparsing::parse_string
+ * (/root/reference/src/generic/stage2/stringparsing.h:150-193 with handle_unicode_codepoint :50-96, escape_map :22-43,
+ * jsoncharutils::hex_to_u32_nocheck / codepoint_to_utf8).  src points BEHIND the opening quote, end is one past the last
+ * readable byte (bytes at or beyond it read as 0x20, the way a space-padded buffer reads); writes the unescaped bytes to
+ * dst (may be NULL: measure only) and returns their number, or -1 where the reference returns nullptr (bad escape, bad
+ * \u hex, lone or unpaired surrogate unless allow_replacement) or the closing quote is missing. */
+long sjo_parse_string(const uint8_t *src, const uint8_t *end, uint8_t *dst, int allow_replacement);
+/* sjo_string_buffer: what dom stage 2 leaves in document::string_buf (tape_builder.h:415-433): for every structural that is
+ * a quote, in document order, [u32 length][unescaped bytes][0].  offsets (n words, may be NULL): offset of structural i's
+ * record, 0xFFFFFFFF for the others.  Returns 0 or SJO_STRING_ERROR; *first_bad = index of the first structural whose
+ * string is invalid (0xFFFFFFFF if none) -- records are produced for the valid strings either way, invalid ones take no
+ * room (the reference stops at the first one, so nothing behind it is observable there). */
+int sjo_string_buffer(const uint8_t *buf, size_t len, const uint32_t *idx, uint32_t n, int allow_replacement, uint8_t *out,
+                      size_t out_cap, uint32_t *offsets, uint64_t *bytes, uint32_t *strings, uint32_t *first_bad);
 
 /* FNV-1a-64 over the n+3 index words (little-endian bytes): the digest SURVEY App. B quotes. */
 uint64_t sjo_fnv1a64(const void *data, size_t nbytes);

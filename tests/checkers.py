@@ -7,6 +7,8 @@ import numpy as np
 from simdjson_amd import _paths
 
 SUCCESS, CAPACITY, UTF8_ERROR, EMPTY, UNESCAPED_CHARS, UNCLOSED_STRING = 0, 1, 11, 13, 14, 15
+STRING_ERROR = 5
+NO_STRING = 0xFFFFFFFF
 MODES = {"regular": 0, "streaming_partial": 1, "streaming_final": 2, "json_sequence_partial": 3,
          "json_sequence_final": 4, "comma_delimited_partial": 5, "comma_delimited_final": 6}
 # error codes after which the reference has not (re)written n_structural_indexes / the array
@@ -42,7 +44,30 @@ class Oracle:
         L.sjo_fnv1a64.argtypes = [_u8p, ctypes.c_size_t]
         L.sjo_bench.restype = ctypes.c_double
         L.sjo_bench.argtypes = [ctypes.c_int, _u8p, ctypes.c_size_t, ctypes.c_int, _u8p]
+        L.sjo_parse_string.restype = ctypes.c_long
+        L.sjo_parse_string.argtypes = [_u8p, _u8p, _u8p, ctypes.c_int]
+        L.sjo_string_buffer.restype = ctypes.c_int
+        L.sjo_string_buffer.argtypes = [_u8p, ctypes.c_size_t, _u8p, ctypes.c_uint32, ctypes.c_int, _u8p, ctypes.c_size_t, _u8p,
+                                        ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
         self.L = L
+
+    def parse_string(self, body, allow_replacement=False):
+        """body = the bytes behind the opening quote (closing quote included).  Returns the unescaped bytes or None."""
+        a = as_u8(body)
+        dst = np.zeros(len(a) + 8, dtype=np.uint8)
+        n = self.L.sjo_parse_string(a.ctypes.data, a.ctypes.data + len(a), dst.ctypes.data, int(allow_replacement))
+        return None if n < 0 else bytes(dst[:n])
+
+    def string_buffer(self, data, idx, n, allow_replacement=False):
+        """(err, bytes of the string buffer, offsets[n], strings, first_bad)"""
+        a = as_u8(data)
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        out = np.zeros(len(a) * 2 + 5 * int(n) + 64, dtype=np.uint8)
+        off = np.zeros(max(int(n), 1), dtype=np.uint32)
+        used, cnt, bad = ctypes.c_uint64(0), ctypes.c_uint32(0), ctypes.c_uint32(0)
+        err = self.L.sjo_string_buffer(a.ctypes.data, len(a), idx.ctypes.data, int(n), int(allow_replacement), out.ctypes.data, len(out),
+                                       off.ctypes.data, ctypes.byref(used), ctypes.byref(cnt), ctypes.byref(bad))
+        return err, out[: used.value].copy(), off[: int(n)].copy(), int(cnt.value), int(bad.value)
 
     def scan(self, data):
         a = as_u8(data)
@@ -93,7 +118,29 @@ class Reference:
         L.sjref_bench.restype = ctypes.c_double
         L.sjref_bench.argtypes = [ctypes.c_char_p, ctypes.c_int, _u8p, ctypes.c_size_t, ctypes.c_int, _u8p,
                                   ctypes.POINTER(ctypes.c_int)]
+        L.sjref_parse_string.restype = ctypes.c_long
+        L.sjref_parse_string.argtypes = [ctypes.c_char_p, _u8p, _u8p, ctypes.c_int]
+        L.sjref_dom_string_buf.restype = ctypes.c_int
+        L.sjref_dom_string_buf.argtypes = [ctypes.c_char_p, _u8p, ctypes.c_size_t, _u8p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64),
+                                           ctypes.POINTER(ctypes.c_uint32)]
         self.L = L
+
+    def parse_string(self, impl, body, allow_replacement=False):
+        """The kernel's parse_string on `body` (bytes behind the opening quote), padded with 128 spaces as a padded_string is."""
+        a = np.concatenate([as_u8(body), np.full(128, 0x20, np.uint8)])
+        dst = np.zeros(len(a) + 128, dtype=np.uint8)
+        n = self.L.sjref_parse_string(impl.encode(), a.ctypes.data, dst.ctypes.data, int(allow_replacement))
+        assert n != -2
+        return None if n < 0 else bytes(dst[:n])
+
+    def dom_string_buf(self, impl, data):
+        """(error_code of dom parse, string_buf bytes, number of strings)"""
+        body = as_u8(data)
+        a = np.concatenate([body, np.full(128, 0x20, np.uint8)])
+        out = np.zeros(len(body) * 2 + 128, dtype=np.uint8)
+        used, cnt = ctypes.c_uint64(0), ctypes.c_uint32(0)
+        err = self.L.sjref_dom_string_buf(impl.encode(), a.ctypes.data, len(body), out.ctypes.data, len(out), ctypes.byref(used), ctypes.byref(cnt))
+        return err, out[: used.value].copy(), int(cnt.value)
 
     def available(self, impl):
         return bool(self.L.sjref_available(impl.encode()))

@@ -116,3 +116,18 @@ def test_random_adversarial_digests(orc):
     g = load("random_digest.json")
     for d in g["digests"]:
         assert digest_results(orc, orc.stage1, orc.minify, orc.validate_utf8, d["seed"]) == d["fnv"], d["seed"]
+
+
+def test_strings_known_answers(orc):
+    """the oracle's parse_string / string buffer against what the reference's x86 kernel produced
+    (tests/golden/make_strings_golden.py): 4 356 string bodies x allow_replacement, and document::string_buf of the fixtures."""
+    g = load("strings.json")
+    for body_hex, allow, want in g["vectors"]:
+        got = orc.parse_string(bytes.fromhex(body_hex), bool(allow))
+        assert (None if got is None else got.hex()) == want, (body_hex, allow)
+    for name, want in g["buffers"].items():
+        data = np.frombuffer(open(os.path.join(GOLD, "jsonexamples", name), "rb").read(), dtype=np.uint8)
+        err, n, idx = orc.stage1(data, 0)
+        assert err == 0
+        e2, buf, off, strings, bad = orc.string_buffer(data, idx, n)
+        assert (e2, strings, len(buf), orc.fnv(buf)) == (0, want["strings"], want["bytes"], want["fnv1a64"]), name
