@@ -198,6 +198,24 @@ int sjgpu_stage1_finish_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
                                uint32_t flags, void *stream, uint32_t *n_io, uint32_t *next_start_out);
 int sjgpu_depth_scan_device(sjgpu_ctx *ctx, const void *buf_dev, const void *idx_dev, uint32_t n, void *depth_dev, void *stream);
 
+/* ---- the strings of a document, unescaped ----------------------------------------------------------
+ * What the reference's stage 2 does at every quote of the structural list: stringparsing::parse_string
+ * (src/generic/stage2/stringparsing.h:150-193; the virtual dom_parser_implementation::parse_string,
+ * include/simdjson/internal/dom_parser_implementation.h:124) into document::string_buf as [u32 length][unescaped bytes][0]
+ * (src/generic/stage2/tape_builder.h:187-205, :415-433) -- here for all strings of the list at once, one lane per
+ * structural: measure, exclusive scan, write.  idx_dev[0..n) is the list sjgpu_stage1_device left for buf_dev[0..len)
+ * (regular mode, no error).  string_buf_dev receives the records in document order, byte for byte the reference's
+ * document::string_buf (5 (len + 1) / 3 bytes always suffice; the reference allocates ROUNDUP(5 len / 3 + 64, 64));
+ * offsets_dev (n + 1 words, may be NULL): offsets_dev[i] = where structural i's record begins -- for a string exactly the
+ * payload of the reference's tape entry -- offsets_dev[i + 1] - offsets_dev[i] = its size (0: not a string, or an invalid
+ * one), offsets_dev[n] = *bytes_out.  allow_replacement as in the reference (On-Demand's option; dom passes false).
+ * Returns SUCCESS, STRING_ERROR (5) when the reference would reject a string (*first_bad_out = list index of the first one;
+ * the records of the valid strings are written all the same), CAPACITY for len > 2.4e9, SJGPU_E_OVERFLOW when
+ * string_buf_bytes is too small, other negatives as usual.  Waits for the stream (reads 24 bytes back). */
+int sjgpu_parse_strings_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const void *idx_dev, uint32_t n, int allow_replacement,
+                               void *string_buf_dev, size_t string_buf_bytes, void *offsets_dev, void *stream, uint64_t *bytes_out,
+                               uint32_t *strings_out, uint32_t *first_bad_out);
+
 /* ---- one large document sharded across GPUs ("general inputs") -------------------------
  * The reference has no counterpart: its stage 1 is one serial pass whose carries (json_escape_scanner.h:50-71
  * next_is_escaped, json_string_scanner.h:62-85 prev_in_string, json_scanner.h:128-157 prev_scalar,

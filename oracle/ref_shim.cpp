@@ -140,6 +140,42 @@ int sjref_dom_string_buf(const char *impl_name, const uint8_t *buf, size_t len, 
   return int(err);
 }
 
+// The string work of stage 2 alone, the way tape_builder does it (visit_string, tape_builder.h:187-205 with :415-433): for every
+// structural that is a quote, parse_string behind a 4-byte length slot, NUL behind it.  buf must be padded; out needs
+// 5 (len + 1) / 3 + 64 bytes.  Returns the best seconds over `iters` runs (after one warm run), negative on failure (incl. a
+// string the kernel rejects); *used_out / *strings_out describe the buffer it leaves in out.
+double sjref_bench_parse_strings(const char *impl_name, const uint8_t *buf, size_t len, const uint32_t *idx, uint32_t n, uint8_t *out, int iters,
+                                 uint64_t *used_out, uint32_t *strings_out) {
+  auto impl = find_impl(impl_name);
+  if (!impl) { return -1.0; }
+  std::unique_ptr<dom_parser_implementation> p;
+  if (impl->create_dom_parser_implementation(64, 16, p) != simdjson::SUCCESS) { return -2.0; }
+  double best = 1e300;
+  uint64_t used = 0;
+  uint32_t strings = 0;
+  for (int it = 0; it < iters + 1; it++) {
+    auto t0 = std::chrono::steady_clock::now();
+    uint8_t *at = out;
+    strings = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      if (idx[i] >= len || buf[idx[i]] != '"') { continue; }
+      uint8_t *dst = p->parse_string(buf + idx[i] + 1, at + sizeof(uint32_t), false);
+      if (!dst) { return -3.0; }
+      const uint32_t l = uint32_t(dst - (at + sizeof(uint32_t)));
+      std::memcpy(at, &l, sizeof(uint32_t));
+      *dst = 0;
+      at = dst + 1;
+      strings++;
+    }
+    used = uint64_t(at - out);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (it > 0 && dt < best) { best = dt; }
+  }
+  if (used_out) { *used_out = used; }
+  if (strings_out) { *strings_out = strings; }
+  return best;
+}
+
 // ---- timing legs for bench.py's cpu_baseline (reference convention: best-of-N, input bytes only,
 // ---- /root/reference/benchmark/benchmarker.h:315-346,418) -------------------------------------
 static double now_s() {

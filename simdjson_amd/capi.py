@@ -29,7 +29,7 @@ EXPORTS = [
     "sjgpu_stage1_range_device", "sjgpu_minify_range_device",
     "sjgpu_host_alloc", "sjgpu_host_free", "sjgpu_host_register", "sjgpu_host_unregister", "sjgpu_last_pipeline",
     "sjgpu_profile_kernel", "sjgpu_debug_trace_pipelined", "sjgpu_stage1_many", "sjgpu_stage1_finish_device",
-    "sjgpu_depth_scan_device", "sjgpu_mgpu_create", "sjgpu_mgpu_destroy", "sjgpu_mgpu_count", "sjgpu_mgpu_stage1", "sjgpu_mgpu_minify",
+    "sjgpu_depth_scan_device", "sjgpu_parse_strings_device", "sjgpu_mgpu_create", "sjgpu_mgpu_destroy", "sjgpu_mgpu_count", "sjgpu_mgpu_stage1", "sjgpu_mgpu_minify",
     "sjgpu_mgpu_validate_utf8",
 ]
 
@@ -110,6 +110,8 @@ def load_library():
     L.sjgpu_stage1_finish_device.argtypes = [vp, vp, sz, ctypes.c_int, vp, ctypes.c_uint32, ctypes.c_uint32, vp, u32p, u32p]
     L.sjgpu_depth_scan_device.restype = ctypes.c_int
     L.sjgpu_depth_scan_device.argtypes = [vp, vp, vp, ctypes.c_uint32, vp, vp]
+    L.sjgpu_parse_strings_device.restype = ctypes.c_int
+    L.sjgpu_parse_strings_device.argtypes = [vp, vp, sz, vp, ctypes.c_uint32, ctypes.c_int, vp, sz, vp, vp, ctypes.POINTER(ctypes.c_uint64), u32p, u32p]
     L.sjgpu_mgpu_create.restype = ctypes.c_int
     L.sjgpu_mgpu_create.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(vp)]
     L.sjgpu_mgpu_destroy.restype = None
@@ -314,6 +316,15 @@ class DomParserImplementation:
         rc = self.L.sjgpu_depth_scan_device(self.h, buf_ptr, idx_ptr, int(n), depth_ptr, stream or None)
         if rc != 0:
             raise SjgpuError(f"sjgpu_depth_scan_device error {rc}: {self.last_error()}")
+
+    def parse_strings_device(self, buf_ptr, length, idx_ptr, n, out_ptr, out_bytes, offsets_ptr=0, allow_replacement=False, stream=0):
+        """sjgpu_parse_strings_device -> (error_code, string buffer bytes used, strings, index of the first invalid string)"""
+        used, cnt, bad = ctypes.c_uint64(0), ctypes.c_uint32(0), ctypes.c_uint32(0)
+        rc = self.L.sjgpu_parse_strings_device(self.h, buf_ptr, int(length), idx_ptr, int(n), int(bool(allow_replacement)), out_ptr, int(out_bytes),
+                                               offsets_ptr or None, stream or None, ctypes.byref(used), ctypes.byref(cnt), ctypes.byref(bad))
+        if rc < 0:
+            raise SjgpuError(f"sjgpu_parse_strings_device error {rc}: {self.last_error()}")
+        return rc, int(used.value), int(cnt.value), int(bad.value)
 
     def result(self, stream=0):  # waits for `stream`
         r = ScanResult()

@@ -1168,6 +1168,35 @@ int sjgpu_depth_scan_device(sjgpu_ctx *ctx, const void *buf_dev, const void *idx
   return 0;
 }
 
+// ---- the strings of a document, unescaped (sjgpu_strings.hip) ----------------------------------------------------------------
+int sjgpu_parse_strings_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const void *idx_dev, uint32_t n, int allow_replacement,
+                               void *string_buf_dev, size_t string_buf_bytes, void *offsets_dev, void *stream, uint64_t *bytes_out,
+                               uint32_t *strings_out, uint32_t *first_bad_out) {
+  if (!ctx || !buf_dev || !idx_dev || !string_buf_dev) { return SJGPU_E_BADARG; }
+  if ((reinterpret_cast<uintptr_t>(buf_dev) & 3u) || (reinterpret_cast<uintptr_t>(offsets_dev) & 3u)) { return SJGPU_E_BADARG; }
+  if (len > 2400000000ull) { return E_CAPACITY; } // record offsets are 32 bits: 5 (len + 1) / 3 bytes of records at most
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  // [result: 32 B][scan scratch][offsets when the caller keeps none]
+  const size_t scratch_at = 32, scratch = (strings_scratch_bytes(n) + 15) & ~size_t(15), offs_at = scratch_at + scratch;
+  int rc = ensure_tmp(ctx, offs_at + (offsets_dev ? 0 : (size_t(n) + 1) * sizeof(uint32_t)));
+  if (rc) { return rc; }
+  uint8_t *tmp = static_cast<uint8_t *>(static_cast<void *>(ctx->d_tmp));
+  strings_result_dev *res = reinterpret_cast<strings_result_dev *>(tmp);
+  uint32_t *offsets = offsets_dev ? static_cast<uint32_t *>(offsets_dev) : reinterpret_cast<uint32_t *>(tmp + offs_at);
+  hipStream_t s = pick(ctx, stream);
+  launch_parse_strings(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, allow_replacement != 0,
+                       static_cast<uint8_t *>(string_buf_dev), string_buf_bytes, offsets, res, tmp + scratch_at, s);
+  SJ_TRY(ctx, hipGetLastError());
+  strings_result_dev h;
+  SJ_TRY(ctx, hipMemcpyAsync(&h, res, sizeof(h), hipMemcpyDeviceToHost, s));
+  SJ_TRY(ctx, hipStreamSynchronize(s));
+  if (bytes_out) { *bytes_out = h.bytes; }
+  if (strings_out) { *strings_out = h.strings; }
+  if (first_bad_out) { *first_bad_out = h.first_bad; }
+  if (h.overflow) { return SJGPU_E_OVERFLOW; }
+  return h.first_bad != 0xFFFFFFFFu ? 5 /* STRING_ERROR */ : 0;
+}
+
 // ---- many small documents per launch (sjgpu_small.hip) -----------------------------------------------------------------------
 int sjgpu_stage1_many(sjgpu_ctx *ctx, sjgpu_doc *docs, size_t count) {
   if (!ctx || (count && !docs) || count > 0xFFFFFFu) { return SJGPU_E_BADARG; }

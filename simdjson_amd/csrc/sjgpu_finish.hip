@@ -298,7 +298,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_count_below(const u32 *__restri
 // ---- host side: enqueue the kernels of one finish ------------------------------------------------------------------------------
 static inline u32 blocks_for(u64 n, u32 per) { return u32((n + per - 1) / per); }
 
-static void enqueue_scan(int *a, u32 n_max, const u32 *n_ptr, int *partial, hipStream_t s) {
+void enqueue_scan(int *a, u32 n_max, const u32 *n_ptr, int *partial, hipStream_t s) {
   const u32 nb = blocks_for(n_max, FIN_BLOCK);
   hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(FIN_THREADS), 0, s, a, n_ptr, partial);
   if (nb > 1) {

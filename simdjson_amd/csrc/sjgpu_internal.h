@@ -172,5 +172,19 @@ uint32_t launch_stage1_pipelined_traced(const uint8_t *buf, uint64_t len, uint64
 const char *launch_minify_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint8_t *dst, scan_result_dev *result,
                                 scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev);
 
+// ---- strings (sjgpu_strings.hip) -------------------------------------------------------------------------------
+struct strings_result_dev {
+  uint64_t bytes;     // string buffer bytes used
+  uint32_t strings;   // records written
+  uint32_t first_bad; // index of the first structural whose string the reference rejects, 0xFFFFFFFF = none
+  uint32_t overflow;  // a record did not fit into the caller's buffer
+  uint32_t pad;
+};
+size_t strings_scratch_bytes(uint32_t n);
+void launch_parse_strings(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
+                          uint32_t *offsets, strings_result_dev *res, void *scratch, hipStream_t s);
+// in-place exclusive scan of a[0 .. *n_ptr) (n_max >= *n_ptr sizes the grid); partial: blocks_for(n_max, 4096) + 64 ints (sjgpu_finish.hip)
+void enqueue_scan(int *a, uint32_t n_max, const uint32_t *n_ptr, int *partial, hipStream_t s);
+
 } // namespace sjgpu
 #endif

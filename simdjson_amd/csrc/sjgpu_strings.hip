@@ -1,0 +1,343 @@
+// simdjson_amd/csrc/sjgpu_strings.hip -- SURVEY 8(f3): the strings of a document, unescaped on the device.
+//
+// The reference's stage 2 walks the structural list and, at every quote, calls stringparsing::parse_string
+// (/root/reference/src/generic/stage2/stringparsing.h:150-193) to copy the string into document::string_buf as
+// [u32 length][unescaped bytes][0] (tape_builder.h:415-433, visit_string :187-205).  That work is independent per token:
+// the list says where every string begins, the bytes say where it ends.  Here one lane owns one structural:
+//   1. k_strings<false> : the string behind every quote of the list is walked once and reports 5 + unescaped length (0 for
+//                      the other structurals and for strings the reference rejects: bad escape, bad \u hex, unpaired
+//                      surrogate -- the first such structural is kept with atomicMin);
+//   2. exclusive scan of the sizes (the three scan kernels of sjgpu_finish.hip): offsets[i] = where structural i's record
+//      begins -- for a string exactly the payload of the reference's tape entry for it -- offsets[n] = bytes used;
+//   3. k_strings<true>  : the records are written.
+// Output is byte for byte document::string_buf of the reference's dom parse (tests/test_gpu_parity.py::test_string_buffer_*).
+// Bytes at or beyond len read as 0x20, like the padding of a padded_string.
+#include "sjgpu_device.h"
+
+namespace sjgpu {
+namespace {
+
+constexpr u32 STR_THREADS = 256;
+constexpr u32 NO_STRING = 0xFFFFFFFFu;
+
+__device__ __forceinline__ u32 str_byte(const u8 *__restrict__ buf, u64 len, u64 pos) { return pos < len ? u32(buf[pos]) : 0x20u; }
+
+// four bytes at any position of a 4-byte aligned buffer (two aligned loads + v_alignbyte); the caller guarantees pos + 8 <= len
+__device__ __forceinline__ u32 load4_unaligned(const u8 *__restrict__ buf, u64 pos) {
+  const u32 *w = reinterpret_cast<const u32 *>(buf + (pos & ~u64(3)));
+  return __builtin_amdgcn_alignbyte(w[1], w[0], u32(pos) & 3u);
+}
+typedef u32 __attribute__((aligned(1))) u32_unaligned; // gfx950 stores a dword at any byte address
+// 0x80 in every byte of x that is zero; exact for the LOWEST flagged byte, which is all the callers use
+__device__ __forceinline__ u32 zero_bytes(u32 x) { return (x - 0x01010101u) & ~x & 0x80808080u; }
+
+// jsoncharutils::hex_to_u32_nocheck (/root/reference/include/simdjson/generic/jsoncharutils.h:31-38)
+__device__ __forceinline__ u32 hex4(const u8 *__restrict__ buf, u64 len, u64 pos) {
+  u32 v = 0;
+#pragma unroll
+  for (u32 k = 0; k < 4; k++) {
+    const u32 c = str_byte(buf, len, pos + k);
+    u32 d;
+    if (c - u32('0') <= 9u) { d = c - u32('0'); }
+    else if ((c | 0x20u) - u32('a') <= 5u) { d = (c | 0x20u) - u32('a') + 10u; }
+    else { return 0xFFFFFFFFu; }
+    v = (v << 4) | d;
+  }
+  return v;
+}
+__device__ __forceinline__ u32 escape_value(u32 c) { // escape_map, stringparsing.h:22-43
+  switch (c) {
+  case '"': return 0x22u;
+  case '/': return 0x2fu;
+  case '\\': return 0x5cu;
+  case 'b': return 0x08u;
+  case 'f': return 0x0cu;
+  case 'n': return 0x0au;
+  case 'r': return 0x0du;
+  case 't': return 0x09u;
+  default: return 0u;
+  }
+}
+
+// parse_string for the string whose first byte is buf[pos]; WRITE: the unescaped bytes go to dst.  Returns the unescaped
+// length or -1 (the reference's nullptr).
+template <bool WRITE>
+__device__ __forceinline__ int unescape(const u8 *__restrict__ buf, u64 len, u64 pos, u8 *__restrict__ dst, bool allow_replacement) {
+  u32 o = 0;
+  for (;;) {
+    u32 c;
+    if (pos + 8 <= len) { // four bytes at a time while nothing special shows up
+      const u32 v = load4_unaligned(buf, pos);
+      const u32 special = zero_bytes(v ^ 0x22222222u) | zero_bytes(v ^ 0x5C5C5C5Cu);
+      const u32 plain = special ? (u32(__builtin_ctz(special)) >> 3) : 4u; // bytes in front of the first quote / backslash
+      if (WRITE) {
+        if (plain == 4u) { *reinterpret_cast<u32_unaligned *>(dst + o) = v; }
+        else { for (u32 k = 0; k < plain; k++) { dst[o + k] = u8(v >> (8u * k)); } }
+      }
+      o += plain;
+      pos += plain;
+      if (!special) { continue; }
+      c = (v >> (8u * plain)) & 0xFFu;
+    } else {
+      if (pos >= len) { return -1; } // no closing quote (stage 1 said UNCLOSED_STRING)
+      c = buf[pos];
+      if (c != '"' && c != '\\') {
+        if (WRITE) { dst[o] = u8(c); }
+        o++;
+        pos++;
+        continue;
+      }
+    }
+    if (c == '"') { return int(o); }
+    const u32 e = str_byte(buf, len, pos + 1);
+    if (e != 'u') {
+      const u32 m = escape_value(e);
+      if (!m) { return -1; }
+      if (WRITE) { dst[o] = u8(m); }
+      o++;
+      pos += 2;
+      continue;
+    }
+    // handle_unicode_codepoint (stringparsing.h:50-96)
+    u32 cp = hex4(buf, len, pos + 2);
+    pos += 6;
+    if (cp >= 0xd800u && cp < 0xdc00u) {
+      if (str_byte(buf, len, pos) != '\\' || str_byte(buf, len, pos + 1) != 'u') {
+        if (!allow_replacement) { return -1; }
+        cp = 0xfffdu;
+      } else {
+        const u32 low = hex4(buf, len, pos + 2) - 0xdc00u;
+        if (low >> 10) {
+          if (!allow_replacement) { return -1; }
+          cp = 0xfffdu; // the second escape is not consumed: it is looked at again on its own
+        } else {
+          cp = (((cp - 0xd800u) << 10) | low) + 0x10000u;
+          pos += 6;
+        }
+      }
+    } else if (cp >= 0xdc00u && cp <= 0xdfffu) {
+      if (!allow_replacement) { return -1; }
+      cp = 0xfffdu;
+    }
+    // jsoncharutils::codepoint_to_utf8 (:52-80)
+    if (cp <= 0x7Fu) {
+      if (WRITE) { dst[o] = u8(cp); }
+      o += 1;
+    } else if (cp <= 0x7FFu) {
+      if (WRITE) { dst[o] = u8((cp >> 6) + 192u); dst[o + 1] = u8((cp & 63u) + 128u); }
+      o += 2;
+    } else if (cp <= 0xFFFFu) {
+      if (WRITE) { dst[o] = u8((cp >> 12) + 224u); dst[o + 1] = u8(((cp >> 6) & 63u) + 128u); dst[o + 2] = u8((cp & 63u) + 128u); }
+      o += 3;
+    } else if (cp <= 0x10FFFFu) {
+      if (WRITE) {
+        dst[o] = u8((cp >> 18) + 240u); dst[o + 1] = u8(((cp >> 12) & 63u) + 128u);
+        dst[o + 2] = u8(((cp >> 6) & 63u) + 128u); dst[o + 3] = u8((cp & 63u) + 128u);
+      }
+      o += 4;
+    } else {
+      return -1; // not hex
+    }
+  }
+}
+
+// ---- one long string, all 64 lanes of a wave -------------------------------------------------------------------------------------
+// Lanes look at 4 bytes each (256 per step).  Everything up to the first quote or backslash of the step is plain text and is
+// copied by the lanes that hold it; a quote ends the string, an escape is decoded by uniform code (all lanes compute the same
+// thing, lane 0 stores) and the walk resumes behind it.  Same results as unescape<>, which the short strings use.
+template <bool WRITE>
+__device__ __forceinline__ int unescape_wave(const u8 *__restrict__ buf, u64 len, u64 pos, u8 *__restrict__ dst, bool allow_replacement, u32 lane) {
+  u32 o = 0; // wave-uniform
+  for (;;) {
+    const u64 mine = pos + 4ull * lane;
+    u32 v;
+    if (pos + 264 <= len) { v = load4_unaligned(buf, mine); }
+    else { v = str_byte(buf, len, mine) | (str_byte(buf, len, mine + 1) << 8) | (str_byte(buf, len, mine + 2) << 16) | (str_byte(buf, len, mine + 3) << 24); }
+    const u32 special = zero_bytes(v ^ 0x22222222u) | zero_bytes(v ^ 0x5C5C5C5Cu);
+    const u32 first = special ? (u32(__builtin_ctz(special)) >> 3) : 4u;
+    const u64 m = __ballot(special != 0);
+    if (m == 0) { // 256 plain bytes
+      if (pos + 256 > len) { return -1; } // ran off the input: no closing quote
+      if (WRITE) { *reinterpret_cast<u32_unaligned *>(dst + o + 4u * lane) = v; }
+      o += 256;
+      pos += 256;
+      continue;
+    }
+    const u32 l0 = ctz64(m);
+    const u32 k = readlane_dyn(first, l0);
+    const u32 plain = 4u * l0 + k;
+    if (pos + plain >= len) { return -1; }
+    if (WRITE) {
+      if (lane < l0) { *reinterpret_cast<u32_unaligned *>(dst + o + 4u * lane) = v; }
+      if (lane == l0) {
+        for (u32 b = 0; b < k; b++) { dst[o + 4u * l0 + b] = u8(v >> (8u * b)); }
+      }
+    }
+    const u32 c = (readlane_dyn(v, l0) >> (8u * k)) & 0xFFu;
+    o += plain;
+    pos += plain;
+    if (c == '"') { return int(o); }
+    // an escape: decoded by every lane alike (uniform), stored by lane 0
+    const u32 e = str_byte(buf, len, pos + 1);
+    if (e != 'u') {
+      const u32 mapped = escape_value(e);
+      if (!mapped) { return -1; }
+      if (WRITE && lane == 0) { dst[o] = u8(mapped); }
+      o++;
+      pos += 2;
+      continue;
+    }
+    u32 cp = hex4(buf, len, pos + 2);
+    pos += 6;
+    if (cp >= 0xd800u && cp < 0xdc00u) {
+      if (str_byte(buf, len, pos) != '\\' || str_byte(buf, len, pos + 1) != 'u') {
+        if (!allow_replacement) { return -1; }
+        cp = 0xfffdu;
+      } else {
+        const u32 low = hex4(buf, len, pos + 2) - 0xdc00u;
+        if (low >> 10) {
+          if (!allow_replacement) { return -1; }
+          cp = 0xfffdu;
+        } else {
+          cp = (((cp - 0xd800u) << 10) | low) + 0x10000u;
+          pos += 6;
+        }
+      }
+    } else if (cp >= 0xdc00u && cp <= 0xdfffu) {
+      if (!allow_replacement) { return -1; }
+      cp = 0xfffdu;
+    }
+    u32 bytes, packed; // UTF-8, first byte in the low bits
+    if (cp <= 0x7Fu) { bytes = 1; packed = cp; }
+    else if (cp <= 0x7FFu) { bytes = 2; packed = ((cp >> 6) + 192u) | (((cp & 63u) + 128u) << 8); }
+    else if (cp <= 0xFFFFu) { bytes = 3; packed = ((cp >> 12) + 224u) | ((((cp >> 6) & 63u) + 128u) << 8) | (((cp & 63u) + 128u) << 16); }
+    else if (cp <= 0x10FFFFu) {
+      bytes = 4;
+      packed = ((cp >> 18) + 240u) | ((((cp >> 12) & 63u) + 128u) << 8) | ((((cp >> 6) & 63u) + 128u) << 16) | (((cp & 63u) + 128u) << 24);
+    } else {
+      return -1; // not hex
+    }
+    if (WRITE && lane == 0) {
+      for (u32 b = 0; b < bytes; b++) { dst[o + b] = u8(packed >> (8u * b)); }
+    }
+    o += bytes;
+  }
+}
+
+// ---- the two passes ------------------------------------------------------------------------------------------------------------------
+// A workgroup takes STR_TILE consecutive structurals, gathers the ones that are quotes into two LDS lists -- short strings
+// (at most STR_SHORT bytes up to the next structural) and long ones -- and works them off with every lane busy: one lane per
+// short string, one wave per long string.  Only ~27 % of twitter-like structurals are strings, and their lengths span 0 ... 140
+// bytes: without the lists three lanes in four idle and the rest wait for the longest string of their wave.
+constexpr u32 STR_TILE = 2048, STR_SHORT = 28;
+
+// WRITE = false: sizes[i] = 5 + unescaped length for a valid string, else 0; sizes[n] = 0 (the scan turns it into the total).
+// WRITE = true : offsets[] = exclusive scan of the sizes (n + 1 entries, CSR style: offsets[i + 1] - offsets[i] = size of
+//                structural i's record, 0 = it has none; offsets[n] = bytes used); the records are written.
+template <bool WRITE>
+__global__ __launch_bounds__(STR_THREADS) void k_strings(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, u32 allow_replacement,
+                                                       u32 *__restrict__ sizes_or_offsets, u8 *__restrict__ out, u64 out_cap, strings_result_dev *__restrict__ res) {
+  __shared__ u32 sh_short[STR_TILE], sh_long[STR_TILE];
+  __shared__ u32 sh_n_short, sh_n_long;
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const bool allow = allow_replacement != 0;
+  if (tid == 0) { sh_n_short = 0; sh_n_long = 0; }
+  __syncthreads();
+  const u64 tile0 = u64(blockIdx.x) * STR_TILE;
+  for (u32 k = 0; k < STR_TILE / STR_THREADS; k++) {
+    const u64 i = tile0 + k * STR_THREADS + tid;
+    bool is_string = false;
+    u32 reach = 0;
+    if (i < n) {
+      const u32 at = idx[i];
+      const u32 next = idx[i + 1]; // the sentinel behind the list (= len) for the last one
+      is_string = at < len && buf[at] == '"';
+      reach = next - at;
+    }
+    if (!WRITE && i <= n && !is_string) { sizes_or_offsets[i] = 0; }
+    const bool is_short = is_string && reach <= STR_SHORT + 1u;
+    const u64 ms = __ballot(is_short), ml = __ballot(is_string && !is_short);
+    u32 base_s = 0, base_l = 0;
+    if (lane == 0) {
+      if (ms) { base_s = atomicAdd(&sh_n_short, u32(popc64(ms))); }
+      if (ml) { base_l = atomicAdd(&sh_n_long, u32(popc64(ml))); }
+    }
+    base_s = readlane(base_s, 0);
+    base_l = readlane(base_l, 0);
+    const u64 below = lanemask_lt(lane);
+    if (is_short) { sh_short[base_s + u32(popc64(ms & below))] = u32(i - tile0); }
+    else if (is_string) { sh_long[base_l + u32(popc64(ml & below))] = u32(i - tile0); }
+  }
+  __syncthreads();
+  const u32 n_short = sh_n_short, n_long = sh_n_long;
+  u32 valid = 0;
+  // ---- one lane per short string
+  for (u32 j = tid; j < n_short; j += STR_THREADS) {
+    const u64 i = tile0 + sh_short[j];
+    const u64 first = u64(idx[i]) + 1;
+    if (!WRITE) {
+      const int l = unescape<false>(buf, len, first, nullptr, allow);
+      if (l < 0) { atomicMin(&res->first_bad, u32(i)); sizes_or_offsets[i] = 0; }
+      else { sizes_or_offsets[i] = 5u + u32(l); valid++; }
+    } else {
+      const u32 off = sizes_or_offsets[i], size = sizes_or_offsets[i + 1] - off;
+      if (size == 0) { continue; }
+      if (u64(off) + size > out_cap) { res->overflow = 1; continue; }
+      u8 *rec = out + off;
+      const u32 l = size - 5u;
+      *reinterpret_cast<u32_unaligned *>(rec) = l;
+      (void)unescape<true>(buf, len, first, rec + 4, allow);
+      rec[4 + l] = 0;
+    }
+  }
+  // ---- one wave per long string
+  for (u32 j = wave; j < n_long; j += STR_THREADS / 64) {
+    const u64 i = tile0 + sh_long[j];
+    const u64 first = u64(idx[i]) + 1;
+    if (!WRITE) {
+      const int l = unescape_wave<false>(buf, len, first, nullptr, allow, lane);
+      if (lane == 0) {
+        if (l < 0) { atomicMin(&res->first_bad, u32(i)); sizes_or_offsets[i] = 0; }
+        else { sizes_or_offsets[i] = 5u + u32(l); valid++; }
+      }
+    } else {
+      const u32 off = sizes_or_offsets[i], size = sizes_or_offsets[i + 1] - off;
+      if (size == 0) { continue; } // wave-uniform
+      if (u64(off) + size > out_cap) { res->overflow = 1; continue; }
+      u8 *rec = out + off;
+      const u32 l = size - 5u;
+      (void)unescape_wave<true>(buf, len, first, rec + 4, allow, lane);
+      if (lane == 0) {
+        *reinterpret_cast<u32_unaligned *>(rec) = l;
+        rec[4 + l] = 0;
+      }
+    }
+  }
+  if (!WRITE) {
+    const u32 total = wave_sum(valid);
+    if (lane == 0 && total) { atomicAdd(&res->strings, total); }
+  } else if (blockIdx.x == 0 && tid == 0) {
+    res->bytes = sizes_or_offsets[n];
+  }
+}
+
+} // namespace
+
+size_t strings_scratch_bytes(uint32_t n) { return 64 + (size_t(n) / 4096 + 72) * 4; }
+
+// scratch: strings_scratch_bytes(n); offsets: n + 1 words; everything asynchronous on `s`
+void launch_parse_strings(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
+                          uint32_t *offsets, strings_result_dev *res, void *scratch, hipStream_t s) {
+  u32 *n_ptr = static_cast<u32 *>(scratch);
+  int *partial = reinterpret_cast<int *>(n_ptr + 4);
+  const u32 n1 = n + 1;
+  strings_result_dev init{0ull, 0u, NO_STRING, 0u, 0u};
+  (void)hipMemcpyAsync(res, &init, sizeof(init), hipMemcpyHostToDevice, s);
+  (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(n_ptr), int(n1), 1, s);
+  const u32 grid = u32((u64(n1) + STR_TILE - 1) / STR_TILE);
+  hipLaunchKernelGGL(k_strings<false>, dim3(grid), dim3(STR_THREADS), 0, s, buf, len, idx, n, allow_replacement ? 1u : 0u, offsets, out, out_cap, res);
+  enqueue_scan(reinterpret_cast<int *>(offsets), n1, n_ptr, partial, s);
+  hipLaunchKernelGGL(k_strings<true>, dim3(grid), dim3(STR_THREADS), 0, s, buf, len, idx, n, allow_replacement ? 1u : 0u, offsets, out, out_cap, res);
+}
+
+} // namespace sjgpu

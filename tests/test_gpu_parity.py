@@ -54,6 +54,15 @@ def orc():
     return checkers.Oracle()
 
 
+@pytest.fixture(scope="module")
+def ref():
+    """the real reference where its library travelled along (and the host CPU can run an x86 kernel), else None"""
+    if not checkers.have_reference_lib():
+        return None
+    r = checkers.Reference()
+    return r if r.best_impl() else None
+
+
 def g_stage1(p, data, mode=0):
     err = p.stage1(data, mode)
     n = p.n_structural_indexes
@@ -512,6 +521,122 @@ def test_depth_scan(orc):
         assert np.array_equal(got, want), (name, first_diff(got, want))
         if name in ("twitter.json", "citm", "large_random 20 MiB", "deep_nesting"):
             assert want[-1] == 0 and want.min() == 0  # a valid document closes what it opens
+    p.close()
+
+
+# ---- the strings of a document, unescaped on the device -----------------------------------------------------------------
+def _device_strings(p, a, allow=False):
+    """-> (err, string buffer bytes, CSR offsets[n + 1], strings, first_bad, n, idx) through stage1_device + parse_strings_device"""
+    import torch
+    stream = torch.cuda.current_stream().cuda_stream
+    L = len(a)
+    buf = torch.from_numpy(np.ascontiguousarray(a).copy()).cuda()
+    idx = torch.empty(L + 16, dtype=torch.int32, device="cuda")
+    assert p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, stream) == 0
+    n, flags, _ = p.result(stream)
+    assert flags == 0
+    cap = 5 * (L + 1) // 3 + 64
+    out = torch.full((cap,), 0xEE, dtype=torch.uint8, device="cuda")
+    off = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+    err, used, strings, bad = p.parse_strings_device(buf.data_ptr(), L, idx.data_ptr(), n, out.data_ptr(), cap, off.data_ptr(), allow, stream)
+    assert bool((out[used:] == 0xEE).all())  # nothing behind the last record was touched
+    return err, out[:used].cpu().numpy(), off.cpu().numpy().view(np.uint32), strings, bad, n, idx[:n].cpu().numpy().view(np.uint32)
+
+
+def _csr(noffsets, used):
+    """the oracle's per-structural offsets (NO_STRING for the others) -> CSR form (offsets[i] = start of the next record)"""
+    out = np.empty(len(noffsets) + 1, dtype=np.uint32)
+    nxt = used
+    out[-1] = used
+    for i in range(len(noffsets) - 1, -1, -1):
+        if noffsets[i] != checkers.NO_STRING:
+            nxt = noffsets[i]
+        out[i] = nxt
+    return out
+
+
+def test_string_buffer_is_the_reference_s(orc, ref):
+    """document::string_buf of the reference's dom parse ([u32 length][unescaped bytes][0] per string, document order:
+    src/generic/stage2/tape_builder.h:415-433) comes out of sjgpu_parse_strings_device byte for byte; the offsets are the payloads
+    of the reference's tape entries."""
+    p = capi.DomParserImplementation(64 << 20)
+    ex = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jsonexamples")
+    gold = load("strings.json")["buffers"]
+    docs = {"twitter.json": np.fromfile(os.path.join(ex, "twitter.json"), dtype=np.uint8), "citm_catalog.json": np.fromfile(os.path.join(ex, "citm_catalog.json"), dtype=np.uint8),
+            "twitter_like 24 MiB": corpus.twitter_like(24 << 20, 5)[0], "large_random 8 MiB": corpus.large_random(8 << 20, 3)[0],
+            "escape_heavy 2 MiB": corpus.escape_heavy(2 << 20)[0], "empty strings": np.frombuffer(b'["","","a",""]', np.uint8), "no strings": np.frombuffer(b"[1,2,{}]", np.uint8)}
+    for name, a in docs.items():
+        err, got, off, strings, bad, n, idx = _device_strings(p, a)
+        oerr, want, ooff, ostrings, obad = orc.string_buffer(a, idx, n)
+        assert (err, strings, bad) == (oerr, ostrings, obad) == (0, ostrings, checkers.NO_STRING), name
+        assert np.array_equal(got, want), (name, first_diff(got, want))
+        assert np.array_equal(off, _csr(ooff, len(want))), name
+        if name in gold:  # the committed known answers of the reference itself
+            assert (strings, len(got), orc.fnv(got)) == (gold[name]["strings"], gold[name]["bytes"], gold[name]["fnv1a64"]), name
+        if ref is not None and name != "escape_heavy 2 MiB":
+            rerr, rbuf, rstrings = ref.dom_string_buf(ref.best_impl(), a)
+            if rerr == 0:  # a whole valid document: the live reference agrees
+                assert rstrings == strings and np.array_equal(rbuf, got), name
+    p.close()
+
+
+def test_strings_with_every_escape_and_every_error(orc):
+    """Every hand-written body of the CPU tier's vectors (all escapes, surrogate pairs, lone / unpaired surrogates, bad hex, bad
+    escape characters, escapes around the 4-byte fast path and at the end of the buffer), valid and invalid ones side by side in one
+    document, with and without allow_replacement: same records, same first offender, same error code as the oracle (which is pinned
+    against the reference's parse_string on exactly these bodies, tests/golden/strings.json)."""
+    from test_oracle_vs_reference import STRING_BODIES
+    p = capi.DomParserImplementation(8 << 20)
+    bodies = list(STRING_BODIES)
+    for pre in (0, 1, 2, 3, 4, 5, 7, 8, 9, 30, 33, 64):
+        for esc in (b'\\n', b'\\u0041', b'\\ud83d\\ude00', b'\\"', b'\\\\', b'\\q', b'\\ud800', b'\\udc00x', b'\\u00e9', b'\\u12G4'):
+            bodies.append(b'a' * pre + esc + b'tail"')
+    # only bodies stage 1 accepts as ONE string token followed by a separator can sit in a document
+    usable = []
+    for b in bodies:
+        doc = np.frombuffer(b'["' + b + b',0]', np.uint8)
+        e1, n, idx = orc.stage1(doc, 0)
+        if e1 == 0 and n == 5 and orc.validate_utf8(doc):
+            usable.append(b)
+    assert len(usable) > 100
+    good = [b for b in usable if orc.parse_string(b, False) is not None]
+    for allow in (False, True):
+        for chosen, label in ((good, "valid only"), (usable, "valid and invalid")):
+            doc = np.frombuffer(b'[' + b','.join(b'"' + b for b in chosen) + b']', np.uint8)
+            err, got, off, strings, bad, n, idx = _device_strings(p, doc, allow)
+            oerr, want, ooff, ostrings, obad = orc.string_buffer(doc, idx, n, allow)
+            assert (err, strings, bad) == (oerr, ostrings, obad), (label, allow)
+            assert np.array_equal(got, want), (label, allow, first_diff(got, want))
+            assert np.array_equal(off, _csr(ooff, len(want))), (label, allow)
+            if label == "valid and invalid" and not allow:
+                assert err == checkers.STRING_ERROR and doc[idx[bad]] == 0x22
+    # the last string of a buffer: escapes whose look-ahead runs into the end of the input
+    for tail in (b'["\\u12"]', b'["\\ud83d\\u"]', b'["x\\', b'["\\ud83d\\ude0'):
+        doc = np.frombuffer(tail, np.uint8)
+        e1, n, idx = orc.stage1(doc, 0)
+        if e1 != 0:
+            continue  # stage 1 already rejects it (unclosed string): stage 2 never sees it
+        err, got, off, strings, bad, n, idx = _device_strings(p, doc)
+        oerr, want, ooff, ostrings, obad = orc.string_buffer(doc, idx, n)
+        assert (err, strings, bad) == (oerr, ostrings, obad) and np.array_equal(got, want), tail
+    p.close()
+
+
+@pytest.mark.parametrize("kind", ["twitter_like", "amazon_ndjson"])
+def test_full_size_strings(orc, kind):
+    """256 MiB through the device path, digest against the oracle's buffer."""
+    import time
+    import torch
+    p = capi.DomParserImplementation(512 << 20)
+    a = getattr(corpus, kind)(256 << 20, 9)[0]
+    t0 = time.perf_counter()
+    err, got, off, strings, bad, n, idx = _device_strings(p, a)
+    dt = time.perf_counter() - t0
+    oerr, want, ooff, ostrings, obad = orc.string_buffer(a, idx, n)
+    assert (err, strings, bad, len(got)) == (oerr, ostrings, obad, len(want))
+    assert orc.fnv(got) == orc.fnv(want)
+    assert off[-1] == len(want)
+    print(f"\n{kind}: {strings} strings, {len(got) / 1e6:.1f} MB of records from {len(a) / 1e6:.1f} MB ({dt * 1e3:.1f} ms incl. copies)")
     p.close()
 
 
