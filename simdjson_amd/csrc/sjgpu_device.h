@@ -567,15 +567,18 @@ __device__ __forceinline__ bool emit_span(const u64 *m, u32 pos0, u32 lane, u32 
   return true;
 }
 // a span of four chunks: in one piece, else as two pairs, else chunk by chunk (st[c] = lane's structural bits of chunk c,
-// zero for chunks beyond the input; span_pos = byte offset of the span)
+// zero for chunks beyond the input; span_pos = byte offset of the span).  span_count = the number of offsets in the span,
+// which every caller knows from its summary: a dense span (large_random: ~5 000 against a window of 1 280) goes straight
+// to the per-chunk path instead of counting itself three times on the way there.
 template <u32 WINDOW>
 __device__ __forceinline__ void emit_span4_adaptive(const u64 (&st)[4], u32 span_pos, u32 lane, u32 *__restrict__ idx, u64 idx_words, u32 &base,
-                                                    u32 *__restrict__ stage, bool &overflow) {
-  if (emit_span<WINDOW, 4>(st, span_pos, lane, idx, idx_words, base, stage, overflow)) { return; }
+                                                    u32 *__restrict__ stage, bool &overflow, u32 span_count) {
+  if (span_count <= WINDOW && emit_span<WINDOW, 4>(st, span_pos, lane, idx, idx_words, base, stage, overflow)) { return; }
+  const bool pairs = span_count <= 2u * WINDOW; // wave-uniform; beyond that at least one pair cannot fit
 #pragma unroll
   for (u32 half = 0; half < 2; half++) {
     const u32 pos = span_pos + half * 2u * CHUNK_BYTES;
-    if (emit_span<WINDOW, 2>(st + 2 * half, pos, lane, idx, idx_words, base, stage, overflow)) { continue; }
+    if (pairs && emit_span<WINDOW, 2>(st + 2 * half, pos, lane, idx, idx_words, base, stage, overflow)) { continue; }
     emit_indices<WINDOW>(st[2 * half], pos + lane * BLOCK_BYTES, lane, idx, idx_words, base, stage, overflow);
     emit_indices<WINDOW>(st[2 * half + 1], pos + CHUNK_BYTES + lane * BLOCK_BYTES, lane, idx, idx_words, base, stage, overflow);
   }

@@ -549,7 +549,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           u64 st[4];
 #pragma unroll
           for (u32 c = 0; c < WC; c++) { st[c] = sh_mask_a[wave][c][lane] & ~(sh_mask_b[wave][c][lane] ^ flip); } // zero beyond len
-          emit_span4_adaptive<PIPE_WINDOW>(st, u32(wave_start), lane, static_cast<u32 *>(out), out_words, base, sh_stage[wave], overflow);
+          const u32 span_count = (carry & CARRY_DEBUG_NO_SPAN_HINT) ? 0u : (s ? sh_wave[cur ^ 1u][wave][2] : sh_wave[cur ^ 1u][wave][1]);
+          emit_span4_adaptive<PIPE_WINDOW>(st, u32(wave_start), lane, static_cast<u32 *>(out), out_words, base, sh_stage[wave], overflow, span_count);
         } else {
 #pragma unroll 1
           for (u32 c = 0; c < WC; c++) {
@@ -853,6 +854,8 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
     static const bool prefetch = []() { const char *v = std::getenv("SJGPU_PREFETCH"); return !v || v[0] != '0'; }(); // A/B switch
     static const bool late_ticket = std::getenv("SJGPU_LATE_TICKET") != nullptr;                                       // A/B switch
     if (late_ticket) { org.carry |= CARRY_DEBUG_LATE_TICKET; }
+    static const bool no_hint = std::getenv("SJGPU_NO_SPAN_HINT") != nullptr; // A/B switch
+    if (no_hint) { org.carry |= CARRY_DEBUG_NO_SPAN_HINT; }
     if (onchip_waves) {
       const u32 resident = max_workgroups / (onchip_waves == 8 ? 4u : 2u); // max_workgroups = 8 per CU
       const u32 g = cap < resident ? cap : resident;

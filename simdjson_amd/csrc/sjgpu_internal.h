@@ -81,6 +81,7 @@ constexpr uint32_t CARRY_IN_STRING = 1u; // the first byte scanned is inside a s
 constexpr uint32_t CARRY_SHARD = 2u;     // minify: report out_len even if the scan ends inside a string
 constexpr uint32_t CARRY_MORE = 4u;      // the scan does not end at the end of the input: no "sequence open at EOF" check
 constexpr uint32_t CARRY_DEBUG_LATE_TICKET = 0x100u; // A/B switch of the pipelined kernel (env SJGPU_LATE_TICKET)
+constexpr uint32_t CARRY_DEBUG_NO_SPAN_HINT = 0x200u; // A/B switch: emission counts the span itself (env SJGPU_NO_SPAN_HINT)
 // A scan covers bytes [begin, len) of a buffer whose bytes [0, begin) are resident too (the look-back of escapes,
 // previous scalar and UTF-8 state reads them); begin is a multiple of RANGE_ALIGN.  Offsets stay relative to byte 0
 // and are appended at output slot base0.  A whole document is {0, 0, 0}.

@@ -19,6 +19,8 @@
 // Behavioural contract: SURVEY.md App. A (restated from /root/reference/src/generic/stage1/*.h).
 #include "sjgpu_device.h"
 
+#include <cstdlib>
+
 namespace sjgpu {
 namespace {
 
@@ -331,7 +333,8 @@ __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask
   u64 st[SEG_CHUNKS];
 #pragma unroll
   for (u32 c = 0; c < SEG_CHUNKS; c++) { st[c] = resolved ? m0[c] : (m0[c] & ~(m1[c] ^ flip)); } // chunks beyond len hold zero masks
-  emit_span4_adaptive<EMIT_WINDOW>(st, u32(seg_start), lane, idx, idx_words, base, stage, overflow); // sparse segments go out in one piece
+  const u32 span_count = (org.carry & CARRY_DEBUG_NO_SPAN_HINT) ? 0u : (pf.in_string ? summ[seg].count_if_in : summ[seg].count_if_out);
+  emit_span4_adaptive<EMIT_WINDOW>(st, u32(seg_start), lane, idx, idx_words, base, stage, overflow, span_count); // sparse segments go out in one piece
   if (__ballot(overflow) && lane == 0) { atomicOr(&result->flags, SJGPU_F_IDX_OVERFLOW); }
 }
 
@@ -527,6 +530,8 @@ static inline void mark(hipEvent_t *ev, int k, hipStream_t stream) {
 void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *summ, seg_prefix *pref, uint32_t *idx,
                    uint64_t idx_words, scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev) {
   const u32 nseg = num_segments(len - org.begin);
+  static const bool no_hint = std::getenv("SJGPU_NO_SPAN_HINT") != nullptr; // A/B switch
+  if (no_hint) { org.carry |= CARRY_DEBUG_NO_SPAN_HINT; }
   mark(ev, 0, stream); // slot 0 = table + summarize
   if (wants_escape_table(len - org.begin, org) && org.esc) { launch_escape_table(buf, org.begin, len, org.esc, stream); }
   else { org.esc = nullptr; }
