@@ -212,24 +212,54 @@ struct chunk_masks {
 // Decides exactly what the reference's lookup algorithm decides (utf8_lookup4_algorithm.h:16-202), incl. the
 // "sequence open at the end of the input" rule (:164-171).
 // =====================================================================================================
+// Dense non-ASCII text (CJK, Cyrillic, emoji-heavy: most blocks of a chunk noted) takes the other road: validating 64
+// queued blocks costs a second transposition of each (~300 VALU per 64 blocks), validating a chunk in line from the bit
+// planes the scan already holds ~124 -- so a chunk that notes more than UTF8_DENSE_FROM blocks is checked on the spot
+// (utf8_dense_chunk) and queues nothing.
 constexpr u32 UTF8Q_SLOTS = 128; // < 64 left over + <= 64 noted by one chunk
+constexpr u32 UTF8_DENSE_FROM = 24;
 struct utf8_queue {
   u32 *slots;  // LDS, UTF8Q_SLOTS words owned by this wave
   u32 count;   // wave-uniform
   u32 pending; // wave-uniform: the last three bytes in front of the next block hold a non-ASCII byte
   u32 error;   // wave-uniform, sticky
+  const u8 *buf = nullptr; // the input, for the in-line check's look-back and end-of-input rule (null: always queue)
+  u64 len = 0;
+  u32 more = 0;            // the input continues behind len
 };
 // state at the start of a span, from the look-back bytes (lane i holds byte start-1-i)
 __device__ __forceinline__ u32 utf8_pending_from(u32 lookback_byte, u32 lane) {
   return (__ballot(lane < 3u && lookback_byte >= 0x80u) != 0) ? 1u : 0u;
 }
-// one chunk: b7 = the lane's plane 7 (non-ASCII positions), w15 = its last dword, block0 = index of lane 0's block
-__device__ __forceinline__ void utf8_note_chunk(utf8_queue &uq, u64 b7, u32 w15, u32 block0, u32 lane) {
-  const u64 m = __ballot(b7 != 0);
+// a chunk with many non-ASCII blocks, checked in line from its bit planes (what k_validate_utf8 does for every chunk)
+__device__ __forceinline__ void utf8_dense_chunk(utf8_queue &uq, const planes &P, u32 block0, u32 lane) {
+  const utf8_leads L = utf8_classify(P);
+  const u32 co = utf8_carry_out(L);
+  u32 ci = __shfl_up(co, 1);
+  if (lane == 0) {
+    ci = 0;
+    if (block0) { // the three bytes in front of the chunk
+      const u32 pw = *reinterpret_cast<const u32 *>(uq.buf + u64(block0) * BLOCK_BYTES - 4);
+      ci = utf8_carry_from_bytes((pw >> 8) & 0xFFu, (pw >> 16) & 0xFFu, pw >> 24);
+    }
+  }
+  bool bad = utf8_errors(P, L, ci) != 0;
+  // the input ends exactly with this chunk: a sequence still open there is an error (utf8_lookup4_algorithm.h:164-171);
+  // an end inside the chunk is followed by 0x20 padding, which the position-wise test already rejects behind a lead
+  if (!uq.more && (u64(block0) + 64u) * BLOCK_BYTES == uq.len && lane == 63 && (co & UTF8_CARRY_OPEN)) { bad = true; }
+  if (__ballot(bad)) { uq.error = 1u; }
+}
+// one chunk: P = the lane's bit planes (plane 7 = non-ASCII positions), w15 = its last dword, block0 = index of lane 0's block
+__device__ __forceinline__ void utf8_note_chunk(utf8_queue &uq, const planes &P, u32 w15, u32 block0, u32 lane) {
+  const u64 m = __ballot(P.b[7] != 0);
   if (m | u64(uq.pending)) { // wave-uniform; ASCII chunks stop here
     const u64 t = __ballot((w15 & 0x80808000u) != 0); // bytes 61..63 of the block
     const u64 need = m | (t << 1) | u64(uq.pending);
     uq.pending = u32(t >> 63);
+    if (uq.buf && u32(popc64(need)) > UTF8_DENSE_FROM) { // wave-uniform
+      utf8_dense_chunk(uq, P, block0, lane);
+      return;
+    }
     const u32 k = __builtin_amdgcn_mbcnt_hi(u32(need >> 32), __builtin_amdgcn_mbcnt_lo(u32(need), 0u));
     if ((need >> lane) & 1ull) { uq.slots[uq.count + k] = block0 + lane; }
     uq.count += u32(popc64(need));
@@ -316,7 +346,7 @@ __device__ __forceinline__ chunk_masks scan_chunk(const u32 (&w)[16], wave_carry
   const planes P = transpose64(w);
   const u64 lt = lanemask_lt(lane);
   chunk_masks out;
-  if (WANT_UTF8) { utf8_note_chunk(*uq, P.b[7], w[15], block0, lane); }
+  if (WANT_UTF8) { utf8_note_chunk(*uq, P, w[15], block0, lane); }
   const classes c = classify(P);
 
   // escapes: each block is "pass" (64 backslashes) or sets the carry by itself; a lane's carry-in is

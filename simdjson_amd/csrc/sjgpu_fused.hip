@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
     clear_minify_stage(reinterpret_cast<u8 *>(sh_stage[wave]), lane);
   }
   const bool more = (carry & CARRY_MORE) != 0;
-  utf8_queue uq{sh_uq[(OP == 0) ? wave : 0], 0u, 0u, 0u}; // lives across tiles: blocks are validated 64 at a time
+  // small inputs (16 KiB tiles) check dense non-ASCII chunks in line; the 64 KiB-tile variant has no registers to spare for that
+  utf8_queue uq{sh_uq[(OP == 0) ? wave : 0], 0u, 0u, 0u, (WC == 1 && !(carry & CARRY_DEBUG_QUEUE_UTF8)) ? buf : nullptr, len, (carry & CARRY_MORE) ? 1u : 0u}; // lives across tiles: blocks are validated 64 at a time
 
   for (;;) {
     // Take the ticket only when we are ready to start the tile: a ticket claimed early would make every
@@ -367,7 +368,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     clear_minify_stage(reinterpret_cast<u8 *>(sh_stage[wave]), lane);
   }
   const bool more = (carry & CARRY_MORE) != 0;
-  utf8_queue uq{sh_uq[(OP == 0) ? wave : 0], 0u, 0u, 0u}; // lives across tiles: blocks are validated 64 at a time
+  // always the queue here: the in-line check of dense non-ASCII chunks (utf8_dense_chunk) costs this kernel 100 B of scratch in
+  // its hot loop and 10-15 % on EVERY workload (profiles/r02_utf8_dense_ab.txt); text-heavy documents have sparse output, for
+  // which AUTO picks the split pipeline, whose summarize kernel has the in-line path
+  utf8_queue uq{sh_uq[(OP == 0) ? wave : 0], 0u, 0u, 0u, nullptr, len, (carry & CARRY_MORE) ? 1u : 0u}; // lives across tiles: blocks are validated 64 at a time
   u32 pend_tile = NO_TILE; // workgroup-uniform
   // Tickets are drawn one iteration AHEAD (the atomic's round trip, 1.4-2 us of an iteration of 21-27, hides behind
   // the scan): thread 0 keeps the next ticket in a register and hands it over through LDS at the end of the iteration.
@@ -856,6 +860,8 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
     if (late_ticket) { org.carry |= CARRY_DEBUG_LATE_TICKET; }
     static const bool no_hint = std::getenv("SJGPU_NO_SPAN_HINT") != nullptr; // A/B switch
     if (no_hint) { org.carry |= CARRY_DEBUG_NO_SPAN_HINT; }
+    static const bool queue_only = std::getenv("SJGPU_UTF8_QUEUE_ONLY") != nullptr; // A/B switch
+    if (queue_only) { org.carry |= CARRY_DEBUG_QUEUE_UTF8; }
     if (onchip_waves) {
       const u32 resident = max_workgroups / (onchip_waves == 8 ? 4u : 2u); // max_workgroups = 8 per CU
       const u32 g = cap < resident ? cap : resident;

@@ -82,6 +82,7 @@ constexpr uint32_t CARRY_SHARD = 2u;     // minify: report out_len even if the s
 constexpr uint32_t CARRY_MORE = 4u;      // the scan does not end at the end of the input: no "sequence open at EOF" check
 constexpr uint32_t CARRY_DEBUG_LATE_TICKET = 0x100u; // A/B switch of the pipelined kernel (env SJGPU_LATE_TICKET)
 constexpr uint32_t CARRY_DEBUG_NO_SPAN_HINT = 0x200u; // A/B switch: emission counts the span itself (env SJGPU_NO_SPAN_HINT)
+constexpr uint32_t CARRY_DEBUG_QUEUE_UTF8 = 0x400u;   // A/B switch: dense non-ASCII chunks are queued like sparse ones (env SJGPU_UTF8_QUEUE_ONLY)
 // A scan covers bytes [begin, len) of a buffer whose bytes [0, begin) are resident too (the look-back of escapes,
 // previous scalar and UTF-8 state reads them); begin is a multiple of RANGE_ALIGN.  Offsets stay relative to byte 0
 // and are appended at output slot base0.  A whole document is {0, 0, 0}.

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu
   const u64 lane_off = u64(lane) * BLOCK_BYTES;
   const u32 lookback = lookback_issue(buf, seg_start, lane); // consumed after chunk 0 has been requested
   wave_carry wc{0u, 0u, 0u};
-  utf8_queue uq{uq_slots[wave], 0u, 0u, 0u};
+  utf8_queue uq{uq_slots[wave], 0u, 0u, 0u, (org.carry & CARRY_DEBUG_QUEUE_UTF8) ? nullptr : buf, len, more ? 1u : 0u};
   u32 n_a = 0, n_b = 0; // resolved: n_a = final count; else n_a = candidates, n_b = candidates in a string tail
   u64 ctrl_a = 0, ctrl_b = 0;
   bool resolved = false;
@@ -532,6 +532,8 @@ void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *
   const u32 nseg = num_segments(len - org.begin);
   static const bool no_hint = std::getenv("SJGPU_NO_SPAN_HINT") != nullptr; // A/B switch
   if (no_hint) { org.carry |= CARRY_DEBUG_NO_SPAN_HINT; }
+  static const bool queue_only = std::getenv("SJGPU_UTF8_QUEUE_ONLY") != nullptr; // A/B switch
+  if (queue_only) { org.carry |= CARRY_DEBUG_QUEUE_UTF8; }
   mark(ev, 0, stream); // slot 0 = table + summarize
   if (wants_escape_table(len - org.begin, org) && org.esc) { launch_escape_table(buf, org.begin, len, org.esc, stream); }
   else { org.esc = nullptr; }

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_docs(const u8 *__restrict__ in_base, co
     if (wave == 0) { init_compaction_lut(sh_lut, lane); }
     clear_minify_stage(reinterpret_cast<u8 *>(sh_stage[wave]), lane);
   }
-  utf8_queue uq{sh_uq[(OP == 1) ? 0 : wave], 0u, 0u, 0u};
+  utf8_queue uq{sh_uq[(OP == 1) ? 0 : wave], 0u, 0u, 0u, buf, len, 0u};
   u32 S = 0, cursor = 0; // workgroup-uniform: in-string bit and output cursor in front of the current step
   u32 *const idx = static_cast<u32 *>(out_base) + d.out_off;   // OP 0
   u8 *const dst = static_cast<u8 *>(out_base) + d.out_off;     // OP 1
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_docs(const u8 *__restrict__ in_base, co
         n_in = u32(popc64(valid & ~(a & b)));
       } else {
         const planes P = transpose64(w);
-        utf8_note_chunk(uq, P.b[7], w[15], u32(cstart / BLOCK_BYTES), lane);
+        utf8_note_chunk(uq, P, w[15], u32(cstart / BLOCK_BYTES), lane);
       }
       parity = wc.s;
       if (OP != 1) { utf8_drain_if_full(uq, buf, len, false, lane); }

@@ -375,6 +375,34 @@ def test_dense_non_ascii_text_with_errors(orc):
         p.close()
 
 
+def test_dense_non_ascii_text_ending_inside_a_character(orc):
+    """Dense non-ASCII chunks are validated in line from the scan's bit planes (utf8_dense_chunk) -- the sequence-open-at-the-end
+    rule (utf8_lookup4_algorithm.h:164-171) included: inputs that end exactly on a 4 KiB chunk boundary, and one byte to either
+    side of it, inside a 2-, 3- or 4-byte character, inside and outside a string; through the one-workgroup kernel, the
+    16 KiB-tile kernel and both large pipelines; minify and validate_utf8 see the same inputs."""
+    text = ("\u65e5\u672c\u8a9e \U0001F600\u00e9" * 2000).encode()
+    for kind in ("fused", "split", "docs"):
+        p = _parser(kind, 32 << 20)
+        for size in (4096, 8192, 65536, 1 << 20, 12 << 20):
+            big = size >= (1 << 20)  # the large pipelines: fewer combinations, the oracle walks them byte by byte
+            for delta in ((0, 1) if big else (-1, 0, 1)):
+                L = size + delta
+                for tail in ((b"\xe6\x97", b"\xf0\x9f\x98", b"\xe6\x97\xa5") if big else (b"\xe6", b"\xe6\x97", b"\xf0\x9f", b"\xf0\x9f\x98", b"\xc3", b"\xe6\x97\xa5")):
+                    body = (text * (L // len(text) + 1))[: L - 2 - len(tail)]
+                    while body and (body[-1] & 0xC0) == 0x80:  # cut the filler on a character boundary
+                        body = body[:-1]
+                    if body and body[-1] >= 0xC0:
+                        body = body[:-1]
+                    body = body + b"x" * (L - 2 - len(tail) - len(body))
+                    doc = np.frombuffer(b'["' + body + tail, np.uint8)  # ends inside the string: UNCLOSED_STRING outranks the UTF-8 verdict in stage 1
+                    assert len(doc) == L
+                    assert_same_all(p, orc, doc, f"{kind}: {L} bytes ending with {tail!r} inside a string")
+                    closed = np.frombuffer(b'["' + body[:-2] + b'"]' + tail, np.uint8)  # the same bytes behind the document: UTF8_ERROR
+                    assert len(closed) == L
+                    assert_same_all(p, orc, closed, f"{kind}: {L} bytes ending with {tail!r} behind the document")
+        p.close()
+
+
 def test_pipelined_kernels_are_deterministic(orc):
     """Tile order, ticket order and look-back timing vary from run to run; the output must not."""
     import torch
