@@ -226,6 +226,7 @@ struct utf8_queue {
   const u8 *buf = nullptr; // the input, for the in-line check's look-back and end-of-input rule (null: always queue)
   u64 len = 0;
   u32 more = 0;            // the input continues behind len
+  u32 dense_from = UTF8_DENSE_FROM; // chunks that note more blocks than this are checked in line
 };
 // state at the start of a span, from the look-back bytes (lane i holds byte start-1-i)
 __device__ __forceinline__ u32 utf8_pending_from(u32 lookback_byte, u32 lane) {
@@ -256,7 +257,7 @@ __device__ __forceinline__ void utf8_note_chunk(utf8_queue &uq, const planes &P,
     const u64 t = __ballot((w15 & 0x80808000u) != 0); // bytes 61..63 of the block
     const u64 need = m | (t << 1) | u64(uq.pending);
     uq.pending = u32(t >> 63);
-    if (uq.buf && u32(popc64(need)) > UTF8_DENSE_FROM) { // wave-uniform
+    if (uq.buf && u32(popc64(need)) > uq.dense_from) { // wave-uniform
       utf8_dense_chunk(uq, P, block0, lane);
       return;
     }

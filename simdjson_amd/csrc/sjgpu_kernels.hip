@@ -62,6 +62,7 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu
   const u32 lookback = lookback_issue(buf, seg_start, lane); // consumed after chunk 0 has been requested
   wave_carry wc{0u, 0u, 0u};
   utf8_queue uq{uq_slots[wave], 0u, 0u, 0u, (org.carry & CARRY_DEBUG_QUEUE_UTF8) ? nullptr : buf, len, more ? 1u : 0u};
+  if (org.carry >> 16) { uq.dense_from = (org.carry >> 16) & 0xFFu; } // A/B: env SJGPU_UTF8_DENSE_FROM
   u32 n_a = 0, n_b = 0; // resolved: n_a = final count; else n_a = candidates, n_b = candidates in a string tail
   u64 ctrl_a = 0, ctrl_b = 0;
   bool resolved = false;
@@ -534,6 +535,8 @@ void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *
   if (no_hint) { org.carry |= CARRY_DEBUG_NO_SPAN_HINT; }
   static const bool queue_only = std::getenv("SJGPU_UTF8_QUEUE_ONLY") != nullptr; // A/B switch
   if (queue_only) { org.carry |= CARRY_DEBUG_QUEUE_UTF8; }
+  static const unsigned dense_from = []() { const char *v = std::getenv("SJGPU_UTF8_DENSE_FROM"); return v ? unsigned(std::atoi(v)) & 0xFFu : 0u; }();
+  org.carry |= dense_from << 16;
   mark(ev, 0, stream); // slot 0 = table + summarize
   if (wants_escape_table(len - org.begin, org) && org.esc) { launch_escape_table(buf, org.begin, len, org.esc, stream); }
   else { org.esc = nullptr; }
