@@ -43,6 +43,23 @@ def test_every_barrier_waits_for_lds(lib):
     assert found == []
 
 
+def test_barrier_check_finds_a_dropped_wait(tmp_path):
+    """The checker is not vacuous: with the explicit waits compiled out (-DSJGPU_SELFTEST_DROP_LDS_WAIT) it reports the loop-top
+    barriers hipcc leaves unguarded -- k_minify_onchip's among them, the one that produced wrong output on the GPU."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("check_barriers", os.path.join(_paths.REPO_ROOT, "scripts", "check_barriers.py"))
+    cb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cb)
+    so = str(tmp_path / "nowait.so")
+    csrc = os.path.join(_paths.PKG_DIR, "csrc")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSJGPU_SELFTEST_DROP_LDS_WAIT", "-I", _paths.INCLUDE_DIR, "-I", csrc,
+                    os.path.join(csrc, "sjgpu_fused.hip"), "-o", so], check=True, capture_output=True)
+    objects, found = cb.check(so)
+    assert objects == 1
+    assert any("k_minify_onchip" in func for func, _ in found), found
+
+
 def test_no_gpu_means_loud_failure(lib):
     import torch
     if torch.cuda.is_available():
