@@ -20,23 +20,55 @@ namespace {
 constexpr u32 STR_THREADS = 256;
 constexpr u32 NO_STRING = 0xFFFFFFFFu;
 
-__device__ __forceinline__ u32 str_byte(const u8 *__restrict__ buf, u64 len, u64 pos) { return pos < len ? u32(buf[pos]) : 0x20u; }
+// positions are 32-bit in this file: the C API refuses inputs beyond 2.4e9 bytes (record offsets are 32 bits, too), and the
+// walkers spend most of their instructions on position arithmetic
+__device__ __forceinline__ u32 str_byte(const u8 *__restrict__ buf, u32 len, u32 pos) { return pos < len ? u32(buf[pos]) : 0x20u; }
 
 // four bytes at any position of a 4-byte aligned buffer (two aligned loads + v_alignbyte); the caller guarantees pos + 8 <= len
-__device__ __forceinline__ u32 load4_unaligned(const u8 *__restrict__ buf, u64 pos) {
-  const u32 *w = reinterpret_cast<const u32 *>(buf + (pos & ~u64(3)));
-  return __builtin_amdgcn_alignbyte(w[1], w[0], u32(pos) & 3u);
+__device__ __forceinline__ u32 load4_unaligned(const u8 *__restrict__ buf, u32 pos) {
+  const u32 *w = reinterpret_cast<const u32 *>(buf + (pos & ~3u));
+  return __builtin_amdgcn_alignbyte(w[1], w[0], pos & 3u);
 }
 typedef u32 __attribute__((aligned(1))) u32_unaligned; // gfx950 stores a dword at any byte address
 // 0x80 in every byte of x that is zero; exact for the LOWEST flagged byte, which is all the callers use
 __device__ __forceinline__ u32 zero_bytes(u32 x) { return (x - 0x01010101u) & ~x & 0x80808080u; }
 
+// ---- where a string's bytes come from ------------------------------------------------------------------------------------------------
+// straight from the input ...
+struct global_bytes {
+  const u8 *buf;
+  u32 len;
+  __device__ __forceinline__ bool can4(u32 pos) const { return pos + 8u <= len; }
+  __device__ __forceinline__ u32 load4(u32 pos) const { return load4_unaligned(buf, pos); }
+  __device__ __forceinline__ u32 byte(u32 pos) const { return str_byte(buf, len, pos); }
+};
+// ... or from the lane's row of LDS, where the STAGE_DWORDS dwords around a SHORT string were parked by independent loads: the walk
+// over the string then costs LDS latencies instead of one global round trip per step (positions outside the row -- the look-ahead of
+// a malformed escape at the end of a string -- fall back to the input)
+constexpr u32 STAGE_DWORDS = 10;
+struct staged_bytes {
+  const u32 *row; // STAGE_DWORDS dwords holding the input bytes [lo, lo + 4 STAGE_DWORDS)
+  u32 lo;
+  const u8 *buf;
+  u32 len;
+  __device__ __forceinline__ bool can4(u32 pos) const { return pos - lo <= 4u * STAGE_DWORDS - 8u; } // wraps for pos < lo: false
+  __device__ __forceinline__ u32 load4(u32 pos) const {
+    const u32 off = pos - lo;
+    return __builtin_amdgcn_alignbyte(row[(off >> 2) + 1], row[off >> 2], off & 3u);
+  }
+  __device__ __forceinline__ u32 byte(u32 pos) const {
+    const u32 off = pos - lo; // wraps for pos < lo: out of range either way
+    return off < 4u * STAGE_DWORDS ? (row[off >> 2] >> (8u * (off & 3u))) & 0xFFu : str_byte(buf, len, pos);
+  }
+};
+
 // jsoncharutils::hex_to_u32_nocheck (/root/reference/include/simdjson/generic/jsoncharutils.h:31-38)
-__device__ __forceinline__ u32 hex4(const u8 *__restrict__ buf, u64 len, u64 pos) {
+template <class SRC>
+__device__ __forceinline__ u32 hex4(const SRC &src, u32 pos) {
   u32 v = 0;
 #pragma unroll
   for (u32 k = 0; k < 4; k++) {
-    const u32 c = str_byte(buf, len, pos + k);
+    const u32 c = src.byte(pos + k);
     u32 d;
     if (c - u32('0') <= 9u) { d = c - u32('0'); }
     else if ((c | 0x20u) - u32('a') <= 5u) { d = (c | 0x20u) - u32('a') + 10u; }
@@ -59,28 +91,33 @@ __device__ __forceinline__ u32 escape_value(u32 c) { // escape_map, stringparsin
   }
 }
 
-// parse_string for the string whose first byte is buf[pos]; WRITE: the unescaped bytes go to dst.  Returns the unescaped
+// parse_string for the string whose first byte sits at pos; WRITE: the unescaped bytes go to dst.  Returns the unescaped
 // length or -1 (the reference's nullptr).
-template <bool WRITE>
-__device__ __forceinline__ int unescape(const u8 *__restrict__ buf, u64 len, u64 pos, u8 *__restrict__ dst, bool allow_replacement) {
+// `plain` bytes of v (0 ... 4), low byte first, to dst: at most three stores, no loop
+__device__ __forceinline__ void store_low_bytes(u8 *__restrict__ dst, u32 v, u32 plain) {
+  typedef unsigned short __attribute__((aligned(1))) u16_unaligned;
+  if (plain == 4u) { *reinterpret_cast<u32_unaligned *>(dst) = v; return; }
+  if (plain & 2u) { *reinterpret_cast<u16_unaligned *>(dst) = (unsigned short)v; }
+  if (plain & 1u) { dst[plain & 2u] = u8(v >> (8u * (plain & 2u))); }
+}
+
+template <bool WRITE, class SRC>
+__device__ __forceinline__ int unescape(const SRC &src, u32 len, u32 pos, u8 *__restrict__ dst, bool allow_replacement) {
   u32 o = 0;
   for (;;) {
     u32 c;
-    if (pos + 8 <= len) { // four bytes at a time while nothing special shows up
-      const u32 v = load4_unaligned(buf, pos);
+    if (src.can4(pos)) { // four bytes at a time while nothing special shows up
+      const u32 v = src.load4(pos);
       const u32 special = zero_bytes(v ^ 0x22222222u) | zero_bytes(v ^ 0x5C5C5C5Cu);
       const u32 plain = special ? (u32(__builtin_ctz(special)) >> 3) : 4u; // bytes in front of the first quote / backslash
-      if (WRITE) {
-        if (plain == 4u) { *reinterpret_cast<u32_unaligned *>(dst + o) = v; }
-        else { for (u32 k = 0; k < plain; k++) { dst[o + k] = u8(v >> (8u * k)); } }
-      }
+      if (WRITE) { store_low_bytes(dst + o, v, plain); }
       o += plain;
       pos += plain;
       if (!special) { continue; }
       c = (v >> (8u * plain)) & 0xFFu;
     } else {
       if (pos >= len) { return -1; } // no closing quote (stage 1 said UNCLOSED_STRING)
-      c = buf[pos];
+      c = src.byte(pos);
       if (c != '"' && c != '\\') {
         if (WRITE) { dst[o] = u8(c); }
         o++;
@@ -89,7 +126,7 @@ __device__ __forceinline__ int unescape(const u8 *__restrict__ buf, u64 len, u64
       }
     }
     if (c == '"') { return int(o); }
-    const u32 e = str_byte(buf, len, pos + 1);
+    const u32 e = src.byte(pos + 1);
     if (e != 'u') {
       const u32 m = escape_value(e);
       if (!m) { return -1; }
@@ -99,14 +136,14 @@ __device__ __forceinline__ int unescape(const u8 *__restrict__ buf, u64 len, u64
       continue;
     }
     // handle_unicode_codepoint (stringparsing.h:50-96)
-    u32 cp = hex4(buf, len, pos + 2);
+    u32 cp = hex4(src, pos + 2);
     pos += 6;
     if (cp >= 0xd800u && cp < 0xdc00u) {
-      if (str_byte(buf, len, pos) != '\\' || str_byte(buf, len, pos + 1) != 'u') {
+      if (src.byte(pos) != '\\' || src.byte(pos + 1) != 'u') {
         if (!allow_replacement) { return -1; }
         cp = 0xfffdu;
       } else {
-        const u32 low = hex4(buf, len, pos + 2) - 0xdc00u;
+        const u32 low = hex4(src, pos + 2) - 0xdc00u;
         if (low >> 10) {
           if (!allow_replacement) { return -1; }
           cp = 0xfffdu; // the second escape is not consumed: it is looked at again on its own
@@ -146,12 +183,12 @@ __device__ __forceinline__ int unescape(const u8 *__restrict__ buf, u64 len, u64
 // copied by the lanes that hold it; a quote ends the string, an escape is decoded by uniform code (all lanes compute the same
 // thing, lane 0 stores) and the walk resumes behind it.  Same results as unescape<>, which the short strings use.
 template <bool WRITE>
-__device__ __forceinline__ int unescape_wave(const u8 *__restrict__ buf, u64 len, u64 pos, u8 *__restrict__ dst, bool allow_replacement, u32 lane) {
+__device__ __forceinline__ int unescape_wave(const u8 *__restrict__ buf, u32 len, u32 pos, u8 *__restrict__ dst, bool allow_replacement, u32 lane) {
   u32 o = 0; // wave-uniform
   for (;;) {
-    const u64 mine = pos + 4ull * lane;
+    const u32 mine = pos + 4u * lane;
     u32 v;
-    if (pos + 264 <= len) { v = load4_unaligned(buf, mine); }
+    if (pos + 264u <= len) { v = load4_unaligned(buf, mine); }
     else { v = str_byte(buf, len, mine) | (str_byte(buf, len, mine + 1) << 8) | (str_byte(buf, len, mine + 2) << 16) | (str_byte(buf, len, mine + 3) << 24); }
     const u32 special = zero_bytes(v ^ 0x22222222u) | zero_bytes(v ^ 0x5C5C5C5Cu);
     const u32 first = special ? (u32(__builtin_ctz(special)) >> 3) : 4u;
@@ -187,14 +224,15 @@ __device__ __forceinline__ int unescape_wave(const u8 *__restrict__ buf, u64 len
       pos += 2;
       continue;
     }
-    u32 cp = hex4(buf, len, pos + 2);
+    const global_bytes src{buf, len};
+    u32 cp = hex4(src, pos + 2);
     pos += 6;
     if (cp >= 0xd800u && cp < 0xdc00u) {
       if (str_byte(buf, len, pos) != '\\' || str_byte(buf, len, pos + 1) != 'u') {
         if (!allow_replacement) { return -1; }
         cp = 0xfffdu;
       } else {
-        const u32 low = hex4(buf, len, pos + 2) - 0xdc00u;
+        const u32 low = hex4(src, pos + 2) - 0xdc00u;
         if (low >> 10) {
           if (!allow_replacement) { return -1; }
           cp = 0xfffdu;
@@ -225,11 +263,14 @@ __device__ __forceinline__ int unescape_wave(const u8 *__restrict__ buf, u64 len
 }
 
 // ---- the two passes ------------------------------------------------------------------------------------------------------------------
-// A workgroup takes STR_TILE consecutive structurals, gathers the ones that are quotes into two LDS lists -- short strings
-// (at most STR_SHORT bytes up to the next structural) and long ones -- and works them off with every lane busy: one lane per
-// short string, one wave per long string.  Only ~27 % of twitter-like structurals are strings, and their lengths span 0 ... 140
-// bytes: without the lists three lanes in four idle and the rest wait for the longest string of their wave.
-constexpr u32 STR_TILE = 2048, STR_SHORT = 28;
+// A workgroup takes STR_TILE consecutive structurals, gathers the ones that are quotes into three LDS lists by the distance to the
+// next structural -- short (<= STR_SHORT bytes), medium (<= STR_MEDIUM) and long -- and works them off with every lane busy: one
+// lane per short string (from its LDS row), one lane per medium string (from the input), one wave per long string.  Only ~27 % of
+// twitter-like structurals are strings, and their lengths span 0 ... 140 bytes: without the lists three lanes in four idle and
+// the rest wait for the longest string of their wave.  The medium class exists because of escapes: a URL with eight "\/" costs a
+// wave eight uniform iterations of ~80 instructions, a lane eight of ~30 with 63 other strings in flight beside it (counters,
+// profiles/r02_pmc_strings.txt: 6 000 VALU instructions per wave with tweets and URLs on the wave path, 57 % of all issue slots).
+constexpr u32 STR_TILE = 2048, STR_SHORT = 28, STR_MEDIUM = 192;
 
 // WRITE = false: sizes[i] = 5 + unescaped length for a valid string, else 0; sizes[n] = 0 (the scan turns it into the total).
 // WRITE = true : offsets[] = exclusive scan of the sizes (n + 1 entries, CSR style: offsets[i + 1] - offsets[i] = size of
@@ -237,46 +278,110 @@ constexpr u32 STR_TILE = 2048, STR_SHORT = 28;
 template <bool WRITE>
 __global__ __launch_bounds__(STR_THREADS) void k_strings(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, u32 allow_replacement,
                                                        u32 *__restrict__ sizes_or_offsets, u8 *__restrict__ out, u64 out_cap, strings_result_dev *__restrict__ res) {
-  __shared__ u32 sh_short[STR_TILE], sh_long[STR_TILE];
-  __shared__ u32 sh_n_short, sh_n_long;
+  constexpr u32 PER_THREAD = STR_TILE / STR_THREADS;
+  __shared__ unsigned short sh_short[STR_TILE], sh_medium[STR_TILE], sh_long[STR_TILE]; // positions inside the tile
+  __shared__ u32 sh_stage[STR_THREADS][STAGE_DWORDS + 1];          // a lane's row; the odd stride keeps the rows on different banks
+  __shared__ u32 sh_n_short, sh_n_medium, sh_n_long;
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const bool allow = allow_replacement != 0;
-  if (tid == 0) { sh_n_short = 0; sh_n_long = 0; }
+  const u32 len32 = u32(len); // <= 2.4e9 (sjgpu_parse_strings_device)
+  if (tid == 0) { sh_n_short = 0; sh_n_medium = 0; sh_n_long = 0; }
   __syncthreads();
   const u64 tile0 = u64(blockIdx.x) * STR_TILE;
-  for (u32 k = 0; k < STR_TILE / STR_THREADS; k++) {
+  // ---- which structurals are strings: all loads of the tile's share in flight together (list, then the bytes it points at)
+  u32 at[PER_THREAD], reach[PER_THREAD], first_byte[PER_THREAD];
+#pragma unroll
+  for (u32 k = 0; k < PER_THREAD; k++) {
     const u64 i = tile0 + k * STR_THREADS + tid;
-    bool is_string = false;
-    u32 reach = 0;
+    at[k] = 0xFFFFFFFFu;
+    reach[k] = 0;
     if (i < n) {
-      const u32 at = idx[i];
-      const u32 next = idx[i + 1]; // the sentinel behind the list (= len) for the last one
-      is_string = at < len && buf[at] == '"';
-      reach = next - at;
+      at[k] = idx[i];
+      reach[k] = idx[i + 1] - at[k]; // the sentinel behind the list (= len) for the last one
     }
+  }
+#pragma unroll
+  for (u32 k = 0; k < PER_THREAD; k++) { first_byte[k] = at[k] < len32 ? u32(buf[at[k]]) : 0u; }
+#pragma unroll
+  for (u32 k = 0; k < PER_THREAD; k++) {
+    const u64 i = tile0 + k * STR_THREADS + tid;
+    const bool is_string = first_byte[k] == '"';
     if (!WRITE && i <= n && !is_string) { sizes_or_offsets[i] = 0; }
-    const bool is_short = is_string && reach <= STR_SHORT + 1u;
-    const u64 ms = __ballot(is_short), ml = __ballot(is_string && !is_short);
-    u32 base_s = 0, base_l = 0;
+    const bool is_short = is_string && reach[k] <= STR_SHORT + 1u;
+    const bool is_medium = is_string && !is_short && reach[k] <= STR_MEDIUM + 1u;
+    const u64 ms = __ballot(is_short), mm = __ballot(is_medium), ml = __ballot(is_string && !is_short && !is_medium);
+    u32 base_s = 0, base_m = 0, base_l = 0;
     if (lane == 0) {
       if (ms) { base_s = atomicAdd(&sh_n_short, u32(popc64(ms))); }
+      if (mm) { base_m = atomicAdd(&sh_n_medium, u32(popc64(mm))); }
       if (ml) { base_l = atomicAdd(&sh_n_long, u32(popc64(ml))); }
     }
     base_s = readlane(base_s, 0);
+    base_m = readlane(base_m, 0);
     base_l = readlane(base_l, 0);
     const u64 below = lanemask_lt(lane);
-    if (is_short) { sh_short[base_s + u32(popc64(ms & below))] = u32(i - tile0); }
-    else if (is_string) { sh_long[base_l + u32(popc64(ml & below))] = u32(i - tile0); }
+    if (is_short) { sh_short[base_s + u32(popc64(ms & below))] = (unsigned short)(i - tile0); }
+    else if (is_medium) { sh_medium[base_m + u32(popc64(mm & below))] = (unsigned short)(i - tile0); }
+    else if (is_string) { sh_long[base_l + u32(popc64(ml & below))] = (unsigned short)(i - tile0); }
   }
   __syncthreads();
-  const u32 n_short = sh_n_short, n_long = sh_n_long;
+  const u32 n_short = sh_n_short, n_medium = sh_n_medium, n_long = sh_n_long;
   u32 valid = 0;
-  // ---- one lane per short string
-  for (u32 j = tid; j < n_short; j += STR_THREADS) {
-    const u64 i = tile0 + sh_short[j];
-    const u64 first = u64(idx[i]) + 1;
+  // ---- one lane per short string: its bytes are parked in the lane's LDS row first (independent loads), the walk runs from there
+  for (u32 j0 = 0; j0 < n_short; j0 += STR_THREADS) { // workgroup-uniform trip count
+    const u32 j = j0 + tid;
+    const bool mine = j < n_short;
+    u64 i = 0;
+    u32 first = 0, lo = 0, off = 0, size = 0;
+    bool go = mine;
+    if (mine) {
+      i = tile0 + sh_short[j];
+      first = idx[i] + 1u;
+      lo = first & ~3u;
+      if (WRITE) {
+        off = sizes_or_offsets[i];
+        size = sizes_or_offsets[i + 1] - off;
+        go = size != 0;
+        if (go && u64(off) + size > out_cap) { res->overflow = 1; go = false; }
+      }
+      if (go) {
+        u32 *row = sh_stage[tid];
+        if (lo + 4u * STAGE_DWORDS <= len32) {
+          const u32 *w = reinterpret_cast<const u32 *>(buf + lo);
+#pragma unroll
+          for (u32 d = 0; d < STAGE_DWORDS; d++) { row[d] = w[d]; }
+        } else { // the end of the input: byte by byte, 0x20 beyond it
+          for (u32 d = 0; d < STAGE_DWORDS; d++) {
+            const u32 p = lo + 4u * d;
+            row[d] = str_byte(buf, len32, p) | (str_byte(buf, len32, p + 1) << 8) | (str_byte(buf, len32, p + 2) << 16) | (str_byte(buf, len32, p + 3) << 24);
+          }
+        }
+      }
+    }
+    wave_lds_fence(); // a lane reads only its own row
+    if (go) {
+      const staged_bytes src{sh_stage[tid], lo, buf, len32};
+      if (!WRITE) {
+        const int l = unescape<false>(src, len32, first, nullptr, allow);
+        if (l < 0) { atomicMin(&res->first_bad, u32(i)); sizes_or_offsets[i] = 0; }
+        else { sizes_or_offsets[i] = 5u + u32(l); valid++; }
+      } else {
+        u8 *rec = out + off;
+        const u32 l = size - 5u;
+        *reinterpret_cast<u32_unaligned *>(rec) = l;
+        (void)unescape<true>(src, len32, first, rec + 4, allow);
+        rec[4 + l] = 0;
+      }
+    }
+    wave_lds_fence();
+  }
+  // ---- one lane per medium string, straight from the input
+  for (u32 j = tid; j < n_medium; j += STR_THREADS) {
+    const u64 i = tile0 + sh_medium[j];
+    const u32 first = idx[i] + 1u;
+    const global_bytes src{buf, len32};
     if (!WRITE) {
-      const int l = unescape<false>(buf, len, first, nullptr, allow);
+      const int l = unescape<false>(src, len32, first, nullptr, allow);
       if (l < 0) { atomicMin(&res->first_bad, u32(i)); sizes_or_offsets[i] = 0; }
       else { sizes_or_offsets[i] = 5u + u32(l); valid++; }
     } else {
@@ -286,16 +391,16 @@ __global__ __launch_bounds__(STR_THREADS) void k_strings(const u8 *__restrict__ 
       u8 *rec = out + off;
       const u32 l = size - 5u;
       *reinterpret_cast<u32_unaligned *>(rec) = l;
-      (void)unescape<true>(buf, len, first, rec + 4, allow);
+      (void)unescape<true>(src, len32, first, rec + 4, allow);
       rec[4 + l] = 0;
     }
   }
   // ---- one wave per long string
   for (u32 j = wave; j < n_long; j += STR_THREADS / 64) {
     const u64 i = tile0 + sh_long[j];
-    const u64 first = u64(idx[i]) + 1;
+    const u32 first = idx[i] + 1u;
     if (!WRITE) {
-      const int l = unescape_wave<false>(buf, len, first, nullptr, allow, lane);
+      const int l = unescape_wave<false>(buf, len32, first, nullptr, allow, lane);
       if (lane == 0) {
         if (l < 0) { atomicMin(&res->first_bad, u32(i)); sizes_or_offsets[i] = 0; }
         else { sizes_or_offsets[i] = 5u + u32(l); valid++; }
@@ -306,7 +411,7 @@ __global__ __launch_bounds__(STR_THREADS) void k_strings(const u8 *__restrict__ 
       if (u64(off) + size > out_cap) { res->overflow = 1; continue; }
       u8 *rec = out + off;
       const u32 l = size - 5u;
-      (void)unescape_wave<true>(buf, len, first, rec + 4, allow, lane);
+      (void)unescape_wave<true>(buf, len32, first, rec + 4, allow, lane);
       if (lane == 0) {
         *reinterpret_cast<u32_unaligned *>(rec) = l;
         rec[4 + l] = 0;
