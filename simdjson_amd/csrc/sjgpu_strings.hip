@@ -436,8 +436,8 @@ void launch_parse_strings(const uint8_t *buf, uint64_t len, const uint32_t *idx,
   u32 *n_ptr = static_cast<u32 *>(scratch);
   int *partial = reinterpret_cast<int *>(n_ptr + 4);
   const u32 n1 = n + 1;
-  strings_result_dev init{0ull, 0u, NO_STRING, 0u, 0u};
-  (void)hipMemcpyAsync(res, &init, sizeof(init), hipMemcpyHostToDevice, s);
+  (void)hipMemsetAsync(res, 0, sizeof(strings_result_dev), s);
+  (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&res->first_bad), int(NO_STRING), 1, s);
   (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(n_ptr), int(n1), 1, s);
   const u32 grid = u32((u64(n1) + STR_TILE - 1) / STR_TILE);
   hipLaunchKernelGGL(k_strings<false>, dim3(grid), dim3(STR_THREADS), 0, s, buf, len, idx, n, allow_replacement ? 1u : 0u, offsets, out, out_cap, res);
