@@ -292,6 +292,7 @@ hipStream_t pick(sjgpu_ctx *, void *stream) { return static_cast<hipStream_t>(st
 // 2 290-2 440 vs 2 580-2 620), so for stage 1 AUTO goes by the density the previous large scan of this context saw.
 constexpr size_t AUTO_FUSED_BELOW = size_t(8) << 20;
 constexpr size_t AUTO_FUSED_FROM = size_t(192) << 20;
+constexpr size_t DIRECT_HOST_MAX = size_t(2) << 20; // sjgpu_stage1 on host buffers: up to here the kernels write the offsets into host memory themselves
 constexpr uint32_t AUTO_DENSE_PERMILLE = 200;
 bool use_fused(const sjgpu_ctx *ctx, size_t len, int op = 1) { // op 0: stage 1, 1: minify
   if (ctx->pipeline != 2) { return ctx->pipeline == 1; }
@@ -1094,9 +1095,32 @@ int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint3
   if (rc) { return rc; }
   hipStream_t s = ctx->stream;
   const bool streamed = take_streamed_path(ctx, len);
+  // Windows of a document stream (dom::DEFAULT_BATCH_SIZE = 1 MB) and other mid-size documents: the scan kernels write the
+  // offsets straight into a page-locked block of the host (posted PCIe writes while they run), so that one wait delivers the
+  // result AND the list -- instead of result, wait, list copy, wait.
+  const bool direct = !streamed && ctx->small_docs && len <= DIRECT_HOST_MAX && ctx->device_finish != 2;
   if (streamed) { // large document: upload, scan and download overlap range by range; the offsets are on the host afterwards
     rc = run_streamed(ctx, 0, buf, len, idx_out, idx_words, &res);
     if (rc) { return rc; }
+  } else if (direct) {
+    rc = ensure_small(ctx, (len + 16) * sizeof(uint32_t));
+    if (rc) { return rc; }
+    uint32_t *h_idx = reinterpret_cast<uint32_t *>(ctx->h_small);
+    SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
+    for (int attempt = 0; attempt < 2; attempt++) { // a single-pass call that gives up is re-run on the split pipeline
+      enqueue_stage1(ctx, use_fused(ctx, len, 0) && attempt == 0, ctx->d_in, len, h_idx, len + 3, s, nullptr);
+      SJ_ENQUEUED(ctx);
+      rc = fetch_result(ctx, s, &res); // the stream is in order: the list is complete when the result has arrived
+      if (rc) { return rc; }
+      if (!(res.flags & SJGPU_F_INTERNAL)) { break; }
+    }
+    if (res.flags & SJGPU_F_INTERNAL) { return E_UNEXPECTED; }
+    if (res.flags & SJGPU_F_IDX_OVERFLOW) { return E_UNEXPECTED; }
+    if ((res.flags & SJGPU_F_UNCLOSED_STRING) && mode == SJGPU_REGULAR) { return E_UNCLOSED; }
+    if (res.flags & SJGPU_F_UNESCAPED_CTRL) { return 14; }
+    if (size_t(res.n) + 3 > idx_words) { return SJGPU_E_OVERFLOW; }
+    std::memcpy(idx_out, h_idx, (size_t(res.n) + 3) * sizeof(uint32_t));
+    return sjgpu_stage1_finish_host(buf, len, mode, idx_out, res.n, res.flags, n_io, next_io);
   } else {
     SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
     for (int attempt = 0; attempt < 2; attempt++) { // a single-pass call that gives up is re-run on the split pipeline
