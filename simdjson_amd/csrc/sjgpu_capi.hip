@@ -612,6 +612,11 @@ extern "C" void sjgpu_ctx_destroy(sjgpu_ctx *ctx) {
     release_staging(ctx);
   }
   if (ctx->d_tmp_bytes > 4 * POOL_KEEP_BYTES) { dev_free(ctx->d_tmp); ctx->d_tmp_bytes = 0; }
+  if (ctx->h_small_bytes > (size_t(1) << 20)) { // page-locked memory is scarce: a parked context keeps at most 1 MiB of it
+    (void)hipHostFree(ctx->h_small);
+    ctx->h_small = nullptr;
+    ctx->h_small_bytes = 0;
+  }
   {
     std::lock_guard<std::mutex> lk(g_pool_m);
     if (g_pool.size() < POOL_MAX) {
@@ -1198,7 +1203,7 @@ int sjgpu_parse_strings_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
                                uint32_t *strings_out, uint32_t *first_bad_out) {
   if (!ctx || !buf_dev || !idx_dev || !string_buf_dev) { return SJGPU_E_BADARG; }
   if ((reinterpret_cast<uintptr_t>(buf_dev) & 3u) || (reinterpret_cast<uintptr_t>(offsets_dev) & 3u)) { return SJGPU_E_BADARG; }
-  if (len > 2400000000ull) { return E_CAPACITY; } // record offsets are 32 bits: 5 (len + 1) / 3 bytes of records at most
+  if (len > 2400000000ull || n >= 0xFFFFFFF0u) { return E_CAPACITY; } // record offsets are 32 bits: 5 (len + 1) / 3 bytes of records at most
   SJ_TRY(ctx, hipSetDevice(ctx->device));
   // [result: 32 B][scan scratch][offsets when the caller keeps none]
   const size_t scratch_at = 32, scratch = (strings_scratch_bytes(n) + 15) & ~size_t(15), offs_at = scratch_at + scratch;
