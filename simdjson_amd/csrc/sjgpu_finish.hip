@@ -57,8 +57,36 @@ __device__ __forceinline__ int block_excl_scan256(int v, int *sh /*[8]*/, int &t
 __global__ __launch_bounds__(FIN_THREADS) void k_scan_blocks(int *__restrict__ a, const u32 *__restrict__ n_ptr, int *__restrict__ partial) {
   __shared__ int sh[8];
   const u32 n = *n_ptr;
-  const u64 base = u64(blockIdx.x) * FIN_BLOCK + u64(threadIdx.x) * FIN_PER_THREAD;
   if (u64(blockIdx.x) * FIN_BLOCK >= n) { if (threadIdx.x == 0) { partial[blockIdx.x] = 0; } return; }
+  if ((reinterpret_cast<uintptr_t>(a) & 15u) == 0) {
+    // 16-byte aligned array: four rows of 1024 ints, a thread owns four CONSECUTIVE ints of each row, so that the lanes of a
+    // wave read and write consecutive 16-byte pieces (16 consecutive ints per thread put the lanes 64 bytes apart: 1.4 TB/s)
+    int before = 0; // sum of the rows in front
+#pragma unroll 1
+    for (u32 row = 0; row < FIN_PER_THREAD / 4; row++) {
+      const u64 e0 = u64(blockIdx.x) * FIN_BLOCK + u64(row) * (FIN_THREADS * 4) + u64(threadIdx.x) * 4;
+      int v[4] = {0, 0, 0, 0};
+      if (e0 + 3 < n) {
+        const int4 q = *reinterpret_cast<const int4 *>(a + e0);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      } else {
+        for (u32 j = 0; j < 4; j++) { if (e0 + j < n) { v[j] = a[e0 + j]; } }
+      }
+      int total;
+      const int run = before + block_excl_scan256(v[0] + v[1] + v[2] + v[3], sh, total);
+      const int4 o = make_int4(run, run + v[0], run + v[0] + v[1], run + v[0] + v[1] + v[2]);
+      if (e0 + 3 < n) {
+        *reinterpret_cast<int4 *>(a + e0) = o;
+      } else {
+        const int w[4] = {o.x, o.y, o.z, o.w};
+        for (u32 j = 0; j < 4; j++) { if (e0 + j < n) { a[e0 + j] = w[j]; } }
+      }
+      before += total;
+    }
+    if (threadIdx.x == 0) { partial[blockIdx.x] = before; }
+    return;
+  }
+  const u64 base = u64(blockIdx.x) * FIN_BLOCK + u64(threadIdx.x) * FIN_PER_THREAD;
   int v[FIN_PER_THREAD], sum = 0;
 #pragma unroll
   for (u32 j = 0; j < FIN_PER_THREAD; j++) {
@@ -100,6 +128,20 @@ __global__ __launch_bounds__(1024) void k_scan_partials(int *__restrict__ partia
 __global__ __launch_bounds__(FIN_THREADS) void k_scan_add(int *__restrict__ a, const u32 *__restrict__ n_ptr, const int *__restrict__ partial) {
   const u32 n = *n_ptr;
   const int add = partial[blockIdx.x];
+  if ((reinterpret_cast<uintptr_t>(a) & 15u) == 0) { // the layout of k_scan_blocks' aligned path: coalesced 16-byte pieces
+#pragma unroll
+    for (u32 row = 0; row < FIN_PER_THREAD / 4; row++) {
+      const u64 e0 = u64(blockIdx.x) * FIN_BLOCK + u64(row) * (FIN_THREADS * 4) + u64(threadIdx.x) * 4;
+      if (e0 + 3 < n) {
+        int4 q = *reinterpret_cast<const int4 *>(a + e0);
+        q.x += add; q.y += add; q.z += add; q.w += add;
+        *reinterpret_cast<int4 *>(a + e0) = q;
+      } else {
+        for (u32 j = 0; j < 4; j++) { if (e0 + j < n) { a[e0 + j] += add; } }
+      }
+    }
+    return;
+  }
   const u64 base = u64(blockIdx.x) * FIN_BLOCK + u64(threadIdx.x) * FIN_PER_THREAD;
 #pragma unroll
   for (u32 j = 0; j < FIN_PER_THREAD; j++) {
