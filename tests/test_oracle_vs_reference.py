@@ -171,3 +171,41 @@ def test_string_errors_are_the_reference_s(both):
         assert (e2 != 0) == (err == checkers.STRING_ERROR), d
         if e2:
             assert e2 == checkers.STRING_ERROR and d[idx[bad]] == 0x22
+
+
+def _random_json(rng, depth=0):
+    """a random VALID document with escape-rich strings (keys and values)"""
+    def rstr():
+        parts = []
+        for _ in range(int(rng.integers(0, 12))):
+            k = int(rng.integers(0, 12))
+            parts.append(["a", "Zq", " ", "\\n", "\\\"", "\\\\", "\\/", "\\u00e9", "\\ud83d\\ude00", "日本", "\\t", "x" * int(rng.integers(1, 70))][k])
+        return '"' + "".join(parts) + '"'
+    kind = int(rng.integers(0, 2)) if depth == 0 else (int(rng.integers(0, 6)) if depth < 4 else int(rng.integers(2, 6)))
+    if kind == 0:
+        return "[" + ",".join(_random_json(rng, depth + 1) for _ in range(int(rng.integers(0, 5)))) + "]"
+    if kind == 1:
+        return "{" + ",".join(rstr() + ": " + _random_json(rng, depth + 1) for _ in range(int(rng.integers(0, 5)))) + "}"
+    if kind == 2:
+        return rstr()
+    return ["true", "null", "-12.5e3", "0"][kind - 3] if kind < 6 else "1"
+
+
+def test_string_buffer_on_random_documents(both):
+    """2 000 random valid documents: the oracle's buffer (from the structural list alone) equals document::string_buf of the
+    reference's dom parse, keys and values, escapes and surrogate pairs included."""
+    orc, ref = both
+    impl = ref.best_impl()
+    rng = np.random.default_rng(777)
+    checked = 0
+    for _ in range(2000):
+        doc = _random_json(rng).encode()
+        err, want, strings = ref.dom_string_buf(impl, doc)
+        assert err == 0, doc
+        e1, n, idx = orc.stage1(doc, 0)
+        assert e1 == 0
+        e2, got, off, cnt, bad = orc.string_buffer(doc, idx, n)
+        assert (e2, cnt, bad) == (0, strings, checkers.NO_STRING), doc
+        assert bytes(got) == bytes(want), doc
+        checked += strings
+    assert checked > 4000
