@@ -110,6 +110,38 @@ def unguarded_barriers(code_object):
     return findings
 
 
+def kernel_resources(lib):
+    """{kernel symbol: {"scratch": bytes per lane, "vgpr": count, "sgpr": count, "lds": bytes}} from the code objects' metadata notes
+    (.private_segment_fixed_size and friends) -- what the hardware is told to reserve, not what a compiler remark claimed."""
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for co in code_objects(lib, d):
+            text = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+            cur = {}
+            for line in text.split("\n"):
+                m = re.match(r"^\s*-?\s*\.(\w+):\s*(.*?)\s*$", line)
+                if not m:
+                    continue
+                key, val = m.group(1), m.group(2)
+                if key == "args" or (key == "agpr_count" and cur.get("_done")):
+                    cur = {}  # a new kernel record begins with its .args (or, for kernels without arguments, .agpr_count)
+                if key == "private_segment_fixed_size":
+                    cur["scratch"] = int(val)
+                elif key == "vgpr_count":
+                    cur["vgpr"] = int(val)
+                elif key == "sgpr_count":
+                    cur["sgpr"] = int(val)
+                elif key == "group_segment_fixed_size":
+                    cur["lds"] = int(val)
+                elif key == "name":
+                    cur["name"] = val.strip("'\"")
+                elif key == "wavefront_size":
+                    cur["_done"] = True
+                    if "name" in cur:
+                        out[cur["name"]] = {k: v for k, v in cur.items() if not k.startswith("_") and k != "name"}
+    return out
+
+
 def check(lib):
     with tempfile.TemporaryDirectory() as d:
         found = []
@@ -120,6 +152,11 @@ def check(lib):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "--resources":
+        for name, r in sorted(kernel_resources(sys.argv[1]).items()):
+            demangled = re.sub(r"\(anonymous namespace\)::", "", subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()).split("(")[0]
+            print(f"{r.get('vgpr', '?'):>4} VGPR {r.get('sgpr', '?'):>4} SGPR {r.get('lds', '?'):>6} B LDS {r.get('scratch', '?'):>5} B scratch  {demangled}")
+        sys.exit(0)
     n, found = check(sys.argv[1])
     for func, addr in found:
         print(f"s_barrier reachable from an LDS store without an lgkmcnt(0) wait: {func} at {addr}")

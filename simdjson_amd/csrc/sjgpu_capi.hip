@@ -117,11 +117,6 @@ struct sjgpu_ctx {
   uint64_t *desc = nullptr; // single-pass pipeline: tile descriptors + ticket
   uint8_t *esc_tab = nullptr; // escape table (launch_escape_table), ESC_TABLE_BYTES whatever the capacity
   int pipeline = 2; // 0 split, 1 single pass, 2 auto (use_fused below)
-  // split pipeline as a chain of overlapping pieces (launch_stage1_pieces): piece size, 0 = one piece (env SJGPU_OVERLAP_MB)
-  size_t overlap_piece = 0;
-  hipStream_t aux = nullptr;           // second stream of the overlapped split pipeline
-  std::vector<hipEvent_t> ev_piece;    // one per piece + 2
-  scan_result_dev *d_chain = nullptr;  // one result per piece (OVERLAP_MAX_PIECES)
   // AUTO remembers how dense the output of the last large stage-1 scan was (offsets per 1000 input bytes): on sparse
   // output the split pipeline is the faster one, and streams of documents / batches look like their predecessors
   uint32_t density_permille = 1000; // unknown: assume dense
@@ -308,19 +303,6 @@ bool use_fused(const sjgpu_ctx *ctx, size_t len, int op = 1) { // op 0: stage 1,
 // `len` is the END of the scan (bytes [org.begin, len) are scanned); a whole document has org = {0, 0, 0}
 // Every scan is handed the context's escape-table workspace; the launchers fill and use it for scans beyond the
 // small-tile limit (launch_escape_table, sjgpu_kernels.hip) and ignore it below.
-constexpr size_t OVERLAP_MAX_PIECES = 1024;
-// second stream, events and per-piece results of the overlapped split pipeline, made by the first call that takes it
-int ensure_overlap(sjgpu_ctx *ctx, size_t npieces) {
-  if (!ctx->aux) { SJ_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking)); }
-  if (!ctx->d_chain) { SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_chain), OVERLAP_MAX_PIECES * sizeof(scan_result_dev))); }
-  while (ctx->ev_piece.size() < npieces + 2) {
-    hipEvent_t e;
-    SJ_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    ctx->ev_piece.push_back(e);
-  }
-  return 0;
-}
-
 void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint32_t *idx, size_t idx_words, hipStream_t s,
                     hipEvent_t *ev, scan_origin org = scan_origin{0, 0, 0}) {
   org.esc = ctx->esc_tab;
@@ -328,16 +310,6 @@ void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, 
   if (ctx->enqueue_rc) { return; }
   ctx->last_pipeline = fused ? 1 : 0;
   ctx->pending_scan_bytes = (org.begin == 0 && org.base0 == 0 && len >= AUTO_FUSED_FROM) ? len : 0;
-  const size_t piece = ctx->overlap_piece;
-  if (!fused && piece && org.begin == 0 && org.base0 == 0 && len >= 2 * piece && (len + piece - 1) / piece <= OVERLAP_MAX_PIECES) {
-    const size_t npieces = (len + piece - 1) / piece;
-    ctx->enqueue_rc = ensure_overlap(ctx, npieces);
-    if (ctx->enqueue_rc) { return; }
-    launch_stage1_pieces(buf, len, ctx->masks, ctx->summ, ctx->pref, idx, idx_words, ctx->d_result, ctx->d_chain, org, piece, s, ctx->aux,
-                         ctx->ev_piece.data(), ev);
-    ctx->last_kernel = "k_stage1_summarize || k_stage1_emit (overlapped pieces)";
-    return;
-  }
   if (fused) { ctx->last_kernel = launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, org, ctx->max_workgroups, s, ev); }
   else {
     launch_stage1(buf, len, ctx->masks, ctx->summ, ctx->pref, idx, idx_words, ctx->d_result, org, s, ev);
@@ -548,11 +520,6 @@ void apply_environment(sjgpu_ctx *ctx) {
   }
   ctx->small_docs = true;
   if (const char *v = std::getenv("SJGPU_SMALL_DOCS")) { ctx->small_docs = v[0] != '0'; }
-  ctx->overlap_piece = 0;
-  if (const char *v = std::getenv("SJGPU_OVERLAP_MB")) {
-    const size_t mb = size_t(std::strtoull(v, nullptr, 10));
-    if (mb <= 2048) { ctx->overlap_piece = mb << 20; }
-  }
   ctx->device_finish = 1; // streaming-mode finish on the device for documents beyond the small-document path
   if (const char *v = std::getenv("SJGPU_FINISH")) { ctx->device_finish = std::strcmp(v, "host") == 0 ? 0 : (std::strcmp(v, "device") == 0 ? 2 : 1); }
 }
@@ -576,10 +543,6 @@ void really_destroy(sjgpu_ctx *ctx) {
   if (ctx->h_small) { (void)hipHostFree(ctx->h_small); }
   dev_free(ctx->esc_tab);
   dev_free(ctx->d_tmp);
-  dev_free(ctx->d_chain);
-  for (hipEvent_t ev : ctx->ev_piece) { (void)hipEventDestroy(ev); }
-  ctx->ev_piece.clear();
-  if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
   if (ctx->stream) { (void)hipStreamDestroy(ctx->stream); }
   delete ctx;
 }

@@ -237,13 +237,14 @@ __device__ __forceinline__ void utf8_dense_chunk(utf8_queue &uq, const planes &P
   const utf8_leads L = utf8_classify(P);
   const u32 co = utf8_carry_out(L);
   u32 ci = __shfl_up(co, 1);
-  if (lane == 0) {
-    ci = 0;
-    if (block0) { // the three bytes in front of the chunk
-      const u32 pw = *reinterpret_cast<const u32 *>(uq.buf + u64(block0) * BLOCK_BYTES - 4);
-      ci = utf8_carry_from_bytes((pw >> 8) & 0xFFu, (pw >> 16) & 0xFFu, pw >> 24);
-    }
+  u32 c0 = 0; // what the three bytes in front of the chunk demand: one value for the wave, computed on the scalar unit (as per-lane
+              // code behind `lane == 0` its dozen compares were what pushed k_stage1_summarize into 20 B of scratch)
+  if (block0) {
+    const u32 b0 = u32(__builtin_amdgcn_readfirstlane(int(block0))); // wave-uniform by construction: lets the load be a scalar one
+    const u32 pw = u32(__builtin_amdgcn_readfirstlane(int(*reinterpret_cast<const u32 *>(uq.buf + u64(b0) * BLOCK_BYTES - 4))));
+    c0 = utf8_carry_from_bytes((pw >> 8) & 0xFFu, (pw >> 16) & 0xFFu, pw >> 24);
   }
+  if (lane == 0) { ci = c0; }
   bool bad = utf8_errors(P, L, ci) != 0;
   // the input ends exactly with this chunk: a sequence still open there is an error (utf8_lookup4_algorithm.h:164-171);
   // an end inside the chunk is followed by 0x20 padding, which the position-wise test already rejects behind a lead

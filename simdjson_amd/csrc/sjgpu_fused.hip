@@ -335,15 +335,14 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
 constexpr u32 PIPE_WINDOW = 1280; // 4 x 5 KiB of emission windows + 16 KiB of pending masks -> 4 workgroups per CU
 constexpr u32 NO_TILE = 0xFFFFFFFFu;
 
-// PF: spans that lie wholly inside the input are scanned with the loads of chunk c+1 in flight while chunk c is
-// classified (two register sets, the four chunks unrolled).  Measured round 2 (profiles/r02_*): nothing on dense output,
-// where the kernel moves bytes at the rate a plain copy of them reaches, but sparse output (NDJSON, pretty-printed text)
-// is bound by how many loads 16 waves per CU keep in flight.
+// (Round 2 carried a variant that requested chunk c+1 while chunk c was classified: two register sets, 128 VGPRs with 20 B of
+// scratch in the hot loop.  Same-box A/B in round 3, profiles/r03_overlap_experiment.txt: 0.5504 vs 0.5501 ms on configs[1],
+// 0.4241 vs 0.4267 ms on NDJSON -- nothing, so the kernel without it, which spills nothing, is the only one left.)
 // TRACE: thread 0 of every workgroup stamps wall_clock64() at 8 phase boundaries of its first PIPE_TRACE_ITERS iterations
 // (sjgpu_debug_trace_pipelined): 0 loop top, 1 ticket known, 2 wave 0 scanned, 3 all scanned, 4 wave 0 published +
 // looked back, 5 prefix broadcast, 6 wave 0 emitted, 7 masks parked.
 constexpr u32 PIPE_TRACE_ITERS = 32;
-template <int OP, bool PF, bool TRACE = false>
+template <int OP, bool TRACE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fused_pipelined(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc,
                                                          u32 *__restrict__ ticket, u32 ntiles, void *__restrict__ out,
                                                          u64 out_words, scan_result_dev *__restrict__ result, scan_origin org,
@@ -425,20 +424,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           a3 = a2; a2 = a1; a1 = a0; a0 = a;
           b3 = b2; b2 = b1; b1 = b0; b0 = b;
         };
-        if (PF && wave_start + WAVE_BYTES <= len) { // wave-uniform: the whole span is input
-          const u64 lane_pos = wave_start + u64(lane) * BLOCK_BYTES;
-          u32 wa[16], wb[16];
-          load_block_full(buf, lane_pos, wa);
-          load_block_full(buf, lane_pos + CHUNK_BYTES, wb);
-          wc = segment_carry_from(buf, wave_start, lane, lookback, esc_ref(org.esc, OP == 1 ? ESC_SHIFT_MINIFY : ESC_SHIFT_STAGE1));
-          uq.pending = utf8_pending_from(lookback, lane);
-          scan_one(wa, wave_start);
-          load_block_full(buf, lane_pos + 2 * CHUNK_BYTES, wa);
-          scan_one(wb, wave_start + CHUNK_BYTES);
-          load_block_full(buf, lane_pos + 3 * CHUNK_BYTES, wb);
-          scan_one(wa, wave_start + 2 * CHUNK_BYTES);
-          scan_one(wb, wave_start + 3 * CHUNK_BYTES);
-        } else {
+        {
 #pragma unroll 1
           for (u32 c = 0; c < WC; c++) {
             const u64 cstart = wave_start + u64(c) * CHUNK_BYTES;
@@ -833,8 +819,8 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
     launch_fused_wc<FUSED_WAVE_CHUNKS>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles);
     return op == 0 ? "k_fused<0> (64 KiB tiles)" : "k_fused<1> (64 KiB tiles)";
   } else {
-    static const int onchip = []() { const char *v = std::getenv("SJGPU_MINIFY_ONCHIP"); return v ? std::atoi(v) : 4; }(); // A/B: 0 = re-reading kernel, 4 / 8 waves
-    const u32 onchip_waves = (op == 1 && onchip != 0) ? (onchip == 8 ? 8u : 4u) : 0u;
+    static const bool onchip = []() { const char *v = std::getenv("SJGPU_MINIFY_ONCHIP"); return !v || v[0] != '0'; }(); // A/B: 0 = the re-reading kernel
+    const u32 onchip_waves = (op == 1 && onchip) ? 4u : 0u; // (an 8-wave / 64 KiB-tile variant measured slower in round 2 and spilled: gone)
     const u64 tile_bytes = onchip_waves ? u64(onchip_waves) * ONCHIP_WAVE_CHUNKS * CHUNK_BYTES : u64(FUSED_TILE_BYTES);
     const u32 ntiles = u32((len - org.begin + tile_bytes - 1) / tile_bytes);
     u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles);
@@ -855,7 +841,6 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
     // half as many workgroups as tiles at most: every workgroup should own >= 2 tiles for the deferral to work
     const u32 cap = (ntiles + 1) / 2;
     const u32 grid = cap < max_workgroups ? cap : max_workgroups;
-    static const bool prefetch = []() { const char *v = std::getenv("SJGPU_PREFETCH"); return !v || v[0] != '0'; }(); // A/B switch
     static const bool late_ticket = std::getenv("SJGPU_LATE_TICKET") != nullptr;                                       // A/B switch
     if (late_ticket) { org.carry |= CARRY_DEBUG_LATE_TICKET; }
     static const bool no_hint = std::getenv("SJGPU_NO_SPAN_HINT") != nullptr; // A/B switch
@@ -863,21 +848,18 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
     static const bool queue_only = std::getenv("SJGPU_UTF8_QUEUE_ONLY") != nullptr; // A/B switch
     if (queue_only) { org.carry |= CARRY_DEBUG_QUEUE_UTF8; }
     if (onchip_waves) {
-      const u32 resident = max_workgroups / (onchip_waves == 8 ? 4u : 2u); // max_workgroups = 8 per CU
+      const u32 resident = max_workgroups / 2u; // max_workgroups = 8 per CU
       const u32 g = cap < resident ? cap : resident;
-      if (onchip_waves == 8) { hipLaunchKernelGGL((k_minify_onchip<8>), dim3(g), dim3(512), 0, stream, buf, len, desc, ticket, ntiles, static_cast<u8 *>(out), result, org); }
-      else { hipLaunchKernelGGL((k_minify_onchip<4>), dim3(g), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, static_cast<u8 *>(out), result, org); }
+      hipLaunchKernelGGL((k_minify_onchip<4>), dim3(g), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, static_cast<u8 *>(out), result, org);
       mark(ev, 1, stream);
       mark(ev, 2, stream);
       mark(ev, 3, stream);
-      return onchip_waves == 8 ? "k_minify_onchip<8>" : "k_minify_onchip<4>";
+      return "k_minify_onchip<4>";
     }
-    if (op == 0 && prefetch) {
-      hipLaunchKernelGGL((k_fused_pipelined<0, true>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result, org);
-    } else if (op == 0) {
-      hipLaunchKernelGGL((k_fused_pipelined<0, false>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result, org);
+    if (op == 0) {
+      hipLaunchKernelGGL((k_fused_pipelined<0>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result, org);
     } else {
-      hipLaunchKernelGGL((k_fused_pipelined<1, false>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result, org);
+      hipLaunchKernelGGL((k_fused_pipelined<1>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result, org);
     }
     mark(ev, 1, stream);
     mark(ev, 2, stream);
@@ -903,12 +885,7 @@ uint32_t launch_stage1_pipelined_traced(const uint8_t *buf, uint64_t len, uint64
   const u32 cap = (ntiles + 1) / 2;
   u32 grid = cap < max_workgroups ? cap : max_workgroups;
   if (grid > max_records / PIPE_TRACE_ITERS) { return 0; }
-  static const bool prefetch = []() { const char *v = std::getenv("SJGPU_PREFETCH"); return !v || v[0] != '0'; }();
-  if (prefetch) {
-    hipLaunchKernelGGL((k_fused_pipelined<0, true, true>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, idx, idx_words, result, org, trace);
-  } else {
-    hipLaunchKernelGGL((k_fused_pipelined<0, false, true>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, idx, idx_words, result, org, trace);
-  }
+  hipLaunchKernelGGL((k_fused_pipelined<0, true>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, idx, idx_words, result, org, trace);
   return grid;
 }
 

@@ -96,11 +96,6 @@ struct scan_origin {
 constexpr uint64_t RANGE_ALIGN = uint64_t(1) << 20; // one resolve group = 16 large tiles = 64 small tiles
 void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *summ, seg_prefix *pref, uint32_t *idx,
                    uint64_t idx_words, scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev);
-// the same document as a chain of pieces of piece_bytes (a multiple of RANGE_ALIGN) whose scan and emission kernels overlap on
-// two streams; chain: one scan_result_dev per piece; piece_done: pieces + 2 events (sjgpu_kernels.hip)
-void launch_stage1_pieces(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *summ, seg_prefix *pref, uint32_t *idx,
-                          uint64_t idx_words, scan_result_dev *result, scan_result_dev *chain, scan_origin org, uint64_t piece_bytes,
-                          hipStream_t stream, hipStream_t aux, hipEvent_t *piece_done, hipEvent_t *ev);
 void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_prefix *pref, uint8_t *dst,
                    scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev);
 void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *result, uint8_t *esc_workspace,

@@ -64,7 +64,8 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu
   utf8_queue uq{uq_slots[wave], 0u, 0u, 0u, (org.carry & CARRY_DEBUG_QUEUE_UTF8) ? nullptr : buf, len, more ? 1u : 0u};
   if (org.carry >> 16) { uq.dense_from = (org.carry >> 16) & 0xFFu; } // A/B: env SJGPU_UTF8_DENSE_FROM
   u32 n_a = 0, n_b = 0; // resolved: n_a = final count; else n_a = candidates, n_b = candidates in a string tail
-  u64 ctrl_a = 0, ctrl_b = 0;
+  bool any_a = false, any_b = false; // wave-uniform: a control character offends under hypothesis a / b (folded per chunk: two
+                                     // compares instead of four VGPRs of masks carried through the segment)
   bool resolved = false;
   u32 derived = 0;
   u64 flip = 0;
@@ -99,13 +100,13 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu
     if (resolved) {
       const u64 structural = m.cand & ~(m.string_tail ^ flip);
       n_a += u32(popc64(structural));
-      ctrl_a |= m.ctrl & (m.in_string ^ flip);
+      any_a |= __ballot((m.ctrl & (m.in_string ^ flip)) != 0) != 0;
       keep0[c] = structural;
     } else {
       n_a += u32(popc64(m.cand));
       n_b += u32(popc64(m.cand & m.string_tail));
-      ctrl_a |= m.ctrl & m.in_string;  // offends if the relative view is the true one
-      ctrl_b |= m.ctrl & ~m.in_string; // offends if the segment really starts inside a string
+      any_a |= __ballot((m.ctrl & m.in_string) != 0) != 0;  // offends if the relative view is the true one
+      any_b |= __ballot((m.ctrl & ~m.in_string) != 0) != 0; // offends if the segment really starts inside a string
       keep0[c] = m.cand;
       keep1[c] = m.string_tail;
     }
@@ -141,7 +142,6 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu
     }
   }
   const u32 ta = wave_sum(n_a), tb = wave_sum(n_b);
-  const bool any_a = __ballot(ctrl_a != 0) != 0, any_b = __ballot(ctrl_b != 0) != 0;
   u32 flags = wc.s ? SF_PARITY : 0u;
   if (uq.error) { flags |= SF_UTF8; }
   seg_summary s;
@@ -192,17 +192,8 @@ __global__ __launch_bounds__(RESOLVE_THREADS) void k_resolve_segments(const seg_
                                                                      seg_prefix *__restrict__ pref, u32 nseg, u64 len,
                                                                      u32 *__restrict__ idx, u64 idx_words,
                                                                      scan_result_dev *__restrict__ result, int what,
-                                                                     scan_origin org, const scan_result_dev *__restrict__ chain = nullptr) {
-  // chain: the result of the piece in front of this one when a document is scanned as a chain of pieces whose kernels
-  // overlap (launch_stage1_pieces): its in-string bit, output cursor and sticky flags continue here, read on the device
-  u32 carry = org.carry;
-  u32 chain_flags = 0;
-  if (chain) {
-    const u32 cf = chain->flags;
-    carry = (carry & ~CARRY_IN_STRING) | ((cf & SJGPU_F_UNCLOSED_STRING) ? CARRY_IN_STRING : 0u);
-    org.base0 = chain->n;
-    chain_flags = cf & ~u32(SJGPU_F_UNCLOSED_STRING);
-  }
+                                                                     scan_origin org) {
+  const u32 carry = org.carry;
   __shared__ u32 sh[RESOLVE_THREADS];
   __shared__ u32 sh_flags;
   const u32 tid = threadIdx.x;
@@ -242,7 +233,7 @@ __global__ __launch_bounds__(RESOLVE_THREADS) void k_resolve_segments(const seg_
   }
   __syncthreads();
   if (tid == 0) {
-    u32 f = sh_flags | chain_flags | (final_parity ? SJGPU_F_UNCLOSED_STRING : 0u);
+    u32 f = sh_flags | (final_parity ? SJGPU_F_UNCLOSED_STRING : 0u);
     if (what == 0) {
       if (u64(total) + 3 <= idx_words) { // sentinels (json_structural_indexer.h:284-286)
         idx[total] = u32(len);
@@ -562,57 +553,6 @@ void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *
   mark(ev, 2, stream);
   hipLaunchKernelGGL(k_stage1_emit, dim3(nseg), dim3(64), 0, stream, mask0, mask1, summ, pref, len, idx, idx_words, result,
                      org);
-  mark(ev, 3, stream);
-}
-
-// The split pipeline as a chain of PIECES whose kernels overlap: the scan (k_stage1_summarize: VALU issue + reads) of piece
-// k+1 runs on `stream` while the emission (k_stage1_emit: writes) of piece k runs on `aux` -- two kernels with
-// complementary bottlenecks sharing the chip instead of taking turns.  A piece is a multiple of RANGE_ALIGN bytes; it is
-// scanned exactly like a range of a resident buffer (scan_origin::begin, CARRY_MORE), only its carry-in (in-string bit,
-// output cursor, sticky flags) is read on the device from the result of the piece in front of it (`chain` results, one
-// per piece; the last piece writes `result`).  Workspace is the whole document's: every piece uses its own slice of it.
-// piece_done: one event per piece (timing disabled) + two more; aux waits for the caller's stream before it starts and
-// the caller's stream waits for aux at the end, so the call is ordered on `stream` like any other.
-void launch_stage1_pieces(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *summ, seg_prefix *pref, uint32_t *idx,
-                          uint64_t idx_words, scan_result_dev *result, scan_result_dev *chain, scan_origin org, uint64_t piece_bytes,
-                          hipStream_t stream, hipStream_t aux, hipEvent_t *piece_done, hipEvent_t *ev) {
-  const u32 nseg_all = num_segments(len);
-  const u32 ngroups_all = (nseg_all + RESOLVE_GROUP - 1) / RESOLVE_GROUP;
-  const u32 npieces = u32((len + piece_bytes - 1) / piece_bytes);
-  static const bool no_hint = std::getenv("SJGPU_NO_SPAN_HINT") != nullptr;
-  if (no_hint) { org.carry |= CARRY_DEBUG_NO_SPAN_HINT; }
-  mark(ev, 0, stream); // slot 0 = the whole call (kernels of both streams); slots 1 and 2 stay empty
-  launch_escape_table(buf, 0, len, org.esc, stream); // one table for the whole document, in front of the first scan
-  (void)hipEventRecord(piece_done[npieces], stream);
-  (void)hipStreamWaitEvent(aux, piece_done[npieces], 0); // whatever the caller enqueued before this call precedes aux's work, too
-  u64 *const mask0_all = reinterpret_cast<u64 *>(masks);
-  u64 *const mask1_all = mask0_all + size_t(nseg_all) * (SEG_BYTES / BLOCK_BYTES);
-  seg_summary *const gsum_all = summ + nseg_all;
-  for (u32 k = 0; k < npieces; k++) {
-    const u64 begin = u64(k) * piece_bytes, end = (begin + piece_bytes < len) ? begin + piece_bytes : len;
-    const bool last = (k + 1 == npieces);
-    const u32 seg0 = u32(begin / SEG_BYTES), group0 = seg0 / RESOLVE_GROUP;
-    const u32 nseg = num_segments(end - begin), ngroups = (nseg + RESOLVE_GROUP - 1) / RESOLVE_GROUP;
-    scan_origin po = org;
-    po.begin = begin;
-    po.base0 = 0; // continued on the device from chain[k - 1]
-    po.carry = (org.carry & ~(CARRY_MORE | CARRY_IN_STRING)) | CARRY_SHARD | (last ? (org.carry & CARRY_MORE) : CARRY_MORE) | (k == 0 ? (org.carry & CARRY_IN_STRING) : 0u);
-    u64 *m0 = mask0_all + size_t(seg0) * (SEG_BYTES / BLOCK_BYTES), *m1 = mask1_all + size_t(seg0) * (SEG_BYTES / BLOCK_BYTES);
-    seg_summary *ps = summ + seg0, *pg = gsum_all + group0;
-    seg_prefix *pp = pref + group0;
-    scan_result_dev *pr = last ? result : chain + k;
-    hipLaunchKernelGGL(k_stage1_summarize, dim3((nseg + SUMM_WAVES - 1) / SUMM_WAVES), dim3(64 * SUMM_WAVES), 0, stream, buf, end, m0, m1, ps, po, nseg);
-    (void)hipEventRecord(piece_done[k], stream);
-    (void)hipStreamWaitEvent(aux, piece_done[k], 0);
-    hipLaunchKernelGGL(k_resolve_groups, dim3(ngroups), dim3(64), 0, aux, ps, pg, nseg);
-    hipLaunchKernelGGL(k_resolve_segments, dim3(1), dim3(RESOLVE_THREADS), 0, aux, pg, pp, ngroups, end, idx, idx_words, pr, 0, po,
-                       k ? chain + (k - 1) : static_cast<const scan_result_dev *>(nullptr));
-    hipLaunchKernelGGL(k_stage1_emit, dim3(nseg), dim3(64), 0, aux, m0, m1, ps, pp, end, idx, idx_words, pr, po);
-  }
-  (void)hipEventRecord(piece_done[npieces + 1], aux);
-  (void)hipStreamWaitEvent(stream, piece_done[npieces + 1], 0);
-  mark(ev, 1, stream);
-  mark(ev, 2, stream);
   mark(ev, 3, stream);
 }
 

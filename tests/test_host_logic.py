@@ -43,6 +43,28 @@ def test_every_barrier_waits_for_lds(lib):
     assert found == []
 
 
+def test_no_kernel_spills(lib):
+    """Round 2's review found 20 B of scratch in the headline kernel and in k_stage1_summarize (spills inside the hot loop of a
+    kernel that is short of issue slots).  What the code objects of the built library tell the hardware to reserve
+    (.private_segment_fixed_size) must be zero for every kernel -- the large-input paths in particular."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_barriers", os.path.join(_paths.REPO_ROOT, "scripts", "check_barriers.py"))
+    cb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cb)
+    res = cb.kernel_resources(os.path.join(_paths.LIB_DIR, "libsjgpu.so"))
+    names = " ".join(res)
+    for must in ("k_fused_pipelined", "k_stage1_summarize", "k_stage1_emit", "k_minify_onchip", "k_validate_utf8"):
+        assert must in names, must
+    spilling = {k: v["scratch"] for k, v in res.items() if v.get("scratch", 0) != 0}
+    assert spilling == {}, spilling
+    # the occupancy the launch bounds ask for is the occupancy the register count allows (MI355X_MICROARCH.md, register file table)
+    for k, v in res.items():
+        if "k_fused_pipelined" in k or "k_minify_onchip" in k:
+            assert v["vgpr"] <= 128, (k, v)
+        if "k_stage1_summarize" in k:
+            assert v["vgpr"] <= 80, (k, v)
+
+
 def test_barrier_check_finds_a_dropped_wait(tmp_path):
     """The checker is not vacuous: with the explicit waits compiled out (-DSJGPU_SELFTEST_DROP_LDS_WAIT) it reports the loop-top
     barriers hipcc leaves unguarded -- k_minify_onchip's among them, the one that produced wrong output on the GPU."""
