@@ -140,6 +140,65 @@ int sjref_dom_string_buf(const char *impl_name, const uint8_t *buf, size_t len, 
   return int(err);
 }
 
+// A full dom parse with the named kernel, handing back what stage 2 left: the tape (doc.tape[0 .. tape[0] payload)) and the string
+// buffer up to the end of the last record.  buf must be padded (SIMDJSON_PADDING readable bytes behind len).  max_depth as
+// dom::parser's.  Returns the parse's error_code; the outputs are only filled on SUCCESS.
+int sjref_dom_parse(const char *impl_name, const uint8_t *buf, size_t len, uint32_t max_depth, uint64_t *tape_out, size_t tape_cap, uint64_t *tape_words_out,
+                    uint8_t *str_out, size_t str_cap, uint64_t *str_bytes_out) {
+  auto impl = find_impl(impl_name);
+  if (!impl) { return -1; }
+  std::unique_ptr<dom_parser_implementation> p;
+  if (impl->create_dom_parser_implementation(len ? len : 1, max_depth, p) != simdjson::SUCCESS) { return -2; }
+  simdjson::dom::document doc;
+  if (doc.allocate(len) != simdjson::SUCCESS) { return -2; }
+  auto err = p->parse(buf, len, doc);
+  if (tape_words_out) { *tape_words_out = 0; }
+  if (str_bytes_out) { *str_bytes_out = 0; }
+  if (err != simdjson::SUCCESS) { return int(err); }
+  const uint64_t words = doc.tape[0] & 0xFFFFFFFFFFFFFFull;
+  uint64_t used = 0;
+  for (uint64_t i = 1; i + 1 < words; i++) {
+    const uint64_t v = doc.tape[i];
+    const char type = char(v >> 56);
+    if (type == '"') {
+      const uint64_t at = v & 0xFFFFFFFFFFFFFFull;
+      uint32_t l;
+      std::memcpy(&l, doc.string_buf.get() + at, 4);
+      if (at + 5 + l > used) { used = at + 5 + l; }
+    } else if (type == 'l' || type == 'u' || type == 'd') {
+      i++;
+    }
+  }
+  if (tape_words_out) { *tape_words_out = words; }
+  if (str_bytes_out) { *str_bytes_out = used; }
+  if (tape_out && words <= tape_cap) { std::memcpy(tape_out, doc.tape.get(), words * sizeof(uint64_t)); }
+  if (str_out && used <= str_cap) { std::memcpy(str_out, doc.string_buf.get(), used); }
+  return 0;
+}
+
+// stage 2 alone (dom_parser_implementation::stage2, tape_builder::parse_document<false>) after one stage 1: best seconds over
+// `iters` runs after a warm one; negative on failure.  What bench.py times beside the device tape builder.
+double sjref_bench_stage2(const char *impl_name, const uint8_t *buf, size_t len, int iters, int *err_out) {
+  auto impl = find_impl(impl_name);
+  if (!impl) { return -1.0; }
+  std::unique_ptr<dom_parser_implementation> p;
+  if (impl->create_dom_parser_implementation(len ? len : 1, 1024, p) != simdjson::SUCCESS) { return -2.0; }
+  simdjson::dom::document doc;
+  if (doc.allocate(len) != simdjson::SUCCESS) { return -2.0; }
+  auto err = p->stage1(buf, len, simdjson::stage1_mode::regular);
+  if (err != simdjson::SUCCESS) { if (err_out) { *err_out = int(err); } return -3.0; }
+  double best = 1e300;
+  for (int it = 0; it < iters + 1; it++) {
+    auto t0 = std::chrono::steady_clock::now();
+    err = p->stage2(doc);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (it > 0 && dt < best) { best = dt; }
+    if (err != simdjson::SUCCESS) { break; }
+  }
+  if (err_out) { *err_out = int(err); }
+  return best;
+}
+
 // The string work of stage 2 alone, the way tape_builder does it (visit_string, tape_builder.h:187-205 with :415-433): for every
 // structural that is a quote, parse_string behind a 4-byte length slot, NUL behind it.  buf must be padded; out needs
 // 5 (len + 1) / 3 + 64 bytes.  Returns the best seconds over `iters` runs (after one warm run), negative on failure (incl. a

@@ -74,6 +74,17 @@ long sjo_parse_string(const uint8_t *src, const uint8_t *end, uint8_t *dst, int 
 int sjo_string_buffer(const uint8_t *buf, size_t len, const uint32_t *idx, uint32_t n, int allow_replacement, uint8_t *out,
                       size_t out_cap, uint32_t *offsets, uint64_t *bytes, uint32_t *strings, uint32_t *first_bad);
 
+/* ---- stage 2 of one document -- the DOM tape (sj_oracle_stage2.c) --------------------------------------------
+ * The reference's serial walk over the structural list with the tape builder as visitor
+ * (/root/reference/src/generic/stage2/json_iterator.h:121-244, tape_builder.h:142-441, format /root/reference/doc/tape.md).
+ * idx[0..n) = the structurals of buf[0..len) as stage 1 left them, idx[n] = len (its first sentinel); max_depth as
+ * dom::parser's (DEFAULT_MAX_DEPTH = 1024).  tape needs up to len + 3 words, string_buf 5 (len / 3) + 64 bytes (what
+ * dom::document::allocate reserves, include/simdjson/dom/document-inl.h:29-67).  Returns the reference's error_code: SUCCESS,
+ * EMPTY, TAPE_ERROR 3, DEPTH_ERROR 4, STRING_ERROR 5, T/F/N_ATOM_ERROR 6/7/8, NUMBER_ERROR 9, BIGINT_ERROR 10 (or CAPACITY
+ * when a buffer was too small).  *tape_words / *string_bytes = what was produced (complete only on SUCCESS). */
+int sjo_stage2(const uint8_t *buf, size_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, uint64_t *tape, size_t tape_cap,
+               uint8_t *string_buf, size_t string_cap, uint64_t *tape_words, uint64_t *string_bytes);
+
 /* FNV-1a-64 over the n+3 index words (little-endian bytes): the digest SURVEY App. B quotes. */
 uint64_t sjo_fnv1a64(const void *data, size_t nbytes);
 

@@ -139,11 +139,13 @@ static int string(builder *b, size_t pos) {
   return E_OK;
 }
 
-/* visit_primitive / visit_root_primitive (json_iterator.h:316-366) */
-static int primitive(builder *b, size_t pos) {
+/* visit_primitive (json_iterator.h:342-370) / visit_root_primitive (:313-340).  Inside a container the reference tests
+ * `(*value - '0') < 10` in int arithmetic, which holds for EVERY byte below ':' -- a ',' or '!' where a value is expected is
+ * handed to parse_number and comes back as NUMBER_ERROR, not TAPE_ERROR; the root value goes through an exact switch. */
+static int primitive(builder *b, size_t pos, int root) {
   const unsigned c = at(b, pos);
   if (c == '"') { return string(b, pos); }
-  if (c - '0' <= 9u || c == '-') { return number(b, pos); }
+  if (root ? (c - '0' <= 9u || c == '-') : ((int)c - '0' < 10 || c == '-')) { return number(b, pos); }
   switch (c) {
   case 't': if (!atom_ok(b, pos, "true")) { return E_T_ATOM; } put(b, tagged('t', 0)); return E_OK;
   case 'f': if (!atom_ok(b, pos, "false")) { return E_F_ATOM; } put(b, tagged('f', 0)); return E_OK;
@@ -184,7 +186,7 @@ int sjo_stage2(const uint8_t *buf, size_t len, const uint32_t *idx, uint32_t n, 
       if (TOK(i) == ']') { i++; put(b, tagged('[', b->tape_at + 2)); put(b, tagged(']', b->tape_at - 1)); state = DOCUMENT_END; }
       else { state = ARRAY_BEGIN; }
     } else {
-      err = primitive(b, pos);
+      err = primitive(b, pos, 1);
       if (err) { goto done; }
       state = DOCUMENT_END;
     }
@@ -220,7 +222,7 @@ int sjo_stage2(const uint8_t *buf, size_t len, const uint32_t *idx, uint32_t n, 
         if (TOK(i) == ']') { i++; put(b, tagged('[', b->tape_at + 2)); put(b, tagged(']', b->tape_at - 1)); state = OBJECT_CONTINUE; }
         else { state = ARRAY_BEGIN; }
       } else {
-        err = primitive(b, pos);
+        err = primitive(b, pos, 0);
         if (err) { goto done; }
         state = OBJECT_CONTINUE;
       }
@@ -271,7 +273,7 @@ int sjo_stage2(const uint8_t *buf, size_t len, const uint32_t *idx, uint32_t n, 
         if (TOK(i) == ']') { i++; put(b, tagged('[', b->tape_at + 2)); put(b, tagged(']', b->tape_at - 1)); state = ARRAY_CONTINUE; }
         else { state = ARRAY_BEGIN; }
       } else {
-        err = primitive(b, pos);
+        err = primitive(b, pos, 0);
         if (err) { goto done; }
         state = ARRAY_CONTINUE;
       }

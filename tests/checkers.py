@@ -49,7 +49,28 @@ class Oracle:
         L.sjo_string_buffer.restype = ctypes.c_int
         L.sjo_string_buffer.argtypes = [_u8p, ctypes.c_size_t, _u8p, ctypes.c_uint32, ctypes.c_int, _u8p, ctypes.c_size_t, _u8p,
                                         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+        L.sjo_stage2.restype = ctypes.c_int
+        L.sjo_stage2.argtypes = [_u8p, ctypes.c_size_t, _u8p, ctypes.c_uint32, ctypes.c_uint32, _u8p, ctypes.c_size_t, _u8p, ctypes.c_size_t,
+                                 ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
         self.L = L
+
+    def stage2(self, data, idx, n, max_depth=1024):
+        """(error_code, tape words, string_buf bytes) of the document whose stage 1 left idx[0..n] (sj_oracle_stage2.c)"""
+        a = as_u8(data)
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        tape = np.zeros(len(a) + 8, dtype=np.uint64)
+        sbuf = np.zeros(5 * (len(a) // 3) + 128, dtype=np.uint8)
+        tw, sb = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        err = self.L.sjo_stage2(a.ctypes.data, len(a), idx.ctypes.data, int(n), int(max_depth), tape.ctypes.data, len(tape), sbuf.ctypes.data, len(sbuf),
+                                ctypes.byref(tw), ctypes.byref(sb))
+        return err, tape[: tw.value].copy(), sbuf[: sb.value].copy()
+
+    def dom_parse(self, data, max_depth=1024):
+        """stage 1 + stage 2 of the oracle: (error_code, tape, string_buf); the stage-1 error if that is where it ends"""
+        err, n, idx = self.stage1(data, 0)
+        if err:
+            return err, np.zeros(0, np.uint64), np.zeros(0, np.uint8)
+        return self.stage2(data, idx, n, max_depth)
 
     def parse_string(self, body, allow_replacement=False):
         """body = the bytes behind the opening quote (closing quote included).  Returns the unescaped bytes or None."""
@@ -123,7 +144,24 @@ class Reference:
         L.sjref_dom_string_buf.restype = ctypes.c_int
         L.sjref_dom_string_buf.argtypes = [ctypes.c_char_p, _u8p, ctypes.c_size_t, _u8p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64),
                                            ctypes.POINTER(ctypes.c_uint32)]
+        L.sjref_dom_parse.restype = ctypes.c_int
+        L.sjref_dom_parse.argtypes = [ctypes.c_char_p, _u8p, ctypes.c_size_t, ctypes.c_uint32, _u8p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64),
+                                      _u8p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
+        L.sjref_bench_stage2.restype = ctypes.c_double
+        L.sjref_bench_stage2.argtypes = [ctypes.c_char_p, _u8p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
         self.L = L
+
+    def dom_parse(self, impl, data, max_depth=1024):
+        """The reference's dom::parser::parse with the named kernel: (error_code, tape words, string_buf bytes)"""
+        body = as_u8(data)
+        a = np.concatenate([body, np.zeros(128, np.uint8)])  # padded the way a padded_string is (zeros)
+        tape = np.zeros(len(body) + 72, dtype=np.uint64)
+        sbuf = np.zeros(5 * (len(body) // 3) + 192, dtype=np.uint8)
+        tw, sb = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        err = self.L.sjref_dom_parse(impl.encode(), a.ctypes.data, len(body), int(max_depth), tape.ctypes.data, len(tape), ctypes.byref(tw),
+                                     sbuf.ctypes.data, len(sbuf), ctypes.byref(sb))
+        assert err >= 0
+        return err, tape[: tw.value].copy(), sbuf[: sb.value].copy()
 
     def parse_string(self, impl, body, allow_replacement=False):
         """The kernel's parse_string on `body` (bytes behind the opening quote), padded with 128 spaces as a padded_string is."""

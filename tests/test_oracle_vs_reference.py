@@ -209,3 +209,77 @@ def test_string_buffer_on_random_documents(both):
         assert bytes(got) == bytes(want), doc
         checked += strings
     assert checked > 4000
+
+
+# ---- stage 2 -- the DOM tape (oracle/sj_oracle_stage2.c against the reference's dom::parser::parse) ---------------------
+import jsongen
+
+
+def _same_parse(orc, ref, impl, doc, max_depth=1024):
+    e_ref, t_ref, s_ref = ref.dom_parse(impl, doc, max_depth)
+    e_orc, t_orc, s_orc = orc.dom_parse(doc, max_depth)
+    assert e_orc == e_ref, (doc[:200], e_orc, e_ref)
+    if e_ref == 0:
+        assert np.array_equal(t_orc, t_ref), (doc[:200], [hex(int(x)) for x in t_orc[:40]], [hex(int(x)) for x in t_ref[:40]])
+        assert bytes(s_orc) == bytes(s_ref), doc[:200]
+    return e_ref
+
+
+@pytest.mark.parametrize("name", ["twitter.json", "citm_catalog.json", "example_config.json"])
+def test_stage2_tape_of_the_fixtures(both, name):
+    import os
+    from simdjson_amd import _paths
+    orc, ref = both
+    path = os.path.join(_paths.REPO_ROOT, "tests", "golden", "jsonexamples", name)
+    if not os.path.exists(path):
+        pytest.skip(name + " is not among the fixtures")
+    doc = open(path, "rb").read()
+    assert _same_parse(orc, ref, ref.best_impl(), doc) == 0
+
+
+def test_stage2_tape_of_random_documents(both):
+    """3 000 random valid documents (every token kind, numbers of every shape, nesting up to 6): tape and string_buf word for word"""
+    orc, ref = both
+    impl = ref.best_impl()
+    rng = np.random.default_rng(4242)
+    for _ in range(3000):
+        assert _same_parse(orc, ref, impl, jsongen.random_document(rng)) == 0
+
+
+def test_stage2_errors_of_broken_documents(both):
+    """8 000 token-level mutations of valid documents: the oracle reports the error_code the reference reports (the walk stops at the
+    FIRST offending token, so the code says which check fired first), and the same tape when the mutation left the document valid"""
+    orc, ref = both
+    impl = ref.best_impl()
+    rng = np.random.default_rng(99)
+    seen = {}
+    for _ in range(8000):
+        doc = jsongen.mutate(rng, jsongen.random_document(rng, max_depth=4))
+        e = _same_parse(orc, ref, impl, doc)
+        seen[e] = seen.get(e, 0) + 1
+    for code in (0, 3, 5, 6, 7, 8, 9, 10):  # SUCCESS, TAPE, STRING, T/F/N_ATOM, NUMBER, BIGINT all occur
+        assert seen.get(code, 0) > 0, seen
+
+
+def test_stage2_numbers(both):
+    """every corner-case number as the only element of an array, as a member value, and as the whole document (root scalars take the
+    reference's space-padded copy, tape_builder.h:243-262)"""
+    orc, ref = both
+    impl = ref.best_impl()
+    for text in jsongen.number_corner_cases():
+        t = text.encode()
+        for doc in (b"[" + t + b"]", b'{"k":' + t + b" }", t, b"[1," + t + b",2]", t + b" "):
+            _same_parse(orc, ref, impl, doc)
+
+
+def test_stage2_depth_limit(both):
+    orc, ref = both
+    impl = ref.best_impl()
+    for depth in (1, 2, 3, 5, 1023, 1024, 1025, 1030):
+        for inner in (b"", b"1", b"{}", b'{"a":[]}'):
+            doc = b"[" * depth + inner + b"]" * depth
+            _same_parse(orc, ref, impl, doc)
+            _same_parse(orc, ref, impl, b'{"a":' * depth + (inner or b"0") + b"}" * depth)
+    for max_depth in (1, 2, 3, 4, 16):
+        for doc in (b"[]", b"[[]]", b"[[[]]]", b"[[[[1]]]]", b'{"a":{"b":{"c":{}}}}', b"1", b"[1,[2,[3,[4]]]]"):
+            _same_parse(orc, ref, impl, doc, max_depth)
