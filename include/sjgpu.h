@@ -216,6 +216,32 @@ int sjgpu_parse_strings_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
                                void *string_buf_dev, size_t string_buf_bytes, void *offsets_dev, void *stream, uint64_t *bytes_out,
                                uint32_t *strings_out, uint32_t *first_bad_out);
 
+/* ---- stage 2 of a resident document: the DOM tape --------------------------------------------------------
+ * What dom_parser_implementation::stage2(dom::document &) (include/simdjson/internal/dom_parser_implementation.h:94) leaves in
+ * the document -- behaviour: json_iterator::walk_document (src/generic/stage2/json_iterator.h:121-244) with the tape builder as
+ * visitor (src/generic/stage2/tape_builder.h:142-441; format doc/tape.md) -- for a document and structural list that live in
+ * HBM, without walking: tape positions and nesting depths are prefix sums over the list, brackets find their partners through
+ * a stable sort by nesting level, every token checks the walk's rule for itself, and the reference's error is the smallest
+ * offending list index (sjgpu_tape.hip).  Numbers are converted exactly like the reference's (Eisel-Lemire, exact big-integer
+ * decision beyond 19 digits: sj_number.h); the strings come from the string pass above.
+ * idx_dev[0..n] = the list sjgpu_stage1_device left for buf_dev[0..len) (regular mode, no error), first sentinel included.
+ * max_depth: dom::parser's (DEFAULT_MAX_DEPTH 1024; at most 4095 here).  tape_dev: room for tape_cap_words 64-bit words
+ * (len + 3 always suffice; the reference allocates ROUNDUP(len + 3, 64)), 8-byte aligned; string_buf_dev as for
+ * sjgpu_parse_strings_device.  Returns the reference's error_code: SUCCESS, EMPTY (n == 0), TAPE_ERROR 3, DEPTH_ERROR 4,
+ * STRING_ERROR 5, T/F/N_ATOM_ERROR 6/7/8, NUMBER_ERROR 9, BIGINT_ERROR 10 (numbers beyond 64 bits: _number_as_string is not
+ * offered here) -- the one the reference's serial walk meets FIRST -- or SJGPU_E_OVERFLOW / other negatives.  On SUCCESS
+ * tape_dev[0 .. *tape_words_out) and string_buf_dev[0 .. *string_bytes_out) are word for word what the reference's dom parse
+ * leaves in dom::document::tape / string_buf.  Waits for the stream (reads 48 bytes back). */
+int sjgpu_stage2_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const void *idx_dev, uint32_t n, uint32_t max_depth, void *tape_dev,
+                        size_t tape_cap_words, void *string_buf_dev, size_t string_buf_bytes, void *stream, uint64_t *tape_words_out,
+                        uint64_t *string_bytes_out);
+/* dom_parser_implementation::parse(buf, len, doc) (include/simdjson/internal/dom_parser_implementation.h:64) for HOST buffers:
+ * upload, stage 1, stage 2 on the device, tape and string buffer copied into the caller's arrays (the document's
+ * doc.tape / doc.string_buf).  The structural list never leaves the device.  Same error codes as the reference's parse
+ * (stage 1's first: CAPACITY, EMPTY, UNCLOSED_STRING, UNESCAPED_CHARS, UTF8_ERROR; then stage 2's). */
+int sjgpu_parse(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, uint32_t max_depth, uint64_t *tape_out, size_t tape_cap_words,
+                uint8_t *string_buf_out, size_t string_buf_bytes, uint64_t *tape_words_out, uint64_t *string_bytes_out);
+
 /* ---- one large document sharded across GPUs ("general inputs") -------------------------
  * The reference has no counterpart: its stage 1 is one serial pass whose carries (json_escape_scanner.h:50-71
  * next_is_escaped, json_string_scanner.h:62-85 prev_in_string, json_scanner.h:128-157 prev_scalar,

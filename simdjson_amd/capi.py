@@ -29,7 +29,7 @@ EXPORTS = [
     "sjgpu_stage1_range_device", "sjgpu_minify_range_device",
     "sjgpu_host_alloc", "sjgpu_host_free", "sjgpu_host_register", "sjgpu_host_unregister", "sjgpu_last_pipeline",
     "sjgpu_profile_kernel", "sjgpu_debug_trace_pipelined", "sjgpu_stage1_many", "sjgpu_stage1_finish_device",
-    "sjgpu_depth_scan_device", "sjgpu_parse_strings_device", "sjgpu_mgpu_create", "sjgpu_mgpu_destroy", "sjgpu_mgpu_count", "sjgpu_mgpu_stage1", "sjgpu_mgpu_minify",
+    "sjgpu_depth_scan_device", "sjgpu_parse_strings_device", "sjgpu_stage2_device", "sjgpu_parse", "sjgpu_mgpu_create", "sjgpu_mgpu_destroy", "sjgpu_mgpu_count", "sjgpu_mgpu_stage1", "sjgpu_mgpu_minify",
     "sjgpu_mgpu_validate_utf8",
 ]
 
@@ -112,6 +112,11 @@ def load_library():
     L.sjgpu_depth_scan_device.argtypes = [vp, vp, vp, ctypes.c_uint32, vp, vp]
     L.sjgpu_parse_strings_device.restype = ctypes.c_int
     L.sjgpu_parse_strings_device.argtypes = [vp, vp, sz, vp, ctypes.c_uint32, ctypes.c_int, vp, sz, vp, vp, ctypes.POINTER(ctypes.c_uint64), u32p, u32p]
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    L.sjgpu_stage2_device.restype = ctypes.c_int
+    L.sjgpu_stage2_device.argtypes = [vp, vp, sz, vp, ctypes.c_uint32, ctypes.c_uint32, vp, sz, vp, sz, vp, u64p, u64p]
+    L.sjgpu_parse.restype = ctypes.c_int
+    L.sjgpu_parse.argtypes = [vp, vp, sz, ctypes.c_uint32, vp, sz, vp, sz, u64p, u64p]
     L.sjgpu_mgpu_create.restype = ctypes.c_int
     L.sjgpu_mgpu_create.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(vp)]
     L.sjgpu_mgpu_destroy.restype = None
@@ -325,6 +330,27 @@ class DomParserImplementation:
         if rc < 0:
             raise SjgpuError(f"sjgpu_parse_strings_device error {rc}: {self.last_error()}")
         return rc, int(used.value), int(cnt.value), int(bad.value)
+
+    def stage2_device(self, buf_ptr, length, idx_ptr, n, tape_ptr, tape_cap_words, strbuf_ptr, strbuf_bytes, max_depth=1024, stream=0):
+        """sjgpu_stage2_device -> (simdjson error_code, tape words, string buffer bytes); raises on infrastructure errors"""
+        tw, sb = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        rc = self.L.sjgpu_stage2_device(self.h, buf_ptr, int(length), idx_ptr, int(n), int(max_depth), tape_ptr, int(tape_cap_words), strbuf_ptr, int(strbuf_bytes),
+                                        stream or None, ctypes.byref(tw), ctypes.byref(sb))
+        if rc < 0:
+            raise SjgpuError(f"sjgpu_stage2_device error {rc}: {self.last_error()}")
+        return rc, int(tw.value), int(sb.value)
+
+    def parse(self, data, max_depth=1024):
+        """dom_parser_implementation::parse for a host buffer: (error_code, tape as uint64 array, string_buf as uint8 array)"""
+        a = _as_u8(data)
+        tape = np.zeros(len(a) + 8, dtype=np.uint64)
+        sbuf = np.zeros(5 * (len(a) // 3) + 256, dtype=np.uint8)
+        tw, sb = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        rc = self.L.sjgpu_parse(self.h, a.ctypes.data if len(a) else None, len(a), int(max_depth), tape.ctypes.data, len(tape), sbuf.ctypes.data, len(sbuf),
+                                ctypes.byref(tw), ctypes.byref(sb))
+        if rc < 0:
+            raise SjgpuError(f"sjgpu_parse error {rc}: {self.last_error()}")
+        return rc, tape[: tw.value], sbuf[: sb.value]
 
     def result(self, stream=0):  # waits for `stream`
         r = ScanResult()

@@ -142,6 +142,11 @@ struct sjgpu_ctx {
   // scratch of the device-side finish / depth scan (sjgpu_finish.hip), grown on demand
   uint8_t *d_tmp = nullptr;
   size_t d_tmp_bytes = 0;
+  // stage 2 (sjgpu_tape.hip): string offsets + the tape builder's arrays; sjgpu_parse's device tape and string buffer
+  uint8_t *d_stage2 = nullptr;
+  size_t d_stage2_bytes = 0;
+  uint8_t *d_doc = nullptr; // [tape words][string buffer] of sjgpu_parse
+  size_t d_doc_bytes = 0;
   // overlapped host-buffer path (large documents): one copy thread per direction, one "range uploaded" event per range
   std::vector<copy_worker *> up, down; // range k travels on up[k % up.size()]; output piece k on down[k % down.size()]
   size_t copy_threads = 1;             // per direction (env SJGPU_COPY_THREADS)
@@ -543,6 +548,8 @@ void really_destroy(sjgpu_ctx *ctx) {
   if (ctx->h_small) { (void)hipHostFree(ctx->h_small); }
   dev_free(ctx->esc_tab);
   dev_free(ctx->d_tmp);
+  dev_free(ctx->d_stage2);
+  dev_free(ctx->d_doc);
   if (ctx->stream) { (void)hipStreamDestroy(ctx->stream); }
   delete ctx;
 }
@@ -612,6 +619,8 @@ extern "C" void sjgpu_ctx_destroy(sjgpu_ctx *ctx) {
     release_staging(ctx);
   }
   if (ctx->d_tmp_bytes > 4 * POOL_KEEP_BYTES) { dev_free(ctx->d_tmp); ctx->d_tmp_bytes = 0; }
+  if (ctx->d_stage2_bytes > 4 * POOL_KEEP_BYTES) { dev_free(ctx->d_stage2); ctx->d_stage2_bytes = 0; }
+  if (ctx->d_doc_bytes > 4 * POOL_KEEP_BYTES) { dev_free(ctx->d_doc); ctx->d_doc_bytes = 0; }
   if (ctx->h_small_bytes > (size_t(1) << 20)) { // page-locked memory is scarce: a parked context keeps at most 1 MiB of it
     (void)hipHostFree(ctx->h_small);
     ctx->h_small = nullptr;
@@ -1224,6 +1233,92 @@ int sjgpu_parse_strings_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
   if (first_bad_out) { *first_bad_out = h.first_bad; }
   if (h.overflow) { return SJGPU_E_OVERFLOW; }
   return h.first_bad != 0xFFFFFFFFu ? 5 /* STRING_ERROR */ : 0;
+}
+
+// ---- stage 2: the tape (sjgpu_tape.hip) -------------------------------------------------------------------------------------------------
+int sjgpu_stage2_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const void *idx_dev, uint32_t n, uint32_t max_depth, void *tape_dev,
+                        size_t tape_cap_words, void *string_buf_dev, size_t string_buf_bytes, void *stream, uint64_t *tape_words_out,
+                        uint64_t *string_bytes_out) {
+  if (!ctx || !buf_dev || !idx_dev || !tape_dev || !string_buf_dev || max_depth == 0 || max_depth > 4095u) { return SJGPU_E_BADARG; }
+  if ((reinterpret_cast<uintptr_t>(buf_dev) & 3u) || (reinterpret_cast<uintptr_t>(tape_dev) & 7u) || (reinterpret_cast<uintptr_t>(idx_dev) & 3u)) { return SJGPU_E_BADARG; }
+  if (tape_words_out) { *tape_words_out = 0; }
+  if (string_bytes_out) { *string_bytes_out = 0; }
+  if (n == 0) { return E_EMPTY; } // walk_document: at_eof() (json_iterator.h:126)
+  if (len > 2400000000ull || n >= 0xFFFFFFF0u) { return E_CAPACITY; } // the string pass's 32-bit record offsets
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  // [strings result 32 B][scan scratch of the string pass][string offsets, n + 1 words][tape workspace]
+  const size_t scratch_at = 32, scratch = (strings_scratch_bytes(n) + 255) & ~size_t(255), offs_at = scratch_at + scratch;
+  const size_t tape_at = (offs_at + (size_t(n) + 1) * sizeof(uint32_t) + 255) & ~size_t(255);
+  int rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_stage2), &ctx->d_stage2_bytes, tape_at + tape_workspace_bytes(n, len));
+  if (rc) { return rc; }
+  uint8_t *ws = ctx->d_stage2;
+  strings_result_dev *sres = reinterpret_cast<strings_result_dev *>(ws);
+  uint32_t *offsets = reinterpret_cast<uint32_t *>(ws + offs_at);
+  hipStream_t s = pick(ctx, stream);
+  launch_parse_strings(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, false, static_cast<uint8_t *>(string_buf_dev),
+                       string_buf_bytes, offsets, sres, ws + scratch_at, s);
+  launch_tape(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, max_depth, offsets, static_cast<uint64_t *>(tape_dev),
+              tape_cap_words, ws + tape_at, s);
+  SJ_TRY(ctx, hipGetLastError());
+  strings_result_dev hs;
+  tape_result_dev ht;
+  SJ_TRY(ctx, hipMemcpyAsync(&hs, sres, sizeof(hs), hipMemcpyDeviceToHost, s));
+  SJ_TRY(ctx, hipMemcpyAsync(&ht, ws + tape_at, sizeof(ht), hipMemcpyDeviceToHost, s));
+  SJ_TRY(ctx, hipStreamSynchronize(s));
+  // the first offender in list order decides; a string's content ranks behind its own position in the grammar (sj_tape_rules.h)
+  uint64_t key = ht.error_key;
+  if (hs.first_bad != 0xFFFFFFFFu) {
+    const uint64_t sk = (uint64_t(hs.first_bad) << 8) | (2u << 4) | 5u; // STRING_ERROR
+    if (sk < key) { key = sk; }
+  }
+  if (key != ~uint64_t(0)) { return int(key & 0xFu); }
+  if (hs.overflow || ht.overflow) { return SJGPU_E_OVERFLOW; }
+  if (tape_words_out) { *tape_words_out = ht.tape_words; }
+  if (string_bytes_out) { *string_bytes_out = hs.bytes; }
+  return 0;
+}
+
+int sjgpu_parse(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, uint32_t max_depth, uint64_t *tape_out, size_t tape_cap_words, uint8_t *string_buf_out,
+                size_t string_buf_bytes, uint64_t *tape_words_out, uint64_t *string_bytes_out) {
+  if (!ctx || !tape_out || !string_buf_out) { return SJGPU_E_BADARG; }
+  if (tape_words_out) { *tape_words_out = 0; }
+  if (string_bytes_out) { *string_bytes_out = 0; }
+  if (len > ctx->capacity) { return E_CAPACITY; }
+  if (len == 0) { return E_EMPTY; }
+  if (!buf) { return SJGPU_E_BADARG; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_staging_in(ctx, len);
+  if (rc) { return rc; }
+  size_t idx_bytes = ctx->d_idx_words * sizeof(uint32_t);
+  rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_idx), &idx_bytes, (grown(len) + 16) * sizeof(uint32_t));
+  ctx->d_idx_words = idx_bytes / sizeof(uint32_t);
+  if (rc) { return rc; }
+  const size_t tape_words_cap = len + 8, str_cap = 5 * (len / 3) + 256, str_at = tape_words_cap * sizeof(uint64_t);
+  rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_doc), &ctx->d_doc_bytes, str_at + str_cap);
+  if (rc) { return rc; }
+  hipStream_t s = ctx->stream;
+  SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, buf, len, hipMemcpyHostToDevice, s));
+  sjgpu_scan_result res{0, 0, 0};
+  for (int attempt = 0; attempt < 2; attempt++) { // a single-pass scan that gives up is re-run on the split pipeline
+    enqueue_stage1(ctx, use_fused(ctx, len, 0) && attempt == 0, ctx->d_in, len, ctx->d_idx, ctx->d_idx_words, s, nullptr);
+    SJ_ENQUEUED(ctx);
+    rc = fetch_result(ctx, s, &res);
+    if (rc) { return rc; }
+    if (!(res.flags & SJGPU_F_INTERNAL)) { break; }
+  }
+  if (res.flags & (SJGPU_F_INTERNAL | SJGPU_F_IDX_OVERFLOW)) { return E_UNEXPECTED; }
+  const int e1 = sjgpu_stage1_error_from_flags(res.n, res.flags);
+  if (e1) { return e1; }
+  uint64_t tw = 0, sb = 0;
+  rc = sjgpu_stage2_device(ctx, ctx->d_in, len, ctx->d_idx, res.n, max_depth, ctx->d_doc, tape_words_cap, ctx->d_doc + str_at, str_cap, s, &tw, &sb);
+  if (rc) { return rc; }
+  if (tw > tape_cap_words || sb > string_buf_bytes) { return SJGPU_E_OVERFLOW; }
+  SJ_TRY(ctx, hipMemcpyAsync(tape_out, ctx->d_doc, tw * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  if (sb) { SJ_TRY(ctx, hipMemcpyAsync(string_buf_out, ctx->d_doc + str_at, sb, hipMemcpyDeviceToHost, s)); }
+  SJ_TRY(ctx, hipStreamSynchronize(s));
+  if (tape_words_out) { *tape_words_out = tw; }
+  if (string_bytes_out) { *string_bytes_out = sb; }
+  return 0;
 }
 
 // ---- many small documents per launch (sjgpu_small.hip) -----------------------------------------------------------------------

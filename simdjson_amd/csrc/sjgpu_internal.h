@@ -185,6 +185,18 @@ struct strings_result_dev {
 size_t strings_scratch_bytes(uint32_t n);
 void launch_parse_strings(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
                           uint32_t *offsets, strings_result_dev *res, void *scratch, hipStream_t s);
+// ---- the tape (sjgpu_tape.hip) ----------------------------------------------------------------------------------
+struct tape_result_dev {
+  uint64_t error_key;   // smallest (list index << 8 | rank << 4 | error_code) over all offending tokens, ~0 = none (sj_tape_rules.h)
+  uint64_t tape_words;  // words of the finished tape (both root words included)
+  uint32_t slow_numbers; // number tokens that took the big-integer decision
+  uint32_t overflow;    // the caller's tape was too small
+};
+size_t tape_workspace_bytes(uint32_t n, uint64_t len);
+// stage 2 of buf[0..len) from its structural list idx[0..n] (idx[n] = len) and the string offsets launch_parse_strings left;
+// writes the reference's tape; workspace: tape_workspace_bytes(n, len), its first bytes are the tape_result_dev afterwards
+void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, const uint32_t *str_offsets, uint64_t *tape,
+                 uint64_t tape_cap, void *workspace, hipStream_t s);
 // in-place exclusive scan of a[0 .. *n_ptr) (n_max >= *n_ptr sizes the grid); partial: blocks_for(n_max, 4096) + 64 ints (sjgpu_finish.hip)
 void enqueue_scan(int *a, uint32_t n_max, const uint32_t *n_ptr, int *partial, hipStream_t s);
 

@@ -1214,3 +1214,132 @@ def test_rccl_world_size_one_smoke():
     ok, counts, total = q.get(timeout=300)
     p.join(timeout=60)
     assert ok, (counts, total)
+
+
+# ---- stage 2 on the device -- the DOM tape (sjgpu_tape.hip) -------------------------------------------------------------
+import jsongen
+
+
+@pytest.fixture(scope="module")
+def tape_parser():
+    build.build_sjgpu()
+    p = capi.DomParserImplementation(CAP)
+    yield p
+    p.close()
+
+
+def _checker_parse(orc, ref):
+    """the live reference's dom::parser::parse where its library travelled along, else the oracle's (pinned against it on the CPU tier)"""
+    if ref is not None:
+        impl = ref.best_impl()
+        return lambda d, md=1024: ref.dom_parse(impl, d, md)
+    return lambda d, md=1024: orc.dom_parse(d, md)
+
+
+def _assert_same_parse(p, want_parse, doc, max_depth=1024):
+    e_want, t_want, s_want = want_parse(doc, max_depth)
+    e_got, t_got, s_got = p.parse(doc, max_depth)
+    assert e_got == e_want, (bytes(doc[:200]), e_got, e_want)
+    if e_want == 0:
+        assert len(t_got) == len(t_want) and np.array_equal(t_got, t_want), (bytes(doc[:200]), first_diff(t_got, t_want))
+        assert bytes(s_got) == bytes(s_want), bytes(doc[:200])
+    return e_want
+
+
+@pytest.mark.parametrize("name", ["twitter.json", "citm_catalog.json"])
+def test_tape_of_the_reference_s_files(tape_parser, orc, ref, name):
+    """dom::parser::parse of the reference's own example files: doc.tape and doc.string_buf word for word"""
+    doc = np.fromfile(os.path.join(_paths.REPO_ROOT, "tests", "golden", "jsonexamples", name), dtype=np.uint8)
+    assert _assert_same_parse(tape_parser, _checker_parse(orc, ref), doc) == 0
+
+
+def test_tape_of_random_documents(tape_parser, orc, ref):
+    want = _checker_parse(orc, ref)
+    rng = np.random.default_rng(515)
+    for _ in range(1500):
+        assert _assert_same_parse(tape_parser, want, jsongen.random_document(rng)) == 0
+
+
+def test_tape_errors_are_the_reference_s(tape_parser, orc, ref):
+    """token-level mutations: the device finds the token the serial walk stops at (same error_code), without walking"""
+    want = _checker_parse(orc, ref)
+    rng = np.random.default_rng(616)
+    seen = {}
+    for _ in range(5000):
+        doc = jsongen.mutate(rng, jsongen.random_document(rng, max_depth=4))
+        if len(doc) == 0:
+            continue
+        e = _assert_same_parse(tape_parser, want, doc)
+        seen[e] = seen.get(e, 0) + 1
+    for code in (0, 3, 5, 6, 7, 8, 9, 10):
+        assert seen.get(code, 0) > 0, seen
+
+
+def test_tape_numbers(tape_parser, orc, ref):
+    """every corner-case number (rounding boundaries, subnormals, range limits, 800-digit texts) alone and inside containers; the valid
+    ones also as ONE array, so that the big-integer kernel sees many tokens at once"""
+    want = _checker_parse(orc, ref)
+    good = []
+    for text in jsongen.number_corner_cases():
+        t = text.encode()
+        e = _assert_same_parse(tape_parser, want, b"[" + t + b"]")
+        _assert_same_parse(tape_parser, want, t)
+        _assert_same_parse(tape_parser, want, b'{"k":' + t + b" }")
+        if e == 0:
+            good.append(t)
+    assert len(good) > 500
+    assert _assert_same_parse(tape_parser, want, b"[" + b",\n".join(good) + b"]") == 0
+
+
+def test_tape_depth_limits(tape_parser, orc, ref):
+    want = _checker_parse(orc, ref)
+    for max_depth in (1, 2, 3, 16, 1024):
+        for depth in (1, 2, 3, 15, 16, 17, 1023, 1024, 1025):
+            for inner in (b"", b"1", b"{}", b'{"a":[]}'):
+                _assert_same_parse(tape_parser, want, b"[" * depth + inner + b"]" * depth, max_depth)
+                _assert_same_parse(tape_parser, want, b'{"a":' * depth + (inner or b"0") + b"}" * depth, max_depth)
+    for doc in (b"[,]", b"[ ,1]", b'{"a":,}', b"[1,,2]", b'{"a":1,,}', b'{"a":1 "b":2}', b'{"a" "b"}', b'{"a"}', b"[1 2]", b"[}", b"{]", b"[1}", b'{"a":1]', b"]", b"}", b"[]]",
+                b"[[]", b"[[1]", b'{"a":{}', b"[", b"{", b'"a" "b"', b"1 2", b"[] []", b"nul", b"tru", b"fals", b"truex", b"[truex]", b"!", b"[!]", b"[1]x", b"x", b'{x:1}',
+                b"[:]", b"[1:2]", b'{"a"::1}', b'{,}', b'["\\q"]', b'{"\\q":1}', b'["a","\\ud800"]', b"[-]", b"[0123]", b"{}", b"[]", b"0", b'""', b"null"):
+        _assert_same_parse(tape_parser, want, doc)
+
+
+@pytest.mark.parametrize("kind", ["large_random", "twitter_like"])
+def test_tape_of_64_mib_documents(tape_parser, orc, ref, kind):
+    """tens of millions of tokens: every scan, both radix passes and the match at scale; compared word for word"""
+    a, _ = getattr(corpus, kind)(64 << 20, 2026)
+    assert _assert_same_parse(tape_parser, _checker_parse(orc, ref), a) == 0
+
+
+def test_tape_of_wide_and_deep_documents(tape_parser, orc, ref):
+    """a container with more than 0xFFFFFF members (saturating count, tape_builder.h:402-404), nesting at the limit, and a document
+    whose brackets span all 64 radix digits and more"""
+    want = _checker_parse(orc, ref)
+    n = 0xFFFFFF + 3
+    assert _assert_same_parse(tape_parser, want, b"[" + b"1," * (n - 1) + b"1]") == 0
+    rng = np.random.default_rng(5)
+    parts = []
+    for d in rng.integers(1, 900, 400):
+        parts.append(b"[" * int(d) + b'{"k":[1,2,{"z":null}]}' + b"]" * int(d))
+    assert _assert_same_parse(tape_parser, want, b"[" + b",".join(parts) + b"]") == 0
+
+
+def test_stage2_device_entry_point(tape_parser, orc, ref):
+    """the device-resident form: list and document stay in HBM, tape and string buffer are written there"""
+    import torch
+    want = _checker_parse(orc, ref)
+    a, _ = corpus.twitter_like(8 << 20, 99)
+    L = len(a)
+    buf = torch.from_numpy(a).cuda()
+    idx = torch.empty(L + 16, dtype=torch.int32, device="cuda")
+    tape = torch.empty(L + 8, dtype=torch.int64, device="cuda")
+    sbuf = torch.empty(5 * (L // 3) + 256, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert tape_parser.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, st) == 0
+    n, flags, _ = tape_parser.result(st)
+    assert flags == 0
+    err, tw, sb = tape_parser.stage2_device(buf.data_ptr(), L, idx.data_ptr(), n, tape.data_ptr(), L + 8, sbuf.data_ptr(), sbuf.numel(), 1024, st)
+    e_want, t_want, s_want = want(a)
+    assert (err, tw, sb) == (e_want, len(t_want), len(s_want))
+    assert np.array_equal(tape[:tw].cpu().numpy().view(np.uint64), t_want)
+    assert bytes(sbuf[:sb].cpu().numpy()) == bytes(s_want)
