@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 measured copy
 ALL_LEGS = ["config0_twitter_json", "config2_minify", "config2_validate_utf8", "config3_amazon_ndjson", "config4_deep_nesting",
-            "config4_escape_heavy", "plugin_host_path", "next_f3_parse_strings"]
+            "config4_escape_heavy", "plugin_host_path", "next_f3_parse_strings", "next_f3_tape"]
 
 
 def position_digest_host(words):
@@ -282,7 +282,11 @@ def leg_parse_strings(cx):
     gpu_ms = e0.elapsed_time(e1) / reps
     leg = {"workload": f"twitter_like {L} B, {n} structurals, {strings} strings -> {used} B of [u32 length][bytes][0] records (document::string_buf of the reference)",
            "gpu_ms_per_call": round(gpu_ms, 3), "value": round(L / gpu_ms / 1e6, 1), "unit": "GB/s of document",
-           "string_bytes_GBps": round(used / gpu_ms / 1e6, 1), "kernel": "k_str_measure + scan + k_str_write (one lane per structural)",
+           "string_bytes_GBps": round(used / gpu_ms / 1e6, 1), "kernel": "k_strings<false> + scan + k_strings<true>",
+           "roofline": {"bound": "hbm", "achieved": round((L + 4 * (n + 1) + used + 4 * (n + 1)) / gpu_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round((L + 4 * (n + 1) + used + 4 * (n + 1)) / gpu_ms / 1e6 / HBM_PEAK_GBS, 4),
+                        "algorithmic_bytes_per_launch": L + 4 * (n + 1) + used + 4 * (n + 1),
+                        "algorithmic_bytes": "document + list in, records + offsets out; the three kernels of one call together"},
            "note": "includes the 24-byte result read-back of every call; the list and the buffer stay on the device"}
     cpu = cx.cpu()
     if cpu.LIB_REF and os.path.exists(cpu.LIB_REF):
@@ -306,6 +310,78 @@ def leg_parse_strings(cx):
                                    "sample": f"{impl.decode()} kernel, parse_string over the same {strings} strings, 1 thread, best of 3 ({sec * 1e3:.1f} ms)"}
     p.close()
     return leg
+
+
+def leg_tape(cx):
+    """SURVEY 8(f3), stage 2 on the device: the reference's DOM tape (sjgpu_stage2_device: strings + tape) for resident documents, next to the
+    reference kernel's stage2() on one host core; tape and string buffer compared word for word with the reference's dom parse."""
+    import ctypes
+    torch, capi, corpus = cx.torch, cx.capi, cx.corpus
+    cpu = cx.cpu()
+    R = impl = None
+    if cpu.LIB_REF and os.path.exists(cpu.LIB_REF):
+        R = ctypes.CDLL(cpu.LIB_REF)
+        R.sjref_available.argtypes = [ctypes.c_char_p]
+        impl = next((i for i in (b"icelake", b"haswell", b"westmere") if R.sjref_available(i)), None)
+    out = {}
+    for kind in ("twitter_like", "large_random"):
+        host, _ = make_workload(corpus, kind, 256 << 20, 3000)
+        L = len(host)
+        p = capi.DomParserImplementation(L, device=cx.local_rank)
+        stream = torch.cuda.current_stream().cuda_stream
+        buf = torch.from_numpy(host).cuda()
+        idx = torch.empty(L + 16, dtype=torch.int32, device="cuda")
+        assert p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, stream) == 0
+        n, flags, _ = p.result(stream)
+        assert flags == 0
+        tape = torch.empty(L + 8, dtype=torch.int64, device="cuda")
+        scap = 5 * (L // 3) + 256
+        sbuf = torch.empty(scap, dtype=torch.uint8, device="cuda")
+        run = lambda: p.stage2_device(buf.data_ptr(), L, idx.data_ptr(), n, tape.data_ptr(), L + 8, sbuf.data_ptr(), scap, 1024, stream)
+        err, tw, sb = run()
+        if err != 0:
+            raise SystemExit(f"tape/{kind}: error {err} on the synthetic document")
+        reps = 8
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        gpu_ms = e0.elapsed_time(e1) / reps
+        alg = L + 4 * (n + 1) + 8 * tw + sb
+        leg = {"workload": f"{kind} {L} B, {n} structurals -> {tw} tape words + {sb} B of string records (dom::document of the reference)",
+               "gpu_ms_per_call": round(gpu_ms, 3), "value": round(L / gpu_ms / 1e6, 1), "unit": "GB/s of document",
+               "kernel": "k_strings x2 + k_tape_classify / select / radix x2 / match / write + 7 scans (sjgpu_tape.hip)",
+               "roofline": {"bound": "hbm", "achieved": round(alg / gpu_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / gpu_ms / 1e6 / HBM_PEAK_GBS, 4),
+                            "algorithmic_bytes_per_launch": alg,
+                            "algorithmic_bytes": "document + 4 (n + 1) list in, 8 tape words + string records out; all kernels of one sjgpu_stage2_device call together"},
+               "note": "includes the 48-byte result read-back of every call; document, list, tape and string buffer stay on the device"}
+        if impl:
+            R.sjref_dom_parse.restype = ctypes.c_int
+            R.sjref_dom_parse.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64),
+                                          ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
+            R.sjref_bench_stage2.restype = ctypes.c_double
+            R.sjref_bench_stage2.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+            padded = np.concatenate([host, np.zeros(128, np.uint8)])
+            rt = np.zeros(L + 72, dtype=np.uint64)
+            rs = np.zeros(scap + 64, dtype=np.uint8)
+            rtw, rsb = ctypes.c_uint64(0), ctypes.c_uint64(0)
+            rerr = R.sjref_dom_parse(impl, padded.ctypes.data, L, 1024, rt.ctypes.data, len(rt), ctypes.byref(rtw), rs.ctypes.data, len(rs), ctypes.byref(rsb))
+            same = rerr == 0 and rtw.value == tw and rsb.value == sb and bool((tape[:tw].cpu().numpy().view(np.uint64) == rt[:tw]).all()) and \
+                bool((sbuf[:sb].cpu().numpy() == rs[:sb]).all())
+            if not same:
+                raise SystemExit(f"PARITY FAILURE tape/{kind}: reference {rerr} / {rtw.value} words / {rsb.value} B vs {tw} / {sb}")
+            leg["parity"] = "doc.tape and doc.string_buf of the reference's dom::parser::parse, word for word"
+            cerr = ctypes.c_int(0)
+            sec = R.sjref_bench_stage2(impl, padded.ctypes.data, L, 2, ctypes.byref(cerr))
+            if sec > 0 and cerr.value == 0:
+                leg["cpu_baseline"] = {"value": round(L / sec / 1e9, 3), "unit": "GB/s of document", "cores": 1, "kind": "reference",
+                                       "sample": f"{impl.decode()} kernel, dom_parser_implementation::stage2 of the same document after one stage1, 1 thread, best of 2 ({sec * 1e3:.1f} ms)"}
+        p.close()
+        del buf, idx, tape, sbuf
+        out[kind] = leg
+    return out
 
 
 def leg_plugin_host_path(cx, host_large):
@@ -484,6 +560,7 @@ def main():
         guarded("plugin_host_path", lambda: leg_plugin_host_path(cx, host))
         del host
         guarded("next_f3_parse_strings", lambda: leg_parse_strings(cx))
+        guarded("next_f3_tape", lambda: leg_tape(cx))
 
         def ndjson():
             h, u = make_workload(corpus, "amazon_ndjson", args.size, 2000)
@@ -504,6 +581,7 @@ def main():
                 return device_leg(cx, "stage1", wl, h, u, sub_steps, sub_warm, args.pipeline, with_cpu=with_cpu, cpu_iters=4)
             guarded(f"config4_{wl}", adversarial)
         line["legs"] = legs
+        line["legs_failed"] = sorted(k for k, v in legs.items() if isinstance(v, dict) and "error" in v)  # a swallowed exception must be visible
 
     # ---- N > 1: BASELINE.json config 4 (parse_many-style NDJSON shards, RCCL concatenation) and the one-document path ----
     ndjson = docshards = None
