@@ -64,9 +64,18 @@ const device_list &listed_devices() noexcept {
   return *l;
 }
 
+// dom::parser::parse of documents of SJGPU_STAGE2_FROM_KB kilobytes and more (default 4096; 0 = never) runs stage 2 on the device as well
+// (sjgpu_parse: the structural list never crosses PCIe, the tape and the string buffer come back instead of it).  Shorter documents,
+// _number_as_string parsers and nesting limits beyond 4095 keep the reference's CPU stage 2.  Read when a parser is made.
+size_t device_stage2_from() noexcept {
+  size_t kb = 4096;
+  if (const char *v = std::getenv("SJGPU_STAGE2_FROM_KB")) { kb = size_t(std::strtoull(v, nullptr, 10)); }
+  return kb ? kb << 10 : ~size_t(0);
+}
+
 class dom_parser_implementation final : public internal::dom_parser_implementation {
 public:
-  dom_parser_implementation() noexcept = default;
+  dom_parser_implementation() noexcept : stage2_from_(device_stage2_from()) {}
   ~dom_parser_implementation() override {
     sjgpu_mgpu_destroy(mgpu_);
     sjgpu_ctx_destroy(ctx_);
@@ -74,6 +83,19 @@ public:
 
   // stage 1 on the GPU, then the reference's own stage 2 (src/haswell.cpp:159-163 shape)
   simdjson_warn_unused error_code parse(const uint8_t *buf, size_t len, dom::document &doc) noexcept final {
+    if (len >= stage2_from_ && ctx_ && !_number_as_string && _max_depth >= 1 && _max_depth <= 4095 && len <= _capacity && doc.capacity() >= len &&
+        doc.tape && doc.string_buf) {
+      // what dom::document::allocate reserved (include/simdjson/dom/document-inl.h:48-56)
+      const size_t cap = doc.capacity();
+      const size_t tape_words = SIMDJSON_ROUNDUP_N(cap + 3, 64), string_bytes = SIMDJSON_ROUNDUP_N(5 * (cap / 3) + SIMDJSON_PADDING, 64);
+      buf_ = buf;
+      len_ = len;
+      uint64_t tw = 0, sb = 0;
+      const int rc = sjgpu_parse(ctx_, buf, len, uint32_t(_max_depth), doc.tape.get(), tape_words, doc.string_buf.get(), string_bytes, &tw, &sb);
+      n_structural_indexes = 0; // the list stayed on the device
+      next_structural_index = 0;
+      return map_error(rc);
+    }
     auto error = stage1(buf, len, stage1_mode::regular);
     if (error) { return error; }
     return stage2(doc);
@@ -159,6 +181,7 @@ private:
   std::unique_ptr<internal::dom_parser_implementation> inner_{};
   const uint8_t *buf_ = nullptr;
   size_t len_ = 0;
+  size_t stage2_from_;
 };
 
 class implementation final : public simdjson::implementation {

@@ -7,6 +7,7 @@
 #include "mi355x_implementation.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -164,6 +165,54 @@ int main(int argc, char **argv) {
     CHECK(p.parse(badutf).error() == UTF8_ERROR, "bad utf8 -> UTF8_ERROR");
     CHECK(p.parse(ctrl).error() == UNESCAPED_CHARS, "ctrl -> UNESCAPED_CHARS");
     CHECK(p.parse(padded_string(std::string("   "))).error() == EMPTY, "blank -> EMPTY");
+  }
+
+  // 2b. the same with stage 2 on the device (SJGPU_STAGE2_FROM_KB, read when a parser is made): dom::document::tape and string_buf
+  //     word for word what the reference's kernel leaves, the same error_code on broken documents
+  {
+    setenv("SJGPU_STAGE2_FROM_KB", "1", 1);
+    padded_string ex_twitter, ex_citm;
+    CHECK(padded_string::load(examples + "/twitter.json").get(ex_twitter) == SUCCESS, "load twitter.json");
+    CHECK(padded_string::load(examples + "/citm_catalog.json").get(ex_citm) == SUCCESS, "load citm_catalog.json");
+    std::string pad(2000, ' ');
+    padded_string broken[] = {padded_string(pad + "[1,2,,3]"), padded_string(pad + "{\"a\":1 \"b\":2}"), padded_string(pad + "[1,2,3"), padded_string(pad + "[truee]"),
+                              padded_string(pad + "[\"\\q\"]"), padded_string(pad + "[12345678901234567890123]"), padded_string(pad + "[1e999]"), padded_string(pad + "[nul]"),
+                              padded_string(pad + "{\"a\":[1,2}"), padded_string(pad + "[1] 2"), padded_string(std::string(1500, '[') + std::string(1500, ']'))};
+    std::vector<const padded_string *> docs = {&twitter, &random, &ex_twitter, &ex_citm};
+    for (const padded_string &b : broken) { docs.push_back(&b); }
+    size_t compared = 0;
+    for (const padded_string *doc : docs) {
+      get_active_implementation() = cpu;
+      dom::parser pc;
+      const error_code ec = pc.parse(*doc).error();
+      get_active_implementation() = gpu;
+      dom::parser pg;
+      const error_code eg = pg.parse(*doc).error();
+      CHECK(ec == eg, "device stage 2: error %d, the reference %d (document of %zu bytes)", int(eg), int(ec), doc->size());
+      if (ec != SUCCESS) { continue; }
+      const uint64_t words = pc.doc.tape[0] & 0xFFFFFFFFFFFFFFull;
+      CHECK((pg.doc.tape[0] & 0xFFFFFFFFFFFFFFull) == words, "device stage 2: tape length");
+      CHECK(std::memcmp(pc.doc.tape.get(), pg.doc.tape.get(), words * 8) == 0, "device stage 2: tape words differ");
+      uint64_t used = 0;
+      for (uint64_t i = 1; i + 1 < words; i++) {
+        const uint64_t v = pc.doc.tape[i];
+        const char type = char(v >> 56);
+        if (type == '"') {
+          const uint64_t at = v & 0xFFFFFFFFFFFFFFull;
+          uint32_t l;
+          std::memcpy(&l, pc.doc.string_buf.get() + at, 4);
+          if (at + 5 + l > used) { used = at + 5 + l; }
+        } else if (type == 'l' || type == 'u' || type == 'd') {
+          i++;
+        }
+      }
+      CHECK(std::memcmp(pc.doc.string_buf.get(), pg.doc.string_buf.get(), used) == 0, "device stage 2: string buffers differ");
+      CHECK(pg.implementation->n_structural_indexes == 0, "the list should have stayed on the device");
+      compared++;
+    }
+    CHECK(compared == 4, "device stage 2: %zu valid documents compared", compared);
+    unsetenv("SJGPU_STAGE2_FROM_KB");
+    std::printf("dom::parser::parse with stage 2 on the device: 4 documents word for word, %zu broken ones by error code: OK\n", sizeof broken / sizeof broken[0]);
   }
 
   // 3. ondemand::parser::iterate (stage 1 only; lazy access over our index)
