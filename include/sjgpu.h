@@ -280,6 +280,28 @@ int sjgpu_mgpu_stage1(sjgpu_mgpu *m, const uint8_t *buf, size_t len, int mode, u
 int sjgpu_mgpu_minify(sjgpu_mgpu *m, const uint8_t *buf, size_t len, uint8_t *dst, size_t *dst_len);
 int sjgpu_mgpu_validate_utf8(sjgpu_mgpu *m, const uint8_t *buf, size_t len, int *ok);
 
+/* ---- the index concatenation across GPUs, one process per GPU (sjgpu_comm.hip) ------------------------------
+ * NDJSON / parse_many shards are scanned independently (no collective in the scan); the only exchange the path has is the
+ * variable-length gather of the per-shard structural lists to a consumer -- over RCCL / xGMI, device-resident in and out.
+ * Global position of a structural = byte base of its shard + its shard-relative offset, the reference's own convention for
+ * batches (include/simdjson/dom/document_stream-inl.h:250: batch_start + structural_indexes[i]).
+ *   sjgpu_comm_unique_id   rank 0 makes the 128-byte id and hands it to the other ranks by any means (file, socket, MPI,
+ *                          torch.distributed); sjgpu_comm_create is collective (ncclCommInitRank) and binds the rank to `device`.
+ *   sjgpu_comm_gather_indices  collective.  Every rank: idx_dev[0..n) shard-relative u32 offsets in HBM, base = byte offset of its
+ *                          shard.  ncclAllGather of (n, base), then every rank sends exactly n words to `root` (ncclSend / ncclRecv,
+ *                          all senders at once: xGMI is point to point), and the root writes base + offset as 64-bit words, shards
+ *                          in rank order, into out_dev[0 .. *total_out) (out_cap_words >= the sum; SJGPU_E_OVERFLOW otherwise, after
+ *                          the receives have drained).  counts_out (world entries, may be NULL): n of every rank.  Asynchronous on
+ *                          `stream` except for the 16 * world bytes of counts the host needs to size the receives. */
+typedef struct sjgpu_comm sjgpu_comm;
+#define SJGPU_COMM_ID_BYTES 128
+int sjgpu_comm_unique_id(void *id_out, size_t id_bytes);
+int sjgpu_comm_create(int rank, int world, const void *id, size_t id_bytes, int device, sjgpu_comm **out);
+void sjgpu_comm_destroy(sjgpu_comm *comm);
+const char *sjgpu_comm_last_error(const sjgpu_comm *comm);
+int sjgpu_comm_gather_indices(sjgpu_comm *comm, const void *idx_dev, uint32_t n, uint64_t base, int root, void *out_dev, size_t out_cap_words,
+                              uint64_t *total_out, uint64_t *counts_out, void *stream);
+
 /* ---- ranges of ONE resident buffer, one after the other (overlap the upload of batch k+1 with
  * the scan of batch k -- the GPU analogue of the reference's stage1_worker, dom/document_stream-inl.h:16-85).
  * Scans bytes [begin, end) of buf_dev; bytes [0, begin) must already be resident (escapes, the previous-scalar bit

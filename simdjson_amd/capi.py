@@ -29,7 +29,7 @@ EXPORTS = [
     "sjgpu_stage1_range_device", "sjgpu_minify_range_device",
     "sjgpu_host_alloc", "sjgpu_host_free", "sjgpu_host_register", "sjgpu_host_unregister", "sjgpu_last_pipeline",
     "sjgpu_profile_kernel", "sjgpu_debug_trace_pipelined", "sjgpu_stage1_many", "sjgpu_stage1_finish_device",
-    "sjgpu_depth_scan_device", "sjgpu_parse_strings_device", "sjgpu_stage2_device", "sjgpu_parse", "sjgpu_mgpu_create", "sjgpu_mgpu_destroy", "sjgpu_mgpu_count", "sjgpu_mgpu_stage1", "sjgpu_mgpu_minify",
+    "sjgpu_depth_scan_device", "sjgpu_parse_strings_device", "sjgpu_stage2_device", "sjgpu_parse", "sjgpu_comm_unique_id", "sjgpu_comm_create", "sjgpu_comm_destroy", "sjgpu_comm_last_error", "sjgpu_comm_gather_indices", "sjgpu_mgpu_create", "sjgpu_mgpu_destroy", "sjgpu_mgpu_count", "sjgpu_mgpu_stage1", "sjgpu_mgpu_minify",
     "sjgpu_mgpu_validate_utf8",
 ]
 
@@ -117,6 +117,16 @@ def load_library():
     L.sjgpu_stage2_device.argtypes = [vp, vp, sz, vp, ctypes.c_uint32, ctypes.c_uint32, vp, sz, vp, sz, vp, u64p, u64p]
     L.sjgpu_parse.restype = ctypes.c_int
     L.sjgpu_parse.argtypes = [vp, vp, sz, ctypes.c_uint32, vp, sz, vp, sz, u64p, u64p]
+    L.sjgpu_comm_unique_id.restype = ctypes.c_int
+    L.sjgpu_comm_unique_id.argtypes = [vp, sz]
+    L.sjgpu_comm_create.restype = ctypes.c_int
+    L.sjgpu_comm_create.argtypes = [ctypes.c_int, ctypes.c_int, vp, sz, ctypes.c_int, ctypes.POINTER(vp)]
+    L.sjgpu_comm_destroy.restype = None
+    L.sjgpu_comm_destroy.argtypes = [vp]
+    L.sjgpu_comm_last_error.restype = ctypes.c_char_p
+    L.sjgpu_comm_last_error.argtypes = [vp]
+    L.sjgpu_comm_gather_indices.restype = ctypes.c_int
+    L.sjgpu_comm_gather_indices.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, vp, sz, u64p, u64p, vp]
     L.sjgpu_mgpu_create.restype = ctypes.c_int
     L.sjgpu_mgpu_create.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(vp)]
     L.sjgpu_mgpu_destroy.restype = None
@@ -395,6 +405,46 @@ class DomParserImplementation:
         if rc != 0:
             raise SjgpuError(f"sjgpu_profile_read error {rc}: {self.last_error()}")
         return [float(x) for x in ms], int(calls.value)
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128 bytes rank 0 makes and hands to every other rank (sjgpu_comm_unique_id = ncclGetUniqueId)"""
+    L = load_library()
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    rc = L.sjgpu_comm_unique_id(buf, COMM_ID_BYTES)
+    if rc != 0:
+        raise SjgpuError(f"sjgpu_comm_unique_id error {rc}")
+    return bytes(buf.raw)
+
+
+class Comm:
+    """sjgpu_comm_*: the RCCL communicator of the index concatenation, one process per GPU (collective calls)."""
+
+    def __init__(self, rank, world, unique_id, device):
+        self.L = load_library()
+        self.h = ctypes.c_void_p()
+        self.rank, self.world = rank, world
+        rc = self.L.sjgpu_comm_create(rank, world, unique_id, len(unique_id), device, ctypes.byref(self.h))
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_comm_create error {rc}")
+
+    def close(self):
+        if self.h:
+            self.L.sjgpu_comm_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def gather_indices(self, idx_ptr, n, base, root, out_ptr, out_cap_words, stream=0):
+        """-> (total structurals, [n of every rank]); the root's out array holds base + offset as u64, shards in rank order"""
+        total = ctypes.c_uint64(0)
+        counts = (ctypes.c_uint64 * self.world)()
+        rc = self.L.sjgpu_comm_gather_indices(self.h, idx_ptr, int(n), int(base), int(root), out_ptr or None, int(out_cap_words), ctypes.byref(total), counts,
+                                              stream or None)
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_comm_gather_indices error {rc}: {self.L.sjgpu_comm_last_error(self.h).decode()}")
+        return int(total.value), [int(c) for c in counts]
 
 
 class MultiGpu:

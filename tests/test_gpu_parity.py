@@ -1343,3 +1343,30 @@ def test_stage2_device_entry_point(tape_parser, orc, ref):
     assert (err, tw, sb) == (e_want, len(t_want), len(s_want))
     assert np.array_equal(tape[:tw].cpu().numpy().view(np.uint64), t_want)
     assert bytes(sbuf[:sb].cpu().numpy()) == bytes(s_want)
+
+
+def test_comm_world_size_one(orc):
+    """sjgpu_comm_* (RCCL below the C-ABI): communicator of one rank -- ncclCommInitRank, the (n, base) all-gather, the root's own slot and
+    the widening kernel; the N > 1 sends need N devices (the driver's 8-GPU node) and are covered on the CPU by the gloo twin"""
+    import torch
+    a, _ = corpus.amazon_ndjson(4 << 20, 31)
+    L = len(a)
+    p = capi.DomParserImplementation(L)
+    buf = torch.from_numpy(a).cuda()
+    idx = torch.empty(L + 16, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, st) == 0
+    n, flags, _ = p.result(st)
+    assert flags == 0
+    comm = capi.Comm(0, 1, capi.comm_unique_id(), 0)
+    out = torch.zeros(n + 8, dtype=torch.int64, device="cuda")
+    base = 123456789012
+    total, counts = comm.gather_indices(idx.data_ptr(), n, base, 0, out.data_ptr(), out.numel(), st)
+    torch.cuda.synchronize()
+    assert (total, counts) == (n, [n])
+    want = orc.stage1(a, 0)[2][:n].astype(np.int64) + base
+    assert np.array_equal(out[:n].cpu().numpy(), want)
+    with pytest.raises(capi.SjgpuError):
+        comm.gather_indices(idx.data_ptr(), n, base, 0, out.data_ptr(), 4, st)  # too small: refused AFTER the exchange has drained
+    comm.close()
+    p.close()
