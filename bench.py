@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 measured copy
 ALL_LEGS = ["config0_twitter_json", "config2_minify", "config2_validate_utf8", "config3_amazon_ndjson", "config4_deep_nesting",
-            "config4_escape_heavy", "plugin_host_path", "next_f3_parse_strings", "next_f3_tape"]
+            "config4_escape_heavy", "plugin_host_path", "next_f2_finish_device", "next_f3_depth_scan", "next_f3_parse_strings", "next_f3_tape"]
 
 
 def position_digest_host(words):
@@ -312,6 +312,79 @@ def leg_parse_strings(cx):
     return leg
 
 
+def leg_list_passes(cx, which):
+    """the passes over the structural LIST on the device -- finish() of a streaming mode (document boundary search,
+    sjgpu_stage1_finish_device) and the nesting-depth scan (sjgpu_depth_scan_device) -- timed on the list of 1 GiB of amazon NDJSON, next to
+    the host walk that needs the list in host memory first (sjgpu_stage1_finish_host over a downloaded copy)."""
+    import ctypes
+    torch, capi, corpus = cx.torch, cx.capi, cx.corpus
+    host, _ = make_workload(corpus, "amazon_ndjson", cx.args.size, 2000)
+    L = len(host)
+    p = capi.DomParserImplementation(L, device=cx.local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    buf = torch.from_numpy(host).cuda()
+    idx = torch.empty(L + 16, dtype=torch.int32, device="cuda")
+    assert p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, stream) == 0
+    n, flags, _ = p.result(stream)
+    keep = idx[: n + 3].clone()
+    reps = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if which == "depth":
+        depth = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+        p.depth_scan_device(buf.data_ptr(), idx.data_ptr(), n, depth.data_ptr(), stream)
+        e0.record()
+        for _ in range(reps):
+            p.depth_scan_device(buf.data_ptr(), idx.data_ptr(), n, depth.data_ptr(), stream)
+        e1.record()
+        torch.cuda.synchronize()
+        gpu_ms = e0.elapsed_time(e1) / reps
+        alg = 4 * n + n + 4 * (n + 1)  # list in, one byte of the document per structural, depths out
+        final_depth = int(depth[n].item())
+        leg = {"workload": f"amazon_ndjson {L} B: {n} structurals -> int32 depth in front of every structural (final depth {final_depth})",
+               "gpu_ms_per_call": round(gpu_ms, 4), "value": round(n / gpu_ms / 1e6, 2), "unit": "G structurals/s",
+               "kernel": "k_bracket_delta + k_scan_blocks + k_scan_partials + k_scan_add",
+               "roofline": {"bound": "hbm", "achieved": round(alg / gpu_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / gpu_ms / 1e6 / HBM_PEAK_GBS, 4),
+                            "algorithmic_bytes_per_launch": alg, "algorithmic_bytes": "4 B of list + 1 B of document in, 4 B of depth out, per structural"}}
+        hidx = keep[:n].cpu().numpy().view(np.uint32)
+        t0 = time.perf_counter()
+        c = host[hidx]
+        d = np.cumsum((c == ord("{")).astype(np.int32) + (c == ord("[")) - (c == ord("}")) - (c == ord("]")))
+        leg["cpu_baseline"] = {"value": round(n / (time.perf_counter() - t0) / 1e9, 3), "unit": "G structurals/s", "cores": 1, "kind": "port",
+                               "sample": "numpy gather + cumsum over the same list on one host core (the reference carries the depth inside its serial stage-2 walk)"}
+        assert int(d[-1]) == final_depth
+    else:
+        mode = capi.STREAMING_FINAL
+        err, n_kept, nxt = p.stage1_finish_device(buf.data_ptr(), L, mode, idx.data_ptr(), n, flags, stream)
+        times = []
+        for _ in range(reps):
+            idx[: n + 3].copy_(keep)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            err, n_kept, nxt = p.stage1_finish_device(buf.data_ptr(), L, mode, idx.data_ptr(), n, flags, stream)  # waits for its 64-byte state
+            times.append(time.perf_counter() - t0)
+        gpu_ms = min(times) * 1e3
+        alg = 4 * n + n
+        leg = {"workload": f"amazon_ndjson {L} B: finish(streaming_final) over {n} structurals on the device -> error {err}, {n_kept} kept",
+               "ms_per_call": round(gpu_ms, 4), "value": round(n / gpu_ms / 1e6, 2), "unit": "G structurals/s",
+               "kernel": "k_last_boundary + k_tail_balance + k_resolve_prefix (+ one 64-byte read-back: host clock around the call)",
+               "roofline": {"bound": "hbm", "achieved": round(alg / gpu_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / gpu_ms / 1e6 / HBM_PEAK_GBS, 4),
+                            "algorithmic_bytes_per_launch": alg, "algorithmic_bytes": "4 B of list + 1 B of document per structural, two passes folded into one count"}}
+        L_ = capi.load_library()
+        hidx = np.zeros(n + 16, dtype=np.uint32)
+        t0 = time.perf_counter()
+        hidx[: n + 3] = keep.cpu().numpy().view(np.uint32)  # the host walk needs the list at home first
+        t_copy = time.perf_counter() - t0
+        n_io, nx = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        t0 = time.perf_counter()
+        herr = L_.sjgpu_stage1_finish_host(host.ctypes.data, L, mode, hidx.ctypes.data, n, flags, ctypes.byref(n_io), ctypes.byref(nx))
+        t_walk = time.perf_counter() - t0
+        assert (herr, n_io.value) == (err, n_kept), (herr, n_io.value, err, n_kept)
+        leg["host_finish"] = {"download_ms": round(t_copy * 1e3, 2), "walk_ms": round(t_walk * 1e3, 4),
+                              "note": "sjgpu_stage1_finish_host (the reference's backward walk) is O(last document) once the list is in host memory; bringing it there is the cost"}
+    p.close()
+    return leg
+
+
 def leg_tape(cx):
     """SURVEY 8(f3), stage 2 on the device: the reference's DOM tape (sjgpu_stage2_device: strings + tape) for resident documents, next to the
     reference kernel's stage2() on one host core; tape and string buffer compared word for word with the reference's dom parse."""
@@ -439,9 +512,15 @@ def leg_plugin_host_path(cx, host_large):
     lines = [bytes(l) for l in bytes(nd[: 4 << 20]).split(b"\n") if l][:8192]
     r = capi.DomParserImplementation(1 << 20, device=cx.local_rank)
     r.stage1_many(lines[:64])
-    t0 = time.perf_counter()
     res = r.stage1_many(lines)
-    dt_many = time.perf_counter() - t0
+    prepared = r.prepare_many(lines)  # the sjgpu_doc array built once: what follows times libsjgpu, not ctypes marshalling
+    r.stage1_many_prepared(prepared)
+    dt_many = 1e9
+    for _ in range(5):
+        t0 = time.perf_counter()
+        done = r.stage1_many_prepared(prepared)
+        dt_many = min(dt_many, time.perf_counter() - t0)
+    assert all(int(d.error) == 0 and int(d.n) == n0 for d, (_, n0, _) in zip(done, res))
     t0 = time.perf_counter()
     for l in lines[:512]:
         r.stage1(l, capi.REGULAR)
@@ -452,7 +531,8 @@ def leg_plugin_host_path(cx, host_large):
     out["small_documents"] = {"documents": len(lines), "mean_bytes": round(nbytes / len(lines), 1),
                               "one_launch_us_per_document": round(dt_many / len(lines) * 1e6, 3), "one_launch_GBps": round(nbytes / dt_many / 1e9, 3),
                               "one_call_each_us_per_document": round(dt_single * 1e6, 2),
-                              "note": "sjgpu_stage1_many (one workgroup per document, one launch, incl. the Python-side marshalling) vs sjgpu_stage1 per document"}
+                              "note": "sjgpu_stage1_many (one workgroup per document, ONE launch; the C call alone, its sjgpu_doc array marshalled beforehand: gather into the "
+                                      "page-locked block, launch, wait, scatter of the lists) vs one sjgpu_stage1 call per document"}
     return out
 
 
@@ -565,6 +645,8 @@ def main():
         guarded("config2_validate_utf8", lambda: device_leg(cx, "validate_utf8", "large_random", host, units, sub_steps, sub_warm, args.pipeline, with_cpu=with_cpu))
         guarded("plugin_host_path", lambda: leg_plugin_host_path(cx, host))
         del host
+        guarded("next_f2_finish_device", lambda: leg_list_passes(cx, "finish"))
+        guarded("next_f3_depth_scan", lambda: leg_list_passes(cx, "depth"))
         guarded("next_f3_parse_strings", lambda: leg_parse_strings(cx))
         guarded("next_f3_tape", lambda: leg_tape(cx))
 

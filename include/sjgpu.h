@@ -73,6 +73,10 @@ int sjgpu_device_count(void); /* number of usable HIP devices, 0 if none */
 int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out);
 void sjgpu_ctx_destroy(sjgpu_ctx *ctx);
 int sjgpu_set_capacity(sjgpu_ctx *ctx, size_t capacity);
+/* sjgpu_ctx_destroy PARKS a context (its stream, page-locked blocks and small workspaces are reused by the next
+ * sjgpu_ctx_create on that device: the reference's tests make 100 000 parsers); up to 64 stay parked.  sjgpu_pool_trim frees
+ * them all and returns how many there were -- for orderly shutdown, or to get the memory back. */
+int sjgpu_pool_trim(void);
 size_t sjgpu_capacity(const sjgpu_ctx *ctx);
 const char *sjgpu_last_error(const sjgpu_ctx *ctx); /* text of the last HIP failure ("" if none) */
 
@@ -194,6 +198,9 @@ int sjgpu_stage1_many(sjgpu_ctx *ctx, sjgpu_doc *docs, size_t count);
  * sjgpu_depth_scan_device: depth_dev[i] (int32, n + 1 entries) = number of containers open in front of structural i --
  * the `depth` the reference's stage 2 carries while it walks the list (src/generic/stage2/json_iterator.h), as a
  * bracket prefix scan; depth_dev[n] = depth behind the last structural (0 for a balanced document).  Asynchronous. */
+/* The list passes (finish, depth scan, strings, stage 2, the staged form of sjgpu_stage1_many) share per-context scratch memory that grows on
+ * demand: calls on ONE context must be ordered on one stream (or separated by a wait) -- two of them in flight on different
+ * streams would use the same scratch.  Use one context per concurrent pipeline, as the reference uses one parser per thread. */
 int sjgpu_stage1_finish_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, int mode, void *idx_dev, uint32_t n_raw,
                                uint32_t flags, void *stream, uint32_t *n_io, uint32_t *next_start_out);
 int sjgpu_depth_scan_device(sjgpu_ctx *ctx, const void *buf_dev, const void *idx_dev, uint32_t n, void *depth_dev, void *stream);

@@ -158,7 +158,7 @@ def build_reference_tests(force=False):
                   "-I", os.path.join(ref, "tests", "dom"), "-I", os.path.join(ref, "tests", "ondemand"),
                   "-I", os.path.join(_paths.CSRC_DIR, "plugin"), "-I", _paths.INCLUDE_DIR,
                   # data files come from the committed fixtures: /root/repo/... exists here AND on the GPU box (symlink)
-                  '-DSIMDJSON_BENCHMARK_DATA_DIR="/root/repo/tests/golden/jsonexamples/"',
+                  '-DSIMDJSON_BENCHMARK_DATA_DIR="tests/golden/jsonexamples/"',
                   src, act, ref_obj, "-o", out, f"-L{_paths.LIB_DIR}", "-lsimdjson_mi355x", "-lsjgpu", "-lpthread",
                   _RPATH])
             _write_stamp(name)
@@ -202,7 +202,7 @@ def build_intree(force=False):
             os.makedirs(TEST_BIN_DIR, exist_ok=True)
             _run(["g++", "-O1", "-std=c++17", "-w", "-DSIMDJSON_THREADS_ENABLED=1", "-DSIMDJSON_IMPLEMENTATION_MI355X=1", "-I", os.path.join(tree, "include"),
                   "-I", os.path.join(ref, "tests"), "-I", os.path.join(ref, "tests", "dom"),
-                  '-DSIMDJSON_BENCHMARK_DATA_DIR="/root/repo/tests/golden/jsonexamples/"', src, obj, "-o", out,
+                  '-DSIMDJSON_BENCHMARK_DATA_DIR="tests/golden/jsonexamples/"', src, obj, "-o", out,
                   f"-L{_paths.LIB_DIR}", "-lsimdjson_mi355x", "-lsjgpu", "-lpthread", _RPATH])
             _write_stamp(name)
         built.append(out)

@@ -29,7 +29,7 @@ EXPORTS = [
     "sjgpu_stage1_range_device", "sjgpu_minify_range_device",
     "sjgpu_host_alloc", "sjgpu_host_free", "sjgpu_host_register", "sjgpu_host_unregister", "sjgpu_last_pipeline",
     "sjgpu_profile_kernel", "sjgpu_debug_trace_pipelined", "sjgpu_stage1_many", "sjgpu_stage1_finish_device",
-    "sjgpu_depth_scan_device", "sjgpu_parse_strings_device", "sjgpu_stage2_device", "sjgpu_parse", "sjgpu_comm_unique_id", "sjgpu_comm_create", "sjgpu_comm_destroy", "sjgpu_comm_last_error", "sjgpu_comm_gather_indices", "sjgpu_mgpu_create", "sjgpu_mgpu_destroy", "sjgpu_mgpu_count", "sjgpu_mgpu_stage1", "sjgpu_mgpu_minify",
+    "sjgpu_depth_scan_device", "sjgpu_parse_strings_device", "sjgpu_stage2_device", "sjgpu_parse", "sjgpu_pool_trim", "sjgpu_comm_unique_id", "sjgpu_comm_create", "sjgpu_comm_destroy", "sjgpu_comm_last_error", "sjgpu_comm_gather_indices", "sjgpu_mgpu_create", "sjgpu_mgpu_destroy", "sjgpu_mgpu_count", "sjgpu_mgpu_stage1", "sjgpu_mgpu_minify",
     "sjgpu_mgpu_validate_utf8",
 ]
 
@@ -315,6 +315,28 @@ class DomParserImplementation:
         if rc != 0:
             raise SjgpuError(f"sjgpu_stage1_many error {rc}: {self.last_error()}")
         return [(int(d.error), int(d.n), o[: d.n + 3].copy()) for d, o in zip(docs, outs)]
+
+    def prepare_many(self, documents):
+        """The sjgpu_doc array of a batch, marshalled ONCE: (docs, arrays, outs).  stage1_many_prepared then times the library, not ctypes."""
+        arrays = [_as_u8(d) for d in documents]
+        total = sum(len(a) + 3 for a in arrays)
+        pool = np.zeros(total, dtype=np.uint32)  # one allocation for all lists
+        docs = (Doc * len(arrays))()
+        at = 0
+        outs = []
+        for k, a in enumerate(arrays):
+            o = pool[at: at + len(a) + 3]
+            at += len(a) + 3
+            outs.append(o)
+            docs[k] = Doc(a.ctypes.data if len(a) else 1, len(a), o.ctypes.data, len(o), 0, 0)
+        return docs, arrays, outs
+
+    def stage1_many_prepared(self, prepared):
+        docs = prepared[0]
+        rc = self.L.sjgpu_stage1_many(self.h, docs, len(docs))
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_stage1_many error {rc}: {self.last_error()}")
+        return docs
 
     # ---- the structural list after the scan, on the device ----
     def stage1_finish_device(self, buf_ptr, length, mode, idx_ptr, n_raw, flags, stream=0):

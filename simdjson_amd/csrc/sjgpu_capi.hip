@@ -231,20 +231,27 @@ size_t grown(size_t want) {
 }
 // what a scan of `len` bytes needs; split: the masks / summaries of the split pipeline too
 int ensure_scan_workspace(sjgpu_ctx *ctx, size_t len, bool split) {
-  if (ctx->ws_capacity >= len && ctx->d_result && (!split || ctx->masks)) { return 0; }
+  if (ctx->ws_capacity >= len && ctx->d_result && (!split || (ctx->masks && ctx->summ && ctx->pref))) { return 0; }
   if (ctx->stream) { SJ_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
   const size_t cap = ctx->ws_capacity >= len ? ctx->ws_capacity : grown(len);
   if (cap != ctx->ws_capacity || !ctx->d_result) {
     release_scan_workspace(ctx);
     const int rc = alloc_result(ctx, cap);
-    if (rc) { return rc; }
+    if (rc) { release_scan_workspace(ctx); return rc; }
     ctx->ws_capacity = cap;
   }
-  if (split && !ctx->masks) {
+  if (split && !(ctx->masks && ctx->summ && ctx->pref)) {
     const size_t nseg = num_segments(cap);
-    SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->masks), nseg * (SEG_BYTES / BLOCK_BYTES) * sizeof(uint4)));
-    SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->summ), (nseg + num_groups(cap)) * sizeof(seg_summary)));
-    SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->pref), nseg * sizeof(seg_prefix)));
+    dev_free(ctx->masks); // all three or none: a later call must never meet half a workspace
+    dev_free(ctx->summ);
+    dev_free(ctx->pref);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->masks), nseg * (SEG_BYTES / BLOCK_BYTES) * sizeof(uint4));
+    if (e == hipSuccess) { e = hipMalloc(reinterpret_cast<void **>(&ctx->summ), (nseg + num_groups(cap)) * sizeof(seg_summary)); }
+    if (e == hipSuccess) { e = hipMalloc(reinterpret_cast<void **>(&ctx->pref), nseg * sizeof(seg_prefix)); }
+    if (e != hipSuccess) {
+      release_scan_workspace(ctx);
+      return fail(ctx, e, "scan workspace");
+    }
   }
   return 0;
 }
@@ -503,8 +510,16 @@ int sjgpu_host_unregister(void *p) {
 namespace {
 constexpr size_t POOL_MAX = 64;                          // parked contexts per process
 constexpr size_t POOL_KEEP_BYTES = size_t(32) << 20;     // workspace / staging for documents beyond this is freed on parking
-std::mutex g_pool_m;
-std::vector<sjgpu_ctx *> g_pool;
+// The pool and its lock are heap objects that are never destroyed: a context may be parked from a static destructor of the
+// caller, or after this library's own statics would have been torn down.
+struct ctx_pool {
+  std::mutex m;
+  std::vector<sjgpu_ctx *> parked;
+};
+ctx_pool &pool() {
+  static ctx_pool *p = new ctx_pool();
+  return *p;
+}
 
 void apply_environment(sjgpu_ctx *ctx) {
   ctx->pipeline = 2;
@@ -563,11 +578,12 @@ extern "C" int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) { return SJGPU_E_NO_DEVICE; }
   sjgpu_ctx *ctx = nullptr;
   {
-    std::lock_guard<std::mutex> lk(g_pool_m);
-    for (size_t i = g_pool.size(); i-- > 0;) {
-      if (g_pool[i]->device == device) {
-        ctx = g_pool[i];
-        g_pool.erase(g_pool.begin() + long(i));
+    ctx_pool &pl = pool();
+    std::lock_guard<std::mutex> lk(pl.m);
+    for (size_t i = pl.parked.size(); i-- > 0;) {
+      if (pl.parked[i]->device == device) {
+        ctx = pl.parked[i];
+        pl.parked.erase(pl.parked.begin() + long(i));
         break;
       }
     }
@@ -627,13 +643,27 @@ extern "C" void sjgpu_ctx_destroy(sjgpu_ctx *ctx) {
     ctx->h_small_bytes = 0;
   }
   {
-    std::lock_guard<std::mutex> lk(g_pool_m);
-    if (g_pool.size() < POOL_MAX) {
-      g_pool.push_back(ctx);
+    ctx_pool &pl = pool();
+    std::lock_guard<std::mutex> lk(pl.m);
+    if (pl.parked.size() < POOL_MAX) {
+      pl.parked.push_back(ctx);
       return;
     }
   }
   really_destroy(ctx);
+}
+
+// Gives back what the parked contexts hold (streams, page-locked blocks, device workspace, copy threads): for callers that have
+// destroyed every parser and want the memory, or shut the library down in an orderly way.  Returns the number of contexts freed.
+extern "C" int sjgpu_pool_trim(void) {
+  std::vector<sjgpu_ctx *> victims;
+  {
+    ctx_pool &pl = pool();
+    std::lock_guard<std::mutex> lk(pl.m);
+    victims.swap(pl.parked);
+  }
+  for (sjgpu_ctx *c : victims) { really_destroy(c); }
+  return int(victims.size());
 }
 
 extern "C" int sjgpu_set_capacity(sjgpu_ctx *ctx, size_t capacity) {

@@ -6,9 +6,11 @@
 // so each device uploads its own shard and downloads its own offsets straight into their final place in the caller's
 // array -- G links in parallel instead of one (the host-buffer path of one GPU is PCIe-bound: 25-50 GB/s).
 // The only thing that crosses between shards is ONE BIT per shard, exchanged through host memory between two phases:
-//   phase A  upload shard g to device g, count its unescaped quotes (sjgpu_string_parity_device)
+//   phase A  upload shard g to device g and scan it as if it began OUTSIDE a string (sjgpu_stage1_shard_device /
+//            sjgpu_minify_shard_device with carry 0).  Whether it ENDS inside one is its quote parity, whatever its true carry-in.
 //   -------  in_string(g) = XOR of the parities of the shards in front (host)
-//   phase B  scan shard g with that carry-in (sjgpu_stage1_shard_device / sjgpu_minify_shard_device)
+//   phase B  only the shards whose true carry-in is 1 are scanned again, from HBM (a clean cut sits behind whitespace or an
+//            operator, so that is the rare case: one read of every byte per device instead of the two a parity pre-pass cost)
 //   -------  output offset(g) = sum of the counts in front (host)
 //   phase C  stage 1: add the shard's byte offset to its offsets on the device; download into idx_out + offset(g)
 // Shards are cut with sjgpu_clean_cut (the byte in front of a cut is ASCII whitespace or , : [ ] { }), so escapes, the
@@ -50,6 +52,21 @@ struct rendezvous { // reusable barrier for the shard threads of one call
     } else {
       cv.wait(lk, [&] { return generation != gen; });
     }
+  }
+};
+
+struct start_gate { // shard threads wait here until ALL of them exist (or are told that they never will)
+  std::mutex m;
+  std::condition_variable cv;
+  int state = 0; // 0 closed, 1 go, 2 cancelled
+  void open(bool go) {
+    { std::lock_guard<std::mutex> lk(m); state = go ? 1 : 2; }
+    cv.notify_all();
+  }
+  bool pass() {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return state != 0; });
+    return state == 1;
   }
 };
 
@@ -104,6 +121,7 @@ int run_shards(sjgpu_mgpu *m, int op, const uint8_t *buf, size_t len, void *out_
   }
   rendezvous meet;
   meet.parties = unsigned(G);
+  start_gate gate;
   auto work = [&](size_t g) {
     shard_dev &d = m->devs[g];
     shard_job &j = jobs[g];
@@ -111,17 +129,23 @@ int run_shards(sjgpu_mgpu *m, int op, const uint8_t *buf, size_t len, void *out_
     auto fail = [&](int rc) { j.rc = rc; };
     bool ok = hipSetDevice(d.device) == hipSuccess;
     if (!ok) { fail(SJGPU_E_HIP); }
-    // ---- phase A: upload, quote parity
+    if (!gate.pass()) { return; } // a thread could not be started: nobody works, nobody waits
+    auto scan = [&](int carry) {
+      int rc = op == 0 ? sjgpu_stage1_shard_device(d.ctx, d.d_in, n, carry, d.d_out, n + 3, d.stream)
+                       : sjgpu_minify_shard_device(d.ctx, d.d_in, n, carry, d.d_out, d.stream);
+      if (!rc) { rc = sjgpu_result(d.ctx, d.stream, &j.res); }
+      if (!rc && (j.res.flags & (SJGPU_F_INTERNAL | SJGPU_F_IDX_OVERFLOW))) { rc = 24; }
+      return rc;
+    };
+    // ---- phase A: upload, scan as if the shard began outside a string
     if (ok && n) {
       int rc = grow(reinterpret_cast<void **>(&d.d_in), &d.d_in_bytes, n + 64);
       if (!rc) { rc = grow(reinterpret_cast<void **>(&d.d_out), &d.d_out_bytes, op == 0 ? (n + 16) * sizeof(uint32_t) : n + 64); }
       if (!rc && sjgpu_capacity(d.ctx) < n) { rc = sjgpu_set_capacity(d.ctx, n); }
       if (!rc && hipMemcpyAsync(d.d_in, buf + j.lo, n, hipMemcpyHostToDevice, d.stream) != hipSuccess) { rc = SJGPU_E_HIP; }
-      if (!rc) { rc = sjgpu_string_parity_device(d.ctx, d.d_in, n, d.stream); }
-      sjgpu_scan_result r{0, 0, 0};
-      if (!rc) { rc = sjgpu_result(d.ctx, d.stream, &r); }
+      if (!rc) { rc = scan(0); }
       if (rc) { fail(rc); ok = false; }
-      j.parity = r.n & 1u;
+      j.parity = (j.res.flags & SJGPU_F_UNCLOSED_STRING) ? 1u : 0u; // begins outside, ends inside <=> an odd number of quotes
     }
     meet.arrive();
     if (g == 0) { // one thread folds the bits (the others wait at the next rendezvous)
@@ -132,12 +156,9 @@ int run_shards(sjgpu_mgpu *m, int op, const uint8_t *buf, size_t len, void *out_
       }
     }
     meet.arrive();
-    // ---- phase B: the scan with the carried in-string bit
-    if (ok && n && j.rc == 0) {
-      int rc = op == 0 ? sjgpu_stage1_shard_device(d.ctx, d.d_in, n, int(j.carry), d.d_out, n + 3, d.stream)
-                       : sjgpu_minify_shard_device(d.ctx, d.d_in, n, int(j.carry), d.d_out, d.stream);
-      if (!rc) { rc = sjgpu_result(d.ctx, d.stream, &j.res); }
-      if (!rc && (j.res.flags & (SJGPU_F_INTERNAL | SJGPU_F_IDX_OVERFLOW))) { rc = 24; }
+    // ---- phase B: a shard that really begins inside a string is scanned again (resident: no second upload)
+    if (ok && n && j.rc == 0 && j.carry) {
+      const int rc = scan(1);
       if (rc) { fail(rc); ok = false; }
     } else if (n == 0) {
       j.res.flags = j.carry ? SJGPU_F_UNCLOSED_STRING : 0u; // an empty shard passes the state through
@@ -169,9 +190,17 @@ int run_shards(sjgpu_mgpu *m, int op, const uint8_t *buf, size_t len, void *out_
     }
   };
   std::vector<std::thread> threads;
-  for (size_t g = 1; g < G; g++) { threads.emplace_back(work, g); }
-  work(0);
+  bool started = true;
+  try {
+    threads.reserve(G);
+    for (size_t g = 1; g < G; g++) { threads.emplace_back(work, g); }
+  } catch (...) { // out of threads: the ones that exist would wait for ever at the first rendezvous -- send them home instead
+    started = false;
+  }
+  gate.open(started);
+  if (started) { work(0); }
   for (std::thread &t : threads) { t.join(); }
+  if (!started) { return SJGPU_E_NOMEM; }
   for (const shard_job &j : jobs) {
     if (j.rc) { return j.rc; }
   }
@@ -279,8 +308,14 @@ int sjgpu_mgpu_validate_utf8(sjgpu_mgpu *m, const uint8_t *buf, size_t len, int 
     if (n) { rcs[g] = sjgpu_validate_utf8(m->devs[g].ctx, buf + cuts[g], n, &verdict[g]); } // pieces / overlapped upload inside
   };
   std::vector<std::thread> threads;
-  for (size_t g = 1; g < G; g++) { threads.emplace_back(work, g); }
+  size_t launched = 1;
+  try {
+    threads.reserve(G);
+    for (size_t g = 1; g < G; g++) { threads.emplace_back(work, g); launched = g + 1; }
+  } catch (...) {
+  }
   work(0);
+  for (size_t g = launched; g < G; g++) { work(g); } // shards whose thread could not be started: on this one (no rendezvous here)
   for (std::thread &t : threads) { t.join(); }
   for (size_t g = 0; g < G; g++) {
     if (rcs[g]) { return rcs[g]; }

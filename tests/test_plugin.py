@@ -58,7 +58,7 @@ def test_reference_own_test_programs_on_mi355x(name):
     built = {os.path.basename(p): p for p in build.build_reference_tests()}
     assert name in built, f"{name} was not built (needs the build container)"
     assert build.binary_is_current(name), f"build/tests/{name} is stale (sources changed since it was built)"
-    out = subprocess.run([built[name]], capture_output=True, text=True, timeout=1200)
+    out = subprocess.run([built[name]], capture_output=True, text=True, timeout=1200, cwd=_paths.REPO_ROOT)  # the data directory is compiled in relative to the checkout
     tail = (out.stdout[-2500:] + out.stderr[-1500:])
     assert out.returncode == 0, tail
     assert "[active implementation: mi355x]" in out.stderr, tail
@@ -82,10 +82,10 @@ def test_intree_registration_keeps_the_cpu_kernels_and_lists_mi355x():
     parser creation answers UNSUPPORTED_ARCHITECTURE -- no abort, no CPU stand-in."""
     import torch
     exe = _intree("intree_basictests")
-    out = subprocess.run([exe, "-a", "haswell"], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([exe, "-a", "haswell"], capture_output=True, text=True, timeout=600, cwd=_paths.REPO_ROOT)
     assert out.returncode == 0 and "Basic tests are ok." in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
     if not torch.cuda.is_available():
-        out = subprocess.run([exe, "-a", "mi355x"], capture_output=True, text=True, timeout=600)
+        out = subprocess.run([exe, "-a", "mi355x"], capture_output=True, text=True, timeout=600, cwd=_paths.REPO_ROOT)
         assert "Unsupported architecture value" not in out.stderr
         assert "Running tests against this implementation: mi355x" in out.stdout
         assert out.returncode != 0 and "UNSUPPORTED_ARCHITECTURE" in (out.stdout + out.stderr)
@@ -104,7 +104,7 @@ def test_intree_reference_tests_select_mi355x_by_name(name, how):
         args += ["-a", "mi355x"]
     else:
         env["SIMDJSON_FORCE_IMPLEMENTATION"] = "mi355x"
-    out = subprocess.run(args, capture_output=True, text=True, timeout=900, env=env)
+    out = subprocess.run(args, capture_output=True, text=True, timeout=900, env=env, cwd=_paths.REPO_ROOT)
     tail = out.stdout[-2500:] + out.stderr[-1500:]
     assert out.returncode == 0, tail
     if name == "intree_basictests":
