@@ -223,6 +223,17 @@ int sjgpu_parse_strings_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
                                void *string_buf_dev, size_t string_buf_bytes, void *offsets_dev, void *stream, uint64_t *bytes_out,
                                uint32_t *strings_out, uint32_t *first_bad_out);
 
+/* ---- On-Demand's raw key comparison, every key of a resident document at once -----------------------------
+ * ondemand's object lookup (value_iterator::find_field_raw, include/simdjson/generic/ondemand/value_iterator-inl.h:132, :229) walks
+ * the fields of an object and compares each key's RAW bytes -- escapes not resolved -- with the wanted name:
+ * raw_json_string::unsafe_is_equal(length, target) (raw_json_string-inl.h:66-69).  Here for ALL keys of the list and K wanted names
+ * in one pass: match_dev[i] (n words) = index of the first name equal to structural i if that structural is a key (a string whose
+ * next structural is ':'), 0xFFFFFFFF otherwise.  names: K byte strings back to back (host memory), name_lens[k] their lengths
+ * (K <= 256, 64 KiB in total).  idx_dev[0..n] as sjgpu_stage1_device left it, first sentinel included.  *matches_out = keys that
+ * matched.  Waits for the stream (reads 4 bytes back). */
+int sjgpu_match_keys_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const void *idx_dev, uint32_t n, const uint8_t *names, const uint32_t *name_lens,
+                            uint32_t K, void *match_dev, void *stream, uint32_t *matches_out);
+
 /* ---- stage 2 of a resident document: the DOM tape --------------------------------------------------------
  * What dom_parser_implementation::stage2(dom::document &) (include/simdjson/internal/dom_parser_implementation.h:94) leaves in
  * the document -- behaviour: json_iterator::walk_document (src/generic/stage2/json_iterator.h:121-244) with the tape builder as

@@ -199,6 +199,13 @@ double sjref_bench_stage2(const char *impl_name, const uint8_t *buf, size_t len,
   return best;
 }
 
+// On-Demand's raw key comparison: ondemand::raw_json_string::unsafe_is_equal(length, target) of the builtin kernel
+// (/root/reference/include/simdjson/generic/ondemand/raw_json_string-inl.h:66-69).  raw points behind the opening quote.
+int sjref_raw_key_equal(const uint8_t *raw, size_t length, const uint8_t *target, size_t m) {
+  simdjson::ondemand::raw_json_string r(raw);
+  return r.unsafe_is_equal(length, std::string_view(reinterpret_cast<const char *>(target), m)) ? 1 : 0;
+}
+
 // The string work of stage 2 alone, the way tape_builder does it (visit_string, tape_builder.h:187-205 with :415-433): for every
 // structural that is a quote, parse_string behind a 4-byte length slot, NUL behind it.  buf must be padded; out needs
 // 5 (len + 1) / 3 + 64 bytes.  Returns the best seconds over `iters` runs (after one warm run), negative on failure (incl. a

@@ -85,6 +85,11 @@ int sjo_string_buffer(const uint8_t *buf, size_t len, const uint32_t *idx, uint3
 int sjo_stage2(const uint8_t *buf, size_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, uint64_t *tape, size_t tape_cap,
                uint8_t *string_buf, size_t string_cap, uint64_t *tape_words, uint64_t *string_bytes);
 
+/* On-Demand's raw key comparison (raw_json_string::unsafe_is_equal, value_iterator::find_field_raw), one key / a whole list */
+int sjo_raw_key_equal(const uint8_t *raw, size_t length, const uint8_t *target, size_t m);
+uint32_t sjo_match_keys(const uint8_t *buf, size_t len, const uint32_t *idx, uint32_t n, const uint8_t *targets, const uint32_t *lens, uint32_t K,
+                        uint32_t *out);
+
 /* FNV-1a-64 over the n+3 index words (little-endian bytes): the digest SURVEY App. B quotes. */
 uint64_t sjo_fnv1a64(const void *data, size_t nbytes);
 

@@ -313,3 +313,30 @@ done:
 #undef TOK
 #undef FAIL
 }
+
+/* ---- On-Demand's raw key comparison, batched --------------------------------------------------------------------------
+ * raw_json_string::unsafe_is_equal(length, target) (/root/reference/include/simdjson/generic/ondemand/raw_json_string-inl.h:66-69),
+ * as value_iterator::find_field_raw applies it to every key of an object (value_iterator-inl.h:132, :229): the key's RAW bytes
+ * (escapes not resolved) against the target's bytes, the byte behind them a quote, and `length` -- the room between this structural
+ * and the next one minus the two quotes -- at least the target's length. */
+int sjo_raw_key_equal(const uint8_t *raw, size_t length, const uint8_t *target, size_t m) {
+  return length >= m && raw[m] == '"' && memcmp(raw, target, m) == 0;
+}
+/* out[i] = index of the first target equal to structural i when that structural is a KEY (a string whose next structural is ':'),
+ * 0xFFFFFFFF otherwise.  targets: K byte strings back to back, lens[k] their lengths.  idx[0..n] incl. the first sentinel.
+ * Returns the number of matches. */
+uint32_t sjo_match_keys(const uint8_t *buf, size_t len, const uint32_t *idx, uint32_t n, const uint8_t *targets, const uint32_t *lens, uint32_t K,
+                        uint32_t *out) {
+  uint32_t matches = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    out[i] = 0xFFFFFFFFu;
+    if (buf[idx[i]] != '"' || i + 1 >= n || buf[idx[i + 1]] != ':') { continue; }
+    const size_t room = (size_t)idx[i + 1] - idx[i];
+    if (room < 2) { continue; }
+    const uint8_t *t = targets;
+    for (uint32_t k = 0; k < K; t += lens[k], k++) {
+      if ((size_t)idx[i] + 1 + lens[k] < len && sjo_raw_key_equal(buf + idx[i] + 1, room - 2, t, lens[k])) { out[i] = k; matches++; break; }
+    }
+  }
+  return matches;
+}

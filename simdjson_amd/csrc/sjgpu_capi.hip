@@ -1265,6 +1265,34 @@ int sjgpu_parse_strings_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
   return h.first_bad != 0xFFFFFFFFu ? 5 /* STRING_ERROR */ : 0;
 }
 
+// ---- On-Demand's raw key comparison (sjgpu_strings.hip) ---------------------------------------------------------------------------------
+int sjgpu_match_keys_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const void *idx_dev, uint32_t n, const uint8_t *names, const uint32_t *name_lens,
+                            uint32_t K, void *match_dev, void *stream, uint32_t *matches_out) {
+  if (!ctx || !buf_dev || !idx_dev || !match_dev || !names || !name_lens || K == 0 || K > 256u || (reinterpret_cast<uintptr_t>(match_dev) & 3u)) { return SJGPU_E_BADARG; }
+  size_t total = 0;
+  for (uint32_t k = 0; k < K; k++) { total += name_lens[k]; }
+  if (total > (size_t(64) << 10)) { return SJGPU_E_BADARG; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t block = size_t(K) * sizeof(uint32_t) + total;
+  int rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_stage2), &ctx->d_stage2_bytes, 256 + block);
+  if (rc) { return rc; }
+  std::vector<uint8_t> host(block);
+  std::memcpy(host.data(), name_lens, size_t(K) * sizeof(uint32_t));
+  std::memcpy(host.data() + size_t(K) * sizeof(uint32_t), names, total);
+  hipStream_t s = pick(ctx, stream);
+  uint32_t *d_matches = reinterpret_cast<uint32_t *>(ctx->d_stage2);
+  uint8_t *d_block = ctx->d_stage2 + 256;
+  SJ_TRY(ctx, hipMemcpyAsync(d_block, host.data(), block, hipMemcpyHostToDevice, s));
+  SJ_TRY(ctx, hipStreamSynchronize(s)); // `host` leaves scope with this call
+  launch_match_keys(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, d_block, K, static_cast<uint32_t *>(match_dev), d_matches, s);
+  SJ_TRY(ctx, hipGetLastError());
+  uint32_t m = 0;
+  SJ_TRY(ctx, hipMemcpyAsync(&m, d_matches, sizeof m, hipMemcpyDeviceToHost, s));
+  SJ_TRY(ctx, hipStreamSynchronize(s));
+  if (matches_out) { *matches_out = m; }
+  return 0;
+}
+
 // ---- stage 2: the tape (sjgpu_tape.hip) -------------------------------------------------------------------------------------------------
 int sjgpu_stage2_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const void *idx_dev, uint32_t n, uint32_t max_depth, void *tape_dev,
                         size_t tape_cap_words, void *string_buf_dev, size_t string_buf_bytes, void *stream, uint64_t *tape_words_out,

@@ -197,6 +197,9 @@ size_t tape_workspace_bytes(uint32_t n, uint64_t len);
 // writes the reference's tape; workspace: tape_workspace_bytes(n, len), its first bytes are the tape_result_dev afterwards
 void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, const uint32_t *str_offsets, uint64_t *tape,
                  uint64_t tape_cap, void *workspace, hipStream_t s);
+// On-Demand's raw key comparison over the whole list (sjgpu_strings.hip); names_block: [u32 lens[K]][name bytes back to back] in device memory
+void launch_match_keys(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, const uint8_t *names_block, uint32_t K, uint32_t *out, uint32_t *matches,
+                       hipStream_t s);
 // in-place exclusive scan of a[0 .. *n_ptr) (n_max >= *n_ptr sizes the grid); partial: blocks_for(n_max, 4096) + 64 ints (sjgpu_finish.hip)
 void enqueue_scan(int *a, uint32_t n_max, const uint32_t *n_ptr, int *partial, hipStream_t s);
 

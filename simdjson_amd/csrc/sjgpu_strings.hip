@@ -426,7 +426,48 @@ __global__ __launch_bounds__(STR_THREADS) void k_strings(const u8 *__restrict__ 
   }
 }
 
+// ---- On-Demand's raw key comparison for every key of the list at once ------------------------------------------------------------------
+// value_iterator::find_field_raw (/root/reference/include/simdjson/generic/ondemand/value_iterator-inl.h:132, :229) walks the fields of an
+// object and compares each key's RAW bytes with the wanted name: raw_json_string::unsafe_is_equal(length, target)
+// (raw_json_string-inl.h:66-69) = room for the target, its bytes, a quote behind them.  Keys are independent: one lane per structural
+// decides "am I a key (a string whose next structural is ':') and which of the K wanted names am I".  Names sit in one small block
+// (lens, then bytes back to back) that every lane reads through the scalar / L1 path.
+constexpr u32 KEY_NONE = 0xFFFFFFFFu;
+__global__ __launch_bounds__(STR_THREADS) void k_match_keys(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, const u32 *__restrict__ lens,
+                                                          const u8 *__restrict__ names, u32 K, u32 *__restrict__ out, u32 *__restrict__ matches) {
+  const u64 i = u64(blockIdx.x) * STR_THREADS + threadIdx.x;
+  u32 found = KEY_NONE;
+  if (i < n) {
+    const u32 at = idx[i], next = idx[i + 1]; // the sentinel behind the list bounds the last one
+    if (at < len && buf[at] == '"' && i + 1 < n && buf[next] == ':' && next - at >= 2u) {
+      const u32 room = next - at - 2u; // what separates this structural from the next, minus the two quotes
+      u32 off = 0;
+      for (u32 k = 0; k < K && found == KEY_NONE; k++) {
+        const u32 m = lens[k];
+        if (room >= m && u64(at) + 1 + m < len && buf[at + 1 + m] == '"') {
+          u32 j = 0;
+          while (j < m && buf[at + 1 + j] == names[off + j]) { j++; }
+          if (j == m) { found = k; }
+        }
+        off += m;
+      }
+    }
+    out[i] = found;
+  }
+  const u64 hit = __ballot(found != KEY_NONE);
+  if (hit && (threadIdx.x & 63u) == 0) { atomicAdd(matches, u32(popc64(hit))); }
+}
+
 } // namespace
+
+// names_block (device): [u32 lens[K]][bytes of the K names back to back]; matches (device, one u32, zeroed here)
+void launch_match_keys(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, const uint8_t *names_block, uint32_t K, uint32_t *out, uint32_t *matches,
+                       hipStream_t s) {
+  (void)hipMemsetAsync(matches, 0, sizeof(uint32_t), s);
+  if (n == 0) { return; }
+  hipLaunchKernelGGL(k_match_keys, dim3(u32((u64(n) + STR_THREADS - 1) / STR_THREADS)), dim3(STR_THREADS), 0, s, buf, len, idx, n,
+                     reinterpret_cast<const u32 *>(names_block), names_block + size_t(K) * sizeof(u32), K, out, matches);
+}
 
 size_t strings_scratch_bytes(uint32_t n) { return 64 + (size_t(n) / 4096 + 72) * 4; }
 

@@ -65,6 +65,18 @@ class Oracle:
                                 ctypes.byref(tw), ctypes.byref(sb))
         return err, tape[: tw.value].copy(), sbuf[: sb.value].copy()
 
+    def match_keys(self, data, idx, n, names):
+        """(out[n] uint32, matches): On-Demand's raw key comparison over the whole list (sjo_match_keys)"""
+        a = as_u8(data)
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        blob = np.frombuffer(b"".join(names) + b" ", dtype=np.uint8).copy()
+        lens = np.array([len(x) for x in names], dtype=np.uint32)
+        out = np.zeros(max(int(n), 1), dtype=np.uint32)
+        self.L.sjo_match_keys.restype = ctypes.c_uint32
+        self.L.sjo_match_keys.argtypes = [_u8p, ctypes.c_size_t, _u8p, ctypes.c_uint32, _u8p, _u8p, ctypes.c_uint32, _u8p]
+        m = self.L.sjo_match_keys(a.ctypes.data, len(a), idx.ctypes.data, int(n), blob.ctypes.data, lens.ctypes.data, len(names), out.ctypes.data)
+        return out[: int(n)], int(m)
+
     def dom_parse(self, data, max_depth=1024):
         """stage 1 + stage 2 of the oracle: (error_code, tape, string_buf); the stage-1 error if that is where it ends"""
         err, n, idx = self.stage1(data, 0)

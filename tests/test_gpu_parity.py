@@ -1370,3 +1370,29 @@ def test_comm_world_size_one(orc):
         comm.gather_indices(idx.data_ptr(), n, base, 0, out.data_ptr(), 4, st)  # too small: refused AFTER the exchange has drained
     comm.close()
     p.close()
+
+
+def test_raw_key_matching(orc):
+    """On-Demand's raw key comparison for every key of the list in one pass (sjgpu_match_keys_device) against the oracle's loop
+    (pinned against the reference's raw_json_string::unsafe_is_equal on the CPU tier)"""
+    import torch
+    docs = [np.fromfile(os.path.join(_paths.REPO_ROOT, "tests", "golden", "jsonexamples", "twitter.json"), dtype=np.uint8),
+            corpus.twitter_like(8 << 20, 5)[0], corpus.large_random(4 << 20, 6)[0],
+            np.frombuffer(b'{"id":1,"id ":2,"i":3,"idx":4, "id" :5,"text":"id","na\\"me":6,"":7,"id":"id"}', dtype=np.uint8).copy()]
+    names = [b"id", b"text", b"screen_name", b"x", b"", b'na\\"me', b"retweet_count", b"not_there", b"i"]
+    p = capi.DomParserImplementation(CAP)
+    st = torch.cuda.current_stream().cuda_stream
+    for a in docs:
+        L = len(a)
+        buf = torch.from_numpy(a).cuda()
+        idx = torch.empty(L + 16, dtype=torch.int32, device="cuda")
+        assert p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, st) == 0
+        n, flags, _ = p.result(st)
+        assert flags == 0
+        out = torch.empty(n, dtype=torch.int32, device="cuda")
+        m = p.match_keys_device(buf.data_ptr(), L, idx.data_ptr(), n, names, out.data_ptr(), st)
+        want, wm = orc.match_keys(a, idx[: n + 1].cpu().numpy().view(np.uint32), n, names)
+        assert m == wm
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want)
+    assert wm >= 6
+    p.close()

@@ -283,3 +283,29 @@ def test_stage2_depth_limit(both):
     for max_depth in (1, 2, 3, 4, 16):
         for doc in (b"[]", b"[[]]", b"[[[]]]", b"[[[[1]]]]", b'{"a":{"b":{"c":{}}}}', b"1", b"[1,[2,[3,[4]]]]"):
             _same_parse(orc, ref, impl, doc, max_depth)
+
+
+def test_raw_key_comparison_is_the_reference_s(both):
+    """sjo_raw_key_equal against ondemand::raw_json_string::unsafe_is_equal(length, target) of the reference, on keys with escapes, prefixes
+    of each other, quotes inside, lengths around the limit"""
+    import ctypes
+    orc, ref = both
+    ref.L.sjref_raw_key_equal.restype = ctypes.c_int
+    ref.L.sjref_raw_key_equal.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    orc.L.sjo_raw_key_equal.restype = ctypes.c_int
+    orc.L.sjo_raw_key_equal.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    raws = [b'name"', b'name" ', b'names"', b'nam"', b'na\\"me"', b'"', b'name\\u0041"', b'a' * 70 + b'"', b'a' * 64 + b'"', b'id":1,"name":2}', b'\xe6\x97\xa5"']
+    targets = [b"name", b"names", b"nam", b"", b'na\\"me', b"a" * 70, b"a" * 64, b"a" * 63, b"id", b"\xe6\x97\xa5", b"name\\u0041", b"nameA"]
+    checked = 0
+    for raw in raws:
+        padded = np.frombuffer(raw + b" " * 128, dtype=np.uint8).copy()
+        for t in targets:
+            tt = np.frombuffer(t + b" ", dtype=np.uint8).copy()
+            for length in (0, len(t) - 1, len(t), len(t) + 1, 200):
+                if length < 0:
+                    continue
+                want = ref.L.sjref_raw_key_equal(padded.ctypes.data, length, tt.ctypes.data, len(t))
+                got = orc.L.sjo_raw_key_equal(padded.ctypes.data, length, tt.ctypes.data, len(t))
+                assert got == want, (raw, t, length)
+                checked += 1
+    assert checked > 500
