@@ -334,6 +334,17 @@ int sjgpu_stage1_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin,
 int sjgpu_minify_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin, size_t end, int more, int in_string,
                               uint32_t out_before, void *dst_dev, void *stream);
 
+/* ---- windows of one stream (parse_many) -------------------------------------------------------------------------------
+ * document_stream calls stage1 once per window of ONE buffer (include/simdjson/dom/document_stream-inl.h:285-317; 1 MB windows by
+ * default); a launch and a PCIe round trip per megabyte lose to a CPU kernel.  The interface only ever sees a window, so the
+ * integrator names the stream: between sjgpu_stream_register(base, len) and sjgpu_stream_unregister(base) the bytes
+ * [base, base + len) must stay valid and unchanged (the range is page-locked meanwhile unless SJGPU_STREAM_PIN=0).  sjgpu_stage1
+ * calls in the streaming_partial / streaming_final modes whose buffer lies inside a registered stream are then answered from a
+ * span of 32 MiB scanned once -- identical results, microseconds per window (profiles / bench.py plugin_host_path).  The in-tree
+ * patch registers in document_stream::start(); out of tree: simdjson::mi355x::register_stream. */
+int sjgpu_stream_register(const uint8_t *base, size_t len);
+int sjgpu_stream_unregister(const uint8_t *base);
+
 /* ---- page-locked host memory ("a pinned-memory padded_string allocator") ----------------------
  * The host-buffer entry points accept any memory.  Ordinary (pageable) memory has to be pinned page by page by the
  * runtime on every call it has not seen before -- measured here ~25 GB/s per direction, 47-57 GB/s when the pages

@@ -29,7 +29,7 @@ EXPORTS = [
     "sjgpu_stage1_range_device", "sjgpu_minify_range_device",
     "sjgpu_host_alloc", "sjgpu_host_free", "sjgpu_host_register", "sjgpu_host_unregister", "sjgpu_last_pipeline",
     "sjgpu_profile_kernel", "sjgpu_debug_trace_pipelined", "sjgpu_stage1_many", "sjgpu_stage1_finish_device",
-    "sjgpu_depth_scan_device", "sjgpu_parse_strings_device", "sjgpu_stage2_device", "sjgpu_parse", "sjgpu_pool_trim", "sjgpu_match_keys_device", "sjgpu_comm_unique_id", "sjgpu_comm_create", "sjgpu_comm_destroy", "sjgpu_comm_last_error", "sjgpu_comm_gather_indices", "sjgpu_mgpu_create", "sjgpu_mgpu_destroy", "sjgpu_mgpu_count", "sjgpu_mgpu_stage1", "sjgpu_mgpu_minify",
+    "sjgpu_depth_scan_device", "sjgpu_parse_strings_device", "sjgpu_stage2_device", "sjgpu_parse", "sjgpu_pool_trim", "sjgpu_stream_register", "sjgpu_stream_unregister", "sjgpu_match_keys_device", "sjgpu_comm_unique_id", "sjgpu_comm_create", "sjgpu_comm_destroy", "sjgpu_comm_last_error", "sjgpu_comm_gather_indices", "sjgpu_mgpu_create", "sjgpu_mgpu_destroy", "sjgpu_mgpu_count", "sjgpu_mgpu_stage1", "sjgpu_mgpu_minify",
     "sjgpu_mgpu_validate_utf8",
 ]
 
@@ -534,6 +534,21 @@ class MultiGpu:
         if rc != 0:
             raise SjgpuError(f"sjgpu_mgpu_validate_utf8 error {rc}")
         return bool(ok.value)
+
+
+def stream_register(arr):
+    """sjgpu_stream_register over a numpy uint8 array: stage1 calls on windows (views) of it are answered from a look-ahead span"""
+    L = load_library()
+    L.sjgpu_stream_register.restype = ctypes.c_int
+    L.sjgpu_stream_register.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    return L.sjgpu_stream_register(arr.ctypes.data, arr.nbytes)
+
+
+def stream_unregister(arr):
+    L = load_library()
+    L.sjgpu_stream_unregister.restype = ctypes.c_int
+    L.sjgpu_stream_unregister.argtypes = [ctypes.c_void_p]
+    return L.sjgpu_stream_unregister(arr.ctypes.data)
 
 
 def stage1_error_from_flags(n, flags):

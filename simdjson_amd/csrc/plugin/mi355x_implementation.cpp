@@ -229,6 +229,9 @@ const simdjson::implementation *get_implementation() noexcept {
 
 bool available() noexcept { return sjgpu_device_count() > 0; }
 
+void register_stream(const uint8_t *buf, size_t len) noexcept { (void)sjgpu_stream_register(buf, len); }
+void unregister_stream(const uint8_t *buf) noexcept { (void)sjgpu_stream_unregister(buf); }
+
 simdjson::error_code activate(int device) noexcept {
   if (device < 0 || device >= sjgpu_device_count()) { return UNSUPPORTED_ARCHITECTURE; }
   g_device.store(device);

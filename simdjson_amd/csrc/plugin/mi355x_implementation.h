@@ -30,6 +30,16 @@ bool available() noexcept;
  */
 simdjson::error_code activate(int device = 0) noexcept;
 
+/**
+ * parse_many / iterate_many hand stage 1 one window of the stream at a time (1 MB by default,
+ * include/simdjson/dom/document_stream-inl.h:285-317); a GPU launch and a PCIe round trip per window lose to a CPU kernel.
+ * Tell the backend where the whole stream lies and it scans 32 MiB spans once and cuts the windows out of them (sjgpu_stream_register,
+ * include/sjgpu.h): call register_stream(buf, len) before parse_many(buf, len) and unregister_stream(buf) when the stream is done.
+ * The bytes must stay valid and unchanged in between.  The in-tree build does this from document_stream::start() by itself.
+ */
+void register_stream(const uint8_t *buf, size_t len) noexcept;
+void unregister_stream(const uint8_t *buf) noexcept;
+
 } // namespace mi355x
 } // namespace simdjson
 

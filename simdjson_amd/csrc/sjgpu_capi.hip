@@ -147,6 +147,14 @@ struct sjgpu_ctx {
   size_t d_stage2_bytes = 0;
   uint8_t *d_doc = nullptr; // [tape words][string buffer] of sjgpu_parse
   size_t d_doc_bytes = 0;
+  // look-ahead over a registered stream (sjgpu_stream_register): the raw structurals of ONE span of the stream, in page-locked
+  // host memory, from which the windows document_stream asks for are cut without touching the GPU again
+  const uint8_t *la_base = nullptr; // the registered stream the span belongs to (null: nothing cached)
+  size_t la_begin = 0, la_end = 0;  // the span, as offsets into the stream
+  uint32_t la_n = 0;
+  bool la_usable = false;           // false: the span holds an error the windows must find for themselves
+  uint32_t *h_la_idx = nullptr;     // offsets relative to la_begin
+  size_t h_la_words = 0;
   // overlapped host-buffer path (large documents): one copy thread per direction, one "range uploaded" event per range
   std::vector<copy_worker *> up, down; // range k travels on up[k % up.size()]; output piece k on down[k % down.size()]
   size_t copy_threads = 1;             // per direction (env SJGPU_COPY_THREADS)
@@ -561,6 +569,7 @@ void really_destroy(sjgpu_ctx *ctx) {
   drop_events(ctx);
   if (ctx->h_result) { (void)hipHostFree(ctx->h_result); }
   if (ctx->h_small) { (void)hipHostFree(ctx->h_small); }
+  if (ctx->h_la_idx) { (void)hipHostFree(ctx->h_la_idx); }
   dev_free(ctx->esc_tab);
   dev_free(ctx->d_tmp);
   dev_free(ctx->d_stage2);
@@ -590,6 +599,7 @@ extern "C" int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out) {
   }
   if (ctx) { // a parked context: same stream, same page-locked blocks, whatever workspace it kept
     apply_environment(ctx);
+    ctx->la_base = nullptr;
     ctx->capacity = capacity;
     ctx->density_permille = 1000;
     ctx->pending_scan_bytes = 0;
@@ -637,6 +647,8 @@ extern "C" void sjgpu_ctx_destroy(sjgpu_ctx *ctx) {
   if (ctx->d_tmp_bytes > 4 * POOL_KEEP_BYTES) { dev_free(ctx->d_tmp); ctx->d_tmp_bytes = 0; }
   if (ctx->d_stage2_bytes > 4 * POOL_KEEP_BYTES) { dev_free(ctx->d_stage2); ctx->d_stage2_bytes = 0; }
   if (ctx->d_doc_bytes > 4 * POOL_KEEP_BYTES) { dev_free(ctx->d_doc); ctx->d_doc_bytes = 0; }
+  ctx->la_base = nullptr;
+  if (ctx->h_la_idx) { (void)hipHostFree(ctx->h_la_idx); ctx->h_la_idx = nullptr; ctx->h_la_words = 0; }
   if (ctx->h_small_bytes > (size_t(1) << 20)) { // page-locked memory is scarce: a parked context keeps at most 1 MiB of it
     (void)hipHostFree(ctx->h_small);
     ctx->h_small = nullptr;
@@ -1103,9 +1115,159 @@ int finish_on_device_and_fetch(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, i
   return d.error;
 }
 
+// ---- windows of ONE stream (parse_many): scan a span once, cut the windows out of it --------------------------------------------------
+// document_stream calls stage1 on consecutive windows of one buffer (/root/reference/include/simdjson/dom/document_stream-inl.h:285-317:
+// &buf[batch_start], batch_size -- 1 MB by default).  One launch and one PCIe round trip per megabyte is what loses to a CPU kernel
+// (round 2: 92 us against 68).  The interface hands over a window, not the stream, and nothing beyond a window may be touched on a
+// guess -- so the integrator says where the stream lies (sjgpu_stream_register: the in-tree patch calls it from document_stream::start,
+// out-of-tree users from simdjson::mi355x::register_stream).  A window inside a registered stream is then answered from a SPAN:
+// tens of megabytes uploaded and scanned once, their raw structurals kept in page-locked host memory.  Cutting a window out of them is
+// exact because every window of a document stream begins at a structural of the scan in front of it (idx[n] of the previous finish())
+// -- outside any string, not escaped, a token start -- or at the start of the span itself; the window's own flags are rebuilt from its
+// bytes (does it end inside a string?), and spans that hold an error the windows must report are not used at all.
+struct stream_extent {
+  const uint8_t *base;
+  size_t len;
+  bool pinned;
+};
+struct stream_registry {
+  std::mutex m;
+  std::vector<stream_extent> list;
+};
+stream_registry &streams() {
+  static stream_registry *r = new stream_registry(); // never destroyed (see ctx_pool)
+  return *r;
+}
+bool find_stream(const uint8_t *buf, size_t len, stream_extent *out) {
+  stream_registry &r = streams();
+  std::lock_guard<std::mutex> lk(r.m);
+  for (const stream_extent &e : r.list) {
+    if (buf >= e.base && buf + len <= e.base + e.len) { *out = e; return true; }
+  }
+  return false;
+}
+
+constexpr size_t LA_WINDOW_MAX = size_t(8) << 20;  // longer windows are worth a scan of their own
+constexpr size_t LA_SPAN = size_t(32) << 20;
+
+// index of the first entry >= x
+uint32_t lower_bound_u32(const uint32_t *a, uint32_t n, uint64_t x) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (a[mid] < x) { lo = mid + 1; } else { hi = mid; }
+  }
+  return lo;
+}
+
+// *served = false: take the ordinary path.  len is the window's length after the partial-UTF-8 trim.
+int stage1_from_span(sjgpu_ctx *ctx, const stream_extent &e, const uint8_t *buf, size_t len, int mode, uint32_t *idx_out, size_t idx_words, uint32_t *n_io,
+                     uint32_t *next_io, bool *served) {
+  *served = false;
+  const size_t off = size_t(buf - e.base);
+  if (!(ctx->la_base == e.base && off >= ctx->la_begin && off + len <= ctx->la_end)) { // a new span, beginning with this window
+    size_t span = e.len - off;
+    if (span > LA_SPAN) { span = LA_SPAN > len ? LA_SPAN : len; }
+    if (span > 0xFFFFFFF0ull) { return 0; }
+    ctx->la_base = nullptr;
+    int rc = ensure_staging_in(ctx, span);
+    if (rc) { return rc; }
+    size_t idx_bytes = ctx->d_idx_words * sizeof(uint32_t);
+    rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_idx), &idx_bytes, (grown(span) + 16) * sizeof(uint32_t));
+    ctx->d_idx_words = idx_bytes / sizeof(uint32_t);
+    if (rc) { return rc; }
+    hipStream_t s = ctx->stream;
+    SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, e.base + off, span, hipMemcpyHostToDevice, s));
+    sjgpu_scan_result res{0, 0, 0};
+    const uint32_t carry = (off + span < e.len) ? CARRY_MORE : 0u; // the stream goes on behind the span: no end-of-input rule
+    for (int attempt = 0; attempt < 2; attempt++) {
+      enqueue_stage1(ctx, use_fused(ctx, span, 0) && attempt == 0, ctx->d_in, span, ctx->d_idx, ctx->d_idx_words, s, nullptr, scan_origin{0, 0, carry});
+      SJ_ENQUEUED(ctx);
+      rc = fetch_result(ctx, s, &res);
+      if (rc) { return rc; }
+      if (!(res.flags & SJGPU_F_INTERNAL)) { break; }
+    }
+    if (res.flags & (SJGPU_F_INTERNAL | SJGPU_F_IDX_OVERFLOW)) { return 0; } // not served: the window's own scan will say what is wrong
+    if (size_t(res.n) + 4 > ctx->h_la_words) {
+      if (ctx->h_la_idx) { (void)hipHostFree(ctx->h_la_idx); ctx->h_la_idx = nullptr; ctx->h_la_words = 0; }
+      size_t want = size_t(1) << 16;
+      while (want < size_t(res.n) + 4) { want <<= 1; }
+      SJ_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_la_idx), want * sizeof(uint32_t), hipHostMallocDefault));
+      ctx->h_la_words = want;
+    }
+    if (res.n) {
+      SJ_TRY(ctx, hipMemcpyAsync(ctx->h_la_idx, ctx->d_idx, size_t(res.n) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      SJ_TRY(ctx, hipStreamSynchronize(s));
+    }
+    ctx->la_base = e.base;
+    ctx->la_begin = off;
+    ctx->la_end = off + span;
+    ctx->la_n = res.n;
+    // a control character inside a string or broken UTF-8 SOMEWHERE in the span says nothing about a particular window
+    ctx->la_usable = (res.flags & (SJGPU_F_UNESCAPED_CTRL | SJGPU_F_UTF8_ERROR)) == 0;
+  }
+  if (!ctx->la_usable) { return 0; }
+  const uint64_t rel = off - ctx->la_begin;
+  const uint32_t *list = ctx->h_la_idx;
+  const uint32_t lo = lower_bound_u32(list, ctx->la_n, rel);
+  if (rel != 0 && !(lo < ctx->la_n && list[lo] == rel)) { return 0; } // the window does not begin at a token of the span's scan: not ours to answer
+  const uint32_t hi = lower_bound_u32(list, ctx->la_n, rel + len);
+  const uint32_t n_raw = hi - lo;
+  if (size_t(n_raw) + 3 > idx_words) { return SJGPU_E_OVERFLOW; }
+  const uint32_t shift = uint32_t(rel);
+  for (uint32_t k = 0; k < n_raw; k++) { idx_out[k] = list[lo + k] - shift; }
+  // the window's own flag: does it end inside a string?  Only an opening quote is ever a structural, so that is the case iff the last
+  // structural is a quote whose closing quote lies beyond the window.
+  uint32_t flags = 0;
+  if (n_raw && buf[idx_out[n_raw - 1]] == '"') {
+    bool closed = false;
+    for (size_t j = size_t(idx_out[n_raw - 1]) + 1; j < len; j++) {
+      if (buf[j] == '\\') { j++; }
+      else if (buf[j] == '"') { closed = true; break; }
+    }
+    if (!closed) { flags |= SJGPU_F_UNCLOSED_STRING; }
+  }
+  *served = true;
+  return sjgpu_stage1_finish_host(buf, len, mode, idx_out, n_raw, flags, n_io, next_io);
+}
+
 } // namespace
 
 extern "C" {
+
+int sjgpu_stream_register(const uint8_t *base, size_t len) {
+  if (!base || len == 0) { return SJGPU_E_BADARG; }
+  stream_extent e{base, len, false};
+  static const bool pin = []() { const char *v = std::getenv("SJGPU_STREAM_PIN"); return !v || v[0] != '0'; }();
+  if (pin && sjgpu_device_count() > 0) { e.pinned = hipHostRegister(const_cast<uint8_t *>(base), len, hipHostRegisterDefault) == hipSuccess; }
+  (void)hipGetLastError(); // a range that cannot be page-locked (already registered, read-only mapping) still works, only slower
+  stream_registry &r = streams();
+  std::lock_guard<std::mutex> lk(r.m);
+  for (stream_extent &x : r.list) {
+    if (x.base == base) { x.len = len; x.pinned = x.pinned || e.pinned; return 0; }
+  }
+  r.list.push_back(e);
+  return 0;
+}
+
+int sjgpu_stream_unregister(const uint8_t *base) {
+  if (!base) { return SJGPU_E_BADARG; }
+  stream_registry &r = streams();
+  bool pinned = false, found = false;
+  {
+    std::lock_guard<std::mutex> lk(r.m);
+    for (size_t i = 0; i < r.list.size(); i++) {
+      if (r.list[i].base == base) {
+        pinned = r.list[i].pinned;
+        r.list.erase(r.list.begin() + long(i));
+        found = true;
+        break;
+      }
+    }
+  }
+  if (pinned) { (void)hipHostUnregister(const_cast<uint8_t *>(base)); }
+  return found ? 0 : SJGPU_E_BADARG;
+}
 
 int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint32_t *idx_out, size_t idx_words, uint32_t *n_io,
                  uint32_t *next_io) {
@@ -1120,6 +1282,14 @@ int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint3
   SJ_TRY(ctx, hipSetDevice(ctx->device));
   sjgpu_scan_result res;
   int rc = 0;
+  if ((mode == SJGPU_STREAMING_PARTIAL || mode == SJGPU_STREAMING_FINAL) && len <= LA_WINDOW_MAX) { // a window of a registered stream?
+    stream_extent e;
+    if (find_stream(buf, len, &e) && e.len > len) {
+      bool served = false;
+      rc = stage1_from_span(ctx, e, buf, len, mode, idx_out, idx_words, n_io, next_io, &served);
+      if (served || rc) { return rc; }
+    }
+  }
   if (ctx->small_docs && len <= DOCS_SINGLE_MAX) { // one launch, one wait, no staging copies on the device
     const void *out = nullptr;
     rc = small_single(ctx, 0, buf, len, &res, &out);

@@ -162,17 +162,24 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bracket_delta(const u8 *__restr
 }
 
 // Last "value directly following a value" among structurals [1, n): atomicMax of its list index + 1 (0 = none).
+// Workgroups walk the list from its END (blockIdx reversed) and a wave only posts a candidate that beats what is already there:
+// in NDJSON every line is such a boundary, and a million atomicMax on one word cost 11 ms of a 1 GiB stream's finish
+// (bench.py leg next_f2_finish_device, round 3) -- now the first workgroups to run settle it and the rest read one cached word.
 __global__ __launch_bounds__(FIN_THREADS) void k_last_boundary(const u8 *__restrict__ buf, const u32 *__restrict__ idx, const u32 *__restrict__ n_ptr,
                                                              finish_state *__restrict__ st) {
   const u32 n = *n_ptr;
-  const u64 i = u64(blockIdx.x) * FIN_THREADS + threadIdx.x;
+  const u64 block = u64(gridDim.x - 1u - blockIdx.x);
+  const u64 i = block * FIN_THREADS + threadIdx.x;
   bool b = false;
   if (i >= 1 && i < n) {
     const u32 cur = classify_byte(buf[idx[i]]), before = classify_byte(buf[idx[i - 1]]);
     b = !is_sep(cur) && !is_close(cur) && !is_open(before) && !is_sep(before);
   }
   const u64 m = __ballot(b);
-  if (m && (threadIdx.x & 63u) == 0) { atomicMax(&st->boundary_plus1, u32(u64(blockIdx.x) * FIN_THREADS + (threadIdx.x & ~63u) + 63u - clz64(m)) + 1u); }
+  if (m && (threadIdx.x & 63u) == 0) {
+    const u32 cand = u32(block * FIN_THREADS + (threadIdx.x & ~63u) + 63u - clz64(m)) + 1u;
+    if (cand > __hip_atomic_load(&st->boundary_plus1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicMax(&st->boundary_plus1, cand); }
+  }
 }
 // Bracket balance of the structurals from the last boundary (or 0) to n, braces and square brackets separately.
 __global__ __launch_bounds__(FIN_THREADS) void k_tail_balance(const u8 *__restrict__ buf, const u32 *__restrict__ idx, const u32 *__restrict__ n_ptr,
@@ -214,7 +221,8 @@ __global__ __launch_bounds__(FIN_THREADS) void k_comma_flags(const u8 *__restric
   const u64 m = __ballot(root);
   if (m && (threadIdx.x & 63u) == 0) {
     atomicAdd(&st->separators, u32(popc64(m)));
-    atomicMax(&st->last_sep_index_plus1, u32(u64(blockIdx.x) * FIN_THREADS + (threadIdx.x & ~63u) + 63u - clz64(m)) + 1u);
+    const u32 cand = u32(u64(blockIdx.x) * FIN_THREADS + (threadIdx.x & ~63u) + 63u - clz64(m)) + 1u;
+    if (cand > __hip_atomic_load(&st->last_sep_index_plus1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicMax(&st->last_sep_index_plus1, cand); }
   }
 }
 

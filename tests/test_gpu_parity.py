@@ -1396,3 +1396,60 @@ def test_raw_key_matching(orc):
         assert np.array_equal(out.cpu().numpy().view(np.uint32), want)
     assert wm >= 6
     p.close()
+
+
+def _walk_windows(stage1_fn, stream, batch):
+    """drive stage1 the way document_stream::run_stage1 does (dom/document_stream-inl.h:285-317): consecutive windows, the next one starting
+    where the last complete document of this one ended; returns every call's observable result"""
+    out, start, guard = [], 0, 0
+    total = len(stream)
+    while start < total and guard < 100000:
+        guard += 1
+        remaining = total - start
+        final = remaining <= batch
+        w = stream[start: start + (remaining if final else batch)]
+        mode = capi.STREAMING_FINAL if final else capi.STREAMING_PARTIAL
+        err, n, idx = stage1_fn(w, mode)
+        out.append((start, err, n, tuple(int(x) for x in idx[: n + 3])))
+        if err not in (0, checkers.EMPTY) or final:
+            break
+        nxt = int(idx[n])  # next_batch_start: structural_indexes[n_structural_indexes]
+        if nxt == 0:
+            break
+        start += nxt
+    return out
+
+
+def test_windows_of_a_registered_stream(orc):
+    """parse_many's windows answered from a look-ahead span (sjgpu_stream_register) are word for word what the same calls deliver without it
+    -- and what the oracle delivers: NDJSON, tight windows that cut strings and multi-byte characters, streams with errors in them"""
+    rng = np.random.default_rng(88)
+    nd, _ = corpus.amazon_ndjson(72 << 20, 9)  # crosses two spans of 32 MiB
+    tw = []
+    for _ in range(3000):
+        tw.append(jsongen.random_document(rng, max_depth=3))
+    small = np.frombuffer(b"\n".join(tw) + b"\n", dtype=np.uint8).copy()
+    broken = small.copy()
+    broken[len(broken) // 2] = 0x01  # a control character, most likely inside a string somewhere in the middle
+    bad_utf8 = small.copy()
+    bad_utf8[len(bad_utf8) // 3] = 0xFF
+    cases = [(nd, 1_000_000), (nd[: 3 << 20], 20000), (small, 4096), (small, 700), (broken, 4096), (bad_utf8, 4096)]
+    p_plain = capi.DomParserImplementation(8 << 20)
+    p_span = capi.DomParserImplementation(8 << 20)
+    for stream, batch in cases:
+        stream = np.ascontiguousarray(stream)
+        plain = _walk_windows(lambda w, m: g_stage1(p_plain, w, m), stream, batch)
+        assert capi.stream_register(stream) == 0
+        try:
+            spanned = _walk_windows(lambda w, m: g_stage1(p_span, w, m), stream, batch)
+        finally:
+            assert capi.stream_unregister(stream) == 0
+        assert len(plain) == len(spanned) and len(plain) >= 3
+        for a, b in zip(plain, spanned):
+            assert a == b, (batch, a[:3], b[:3])
+        if len(stream) <= (4 << 20):
+            want = _walk_windows(lambda w, m: orc.stage1(w, m), stream, batch)
+            assert [x[:3] for x in want] == [x[:3] for x in plain]
+            assert want == plain
+    p_plain.close()
+    p_span.close()
