@@ -149,12 +149,22 @@ struct sjgpu_ctx {
   size_t d_doc_bytes = 0;
   // look-ahead over a registered stream (sjgpu_stream_register): the raw structurals of ONE span of the stream, in page-locked
   // host memory, from which the windows document_stream asks for are cut without touching the GPU again
-  const uint8_t *la_base = nullptr; // the registered stream the span belongs to (null: nothing cached)
-  size_t la_begin = 0, la_end = 0;  // the span, as offsets into the stream
-  uint32_t la_n = 0;
-  bool la_usable = false;           // false: the span holds an error the windows must find for themselves
-  uint32_t *h_la_idx = nullptr;     // offsets relative to la_begin
-  size_t h_la_words = 0;
+  struct span_slot {
+    const uint8_t *base = nullptr; // the registered stream the span belongs to (null: empty slot)
+    size_t begin = 0, end = 0;     // the span, as offsets into the stream
+    int state = 0;                 // 0 empty | 1 scan enqueued | 2 list download enqueued | 3 ready
+    uint32_t n = 0;
+    bool usable = false;           // false: the span holds an error the windows must find for themselves
+    uint8_t *d_in = nullptr;
+    size_t d_in_bytes = 0;
+    uint32_t *d_idx = nullptr;
+    size_t d_idx_bytes = 0;
+    uint32_t *h_idx = nullptr;     // page-locked: offsets relative to `begin`
+    size_t h_words = 0;
+    scan_result_dev *h_res = nullptr; // page-locked copy of the scan's result
+    hipEvent_t ev = nullptr;
+  } la[2];
+  int la_cur = 0; // the slot windows are being cut from; the other one holds (or awaits) the span behind it
   // overlapped host-buffer path (large documents): one copy thread per direction, one "range uploaded" event per range
   std::vector<copy_worker *> up, down; // range k travels on up[k % up.size()]; output piece k on down[k % down.size()]
   size_t copy_threads = 1;             // per direction (env SJGPU_COPY_THREADS)
@@ -569,7 +579,13 @@ void really_destroy(sjgpu_ctx *ctx) {
   drop_events(ctx);
   if (ctx->h_result) { (void)hipHostFree(ctx->h_result); }
   if (ctx->h_small) { (void)hipHostFree(ctx->h_small); }
-  if (ctx->h_la_idx) { (void)hipHostFree(ctx->h_la_idx); }
+  for (sjgpu_ctx::span_slot &sl : ctx->la) {
+    if (sl.h_idx) { (void)hipHostFree(sl.h_idx); }
+    if (sl.h_res) { (void)hipHostFree(sl.h_res); }
+    if (sl.d_in) { (void)hipFree(sl.d_in); }
+    if (sl.d_idx) { (void)hipFree(sl.d_idx); }
+    if (sl.ev) { (void)hipEventDestroy(sl.ev); }
+  }
   dev_free(ctx->esc_tab);
   dev_free(ctx->d_tmp);
   dev_free(ctx->d_stage2);
@@ -599,7 +615,6 @@ extern "C" int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out) {
   }
   if (ctx) { // a parked context: same stream, same page-locked blocks, whatever workspace it kept
     apply_environment(ctx);
-    ctx->la_base = nullptr;
     ctx->capacity = capacity;
     ctx->density_permille = 1000;
     ctx->pending_scan_bytes = 0;
@@ -647,8 +662,16 @@ extern "C" void sjgpu_ctx_destroy(sjgpu_ctx *ctx) {
   if (ctx->d_tmp_bytes > 4 * POOL_KEEP_BYTES) { dev_free(ctx->d_tmp); ctx->d_tmp_bytes = 0; }
   if (ctx->d_stage2_bytes > 4 * POOL_KEEP_BYTES) { dev_free(ctx->d_stage2); ctx->d_stage2_bytes = 0; }
   if (ctx->d_doc_bytes > 4 * POOL_KEEP_BYTES) { dev_free(ctx->d_doc); ctx->d_doc_bytes = 0; }
-  ctx->la_base = nullptr;
-  if (ctx->h_la_idx) { (void)hipHostFree(ctx->h_la_idx); ctx->h_la_idx = nullptr; ctx->h_la_words = 0; }
+  for (sjgpu_ctx::span_slot &sl : ctx->la) { // a parked context keeps no span: streams end, their memory goes away
+    if (sl.state == 1 || sl.state == 2) { (void)hipStreamSynchronize(ctx->stream); }
+    sl.base = nullptr;
+    sl.state = 0;
+    if (sl.h_idx) { (void)hipHostFree(sl.h_idx); sl.h_idx = nullptr; sl.h_words = 0; }
+    dev_free(sl.d_in);
+    sl.d_in_bytes = 0;
+    dev_free(sl.d_idx);
+    sl.d_idx_bytes = 0;
+  }
   if (ctx->h_small_bytes > (size_t(1) << 20)) { // page-locked memory is scarce: a parked context keeps at most 1 MiB of it
     (void)hipHostFree(ctx->h_small);
     ctx->h_small = nullptr;
@@ -1160,73 +1183,134 @@ uint32_t lower_bound_u32(const uint32_t *a, uint32_t n, uint64_t x) {
   return lo;
 }
 
+// Upload, scan and result read-back of the span [begin, begin + span) of stream e into slot sl: only enqueued.
+int span_issue(sjgpu_ctx *ctx, sjgpu_ctx::span_slot &sl, const stream_extent &e, size_t begin, size_t min_len) {
+  sl.base = nullptr;
+  sl.state = 0;
+  size_t span = e.len - begin;
+  if (span > LA_SPAN) { span = LA_SPAN > min_len ? LA_SPAN : min_len; }
+  if (span > 0xFFFFFFF0ull) { return 0; }
+  int rc = grow(ctx, reinterpret_cast<void **>(&sl.d_in), &sl.d_in_bytes, grown(span) + 64);
+  if (!rc) { rc = grow(ctx, reinterpret_cast<void **>(&sl.d_idx), &sl.d_idx_bytes, (grown(span) + 16) * sizeof(uint32_t)); }
+  if (rc) { return rc; }
+  if (!sl.h_res) { SJ_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_res), sizeof(scan_result_dev), hipHostMallocDefault)); }
+  if (!sl.ev) { SJ_TRY(ctx, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming)); }
+  hipStream_t s = ctx->stream;
+  SJ_TRY(ctx, hipMemcpyAsync(sl.d_in, e.base + begin, span, hipMemcpyHostToDevice, s));
+  const uint32_t carry = (begin + span < e.len) ? CARRY_MORE : 0u; // the stream goes on behind the span: no end-of-input rule
+  // the split pipeline: a look-ahead scan must not be able to give up (the single-pass kernels' SJGPU_F_INTERNAL needs a re-run)
+  enqueue_stage1(ctx, false, sl.d_in, span, sl.d_idx, sl.d_idx_bytes / sizeof(uint32_t), s, nullptr, scan_origin{0, 0, carry});
+  SJ_ENQUEUED(ctx);
+  ctx->pending_scan_bytes = 0;
+  SJ_TRY(ctx, hipMemcpyAsync(sl.h_res, ctx->d_result, sizeof(scan_result_dev), hipMemcpyDeviceToHost, s));
+  SJ_TRY(ctx, hipEventRecord(sl.ev, s));
+  sl.base = e.base;
+  sl.begin = begin;
+  sl.end = begin + span;
+  sl.state = 1;
+  return 0;
+}
+// Moves a slot towards "ready"; blocking = wait for what is in flight, else only take what has already happened.
+int span_advance(sjgpu_ctx *ctx, sjgpu_ctx::span_slot &sl, bool blocking) {
+  if (sl.state == 1) {
+    if (blocking) { SJ_TRY(ctx, hipEventSynchronize(sl.ev)); }
+    else if (hipEventQuery(sl.ev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    sl.n = sl.h_res->n;
+    const uint32_t flags = sl.h_res->flags;
+    // a control character inside a string or broken UTF-8 SOMEWHERE in the span says nothing about a particular window
+    sl.usable = (flags & (SJGPU_F_UNESCAPED_CTRL | SJGPU_F_UTF8_ERROR | SJGPU_F_INTERNAL | SJGPU_F_IDX_OVERFLOW)) == 0;
+    if (size_t(sl.n) + 8 > sl.h_words) {
+      if (sl.h_idx) { (void)hipHostFree(sl.h_idx); sl.h_idx = nullptr; sl.h_words = 0; }
+      size_t want = size_t(1) << 16;
+      while (want < size_t(sl.n) + 8) { want <<= 1; }
+      SJ_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_idx), want * sizeof(uint32_t), hipHostMallocDefault));
+      sl.h_words = want;
+    }
+    if (sl.n && sl.usable) { SJ_TRY(ctx, hipMemcpyAsync(sl.h_idx, sl.d_idx, size_t(sl.n) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream)); }
+    SJ_TRY(ctx, hipEventRecord(sl.ev, ctx->stream));
+    sl.state = 2;
+  }
+  if (sl.state == 2) {
+    if (blocking) { SJ_TRY(ctx, hipEventSynchronize(sl.ev)); }
+    else if (hipEventQuery(sl.ev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    sl.state = 3;
+  }
+  return 0;
+}
+// does buf[0 .. len) end inside a string, given that its last structural sits at `last`?  Only an OPENING quote is ever a structural.
+bool ends_inside_string(const uint8_t *buf, size_t len, uint32_t last) {
+  if (buf[last] != '"') { return false; }
+  for (size_t j = size_t(last) + 1; j < len; j++) {
+    if (buf[j] == '\\') { j++; }
+    else if (buf[j] == '"') { return false; }
+  }
+  return true;
+}
+// Where the span behind a ready one should begin: the first structural of the document that is still open `window` bytes in front
+// of the span's end -- a position the scan has PROVED to lie outside every string and between tokens (what finish() of a partial
+// batch computes, json_structural_indexer.h:295-333), chosen so that every window of that size which begins in front of it still
+// fits this span.  0 = no such position (no complete document in front of it).
+size_t span_successor(const sjgpu_ctx::span_slot &sl, const stream_extent &e, size_t window) {
+  if (!sl.usable || sl.n < 2 || sl.end >= e.len) { return 0; }
+  const size_t span = sl.end - sl.begin;
+  if (window < (size_t(64) << 10)) { window = size_t(64) << 10; }
+  if (span < 4 * window) { return 0; }
+  const size_t cut = span - window;
+  const uint32_t n_cut = lower_bound_u32(sl.h_idx, sl.n, cut);
+  if (n_cut < 2) { return 0; }
+  const uint8_t *base = e.base + sl.begin;
+  const uint32_t flags = ends_inside_string(base, cut, sl.h_idx[n_cut - 1]) ? SJGPU_F_UNCLOSED_STRING : 0u;
+  uint32_t n_io = 0, next = 0;
+  const uint32_t s0 = sl.h_idx[n_cut], s1 = sl.h_idx[n_cut + 1], s2 = sl.h_idx[n_cut + 2]; // finish() parks its sentinels behind the list it is given
+  const int err = sjgpu_stage1_finish_host(base, cut, SJGPU_STREAMING_PARTIAL, sl.h_idx, n_cut, flags, &n_io, &next);
+  sl.h_idx[n_cut] = s0; sl.h_idx[n_cut + 1] = s1; sl.h_idx[n_cut + 2] = s2;
+  if (err != 0 || n_io == 0 || n_io >= sl.n) { return 0; }
+  return sl.begin + sl.h_idx[n_io];
+}
+
 // *served = false: take the ordinary path.  len is the window's length after the partial-UTF-8 trim.
 int stage1_from_span(sjgpu_ctx *ctx, const stream_extent &e, const uint8_t *buf, size_t len, int mode, uint32_t *idx_out, size_t idx_words, uint32_t *n_io,
                      uint32_t *next_io, bool *served) {
   *served = false;
   const size_t off = size_t(buf - e.base);
-  if (!(ctx->la_base == e.base && off >= ctx->la_begin && off + len <= ctx->la_end)) { // a new span, beginning with this window
-    size_t span = e.len - off;
-    if (span > LA_SPAN) { span = LA_SPAN > len ? LA_SPAN : len; }
-    if (span > 0xFFFFFFF0ull) { return 0; }
-    ctx->la_base = nullptr;
-    int rc = ensure_staging_in(ctx, span);
-    if (rc) { return rc; }
-    size_t idx_bytes = ctx->d_idx_words * sizeof(uint32_t);
-    rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_idx), &idx_bytes, (grown(span) + 16) * sizeof(uint32_t));
-    ctx->d_idx_words = idx_bytes / sizeof(uint32_t);
-    if (rc) { return rc; }
-    hipStream_t s = ctx->stream;
-    SJ_TRY(ctx, hipMemcpyAsync(ctx->d_in, e.base + off, span, hipMemcpyHostToDevice, s));
-    sjgpu_scan_result res{0, 0, 0};
-    const uint32_t carry = (off + span < e.len) ? CARRY_MORE : 0u; // the stream goes on behind the span: no end-of-input rule
-    for (int attempt = 0; attempt < 2; attempt++) {
-      enqueue_stage1(ctx, use_fused(ctx, span, 0) && attempt == 0, ctx->d_in, span, ctx->d_idx, ctx->d_idx_words, s, nullptr, scan_origin{0, 0, carry});
-      SJ_ENQUEUED(ctx);
-      rc = fetch_result(ctx, s, &res);
-      if (rc) { return rc; }
-      if (!(res.flags & SJGPU_F_INTERNAL)) { break; }
+  auto covers = [&](const sjgpu_ctx::span_slot &sl) { return sl.state != 0 && sl.base == e.base && off >= sl.begin && off + len <= sl.end; };
+  if (!covers(ctx->la[ctx->la_cur])) {
+    if (covers(ctx->la[ctx->la_cur ^ 1])) { ctx->la_cur ^= 1; } // the span that was fetched ahead
+    else { // a new span, beginning with this window
+      sjgpu_ctx::span_slot &other = ctx->la[ctx->la_cur ^ 1];
+      if (other.state == 1 || other.state == 2) { SJ_TRY(ctx, hipStreamSynchronize(ctx->stream)); other.state = 0; other.base = nullptr; } // nothing of ours stays in flight
+      const int rc = span_issue(ctx, ctx->la[ctx->la_cur], e, off, len);
+      if (rc || ctx->la[ctx->la_cur].state == 0) { return rc; }
     }
-    if (res.flags & (SJGPU_F_INTERNAL | SJGPU_F_IDX_OVERFLOW)) { return 0; } // not served: the window's own scan will say what is wrong
-    if (size_t(res.n) + 4 > ctx->h_la_words) {
-      if (ctx->h_la_idx) { (void)hipHostFree(ctx->h_la_idx); ctx->h_la_idx = nullptr; ctx->h_la_words = 0; }
-      size_t want = size_t(1) << 16;
-      while (want < size_t(res.n) + 4) { want <<= 1; }
-      SJ_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_la_idx), want * sizeof(uint32_t), hipHostMallocDefault));
-      ctx->h_la_words = want;
-    }
-    if (res.n) {
-      SJ_TRY(ctx, hipMemcpyAsync(ctx->h_la_idx, ctx->d_idx, size_t(res.n) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-      SJ_TRY(ctx, hipStreamSynchronize(s));
-    }
-    ctx->la_base = e.base;
-    ctx->la_begin = off;
-    ctx->la_end = off + span;
-    ctx->la_n = res.n;
-    // a control character inside a string or broken UTF-8 SOMEWHERE in the span says nothing about a particular window
-    ctx->la_usable = (res.flags & (SJGPU_F_UNESCAPED_CTRL | SJGPU_F_UTF8_ERROR)) == 0;
   }
-  if (!ctx->la_usable) { return 0; }
-  const uint64_t rel = off - ctx->la_begin;
-  const uint32_t *list = ctx->h_la_idx;
-  const uint32_t lo = lower_bound_u32(list, ctx->la_n, rel);
-  if (rel != 0 && !(lo < ctx->la_n && list[lo] == rel)) { return 0; } // the window does not begin at a token of the span's scan: not ours to answer
-  const uint32_t hi = lower_bound_u32(list, ctx->la_n, rel + len);
+  sjgpu_ctx::span_slot &sl = ctx->la[ctx->la_cur];
+  const bool fresh = sl.state != 3;
+  int rc = span_advance(ctx, sl, true);
+  if (rc) { return rc; }
+  if (fresh) { // the span has just become readable: fetch the one behind it while the caller works through this one's windows
+    sjgpu_ctx::span_slot &next = ctx->la[ctx->la_cur ^ 1];
+    const size_t at = span_successor(sl, e, len);
+    if (at > sl.begin && !(next.state != 0 && next.base == e.base && next.begin == at)) {
+      rc = span_issue(ctx, next, e, at, 0);
+      if (rc) { return rc; }
+    }
+  } else {
+    rc = span_advance(ctx, ctx->la[ctx->la_cur ^ 1], false); // keep the prefetch moving (its list download waits for its scan)
+    if (rc) { return rc; }
+  }
+  if (!sl.usable) { return 0; }
+  const uint64_t rel = off - sl.begin;
+  const uint32_t *list = sl.h_idx;
+  const uint32_t lo = lower_bound_u32(list, sl.n, rel);
+  if (rel != 0 && !(lo < sl.n && list[lo] == rel)) { return 0; } // the window does not begin at a token of the span's scan: not ours to answer
+  const uint32_t hi = lower_bound_u32(list, sl.n, rel + len);
   const uint32_t n_raw = hi - lo;
   if (size_t(n_raw) + 3 > idx_words) { return SJGPU_E_OVERFLOW; }
   const uint32_t shift = uint32_t(rel);
   for (uint32_t k = 0; k < n_raw; k++) { idx_out[k] = list[lo + k] - shift; }
   // the window's own flag: does it end inside a string?  Only an opening quote is ever a structural, so that is the case iff the last
   // structural is a quote whose closing quote lies beyond the window.
-  uint32_t flags = 0;
-  if (n_raw && buf[idx_out[n_raw - 1]] == '"') {
-    bool closed = false;
-    for (size_t j = size_t(idx_out[n_raw - 1]) + 1; j < len; j++) {
-      if (buf[j] == '\\') { j++; }
-      else if (buf[j] == '"') { closed = true; break; }
-    }
-    if (!closed) { flags |= SJGPU_F_UNCLOSED_STRING; }
-  }
+  const uint32_t flags = (n_raw && ends_inside_string(buf, len, idx_out[n_raw - 1])) ? SJGPU_F_UNCLOSED_STRING : 0u;
   *served = true;
   return sjgpu_stage1_finish_host(buf, len, mode, idx_out, n_raw, flags, n_io, next_io);
 }
@@ -1264,6 +1348,18 @@ int sjgpu_stream_unregister(const uint8_t *base) {
         break;
       }
     }
+  }
+  if (found) { // a span may still be on its way to some device: the caller is about to let go of the bytes
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess) {
+      int before = 0;
+      (void)hipGetDevice(&before);
+      for (int d = 0; d < ndev; d++) {
+        if (hipSetDevice(d) == hipSuccess) { (void)hipDeviceSynchronize(); }
+      }
+      (void)hipSetDevice(before);
+    }
+    (void)hipGetLastError();
   }
   if (pinned) { (void)hipHostUnregister(const_cast<uint8_t *>(base)); }
   return found ? 0 : SJGPU_E_BADARG;
