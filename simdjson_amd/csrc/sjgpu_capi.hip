@@ -151,6 +151,7 @@ struct sjgpu_ctx {
   // host memory, from which the windows document_stream asks for are cut without touching the GPU again
   struct span_slot {
     const uint8_t *base = nullptr; // the registered stream the span belongs to (null: empty slot)
+    uint64_t stream_id = 0;        // ... and the registration it was made under
     size_t begin = 0, end = 0;     // the span, as offsets into the stream
     int state = 0;                 // 0 empty | 1 scan enqueued | 2 list download enqueued | 3 ready
     uint32_t n = 0;
@@ -1152,10 +1153,12 @@ struct stream_extent {
   const uint8_t *base;
   size_t len;
   bool pinned;
+  uint64_t id; // unique per registration: a later stream at the same address must not meet the spans of an earlier one
 };
 struct stream_registry {
   std::mutex m;
   std::vector<stream_extent> list;
+  uint64_t next_id = 1;
 };
 stream_registry &streams() {
   static stream_registry *r = new stream_registry(); // never destroyed (see ctx_pool)
@@ -1205,6 +1208,7 @@ int span_issue(sjgpu_ctx *ctx, sjgpu_ctx::span_slot &sl, const stream_extent &e,
   SJ_TRY(ctx, hipMemcpyAsync(sl.h_res, ctx->d_result, sizeof(scan_result_dev), hipMemcpyDeviceToHost, s));
   SJ_TRY(ctx, hipEventRecord(sl.ev, s));
   sl.base = e.base;
+  sl.stream_id = e.id;
   sl.begin = begin;
   sl.end = begin + span;
   sl.state = 1;
@@ -1273,7 +1277,7 @@ int stage1_from_span(sjgpu_ctx *ctx, const stream_extent &e, const uint8_t *buf,
                      uint32_t *next_io, bool *served) {
   *served = false;
   const size_t off = size_t(buf - e.base);
-  auto covers = [&](const sjgpu_ctx::span_slot &sl) { return sl.state != 0 && sl.base == e.base && off >= sl.begin && off + len <= sl.end; };
+  auto covers = [&](const sjgpu_ctx::span_slot &sl) { return sl.state != 0 && sl.base == e.base && sl.stream_id == e.id && off >= sl.begin && off + len <= sl.end; };
   if (!covers(ctx->la[ctx->la_cur])) {
     if (covers(ctx->la[ctx->la_cur ^ 1])) { ctx->la_cur ^= 1; } // the span that was fetched ahead
     else { // a new span, beginning with this window
@@ -1290,7 +1294,7 @@ int stage1_from_span(sjgpu_ctx *ctx, const stream_extent &e, const uint8_t *buf,
   if (fresh) { // the span has just become readable: fetch the one behind it while the caller works through this one's windows
     sjgpu_ctx::span_slot &next = ctx->la[ctx->la_cur ^ 1];
     const size_t at = span_successor(sl, e, len);
-    if (at > sl.begin && !(next.state != 0 && next.base == e.base && next.begin == at)) {
+    if (at > sl.begin && !(next.state != 0 && next.base == e.base && next.stream_id == e.id && next.begin == at)) {
       rc = span_issue(ctx, next, e, at, 0);
       if (rc) { return rc; }
     }
@@ -1321,14 +1325,15 @@ extern "C" {
 
 int sjgpu_stream_register(const uint8_t *base, size_t len) {
   if (!base || len == 0) { return SJGPU_E_BADARG; }
-  stream_extent e{base, len, false};
+  stream_extent e{base, len, false, 0};
   static const bool pin = []() { const char *v = std::getenv("SJGPU_STREAM_PIN"); return !v || v[0] != '0'; }();
   if (pin && sjgpu_device_count() > 0) { e.pinned = hipHostRegister(const_cast<uint8_t *>(base), len, hipHostRegisterDefault) == hipSuccess; }
   (void)hipGetLastError(); // a range that cannot be page-locked (already registered, read-only mapping) still works, only slower
   stream_registry &r = streams();
   std::lock_guard<std::mutex> lk(r.m);
+  e.id = r.next_id++;
   for (stream_extent &x : r.list) {
-    if (x.base == base) { x.len = len; x.pinned = x.pinned || e.pinned; return 0; }
+    if (x.base == base) { x.len = len; x.pinned = x.pinned || e.pinned; x.id = e.id; return 0; } // registered again: as good as new
   }
   r.list.push_back(e);
   return 0;

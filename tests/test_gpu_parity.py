@@ -1451,5 +1451,15 @@ def test_windows_of_a_registered_stream(orc):
             want = _walk_windows(lambda w, m: orc.stage1(w, m), stream, batch)
             assert [x[:3] for x in want] == [x[:3] for x in plain]
             assert want == plain
+    # a NEW stream at the address of an old one (allocators do that) must not be answered from the old one's spans
+    again = np.ascontiguousarray(small)
+    assert capi.stream_register(again) == 0
+    first = _walk_windows(lambda w, m: g_stage1(p_span, w, m), again, 4096)
+    assert capi.stream_unregister(again) == 0
+    again[:] = np.frombuffer((b'{"k":[1,2,3]}\n' * (len(again) // 14 + 1))[: len(again)], dtype=np.uint8)
+    assert capi.stream_register(again) == 0
+    second = _walk_windows(lambda w, m: g_stage1(p_span, w, m), again, 4096)
+    assert capi.stream_unregister(again) == 0
+    assert second == _walk_windows(lambda w, m: g_stage1(p_plain, w, m), again, 4096) and second != first
     p_plain.close()
     p_span.close()
