@@ -189,6 +189,8 @@ constexpr int E_CAPACITY = 1, E_UTF8 = 11, E_EMPTY = 13, E_UNCLOSED = 15, E_UNEX
 
 int fail(sjgpu_ctx *ctx, hipError_t e, const char *what) {
   if (ctx) { std::snprintf(ctx->err, sizeof ctx->err, "%s: %s", what, hipGetErrorString(e)); }
+  static const bool trace = std::getenv("SJGPU_TRACE_ERRORS") != nullptr; // diagnostics: the library itself never prints otherwise
+  if (trace) { std::fprintf(stderr, "[sjgpu] %s: %s\n", what, hipGetErrorString(e)); }
   return (e == hipErrorOutOfMemory) ? SJGPU_E_NOMEM : SJGPU_E_HIP;
 }
 #define SJ_TRY(ctx, call)                                  \
@@ -1173,6 +1175,7 @@ bool find_stream(const uint8_t *buf, size_t len, stream_extent *out) {
   return false;
 }
 
+constexpr size_t STREAM_PIN_FROM = size_t(8) << 20;
 constexpr size_t LA_WINDOW_MAX = size_t(8) << 20;  // longer windows are worth a scan of their own
 constexpr size_t LA_SPAN = size_t(32) << 20;
 
@@ -1199,7 +1202,10 @@ int span_issue(sjgpu_ctx *ctx, sjgpu_ctx::span_slot &sl, const stream_extent &e,
   if (!sl.h_res) { SJ_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&sl.h_res), sizeof(scan_result_dev), hipHostMallocDefault)); }
   if (!sl.ev) { SJ_TRY(ctx, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming)); }
   hipStream_t s = ctx->stream;
-  SJ_TRY(ctx, hipMemcpyAsync(sl.d_in, e.base + begin, span, hipMemcpyHostToDevice, s));
+  if (hipMemcpyAsync(sl.d_in, e.base + begin, span, hipMemcpyHostToDevice, s) != hipSuccess) {
+    (void)hipGetLastError(); // the runtime refuses this host range: no span, the window takes the ordinary path
+    return 0;
+  }
   const uint32_t carry = (begin + span < e.len) ? CARRY_MORE : 0u; // the stream goes on behind the span: no end-of-input rule
   // the split pipeline: a look-ahead scan must not be able to give up (the single-pass kernels' SJGPU_F_INTERNAL needs a re-run)
   enqueue_stage1(ctx, false, sl.d_in, span, sl.d_idx, sl.d_idx_bytes / sizeof(uint32_t), s, nullptr, scan_origin{0, 0, carry});
@@ -1326,8 +1332,11 @@ extern "C" {
 int sjgpu_stream_register(const uint8_t *base, size_t len) {
   if (!base || len == 0) { return SJGPU_E_BADARG; }
   stream_extent e{base, len, false, 0};
+  // Page-locking pays for itself on streams of many megabytes (the upload of a span runs at twice the rate and truly asynchronously);
+  // small buffers come and go at addresses the allocator hands out again, and registering / unregistering those by the thousand
+  // (the reference's document_stream tests) is what the runtime is not made for: they stay pageable.
   static const bool pin = []() { const char *v = std::getenv("SJGPU_STREAM_PIN"); return !v || v[0] != '0'; }();
-  if (pin && sjgpu_device_count() > 0) { e.pinned = hipHostRegister(const_cast<uint8_t *>(base), len, hipHostRegisterDefault) == hipSuccess; }
+  if (pin && len >= STREAM_PIN_FROM && sjgpu_device_count() > 0) { e.pinned = hipHostRegister(const_cast<uint8_t *>(base), len, hipHostRegisterDefault) == hipSuccess; }
   (void)hipGetLastError(); // a range that cannot be page-locked (already registered, read-only mapping) still works, only slower
   stream_registry &r = streams();
   std::lock_guard<std::mutex> lk(r.m);

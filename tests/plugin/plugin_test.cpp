@@ -260,6 +260,34 @@ int main(int argc, char **argv) {
           (unsigned long long)docs[0], (unsigned long long)bytes[0], (unsigned long long)docs[1], (unsigned long long)bytes[1]);
   }
 
+  // 4b. the same with the stream registered (what document_stream::start() of the in-tree build does): windows cut out of look-ahead
+  //     spans, threaded and tiny batches included (tests/dom/document_stream_tests.cpp: stress_data_race)
+  {
+    get_active_implementation() = gpu;
+    const padded_string tiny = R"([1,23] [1,23] [1,23] [1,23] [1,23] [1,23] [1,23] [1,23] [1,23] [1,23] [1,23] [1,23] [1,23] [1,23] [1,23] )"_padded;
+    struct job { const padded_string *doc; size_t batch; uint64_t expect; };
+    const job jobs[] = {{&tiny, 32, 15}, {&tiny, 64, 15}, {&amazon, 200000, 0}, {&amazon, 1000000, 0}, {&amazon, 5000, 0}};
+    for (const job &j : jobs) {
+      uint64_t counts[2] = {0, 0};
+      for (int registered = 0; registered < 2; registered++) {
+        if (registered) { mi355x::register_stream(reinterpret_cast<const uint8_t *>(j.doc->data()), j.doc->size()); }
+        {
+          dom::parser parser;
+          dom::document_stream stream;
+          CHECK(parser.parse_many(*j.doc, j.batch).get(stream) == SUCCESS, "parse_many");
+          for (auto doc : stream) {
+            CHECK(doc.error() == SUCCESS, "registered %d, batch %zu, document %llu: %s", registered, j.batch, (unsigned long long)counts[registered], error_message(doc.error()));
+            counts[registered]++;
+          }
+        }
+        if (registered) { mi355x::unregister_stream(reinterpret_cast<const uint8_t *>(j.doc->data())); }
+      }
+      CHECK(counts[0] == counts[1] && (j.expect == 0 || counts[0] == j.expect), "registered stream: %llu documents, unregistered %llu", (unsigned long long)counts[1],
+            (unsigned long long)counts[0]);
+    }
+    std::printf("parse_many over registered streams (look-ahead spans): OK\n");
+  }
+
   // 5. free functions minify() / validate_utf8() route to the active implementation
   get_active_implementation() = gpu;
   for (const padded_string *doc : {&twitter, &random, &amazon}) {
