@@ -342,6 +342,22 @@ constexpr u32 NO_TILE = 0xFFFFFFFFu;
 // (sjgpu_debug_trace_pipelined): 0 loop top, 1 ticket known, 2 wave 0 scanned, 3 all scanned, 4 wave 0 published +
 // looked back, 5 prefix broadcast, 6 wave 0 emitted, 7 masks parked.
 constexpr u32 PIPE_TRACE_ITERS = 32;
+// wave priority by phase (s_setprio 0..3): which of the four workgroups of a CU gets the issue slots when a scanning wave (VALU) and an
+// emitting or look-back wave (LDS, stores, descriptor loads) compete.  Policy = bits 24-26 of scan_origin::carry (env SJGPU_PRIO), 0 = leave alone.
+__device__ __forceinline__ void set_prio(u32 p) {
+  switch (p) {
+  case 1: __builtin_amdgcn_s_setprio(1); break;
+  case 2: __builtin_amdgcn_s_setprio(2); break;
+  case 3: __builtin_amdgcn_s_setprio(3); break;
+  default: __builtin_amdgcn_s_setprio(0); break;
+  }
+}
+__device__ __forceinline__ void phase_prio(u32 policy, u32 phase /* 0 scan, 1 look-back, 2 emit */) {
+  if (policy == 0) { return; }
+  // policy: 1 = (0,3,3)  2 = (3,0,0)  3 = (0,3,0)  4 = (0,0,3)  5 = (1,3,2)
+  const u32 table[6][3] = {{0, 0, 0}, {0, 3, 3}, {3, 0, 0}, {0, 3, 0}, {0, 0, 3}, {1, 3, 2}};
+  set_prio(table[policy < 6 ? policy : 0][phase]);
+}
 template <int OP, bool TRACE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fused_pipelined(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc,
                                                          u32 *__restrict__ ticket, u32 ntiles, void *__restrict__ out,
@@ -371,6 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // its hot loop and 10-15 % on EVERY workload (profiles/r02_utf8_dense_ab.txt); text-heavy documents have sparse output, for
   // which AUTO picks the split pipeline, whose summarize kernel has the in-line path
   utf8_queue uq{sh_uq[(OP == 0) ? wave : 0], 0u, 0u, 0u, nullptr, len, (carry & CARRY_MORE) ? 1u : 0u}; // lives across tiles: blocks are validated 64 at a time
+  const u32 prio_policy = (carry >> 24) & 7u;
   u32 pend_tile = NO_TILE; // workgroup-uniform
   // Tickets are drawn one iteration AHEAD (the atomic's round trip, 1.4-2 us of an iteration of 21-27, hides behind
   // the scan): thread 0 keeps the next ticket in a register and hands it over through LDS at the end of the iteration.
@@ -392,6 +409,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     SJ_PSTAMP(1);
 
     // ---- scan the new tile into the register FIFO ------------------------------------------------------------
+    phase_prio(prio_policy, 0);
     u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0; // slot 3 = oldest chunk
     if (have) {
       const u64 wave_start = org.begin + u64(tile) * FUSED_TILE_BYTES + u64(wave) * WAVE_BYTES;
@@ -464,6 +482,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     // ---- wave 0: publish the new tile's aggregate, then resolve the PENDING tile's prefix -------------------------
     if (wave == 0) {
+      phase_prio(prio_policy, 1);
       if (have) {
         u32 tq = 0, tout = 0, tin = 0;
 #pragma unroll
@@ -521,6 +540,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     SJ_PSTAMP(5);
 
     // ---- every wave: emit its share of the pending tile from the LDS masks -----------------------------------------
+    phase_prio(prio_policy, 2);
     if (pend && sh_prefix[2] != 0u) {
       const u64 wave_start = org.begin + u64(pend_tile) * FUSED_TILE_BYTES + u64(wave) * WAVE_BYTES;
       u32 s = sh_prefix[0], base = sh_prefix[1];
@@ -612,6 +632,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
 
   const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   if (wave == 0) { init_compaction_lut(sh_lut, lane); }
+  const u32 prio_policy = (carry >> 24) & 7u;
   u32 pend_tile = NO_TILE;
   u64 pa0 = 0, pa1 = 0, pb0 = 0, pb1 = 0; // the pending tile's masks: droppable-if-outside-a-string, in-string (relative)
   u32 next_ticket = 0;
@@ -626,6 +647,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     if (threadIdx.x == 0 && have) { next_ticket = atomicAdd(ticket, 1u); }
 
     // ---- scan the new tile; its bytes stay in wa / wb until the pending tile has left the LDS ------------------------
+    phase_prio(prio_policy, 0);
     u32 wa[16], wb[16];
     u64 a0 = 0, a1 = 0, b0 = 0, b1 = 0;
     bool park = false;
@@ -716,6 +738,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     __syncthreads();
 
     // ---- every wave: compact its two parked chunks of the pending tile ----------------------------------------------
+    phase_prio(prio_policy, 2);
     if (pend && sh_prefix[2] != 0u) {
       const u64 wave_start = org.begin + u64(pend_tile) * TILE_BYTES + u64(wave) * WAVE_BYTES;
       u32 s = sh_prefix[0], base = sh_prefix[1];
@@ -841,6 +864,9 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
     // half as many workgroups as tiles at most: every workgroup should own >= 2 tiles for the deferral to work
     const u32 cap = (ntiles + 1) / 2;
     const u32 grid = cap < max_workgroups ? cap : max_workgroups;
+    // measured round 3 (profiles/r03_phase_priority.txt): emission at priority 3 (policy 4) is 2.4-2.9 % faster on dense output, nothing else moves
+    static const unsigned prio = []() { const char *v = std::getenv("SJGPU_PRIO"); return v ? unsigned(std::atoi(v)) & 7u : 4u; }(); // A/B switch: phase_prio, 0 = off
+    org.carry |= prio << 24;
     static const bool late_ticket = std::getenv("SJGPU_LATE_TICKET") != nullptr;                                       // A/B switch
     if (late_ticket) { org.carry |= CARRY_DEBUG_LATE_TICKET; }
     static const bool no_hint = std::getenv("SJGPU_NO_SPAN_HINT") != nullptr; // A/B switch
