@@ -37,6 +37,29 @@ struct dev_bytes {
   u32 len;
   __device__ __forceinline__ u32 byte(u32 pos) const { return pos < len ? u32(buf[pos]) : 0x20u; }
 };
+// The same bytes through an 8-byte window in registers: a token is read front to back, so one (unaligned) 8-byte load serves eight
+// byte() calls -- the per-byte loads of the first version were what made k_tape_write the longest kernel of the tape
+// (profiles/r03_tape_kernel_stats.txt: 1.9 ms of 6.5 per 256 MiB document, numbers parsed with a round trip to L2 per digit).
+struct windowed_bytes {
+  const u8 *buf;
+  u32 len;
+  mutable u64 window = 0;
+  mutable u32 at = 0xFFFFFFF0u; // position of the window's first byte (nothing loaded yet)
+  typedef u64 __attribute__((aligned(1))) u64_unaligned;
+  __device__ __forceinline__ u32 byte(u32 pos) const {
+    const u32 d = pos - at;
+    if (d >= 8u) { // also true for pos < at (wraps)
+      at = pos;
+      if (u64(pos) + 8u <= len) { window = *reinterpret_cast<const u64_unaligned *>(buf + pos); }
+      else {
+        window = 0;
+        for (u32 k = 0; k < 8; k++) { window |= u64(pos + k < len ? u32(buf[pos + k]) : 0x20u) << (8u * k); }
+      }
+      return u32(window) & 0xFFu;
+    }
+    return u32(window >> (8u * d)) & 0xFFu;
+  }
+};
 
 __device__ __forceinline__ void report_error(tape_result_dev *res, u64 key) { atomicMin(reinterpret_cast<unsigned long long *>(&res->error_key), (unsigned long long)key); }
 
@@ -195,7 +218,7 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_write(const u8 *__restrict_
   if (g) { report_error(res, error_key(i, rank, g)); }
   const u64 at = 1 + u64(u32(tpos[i]));
   const bool root = i == 0;
-  const dev_bytes src{buf, u32(len)};
+  const windowed_bytes src{buf, u32(len)};
   if (c == '"') {
     if (at < tape_cap) { tape[at] = tape_word('"', str_offsets[i]); } // on_start_string, tape_builder.h:415-419
   } else if (c == ',') {
