@@ -52,8 +52,8 @@ def build_corpus(force=False):
 
 def build_sjgpu(force=False):
     out = os.path.join(_paths.LIB_DIR, "libsjgpu.so")  # always the in-tree default, never an SJGPU_LIB override
-    srcs = _csrc("sjgpu_kernels.hip", "sjgpu_fused.hip", "sjgpu_small.hip", "sjgpu_finish.hip", "sjgpu_strings.hip", "sjgpu_tape.hip", "sjgpu_mgpu.hip", "sjgpu_comm.hip", "sjgpu_capi.hip", "stage1_finish.cpp")
-    deps = srcs + _csrc("sj_block.h", "sj_number.h", "sj_tape_rules.h", "sj_pow5_table.inc", "sjgpu_internal.h", "sjgpu_device.h") + [os.path.join(_paths.INCLUDE_DIR, "sjgpu.h")]
+    srcs = _csrc("sjgpu_kernels.hip", "sjgpu_fused.hip", "sjgpu_small.hip", "sjgpu_finish.hip", "sjgpu_strings.hip", "sjgpu_string_stream.hip", "sjgpu_tape.hip", "sjgpu_mgpu.hip", "sjgpu_comm.hip", "sjgpu_capi.hip", "stage1_finish.cpp")
+    deps = srcs + _csrc("sj_block.h", "sj_number.h", "sj_tape_rules.h", "sj_string_stream.h", "sj_pow5_table.inc", "sjgpu_internal.h", "sjgpu_device.h") + [os.path.join(_paths.INCLUDE_DIR, "sjgpu.h")]
     if force or _stale(out, deps):
         os.makedirs(_paths.LIB_DIR, exist_ok=True)
         _run([HIPCC, f"--offload-arch={GFX_ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",

@@ -1524,8 +1524,8 @@ int sjgpu_parse_strings_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
   if ((reinterpret_cast<uintptr_t>(buf_dev) & 3u) || (reinterpret_cast<uintptr_t>(offsets_dev) & 3u)) { return SJGPU_E_BADARG; }
   if (len > 2400000000ull || n >= 0xFFFFFFF0u) { return E_CAPACITY; } // record offsets are 32 bits: 5 (len + 1) / 3 bytes of records at most
   SJ_TRY(ctx, hipSetDevice(ctx->device));
-  // [result: 32 B][scan scratch][offsets when the caller keeps none]
-  const size_t scratch_at = 32, scratch = (strings_scratch_bytes(n) + 15) & ~size_t(15), offs_at = scratch_at + scratch;
+  // [result: 32 B, padded to 256][scratch of the string pass][offsets when the caller keeps none]
+  const size_t scratch_at = 256, scratch = strings_scratch_bytes(n, len), offs_at = scratch_at + scratch;
   int rc = ensure_tmp(ctx, offs_at + (offsets_dev ? 0 : (size_t(n) + 1) * sizeof(uint32_t)));
   if (rc) { return rc; }
   uint8_t *tmp = static_cast<uint8_t *>(static_cast<void *>(ctx->d_tmp));
@@ -1584,8 +1584,8 @@ int sjgpu_stage2_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const v
   if (n == 0) { return E_EMPTY; } // walk_document: at_eof() (json_iterator.h:126)
   if (len > 2400000000ull || n >= 0xFFFFFFF0u) { return E_CAPACITY; } // the string pass's 32-bit record offsets
   SJ_TRY(ctx, hipSetDevice(ctx->device));
-  // [strings result 32 B][scan scratch of the string pass][string offsets, n + 1 words][tape workspace]
-  const size_t scratch_at = 32, scratch = (strings_scratch_bytes(n) + 255) & ~size_t(255), offs_at = scratch_at + scratch;
+  // [strings result 32 B, padded to 256][scratch of the string pass][string offsets, n + 1 words][tape workspace]
+  const size_t scratch_at = 256, scratch = strings_scratch_bytes(n, len), offs_at = scratch_at + scratch;
   const size_t tape_at = (offs_at + (size_t(n) + 1) * sizeof(uint32_t) + 255) & ~size_t(255);
   int rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_stage2), &ctx->d_stage2_bytes, tape_at + tape_workspace_bytes(n, len));
   if (rc) { return rc; }

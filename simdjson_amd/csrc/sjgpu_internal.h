@@ -182,7 +182,24 @@ struct strings_result_dev {
   uint32_t overflow;  // a record did not fit into the caller's buffer
   uint32_t pad;
 };
-size_t strings_scratch_bytes(uint32_t n);
+// scratch of one string pass, carved from one allocation of strings_scratch_bytes(n, len) bytes (256-byte aligned pieces)
+constexpr size_t STRS_SUMMARY_BYTES = 32, STRS_BASE_BYTES = 16;
+struct strings_scratch {
+  void *ctrl;        // 64 bytes: scan lengths, which path writes the buffer, totals (sjgpu_string_stream.hip: strs_ctrl)
+  int *partial;      // block sums of the scans
+  int *kord;         // n + 1: string tokens in front of every structural
+  uint32_t *outq;    // n + 2: where the k-th string's record begins
+  void *seg_summary; // per 16 KiB segment of the document
+  void *seg_base;
+  uint8_t *esc;      // escape table of the document (launch_escape_table)
+  size_t bytes;
+};
+strings_scratch carve_strings_scratch(void *base, uint32_t n, uint64_t len);
+size_t strings_scratch_bytes(uint32_t n, uint64_t len);
+// the buffer as a stream compaction of the document (sjgpu_string_stream.hip); leaves in the control block whether the
+// per-string kernels have to run instead
+void enqueue_string_stream(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
+                           uint32_t *offsets, strings_result_dev *res, const strings_scratch &w, hipStream_t s);
 void launch_parse_strings(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
                           uint32_t *offsets, strings_result_dev *res, void *scratch, hipStream_t s);
 // ---- the tape (sjgpu_tape.hip) ----------------------------------------------------------------------------------

@@ -1,0 +1,429 @@
+// simdjson_amd/csrc/sjgpu_string_stream.hip -- SURVEY 8(f3): document::string_buf as a stream compaction of the document.
+//
+// The per-string walk of sjgpu_strings.hip gives one LANE one string: loads are gathers, lanes wait for the longest string of
+// their wave, and the pass sits at 4 % of the HBM roofline (profiles/r02_pmc_strings.txt).  But the records of string_buf
+// -- [u32 length][unescaped bytes][0], /root/reference/src/generic/stage2/tape_builder.h:415-433, stringparsing.h:150-193 --
+// follow each other in document order, so the buffer is the DOCUMENT with the bytes outside strings dropped, the quotes
+// replaced by 4 + 1 bytes and the escapes by what they stand for (sj_string_stream.h): the job has the shape of minify.
+// A lane owns 64 bytes, a wave 4 KiB, a wave's share is one 16 KiB segment; loads are the 16-byte row loads of stage 1.
+//   k_strs_count     per segment: output bytes, opening quotes and rejected escapes for both "starts inside / outside a string"
+//   k_strs_resolve   one workgroup: in-string state, output base and string ordinal in front of every segment; totals
+//   k_strs_tokens + scan   which structurals are quotes, and the ordinal of each among them
+//   k_strs_decide    the stream is taken iff every string is valid, every opening quote of the document is a structural (a quote
+//                    glued to a scalar, a"b", is not: such documents are invalid and take the per-string path) and the buffer fits
+//   k_strs_write     the bytes, through a per-wave LDS window (16-byte stores); where every string begins (by ordinal)
+//   k_strs_finalize  per structural: its record offset (CSR, as before) and, for a string, the length word
+// Everything else -- a rejected escape, an unclosed string, unlisted quotes -- is left to k_strings<> (sjgpu_strings.hip), which
+// then runs instead: same results as before for those documents, the fast path for all valid ones.
+#include "sjgpu_device.h"
+#include "sj_string_stream.h"
+
+namespace sjgpu {
+namespace {
+
+constexpr u32 STRS_WAVES = 4; // waves (= segments) per workgroup
+
+struct global_doc {
+  const u8 *buf;
+  u32 len;
+  __device__ __forceinline__ u32 byte(u32 pos) const { return pos < len ? u32(buf[pos]) : 0x20u; }
+};
+
+// per segment, from its bytes alone (hypothesis 0 = the segment starts outside a string)
+struct strs_summary {
+  u32 bytes0, bytes1; // output bytes if it starts outside / inside a string
+  u32 opens0, quotes; // opening quotes if it starts outside; real quotes
+  u32 flags;          // bit 0: odd number of quotes; bit 1 / 2: an escape the reference rejects inside a string if it starts outside / inside
+  u32 pad[3];
+};
+struct strs_base {
+  u32 out;       // output bytes in front of the segment
+  u32 ordinal;   // strings that begin in front of it
+  u32 in_string; // it starts inside a string
+  u32 pad;
+};
+
+struct strs_carry {
+  u32 e; // first byte of the next chunk is escaped
+  u32 s; // inside a string (relative to the segment start in k_strs_count, absolute in k_strs_write)
+  u32 u; // the last 10 bytes: bit k = byte (next chunk) - 10 + k is an escaped 'u'
+};
+struct strs_chunk {
+  u64 quote, in_string; // real quotes; stage 1's in-string mask (opening quote included, closing excluded)
+  string_block b;
+  u64 U;      // escaped 'u' of the lane's block
+  u32 u_prev; // ... of the 10 bytes in front of it
+};
+
+// escaped 'u' among the 10 bytes in front of a segment (bit k = byte start - 10 + k): byte q is one iff it is a 'u' behind a
+// backslash run of odd length
+__device__ __forceinline__ u32 u_tail_before(const u8 *__restrict__ buf, u64 start, u32 lane, u32 lookback, esc_ref esc) {
+  if (start == 0) { return 0; }
+  const u64 um = __ballot(lookback == u32('u')) & 0x3FFull; // lane i holds byte start - 1 - i
+  if (!um) { return 0; }
+  const u64 m = __ballot(lookback == 0x5Cu);
+  u32 r = 0;
+  for (u64 t = um; t; t &= t - 1) { // wave-uniform
+    const u32 j = ctz64(t);
+    if (run_parity_from_mask(buf, start, lane, m, j + 1u, esc)) { r |= 1u << (9u - j); }
+  }
+  return r;
+}
+
+// one chunk: stage 1's escape and quote algebra (scan_chunk, sjgpu_device.h), then what the strings need on top of it
+__device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carry &wc, u32 lane, const global_doc &src, u32 block_pos, bool allow) {
+  const planes P = transpose64(w);
+  const classes c = classify(P);
+  const u64 lt = lanemask_lt(lane);
+  strs_chunk out;
+  u64 escaped = 0;
+  const bool any_backslash = (__ballot(c.backslash != 0) | u64(wc.e)) != 0; // wave-uniform
+  if (any_backslash) {
+    const bool all_bs = (c.backslash == ~0ull);
+    const u32 own_out = all_bs ? 0u : (clz64(~c.backslash) & 1u);
+    const u64 passm = __ballot(all_bs), setm = __ballot(own_out != 0);
+    const u64 below = ~passm & lt;
+    const u32 e_in = below ? u32((setm >> (63u - clz64(below))) & 1ull) : wc.e;
+    u64 unused;
+    escaped = escaped_mask(c.backslash, u64(e_in), unused);
+    const u64 nonpass = ~passm;
+    wc.e = nonpass ? u32((setm >> (63u - clz64(nonpass))) & 1ull) : wc.e;
+  }
+  out.quote = andn(c.quote, escaped);
+  const u64 parm = __ballot((popc64(out.quote) & 1) != 0);
+  const u32 s_in = (u32(popc64(parm & lt)) & 1u) ^ wc.s;
+  wc.s ^= u32(popc64(parm)) & 1u;
+  out.in_string = prefix_xor(out.quote) ^ (0 - u64(s_in));
+  out.b = no_escapes(out.quote);
+  out.U = 0;
+  out.u_prev = 0;
+  u32 u_out = 0;
+  if (any_backslash || wc.u) { // wave-uniform; a backslash in the last byte of a block escapes nothing INSIDE the block but is dropped
+    const escape_classes ec = classify_escapes(P);
+    out.b = simple_escapes(c.backslash, escaped, out.quote, ec);
+    out.U = escaped & ec.u;
+    const u32 top = u32(out.U >> 54);
+    if (__ballot(out.U != 0) | u64(wc.u)) { // wave-uniform: a \u escape somewhere in the chunk or just in front of it
+      u32 prev = u32(__shfl_up(int(top), 1));
+      if (lane == 0) { prev = wc.u; }
+      out.u_prev = prev;
+      if (out.U | u64(prev)) {
+        no_patches none;
+        unicode_escapes(src, block_pos, out.U, prev, allow, out.b, none);
+      }
+    }
+    u_out = readlane(top, 63);
+  }
+  wc.u = u_out;
+  return out;
+}
+
+// ---- pass 1: what every segment contributes, for both carry-ins ------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_count(const u8 *__restrict__ buf, u64 len, u32 nseg, u32 allow_replacement, const u8 *__restrict__ esc_tab,
+                                                               strs_summary *__restrict__ summ) {
+  const u32 lane = threadIdx.x & 63u;
+  const u32 seg = blockIdx.x * STRS_WAVES + (threadIdx.x >> 6);
+  if (seg >= nseg) { return; }
+  const u64 seg_start = u64(seg) * SEG_BYTES;
+  const global_doc src{buf, u32(len)};
+  const esc_ref esc(esc_tab);
+  const u32 lookback = lookback_issue(buf, seg_start, lane);
+  strs_carry wc{0u, 0u, 0u};
+  u32 d0 = 0, dall = 0, o0 = 0, qall = 0;
+  u64 bad0 = 0, bad1 = 0;
+  for (u32 c = 0; c < SEG_CHUNKS; c++) {
+    const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
+    if (cstart >= len) { break; }
+    const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
+    u32 w[16];
+    if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
+    else { load_block(buf, pos, len, w); }
+    if (c == 0) {
+      wc.e = segment_carry_from(buf, seg_start, lane, lookback, esc).e;
+      wc.u = u_tail_before(buf, seg_start, lane, lookback, esc);
+    }
+    const strs_chunk m = string_chunk(w, wc, lane, src, u32(pos), allow_replacement != 0);
+    d0 += u32(popc64(m.b.keep & m.in_string));
+    dall += u32(popc64(m.b.keep));
+    o0 += u32(popc64(m.quote & m.in_string));
+    qall += u32(popc64(m.quote));
+    bad0 |= m.b.bad & m.in_string & ~m.quote;
+    bad1 |= m.b.bad & ~m.in_string & ~m.quote;
+  }
+  d0 = wave_sum(d0);
+  dall = wave_sum(dall);
+  o0 = wave_sum(o0);
+  qall = wave_sum(qall);
+  const u64 any0 = __ballot(bad0 != 0), any1 = __ballot(bad1 != 0);
+  if (lane == 0) {
+    strs_summary s;
+    s.bytes0 = d0 + 4u * o0 + (qall - o0);
+    s.bytes1 = (dall - d0) + 4u * (qall - o0) + o0;
+    s.opens0 = o0;
+    s.quotes = qall;
+    s.flags = (qall & 1u) | (any0 ? 2u : 0u) | (any1 ? 4u : 0u);
+    s.pad[0] = 0; s.pad[1] = 0; s.pad[2] = 0;
+    summ[seg] = s;
+  }
+}
+
+// ---- pass 2: one workgroup walks the segment summaries ------------------------------------------------------------------------------------
+struct strs_ctrl {
+  u32 n1_scan;   // entries of the ordinal scan (n + 1)
+  u32 n1_old;    // entries of the per-string path's scan: n + 1 if it runs, else 0 (its scan kernels then do nothing)
+  u32 go_stream; // the stream writes the buffer
+  u32 go_old;    // the per-string kernels write it
+  u32 opens;     // opening quotes of the document
+  u32 bad;       // a rejected escape inside a string, or the document ends inside one
+  u64 total;     // output bytes
+};
+constexpr u32 RES_THREADS = 1024;
+__global__ __launch_bounds__(RES_THREADS) void k_strs_resolve(const strs_summary *__restrict__ summ, u32 nseg, strs_base *__restrict__ base, strs_ctrl *__restrict__ ctrl) {
+  __shared__ u64 sh_bytes[RES_THREADS];
+  __shared__ u32 sh_opens[RES_THREADS], sh_par[RES_THREADS], sh_bad[RES_THREADS];
+  const u32 t = threadIdx.x;
+  const u32 per = (nseg + RES_THREADS - 1) / RES_THREADS;
+  const u32 lo = min(t * per, nseg), hi = min(lo + per, nseg);
+  u32 par = 0;
+  for (u32 i = lo; i < hi; i++) { par ^= summ[i].flags & 1u; }
+  sh_par[t] = par;
+  __syncthreads();
+  for (u32 d = 1; d < RES_THREADS; d <<= 1) {
+    const u32 x = t >= d ? sh_par[t - d] : 0u;
+    __syncthreads();
+    sh_par[t] ^= x;
+    __syncthreads();
+  }
+  const u32 s_start = sh_par[t] ^ par; // exclusive
+  u32 s = s_start, opens = 0, bad = 0;
+  u64 bytes = 0;
+  for (u32 i = lo; i < hi; i++) {
+    const strs_summary v = summ[i];
+    bytes += s ? v.bytes1 : v.bytes0;
+    opens += s ? v.quotes - v.opens0 : v.opens0;
+    bad |= s ? (v.flags >> 2) & 1u : (v.flags >> 1) & 1u;
+    s ^= v.flags & 1u;
+  }
+  sh_bytes[t] = bytes;
+  sh_opens[t] = opens;
+  sh_bad[t] = bad;
+  __syncthreads();
+  for (u32 d = 1; d < RES_THREADS; d <<= 1) {
+    const u64 xb = t >= d ? sh_bytes[t - d] : 0ull;
+    const u32 xo = t >= d ? sh_opens[t - d] : 0u, xe = t >= d ? sh_bad[t - d] : 0u;
+    __syncthreads();
+    sh_bytes[t] += xb;
+    sh_opens[t] += xo;
+    sh_bad[t] |= xe;
+    __syncthreads();
+  }
+  u64 run_bytes = sh_bytes[t] - bytes;
+  u32 run_opens = sh_opens[t] - opens;
+  s = s_start;
+  for (u32 i = lo; i < hi; i++) {
+    const strs_summary v = summ[i];
+    base[i] = strs_base{u32(run_bytes), run_opens, s, 0u};
+    run_bytes += s ? v.bytes1 : v.bytes0;
+    run_opens += s ? v.quotes - v.opens0 : v.opens0;
+    s ^= v.flags & 1u;
+  }
+  if (t == RES_THREADS - 1) {
+    ctrl->total = sh_bytes[t];
+    ctrl->opens = sh_opens[t];
+    ctrl->bad = sh_bad[t] | sh_par[t]; // the last thread's inclusive parity = the state behind the last byte
+  }
+}
+
+// ---- the structural list: which tokens are strings ------------------------------------------------------------------------------------------
+constexpr u32 TOK_THREADS = 256;
+__global__ __launch_bounds__(TOK_THREADS) void k_strs_tokens(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, int *__restrict__ isq) {
+  const u64 i = u64(blockIdx.x) * TOK_THREADS + threadIdx.x;
+  if (i > n) { return; }
+  int q = 0;
+  if (i < n) {
+    const u32 pos = idx[i];
+    q = (pos < len && buf[pos] == '"') ? 1 : 0;
+  }
+  isq[i] = q; // isq[n] = 0: the scan leaves the number of string tokens there
+}
+
+__global__ void k_strs_decide(strs_ctrl *__restrict__ ctrl, const int *__restrict__ kord, u32 n, u64 out_cap, u32 *__restrict__ outq, strings_result_dev *__restrict__ res) {
+  const u32 listed = u32(kord[n]);
+  const bool ok = ctrl->bad == 0 && listed == ctrl->opens;
+  if (ok && ctrl->total > out_cap) {
+    res->overflow = 1;
+    ctrl->go_stream = 0;
+    ctrl->go_old = 0;
+    ctrl->n1_old = 0;
+    return;
+  }
+  ctrl->go_stream = ok ? 1u : 0u;
+  ctrl->go_old = ok ? 0u : 1u;
+  ctrl->n1_old = ok ? 0u : n + 1u;
+  if (ok) {
+    outq[listed] = u32(ctrl->total); // behind the last record
+    res->bytes = ctrl->total;
+    res->strings = listed;
+  }
+}
+
+// ---- pass 3: the bytes ----------------------------------------------------------------------------------------------------------------------
+// A chunk's output: at most 2.5 bytes per input byte ("" -> 5), plus the skew that lines the window up with the destination
+constexpr u32 STRS_WINDOW = 16 + (CHUNK_BYTES / 2) * 5 + 16;
+constexpr u32 STRS_STAGE_BYTES = STRS_WINDOW + 64; // + one dump byte per lane (stores of bytes that are not kept land there)
+
+// window offset of the lane's byte p: one slot per kept byte and closing quote in front of it, four per opening quote
+struct window_map {
+  u32 lane_off;
+  u64 one, open;
+  __device__ __forceinline__ u32 at(u32 p) const {
+    const u64 below = (u64(1) << p) - 1;
+    return lane_off + u32(popc64(one & below)) + 4u * u32(popc64(open & below));
+  }
+};
+struct window_patches {
+  u8 *stage;
+  window_map map;
+  u64 kept; // data bytes of the lane
+  __device__ __forceinline__ void patch(u32 p, u32 v) {
+    if ((kept >> p) & 1u) { stage[map.at(p)] = u8(v); }
+  }
+};
+
+__global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__restrict__ buf, u64 len, u32 nseg, u32 allow_replacement, const u8 *__restrict__ esc_tab,
+                                                               const strs_base *__restrict__ base, const strs_ctrl *__restrict__ ctrl, u8 *__restrict__ out,
+                                                               u32 *__restrict__ outq) {
+  __shared__ __attribute__((aligned(16))) u8 sh_stage[STRS_WAVES][STRS_STAGE_BYTES];
+  if (ctrl->go_stream == 0) { return; }
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const u32 seg = blockIdx.x * STRS_WAVES + wave;
+  if (seg >= nseg) { return; }
+  u8 *const stage = sh_stage[wave];
+  u8 *const dump = stage + STRS_WINDOW + lane;
+  const u64 seg_start = u64(seg) * SEG_BYTES;
+  const global_doc src{buf, u32(len)};
+  const esc_ref esc(esc_tab);
+  const bool allow = allow_replacement != 0;
+  const u32 lookback = lookback_issue(buf, seg_start, lane);
+  const strs_base sb = base[seg];
+  strs_carry wc{0u, sb.in_string, 0u};
+  u32 out_base = sb.out, ordinal = sb.ordinal;
+  for (u32 c = 0; c < SEG_CHUNKS; c++) {
+    const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
+    if (cstart >= len) { break; }
+    const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
+    u32 w[16];
+    if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
+    else { load_block(buf, pos, len, w); }
+    if (c == 0) {
+      wc.e = segment_carry_from(buf, seg_start, lane, lookback, esc).e;
+      wc.u = u_tail_before(buf, seg_start, lane, lookback, esc);
+    }
+    const strs_chunk m = string_chunk(w, wc, lane, src, u32(pos), allow);
+    const u64 kept = m.b.keep & m.in_string;       // data bytes
+    const u64 open = m.quote & m.in_string;         // 4 bytes each: the length, written by k_strs_finalize
+    const u64 one = kept | andn(m.quote, m.in_string); // one byte each: data, and the 0 a closing quote turns into
+    const u64 closing = andn(m.quote, m.in_string);
+    const u32 cnt = u32(popc64(one)) + 4u * u32(popc64(open));
+    const u32 incl = wave_incl_scan(cnt);
+    const u32 total = readlane(incl, 63);
+    const u32 nopen = u32(popc64(open));
+    const u32 oincl = wave_incl_scan(nopen);
+    if (total) {
+      const u32 skew = out_base & 15u; // window offset and destination address agree modulo 16
+      const window_map map{skew + (incl - cnt), one, open};
+      // where the strings of this lane begin
+      {
+        u32 k = ordinal + (oincl - nopen);
+        for (u64 t = open; t; t &= t - 1) { outq[k++] = out_base + (map.at(ctz64(t)) - skew); }
+      }
+      // the bytes: one LDS store per input byte (those that are dropped go to the lane's dump byte)
+      u32 off = map.lane_off;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const int i = 4 * j + b;
+          const u32 is_one = u32(one >> i) & 1u, is_open = u32(open >> i) & 1u, is_close = u32(closing >> i) & 1u;
+          const u32 v = is_close ? 0u : ((w[j] >> (8 * b)) & 0xFFu);
+          u8 *const at = is_one ? stage + off : dump;
+          *at = u8(v);
+          off += is_one + 4u * is_open;
+        }
+      }
+      wave_lds_fence();
+      // the few bytes whose value is not the input's: escaped b f n r t, and what \u escapes stand for
+      for (u64 t = m.b.remap & kept; t; t &= t - 1) {
+        const u32 p = ctz64(t);
+        stage[map.at(p)] = u8(simple_escape_value(src.byte(u32(pos) + p)));
+      }
+      if (m.U | u64(m.u_prev)) {
+        window_patches sink{stage, map, kept};
+        string_block ignored = m.b;
+        unicode_escapes(src, u32(pos), m.U, m.u_prev, allow, ignored, sink);
+      }
+      wave_lds_fence();
+      // the window leaves as 16-byte stores (emit_bytes' write-out); the 4-byte holes of the lengths carry whatever the window held
+      u8 *const g0 = out + (u64(out_base) - skew);
+      const u32 end = skew + total;
+      const u32 v_first = (skew + 15u) >> 4, v_last = end >> 4;
+      if (v_last > v_first) {
+#pragma unroll 1
+        for (u32 v = v_first + lane; v < v_last; v += 64) {
+          *reinterpret_cast<uint4 *>(g0 + 16u * v) = *reinterpret_cast<const uint4 *>(stage + 16u * v);
+        }
+        if (skew + lane < 16u * v_first) { g0[skew + lane] = stage[skew + lane]; }
+        if (16u * v_last + lane < end) { g0[16u * v_last + lane] = stage[16u * v_last + lane]; }
+      } else {
+#pragma unroll 1
+        for (u32 i = skew + lane; i < end; i += 64) { g0[i] = stage[i]; }
+      }
+      wave_lds_fence();
+      out_base += total;
+      ordinal += readlane(oincl, 63);
+    }
+  }
+}
+
+// ---- pass 4: per structural -------------------------------------------------------------------------------------------------------------
+typedef u32 __attribute__((aligned(1))) u32_any; // gfx950 stores a dword at any byte address
+__global__ __launch_bounds__(TOK_THREADS) void k_strs_finalize(const int *__restrict__ kord, u32 n, const u32 *__restrict__ outq, const strs_ctrl *__restrict__ ctrl,
+                                                              u32 *__restrict__ offsets, u8 *__restrict__ out) {
+  if (ctrl->go_stream == 0) { return; }
+  const u64 i = u64(blockIdx.x) * TOK_THREADS + threadIdx.x;
+  if (i > n) { return; }
+  const u32 k = u32(kord[i]);
+  const u32 at = outq[k];
+  offsets[i] = at; // CSR: a structural that is no string has an empty record where the next one begins
+  if (i < n && u32(kord[i + 1]) != k) { *reinterpret_cast<u32_any *>(out + at) = outq[k + 1] - at - 5u; }
+}
+
+} // namespace
+
+// scratch of the stream (carved by sjgpu_strings.hip): see strings_scratch in sjgpu_internal.h
+void enqueue_string_stream(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
+                           uint32_t *offsets, strings_result_dev *res, const strings_scratch &w, hipStream_t s) {
+  strs_ctrl *ctrl = static_cast<strs_ctrl *>(w.ctrl);
+  static_assert(sizeof(strs_ctrl) <= 64, "the control block has 64 bytes");
+  static_assert(sizeof(strs_summary) == STRS_SUMMARY_BYTES && sizeof(strs_base) == STRS_BASE_BYTES, "strings_scratch_bytes counts on these");
+  const u32 nseg = num_segments(len), n1 = n + 1;
+  const u32 a = allow_replacement ? 1u : 0u;
+  (void)hipMemsetAsync(ctrl, 0, 64, s);
+  (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&ctrl->n1_scan), int(n1), 1, s);
+  strs_summary *summ = static_cast<strs_summary *>(w.seg_summary);
+  strs_base *base = static_cast<strs_base *>(w.seg_base);
+  if (nseg) {
+    launch_escape_table(buf, 0, len, w.esc, s);
+    hipLaunchKernelGGL(k_strs_count, dim3((nseg + STRS_WAVES - 1) / STRS_WAVES), dim3(64 * STRS_WAVES), 0, s, buf, len, nseg, a, w.esc, summ);
+  }
+  hipLaunchKernelGGL(k_strs_resolve, dim3(1), dim3(RES_THREADS), 0, s, summ, nseg, base, ctrl);
+  hipLaunchKernelGGL(k_strs_tokens, dim3(u32((u64(n1) + TOK_THREADS - 1) / TOK_THREADS)), dim3(TOK_THREADS), 0, s, buf, len, idx, n, w.kord);
+  enqueue_scan(w.kord, n1, &ctrl->n1_scan, w.partial, s);
+  hipLaunchKernelGGL(k_strs_decide, dim3(1), dim3(1), 0, s, ctrl, w.kord, n, out_cap, w.outq, res);
+  if (nseg) {
+    hipLaunchKernelGGL(k_strs_write, dim3((nseg + STRS_WAVES - 1) / STRS_WAVES), dim3(64 * STRS_WAVES), 0, s, buf, len, nseg, a, w.esc, base, ctrl, out, w.outq);
+  }
+  hipLaunchKernelGGL(k_strs_finalize, dim3(u32((u64(n1) + TOK_THREADS - 1) / TOK_THREADS)), dim3(TOK_THREADS), 0, s, w.kord, n, w.outq, ctrl, offsets, out);
+}
+
+} // namespace sjgpu

@@ -14,6 +14,8 @@
 // Bytes at or beyond len read as 0x20, like the padding of a padded_string.
 #include "sjgpu_device.h"
 
+#include <cstdlib>
+
 namespace sjgpu {
 namespace {
 
@@ -277,7 +279,9 @@ constexpr u32 STR_TILE = 2048, STR_SHORT = 28, STR_MEDIUM = 192;
 //                structural i's record, 0 = it has none; offsets[n] = bytes used); the records are written.
 template <bool WRITE>
 __global__ __launch_bounds__(STR_THREADS) void k_strings(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, u32 allow_replacement,
-                                                       u32 *__restrict__ sizes_or_offsets, u8 *__restrict__ out, u64 out_cap, strings_result_dev *__restrict__ res) {
+                                                       u32 *__restrict__ sizes_or_offsets, u8 *__restrict__ out, u64 out_cap, strings_result_dev *__restrict__ res,
+                                                       const u32 *__restrict__ go) {
+  if (*go == 0) { return; } // the stream (sjgpu_string_stream.hip) has written the buffer
   constexpr u32 PER_THREAD = STR_TILE / STR_THREADS;
   __shared__ unsigned short sh_short[STR_TILE], sh_medium[STR_TILE], sh_long[STR_TILE]; // positions inside the tile
   __shared__ u32 sh_stage[STR_THREADS][STAGE_DWORDS + 1];          // a lane's row; the odd stride keeps the rows on different banks
@@ -469,21 +473,49 @@ void launch_match_keys(const uint8_t *buf, uint64_t len, const uint32_t *idx, ui
                      reinterpret_cast<const u32 *>(names_block), names_block + size_t(K) * sizeof(u32), K, out, matches);
 }
 
-size_t strings_scratch_bytes(uint32_t n) { return 64 + (size_t(n) / 4096 + 72) * 4; }
+static inline size_t up256(size_t x) { return (x + 255) & ~size_t(255); }
+strings_scratch carve_strings_scratch(void *base, uint32_t n, uint64_t len) {
+  uint8_t *b = static_cast<uint8_t *>(base);
+  const size_t nseg = num_segments(len);
+  strings_scratch w;
+  size_t at = 0;
+  w.ctrl = b + at; at += 256;
+  w.partial = reinterpret_cast<int *>(b + at); at += up256((size_t(n) / 4096 + 72) * 4);
+  w.kord = reinterpret_cast<int *>(b + at); at += up256((size_t(n) + 2) * 4);
+  w.outq = reinterpret_cast<uint32_t *>(b + at); at += up256((size_t(n) + 2) * 4);
+  w.seg_summary = b + at; at += up256(nseg * STRS_SUMMARY_BYTES);
+  w.seg_base = b + at; at += up256(nseg * STRS_BASE_BYTES);
+  w.esc = b + at; at += up256(nseg + 64);
+  w.bytes = at;
+  return w;
+}
+size_t strings_scratch_bytes(uint32_t n, uint64_t len) { return carve_strings_scratch(nullptr, n, len).bytes; }
 
-// scratch: strings_scratch_bytes(n); offsets: n + 1 words; everything asynchronous on `s`
+// scratch: strings_scratch_bytes(n, len), 256-byte aligned; offsets: n + 1 words; everything asynchronous on `s`.
+// Two roads to the same buffer: the stream compaction of sjgpu_string_stream.hip for documents whose strings are all valid and all
+// listed, the per-string kernels above for the rest (the decision is taken on the device: the kernels of the road not taken return
+// at once, its scan runs over zero entries).
 void launch_parse_strings(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
                           uint32_t *offsets, strings_result_dev *res, void *scratch, hipStream_t s) {
-  u32 *n_ptr = static_cast<u32 *>(scratch);
-  int *partial = reinterpret_cast<int *>(n_ptr + 4);
+  const strings_scratch w = carve_strings_scratch(scratch, n, len);
   const u32 n1 = n + 1;
   (void)hipMemsetAsync(res, 0, sizeof(strings_result_dev), s);
   (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&res->first_bad), int(NO_STRING), 1, s);
-  (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(n_ptr), int(n1), 1, s);
+  enqueue_string_stream(buf, len, idx, n, allow_replacement, out, out_cap, offsets, res, w, s);
+  const u32 *ctrl = static_cast<const u32 *>(w.ctrl); // strs_ctrl: [1] = entries of this path's scan, [3] = it runs
+  static const bool stream_off = std::getenv("SJGPU_STRING_STREAM") != nullptr && std::getenv("SJGPU_STRING_STREAM")[0] == '0'; // A/B switch
+  if (stream_off) { // force the per-string kernels: overwrite the verdict
+    u32 *c = static_cast<u32 *>(w.ctrl);
+    (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c), int(n1), 2, s);
+    (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c + 2), 0, 1, s);
+    (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c + 3), 1, 1, s);
+    (void)hipMemsetAsync(res, 0, sizeof(strings_result_dev), s);
+    (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&res->first_bad), int(NO_STRING), 1, s);
+  }
   const u32 grid = u32((u64(n1) + STR_TILE - 1) / STR_TILE);
-  hipLaunchKernelGGL(k_strings<false>, dim3(grid), dim3(STR_THREADS), 0, s, buf, len, idx, n, allow_replacement ? 1u : 0u, offsets, out, out_cap, res);
-  enqueue_scan(reinterpret_cast<int *>(offsets), n1, n_ptr, partial, s);
-  hipLaunchKernelGGL(k_strings<true>, dim3(grid), dim3(STR_THREADS), 0, s, buf, len, idx, n, allow_replacement ? 1u : 0u, offsets, out, out_cap, res);
+  hipLaunchKernelGGL(k_strings<false>, dim3(grid), dim3(STR_THREADS), 0, s, buf, len, idx, n, allow_replacement ? 1u : 0u, offsets, out, out_cap, res, ctrl + 3);
+  enqueue_scan(reinterpret_cast<int *>(offsets), n1, ctrl + 1, w.partial, s);
+  hipLaunchKernelGGL(k_strings<true>, dim3(grid), dim3(STR_THREADS), 0, s, buf, len, idx, n, allow_replacement ? 1u : 0u, offsets, out, out_cap, res, ctrl + 3);
 }
 
 } // namespace sjgpu
