@@ -141,6 +141,11 @@ int sjgpu_debug_trace_stage1(sjgpu_ctx *ctx, const void *buf_dev, size_t len, vo
 int sjgpu_debug_trace_pipelined(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *idx_dev, size_t idx_words,
                                 uint64_t *trace_host, uint32_t max_records, uint32_t *workgroups_out);
 
+/* Diagnostics: which kernels produced the string buffer of the context's last sjgpu_parse_strings_device / sjgpu_stage2_device /
+ * sjgpu_parse call: 1 = the stream compaction of the document (every string valid and listed: sjgpu_string_stream.hip),
+ * 2 = the per-string walk (a string the reference rejects, an unclosed string, or a quote glued to a scalar), 0 = none yet. */
+int sjgpu_debug_string_path(const sjgpu_ctx *ctx);
+
 /* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).  While enabled,
  * each *_device call brackets every kernel it enqueues with events (up to 4096 calls are retained);
  * sjgpu_profile_read waits for the stream, adds the elapsed milliseconds per kernel slot into

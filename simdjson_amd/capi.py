@@ -28,7 +28,7 @@ EXPORTS = [
     "sjgpu_clean_cut", "sjgpu_string_parity_device", "sjgpu_stage1_shard_device", "sjgpu_minify_shard_device",
     "sjgpu_stage1_range_device", "sjgpu_minify_range_device",
     "sjgpu_host_alloc", "sjgpu_host_free", "sjgpu_host_register", "sjgpu_host_unregister", "sjgpu_last_pipeline",
-    "sjgpu_profile_kernel", "sjgpu_debug_trace_pipelined", "sjgpu_stage1_many", "sjgpu_stage1_finish_device",
+    "sjgpu_profile_kernel", "sjgpu_debug_trace_pipelined", "sjgpu_debug_string_path", "sjgpu_stage1_many", "sjgpu_stage1_finish_device",
     "sjgpu_depth_scan_device", "sjgpu_parse_strings_device", "sjgpu_stage2_device", "sjgpu_parse", "sjgpu_pool_trim", "sjgpu_stream_register", "sjgpu_stream_unregister", "sjgpu_match_keys_device", "sjgpu_comm_unique_id", "sjgpu_comm_create", "sjgpu_comm_destroy", "sjgpu_comm_last_error", "sjgpu_comm_gather_indices", "sjgpu_mgpu_create", "sjgpu_mgpu_destroy", "sjgpu_mgpu_count", "sjgpu_mgpu_stage1", "sjgpu_mgpu_minify",
     "sjgpu_mgpu_validate_utf8",
 ]
@@ -102,6 +102,8 @@ def load_library():
     L.sjgpu_stage1_finish_host.argtypes = [vp, sz, ctypes.c_int, vp, ctypes.c_uint32, ctypes.c_uint32, u32p, u32p]
     L.sjgpu_debug_trace_stage1.restype = ctypes.c_int
     L.sjgpu_debug_trace_stage1.argtypes = [vp, vp, sz, vp, sz, vp, ctypes.c_uint32]
+    L.sjgpu_debug_string_path.restype = ctypes.c_int
+    L.sjgpu_debug_string_path.argtypes = [vp]
     L.sjgpu_debug_trace_pipelined.restype = ctypes.c_int
     L.sjgpu_debug_trace_pipelined.argtypes = [vp, vp, sz, vp, sz, vp, ctypes.c_uint32, u32p]
     L.sjgpu_stage1_many.restype = ctypes.c_int
@@ -364,6 +366,10 @@ class DomParserImplementation:
         if rc < 0:
             raise SjgpuError(f"sjgpu_parse_strings_device error {rc}: {self.last_error()}")
         return rc, int(used.value), int(cnt.value), int(bad.value)
+
+    def string_path(self):
+        """sjgpu_debug_string_path: 1 = the last string buffer came from the stream compaction, 2 = from the per-string walk"""
+        return int(self.L.sjgpu_debug_string_path(self.h))
 
     def match_keys_device(self, buf_ptr, length, idx_ptr, n, names, match_ptr, stream=0):
         """sjgpu_match_keys_device: names = list of bytes; match_ptr -> n uint32 on the device.  Returns the number of matching keys."""

@@ -165,6 +165,7 @@ struct sjgpu_ctx {
     scan_result_dev *h_res = nullptr; // page-locked copy of the scan's result
     hipEvent_t ev = nullptr;
   } la[2];
+  uint32_t last_string_path = 0; // strings_result_dev::path of the last string pass (sjgpu_debug_string_path)
   int la_cur = 0; // the slot windows are being cut from; the other one holds (or awaits) the span behind it
   // overlapped host-buffer path (large documents): one copy thread per direction, one "range uploaded" event per range
   std::vector<copy_worker *> up, down; // range k travels on up[k % up.size()]; output piece k on down[k % down.size()]
@@ -1538,12 +1539,15 @@ int sjgpu_parse_strings_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
   strings_result_dev h;
   SJ_TRY(ctx, hipMemcpyAsync(&h, res, sizeof(h), hipMemcpyDeviceToHost, s));
   SJ_TRY(ctx, hipStreamSynchronize(s));
+  ctx->last_string_path = h.path;
   if (bytes_out) { *bytes_out = h.bytes; }
   if (strings_out) { *strings_out = h.strings; }
   if (first_bad_out) { *first_bad_out = h.first_bad; }
   if (h.overflow) { return SJGPU_E_OVERFLOW; }
   return h.first_bad != 0xFFFFFFFFu ? 5 /* STRING_ERROR */ : 0;
 }
+
+int sjgpu_debug_string_path(const sjgpu_ctx *ctx) { return ctx ? int(ctx->last_string_path) : SJGPU_E_BADARG; }
 
 // ---- On-Demand's raw key comparison (sjgpu_strings.hip) ---------------------------------------------------------------------------------
 int sjgpu_match_keys_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const void *idx_dev, uint32_t n, const uint8_t *names, const uint32_t *name_lens,
@@ -1593,16 +1597,18 @@ int sjgpu_stage2_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const v
   strings_result_dev *sres = reinterpret_cast<strings_result_dev *>(ws);
   uint32_t *offsets = reinterpret_cast<uint32_t *>(ws + offs_at);
   hipStream_t s = pick(ctx, stream);
-  launch_parse_strings(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, false, static_cast<uint8_t *>(string_buf_dev),
-                       string_buf_bytes, offsets, sres, ws + scratch_at, s);
-  launch_tape(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, max_depth, offsets, static_cast<uint64_t *>(tape_dev),
-              tape_cap_words, ws + tape_at, s);
+  const int *kord = launch_tape_front(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, max_depth, ws + tape_at, s);
+  const strings_handoff strs = launch_parse_strings(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, false,
+                                                    static_cast<uint8_t *>(string_buf_dev), string_buf_bytes, offsets, sres, ws + scratch_at, s, kord);
+  launch_tape(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, max_depth, offsets, strs, static_cast<uint8_t *>(string_buf_dev),
+              static_cast<uint64_t *>(tape_dev), tape_cap_words, ws + tape_at, s);
   SJ_TRY(ctx, hipGetLastError());
   strings_result_dev hs;
   tape_result_dev ht;
   SJ_TRY(ctx, hipMemcpyAsync(&hs, sres, sizeof(hs), hipMemcpyDeviceToHost, s));
   SJ_TRY(ctx, hipMemcpyAsync(&ht, ws + tape_at, sizeof(ht), hipMemcpyDeviceToHost, s));
   SJ_TRY(ctx, hipStreamSynchronize(s));
+  ctx->last_string_path = hs.path;
   // the first offender in list order decides; a string's content ranks behind its own position in the grammar (sj_tape_rules.h)
   uint64_t key = ht.error_key;
   if (hs.first_bad != 0xFFFFFFFFu) {

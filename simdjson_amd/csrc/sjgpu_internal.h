@@ -180,7 +180,7 @@ struct strings_result_dev {
   uint32_t strings;   // records written
   uint32_t first_bad; // index of the first structural whose string the reference rejects, 0xFFFFFFFF = none
   uint32_t overflow;  // a record did not fit into the caller's buffer
-  uint32_t pad;
+  uint32_t path;      // which kernels wrote the buffer: 1 = the stream compaction (sjgpu_string_stream.hip), 2 = the per-string walk
 };
 // scratch of one string pass, carved from one allocation of strings_scratch_bytes(n, len) bytes (256-byte aligned pieces)
 constexpr size_t STRS_SUMMARY_BYTES = 32, STRS_BASE_BYTES = 16;
@@ -199,9 +199,17 @@ size_t strings_scratch_bytes(uint32_t n, uint64_t len);
 // the buffer as a stream compaction of the document (sjgpu_string_stream.hip); leaves in the control block whether the
 // per-string kernels have to run instead
 void enqueue_string_stream(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
-                           uint32_t *offsets, strings_result_dev *res, const strings_scratch &w, hipStream_t s);
-void launch_parse_strings(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
-                          uint32_t *offsets, strings_result_dev *res, void *scratch, hipStream_t s);
+                           uint32_t *offsets, strings_result_dev *res, const strings_scratch &w, hipStream_t s, const int *kord);
+// What the string pass hands to a caller that finishes the records itself (the tape): where the k-th string's record begins, and the device
+// flag that says whether the stream compaction wrote the buffer (then the length words are still missing) or the per-string kernels did.
+struct strings_handoff {
+  const uint32_t *outq;
+  const uint32_t *go_stream;
+};
+// kord (optional): the string ordinal of every structural, n + 1 ints, computed by the caller (launch_tape_front) -- the pass then neither
+// counts the string tokens itself nor writes offsets / length words for the stream's records (the caller does, from the handoff)
+strings_handoff launch_parse_strings(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
+                                     uint32_t *offsets, strings_result_dev *res, void *scratch, hipStream_t s, const int *kord = nullptr);
 // ---- the tape (sjgpu_tape.hip) ----------------------------------------------------------------------------------
 struct tape_result_dev {
   uint64_t error_key;   // smallest (list index << 8 | rank << 4 | error_code) over all offending tokens, ~0 = none (sj_tape_rules.h)
@@ -210,10 +218,13 @@ struct tape_result_dev {
   uint32_t overflow;    // the caller's tape was too small
 };
 size_t tape_workspace_bytes(uint32_t n, uint64_t len);
-// stage 2 of buf[0..len) from its structural list idx[0..n] (idx[n] = len) and the string offsets launch_parse_strings left;
-// writes the reference's tape; workspace: tape_workspace_bytes(n, len), its first bytes are the tape_result_dev afterwards
-void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, const uint32_t *str_offsets, uint64_t *tape,
-                 uint64_t tape_cap, void *workspace, hipStream_t s);
+// stage 2 of buf[0..len) from its structural list idx[0..n] (idx[n] = len), in two halves around the string pass: launch_tape_front leaves
+// the token bytes, tape positions, depths and the sort's input in the workspace and returns the string ordinals of the tokens (n + 1 ints);
+// launch_tape writes the reference's tape (and the length words of the string records when the stream compaction wrote them).
+// workspace: tape_workspace_bytes(n, len), its first bytes are the tape_result_dev afterwards
+const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, void *workspace, hipStream_t s);
+void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, const uint32_t *str_offsets, strings_handoff strs,
+                 uint8_t *string_buf, uint64_t *tape, uint64_t tape_cap, void *workspace, hipStream_t s);
 // On-Demand's raw key comparison over the whole list (sjgpu_strings.hip); names_block: [u32 lens[K]][name bytes back to back] in device memory
 void launch_match_keys(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, const uint8_t *names_block, uint32_t K, uint32_t *out, uint32_t *matches,
                        hipStream_t s);

@@ -8,11 +8,11 @@
 // A lane owns 64 bytes, a wave 4 KiB, a wave's share is one 16 KiB segment; loads are the 16-byte row loads of stage 1.
 //   k_strs_count     per segment: output bytes, opening quotes and rejected escapes for both "starts inside / outside a string"
 //   k_strs_resolve   one workgroup: in-string state, output base and string ordinal in front of every segment; totals
-//   k_strs_tokens + scan   which structurals are quotes, and the ordinal of each among them
+//   k_strs_tokens + scan   which structurals are quotes, and the ordinal of each among them (skipped when the tape has them already)
 //   k_strs_decide    the stream is taken iff every string is valid, every opening quote of the document is a structural (a quote
 //                    glued to a scalar, a"b", is not: such documents are invalid and take the per-string path) and the buffer fits
 //   k_strs_write     the bytes, through a per-wave LDS window (16-byte stores); where every string begins (by ordinal)
-//   k_strs_finalize  per structural: its record offset (CSR, as before) and, for a string, the length word
+//   k_strs_finalize  per structural: its record offset (CSR, as before) and, for a string, the length word (the tape does this itself)
 // Everything else -- a rejected escape, an unclosed string, unlisted quotes -- is left to k_strings<> (sjgpu_strings.hip), which
 // then runs instead: same results as before for those documents, the fast path for all valid ones.
 #include "sjgpu_device.h"
@@ -23,10 +23,35 @@ namespace {
 
 constexpr u32 STRS_WAVES = 4; // waves (= segments) per workgroup
 
+// The document's bytes for the escape decoders, through a 16-byte window in registers: a \\u escape (or a surrogate pair of two) is read
+// front to back, so two unaligned 8-byte loads serve the up to 12 byte() calls of one decode -- with one load per byte the decoders
+// were what the twitter-like buffer spent its time on (0.19 \\u escapes per 64-byte block: k_strs_write 417 us against 160 us for a
+// document without them, first measurement of this file).  Bytes at or beyond len read as 0x20.
 struct global_doc {
   const u8 *buf;
   u32 len;
-  __device__ __forceinline__ u32 byte(u32 pos) const { return pos < len ? u32(buf[pos]) : 0x20u; }
+  mutable u64 lo = 0, hi = 0;
+  mutable u32 at = 0xFFFFFF00u; // position of the window's first byte (nothing loaded yet)
+  typedef u64 __attribute__((aligned(1))) u64_any;
+  __device__ __forceinline__ u32 byte(u32 pos) const {
+    u32 d = pos - at;
+    if (d >= 16u) { // also for pos < at (wraps)
+      at = pos;
+      d = 0;
+      if (u64(pos) + 16u <= len) {
+        lo = *reinterpret_cast<const u64_any *>(buf + pos);
+        hi = *reinterpret_cast<const u64_any *>(buf + pos + 8);
+      } else {
+        lo = 0; hi = 0;
+        for (u32 k = 0; k < 8; k++) {
+          lo |= u64(pos + k < len ? u32(buf[pos + k]) : 0x20u) << (8u * k);
+          hi |= u64(pos + 8 + k < len ? u32(buf[pos + 8 + k]) : 0x20u) << (8u * k);
+        }
+      }
+    }
+    const u64 half = d >= 8u ? hi : lo;
+    return u32(half >> (8u * (d & 7u))) & 0xFFu;
+  }
 };
 
 // per segment, from its bytes alone (hypothesis 0 = the segment starts outside a string)
@@ -177,60 +202,51 @@ struct strs_ctrl {
   u32 bad;       // a rejected escape inside a string, or the document ends inside one
   u64 total;     // output bytes
 };
-constexpr u32 RES_THREADS = 1024;
+constexpr u32 RES_THREADS = 1024, RES_WAVES = RES_THREADS / 64;
+// exclusive prefix over the workgroup of one value per thread (wave scans + one pass over the 16 wave totals); total = the sum
+__device__ __forceinline__ u32 block_excl_scan1024(u32 v, u32 *sh /*[RES_WAVES]*/, u32 &total) {
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const u32 incl = wave_incl_scan(v);
+  if (lane == 63) { sh[wave] = incl; }
+  __syncthreads();
+  u32 base = 0, sum = 0;
+  for (u32 w = 0; w < RES_WAVES; w++) {
+    if (w < wave) { base += sh[w]; }
+    sum += sh[w];
+  }
+  total = sum;
+  __syncthreads();
+  return base + incl - v;
+}
+// The segments in tiles of 1024, a thread per segment (consecutive threads read consecutive summaries): first the in-string state in front
+// of every segment (a prefix XOR of the parities), which selects the segment's counts, then the prefix sums of those.
 __global__ __launch_bounds__(RES_THREADS) void k_strs_resolve(const strs_summary *__restrict__ summ, u32 nseg, strs_base *__restrict__ base, strs_ctrl *__restrict__ ctrl) {
-  __shared__ u64 sh_bytes[RES_THREADS];
-  __shared__ u32 sh_opens[RES_THREADS], sh_par[RES_THREADS], sh_bad[RES_THREADS];
+  __shared__ u32 sh[RES_WAVES];
   const u32 t = threadIdx.x;
-  const u32 per = (nseg + RES_THREADS - 1) / RES_THREADS;
-  const u32 lo = min(t * per, nseg), hi = min(lo + per, nseg);
-  u32 par = 0;
-  for (u32 i = lo; i < hi; i++) { par ^= summ[i].flags & 1u; }
-  sh_par[t] = par;
-  __syncthreads();
-  for (u32 d = 1; d < RES_THREADS; d <<= 1) {
-    const u32 x = t >= d ? sh_par[t - d] : 0u;
-    __syncthreads();
-    sh_par[t] ^= x;
-    __syncthreads();
+  u32 s_run = 0, opens_run = 0, bad = 0; // in front of the tile
+  u64 bytes_run = 0;
+  for (u32 tile = 0; tile < nseg; tile += RES_THREADS) {
+    const u32 i = tile + t;
+    strs_summary v{0u, 0u, 0u, 0u, 0u, {0u, 0u, 0u}};
+    if (i < nseg) { v = summ[i]; }
+    u32 par_total, bytes_total, opens_total;
+    const u32 s = (s_run + block_excl_scan1024(v.flags & 1u, sh, par_total)) & 1u;
+    const u32 my_bytes = s ? v.bytes1 : v.bytes0, my_opens = s ? v.quotes - v.opens0 : v.opens0;
+    const u32 b0 = block_excl_scan1024(my_bytes, sh, bytes_total); // a tile: at most 1024 x 2.5 x 16 KiB = 40 MiB
+    const u32 o0 = block_excl_scan1024(my_opens, sh, opens_total);
+    if (i < nseg) {
+      base[i] = strs_base{u32(bytes_run + b0), opens_run + o0, s, 0u};
+      bad |= s ? (v.flags >> 2) & 1u : (v.flags >> 1) & 1u;
+    }
+    s_run = (s_run + par_total) & 1u;
+    bytes_run += bytes_total;
+    opens_run += opens_total;
   }
-  const u32 s_start = sh_par[t] ^ par; // exclusive
-  u32 s = s_start, opens = 0, bad = 0;
-  u64 bytes = 0;
-  for (u32 i = lo; i < hi; i++) {
-    const strs_summary v = summ[i];
-    bytes += s ? v.bytes1 : v.bytes0;
-    opens += s ? v.quotes - v.opens0 : v.opens0;
-    bad |= s ? (v.flags >> 2) & 1u : (v.flags >> 1) & 1u;
-    s ^= v.flags & 1u;
-  }
-  sh_bytes[t] = bytes;
-  sh_opens[t] = opens;
-  sh_bad[t] = bad;
-  __syncthreads();
-  for (u32 d = 1; d < RES_THREADS; d <<= 1) {
-    const u64 xb = t >= d ? sh_bytes[t - d] : 0ull;
-    const u32 xo = t >= d ? sh_opens[t - d] : 0u, xe = t >= d ? sh_bad[t - d] : 0u;
-    __syncthreads();
-    sh_bytes[t] += xb;
-    sh_opens[t] += xo;
-    sh_bad[t] |= xe;
-    __syncthreads();
-  }
-  u64 run_bytes = sh_bytes[t] - bytes;
-  u32 run_opens = sh_opens[t] - opens;
-  s = s_start;
-  for (u32 i = lo; i < hi; i++) {
-    const strs_summary v = summ[i];
-    base[i] = strs_base{u32(run_bytes), run_opens, s, 0u};
-    run_bytes += s ? v.bytes1 : v.bytes0;
-    run_opens += s ? v.quotes - v.opens0 : v.opens0;
-    s ^= v.flags & 1u;
-  }
-  if (t == RES_THREADS - 1) {
-    ctrl->total = sh_bytes[t];
-    ctrl->opens = sh_opens[t];
-    ctrl->bad = sh_bad[t] | sh_par[t]; // the last thread's inclusive parity = the state behind the last byte
+  const u32 any_bad = __syncthreads_or(int(bad));
+  if (t == 0) {
+    ctrl->total = bytes_run;
+    ctrl->opens = opens_run;
+    ctrl->bad = (any_bad ? 1u : 0u) | s_run; // s_run: the state behind the last byte
   }
 }
 
@@ -260,6 +276,7 @@ __global__ void k_strs_decide(strs_ctrl *__restrict__ ctrl, const int *__restric
   ctrl->go_stream = ok ? 1u : 0u;
   ctrl->go_old = ok ? 0u : 1u;
   ctrl->n1_old = ok ? 0u : n + 1u;
+  res->path = ok ? 1u : 2u;
   if (ok) {
     outq[listed] = u32(ctrl->total); // behind the last record
     res->bytes = ctrl->total;
@@ -402,7 +419,7 @@ __global__ __launch_bounds__(TOK_THREADS) void k_strs_finalize(const int *__rest
 
 // scratch of the stream (carved by sjgpu_strings.hip): see strings_scratch in sjgpu_internal.h
 void enqueue_string_stream(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
-                           uint32_t *offsets, strings_result_dev *res, const strings_scratch &w, hipStream_t s) {
+                           uint32_t *offsets, strings_result_dev *res, const strings_scratch &w, hipStream_t s, const int *kord) {
   strs_ctrl *ctrl = static_cast<strs_ctrl *>(w.ctrl);
   static_assert(sizeof(strs_ctrl) <= 64, "the control block has 64 bytes");
   static_assert(sizeof(strs_summary) == STRS_SUMMARY_BYTES && sizeof(strs_base) == STRS_BASE_BYTES, "strings_scratch_bytes counts on these");
@@ -417,13 +434,19 @@ void enqueue_string_stream(const uint8_t *buf, uint64_t len, const uint32_t *idx
     hipLaunchKernelGGL(k_strs_count, dim3((nseg + STRS_WAVES - 1) / STRS_WAVES), dim3(64 * STRS_WAVES), 0, s, buf, len, nseg, a, w.esc, summ);
   }
   hipLaunchKernelGGL(k_strs_resolve, dim3(1), dim3(RES_THREADS), 0, s, summ, nseg, base, ctrl);
-  hipLaunchKernelGGL(k_strs_tokens, dim3(u32((u64(n1) + TOK_THREADS - 1) / TOK_THREADS)), dim3(TOK_THREADS), 0, s, buf, len, idx, n, w.kord);
-  enqueue_scan(w.kord, n1, &ctrl->n1_scan, w.partial, s);
-  hipLaunchKernelGGL(k_strs_decide, dim3(1), dim3(1), 0, s, ctrl, w.kord, n, out_cap, w.outq, res);
+  const bool own_ordinals = kord == nullptr; // else the caller has them (launch_tape_front) and finishes the records itself
+  if (own_ordinals) {
+    hipLaunchKernelGGL(k_strs_tokens, dim3(u32((u64(n1) + TOK_THREADS - 1) / TOK_THREADS)), dim3(TOK_THREADS), 0, s, buf, len, idx, n, w.kord);
+    enqueue_scan(w.kord, n1, &ctrl->n1_scan, w.partial, s);
+    kord = w.kord;
+  }
+  hipLaunchKernelGGL(k_strs_decide, dim3(1), dim3(1), 0, s, ctrl, kord, n, out_cap, w.outq, res);
   if (nseg) {
     hipLaunchKernelGGL(k_strs_write, dim3((nseg + STRS_WAVES - 1) / STRS_WAVES), dim3(64 * STRS_WAVES), 0, s, buf, len, nseg, a, w.esc, base, ctrl, out, w.outq);
   }
-  hipLaunchKernelGGL(k_strs_finalize, dim3(u32((u64(n1) + TOK_THREADS - 1) / TOK_THREADS)), dim3(TOK_THREADS), 0, s, w.kord, n, w.outq, ctrl, offsets, out);
+  if (own_ordinals) {
+    hipLaunchKernelGGL(k_strs_finalize, dim3(u32((u64(n1) + TOK_THREADS - 1) / TOK_THREADS)), dim3(TOK_THREADS), 0, s, kord, n, w.outq, ctrl, offsets, out);
+  }
 }
 
 } // namespace sjgpu

@@ -495,27 +495,29 @@ size_t strings_scratch_bytes(uint32_t n, uint64_t len) { return carve_strings_sc
 // Two roads to the same buffer: the stream compaction of sjgpu_string_stream.hip for documents whose strings are all valid and all
 // listed, the per-string kernels above for the rest (the decision is taken on the device: the kernels of the road not taken return
 // at once, its scan runs over zero entries).
-void launch_parse_strings(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
-                          uint32_t *offsets, strings_result_dev *res, void *scratch, hipStream_t s) {
+strings_handoff launch_parse_strings(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
+                                     uint32_t *offsets, strings_result_dev *res, void *scratch, hipStream_t s, const int *kord) {
   const strings_scratch w = carve_strings_scratch(scratch, n, len);
   const u32 n1 = n + 1;
   (void)hipMemsetAsync(res, 0, sizeof(strings_result_dev), s);
   (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&res->first_bad), int(NO_STRING), 1, s);
-  enqueue_string_stream(buf, len, idx, n, allow_replacement, out, out_cap, offsets, res, w, s);
+  enqueue_string_stream(buf, len, idx, n, allow_replacement, out, out_cap, offsets, res, w, s, kord);
   const u32 *ctrl = static_cast<const u32 *>(w.ctrl); // strs_ctrl: [1] = entries of this path's scan, [3] = it runs
-  static const bool stream_off = std::getenv("SJGPU_STRING_STREAM") != nullptr && std::getenv("SJGPU_STRING_STREAM")[0] == '0'; // A/B switch
-  if (stream_off) { // force the per-string kernels: overwrite the verdict
+  const char *sw = std::getenv("SJGPU_STRING_STREAM"); // A/B switch, read per call (the tests flip it)
+  if (sw && sw[0] == '0') { // force the per-string kernels: overwrite the verdict
     u32 *c = static_cast<u32 *>(w.ctrl);
     (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c), int(n1), 2, s);
     (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c + 2), 0, 1, s);
     (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c + 3), 1, 1, s);
     (void)hipMemsetAsync(res, 0, sizeof(strings_result_dev), s);
     (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&res->first_bad), int(NO_STRING), 1, s);
+    (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&res->path), 2, 1, s);
   }
   const u32 grid = u32((u64(n1) + STR_TILE - 1) / STR_TILE);
   hipLaunchKernelGGL(k_strings<false>, dim3(grid), dim3(STR_THREADS), 0, s, buf, len, idx, n, allow_replacement ? 1u : 0u, offsets, out, out_cap, res, ctrl + 3);
   enqueue_scan(reinterpret_cast<int *>(offsets), n1, ctrl + 1, w.partial, s);
   hipLaunchKernelGGL(k_strings<true>, dim3(grid), dim3(STR_THREADS), 0, s, buf, len, idx, n, allow_replacement ? 1u : 0u, offsets, out, out_cap, res, ctrl + 3);
+  return strings_handoff{w.outq, ctrl + 2};
 }
 
 } // namespace sjgpu

@@ -13,9 +13,10 @@
 // The first error of the serial walk is the smallest (list index, rank) over all tokens that break their rule: one atomicMin.
 //
 // Passes (all asynchronous on the caller's stream; one 32-byte result is read back by the caller):
-//   k_tape_classify   token byte, word count, bracket delta, "goes into the sort" flag            1 thread / token
-//   3 x scan          tape positions, depths, sort slots (sjgpu_finish.hip's scan kernels)
-//   k_tape_select     (level, token) of every bracket and comma into the sort's input
+//   k_tape_classify   the byte of every token                                                    1 thread / token
+//   k_tok_reduce / k_tok_scan_sums / k_tok_apply   tape position, nesting depth and string ordinal of every token in one sweep over
+//                     the token bytes; (level, token) of every bracket and comma into the sort's input
+//   (the string buffer: sjgpu_strings.hip / sjgpu_string_stream.hip, which take the string ordinals from here)
 //   2 x radix pass    stable LSD radix sort on the level, 6 bits per pass: histogram, scan, scatter   1 wave / 2048 elements
 //   k_tape_opens + scan + k_tape_openpos   container ordinal per sorted element, sorted position of every open
 //   k_tape_match      commas learn their container's kind; closes write BOTH bracket words (count, partner index), kinds checked
@@ -64,36 +65,165 @@ struct windowed_bytes {
 __device__ __forceinline__ void report_error(tape_result_dev *res, u64 key) { atomicMin(reinterpret_cast<unsigned long long *>(&res->error_key), (unsigned long long)key); }
 
 // tokc holds the token bytes with TWO zero bytes in front and behind: tokc[i + 2] = byte of token i
-__global__ __launch_bounds__(TP_THREADS) void k_tape_classify(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, u8 *__restrict__ tokc,
-                                                             int *__restrict__ slots, int *__restrict__ delta, int *__restrict__ sel) {
+__global__ __launch_bounds__(TP_THREADS) void k_tape_classify(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, u8 *__restrict__ tokc) {
   const u64 i = u64(blockIdx.x) * TP_THREADS + threadIdx.x;
   if (i > n) { return; }
-  if (i == n) { // the slot behind the list: the scans turn it into the totals
-    slots[n] = 0; delta[n] = 0; sel[n] = 0;
+  if (i == n) {
     tokc[0] = 0; tokc[1] = 0; tokc[n + 2] = 0; tokc[n + 3] = 0;
     return;
   }
   const u32 pos = idx[i];
-  const u32 c = pos < len ? u32(buf[pos]) : 0x20u;
-  tokc[i + 2] = u8(c);
-  slots[i] = int(tape_slots(c, i == 0));
-  delta[i] = is_open_char(c) ? 1 : (is_close_char(c) ? -1 : 0);
-  sel[i] = (is_open_char(c) || is_close_char(c) || c == ',') ? 1 : 0;
+  tokc[i + 2] = u8(pos < len ? u32(buf[pos]) : 0x20u);
 }
 
-// level of a sorted element: the depth in front of an opening bracket, the depth behind a closing one, and that of the
-// container a comma separates the members of -- clamped to [0, kmax] (beyond the nesting limit an error is already certain)
-__global__ __launch_bounds__(TP_THREADS) void k_tape_select(const u8 *__restrict__ tokc, const int *__restrict__ depth, const int *__restrict__ selpos, u32 n, u32 kmax,
-                                                           unsigned short *__restrict__ key, u32 *__restrict__ tok) {
-  const u64 i = u64(blockIdx.x) * TP_THREADS + threadIdx.x;
-  if (i >= n) { return; }
-  const u32 c = tokc[i + 2];
-  if (!(is_open_char(c) || is_close_char(c) || c == ',')) { return; }
-  int k = is_open_char(c) ? depth[i] : depth[i] - 1;
-  k = k < 0 ? 0 : (k > int(kmax) ? int(kmax) : k);
-  const u32 at = u32(selpos[i]);
-  key[at] = (unsigned short)k;
-  tok[at] = u32(i);
+// ---- the token front: every prefix sum the tape needs, in one sweep over the token bytes ----------------------------------------------
+// Per token (sj_tape_rules.h): tape words (0 / 1 / 2), "goes into the sort" (brackets and commas), "is a string", opening, closing.
+// Their exclusive prefix sums are the token's tape position, its slot in the sort's input, its ordinal among the strings and
+// (opens - closes) its nesting depth.  The first version wrote three int arrays and ran the generic three-kernel scan over each
+// (profiles/r03_pmc_summary.txt: 2.6 GB of the 9.2 GB a twitter-like call moved); all five sums are functions of ONE byte per token,
+// so here a block of 4096 tokens reads its 4 KiB of token bytes twice (k_tok_reduce: block totals; k_tok_apply: prefixes + outputs)
+// and nothing else.  Inside a block the five counters travel packed in three dwords (each field < 2^16).
+constexpr u32 TS_THREADS = 256, TS_ROW = TS_THREADS * 4, TS_ROWS = 4, TS_BLOCK = TS_ROW * TS_ROWS, TS_SUMS = 5;
+struct tok_packed {
+  u32 a, b, c; // a: tape words | sort flag << 16;  b: string | opening << 16;  c: closing
+};
+__device__ __forceinline__ tok_packed tok_contribution(u32 ch, bool root) {
+  const u32 open = is_open_char(ch) ? 1u : 0u, close = is_close_char(ch) ? 1u : 0u;
+  tok_packed p;
+  p.a = tape_slots(ch, root) | ((open | close | (ch == ',' ? 1u : 0u)) << 16);
+  p.b = (ch == '"' ? 1u : 0u) | (open << 16);
+  p.c = close;
+  return p;
+}
+typedef u32 __attribute__((aligned(1))) u32_unaligned_t;
+// the four token bytes i0 ... i0 + 3 (tokc is two bytes off the dword grid: one unaligned load)
+__device__ __forceinline__ u32 four_tokens(const u8 *__restrict__ tokc, u64 i0) { return *reinterpret_cast<const u32_unaligned_t *>(tokc + 2 + i0); }
+
+// sums[k * nblocks + block], k = tape words, sort flags, strings, opens, closes
+__global__ __launch_bounds__(TS_THREADS) void k_tok_reduce(const u8 *__restrict__ tokc, u32 n, int *__restrict__ sums, u32 nblocks) {
+  __shared__ u32 sh[3][TS_THREADS / 64];
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const u64 block0 = u64(blockIdx.x) * TS_BLOCK;
+  u32 a = 0, b = 0, c = 0;
+#pragma unroll
+  for (u32 row = 0; row < TS_ROWS; row++) {
+    const u64 i0 = block0 + u64(row) * TS_ROW + 4u * tid;
+    if (i0 < n) {
+      const u32 four = four_tokens(tokc, i0);
+#pragma unroll
+      for (u32 j = 0; j < 4; j++) {
+        if (i0 + j < n) {
+          const tok_packed p = tok_contribution((four >> (8u * j)) & 0xFFu, i0 + j == 0);
+          a += p.a; b += p.b; c += p.c;
+        }
+      }
+    }
+  }
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); // a wave: at most 64 x 16 tokens x 2 words: the fields do not overflow
+  if (lane == 0) { sh[0][wave] = a; sh[1][wave] = b; sh[2][wave] = c; }
+  __syncthreads();
+  if (tid == 0) {
+    u32 slots = 0, sel = 0, strs = 0, opens = 0, closes = 0;
+    for (u32 w = 0; w < TS_THREADS / 64; w++) {
+      slots += sh[0][w] & 0xFFFFu; sel += sh[0][w] >> 16;
+      strs += sh[1][w] & 0xFFFFu; opens += sh[1][w] >> 16;
+      closes += sh[2][w];
+    }
+    sums[0 * nblocks + blockIdx.x] = int(slots);
+    sums[1 * nblocks + blockIdx.x] = int(sel);
+    sums[2 * nblocks + blockIdx.x] = int(strs);
+    sums[3 * nblocks + blockIdx.x] = int(opens);
+    sums[4 * nblocks + blockIdx.x] = int(closes);
+  }
+}
+// one workgroup: the five rows of block totals become exclusive prefixes, in place
+__global__ __launch_bounds__(1024) void k_tok_scan_sums(int *__restrict__ sums, u32 nblocks) {
+  __shared__ int sh[1024];
+  const u32 per = (nblocks + 1023) / 1024;
+  const u32 lo = min(threadIdx.x * per, nblocks), hi = min(lo + per, nblocks);
+  for (u32 k = 0; k < TS_SUMS; k++) {
+    int *row = sums + size_t(k) * nblocks;
+    int sum = 0;
+    for (u32 i = lo; i < hi; i++) { sum += row[i]; }
+    sh[threadIdx.x] = sum;
+    __syncthreads();
+    for (u32 d = 1; d < 1024; d <<= 1) {
+      const int t = (threadIdx.x >= d) ? sh[threadIdx.x - d] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    int run = sh[threadIdx.x] - sum;
+    for (u32 i = lo; i < hi; i++) {
+      const int x = row[i];
+      row[i] = run;
+      run += x;
+    }
+    __syncthreads();
+  }
+}
+// tpos[i], depth[i], kord[i] for i in [0, n] (entry n = the totals); the brackets and commas go straight into the sort's input with
+// their level: the depth in front of an opening bracket, the depth behind a closing one, and that of the container a comma separates
+// the members of -- clamped to [0, kmax] (beyond the nesting limit an error is already certain); *m_out = how many went in
+__global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__ tokc, u32 n, u32 kmax, const int *__restrict__ sums, u32 nblocks, int *__restrict__ tpos,
+                                                         int *__restrict__ depth, int *__restrict__ kord, unsigned short *__restrict__ key, u32 *__restrict__ tok,
+                                                         int *__restrict__ m_out) {
+  __shared__ u32 sh[3][TS_THREADS / 64];
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const u64 block0 = u64(blockIdx.x) * TS_BLOCK;
+  const int slots0 = sums[0 * nblocks + blockIdx.x], sel0 = sums[1 * nblocks + blockIdx.x], strs0 = sums[2 * nblocks + blockIdx.x];
+  const int depth0 = sums[3 * nblocks + blockIdx.x] - sums[4 * nblocks + blockIdx.x];
+  u32 ra = 0, rb = 0, rc = 0; // what the rows in front of this one hold (packed)
+#pragma unroll 1
+  for (u32 row = 0; row < TS_ROWS; row++) {
+    const u64 i0 = block0 + u64(row) * TS_ROW + 4u * tid;
+    u32 four = 0;
+    if (i0 < n) { four = four_tokens(tokc, i0); }
+    tok_packed p[4];
+    u32 ta = 0, tb = 0, tc = 0;
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) {
+      p[j] = tok_packed{0u, 0u, 0u};
+      if (i0 + j < n) { p[j] = tok_contribution((four >> (8u * j)) & 0xFFu, i0 + j == 0); }
+      ta += p[j].a; tb += p[j].b; tc += p[j].c;
+    }
+    const u32 ia = wave_incl_scan(ta), ib = wave_incl_scan(tb), ic = wave_incl_scan(tc);
+    if (lane == 63) { sh[0][wave] = ia; sh[1][wave] = ib; sh[2][wave] = ic; }
+    __syncthreads();
+    u32 ea = ra + ia - ta, eb = rb + ib - tb, ec = rc + ic - tc;
+    for (u32 w = 0; w < TS_THREADS / 64; w++) {
+      if (w < wave) { ea += sh[0][w]; eb += sh[1][w]; ec += sh[2][w]; }
+      ra += sh[0][w]; rb += sh[1][w]; rc += sh[2][w];
+    }
+    __syncthreads();
+    if (i0 <= n) {
+      int tp[4], dp[4], ko[4];
+#pragma unroll
+      for (u32 j = 0; j < 4; j++) {
+        const u64 i = i0 + j;
+        const int d = depth0 + int(eb >> 16) - int(ec);
+        tp[j] = slots0 + int(ea & 0xFFFFu);
+        dp[j] = d;
+        ko[j] = strs0 + int(eb & 0xFFFFu);
+        const int slot = sel0 + int(ea >> 16);
+        if (i == n) { *m_out = slot; }
+        if (i < n && (p[j].a >> 16)) {
+          int k = (p[j].b >> 16) ? d : d - 1;
+          k = k < 0 ? 0 : (k > int(kmax) ? int(kmax) : k);
+          key[slot] = (unsigned short)k;
+          tok[slot] = u32(i);
+        }
+        ea += p[j].a; eb += p[j].b; ec += p[j].c;
+      }
+      if (i0 + 3 <= n) {
+        *reinterpret_cast<int4 *>(tpos + i0) = make_int4(tp[0], tp[1], tp[2], tp[3]);
+        *reinterpret_cast<int4 *>(depth + i0) = make_int4(dp[0], dp[1], dp[2], dp[3]);
+        *reinterpret_cast<int4 *>(kord + i0) = make_int4(ko[0], ko[1], ko[2], ko[3]);
+      } else {
+        for (u32 j = 0; j < 4 && i0 + j <= n; j++) { tpos[i0 + j] = tp[j]; depth[i0 + j] = dp[j]; kord[i0 + j] = ko[j]; }
+      }
+    }
+  }
 }
 
 // ---- stable radix sort on the level, one digit of RADIX_BITS per pass ----------------------------------------------------------------
@@ -194,7 +324,8 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_match(const u8 *__restrict_
 // ---- per token: rule, limit, content ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TP_THREADS) void k_tape_write(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, u32 max_depth, const u8 *__restrict__ tokc,
                                                           const int *__restrict__ tpos, const int *__restrict__ depth, const u8 *__restrict__ ctx, const u32 *__restrict__ str_offsets,
-                                                          u64 *__restrict__ tape, u64 tape_cap, u32 *__restrict__ slow_list, u32 slow_cap, tape_result_dev *__restrict__ res) {
+                                                          const int *__restrict__ kord, strings_handoff strs, u8 *__restrict__ string_buf, u64 *__restrict__ tape, u64 tape_cap,
+                                                          u32 *__restrict__ slow_list, u32 slow_cap, tape_result_dev *__restrict__ res) {
   const u64 i = u64(blockIdx.x) * TP_THREADS + threadIdx.x;
   if (i > n) { return; }
   if (i == n) { // behind the last token: the root words and the checks that belong to no token
@@ -220,7 +351,18 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_write(const u8 *__restrict_
   const bool root = i == 0;
   const windowed_bytes src{buf, u32(len)};
   if (c == '"') {
-    if (at < tape_cap) { tape[at] = tape_word('"', str_offsets[i]); } // on_start_string, tape_builder.h:415-419
+    // on_start_string, tape_builder.h:415-419: the payload is where the string's record begins.  When the string buffer came from the
+    // stream compaction (sjgpu_string_stream.hip) the records are known by ORDINAL and their length words are still missing: the k-th
+    // string begins at outq[k] and ends where the next one begins ([u32 length][bytes][0]: on_end_string, :428-433)
+    u32 payload;
+    if (strs.go_stream && *strs.go_stream) {
+      const u32 k = u32(kord[i]);
+      payload = strs.outq[k];
+      *reinterpret_cast<u32_unaligned_t *>(string_buf + payload) = strs.outq[k + 1] - payload - 5u;
+    } else {
+      payload = str_offsets[i];
+    }
+    if (at < tape_cap) { tape[at] = tape_word('"', payload); }
   } else if (c == ',') {
     if (comma_in_value_position(i, prev, ctx_prev)) { report_error(res, error_key(i, 2, SJ_NUMBER_ERROR)); }
   } else if (is_open_char(c) || is_close_char(c) || c == ':') {
@@ -271,7 +413,10 @@ struct tape_workspace {
   tape_result_dev *res;
   u32 *n_words;       // [0] = n + 1 (scan lengths), [1] = n (upper bound of the sorted elements + 1 for the opens scan), [2] = hist length per pass
   u8 *tokc, *ctx;
-  int *slots, *depth, *sel; // in place: tape positions, depths, sort slots
+  int *slots, *depth, *kord; // tape position, nesting depth, string ordinal of every token (entry n: the totals)
+  int *m;                    // brackets and commas = elements of the sort
+  int *sums;                 // k_tok_reduce's block totals (5 rows)
+  u32 tok_blocks;
   unsigned short *key_a, *key_b;
   u32 *tok_a, *tok_b, *openpos, *slow_list;
   int *hist, *opens, *partial;
@@ -287,11 +432,14 @@ static tape_workspace carve(uint8_t *base, uint32_t n, uint64_t len) {
   w.slow_cap = u32(len / 20 + 64 < n1 ? len / 20 + 64 : n1);
   w.res = reinterpret_cast<tape_result_dev *>(take(sizeof(tape_result_dev)));
   w.n_words = reinterpret_cast<u32 *>(take(64));
+  w.m = reinterpret_cast<int *>(w.n_words) + 8;
   w.tokc = take(n1 + 8);
   w.ctx = take(n1 + 8);
   w.slots = reinterpret_cast<int *>(take(n1 * 4 + 64));
   w.depth = reinterpret_cast<int *>(take(n1 * 4 + 64));
-  w.sel = reinterpret_cast<int *>(take(n1 * 4 + 64));
+  w.kord = reinterpret_cast<int *>(take(n1 * 4 + 64));
+  w.tok_blocks = blocks_of(n1, TS_BLOCK);
+  w.sums = reinterpret_cast<int *>(take(size_t(w.tok_blocks) * TS_SUMS * 4 + 64));
   w.key_a = reinterpret_cast<unsigned short *>(take(n1 * 2 + 64));
   w.key_b = reinterpret_cast<unsigned short *>(take(n1 * 2 + 64));
   w.tok_a = reinterpret_cast<u32 *>(take(n1 * 4 + 64));
@@ -307,10 +455,11 @@ static tape_workspace carve(uint8_t *base, uint32_t n, uint64_t len) {
 }
 size_t tape_workspace_bytes(uint32_t n, uint64_t len) { return carve(nullptr, n, len).bytes; }
 
-// idx[0 .. n] (n >= 1; idx[n] = len, stage 1's first sentinel); str_offsets: what launch_parse_strings left (n + 1 words);
-// workspace: tape_workspace_bytes(n, len).  Leaves tape_result_dev at the start of the workspace.
-void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, const uint32_t *str_offsets, uint64_t *tape, uint64_t tape_cap,
-                 void *workspace, hipStream_t s) {
+// Stage 2 in two halves, the string buffer in between (sjgpu_capi.hip: sjgpu_stage2_device).  idx[0 .. n] (n >= 1; idx[n] = len, stage 1's first
+// sentinel); workspace: tape_workspace_bytes(n, len), its first bytes are the tape_result_dev afterwards.
+// launch_tape_front: the byte, tape position, depth and string ordinal of every token, the sort's input.  Returns the ordinals (n + 1 ints,
+// entry n = the number of string tokens), which the string pass takes instead of counting them itself.
+const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, void *workspace, hipStream_t s) {
   const tape_workspace w = carve(static_cast<uint8_t *>(workspace), n, len);
   const u32 n1 = n + 1;
   (void)hipMemsetAsync(w.res, 0, sizeof(tape_result_dev), s);
@@ -318,14 +467,22 @@ void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t
   (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.n_words), int(n1), 1, s);
   (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.n_words + 1), int(w.tiles * RADIX_BINS), 1, s);
   (void)hipMemsetAsync(w.ctx, 0, size_t(n1) + 8, s);
-  const u32 grid = blocks_of(n1, TP_THREADS);
-  hipLaunchKernelGGL(k_tape_classify, dim3(grid), dim3(TP_THREADS), 0, s, buf, len, idx, n, w.tokc, w.slots, w.depth, w.sel);
-  enqueue_scan(w.slots, n1, w.n_words, w.partial, s); // slots -> tape positions (the root word in front not counted)
-  enqueue_scan(w.depth, n1, w.n_words, w.partial, s); // deltas -> depth in front of every token
-  enqueue_scan(w.sel, n1, w.n_words, w.partial, s);   // flags -> slot in the sort's input; sel[n] = m
-  const int *m_ptr = w.sel + n;
+  hipLaunchKernelGGL(k_tape_classify, dim3(blocks_of(n1, TP_THREADS)), dim3(TP_THREADS), 0, s, buf, len, idx, n, w.tokc);
   const u32 kmax = max_depth < 4095u ? max_depth : 4095u;
-  hipLaunchKernelGGL(k_tape_select, dim3(grid), dim3(TP_THREADS), 0, s, w.tokc, w.depth, w.sel, n, kmax, w.key_a, w.tok_a);
+  hipLaunchKernelGGL(k_tok_reduce, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, w.tokc, n, w.sums, w.tok_blocks);
+  hipLaunchKernelGGL(k_tok_scan_sums, dim3(1), dim3(1024), 0, s, w.sums, w.tok_blocks);
+  hipLaunchKernelGGL(k_tok_apply, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, w.tokc, n, kmax, w.sums, w.tok_blocks, w.slots, w.depth, w.kord, w.key_a, w.tok_a, w.m);
+  return w.kord;
+}
+
+// launch_tape: the rest.  str_offsets: what the per-string kernels left (n + 1 words), read when they wrote the buffer; strs: where the records
+// of the stream compaction begin, read when IT wrote the buffer (the flag decides on the device); string_buf: the buffer, for the length words.
+void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, const uint32_t *str_offsets, strings_handoff strs,
+                 uint8_t *string_buf, uint64_t *tape, uint64_t tape_cap, void *workspace, hipStream_t s) {
+  const tape_workspace w = carve(static_cast<uint8_t *>(workspace), n, len);
+  const u32 n1 = n + 1;
+  const u32 grid = blocks_of(n1, TP_THREADS);
+  const int *m_ptr = w.m;
   // two passes of six bits cover levels up to 4095
   hipLaunchKernelGGL(k_radix_hist, dim3(w.tiles), dim3(64), 0, s, w.key_a, m_ptr, 0u, w.tiles, w.hist);
   enqueue_scan(w.hist, w.tiles * RADIX_BINS, w.n_words + 1, w.partial, s);
@@ -338,8 +495,8 @@ void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t
   enqueue_scan(w.opens, n1, w.n_words, w.partial, s);
   hipLaunchKernelGGL(k_tape_openpos, dim3(grid), dim3(TP_THREADS), 0, s, w.tokc, w.tok_a, m_ptr, w.opens, w.openpos);
   hipLaunchKernelGGL(k_tape_match, dim3(grid), dim3(TP_THREADS), 0, s, w.tokc, w.key_a, w.tok_a, m_ptr, w.opens, w.openpos, w.slots, w.ctx, tape, tape_cap, w.res);
-  hipLaunchKernelGGL(k_tape_write, dim3(grid), dim3(TP_THREADS), 0, s, buf, len, idx, n, max_depth, w.tokc, w.slots, w.depth, w.ctx, str_offsets, tape, tape_cap, w.slow_list,
-                     w.slow_cap, w.res);
+  hipLaunchKernelGGL(k_tape_write, dim3(grid), dim3(TP_THREADS), 0, s, buf, len, idx, n, max_depth, w.tokc, w.slots, w.depth, w.ctx, str_offsets, w.kord, strs, string_buf,
+                     tape, tape_cap, w.slow_list, w.slow_cap, w.res);
   hipLaunchKernelGGL(k_tape_slow_numbers, dim3(64), dim3(64), 0, s, buf, len, idx, w.slots, w.slow_list, w.slow_cap, tape, tape_cap, w.res);
 }
 

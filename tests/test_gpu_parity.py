@@ -650,6 +650,101 @@ def test_strings_with_every_escape_and_every_error(orc):
     p.close()
 
 
+def test_string_stream_takes_valid_documents_and_only_those(orc, monkeypatch):
+    """The string buffer is produced as a stream compaction of the document (sjgpu_string_stream.hip) when every string is valid and
+    listed, by the per-string walk otherwise -- sjgpu_debug_string_path tells which; both roads give the oracle's bytes, and forcing
+    the per-string road (SJGPU_STRING_STREAM=0) changes nothing."""
+    p = capi.DomParserImplementation(16 << 20)
+    S = 16384
+    docs = {}
+    # escapes of every kind straddling the 64-byte blocks, the 4 KiB chunks and the 16 KiB segments at every phase
+    escapes = [b'\\n', b'\\u0041', b'\\u00e9', b'\\u20ac', b'\\ud83d\\ude00', b'\\"', b'\\\\', b'\\/', b'\\t\\r\\b\\f', b'\\ud83d\\ude00\\ud83d\\ude00', b'\\\\\\u0041']
+    for boundary in (64, 4096, S, 2 * S):
+        parts = []
+        for k, esc in enumerate(escapes):
+            for back in range(0, 15):
+                body = b'a' * (boundary - 2 - back) + esc + b'tail'
+                parts.append(b'"' + body + b'"')
+                parts.append(b'"' + esc + b'"')
+                if len(b",".join(parts)) > 3 * boundary + 200:
+                    docs[f"escapes around {boundary} ({k}, {back})"] = b'[' + b",".join(parts) + b']'
+                    parts = []
+        # every string of this document starts a fixed distance in front of a multiple of `boundary`
+        for back in range(0, 14):
+            for esc in escapes[:6]:
+                lead = b'[' + b' ' * ((boundary - 1 - back - 1) % boundary)
+                docs[f"one escape {esc!r} {back} bytes in front of {boundary}"] = lead + b'"' + esc + b'xyz","' + b'q' * boundary + esc + b'"]'
+    docs["quotes at the segment boundary"] = b'[' + b' ' * (S - 3) + b'"","","a","",' + b' ' * (S - 20) + b'"\\"","\\\\"]'
+    docs["one long string over many segments"] = b'["' + b"lorem ipsum \\\" dolor \\u00e9\\ud83d\\ude00 sit \\n amet " * 9000 + b'", "next"]'
+    docs["long runs of backslashes"] = corpus.escape_heavy(300000)[0].tobytes()
+    docs["nothing but empty strings"] = b'[' + b'"",' * 20000 + b'""]'
+    docs["no strings at all"] = b'[' + b'1,' * 20000 + b'2]'
+    docs["twitter_like 3 MiB"] = corpus.twitter_like(3 << 20, 11)[0].tobytes()
+    taken = {1: 0, 2: 0}
+    for name, d in docs.items():
+        a = np.frombuffer(d, np.uint8)
+        if not orc.validate_utf8(a):
+            continue
+        results = []
+        for forced in (False, True):
+            if forced:
+                monkeypatch.setenv("SJGPU_STRING_STREAM", "0")
+            else:
+                monkeypatch.delenv("SJGPU_STRING_STREAM", raising=False)
+            err, got, off, strings, bad, n, idx = _device_strings(p, a)
+            path = p.string_path()
+            oerr, want, ooff, ostrings, obad = orc.string_buffer(a, idx, n)
+            assert (err, strings, bad) == (oerr, ostrings, obad), (name, forced)
+            assert np.array_equal(got, want), (name, forced, first_diff(got, want))
+            assert np.array_equal(off, _csr(ooff, len(want))), (name, forced)
+            assert path == (2 if forced else 1), (name, forced, path)
+            taken[path] += 1
+            results.append(got)
+        assert np.array_equal(results[0], results[1]), name
+    monkeypatch.delenv("SJGPU_STRING_STREAM", raising=False)
+    assert taken[1] > 100 and taken[2] == taken[1]
+    # documents the stream must hand over: a string the reference rejects, quotes glued to scalars (not in the list), both
+    for name, d in {"bad escape": b'["ok","a\\qb","\\u00e9"]', "lone surrogate": b'["\\ud800","x"]', "bad hex behind a segment of text": b'["' + b'a' * 20000 + b'\\u12G4"]',
+                    "a quote glued to a number": b'[1"abc","def"]', "glued, with a bad escape in it": b'[true"a\\qc","def","\\n"]'}.items():
+        a = np.frombuffer(d, np.uint8)
+        err, got, off, strings, bad, n, idx = _device_strings(p, a)
+        oerr, want, ooff, ostrings, obad = orc.string_buffer(a, idx, n)
+        assert p.string_path() == 2, name
+        assert (err, strings, bad) == (oerr, ostrings, obad) and np.array_equal(got, want) and np.array_equal(off, _csr(ooff, len(want))), name
+    # with replacement characters a lone surrogate is a valid string again: the stream takes it
+    a = np.frombuffer(b'["\\ud800","x\\udc00\\ud83d","\\ud83d\\ude00"]', np.uint8)
+    err, got, off, strings, bad, n, idx = _device_strings(p, a, True)
+    oerr, want, ooff, ostrings, obad = orc.string_buffer(a, idx, n, True)
+    assert p.string_path() == 1 and (err, strings, bad) == (oerr, ostrings, obad) == (0, 3, checkers.NO_STRING) and np.array_equal(got, want)
+    p.close()
+
+
+def test_string_stream_random_documents(orc):
+    """random valid documents and token-level mutations of them, several thousand in one NDJSON-like buffer each way"""
+    import jsongen
+    p = capi.DomParserImplementation(16 << 20)
+    rng = np.random.default_rng(31337)
+    for mutate, count in ((False, 600), (True, 600)):
+        for _ in range(count):
+            d = jsongen.random_document(rng, max_depth=5)
+            if mutate:
+                d = jsongen.mutate(rng, d)
+            a = np.frombuffer(d, np.uint8)
+            if len(a) == 0 or not orc.validate_utf8(a):
+                continue
+            e1, n1, _ = orc.stage1(a, 0)
+            if e1 != 0:
+                continue
+            err, got, off, strings, bad, n, idx = _device_strings(p, a)
+            oerr, want, ooff, ostrings, obad = orc.string_buffer(a, idx, n)
+            assert (err, strings, bad) == (oerr, ostrings, obad), d
+            assert np.array_equal(got, want), (d, first_diff(got, want))
+            assert np.array_equal(off, _csr(ooff, len(want))), d
+            if not mutate:
+                assert p.string_path() == 1, d
+    p.close()
+
+
 @pytest.mark.parametrize("kind", ["twitter_like", "amazon_ndjson"])
 def test_full_size_strings(orc, kind):
     """256 MiB through the device path, digest against the oracle's buffer."""
@@ -1343,6 +1438,17 @@ def test_stage2_device_entry_point(tape_parser, orc, ref):
     assert (err, tw, sb) == (e_want, len(t_want), len(s_want))
     assert np.array_equal(tape[:tw].cpu().numpy().view(np.uint64), t_want)
     assert bytes(sbuf[:sb].cpu().numpy()) == bytes(s_want)
+    assert tape_parser.string_path() == 1  # the string buffer came from the stream compaction, the tape wrote its length words
+    # the same with the per-string kernels forced, and a document they have to take over (a string the reference rejects far behind)
+    os.environ["SJGPU_STRING_STREAM"] = "0"
+    try:
+        err2, tw2, sb2 = tape_parser.stage2_device(buf.data_ptr(), L, idx.data_ptr(), n, tape.data_ptr(), L + 8, sbuf.data_ptr(), sbuf.numel(), 1024, st)
+    finally:
+        del os.environ["SJGPU_STRING_STREAM"]
+    assert (err2, tw2, sb2) == (err, tw, sb) and tape_parser.string_path() == 2
+    assert np.array_equal(tape[:tw].cpu().numpy().view(np.uint64), t_want) and bytes(sbuf[:sb].cpu().numpy()) == bytes(s_want)
+    bad = np.concatenate([np.frombuffer(b"[", np.uint8), a, np.frombuffer(b',"x\\qy"]', np.uint8)])
+    assert _assert_same_parse(tape_parser, want, bad) == checkers.STRING_ERROR and tape_parser.string_path() == 2
 
 
 def test_comm_world_size_one(orc):
