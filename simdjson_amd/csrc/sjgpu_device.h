@@ -32,6 +32,14 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
   return v;
 }
 __device__ __forceinline__ u32 wave_sum(u32 v) { return readlane(wave_incl_scan(v), 63); }
+__device__ __forceinline__ u32 wave_max(u32 v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    const u32 other = u32(__shfl_xor(int(v), o));
+    v = other > v ? other : v;
+  }
+  return v;
+}
 
 // LDS traffic of ONE wave is processed in program order, so a wave may read back what its own lanes
 // wrote without a workgroup barrier; this only stops the compiler from reordering around the hand-off.

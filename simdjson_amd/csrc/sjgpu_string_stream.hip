@@ -27,6 +27,11 @@ constexpr u32 STRS_WAVES = 4; // waves (= segments) per workgroup
 // front to back, so two unaligned 8-byte loads serve the up to 12 byte() calls of one decode -- with one load per byte the decoders
 // were what the twitter-like buffer spent its time on (0.19 \\u escapes per 64-byte block: k_strs_write 417 us against 160 us for a
 // document without them, first measurement of this file).  Bytes at or beyond len read as 0x20.
+struct plain_doc { // one load per byte: what k_strs_count uses (the window costs it 27 VGPRs and a third of its occupancy: measured slower)
+  const u8 *buf;
+  u32 len;
+  __device__ __forceinline__ u32 byte(u32 pos) const { return pos < len ? u32(buf[pos]) : 0x20u; }
+};
 struct global_doc {
   const u8 *buf;
   u32 len;
@@ -96,7 +101,8 @@ __device__ __forceinline__ u32 u_tail_before(const u8 *__restrict__ buf, u64 sta
 }
 
 // one chunk: stage 1's escape and quote algebra (scan_chunk, sjgpu_device.h), then what the strings need on top of it
-__device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carry &wc, u32 lane, const global_doc &src, u32 block_pos, bool allow) {
+template <class SRC>
+__device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carry &wc, u32 lane, const SRC &src, u32 block_pos, bool allow) {
   const planes P = transpose64(w);
   const classes c = classify(P);
   const u64 lt = lanemask_lt(lane);
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_count(const u8 *__rest
   const u32 seg = blockIdx.x * STRS_WAVES + (threadIdx.x >> 6);
   if (seg >= nseg) { return; }
   const u64 seg_start = u64(seg) * SEG_BYTES;
-  const global_doc src{buf, u32(len)};
+  const plain_doc src{buf, u32(len)};
   const esc_ref esc(esc_tab);
   const u32 lookback = lookback_issue(buf, seg_start, lane);
   strs_carry wc{0u, 0u, 0u};

@@ -20,7 +20,8 @@
 //   2 x radix pass    stable LSD radix sort on the level, 6 bits per pass: histogram, scan, scatter   1 wave / 2048 elements
 //   k_tape_opens + scan + k_tape_openpos   container ordinal per sorted element, sorted position of every open
 //   k_tape_match      commas learn their container's kind; closes write BOTH bracket words (count, partner index), kinds checked
-//   k_tape_write      per token: the walk's rule, nesting limit, numbers / atoms / string words, root words
+//   k_tape_write      per token: the walk's rule, nesting limit, atoms / string words, root words
+//   k_tape_numbers    the number tokens (listed by k_tok_apply), one per lane
 //   k_tape_slow_numbers  the handful of number tokens whose rounding needs exact big-integer arithmetic (sj_number.h)
 // Parity: tests/test_gpu_parity.py::test_tape_* against the live reference's dom::parser::parse (tape and string_buf word for word,
 // error codes of broken documents); the same steps run on the CPU in tests/host/test_tape_model.cpp.
@@ -83,23 +84,24 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_classify(const u8 *__restri
 // (profiles/r03_pmc_summary.txt: 2.6 GB of the 9.2 GB a twitter-like call moved); all five sums are functions of ONE byte per token,
 // so here a block of 4096 tokens reads its 4 KiB of token bytes twice (k_tok_reduce: block totals; k_tok_apply: prefixes + outputs)
 // and nothing else.  Inside a block the five counters travel packed in three dwords (each field < 2^16).
-constexpr u32 TS_THREADS = 256, TS_ROW = TS_THREADS * 4, TS_ROWS = 4, TS_BLOCK = TS_ROW * TS_ROWS, TS_SUMS = 5;
+constexpr u32 TS_THREADS = 256, TS_ROW = TS_THREADS * 4, TS_ROWS = 4, TS_BLOCK = TS_ROW * TS_ROWS, TS_SUMS = 6;
 struct tok_packed {
-  u32 a, b, c; // a: tape words | sort flag << 16;  b: string | opening << 16;  c: closing
+  u32 a, b, c; // a: tape words | sort flag << 16;  b: string | opening << 16;  c: closing | number << 16
 };
 __device__ __forceinline__ tok_packed tok_contribution(u32 ch, bool root) {
   const u32 open = is_open_char(ch) ? 1u : 0u, close = is_close_char(ch) ? 1u : 0u;
   tok_packed p;
-  p.a = tape_slots(ch, root) | ((open | close | (ch == ',' ? 1u : 0u)) << 16);
+  const u32 slots = tape_slots(ch, root); // two words: a number token (visit_primitive's number path, sj_tape_rules.h)
+  p.a = slots | ((open | close | (ch == ',' ? 1u : 0u)) << 16);
   p.b = (ch == '"' ? 1u : 0u) | (open << 16);
-  p.c = close;
+  p.c = close | ((slots == 2u ? 1u : 0u) << 16);
   return p;
 }
 typedef u32 __attribute__((aligned(1))) u32_unaligned_t;
 // the four token bytes i0 ... i0 + 3 (tokc is two bytes off the dword grid: one unaligned load)
 __device__ __forceinline__ u32 four_tokens(const u8 *__restrict__ tokc, u64 i0) { return *reinterpret_cast<const u32_unaligned_t *>(tokc + 2 + i0); }
 
-// sums[k * nblocks + block], k = tape words, sort flags, strings, opens, closes
+// sums[k * nblocks + block], k = tape words, sort flags, strings, opens, closes, numbers
 __global__ __launch_bounds__(TS_THREADS) void k_tok_reduce(const u8 *__restrict__ tokc, u32 n, int *__restrict__ sums, u32 nblocks) {
   __shared__ u32 sh[3][TS_THREADS / 64];
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -123,17 +125,18 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_reduce(const u8 *__restrict_
   if (lane == 0) { sh[0][wave] = a; sh[1][wave] = b; sh[2][wave] = c; }
   __syncthreads();
   if (tid == 0) {
-    u32 slots = 0, sel = 0, strs = 0, opens = 0, closes = 0;
+    u32 slots = 0, sel = 0, strs = 0, opens = 0, closes = 0, numbers = 0;
     for (u32 w = 0; w < TS_THREADS / 64; w++) {
       slots += sh[0][w] & 0xFFFFu; sel += sh[0][w] >> 16;
       strs += sh[1][w] & 0xFFFFu; opens += sh[1][w] >> 16;
-      closes += sh[2][w];
+      closes += sh[2][w] & 0xFFFFu; numbers += sh[2][w] >> 16;
     }
     sums[0 * nblocks + blockIdx.x] = int(slots);
     sums[1 * nblocks + blockIdx.x] = int(sel);
     sums[2 * nblocks + blockIdx.x] = int(strs);
     sums[3 * nblocks + blockIdx.x] = int(opens);
     sums[4 * nblocks + blockIdx.x] = int(closes);
+    sums[5 * nblocks + blockIdx.x] = int(numbers);
   }
 }
 // one workgroup: the five rows of block totals become exclusive prefixes, in place
@@ -162,18 +165,20 @@ __global__ __launch_bounds__(1024) void k_tok_scan_sums(int *__restrict__ sums, 
     __syncthreads();
   }
 }
-// tpos[i], depth[i], kord[i] for i in [0, n] (entry n = the totals); the brackets and commas go straight into the sort's input with
+// tpos[i], depth[i], kord[i] for i in [0, n] (entry n = the totals); the number tokens are listed (m_out[2] = how many); the brackets
+// and commas go straight into the sort's input with
 // their level: the depth in front of an opening bracket, the depth behind a closing one, and that of the container a comma separates
 // the members of -- clamped to [0, kmax] (beyond the nesting limit an error is already certain); *m_out = how many went in
 __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__ tokc, u32 n, u32 kmax, const int *__restrict__ sums, u32 nblocks, int *__restrict__ tpos,
                                                          int *__restrict__ depth, int *__restrict__ kord, unsigned short *__restrict__ key, u32 *__restrict__ tok,
-                                                         int *__restrict__ m_out) {
+                                                         int *__restrict__ m_out, int *__restrict__ max_level, u32 *__restrict__ number_list) {
   __shared__ u32 sh[3][TS_THREADS / 64];
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u64 block0 = u64(blockIdx.x) * TS_BLOCK;
   const int slots0 = sums[0 * nblocks + blockIdx.x], sel0 = sums[1 * nblocks + blockIdx.x], strs0 = sums[2 * nblocks + blockIdx.x];
-  const int depth0 = sums[3 * nblocks + blockIdx.x] - sums[4 * nblocks + blockIdx.x];
+  const int depth0 = sums[3 * nblocks + blockIdx.x] - sums[4 * nblocks + blockIdx.x], numbers0 = sums[5 * nblocks + blockIdx.x];
   u32 ra = 0, rb = 0, rc = 0; // what the rows in front of this one hold (packed)
+  int top = 0;                // highest level this thread sent into the sort
 #pragma unroll 1
   for (u32 row = 0; row < TS_ROWS; row++) {
     const u64 i0 = block0 + u64(row) * TS_ROW + 4u * tid;
@@ -201,17 +206,19 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
 #pragma unroll
       for (u32 j = 0; j < 4; j++) {
         const u64 i = i0 + j;
-        const int d = depth0 + int(eb >> 16) - int(ec);
+        const int d = depth0 + int(eb >> 16) - int(ec & 0xFFFFu);
         tp[j] = slots0 + int(ea & 0xFFFFu);
         dp[j] = d;
         ko[j] = strs0 + int(eb & 0xFFFFu);
         const int slot = sel0 + int(ea >> 16);
-        if (i == n) { *m_out = slot; }
+        if (i == n) { *m_out = slot; m_out[2] = numbers0 + int(ec >> 16); }
+        if (i < n && (p[j].c >> 16)) { number_list[numbers0 + int(ec >> 16)] = u32(i); } // k_tape_numbers parses them, one per lane
         if (i < n && (p[j].a >> 16)) {
           int k = (p[j].b >> 16) ? d : d - 1;
           k = k < 0 ? 0 : (k > int(kmax) ? int(kmax) : k);
           key[slot] = (unsigned short)k;
           tok[slot] = u32(i);
+          top = k > top ? k : top;
         }
         ea += p[j].a; eb += p[j].b; ec += p[j].c;
       }
@@ -224,14 +231,22 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
       }
     }
   }
+  // one atomic per wave, and only from waves that raise the mark (it decides whether the sort needs its second pass)
+  const u32 wave_top = wave_max(u32(top));
+  if (lane == 0 && int(wave_top) > __hip_atomic_load(max_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicMax(max_level, int(wave_top)); }
 }
 
 // ---- stable radix sort on the level, one digit of RADIX_BITS per pass ----------------------------------------------------------------
 // m = number of elements = selpos[n] (device memory).  hist is digit-major: hist[d * tiles + t], so that ONE exclusive scan of the
 // whole table yields, for every (digit, tile), where that tile's elements with that digit begin in the output.
-__global__ __launch_bounds__(64) void k_radix_hist(const unsigned short *__restrict__ key, const int *__restrict__ m_ptr, u32 shift, u32 tiles, int *__restrict__ hist) {
+// second pass (shift > 0): nothing to do when every level fits into the first digit; the first pass tells the second's scan how long it is
+__global__ __launch_bounds__(64) void k_radix_hist(const unsigned short *__restrict__ key, const int *__restrict__ m_ptr, u32 shift, u32 tiles, int *__restrict__ hist,
+                                                   const int *__restrict__ max_level, u32 *__restrict__ second_scan_len) {
   __shared__ u32 cnt[RADIX_BINS];
   const u32 lane = threadIdx.x, tile = blockIdx.x;
+  const bool one_pass = u32(*max_level) < RADIX_BINS;
+  if (shift == 0 && tile == 0 && lane == 0) { *second_scan_len = one_pass ? 0u : tiles * RADIX_BINS; }
+  if (shift != 0 && one_pass) { return; }
   const u32 m = u32(*m_ptr);
   cnt[lane] = 0;
   wave_lds_fence();
@@ -244,9 +259,11 @@ __global__ __launch_bounds__(64) void k_radix_hist(const unsigned short *__restr
   hist[lane * tiles + tile] = int(cnt[lane]);
 }
 __global__ __launch_bounds__(64) void k_radix_scatter(const unsigned short *__restrict__ key_in, const u32 *__restrict__ tok_in, const int *__restrict__ m_ptr, u32 shift,
-                                                      u32 tiles, const int *__restrict__ hist, unsigned short *__restrict__ key_out, u32 *__restrict__ tok_out) {
+                                                      u32 tiles, const int *__restrict__ hist, unsigned short *__restrict__ key_out, u32 *__restrict__ tok_out,
+                                                      const int *__restrict__ max_level) {
   __shared__ u32 next[RADIX_BINS]; // where the next element of each digit goes
   const u32 lane = threadIdx.x, tile = blockIdx.x;
+  if (shift != 0 && u32(*max_level) < RADIX_BINS) { return; }
   const u32 m = u32(*m_ptr);
   next[lane] = u32(hist[lane * tiles + tile]);
   wave_lds_fence();
@@ -274,17 +291,30 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const unsigned short *__re
   }
 }
 
+// Where the sorted elements are: two passes leave them in the first buffer pair; a document whose levels all fit into one digit
+// (nesting below 64 -- nearly every document) is sorted after the first pass, the second is skipped and they sit in the other pair.
+struct sorted_pairs {
+  const unsigned short *key_two, *key_one;
+  const u32 *tok_two, *tok_one;
+  const int *max_level;
+  __device__ __forceinline__ bool one_pass() const { return u32(*max_level) < RADIX_BINS; }
+  __device__ __forceinline__ const unsigned short *key() const { return one_pass() ? key_one : key_two; }
+  __device__ __forceinline__ const u32 *tok() const { return one_pass() ? tok_one : tok_two; }
+};
+
 // ---- containers -------------------------------------------------------------------------------------------------------------------------
 // opens[j] = 1 where the sorted element j is an opening bracket (the scan turns it into "opens in front of j"); opens[m] = 0
-__global__ __launch_bounds__(TP_THREADS) void k_tape_opens(const u8 *__restrict__ tokc, const u32 *__restrict__ tok, const int *__restrict__ m_ptr, u32 n, int *__restrict__ opens) {
+__global__ __launch_bounds__(TP_THREADS) void k_tape_opens(const u8 *__restrict__ tokc, sorted_pairs sorted, const int *__restrict__ m_ptr, u32 n, int *__restrict__ opens) {
+  const u32 *__restrict__ tok = sorted.tok();
   const u64 j = u64(blockIdx.x) * TP_THREADS + threadIdx.x;
   const u32 m = u32(*m_ptr);
   if (j > n) { return; }
   opens[j] = (j < m && is_open_char(tokc[tok[j] + 2])) ? 1 : 0; // zeros behind the m sorted elements: the scan runs over n + 1 entries
 }
 // openpos[k] = sorted position of the k-th opening bracket
-__global__ __launch_bounds__(TP_THREADS) void k_tape_openpos(const u8 *__restrict__ tokc, const u32 *__restrict__ tok, const int *__restrict__ m_ptr, const int *__restrict__ opens_before,
+__global__ __launch_bounds__(TP_THREADS) void k_tape_openpos(const u8 *__restrict__ tokc, sorted_pairs sorted, const int *__restrict__ m_ptr, const int *__restrict__ opens_before,
                                                             u32 *__restrict__ openpos) {
+  const u32 *__restrict__ tok = sorted.tok();
   const u64 j = u64(blockIdx.x) * TP_THREADS + threadIdx.x;
   const u32 m = u32(*m_ptr);
   if (j >= m) { return; }
@@ -292,9 +322,11 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_openpos(const u8 *__restric
 }
 // commas: ctx[token] = kind of their container.  Closing brackets: the two bracket words of the tape
 // (end_container, tape_builder.h:396-407; an empty container is the same formula with count 0, :386-391).
-__global__ __launch_bounds__(TP_THREADS) void k_tape_match(const u8 *__restrict__ tokc, const unsigned short *__restrict__ key, const u32 *__restrict__ tok, const int *__restrict__ m_ptr,
+__global__ __launch_bounds__(TP_THREADS) void k_tape_match(const u8 *__restrict__ tokc, sorted_pairs sorted, const int *__restrict__ m_ptr,
                                                           const int *__restrict__ opens_before, const u32 *__restrict__ openpos, const int *__restrict__ tpos, u8 *__restrict__ ctx,
                                                           u64 *__restrict__ tape, u64 tape_cap, tape_result_dev *__restrict__ res) {
+  const unsigned short *__restrict__ key = sorted.key();
+  const u32 *__restrict__ tok = sorted.tok();
   const u64 j = u64(blockIdx.x) * TP_THREADS + threadIdx.x;
   const u32 m = u32(*m_ptr);
   if (j >= m) { return; }
@@ -322,12 +354,16 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_match(const u8 *__restrict_
 }
 
 // ---- per token: rule, limit, content ------------------------------------------------------------------------------------------------------
+// Number tokens are not parsed here: a wave of consecutive tokens holds a few of them, of very different lengths, and the other lanes would
+// wait for the longest one (the first version spent three quarters of its issue slots that way, profiles/r03_pmc_summary.txt).
+// k_tok_apply lists them, k_tape_numbers parses them one per lane.  (Two other ways to gather them were measured and dropped: a device-wide
+// list behind one atomic counter -- 0.5 M same-address atomics took 5 ms -- and gathering per workgroup of 1024 tokens in LDS with the
+// first threads parsing -- no faster than parsing in place, the idle waves keep their slots.)
 __global__ __launch_bounds__(TP_THREADS) void k_tape_write(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, u32 max_depth, const u8 *__restrict__ tokc,
                                                           const int *__restrict__ tpos, const int *__restrict__ depth, const u8 *__restrict__ ctx, const u32 *__restrict__ str_offsets,
                                                           const int *__restrict__ kord, strings_handoff strs, u8 *__restrict__ string_buf, u64 *__restrict__ tape, u64 tape_cap,
-                                                          u32 *__restrict__ slow_list, u32 slow_cap, tape_result_dev *__restrict__ res) {
+                                                          tape_result_dev *__restrict__ res) {
   const u64 i = u64(blockIdx.x) * TP_THREADS + threadIdx.x;
-  if (i > n) { return; }
   if (i == n) { // behind the last token: the root words and the checks that belong to no token
     const u64 words = u64(u32(tpos[n])) + 2;
     res->tape_words = words;
@@ -340,49 +376,62 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_write(const u8 *__restrict_
     const u32 c0 = tokc[2], last = tokc[n + 1];
     if ((c0 == '{' && last != '}') || (c0 == '[' && last != ']')) { report_error(res, error_key(0, 0, SJ_TAPE_ERROR)); } // json_iterator.h:138-143
     if (depth[n] != 0) { report_error(res, error_key(n, 0, SJ_TAPE_ERROR)); } // the walk meets the sentinel inside a container
-    return;
-  }
-  const u32 c = tokc[i + 2], prev = tokc[i + 1], prev2 = tokc[i], next = tokc[i + 3];
-  const u32 ctx_prev = i >= 1 ? ctx[i - 1] : 0u, ctx_prev2 = i >= 2 ? ctx[i - 2] : 0u;
-  u32 rank = 0;
-  const u32 g = token_grammar_error(i, c, prev, prev2, next, ctx_prev, ctx_prev2, (long long)depth[i], max_depth, &rank);
-  if (g) { report_error(res, error_key(i, rank, g)); }
-  const u64 at = 1 + u64(u32(tpos[i]));
-  const bool root = i == 0;
-  const windowed_bytes src{buf, u32(len)};
-  if (c == '"') {
-    // on_start_string, tape_builder.h:415-419: the payload is where the string's record begins.  When the string buffer came from the
-    // stream compaction (sjgpu_string_stream.hip) the records are known by ORDINAL and their length words are still missing: the k-th
-    // string begins at outq[k] and ends where the next one begins ([u32 length][bytes][0]: on_end_string, :428-433)
-    u32 payload;
-    if (strs.go_stream && *strs.go_stream) {
-      const u32 k = u32(kord[i]);
-      payload = strs.outq[k];
-      *reinterpret_cast<u32_unaligned_t *>(string_buf + payload) = strs.outq[k + 1] - payload - 5u;
-    } else {
-      payload = str_offsets[i];
+  } else if (i < n) {
+    const u32 c = tokc[i + 2], prev = tokc[i + 1], prev2 = tokc[i], next = tokc[i + 3];
+    const u32 ctx_prev = i >= 1 ? ctx[i - 1] : 0u, ctx_prev2 = i >= 2 ? ctx[i - 2] : 0u;
+    u32 rank = 0;
+    const u32 g = token_grammar_error(i, c, prev, prev2, next, ctx_prev, ctx_prev2, (long long)depth[i], max_depth, &rank);
+    if (g) { report_error(res, error_key(i, rank, g)); }
+    const u64 at = 1 + u64(u32(tpos[i]));
+    const bool root = i == 0;
+    if (c == '"') {
+      // on_start_string, tape_builder.h:415-419: the payload is where the string's record begins.  When the string buffer came from the
+      // stream compaction (sjgpu_string_stream.hip) the records are known by ORDINAL and their length words are still missing: the k-th
+      // string begins at outq[k] and ends where the next one begins ([u32 length][bytes][0]: on_end_string, :428-433)
+      u32 payload;
+      if (strs.go_stream && *strs.go_stream) {
+        const u32 k = u32(kord[i]);
+        payload = strs.outq[k];
+        *reinterpret_cast<u32_unaligned_t *>(string_buf + payload) = strs.outq[k + 1] - payload - 5u;
+      } else {
+        payload = str_offsets[i];
+      }
+      if (at < tape_cap) { tape[at] = tape_word('"', payload); }
+    } else if (c == ',') {
+      if (comma_in_value_position(i, prev, ctx_prev)) { report_error(res, error_key(i, 2, SJ_NUMBER_ERROR)); }
+    } else if (is_open_char(c) || is_close_char(c) || c == ':') {
+      // bracket words come from k_tape_match
+    } else if (takes_number_path(c, root)) {
+      // k_tape_numbers
+    } else if (c == 't' || c == 'f' || c == 'n') {
+      const windowed_bytes src{buf, u32(len)};
+      const bool ok = c == 't' ? atom_matches(src, idx[i], 't', 'r', 'u', 'e', 0)
+                               : (c == 'f' ? atom_matches(src, idx[i], 'f', 'a', 'l', 's', 'e') : atom_matches(src, idx[i], 'n', 'u', 'l', 'l', 0));
+      if (!ok) { report_error(res, error_key(i, 2, c == 't' ? SJ_T_ATOM_ERROR : (c == 'f' ? SJ_F_ATOM_ERROR : SJ_N_ATOM_ERROR))); }
+      if (at < tape_cap) { tape[at] = tape_word(c, 0); }
     }
-    if (at < tape_cap) { tape[at] = tape_word('"', payload); }
-  } else if (c == ',') {
-    if (comma_in_value_position(i, prev, ctx_prev)) { report_error(res, error_key(i, 2, SJ_NUMBER_ERROR)); }
-  } else if (is_open_char(c) || is_close_char(c) || c == ':') {
-    // bracket words come from k_tape_match
-  } else if (takes_number_path(c, root)) {
+  }
+}
+
+// the number tokens k_tok_apply listed, one per lane: visit_number (tape_builder.h:213-275) = parse_number (numberparsing.h:859-971, sj_number.h)
+__global__ __launch_bounds__(TP_THREADS) void k_tape_numbers(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, const int *__restrict__ tpos,
+                                                            const u32 *__restrict__ number_list, const int *__restrict__ count_ptr, u64 *__restrict__ tape, u64 tape_cap,
+                                                            u32 *__restrict__ slow_list, u32 slow_cap, tape_result_dev *__restrict__ res) {
+  const u32 count = u32(*count_ptr);
+  for (u64 k = u64(blockIdx.x) * TP_THREADS + threadIdx.x; k < count; k += u64(gridDim.x) * TP_THREADS) {
+    const u32 i = number_list[k];
+    const windowed_bytes src{buf, u32(len)};
     const number_value v = parse_number_token(src, idx[i], static_cast<bigint *>(nullptr));
-    if (v.error) { report_error(res, error_key(i, 2, v.error)); }
-    else if (at + 1 < tape_cap) {
+    if (v.error) { report_error(res, error_key(i, 2, v.error)); continue; }
+    const u64 at = 1 + u64(u32(tpos[i]));
+    if (at + 1 < tape_cap) {
       tape[at] = tape_word(v.type, 0);
       tape[at + 1] = v.bits; // sign only when v.slow: k_tape_slow_numbers completes it
       if (v.slow) {
-        const u32 k = atomicAdd(&res->slow_numbers, 1u);
-        if (k < slow_cap) { slow_list[k] = u32(i); }
+        const u32 s = atomicAdd(&res->slow_numbers, 1u);
+        if (s < slow_cap) { slow_list[s] = i; }
       }
     }
-  } else if (c == 't' || c == 'f' || c == 'n') {
-    const bool ok = c == 't' ? atom_matches(src, idx[i], 't', 'r', 'u', 'e', 0)
-                             : (c == 'f' ? atom_matches(src, idx[i], 'f', 'a', 'l', 's', 'e') : atom_matches(src, idx[i], 'n', 'u', 'l', 'l', 0));
-    if (!ok) { report_error(res, error_key(i, 2, c == 't' ? SJ_T_ATOM_ERROR : (c == 'f' ? SJ_F_ATOM_ERROR : SJ_N_ATOM_ERROR))); }
-    if (at < tape_cap) { tape[at] = tape_word(c, 0); }
   }
 }
 
@@ -415,7 +464,8 @@ struct tape_workspace {
   u8 *tokc, *ctx;
   int *slots, *depth, *kord; // tape position, nesting depth, string ordinal of every token (entry n: the totals)
   int *m;                    // brackets and commas = elements of the sort
-  int *sums;                 // k_tok_reduce's block totals (5 rows)
+  int *sums;                 // k_tok_reduce's block totals (6 rows)
+  u32 *number_list;          // the number tokens
   u32 tok_blocks;
   unsigned short *key_a, *key_b;
   u32 *tok_a, *tok_b, *openpos, *slow_list;
@@ -432,12 +482,13 @@ static tape_workspace carve(uint8_t *base, uint32_t n, uint64_t len) {
   w.slow_cap = u32(len / 20 + 64 < n1 ? len / 20 + 64 : n1);
   w.res = reinterpret_cast<tape_result_dev *>(take(sizeof(tape_result_dev)));
   w.n_words = reinterpret_cast<u32 *>(take(64));
-  w.m = reinterpret_cast<int *>(w.n_words) + 8;
+  w.m = reinterpret_cast<int *>(w.n_words) + 8; // [8] = m, [9] = highest level in the sort, [10] = number tokens; n_words[2] = length of the second pass's scan
   w.tokc = take(n1 + 8);
   w.ctx = take(n1 + 8);
   w.slots = reinterpret_cast<int *>(take(n1 * 4 + 64));
   w.depth = reinterpret_cast<int *>(take(n1 * 4 + 64));
   w.kord = reinterpret_cast<int *>(take(n1 * 4 + 64));
+  w.number_list = reinterpret_cast<u32 *>(take(n1 * 4 + 64));
   w.tok_blocks = blocks_of(n1, TS_BLOCK);
   w.sums = reinterpret_cast<int *>(take(size_t(w.tok_blocks) * TS_SUMS * 4 + 64));
   w.key_a = reinterpret_cast<unsigned short *>(take(n1 * 2 + 64));
@@ -471,7 +522,8 @@ const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *i
   const u32 kmax = max_depth < 4095u ? max_depth : 4095u;
   hipLaunchKernelGGL(k_tok_reduce, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, w.tokc, n, w.sums, w.tok_blocks);
   hipLaunchKernelGGL(k_tok_scan_sums, dim3(1), dim3(1024), 0, s, w.sums, w.tok_blocks);
-  hipLaunchKernelGGL(k_tok_apply, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, w.tokc, n, kmax, w.sums, w.tok_blocks, w.slots, w.depth, w.kord, w.key_a, w.tok_a, w.m);
+  (void)hipMemsetAsync(w.m, 0, 3 * sizeof(int), s);
+  hipLaunchKernelGGL(k_tok_apply, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, w.tokc, n, kmax, w.sums, w.tok_blocks, w.slots, w.depth, w.kord, w.key_a, w.tok_a, w.m, w.m + 1, w.number_list);
   return w.kord;
 }
 
@@ -483,20 +535,24 @@ void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t
   const u32 n1 = n + 1;
   const u32 grid = blocks_of(n1, TP_THREADS);
   const int *m_ptr = w.m;
-  // two passes of six bits cover levels up to 4095
-  hipLaunchKernelGGL(k_radix_hist, dim3(w.tiles), dim3(64), 0, s, w.key_a, m_ptr, 0u, w.tiles, w.hist);
+  // two passes of six bits cover levels up to 4095; the second one only runs for documents nested 64 deep and more
+  const int *max_level = w.m + 1;
+  hipLaunchKernelGGL(k_radix_hist, dim3(w.tiles), dim3(64), 0, s, w.key_a, m_ptr, 0u, w.tiles, w.hist, max_level, w.n_words + 2);
   enqueue_scan(w.hist, w.tiles * RADIX_BINS, w.n_words + 1, w.partial, s);
-  hipLaunchKernelGGL(k_radix_scatter, dim3(w.tiles), dim3(64), 0, s, w.key_a, w.tok_a, m_ptr, 0u, w.tiles, w.hist, w.key_b, w.tok_b);
-  hipLaunchKernelGGL(k_radix_hist, dim3(w.tiles), dim3(64), 0, s, w.key_b, m_ptr, RADIX_BITS, w.tiles, w.hist);
-  enqueue_scan(w.hist, w.tiles * RADIX_BINS, w.n_words + 1, w.partial, s);
-  hipLaunchKernelGGL(k_radix_scatter, dim3(w.tiles), dim3(64), 0, s, w.key_b, w.tok_b, m_ptr, RADIX_BITS, w.tiles, w.hist, w.key_a, w.tok_a);
+  hipLaunchKernelGGL(k_radix_scatter, dim3(w.tiles), dim3(64), 0, s, w.key_a, w.tok_a, m_ptr, 0u, w.tiles, w.hist, w.key_b, w.tok_b, max_level);
+  hipLaunchKernelGGL(k_radix_hist, dim3(w.tiles), dim3(64), 0, s, w.key_b, m_ptr, RADIX_BITS, w.tiles, w.hist, max_level, w.n_words + 2);
+  enqueue_scan(w.hist, w.tiles * RADIX_BINS, w.n_words + 2, w.partial, s);
+  hipLaunchKernelGGL(k_radix_scatter, dim3(w.tiles), dim3(64), 0, s, w.key_b, w.tok_b, m_ptr, RADIX_BITS, w.tiles, w.hist, w.key_a, w.tok_a, max_level);
+  const sorted_pairs sorted{w.key_a, w.key_b, w.tok_a, w.tok_b, max_level};
   // containers
-  hipLaunchKernelGGL(k_tape_opens, dim3(grid), dim3(TP_THREADS), 0, s, w.tokc, w.tok_a, m_ptr, n, w.opens);
+  hipLaunchKernelGGL(k_tape_opens, dim3(grid), dim3(TP_THREADS), 0, s, w.tokc, sorted, m_ptr, n, w.opens);
   enqueue_scan(w.opens, n1, w.n_words, w.partial, s);
-  hipLaunchKernelGGL(k_tape_openpos, dim3(grid), dim3(TP_THREADS), 0, s, w.tokc, w.tok_a, m_ptr, w.opens, w.openpos);
-  hipLaunchKernelGGL(k_tape_match, dim3(grid), dim3(TP_THREADS), 0, s, w.tokc, w.key_a, w.tok_a, m_ptr, w.opens, w.openpos, w.slots, w.ctx, tape, tape_cap, w.res);
+  hipLaunchKernelGGL(k_tape_openpos, dim3(grid), dim3(TP_THREADS), 0, s, w.tokc, sorted, m_ptr, w.opens, w.openpos);
+  hipLaunchKernelGGL(k_tape_match, dim3(grid), dim3(TP_THREADS), 0, s, w.tokc, sorted, m_ptr, w.opens, w.openpos, w.slots, w.ctx, tape, tape_cap, w.res);
   hipLaunchKernelGGL(k_tape_write, dim3(grid), dim3(TP_THREADS), 0, s, buf, len, idx, n, max_depth, w.tokc, w.slots, w.depth, w.ctx, str_offsets, w.kord, strs, string_buf,
-                     tape, tape_cap, w.slow_list, w.slow_cap, w.res);
+                     tape, tape_cap, w.res);
+  hipLaunchKernelGGL(k_tape_numbers, dim3(grid < 8192u ? grid : 8192u), dim3(TP_THREADS), 0, s, buf, len, idx, w.slots, w.number_list, w.m + 2, tape, tape_cap, w.slow_list,
+                     w.slow_cap, w.res);
   hipLaunchKernelGGL(k_tape_slow_numbers, dim3(64), dim3(64), 0, s, buf, len, idx, w.slots, w.slow_list, w.slow_cap, tape, tape_cap, w.res);
 }
 
