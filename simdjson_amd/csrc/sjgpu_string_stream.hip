@@ -364,13 +364,15 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__rest
       u32 off = map.lane_off;
 #pragma unroll
       for (int j = 0; j < 16; j++) {
+        // a closing quote leaves as a zero byte: clear it in the dword (bit k of the nibble -> byte k: one multiply spreads the bits)
+        const u32 close4 = u32(closing >> (4 * j)) & 0xFu;
+        const u32 wj = w[j] & ~(((close4 * 0x00204081u) & 0x01010101u) * 0xFFu);
 #pragma unroll
         for (int b = 0; b < 4; b++) {
           const int i = 4 * j + b;
-          const u32 is_one = u32(one >> i) & 1u, is_open = u32(open >> i) & 1u, is_close = u32(closing >> i) & 1u;
-          const u32 v = is_close ? 0u : ((w[j] >> (8 * b)) & 0xFFu);
+          const u32 is_one = u32(one >> i) & 1u, is_open = u32(open >> i) & 1u;
           u8 *const at = is_one ? stage + off : dump;
-          *at = u8(v);
+          *at = u8(wj >> (8 * b));
           off += is_one + 4u * is_open;
         }
       }

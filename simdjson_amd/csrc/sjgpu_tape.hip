@@ -13,9 +13,9 @@
 // The first error of the serial walk is the smallest (list index, rank) over all tokens that break their rule: one atomicMin.
 //
 // Passes (all asynchronous on the caller's stream; one 32-byte result is read back by the caller):
-//   k_tape_classify   the byte of every token                                                    1 thread / token
-//   k_tok_reduce / k_tok_scan_sums / k_tok_apply   tape position, nesting depth and string ordinal of every token in one sweep over
-//                     the token bytes; (level, token) of every bracket and comma into the sort's input
+//   k_tok_classify / k_tok_scan_sums / k_tok_apply   the byte of every token; tape position, nesting depth and string ordinal of every
+//                     token in one sweep over those bytes; (level, kind, token) of every bracket and comma into the sort's input;
+//                     the number tokens into a list
 //   (the string buffer: sjgpu_strings.hip / sjgpu_string_stream.hip, which take the string ordinals from here)
 //   2 x radix pass    stable LSD radix sort on the level, 6 bits per pass: histogram, scan, scatter   1 wave / 2048 elements
 //   k_tape_opens + scan + k_tape_openpos   container ordinal per sorted element, sorted position of every open
@@ -65,25 +65,13 @@ struct windowed_bytes {
 
 __device__ __forceinline__ void report_error(tape_result_dev *res, u64 key) { atomicMin(reinterpret_cast<unsigned long long *>(&res->error_key), (unsigned long long)key); }
 
-// tokc holds the token bytes with TWO zero bytes in front and behind: tokc[i + 2] = byte of token i
-__global__ __launch_bounds__(TP_THREADS) void k_tape_classify(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, u8 *__restrict__ tokc) {
-  const u64 i = u64(blockIdx.x) * TP_THREADS + threadIdx.x;
-  if (i > n) { return; }
-  if (i == n) {
-    tokc[0] = 0; tokc[1] = 0; tokc[n + 2] = 0; tokc[n + 3] = 0;
-    return;
-  }
-  const u32 pos = idx[i];
-  tokc[i + 2] = u8(pos < len ? u32(buf[pos]) : 0x20u);
-}
-
 // ---- the token front: every prefix sum the tape needs, in one sweep over the token bytes ----------------------------------------------
 // Per token (sj_tape_rules.h): tape words (0 / 1 / 2), "goes into the sort" (brackets and commas), "is a string", opening, closing.
 // Their exclusive prefix sums are the token's tape position, its slot in the sort's input, its ordinal among the strings and
 // (opens - closes) its nesting depth.  The first version wrote three int arrays and ran the generic three-kernel scan over each
 // (profiles/r03_pmc_summary.txt: 2.6 GB of the 9.2 GB a twitter-like call moved); all five sums are functions of ONE byte per token,
-// so here a block of 4096 tokens reads its 4 KiB of token bytes twice (k_tok_reduce: block totals; k_tok_apply: prefixes + outputs)
-// and nothing else.  Inside a block the five counters travel packed in three dwords (each field < 2^16).
+// so here a block of 4096 tokens adds them up while it fetches its token bytes (k_tok_classify) and reads the 4 KiB of bytes once more
+// for the prefixes (k_tok_apply) -- nothing else.  Inside a block the five counters travel packed in three dwords (each field < 2^16).
 constexpr u32 TS_THREADS = 256, TS_ROW = TS_THREADS * 4, TS_ROWS = 4, TS_BLOCK = TS_ROW * TS_ROWS, TS_SUMS = 6;
 struct tok_packed {
   u32 a, b, c; // a: tape words | sort flag << 16;  b: string | opening << 16;  c: closing | number << 16
@@ -97,28 +85,51 @@ __device__ __forceinline__ tok_packed tok_contribution(u32 ch, bool root) {
   p.c = close | ((slots == 2u ? 1u : 0u) << 16);
   return p;
 }
+// what an element of the sort is, kept in the four bits of its 16-bit key the level (<= 4095) leaves free: the passes behind the sort
+// then never have to look the token's byte up again
+constexpr u32 KIND_SHIFT = 12, KIND_COMMA = 0, KIND_OPEN_OBJECT = 1, KIND_OPEN_ARRAY = 2, KIND_CLOSE_OBJECT = 3, KIND_CLOSE_ARRAY = 4;
+__device__ __forceinline__ u32 sort_kind(u32 ch) {
+  return ch == '{' ? KIND_OPEN_OBJECT : (ch == '[' ? KIND_OPEN_ARRAY : (ch == '}' ? KIND_CLOSE_OBJECT : (ch == ']' ? KIND_CLOSE_ARRAY : KIND_COMMA)));
+}
+__device__ __forceinline__ bool kind_is_open(u32 kind) { return kind == KIND_OPEN_OBJECT || kind == KIND_OPEN_ARRAY; }
 typedef u32 __attribute__((aligned(1))) u32_unaligned_t;
 // the four token bytes i0 ... i0 + 3 (tokc is two bytes off the dword grid: one unaligned load)
 __device__ __forceinline__ u32 four_tokens(const u8 *__restrict__ tokc, u64 i0) { return *reinterpret_cast<const u32_unaligned_t *>(tokc + 2 + i0); }
 
-// sums[k * nblocks + block], k = tape words, sort flags, strings, opens, closes, numbers
-__global__ __launch_bounds__(TS_THREADS) void k_tok_reduce(const u8 *__restrict__ tokc, u32 n, int *__restrict__ sums, u32 nblocks) {
+// tokc holds the token bytes with TWO zero bytes in front and behind: tokc[i + 2] = byte of token i (k_tape_write looks two tokens back
+// and one ahead).  The same sweep leaves the block totals: sums[k * nblocks + block], k = tape words, sort flags, strings, opens,
+// closes, numbers.
+__global__ __launch_bounds__(TS_THREADS) void k_tok_classify(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, u8 *__restrict__ tokc,
+                                                            int *__restrict__ sums, u32 nblocks) {
   __shared__ u32 sh[3][TS_THREADS / 64];
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u64 block0 = u64(blockIdx.x) * TS_BLOCK;
+  if (blockIdx.x == 0 && tid == 0) { tokc[0] = 0; tokc[1] = 0; tokc[n + 2] = 0; tokc[n + 3] = 0; }
+  const bool aligned16 = (reinterpret_cast<uintptr_t>(idx) & 15u) == 0;
   u32 a = 0, b = 0, c = 0;
 #pragma unroll
   for (u32 row = 0; row < TS_ROWS; row++) {
     const u64 i0 = block0 + u64(row) * TS_ROW + 4u * tid;
     if (i0 < n) {
-      const u32 four = four_tokens(tokc, i0);
+      u32 pos[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+      if (i0 + 3 < n && aligned16) { // (stage 1 writes 16-byte aligned lists; the C API only asks for 4 here)
+        const uint4 q = *reinterpret_cast<const uint4 *>(idx + i0);
+        pos[0] = q.x; pos[1] = q.y; pos[2] = q.z; pos[3] = q.w;
+      } else {
+        for (u32 j = 0; j < 4; j++) { if (i0 + j < n) { pos[j] = idx[i0 + j]; } }
+      }
+      u32 four = 0;
 #pragma unroll
       for (u32 j = 0; j < 4; j++) {
         if (i0 + j < n) {
-          const tok_packed p = tok_contribution((four >> (8u * j)) & 0xFFu, i0 + j == 0);
+          const u32 ch = pos[j] < len ? u32(buf[pos[j]]) : 0x20u;
+          four |= ch << (8u * j);
+          const tok_packed p = tok_contribution(ch, i0 + j == 0);
           a += p.a; b += p.b; c += p.c;
         }
       }
+      if (i0 + 3 < n) { *reinterpret_cast<u32_unaligned_t *>(tokc + 2 + i0) = four; }
+      else { for (u32 j = 0; j < 4; j++) { if (i0 + j < n) { tokc[2 + i0 + j] = u8(four >> (8u * j)); } } }
     }
   }
   a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); // a wave: at most 64 x 16 tokens x 2 words: the fields do not overflow
@@ -139,12 +150,13 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_reduce(const u8 *__restrict_
     sums[5 * nblocks + blockIdx.x] = int(numbers);
   }
 }
-// one workgroup: the five rows of block totals become exclusive prefixes, in place
+// one workgroup per row: the block totals become exclusive prefixes, in place
 __global__ __launch_bounds__(1024) void k_tok_scan_sums(int *__restrict__ sums, u32 nblocks) {
   __shared__ int sh[1024];
   const u32 per = (nblocks + 1023) / 1024;
   const u32 lo = min(threadIdx.x * per, nblocks), hi = min(lo + per, nblocks);
-  for (u32 k = 0; k < TS_SUMS; k++) {
+  {
+    const u32 k = blockIdx.x;
     int *row = sums + size_t(k) * nblocks;
     int sum = 0;
     for (u32 i = lo; i < hi; i++) { sum += row[i]; }
@@ -216,7 +228,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
         if (i < n && (p[j].a >> 16)) {
           int k = (p[j].b >> 16) ? d : d - 1;
           k = k < 0 ? 0 : (k > int(kmax) ? int(kmax) : k);
-          key[slot] = (unsigned short)k;
+          key[slot] = (unsigned short)(u32(k) | (sort_kind((four >> (8u * j)) & 0xFFu) << KIND_SHIFT));
           tok[slot] = u32(i);
           top = k > top ? k : top;
         }
@@ -304,50 +316,52 @@ struct sorted_pairs {
 
 // ---- containers -------------------------------------------------------------------------------------------------------------------------
 // opens[j] = 1 where the sorted element j is an opening bracket (the scan turns it into "opens in front of j"); opens[m] = 0
-__global__ __launch_bounds__(TP_THREADS) void k_tape_opens(const u8 *__restrict__ tokc, sorted_pairs sorted, const int *__restrict__ m_ptr, u32 n, int *__restrict__ opens) {
-  const u32 *__restrict__ tok = sorted.tok();
+__global__ __launch_bounds__(TP_THREADS) void k_tape_opens(sorted_pairs sorted, const int *__restrict__ m_ptr, u32 n, int *__restrict__ opens) {
+  const unsigned short *__restrict__ key = sorted.key();
   const u64 j = u64(blockIdx.x) * TP_THREADS + threadIdx.x;
   const u32 m = u32(*m_ptr);
   if (j > n) { return; }
-  opens[j] = (j < m && is_open_char(tokc[tok[j] + 2])) ? 1 : 0; // zeros behind the m sorted elements: the scan runs over n + 1 entries
+  opens[j] = (j < m && kind_is_open(u32(key[j]) >> KIND_SHIFT)) ? 1 : 0; // zeros behind the m sorted elements: the scan runs over n + 1 entries
 }
 // openpos[k] = sorted position of the k-th opening bracket
-__global__ __launch_bounds__(TP_THREADS) void k_tape_openpos(const u8 *__restrict__ tokc, sorted_pairs sorted, const int *__restrict__ m_ptr, const int *__restrict__ opens_before,
-                                                            u32 *__restrict__ openpos) {
-  const u32 *__restrict__ tok = sorted.tok();
+__global__ __launch_bounds__(TP_THREADS) void k_tape_openpos(sorted_pairs sorted, const int *__restrict__ m_ptr, const int *__restrict__ opens_before, u32 *__restrict__ openpos) {
+  const unsigned short *__restrict__ key = sorted.key();
   const u64 j = u64(blockIdx.x) * TP_THREADS + threadIdx.x;
   const u32 m = u32(*m_ptr);
   if (j >= m) { return; }
-  if (is_open_char(tokc[tok[j] + 2])) { openpos[opens_before[j]] = u32(j); }
+  if (kind_is_open(u32(key[j]) >> KIND_SHIFT)) { openpos[opens_before[j]] = u32(j); }
 }
 // commas: ctx[token] = kind of their container.  Closing brackets: the two bracket words of the tape
 // (end_container, tape_builder.h:396-407; an empty container is the same formula with count 0, :386-391).
-__global__ __launch_bounds__(TP_THREADS) void k_tape_match(const u8 *__restrict__ tokc, sorted_pairs sorted, const int *__restrict__ m_ptr,
-                                                          const int *__restrict__ opens_before, const u32 *__restrict__ openpos, const int *__restrict__ tpos, u8 *__restrict__ ctx,
-                                                          u64 *__restrict__ tape, u64 tape_cap, tape_result_dev *__restrict__ res) {
+__global__ __launch_bounds__(TP_THREADS) void k_tape_match(sorted_pairs sorted, const int *__restrict__ m_ptr, const int *__restrict__ opens_before,
+                                                          const u32 *__restrict__ openpos, const int *__restrict__ tpos, u8 *__restrict__ ctx, u64 *__restrict__ tape,
+                                                          u64 tape_cap, tape_result_dev *__restrict__ res) {
   const unsigned short *__restrict__ key = sorted.key();
   const u32 *__restrict__ tok = sorted.tok();
   const u64 j = u64(blockIdx.x) * TP_THREADS + threadIdx.x;
   const u32 m = u32(*m_ptr);
   if (j >= m) { return; }
-  const u32 i = tok[j], c = tokc[i + 2];
-  if (is_open_char(c)) { return; }
+  const u32 kj = key[j], kind = kj >> KIND_SHIFT;
+  if (kind_is_open(kind)) { return; }
   const u32 cid = u32(opens_before[j]); // an element that is not an open: opens in front of it = opens at positions <= j
   if (cid == 0) { return; }
   const u32 jo = openpos[cid - 1];
-  if (key[jo] != key[j]) { return; } // no container of this level in front: the token's own rule reports it
-  const u32 io = tok[jo], co = tokc[io + 2];
-  if (c == ',') {
-    ctx[i] = u8(co == '{' ? CTX_OBJECT : CTX_ARRAY);
+  const u32 ko = key[jo];
+  if (((ko ^ kj) & ((1u << KIND_SHIFT) - 1)) != 0) { return; } // no container of this level in front: the token's own rule reports it
+  const bool object = (ko >> KIND_SHIFT) == KIND_OPEN_OBJECT;
+  const u32 i = tok[j];
+  if (kind == KIND_COMMA) {
+    ctx[i] = u8(object ? CTX_OBJECT : CTX_ARRAY);
     return;
   }
-  if ((c == '}') != (co == '{')) { report_error(res, error_key(i, 0, SJ_TAPE_ERROR)); }
+  if ((kind == KIND_CLOSE_OBJECT) != object) { report_error(res, error_key(i, 0, SJ_TAPE_ERROR)); }
+  const u32 io = tok[jo];
   const u64 open_at = 1 + u64(u32(tpos[io])), close_at = 1 + u64(u32(tpos[i]));
   const u64 between = j - jo; // commas + 1
   const u64 count = (i == io + 1) ? 0 : (between > 0xFFFFFFull ? 0xFFFFFFull : between);
   if (close_at < tape_cap) {
-    tape[close_at] = tape_word(c, open_at);
-    tape[open_at] = tape_word(co, (count << 32) | (close_at + 1));
+    tape[close_at] = tape_word(kind == KIND_CLOSE_OBJECT ? u32('}') : u32(']'), open_at);
+    tape[open_at] = tape_word(object ? u32('{') : u32('['), (count << 32) | (close_at + 1));
   } else {
     res->overflow = 1;
   }
@@ -377,8 +391,17 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_write(const u8 *__restrict_
     if ((c0 == '{' && last != '}') || (c0 == '[' && last != ']')) { report_error(res, error_key(0, 0, SJ_TAPE_ERROR)); } // json_iterator.h:138-143
     if (depth[n] != 0) { report_error(res, error_key(n, 0, SJ_TAPE_ERROR)); } // the walk meets the sentinel inside a container
   } else if (i < n) {
-    const u32 c = tokc[i + 2], prev = tokc[i + 1], prev2 = tokc[i], next = tokc[i + 3];
-    const u32 ctx_prev = i >= 1 ? ctx[i - 1] : 0u, ctx_prev2 = i >= 2 ? ctx[i - 2] : 0u;
+    const u32 around = *reinterpret_cast<const u32_unaligned_t *>(tokc + i); // the bytes of tokens i - 2 ... i + 1 in one load
+    const u32 prev2 = around & 0xFFu, prev = (around >> 8) & 0xFFu, c = (around >> 16) & 0xFFu, next = around >> 24;
+    u32 ctx_prev = 0, ctx_prev2 = 0;
+    if (i >= 2) {
+      typedef unsigned short __attribute__((aligned(1))) u16_unaligned_t;
+      const u32 two = *reinterpret_cast<const u16_unaligned_t *>(ctx + i - 2);
+      ctx_prev2 = two & 0xFFu;
+      ctx_prev = two >> 8;
+    } else if (i == 1) {
+      ctx_prev = ctx[0];
+    }
     u32 rank = 0;
     const u32 g = token_grammar_error(i, c, prev, prev2, next, ctx_prev, ctx_prev2, (long long)depth[i], max_depth, &rank);
     if (g) { report_error(res, error_key(i, rank, g)); }
@@ -464,7 +487,7 @@ struct tape_workspace {
   u8 *tokc, *ctx;
   int *slots, *depth, *kord; // tape position, nesting depth, string ordinal of every token (entry n: the totals)
   int *m;                    // brackets and commas = elements of the sort
-  int *sums;                 // k_tok_reduce's block totals (6 rows)
+  int *sums;                 // k_tok_classify's block totals (6 rows)
   u32 *number_list;          // the number tokens
   u32 tok_blocks;
   unsigned short *key_a, *key_b;
@@ -518,10 +541,9 @@ const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *i
   (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.n_words), int(n1), 1, s);
   (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.n_words + 1), int(w.tiles * RADIX_BINS), 1, s);
   (void)hipMemsetAsync(w.ctx, 0, size_t(n1) + 8, s);
-  hipLaunchKernelGGL(k_tape_classify, dim3(blocks_of(n1, TP_THREADS)), dim3(TP_THREADS), 0, s, buf, len, idx, n, w.tokc);
   const u32 kmax = max_depth < 4095u ? max_depth : 4095u;
-  hipLaunchKernelGGL(k_tok_reduce, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, w.tokc, n, w.sums, w.tok_blocks);
-  hipLaunchKernelGGL(k_tok_scan_sums, dim3(1), dim3(1024), 0, s, w.sums, w.tok_blocks);
+  hipLaunchKernelGGL(k_tok_classify, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, buf, len, idx, n, w.tokc, w.sums, w.tok_blocks);
+  hipLaunchKernelGGL(k_tok_scan_sums, dim3(TS_SUMS), dim3(1024), 0, s, w.sums, w.tok_blocks);
   (void)hipMemsetAsync(w.m, 0, 3 * sizeof(int), s);
   hipLaunchKernelGGL(k_tok_apply, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, w.tokc, n, kmax, w.sums, w.tok_blocks, w.slots, w.depth, w.kord, w.key_a, w.tok_a, w.m, w.m + 1, w.number_list);
   return w.kord;
@@ -545,10 +567,10 @@ void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t
   hipLaunchKernelGGL(k_radix_scatter, dim3(w.tiles), dim3(64), 0, s, w.key_b, w.tok_b, m_ptr, RADIX_BITS, w.tiles, w.hist, w.key_a, w.tok_a, max_level);
   const sorted_pairs sorted{w.key_a, w.key_b, w.tok_a, w.tok_b, max_level};
   // containers
-  hipLaunchKernelGGL(k_tape_opens, dim3(grid), dim3(TP_THREADS), 0, s, w.tokc, sorted, m_ptr, n, w.opens);
+  hipLaunchKernelGGL(k_tape_opens, dim3(grid), dim3(TP_THREADS), 0, s, sorted, m_ptr, n, w.opens);
   enqueue_scan(w.opens, n1, w.n_words, w.partial, s);
-  hipLaunchKernelGGL(k_tape_openpos, dim3(grid), dim3(TP_THREADS), 0, s, w.tokc, sorted, m_ptr, w.opens, w.openpos);
-  hipLaunchKernelGGL(k_tape_match, dim3(grid), dim3(TP_THREADS), 0, s, w.tokc, sorted, m_ptr, w.opens, w.openpos, w.slots, w.ctx, tape, tape_cap, w.res);
+  hipLaunchKernelGGL(k_tape_openpos, dim3(grid), dim3(TP_THREADS), 0, s, sorted, m_ptr, w.opens, w.openpos);
+  hipLaunchKernelGGL(k_tape_match, dim3(grid), dim3(TP_THREADS), 0, s, sorted, m_ptr, w.opens, w.openpos, w.slots, w.ctx, tape, tape_cap, w.res);
   hipLaunchKernelGGL(k_tape_write, dim3(grid), dim3(TP_THREADS), 0, s, buf, len, idx, n, max_depth, w.tokc, w.slots, w.depth, w.ctx, str_offsets, w.kord, strs, string_buf,
                      tape, tape_cap, w.res);
   hipLaunchKernelGGL(k_tape_numbers, dim3(grid < 8192u ? grid : 8192u), dim3(TP_THREADS), 0, s, buf, len, idx, w.slots, w.number_list, w.m + 2, tape, tape_cap, w.slow_list,
