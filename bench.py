@@ -282,11 +282,13 @@ def leg_parse_strings(cx):
     gpu_ms = e0.elapsed_time(e1) / reps
     leg = {"workload": f"twitter_like {L} B, {n} structurals, {strings} strings -> {used} B of [u32 length][bytes][0] records (document::string_buf of the reference)",
            "gpu_ms_per_call": round(gpu_ms, 3), "value": round(L / gpu_ms / 1e6, 1), "unit": "GB/s of document",
-           "string_bytes_GBps": round(used / gpu_ms / 1e6, 1), "kernel": "k_strings<false> + scan + k_strings<true>",
+           "string_bytes_GBps": round(used / gpu_ms / 1e6, 1),
+           "kernel": ("k_strs_count + k_strs_resolve + k_strs_tokens + scan + k_strs_write + k_strs_finalize (stream compaction of the document, sjgpu_string_stream.hip)"
+                      if p.string_path() == 1 else "k_strings<false> + scan + k_strings<true> (per-string walk)"),
            "roofline": {"bound": "hbm", "achieved": round((L + 4 * (n + 1) + used + 4 * (n + 1)) / gpu_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round((L + 4 * (n + 1) + used + 4 * (n + 1)) / gpu_ms / 1e6 / HBM_PEAK_GBS, 4),
                         "algorithmic_bytes_per_launch": L + 4 * (n + 1) + used + 4 * (n + 1),
-                        "algorithmic_bytes": "document + list in, records + offsets out; the three kernels of one call together"},
+                        "algorithmic_bytes": "document + list in, records + offsets out; all kernels of one call together"},
            "note": "includes the 24-byte result read-back of every call; the list and the buffer stay on the device"}
     cpu = cx.cpu()
     if cpu.LIB_REF and os.path.exists(cpu.LIB_REF):
@@ -425,7 +427,8 @@ def leg_tape(cx):
         alg = L + 4 * (n + 1) + 8 * tw + sb
         leg = {"workload": f"{kind} {L} B, {n} structurals -> {tw} tape words + {sb} B of string records (dom::document of the reference)",
                "gpu_ms_per_call": round(gpu_ms, 3), "value": round(L / gpu_ms / 1e6, 1), "unit": "GB/s of document",
-               "kernel": "k_strings x2 + k_tape_classify / select / radix x2 / match / write + 7 scans (sjgpu_tape.hip)",
+               "kernel": "k_tok_classify / scan_sums / apply + string buffer (" + ("stream compaction: k_strs_count / resolve / write" if p.string_path() == 1 else "per-string walk")
+                         + ") + k_radix_hist / scatter + k_tape_opens / openpos / match / write / numbers + 3 scans (sjgpu_tape.hip, sjgpu_string_stream.hip)",
                "roofline": {"bound": "hbm", "achieved": round(alg / gpu_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / gpu_ms / 1e6 / HBM_PEAK_GBS, 4),
                             "algorithmic_bytes_per_launch": alg,
                             "algorithmic_bytes": "document + 4 (n + 1) list in, 8 tape words + string records out; all kernels of one sjgpu_stage2_device call together"},

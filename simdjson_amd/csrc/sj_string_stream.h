@@ -144,7 +144,8 @@ SJ_HD string_block no_escapes(u64 quote) { return string_block{~quote, 0, 0}; }
 // \u escapes: the ones whose 'u' lies in this block (U) and the ones up to 10 bytes in front of it whose bytes may reach into it
 // (u_prev: bit k = byte block_pos - 10 + k is an escaped 'u').  The reference consumes a valid low-surrogate escape together with
 // the high one in front of it (stringparsing.h:64-81), so the candidates are walked front to back and a consumed one is skipped.
-// sink.patch(p, byte): the kept byte at block position p (0 ... 63) has this value.
+// sink.escape(rel, len, packed): the escape whose 'u' sits at block position rel (-10 ... 63) stands for len bytes (packed, first one low),
+// which are the kept bytes at positions rel ... rel + len - 1.
 template <class SRC, class SINK>
 SJ_HD void unicode_escapes(const SRC &src, u32 block_pos, u64 U, u32 u_prev, bool allow_replacement, string_block &b, SINK &sink) {
   int consumed_at = -100; // block-relative position of the 'u' of a low-surrogate escape that went with its high one
@@ -160,17 +161,21 @@ SJ_HD void unicode_escapes(const SRC &src, u32 block_pos, u64 U, u32 u_prev, boo
       const u_escape e = decode_u_escape(src, block_pos + u32(rel), allow_replacement);
       b.keep = (b.keep & ~bits_between(rel - 1, rel + int(e.span))) | bits_between(rel, rel + int(e.len) - 1);
       if (e.bad && rel >= 0) { b.bad |= u64(1) << rel; }
-      for (u32 j = 0; j < e.len; j++) {
-        const int p = rel + int(j);
-        if (p >= 0 && p < 64) { sink.patch(u32(p), (e.packed >> (8u * j)) & 0xFFu); }
-      }
+      if (e.len) { sink.escape(rel, e.len, e.packed); }
       if (e.span == 10u) { consumed_at = rel + 6; }
     }
   }
 }
 struct no_patches {
-  SJ_HD void patch(u32, u32) {}
+  SJ_HD void escape(int, u32, u32) {}
 };
+// the bytes of one escape that fall into the block, one call of f(position 0 ... 63, byte) each
+template <class F> SJ_HD void for_each_escape_byte(int rel, u32 len, u32 packed, F &&f) {
+  for (u32 j = 0; j < len; j++) {
+    const int p = rel + int(j);
+    if (p >= 0 && p < 64) { f(u32(p), (packed >> (8u * j)) & 0xFFu); }
+  }
+}
 
 // output bytes of a block given which of its bytes are inside strings (in_string: stage 1's mask, opening quote included,
 // closing quote excluded): data bytes + 4 per opening quote + 1 per closing quote

@@ -78,6 +78,20 @@ struct strs_carry {
   u32 s; // inside a string (relative to the segment start in k_strs_count, absolute in k_strs_write)
   u32 u; // the last 10 bytes: bit k = byte (next chunk) - 10 + k is an escaped 'u'
 };
+// what the first \\u escapes of a lane stand for, kept from the decode that sized them so that k_strs_write need not decode them again
+// when it knows where their bytes go (a lane with more of them decodes a second time)
+struct escape_notes {
+  static constexpr u32 ROOM = 2;
+  u32 count = 0;
+  int rel0 = 0, rel1 = 0;
+  u32 len0 = 0, len1 = 0, packed0 = 0, packed1 = 0; // (named, not indexed: an indexed array would be parked in LDS)
+  __device__ __forceinline__ void escape(int r, u32 len, u32 pk) {
+    const bool first = count == 0, second = count == 1; // selects of values: stores through a chosen address would put the notes on the stack
+    rel0 = first ? r : rel0; len0 = first ? len : len0; packed0 = first ? pk : packed0;
+    rel1 = second ? r : rel1; len1 = second ? len : len1; packed1 = second ? pk : packed1;
+    count++;
+  }
+};
 struct strs_chunk {
   u64 quote, in_string; // real quotes; stage 1's in-string mask (opening quote included, closing excluded)
   string_block b;
@@ -101,8 +115,8 @@ __device__ __forceinline__ u32 u_tail_before(const u8 *__restrict__ buf, u64 sta
 }
 
 // one chunk: stage 1's escape and quote algebra (scan_chunk, sjgpu_device.h), then what the strings need on top of it
-template <class SRC>
-__device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carry &wc, u32 lane, const SRC &src, u32 block_pos, bool allow) {
+template <class SRC, class SINK>
+__device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carry &wc, u32 lane, const SRC &src, u32 block_pos, bool allow, SINK &notes) {
   const planes P = transpose64(w);
   const classes c = classify(P);
   const u64 lt = lanemask_lt(lane);
@@ -138,10 +152,7 @@ __device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carr
       u32 prev = u32(__shfl_up(int(top), 1));
       if (lane == 0) { prev = wc.u; }
       out.u_prev = prev;
-      if (out.U | u64(prev)) {
-        no_patches none;
-        unicode_escapes(src, block_pos, out.U, prev, allow, out.b, none);
-      }
+      if (out.U | u64(prev)) { unicode_escapes(src, block_pos, out.U, prev, allow, out.b, notes); }
     }
     u_out = readlane(top, 63);
   }
@@ -173,7 +184,8 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_count(const u8 *__rest
       wc.e = segment_carry_from(buf, seg_start, lane, lookback, esc).e;
       wc.u = u_tail_before(buf, seg_start, lane, lookback, esc);
     }
-    const strs_chunk m = string_chunk(w, wc, lane, src, u32(pos), allow_replacement != 0);
+    no_patches none;
+    const strs_chunk m = string_chunk(w, wc, lane, src, u32(pos), allow_replacement != 0, none);
     d0 += u32(popc64(m.b.keep & m.in_string));
     dall += u32(popc64(m.b.keep));
     o0 += u32(popc64(m.quote & m.in_string));
@@ -308,8 +320,10 @@ struct window_patches {
   u8 *stage;
   window_map map;
   u64 kept; // data bytes of the lane
-  __device__ __forceinline__ void patch(u32 p, u32 v) {
-    if ((kept >> p) & 1u) { stage[map.at(p)] = u8(v); }
+  __device__ __forceinline__ void escape(int rel, u32 len, u32 packed) {
+    for_each_escape_byte(rel, len, packed, [&](u32 p, u32 v) {
+      if ((kept >> p) & 1u) { stage[map.at(p)] = u8(v); }
+    });
   }
 };
 
@@ -342,7 +356,8 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__rest
       wc.e = segment_carry_from(buf, seg_start, lane, lookback, esc).e;
       wc.u = u_tail_before(buf, seg_start, lane, lookback, esc);
     }
-    const strs_chunk m = string_chunk(w, wc, lane, src, u32(pos), allow);
+    escape_notes notes;
+    const strs_chunk m = string_chunk(w, wc, lane, src, u32(pos), allow, notes);
     const u64 kept = m.b.keep & m.in_string;       // data bytes
     const u64 open = m.quote & m.in_string;         // 4 bytes each: the length, written by k_strs_finalize
     const u64 one = kept | andn(m.quote, m.in_string); // one byte each: data, and the 0 a closing quote turns into
@@ -382,10 +397,15 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__rest
         const u32 p = ctz64(t);
         stage[map.at(p)] = u8(simple_escape_value(src.byte(u32(pos) + p)));
       }
-      if (m.U | u64(m.u_prev)) {
+      if (notes.count) { // (divergent: the lanes that hold \\u escapes)
         window_patches sink{stage, map, kept};
-        string_block ignored = m.b;
-        unicode_escapes(src, u32(pos), m.U, m.u_prev, allow, ignored, sink);
+        if (notes.count <= escape_notes::ROOM) {
+          sink.escape(notes.rel0, notes.len0, notes.packed0);
+          if (notes.count == 2) { sink.escape(notes.rel1, notes.len1, notes.packed1); }
+        } else {
+          string_block ignored = m.b;
+          unicode_escapes(src, u32(pos), m.U, m.u_prev, allow, ignored, sink);
+        }
       }
       wave_lds_fence();
       // the window leaves as 16-byte stores (emit_bytes' write-out); the 4-byte holes of the lengths carry whatever the window held

@@ -23,7 +23,7 @@ struct doc_bytes {
 };
 struct patch_list {
   int value[64];
-  void patch(u32 p, u32 v) { value[p] = int(v); }
+  void escape(int rel, u32 len, u32 packed) { for_each_escape_byte(rel, len, packed, [&](u32 p, u32 v) { value[p] = int(v); }); }
 };
 
 // returns false if a string is rejected (or the document ends inside one); out = the string buffer with the lengths filled in
