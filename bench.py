@@ -431,7 +431,9 @@ def leg_tape(cx):
                          + ") + k_radix_hist / scatter + k_tape_opens / openpos / match / write / numbers + 3 scans (sjgpu_tape.hip, sjgpu_string_stream.hip)",
                "roofline": {"bound": "hbm", "achieved": round(alg / gpu_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / gpu_ms / 1e6 / HBM_PEAK_GBS, 4),
                             "algorithmic_bytes_per_launch": alg,
-                            "algorithmic_bytes": "document + 4 (n + 1) list in, 8 tape words + string records out; all kernels of one sjgpu_stage2_device call together"},
+                            "algorithmic_bytes": "document + 4 (n + 1) list in, 8 tape words + string records out; all kernels of one sjgpu_stage2_device call together",
+                            "traffic": cx.traffic.get(f"tape:{kind}:{256 << 20}"),
+                            "traffic_source": "profiles/traffic.json (profiles/r03_pmc_summary.txt, addendum): FETCH_SIZE x 2 + WRITE_SIZE summed over the kernels of one call"},
                "note": "includes the 48-byte result read-back of every call; document, list, tape and string buffer stay on the device"}
         if impl:
             R.sjref_dom_parse.restype = ctypes.c_int

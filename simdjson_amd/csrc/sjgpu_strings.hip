@@ -12,6 +12,10 @@
 //   3. k_strings<true>  : the records are written.
 // Output is byte for byte document::string_buf of the reference's dom parse (tests/test_gpu_parity.py::test_string_buffer_*).
 // Bytes at or beyond len read as 0x20, like the padding of a padded_string.
+// Since round 3 these kernels are the SECOND road: launch_parse_strings first lets sjgpu_string_stream.hip try the buffer as a stream
+// compaction of the document, which takes every document whose strings are all valid and all listed; what it declines -- a string the
+// reference rejects, an unclosed string, a quote glued to a scalar -- is done here, with the results these kernels always gave (the first
+// offender, the records of the valid strings).  The switch is a word in device memory: the kernels of the road not taken return at once.
 #include "sjgpu_device.h"
 
 #include <cstdlib>

@@ -17,7 +17,8 @@
 //                     token in one sweep over those bytes; (level, kind, token) of every bracket and comma into the sort's input;
 //                     the number tokens into a list
 //   (the string buffer: sjgpu_strings.hip / sjgpu_string_stream.hip, which take the string ordinals from here)
-//   2 x radix pass    stable LSD radix sort on the level, 6 bits per pass: histogram, scan, scatter   1 wave / 2048 elements
+//   radix passes      stable LSD radix sort on the level, 6 bits per pass: histogram, scan, scatter   1 wave / 2048 elements;
+//                     the second pass only runs for documents nested 64 deep and more
 //   k_tape_opens + scan + k_tape_openpos   container ordinal per sorted element, sorted position of every open
 //   k_tape_match      commas learn their container's kind; closes write BOTH bracket words (count, partner index), kinds checked
 //   k_tape_write      per token: the walk's rule, nesting limit, atoms / string words, root words
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
         dp[j] = d;
         ko[j] = strs0 + int(eb & 0xFFFFu);
         const int slot = sel0 + int(ea >> 16);
-        if (i == n) { *m_out = slot; m_out[2] = numbers0 + int(ec >> 16); }
+        if (i == n) { *m_out = slot; m_out[2] = numbers0 + int(ec >> 16); m_out[3] = slot + 1; }
         if (i < n && (p[j].c >> 16)) { number_list[numbers0 + int(ec >> 16)] = u32(i); } // k_tape_numbers parses them, one per lane
         if (i < n && (p[j].a >> 16)) {
           int k = (p[j].b >> 16) ? d : d - 1;
@@ -320,8 +321,8 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_opens(sorted_pairs sorted, 
   const unsigned short *__restrict__ key = sorted.key();
   const u64 j = u64(blockIdx.x) * TP_THREADS + threadIdx.x;
   const u32 m = u32(*m_ptr);
-  if (j > n) { return; }
-  opens[j] = (j < m && kind_is_open(u32(key[j]) >> KIND_SHIFT)) ? 1 : 0; // zeros behind the m sorted elements: the scan runs over n + 1 entries
+  if (j > m) { return; }
+  opens[j] = (j < m && kind_is_open(u32(key[j]) >> KIND_SHIFT)) ? 1 : 0; // entry m: the scan (over m + 1 entries) leaves the number of containers there
 }
 // openpos[k] = sorted position of the k-th opening bracket
 __global__ __launch_bounds__(TP_THREADS) void k_tape_openpos(sorted_pairs sorted, const int *__restrict__ m_ptr, const int *__restrict__ opens_before, u32 *__restrict__ openpos) {
@@ -505,7 +506,7 @@ static tape_workspace carve(uint8_t *base, uint32_t n, uint64_t len) {
   w.slow_cap = u32(len / 20 + 64 < n1 ? len / 20 + 64 : n1);
   w.res = reinterpret_cast<tape_result_dev *>(take(sizeof(tape_result_dev)));
   w.n_words = reinterpret_cast<u32 *>(take(64));
-  w.m = reinterpret_cast<int *>(w.n_words) + 8; // [8] = m, [9] = highest level in the sort, [10] = number tokens; n_words[2] = length of the second pass's scan
+  w.m = reinterpret_cast<int *>(w.n_words) + 8; // [8] = m, [9] = highest level in the sort, [10] = number tokens, [11] = m + 1 (length of the opens scan); n_words[2] = length of the second pass's scan
   w.tokc = take(n1 + 8);
   w.ctx = take(n1 + 8);
   w.slots = reinterpret_cast<int *>(take(n1 * 4 + 64));
@@ -544,7 +545,7 @@ const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *i
   const u32 kmax = max_depth < 4095u ? max_depth : 4095u;
   hipLaunchKernelGGL(k_tok_classify, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, buf, len, idx, n, w.tokc, w.sums, w.tok_blocks);
   hipLaunchKernelGGL(k_tok_scan_sums, dim3(TS_SUMS), dim3(1024), 0, s, w.sums, w.tok_blocks);
-  (void)hipMemsetAsync(w.m, 0, 3 * sizeof(int), s);
+  (void)hipMemsetAsync(w.m, 0, 4 * sizeof(int), s);
   hipLaunchKernelGGL(k_tok_apply, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, w.tokc, n, kmax, w.sums, w.tok_blocks, w.slots, w.depth, w.kord, w.key_a, w.tok_a, w.m, w.m + 1, w.number_list);
   return w.kord;
 }
@@ -568,7 +569,7 @@ void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t
   const sorted_pairs sorted{w.key_a, w.key_b, w.tok_a, w.tok_b, max_level};
   // containers
   hipLaunchKernelGGL(k_tape_opens, dim3(grid), dim3(TP_THREADS), 0, s, sorted, m_ptr, n, w.opens);
-  enqueue_scan(w.opens, n1, w.n_words, w.partial, s);
+  enqueue_scan(w.opens, n1, reinterpret_cast<const u32 *>(w.m + 3), w.partial, s); // over the m + 1 sorted elements only (m is known on the device)
   hipLaunchKernelGGL(k_tape_openpos, dim3(grid), dim3(TP_THREADS), 0, s, sorted, m_ptr, w.opens, w.openpos);
   hipLaunchKernelGGL(k_tape_match, dim3(grid), dim3(TP_THREADS), 0, s, sorted, m_ptr, w.opens, w.openpos, w.slots, w.ctx, tape, tape_cap, w.res);
   hipLaunchKernelGGL(k_tape_write, dim3(grid), dim3(TP_THREADS), 0, s, buf, len, idx, n, max_depth, w.tokc, w.slots, w.depth, w.ctx, str_offsets, w.kord, strs, string_buf,
