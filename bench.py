@@ -793,14 +793,29 @@ def ndjson_leg(args, torch, dist, corpus, capi, rank, world, local_rank, fence):
     # the exchange below the C-ABI (sjgpu_comm_*: RCCL from C++); torch.distributed only carries the 128-byte id to the ranks
     comm = None
     exchange = "sjgpu_comm_gather_indices (libsjgpu: ncclAllGather of (n, base) + exact-count ncclSend / ncclRecv to rank 0, widened to 64-bit global positions there)"
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = capi.comm_unique_id()
+        except Exception as e:  # the ranks still meet in the broadcast below and all take the twin
+            box[0] = None
+    dist.broadcast_object_list(box, src=0)
     try:
-        box = [capi.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        comm = capi.Comm(rank, world, box[0], local_rank)
+        if box[0] is None:
+            raise RuntimeError("rank 0 could not create a communicator id")
         gathered = torch.empty(world * (L // 8 + 1024) if rank == 0 else 8, dtype=torch.int64, device="cuda")
+        comm = capi.Comm(rank, world, box[0], local_rank)
     except Exception as e:  # never seen N > 1 hardware: keep the leg alive on the torch.distributed twin and say so
         comm = None
         exchange = f"sharded.gather_to_root over torch.distributed (sjgpu_comm unavailable: {repr(e)[:120]})"
+    # every rank takes the same road: one rank without a communicator sends all of them to the twin (no rank may wait in a
+    # collective the others never enter)
+    have = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(have, op=dist.ReduceOp.MIN)
+    if int(have) == 0 and comm is not None:
+        comm.close()
+        comm = None
+        exchange = "sharded.gather_to_root over torch.distributed (sjgpu_comm unavailable on another rank)"
 
     def concat(n_now, f_now):
         if comm is not None:
