@@ -44,10 +44,16 @@ SJ_HD u32 tape_slots(u32 c, bool root) {
 //   i: list index; c / prev / prev2 / next: the bytes at idx[i], idx[i-1], idx[i-2], idx[i+1] (0 where there is none);
 //   ctx_prev / ctx_prev2: kind of the container a ',' at i-1 / i-2 sits in (CTX_*; only read when that token is a ',');
 //   depth: containers open in front of token i.
+//   (first / int depth: the form the kernels call -- 32-bit arithmetic only; depths beyond +-2^31 do not occur, the list has < 2^32 entries)
+SJ_HD u32 token_rule(bool first, u32 c, u32 prev, u32 prev2, u32 next, u32 ctx_prev, u32 ctx_prev2, int depth, u32 max_depth, u32 *rank);
 SJ_HD u32 token_grammar_error(u64 i, u32 c, u32 prev, u32 prev2, u32 next, u32 ctx_prev, u32 ctx_prev2, long long depth, u32 max_depth, u32 *rank) {
+  const int d = depth > 0x7FFFFFFFll ? 0x7FFFFFFF : (depth < -0x7FFFFFFFll ? -0x7FFFFFFF : int(depth));
+  return token_rule(i == 0, c, prev, prev2, next, ctx_prev, ctx_prev2, d, max_depth, rank);
+}
+SJ_HD u32 token_rule(bool first, u32 c, u32 prev, u32 prev2, u32 next, u32 ctx_prev, u32 ctx_prev2, int depth, u32 max_depth, u32 *rank) {
   *rank = 0;
   bool ok;
-  if (i == 0) { // the root value (json_iterator.h:133-152, visit_root_primitive :313-340)
+  if (first) { // the root value (json_iterator.h:133-152, visit_root_primitive :313-340)
     ok = starts_value(c, true);
   } else if (depth <= 0) { // the root value has ended: "more than one JSON value at the root" (:236-239)
     ok = false;
@@ -65,7 +71,66 @@ SJ_HD u32 token_grammar_error(u64 i, u32 c, u32 prev, u32 prev2, u32 next, u32 c
   }
   if (!ok) { return SJ_TAPE_ERROR; }
   // a non-empty container one level too deep (:165-166, :206-207); empty ones are written without descending (:146-147 ...)
-  if (is_open_char(c) && next != (c == '{' ? u32('}') : u32(']')) && depth + 1 >= (long long)max_depth) {
+  if (is_open_char(c) && next != (c == '{' ? u32('}') : u32(']')) && max_depth <= 0x7FFFFFFFu && depth >= int(max_depth) - 1) { // depth + 1 >= max_depth
+    *rank = 1;
+    return SJ_DEPTH_ERROR;
+  }
+  return 0;
+}
+
+// ---- the same rule from tables ---------------------------------------------------------------------------------------------------------
+// token_rule spelled out is ~60 boolean operations on per-lane conditions, which the GPU compiler turns into as many scalar mask
+// instructions per token: the kernel that only applies the rule was bound by their issue (profiles/r03_pmc_summary.txt: 250 M scalar
+// against 100 M vector instructions per call).  Here the bytes are looked up: what a byte IS (props), which state the walk is in behind a
+// byte (state_behind), and which properties each state accepts (accepts) -- three small tables a workgroup builds in LDS from the very
+// predicates above (so they cannot drift apart), a handful of selects on small integers, one AND.  tests/host/test_tape_rules.cpp compares
+// the two forms on every combination of bytes, container kinds and depths that can make a difference.
+enum : u32 { P_QUOTE = 1, P_LBRACE = 2, P_LBRACKET = 4, P_RBRACE = 8, P_RBRACKET = 16, P_COLON = 32, P_COMMA = 64, P_VALUE_AT_ROOT = 128, P_VALUE_INSIDE = 256 };
+enum : u32 { ST_ROOT = 0, ST_DONE = 1, ST_BEHIND_LBRACE = 2, ST_BEHIND_LBRACKET = 3, ST_BEHIND_COLON = 4, ST_BEHIND_COMMA = 5 /* + CTX_* */, ST_BEHIND_KEY = 8,
+              ST_BEHIND_VALUE = 9, ST_BEHIND_QUOTE = 10 /* key or value: decided by the token in front of it */, ST_COUNT = 11 };
+SJ_HD u32 byte_props_of(u32 c) {
+  return (c == '"' ? P_QUOTE : 0u) | (c == '{' ? P_LBRACE : 0u) | (c == '[' ? P_LBRACKET : 0u) | (c == '}' ? P_RBRACE : 0u) | (c == ']' ? P_RBRACKET : 0u) |
+         (c == ':' ? P_COLON : 0u) | (c == ',' ? P_COMMA : 0u) | (starts_value(c, true) ? P_VALUE_AT_ROOT : 0u) | (starts_value(c, false) ? P_VALUE_INSIDE : 0u);
+}
+SJ_HD u32 state_behind_byte(u32 prev) {
+  return prev == '{' ? ST_BEHIND_LBRACE : (prev == '[' ? ST_BEHIND_LBRACKET : (prev == ':' ? ST_BEHIND_COLON : (prev == ',' ? ST_BEHIND_COMMA : (prev == '"' ? ST_BEHIND_QUOTE : ST_BEHIND_VALUE))));
+}
+SJ_HD u32 state_accepts(u32 st) {
+  switch (st) {
+  case ST_ROOT: return P_VALUE_AT_ROOT;
+  case ST_BEHIND_LBRACE: return P_QUOTE | P_RBRACE;
+  case ST_BEHIND_LBRACKET: return P_RBRACKET | P_VALUE_INSIDE;
+  case ST_BEHIND_COLON: return P_VALUE_INSIDE;
+  case ST_BEHIND_COMMA + CTX_OBJECT: return P_QUOTE;
+  case ST_BEHIND_COMMA + CTX_ARRAY: return P_VALUE_INSIDE;
+  case ST_BEHIND_KEY: return P_COLON;
+  case ST_BEHIND_VALUE: return P_COMMA | P_RBRACE | P_RBRACKET;
+  default: return 0u; // ST_DONE, a ',' that sits in no container
+  }
+}
+struct rule_tables {
+  const unsigned short *props;  // [256]
+  const u8 *state_behind;       // [256]
+  const unsigned short *accepts; // [ST_COUNT]
+};
+// entry t of the three tables (t < 256; the accepts table is shorter): what thread t of a workgroup writes
+SJ_HD void rule_table_entry(u32 t, unsigned short *props, u8 *state_behind, unsigned short *accepts) {
+  props[t] = (unsigned short)byte_props_of(t);
+  state_behind[t] = u8(state_behind_byte(t));
+  if (t < ST_COUNT) { accepts[t] = (unsigned short)state_accepts(t); }
+}
+SJ_HD u32 token_rule_tables(const rule_tables &T, bool first, u32 c, u32 prev, u32 prev2, u32 next, u32 ctx_prev, u32 ctx_prev2, int depth, u32 max_depth, u32 *rank) {
+  *rank = 0;
+  const u32 pc = T.props[c & 0xFFu], p2 = T.props[prev2 & 0xFFu];
+  u32 st = T.state_behind[prev & 0xFFu];
+  const u32 behind_key = ((p2 & P_LBRACE) != 0u) | (((p2 & P_COMMA) != 0u) & (ctx_prev2 == CTX_OBJECT));
+  st = st == ST_BEHIND_COMMA ? ST_BEHIND_COMMA + (ctx_prev <= CTX_ARRAY ? ctx_prev : 0u) : st;
+  st = st == ST_BEHIND_QUOTE ? (behind_key ? u32(ST_BEHIND_KEY) : u32(ST_BEHIND_VALUE)) : st;
+  st = depth <= 0 ? u32(ST_DONE) : st;
+  st = first ? u32(ST_ROOT) : st;
+  if ((pc & T.accepts[st]) == 0u) { return SJ_TAPE_ERROR; }
+  // a non-empty container one level too deep ('{' + 2 = '}', '[' + 2 = ']')
+  if ((pc & (P_LBRACE | P_LBRACKET)) != 0u && next != c + 2u && max_depth <= 0x7FFFFFFFu && depth >= int(max_depth) - 1) {
     *rank = 1;
     return SJ_DEPTH_ERROR;
   }
@@ -80,6 +145,8 @@ SJ_HD bool comma_in_value_position(u64 i, u32 prev, u32 ctx_prev) {
 
 // tape words (/root/reference/doc/tape.md, tape_writer.h)
 SJ_HD u64 tape_word(u32 type, u64 payload) { return (u64(type) << 56) | payload; }
+// the same for a payload of 32 bits, put together from two dwords (a 64-bit shift costs a quarter-rate instruction on the device)
+SJ_HD u64 tape_word32(u32 type, u32 payload) { return (u64(type << 24) << 32) | payload; }
 
 } // namespace sjgpu
 #endif

@@ -1597,9 +1597,9 @@ int sjgpu_stage2_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const v
   strings_result_dev *sres = reinterpret_cast<strings_result_dev *>(ws);
   uint32_t *offsets = reinterpret_cast<uint32_t *>(ws + offs_at);
   hipStream_t s = pick(ctx, stream);
-  const int *kord = launch_tape_front(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, max_depth, ws + tape_at, s);
+  const int *string_tokens = launch_tape_front(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, max_depth, ws + tape_at, s);
   const strings_handoff strs = launch_parse_strings(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, false,
-                                                    static_cast<uint8_t *>(string_buf_dev), string_buf_bytes, offsets, sres, ws + scratch_at, s, kord);
+                                                    static_cast<uint8_t *>(string_buf_dev), string_buf_bytes, offsets, sres, ws + scratch_at, s, string_tokens);
   launch_tape(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, max_depth, offsets, strs, static_cast<uint8_t *>(string_buf_dev),
               static_cast<uint64_t *>(tape_dev), tape_cap_words, ws + tape_at, s);
   SJ_TRY(ctx, hipGetLastError());

@@ -199,17 +199,18 @@ size_t strings_scratch_bytes(uint32_t n, uint64_t len);
 // the buffer as a stream compaction of the document (sjgpu_string_stream.hip); leaves in the control block whether the
 // per-string kernels have to run instead
 void enqueue_string_stream(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
-                           uint32_t *offsets, strings_result_dev *res, const strings_scratch &w, hipStream_t s, const int *kord);
+                           uint32_t *offsets, strings_result_dev *res, const strings_scratch &w, hipStream_t s, const int *listed);
 // What the string pass hands to a caller that finishes the records itself (the tape): where the k-th string's record begins, and the device
 // flag that says whether the stream compaction wrote the buffer (then the length words are still missing) or the per-string kernels did.
 struct strings_handoff {
   const uint32_t *outq;
   const uint32_t *go_stream;
 };
-// kord (optional): the string ordinal of every structural, n + 1 ints, computed by the caller (launch_tape_front) -- the pass then neither
-// counts the string tokens itself nor writes offsets / length words for the stream's records (the caller does, from the handoff)
+// listed (optional): device pointer to the number of string tokens of the list, counted by the caller (launch_tape_front) -- the pass then
+// neither counts them itself nor writes offsets / length words for the stream's records (the caller does, from the handoff: the k-th string
+// token's record begins at outq[k])
 strings_handoff launch_parse_strings(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
-                                     uint32_t *offsets, strings_result_dev *res, void *scratch, hipStream_t s, const int *kord = nullptr);
+                                     uint32_t *offsets, strings_result_dev *res, void *scratch, hipStream_t s, const int *listed = nullptr);
 // ---- the tape (sjgpu_tape.hip) ----------------------------------------------------------------------------------
 struct tape_result_dev {
   uint64_t error_key;   // smallest (list index << 8 | rank << 4 | error_code) over all offending tokens, ~0 = none (sj_tape_rules.h)
@@ -219,7 +220,7 @@ struct tape_result_dev {
 };
 size_t tape_workspace_bytes(uint32_t n, uint64_t len);
 // stage 2 of buf[0..len) from its structural list idx[0..n] (idx[n] = len), in two halves around the string pass: launch_tape_front leaves
-// the token bytes, tape positions, depths and the sort's input in the workspace and returns the string ordinals of the tokens (n + 1 ints);
+// the token bytes, tape positions, depths, value lists and the sort's input in the workspace and returns the number of string tokens (device);
 // launch_tape writes the reference's tape (and the length words of the string records when the stream compaction wrote them).
 // workspace: tape_workspace_bytes(n, len), its first bytes are the tape_result_dev afterwards
 const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, void *workspace, hipStream_t s);

@@ -281,8 +281,8 @@ __global__ __launch_bounds__(TOK_THREADS) void k_strs_tokens(const u8 *__restric
   isq[i] = q; // isq[n] = 0: the scan leaves the number of string tokens there
 }
 
-__global__ void k_strs_decide(strs_ctrl *__restrict__ ctrl, const int *__restrict__ kord, u32 n, u64 out_cap, u32 *__restrict__ outq, strings_result_dev *__restrict__ res) {
-  const u32 listed = u32(kord[n]);
+__global__ void k_strs_decide(strs_ctrl *__restrict__ ctrl, const int *__restrict__ listed_ptr, u32 n, u64 out_cap, u32 *__restrict__ outq, strings_result_dev *__restrict__ res) {
+  const u32 listed = u32(*listed_ptr); // string tokens of the list
   const bool ok = ctrl->bad == 0 && listed == ctrl->opens;
   if (ok && ctrl->total > out_cap) {
     res->overflow = 1;
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(TOK_THREADS) void k_strs_finalize(const int *__rest
 
 // scratch of the stream (carved by sjgpu_strings.hip): see strings_scratch in sjgpu_internal.h
 void enqueue_string_stream(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
-                           uint32_t *offsets, strings_result_dev *res, const strings_scratch &w, hipStream_t s, const int *kord) {
+                           uint32_t *offsets, strings_result_dev *res, const strings_scratch &w, hipStream_t s, const int *listed) {
   strs_ctrl *ctrl = static_cast<strs_ctrl *>(w.ctrl);
   static_assert(sizeof(strs_ctrl) <= 64, "the control block has 64 bytes");
   static_assert(sizeof(strs_summary) == STRS_SUMMARY_BYTES && sizeof(strs_base) == STRS_BASE_BYTES, "strings_scratch_bytes counts on these");
@@ -462,18 +462,18 @@ void enqueue_string_stream(const uint8_t *buf, uint64_t len, const uint32_t *idx
     hipLaunchKernelGGL(k_strs_count, dim3((nseg + STRS_WAVES - 1) / STRS_WAVES), dim3(64 * STRS_WAVES), 0, s, buf, len, nseg, a, w.esc, summ);
   }
   hipLaunchKernelGGL(k_strs_resolve, dim3(1), dim3(RES_THREADS), 0, s, summ, nseg, base, ctrl);
-  const bool own_ordinals = kord == nullptr; // else the caller has them (launch_tape_front) and finishes the records itself
+  const bool own_ordinals = listed == nullptr; // else the caller has counted the string tokens (launch_tape_front) and finishes the records itself
   if (own_ordinals) {
     hipLaunchKernelGGL(k_strs_tokens, dim3(u32((u64(n1) + TOK_THREADS - 1) / TOK_THREADS)), dim3(TOK_THREADS), 0, s, buf, len, idx, n, w.kord);
     enqueue_scan(w.kord, n1, &ctrl->n1_scan, w.partial, s);
-    kord = w.kord;
+    listed = w.kord + n;
   }
-  hipLaunchKernelGGL(k_strs_decide, dim3(1), dim3(1), 0, s, ctrl, kord, n, out_cap, w.outq, res);
+  hipLaunchKernelGGL(k_strs_decide, dim3(1), dim3(1), 0, s, ctrl, listed, n, out_cap, w.outq, res);
   if (nseg) {
     hipLaunchKernelGGL(k_strs_write, dim3((nseg + STRS_WAVES - 1) / STRS_WAVES), dim3(64 * STRS_WAVES), 0, s, buf, len, nseg, a, w.esc, base, ctrl, out, w.outq);
   }
   if (own_ordinals) {
-    hipLaunchKernelGGL(k_strs_finalize, dim3(u32((u64(n1) + TOK_THREADS - 1) / TOK_THREADS)), dim3(TOK_THREADS), 0, s, kord, n, w.outq, ctrl, offsets, out);
+    hipLaunchKernelGGL(k_strs_finalize, dim3(u32((u64(n1) + TOK_THREADS - 1) / TOK_THREADS)), dim3(TOK_THREADS), 0, s, w.kord, n, w.outq, ctrl, offsets, out);
   }
 }
 

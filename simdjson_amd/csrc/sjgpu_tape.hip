@@ -13,16 +13,16 @@
 // The first error of the serial walk is the smallest (list index, rank) over all tokens that break their rule: one atomicMin.
 //
 // Passes (all asynchronous on the caller's stream; one 32-byte result is read back by the caller):
-//   k_tok_classify / k_tok_scan_sums / k_tok_apply   the byte of every token; tape position, nesting depth and string ordinal of every
-//                     token in one sweep over those bytes; (level, kind, token) of every bracket and comma into the sort's input;
-//                     the number tokens into a list
+//   k_tok_classify / k_tok_scan_sums / k_tok_apply   the byte of every token; tape position and nesting depth of every token in one sweep
+//                     over those bytes; (level, kind, token) of every bracket and comma into the sort's input; strings, atoms and
+//                     numbers into lists
 //   (the string buffer: sjgpu_strings.hip / sjgpu_string_stream.hip, which take the string ordinals from here)
 //   radix passes      stable LSD radix sort on the level, 6 bits per pass: histogram, scan, scatter   1 wave / 2048 elements;
 //                     the second pass only runs for documents nested 64 deep and more
 //   k_tape_opens + scan + k_tape_openpos   container ordinal per sorted element, sorted position of every open
 //   k_tape_match      commas learn their container's kind; closes write BOTH bracket words (count, partner index), kinds checked
-//   k_tape_write      per token: the walk's rule, nesting limit, atoms / string words, root words
-//   k_tape_numbers    the number tokens (listed by k_tok_apply), one per lane
+//   k_tape_rules      per token: the walk's rule and the nesting limit; root words
+//   k_tape_strings / k_tape_atoms / k_tape_numbers    the value words, one listed token per lane (lists by k_tok_apply)
 //   k_tape_slow_numbers  the handful of number tokens whose rounding needs exact big-integer arithmetic (sj_number.h)
 // Parity: tests/test_gpu_parity.py::test_tape_* against the live reference's dom::parser::parse (tape and string_buf word for word,
 // error codes of broken documents); the same steps run on the CPU in tests/host/test_tape_model.cpp.
@@ -178,18 +178,24 @@ __global__ __launch_bounds__(1024) void k_tok_scan_sums(int *__restrict__ sums, 
     __syncthreads();
   }
 }
-// tpos[i], depth[i], kord[i] for i in [0, n] (entry n = the totals); the number tokens are listed (m_out[2] = how many); the brackets
+// tpos[i], depth[i] for i in [0, n] (entry n = the totals).  The tokens that write a value word are LISTED by kind, so that each kind is
+// finished by a dense kernel of its own instead of a branch of a per-token kernel: numbers (number_list, m_out[2] of them), strings
+// (value_list from the front: the k-th string token, m_out[4] of them = its ordinal in the string buffer) and the one-word rest -- atoms, and
+// bytes that are no token at all -- (value_list from the back: entry n - k, m_out[5] of them; their count in front of a token follows from the
+// other prefix sums: words = strings + rest + 2 numbers + brackets).  The brackets
 // and commas go straight into the sort's input with
 // their level: the depth in front of an opening bracket, the depth behind a closing one, and that of the container a comma separates
 // the members of -- clamped to [0, kmax] (beyond the nesting limit an error is already certain); *m_out = how many went in
 __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__ tokc, u32 n, u32 kmax, const int *__restrict__ sums, u32 nblocks, int *__restrict__ tpos,
-                                                         int *__restrict__ depth, int *__restrict__ kord, unsigned short *__restrict__ key, u32 *__restrict__ tok,
+                                                         int *__restrict__ depth, u32 *__restrict__ value_list, unsigned short *__restrict__ key, u32 *__restrict__ tok,
                                                          int *__restrict__ m_out, int *__restrict__ max_level, u32 *__restrict__ number_list) {
   __shared__ u32 sh[3][TS_THREADS / 64];
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u64 block0 = u64(blockIdx.x) * TS_BLOCK;
   const int slots0 = sums[0 * nblocks + blockIdx.x], sel0 = sums[1 * nblocks + blockIdx.x], strs0 = sums[2 * nblocks + blockIdx.x];
-  const int depth0 = sums[3 * nblocks + blockIdx.x] - sums[4 * nblocks + blockIdx.x], numbers0 = sums[5 * nblocks + blockIdx.x];
+  const int opens0 = sums[3 * nblocks + blockIdx.x], closes0 = sums[4 * nblocks + blockIdx.x];
+  const int depth0 = opens0 - closes0, numbers0 = sums[5 * nblocks + blockIdx.x];
+  const int rest0 = slots0 - strs0 - 2 * numbers0 - opens0 - closes0; // one-word tokens that are neither strings nor brackets
   u32 ra = 0, rb = 0, rc = 0; // what the rows in front of this one hold (packed)
   int top = 0;                // highest level this thread sent into the sort
 #pragma unroll 1
@@ -215,17 +221,23 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
     }
     __syncthreads();
     if (i0 <= n) {
-      int tp[4], dp[4], ko[4];
+      int tp[4], dp[4];
 #pragma unroll
       for (u32 j = 0; j < 4; j++) {
         const u64 i = i0 + j;
         const int d = depth0 + int(eb >> 16) - int(ec & 0xFFFFu);
         tp[j] = slots0 + int(ea & 0xFFFFu);
         dp[j] = d;
-        ko[j] = strs0 + int(eb & 0xFFFFu);
+        const int strings_before = strs0 + int(eb & 0xFFFFu), numbers_before = numbers0 + int(ec >> 16);
+        const int rest_before = rest0 + int(ea & 0xFFFFu) - int(eb & 0xFFFFu) - 2 * int(ec >> 16) - int(eb >> 16) - int(ec & 0xFFFFu);
         const int slot = sel0 + int(ea >> 16);
-        if (i == n) { *m_out = slot; m_out[2] = numbers0 + int(ec >> 16); m_out[3] = slot + 1; }
-        if (i < n && (p[j].c >> 16)) { number_list[numbers0 + int(ec >> 16)] = u32(i); } // k_tape_numbers parses them, one per lane
+        if (i == n) { *m_out = slot; m_out[2] = numbers_before; m_out[3] = slot + 1; m_out[4] = strings_before; m_out[5] = rest_before; }
+        if (i < n) {
+          const u32 words = p[j].a & 0xFFFFu;
+          if (p[j].c >> 16) { number_list[numbers_before] = u32(i); }            // k_tape_numbers
+          else if (p[j].b & 0xFFFFu) { value_list[strings_before] = u32(i); }      // k_tape_strings
+          else if (words == 1u && !(p[j].a >> 16)) { value_list[n - u32(rest_before)] = u32(i); } // k_tape_atoms (brackets have the sort flag)
+        }
         if (i < n && (p[j].a >> 16)) {
           int k = (p[j].b >> 16) ? d : d - 1;
           k = k < 0 ? 0 : (k > int(kmax) ? int(kmax) : k);
@@ -238,9 +250,8 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
       if (i0 + 3 <= n) {
         *reinterpret_cast<int4 *>(tpos + i0) = make_int4(tp[0], tp[1], tp[2], tp[3]);
         *reinterpret_cast<int4 *>(depth + i0) = make_int4(dp[0], dp[1], dp[2], dp[3]);
-        *reinterpret_cast<int4 *>(kord + i0) = make_int4(ko[0], ko[1], ko[2], ko[3]);
       } else {
-        for (u32 j = 0; j < 4 && i0 + j <= n; j++) { tpos[i0 + j] = tp[j]; depth[i0 + j] = dp[j]; kord[i0 + j] = ko[j]; }
+        for (u32 j = 0; j < 4 && i0 + j <= n; j++) { tpos[i0 + j] = tp[j]; depth[i0 + j] = dp[j]; }
       }
     }
   }
@@ -334,52 +345,96 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_openpos(sorted_pairs sorted
 }
 // commas: ctx[token] = kind of their container.  Closing brackets: the two bracket words of the tape
 // (end_container, tape_builder.h:396-407; an empty container is the same formula with count 0, :386-391).
+// Four consecutive sorted elements per thread, the loads of each step of the chain (element -> its container's open -> that open's key and
+// token -> tape positions) issued for all four before any is used: like k_tape_write, this kernel ran at the latency of its chain.
+constexpr u32 TM_PER = 4;
 __global__ __launch_bounds__(TP_THREADS) void k_tape_match(sorted_pairs sorted, const int *__restrict__ m_ptr, const int *__restrict__ opens_before,
                                                           const u32 *__restrict__ openpos, const int *__restrict__ tpos, u8 *__restrict__ ctx, u64 *__restrict__ tape,
                                                           u64 tape_cap, tape_result_dev *__restrict__ res) {
   const unsigned short *__restrict__ key = sorted.key();
   const u32 *__restrict__ tok = sorted.tok();
-  const u64 j = u64(blockIdx.x) * TP_THREADS + threadIdx.x;
+  const u64 j0 = (u64(blockIdx.x) * TP_THREADS + threadIdx.x) * TM_PER;
   const u32 m = u32(*m_ptr);
-  if (j >= m) { return; }
-  const u32 kj = key[j], kind = kj >> KIND_SHIFT;
-  if (kind_is_open(kind)) { return; }
-  const u32 cid = u32(opens_before[j]); // an element that is not an open: opens in front of it = opens at positions <= j
-  if (cid == 0) { return; }
-  const u32 jo = openpos[cid - 1];
-  const u32 ko = key[jo];
-  if (((ko ^ kj) & ((1u << KIND_SHIFT) - 1)) != 0) { return; } // no container of this level in front: the token's own rule reports it
-  const bool object = (ko >> KIND_SHIFT) == KIND_OPEN_OBJECT;
-  const u32 i = tok[j];
-  if (kind == KIND_COMMA) {
-    ctx[i] = u8(object ? CTX_OBJECT : CTX_ARRAY);
-    return;
+  if (j0 >= m) { return; }
+  u32 kj[TM_PER], cid[TM_PER], ti[TM_PER];
+  bool live[TM_PER];
+#pragma unroll
+  for (u32 e = 0; e < TM_PER; e++) {
+    const u64 j = j0 + e;
+    const bool in = j < m;
+    const u64 at = in ? j : j0; // (j0 < m: a valid element to read instead)
+    kj[e] = key[at];
+    cid[e] = u32(opens_before[at]); // an element that is not an open: opens in front of it = opens at positions <= j
+    ti[e] = tok[at];
+    live[e] = in && !kind_is_open(kj[e] >> KIND_SHIFT) && cid[e] != 0;
   }
-  if ((kind == KIND_CLOSE_OBJECT) != object) { report_error(res, error_key(i, 0, SJ_TAPE_ERROR)); }
-  const u32 io = tok[jo];
-  const u64 open_at = 1 + u64(u32(tpos[io])), close_at = 1 + u64(u32(tpos[i]));
-  const u64 between = j - jo; // commas + 1
-  const u64 count = (i == io + 1) ? 0 : (between > 0xFFFFFFull ? 0xFFFFFFull : between);
-  if (close_at < tape_cap) {
-    tape[close_at] = tape_word(kind == KIND_CLOSE_OBJECT ? u32('}') : u32(']'), open_at);
-    tape[open_at] = tape_word(object ? u32('{') : u32('['), (count << 32) | (close_at + 1));
-  } else {
-    res->overflow = 1;
+  u32 jo[TM_PER];
+#pragma unroll
+  for (u32 e = 0; e < TM_PER; e++) { jo[e] = live[e] ? openpos[cid[e] - 1] : 0u; } // (openpos[0] does not exist in a list without brackets)
+  u32 ko[TM_PER], io[TM_PER];
+#pragma unroll
+  for (u32 e = 0; e < TM_PER; e++) {
+    ko[e] = key[jo[e]];
+    io[e] = tok[jo[e]];
+    live[e] = live[e] && ((ko[e] ^ kj[e]) & ((1u << KIND_SHIFT) - 1)) == 0; // else: no container of this level in front, the token's own rule reports it
+  }
+  int open_pos[TM_PER], close_pos[TM_PER];
+#pragma unroll
+  for (u32 e = 0; e < TM_PER; e++) {
+    const bool closes = live[e] && (kj[e] >> KIND_SHIFT) != KIND_COMMA;
+    open_pos[e] = tpos[closes ? io[e] : 0u];
+    close_pos[e] = tpos[closes ? ti[e] : 0u];
+  }
+#pragma unroll
+  for (u32 e = 0; e < TM_PER; e++) {
+    if (!live[e]) { continue; }
+    const u32 kind = kj[e] >> KIND_SHIFT;
+    const bool object = (ko[e] >> KIND_SHIFT) == KIND_OPEN_OBJECT;
+    const u32 i = ti[e];
+    if (kind == KIND_COMMA) {
+      ctx[i] = u8(object ? CTX_OBJECT : CTX_ARRAY);
+      continue;
+    }
+    if ((kind == KIND_CLOSE_OBJECT) != object) { report_error(res, error_key(i, 0, SJ_TAPE_ERROR)); }
+    const u64 open_at = 1 + u64(u32(open_pos[e])), close_at = 1 + u64(u32(close_pos[e]));
+    const u64 between = (j0 + e) - jo[e]; // commas + 1
+    const u64 count = (i == io[e] + 1) ? 0 : (between > 0xFFFFFFull ? 0xFFFFFFull : between);
+    if (close_at < tape_cap) {
+      tape[close_at] = tape_word(kind == KIND_CLOSE_OBJECT ? u32('}') : u32(']'), open_at);
+      tape[open_at] = tape_word(object ? u32('{') : u32('['), (count << 32) | (close_at + 1));
+    } else {
+      res->overflow = 1;
+    }
   }
 }
 
-// ---- per token: rule, limit, content ------------------------------------------------------------------------------------------------------
-// Number tokens are not parsed here: a wave of consecutive tokens holds a few of them, of very different lengths, and the other lanes would
-// wait for the longest one (the first version spent three quarters of its issue slots that way, profiles/r03_pmc_summary.txt).
-// k_tok_apply lists them, k_tape_numbers parses them one per lane.  (Two other ways to gather them were measured and dropped: a device-wide
-// list behind one atomic counter -- 0.5 M same-address atomics took 5 ms -- and gathering per workgroup of 1024 tokens in LDS with the
-// first threads parsing -- no faster than parsing in place, the idle waves keep their slots.)
-__global__ __launch_bounds__(TP_THREADS) void k_tape_write(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, u32 max_depth, const u8 *__restrict__ tokc,
-                                                          const int *__restrict__ tpos, const int *__restrict__ depth, const u8 *__restrict__ ctx, const u32 *__restrict__ str_offsets,
-                                                          const int *__restrict__ kord, strings_handoff strs, u8 *__restrict__ string_buf, u64 *__restrict__ tape, u64 tape_cap,
-                                                          tape_result_dev *__restrict__ res) {
-  const u64 i = u64(blockIdx.x) * TP_THREADS + threadIdx.x;
-  if (i == n) { // behind the last token: the root words and the checks that belong to no token
+// ---- per token: the walk's rule and the nesting limit --------------------------------------------------------------------------------------
+// Only the rule: the value words are written by the dense kernels below, one per kind of token (k_tape_strings, k_tape_atoms,
+// k_tape_numbers), the bracket words by k_tape_match.  The first version did all of it per token: a wave of 64 consecutive tokens then
+// executes every kind's branch (counters of that kernel: 250 M scalar and 100 M vector instructions per twitter-like call, waves waiting
+// for issue a third of their time, four tokens per thread and 32-bit arithmetic changed nothing: profiles/r03_pmc_summary.txt).
+constexpr u32 TW_PER = 4;
+// byte k (0 ... 7) of the eight bytes {hi:lo}, k known at compile time
+__device__ __forceinline__ u32 byte_of(u32 lo, u32 hi, u32 k) { return ((k < 4u ? lo : hi) >> (8u * (k & 3u))) & 0xFFu; }
+__device__ __forceinline__ void check_token(const rule_tables &T, u32 i, u32 c, u32 prev, u32 prev2, u32 next, u32 ctx_prev, u32 ctx_prev2, int depth, u32 max_depth,
+                                            tape_result_dev *__restrict__ res) {
+  u32 rank = 0;
+  const u32 g = token_rule_tables(T, i == 0, c, prev, prev2, next, ctx_prev, ctx_prev2, depth, max_depth, &rank); // (sj_tape_rules.h: the rule from tables)
+  if (g) { report_error(res, error_key(i, rank, g)); }
+  if (c == ',' && comma_in_value_position(i, prev, ctx_prev)) { report_error(res, error_key(i, 2, SJ_NUMBER_ERROR)); }
+}
+__global__ __launch_bounds__(TP_THREADS) void k_tape_rules(u32 n, u32 max_depth, const u8 *__restrict__ tokc, const int *__restrict__ tpos, const int *__restrict__ depth,
+                                                          const u8 *__restrict__ ctx, u64 *__restrict__ tape, u64 tape_cap, tape_result_dev *__restrict__ res) {
+  __shared__ unsigned short sh_props[256], sh_accepts[16];
+  __shared__ u8 sh_state[256];
+  static_assert(TP_THREADS == 256 && ST_COUNT <= 16, "one table entry per thread");
+  rule_table_entry(threadIdx.x, sh_props, sh_state, sh_accepts);
+  __syncthreads();
+  const rule_tables T{sh_props, sh_state, sh_accepts};
+  const u64 first = (u64(blockIdx.x) * TP_THREADS + threadIdx.x) * TW_PER;
+  if (first > n) { return; }
+  const u32 i0 = u32(first);
+  if (n - i0 < TW_PER) { // the thread that holds "behind the last token": the root words and the checks that belong to no token
     const u64 words = u64(u32(tpos[n])) + 2;
     res->tape_words = words;
     if (words <= tape_cap) {
@@ -391,49 +446,66 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_write(const u8 *__restrict_
     const u32 c0 = tokc[2], last = tokc[n + 1];
     if ((c0 == '{' && last != '}') || (c0 == '[' && last != ']')) { report_error(res, error_key(0, 0, SJ_TAPE_ERROR)); } // json_iterator.h:138-143
     if (depth[n] != 0) { report_error(res, error_key(n, 0, SJ_TAPE_ERROR)); } // the walk meets the sentinel inside a container
-  } else if (i < n) {
-    const u32 around = *reinterpret_cast<const u32_unaligned_t *>(tokc + i); // the bytes of tokens i - 2 ... i + 1 in one load
-    const u32 prev2 = around & 0xFFu, prev = (around >> 8) & 0xFFu, c = (around >> 16) & 0xFFu, next = around >> 24;
-    u32 ctx_prev = 0, ctx_prev2 = 0;
-    if (i >= 2) {
-      typedef unsigned short __attribute__((aligned(1))) u16_unaligned_t;
-      const u32 two = *reinterpret_cast<const u16_unaligned_t *>(ctx + i - 2);
-      ctx_prev2 = two & 0xFFu;
-      ctx_prev = two >> 8;
-    } else if (i == 1) {
-      ctx_prev = ctx[0];
+  }
+  if (i0 >= 2 && n - i0 >= TW_PER) { // the common case: four whole tokens, everything in wide loads
+    typedef u64 __attribute__((aligned(1))) u64_unaligned_t;
+    const u64 around8 = *reinterpret_cast<const u64_unaligned_t *>(tokc + i0);   // bytes of tokens i0 - 2 ... i0 + 5
+    const u64 kinds8 = *reinterpret_cast<const u64_unaligned_t *>(ctx + i0 - 2); // container kinds of tokens i0 - 2 ... i0 + 5 (zero where no comma)
+    const uint2 around = make_uint2(u32(around8), u32(around8 >> 32)), kinds = make_uint2(u32(kinds8), u32(kinds8 >> 32));
+    const int4 d = *reinterpret_cast<const int4 *>(depth + i0);
+    const int dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (u32 j = 0; j < TW_PER; j++) {
+      check_token(T, i0 + j, byte_of(around.x, around.y, j + 2), byte_of(around.x, around.y, j + 1), byte_of(around.x, around.y, j), byte_of(around.x, around.y, j + 3),
+                  byte_of(kinds.x, kinds.y, j + 1), byte_of(kinds.x, kinds.y, j), dd[j], max_depth, res);
     }
-    u32 rank = 0;
-    const u32 g = token_grammar_error(i, c, prev, prev2, next, ctx_prev, ctx_prev2, (long long)depth[i], max_depth, &rank);
-    if (g) { report_error(res, error_key(i, rank, g)); }
-    const u64 at = 1 + u64(u32(tpos[i]));
-    const bool root = i == 0;
-    if (c == '"') {
-      // on_start_string, tape_builder.h:415-419: the payload is where the string's record begins.  When the string buffer came from the
-      // stream compaction (sjgpu_string_stream.hip) the records are known by ORDINAL and their length words are still missing: the k-th
-      // string begins at outq[k] and ends where the next one begins ([u32 length][bytes][0]: on_end_string, :428-433)
-      u32 payload;
-      if (strs.go_stream && *strs.go_stream) {
-        const u32 k = u32(kord[i]);
-        payload = strs.outq[k];
-        *reinterpret_cast<u32_unaligned_t *>(string_buf + payload) = strs.outq[k + 1] - payload - 5u;
-      } else {
-        payload = str_offsets[i];
-      }
-      if (at < tape_cap) { tape[at] = tape_word('"', payload); }
-    } else if (c == ',') {
-      if (comma_in_value_position(i, prev, ctx_prev)) { report_error(res, error_key(i, 2, SJ_NUMBER_ERROR)); }
-    } else if (is_open_char(c) || is_close_char(c) || c == ':') {
-      // bracket words come from k_tape_match
-    } else if (takes_number_path(c, root)) {
-      // k_tape_numbers
-    } else if (c == 't' || c == 'f' || c == 'n') {
-      const windowed_bytes src{buf, u32(len)};
-      const bool ok = c == 't' ? atom_matches(src, idx[i], 't', 'r', 'u', 'e', 0)
-                               : (c == 'f' ? atom_matches(src, idx[i], 'f', 'a', 'l', 's', 'e') : atom_matches(src, idx[i], 'n', 'u', 'l', 'l', 0));
-      if (!ok) { report_error(res, error_key(i, 2, c == 't' ? SJ_T_ATOM_ERROR : (c == 'f' ? SJ_F_ATOM_ERROR : SJ_N_ATOM_ERROR))); }
-      if (at < tape_cap) { tape[at] = tape_word(c, 0); }
+    return;
+  }
+  for (u32 i = i0; i - i0 < TW_PER && i < n; i++) { // the first and the last tokens of the list: one by one
+    const u32 around = *reinterpret_cast<const u32_unaligned_t *>(tokc + i); // the bytes of tokens i - 2 ... i + 1 (two zero bytes lead the array)
+    check_token(T, i, (around >> 16) & 0xFFu, (around >> 8) & 0xFFu, around & 0xFFu, around >> 24, i >= 1 ? u32(ctx[i - 1]) : 0u, i >= 2 ? u32(ctx[i - 2]) : 0u, depth[i],
+                max_depth, res);
+  }
+}
+
+// the string tokens, one per lane: on_start_string (tape_builder.h:415-419): the payload of the word is where the string's record begins.
+// When the string buffer came from the stream compaction (sjgpu_string_stream.hip) the records are known by ORDINAL -- the k-th string
+// token is entry k of the list and its record begins at outq[k] -- and their length words are still missing: a record ends where the
+// next one begins ([u32 length][bytes][0]: on_end_string, :428-433).  Otherwise the per-string kernels left the offsets per token.
+__global__ __launch_bounds__(TP_THREADS) void k_tape_strings(const u32 *__restrict__ value_list, const int *__restrict__ count_ptr, const int *__restrict__ tpos,
+                                                            const u32 *__restrict__ str_offsets, strings_handoff strs, u8 *__restrict__ string_buf, u64 *__restrict__ tape,
+                                                            u64 tape_cap) {
+  const u32 count = u32(*count_ptr);
+  const bool stream_strings = strs.go_stream != nullptr && *strs.go_stream != 0; // uniform
+  for (u64 k = u64(blockIdx.x) * TP_THREADS + threadIdx.x; k < count; k += u64(gridDim.x) * TP_THREADS) {
+    const u32 i = value_list[k];
+    u32 payload;
+    if (stream_strings) {
+      payload = strs.outq[k];
+      *reinterpret_cast<u32_unaligned_t *>(string_buf + payload) = strs.outq[k + 1] - payload - 5u;
+    } else {
+      payload = str_offsets[i];
     }
+    const u64 at = u64(u32(tpos[i])) + 1u;
+    if (at < tape_cap) { tape[at] = tape_word32('"', payload); }
+  }
+}
+// the other one-word tokens (listed from the back of value_list): true / false / null (visit_true_atom ..., tape_builder.h:278-329) -- any
+// other byte here is no token at all and k_tape_rules has said so
+__global__ __launch_bounds__(TP_THREADS) void k_tape_atoms(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, const u8 *__restrict__ tokc,
+                                                          const u32 *__restrict__ value_list, const int *__restrict__ count_ptr, const int *__restrict__ tpos,
+                                                          u64 *__restrict__ tape, u64 tape_cap, tape_result_dev *__restrict__ res) {
+  const u32 count = u32(*count_ptr);
+  for (u64 k = u64(blockIdx.x) * TP_THREADS + threadIdx.x; k < count; k += u64(gridDim.x) * TP_THREADS) {
+    const u32 i = value_list[n - u32(k)];
+    const u32 c = tokc[i + 2];
+    if (c != 't' && c != 'f' && c != 'n') { continue; }
+    const windowed_bytes src{buf, u32(len)};
+    const bool ok = c == 't' ? atom_matches(src, idx[i], 't', 'r', 'u', 'e', 0)
+                             : (c == 'f' ? atom_matches(src, idx[i], 'f', 'a', 'l', 's', 'e') : atom_matches(src, idx[i], 'n', 'u', 'l', 'l', 0));
+    if (!ok) { report_error(res, error_key(i, 2, c == 't' ? SJ_T_ATOM_ERROR : (c == 'f' ? SJ_F_ATOM_ERROR : SJ_N_ATOM_ERROR))); }
+    const u64 at = u64(u32(tpos[i])) + 1u;
+    if (at < tape_cap) { tape[at] = tape_word32(c, 0); }
   }
 }
 
@@ -486,7 +558,8 @@ struct tape_workspace {
   tape_result_dev *res;
   u32 *n_words;       // [0] = n + 1 (scan lengths), [1] = n (upper bound of the sorted elements + 1 for the opens scan), [2] = hist length per pass
   u8 *tokc, *ctx;
-  int *slots, *depth, *kord; // tape position, nesting depth, string ordinal of every token (entry n: the totals)
+  int *slots, *depth;        // tape position, nesting depth of every token (entry n: the totals)
+  u32 *value_list;           // string tokens from the front, the other one-word tokens from the back
   int *m;                    // brackets and commas = elements of the sort
   int *sums;                 // k_tok_classify's block totals (6 rows)
   u32 *number_list;          // the number tokens
@@ -506,12 +579,13 @@ static tape_workspace carve(uint8_t *base, uint32_t n, uint64_t len) {
   w.slow_cap = u32(len / 20 + 64 < n1 ? len / 20 + 64 : n1);
   w.res = reinterpret_cast<tape_result_dev *>(take(sizeof(tape_result_dev)));
   w.n_words = reinterpret_cast<u32 *>(take(64));
-  w.m = reinterpret_cast<int *>(w.n_words) + 8; // [8] = m, [9] = highest level in the sort, [10] = number tokens, [11] = m + 1 (length of the opens scan); n_words[2] = length of the second pass's scan
+  w.m = reinterpret_cast<int *>(w.n_words) + 8; // [8] = m, [9] = highest level in the sort, [10] = number tokens, [11] = m + 1 (length of the opens scan), [12] = string tokens,
+  // [13] = other one-word tokens; n_words[2] = length of the second pass's scan
   w.tokc = take(n1 + 8);
   w.ctx = take(n1 + 8);
   w.slots = reinterpret_cast<int *>(take(n1 * 4 + 64));
   w.depth = reinterpret_cast<int *>(take(n1 * 4 + 64));
-  w.kord = reinterpret_cast<int *>(take(n1 * 4 + 64));
+  w.value_list = reinterpret_cast<u32 *>(take(n1 * 4 + 64));
   w.number_list = reinterpret_cast<u32 *>(take(n1 * 4 + 64));
   w.tok_blocks = blocks_of(n1, TS_BLOCK);
   w.sums = reinterpret_cast<int *>(take(size_t(w.tok_blocks) * TS_SUMS * 4 + 64));
@@ -532,8 +606,8 @@ size_t tape_workspace_bytes(uint32_t n, uint64_t len) { return carve(nullptr, n,
 
 // Stage 2 in two halves, the string buffer in between (sjgpu_capi.hip: sjgpu_stage2_device).  idx[0 .. n] (n >= 1; idx[n] = len, stage 1's first
 // sentinel); workspace: tape_workspace_bytes(n, len), its first bytes are the tape_result_dev afterwards.
-// launch_tape_front: the byte, tape position, depth and string ordinal of every token, the sort's input.  Returns the ordinals (n + 1 ints,
-// entry n = the number of string tokens), which the string pass takes instead of counting them itself.
+// launch_tape_front: the byte, tape position and depth of every token, the lists of value tokens, the sort's input.  Returns (a device pointer
+// to) the number of string tokens, which the string pass takes instead of counting them itself.
 const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, void *workspace, hipStream_t s) {
   const tape_workspace w = carve(static_cast<uint8_t *>(workspace), n, len);
   const u32 n1 = n + 1;
@@ -545,9 +619,9 @@ const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *i
   const u32 kmax = max_depth < 4095u ? max_depth : 4095u;
   hipLaunchKernelGGL(k_tok_classify, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, buf, len, idx, n, w.tokc, w.sums, w.tok_blocks);
   hipLaunchKernelGGL(k_tok_scan_sums, dim3(TS_SUMS), dim3(1024), 0, s, w.sums, w.tok_blocks);
-  (void)hipMemsetAsync(w.m, 0, 4 * sizeof(int), s);
-  hipLaunchKernelGGL(k_tok_apply, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, w.tokc, n, kmax, w.sums, w.tok_blocks, w.slots, w.depth, w.kord, w.key_a, w.tok_a, w.m, w.m + 1, w.number_list);
-  return w.kord;
+  (void)hipMemsetAsync(w.m, 0, 6 * sizeof(int), s);
+  hipLaunchKernelGGL(k_tok_apply, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, w.tokc, n, kmax, w.sums, w.tok_blocks, w.slots, w.depth, w.value_list, w.key_a, w.tok_a, w.m, w.m + 1, w.number_list);
+  return w.m + 4; // the number of string tokens (device)
 }
 
 // launch_tape: the rest.  str_offsets: what the per-string kernels left (n + 1 words), read when they wrote the buffer; strs: where the records
@@ -571,10 +645,12 @@ void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t
   hipLaunchKernelGGL(k_tape_opens, dim3(grid), dim3(TP_THREADS), 0, s, sorted, m_ptr, n, w.opens);
   enqueue_scan(w.opens, n1, reinterpret_cast<const u32 *>(w.m + 3), w.partial, s); // over the m + 1 sorted elements only (m is known on the device)
   hipLaunchKernelGGL(k_tape_openpos, dim3(grid), dim3(TP_THREADS), 0, s, sorted, m_ptr, w.opens, w.openpos);
-  hipLaunchKernelGGL(k_tape_match, dim3(grid), dim3(TP_THREADS), 0, s, sorted, m_ptr, w.opens, w.openpos, w.slots, w.ctx, tape, tape_cap, w.res);
-  hipLaunchKernelGGL(k_tape_write, dim3(grid), dim3(TP_THREADS), 0, s, buf, len, idx, n, max_depth, w.tokc, w.slots, w.depth, w.ctx, str_offsets, w.kord, strs, string_buf,
-                     tape, tape_cap, w.res);
-  hipLaunchKernelGGL(k_tape_numbers, dim3(grid < 8192u ? grid : 8192u), dim3(TP_THREADS), 0, s, buf, len, idx, w.slots, w.number_list, w.m + 2, tape, tape_cap, w.slow_list,
+  hipLaunchKernelGGL(k_tape_match, dim3(blocks_of(n1, TP_THREADS * TM_PER)), dim3(TP_THREADS), 0, s, sorted, m_ptr, w.opens, w.openpos, w.slots, w.ctx, tape, tape_cap, w.res);
+  hipLaunchKernelGGL(k_tape_rules, dim3(blocks_of(n1, TP_THREADS * TW_PER)), dim3(TP_THREADS), 0, s, n, max_depth, w.tokc, w.slots, w.depth, w.ctx, tape, tape_cap, w.res);
+  const u32 list_grid = grid < 8192u ? grid : 8192u;
+  hipLaunchKernelGGL(k_tape_strings, dim3(list_grid), dim3(TP_THREADS), 0, s, w.value_list, w.m + 4, w.slots, str_offsets, strs, string_buf, tape, tape_cap);
+  hipLaunchKernelGGL(k_tape_atoms, dim3(list_grid), dim3(TP_THREADS), 0, s, buf, len, idx, n, w.tokc, w.value_list, w.m + 5, w.slots, tape, tape_cap, w.res);
+  hipLaunchKernelGGL(k_tape_numbers, dim3(list_grid), dim3(TP_THREADS), 0, s, buf, len, idx, w.slots, w.number_list, w.m + 2, tape, tape_cap, w.slow_list,
                      w.slow_cap, w.res);
   hipLaunchKernelGGL(k_tape_slow_numbers, dim3(64), dim3(64), 0, s, buf, len, idx, w.slots, w.slow_list, w.slow_cap, tape, tape_cap, w.res);
 }

@@ -56,10 +56,10 @@ def test_no_kernel_spills(lib):
     for must in ("k_fused_pipelined", "k_stage1_summarize", "k_stage1_emit", "k_minify_onchip", "k_validate_utf8"):
         assert must in names, must
     # one kernel is MEANT to use private memory: k_tape_slow_numbers keeps two 516-byte big integers per thread for the handful of
-    # number tokens whose rounding needs exact arithmetic (sj_number.h); it exists so that k_tape_write needs none
+    # number tokens whose rounding needs exact arithmetic (sj_number.h); it exists so that k_tape_numbers needs none
     spilling = {k: v["scratch"] for k, v in res.items() if v.get("scratch", 0) != 0 and "k_tape_slow_numbers" not in k}
     assert spilling == {}, spilling
-    assert any("k_tape_write" in k for k in res)
+    assert any("k_tape_numbers" in k for k in res) and any("k_tape_rules" in k for k in res)
     # the occupancy the launch bounds ask for is the occupancy the register count allows (MI355X_MICROARCH.md, register file table)
     for k, v in res.items():
         if "k_fused_pipelined" in k or "k_minify_onchip" in k:

@@ -79,3 +79,14 @@ def test_wide_containers_saturate_their_count(model):
     """more than 0xFFFFFF elements: the count field of the opening word saturates (tape_builder.h:402-404)"""
     n = 0xFFFFFF + 5
     model([b"[" + b"1," * (n - 1) + b"1]", b"[" + b"1," * 0xFFFFFE + b"1]"])
+
+
+def test_the_rule_from_tables_is_the_rule(tmp_path):
+    """k_tape_rules applies the walk's rule from three small tables (byte properties, state behind a byte, what a state accepts) instead of
+    the spelled-out rule this file's model runs: both forms on every combination that can make a difference (2 x 10^9 of them)"""
+    exe = str(tmp_path / "test_tape_rules")
+    src = os.path.join(_paths.REPO_ROOT, "tests", "host", "test_tape_rules.cpp")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", _paths.CSRC_DIR, src, "-o", exe], check=True)
+    p = subprocess.run([exe], capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()[:2000]
+    assert b"combinations agree" in p.stdout
