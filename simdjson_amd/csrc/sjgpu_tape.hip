@@ -187,8 +187,8 @@ __global__ __launch_bounds__(1024) void k_tok_scan_sums(int *__restrict__ sums, 
 // their level: the depth in front of an opening bracket, the depth behind a closing one, and that of the container a comma separates
 // the members of -- clamped to [0, kmax] (beyond the nesting limit an error is already certain); *m_out = how many went in
 __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__ tokc, u32 n, u32 kmax, const int *__restrict__ sums, u32 nblocks, int *__restrict__ tpos,
-                                                         int *__restrict__ depth, u32 *__restrict__ value_list, unsigned short *__restrict__ key, u32 *__restrict__ tok,
-                                                         int *__restrict__ m_out, int *__restrict__ max_level, u32 *__restrict__ number_list) {
+                                                         int *__restrict__ depth, u64 *__restrict__ value_list, unsigned short *__restrict__ key, u32 *__restrict__ tok,
+                                                         int *__restrict__ m_out, int *__restrict__ max_level, u64 *__restrict__ number_list) {
   __shared__ u32 sh[3][TS_THREADS / 64];
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u64 block0 = u64(blockIdx.x) * TS_BLOCK;
@@ -234,9 +234,10 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
         if (i == n) { *m_out = slot; m_out[2] = numbers_before; m_out[3] = slot + 1; m_out[4] = strings_before; m_out[5] = rest_before; }
         if (i < n) {
           const u32 words = p[j].a & 0xFFFFu;
-          if (p[j].c >> 16) { number_list[numbers_before] = u32(i); }            // k_tape_numbers
-          else if (p[j].b & 0xFFFFu) { value_list[strings_before] = u32(i); }      // k_tape_strings
-          else if (words == 1u && !(p[j].a >> 16)) { value_list[n - u32(rest_before)] = u32(i); } // k_tape_atoms (brackets have the sort flag)
+          const u64 entry = (u64(u32(tp[j])) << 32) | u32(i); // a list entry carries the token's tape position: the value kernels need no gather for it
+          if (p[j].c >> 16) { number_list[numbers_before] = entry; }            // k_tape_numbers
+          else if (p[j].b & 0xFFFFu) { value_list[strings_before] = entry; }      // k_tape_strings
+          else if (words == 1u && !(p[j].a >> 16)) { value_list[n - u32(rest_before)] = entry; } // k_tape_atoms (brackets have the sort flag)
         }
         if (i < n && (p[j].a >> 16)) {
           int k = (p[j].b >> 16) ? d : d - 1;
@@ -472,54 +473,56 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_rules(u32 n, u32 max_depth,
 // When the string buffer came from the stream compaction (sjgpu_string_stream.hip) the records are known by ORDINAL -- the k-th string
 // token is entry k of the list and its record begins at outq[k] -- and their length words are still missing: a record ends where the
 // next one begins ([u32 length][bytes][0]: on_end_string, :428-433).  Otherwise the per-string kernels left the offsets per token.
-__global__ __launch_bounds__(TP_THREADS) void k_tape_strings(const u32 *__restrict__ value_list, const int *__restrict__ count_ptr, const int *__restrict__ tpos,
+__global__ __launch_bounds__(TP_THREADS) void k_tape_strings(const u64 *__restrict__ value_list, const int *__restrict__ count_ptr,
                                                             const u32 *__restrict__ str_offsets, strings_handoff strs, u8 *__restrict__ string_buf, u64 *__restrict__ tape,
                                                             u64 tape_cap) {
   const u32 count = u32(*count_ptr);
   const bool stream_strings = strs.go_stream != nullptr && *strs.go_stream != 0; // uniform
   for (u64 k = u64(blockIdx.x) * TP_THREADS + threadIdx.x; k < count; k += u64(gridDim.x) * TP_THREADS) {
-    const u32 i = value_list[k];
+    const u64 entry = value_list[k];
     u32 payload;
     if (stream_strings) {
       payload = strs.outq[k];
       *reinterpret_cast<u32_unaligned_t *>(string_buf + payload) = strs.outq[k + 1] - payload - 5u;
     } else {
-      payload = str_offsets[i];
+      payload = str_offsets[u32(entry)];
     }
-    const u64 at = u64(u32(tpos[i])) + 1u;
+    const u64 at = (entry >> 32) + 1u;
     if (at < tape_cap) { tape[at] = tape_word32('"', payload); }
   }
 }
 // the other one-word tokens (listed from the back of value_list): true / false / null (visit_true_atom ..., tape_builder.h:278-329) -- any
 // other byte here is no token at all and k_tape_rules has said so
 __global__ __launch_bounds__(TP_THREADS) void k_tape_atoms(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, const u8 *__restrict__ tokc,
-                                                          const u32 *__restrict__ value_list, const int *__restrict__ count_ptr, const int *__restrict__ tpos,
-                                                          u64 *__restrict__ tape, u64 tape_cap, tape_result_dev *__restrict__ res) {
+                                                          const u64 *__restrict__ value_list, const int *__restrict__ count_ptr, u64 *__restrict__ tape, u64 tape_cap,
+                                                          tape_result_dev *__restrict__ res) {
   const u32 count = u32(*count_ptr);
   for (u64 k = u64(blockIdx.x) * TP_THREADS + threadIdx.x; k < count; k += u64(gridDim.x) * TP_THREADS) {
-    const u32 i = value_list[n - u32(k)];
+    const u64 entry = value_list[n - u32(k)];
+    const u32 i = u32(entry);
     const u32 c = tokc[i + 2];
     if (c != 't' && c != 'f' && c != 'n') { continue; }
     const windowed_bytes src{buf, u32(len)};
     const bool ok = c == 't' ? atom_matches(src, idx[i], 't', 'r', 'u', 'e', 0)
                              : (c == 'f' ? atom_matches(src, idx[i], 'f', 'a', 'l', 's', 'e') : atom_matches(src, idx[i], 'n', 'u', 'l', 'l', 0));
     if (!ok) { report_error(res, error_key(i, 2, c == 't' ? SJ_T_ATOM_ERROR : (c == 'f' ? SJ_F_ATOM_ERROR : SJ_N_ATOM_ERROR))); }
-    const u64 at = u64(u32(tpos[i])) + 1u;
+    const u64 at = (entry >> 32) + 1u;
     if (at < tape_cap) { tape[at] = tape_word32(c, 0); }
   }
 }
 
 // the number tokens k_tok_apply listed, one per lane: visit_number (tape_builder.h:213-275) = parse_number (numberparsing.h:859-971, sj_number.h)
-__global__ __launch_bounds__(TP_THREADS) void k_tape_numbers(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, const int *__restrict__ tpos,
-                                                            const u32 *__restrict__ number_list, const int *__restrict__ count_ptr, u64 *__restrict__ tape, u64 tape_cap,
+__global__ __launch_bounds__(TP_THREADS) void k_tape_numbers(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx,
+                                                            const u64 *__restrict__ number_list, const int *__restrict__ count_ptr, u64 *__restrict__ tape, u64 tape_cap,
                                                             u32 *__restrict__ slow_list, u32 slow_cap, tape_result_dev *__restrict__ res) {
   const u32 count = u32(*count_ptr);
   for (u64 k = u64(blockIdx.x) * TP_THREADS + threadIdx.x; k < count; k += u64(gridDim.x) * TP_THREADS) {
-    const u32 i = number_list[k];
+    const u64 entry = number_list[k];
+    const u32 i = u32(entry);
     const windowed_bytes src{buf, u32(len)};
     const number_value v = parse_number_token(src, idx[i], static_cast<bigint *>(nullptr));
     if (v.error) { report_error(res, error_key(i, 2, v.error)); continue; }
-    const u64 at = 1 + u64(u32(tpos[i]));
+    const u64 at = (entry >> 32) + 1u;
     if (at + 1 < tape_cap) {
       tape[at] = tape_word(v.type, 0);
       tape[at + 1] = v.bits; // sign only when v.slow: k_tape_slow_numbers completes it
@@ -559,10 +562,10 @@ struct tape_workspace {
   u32 *n_words;       // [0] = n + 1 (scan lengths), [1] = n (upper bound of the sorted elements + 1 for the opens scan), [2] = hist length per pass
   u8 *tokc, *ctx;
   int *slots, *depth;        // tape position, nesting depth of every token (entry n: the totals)
-  u32 *value_list;           // string tokens from the front, the other one-word tokens from the back
+  u64 *value_list;           // (tape position << 32 | token): string tokens from the front, the other one-word tokens from the back
   int *m;                    // brackets and commas = elements of the sort
   int *sums;                 // k_tok_classify's block totals (6 rows)
-  u32 *number_list;          // the number tokens
+  u64 *number_list;          // the number tokens, same form
   u32 tok_blocks;
   unsigned short *key_a, *key_b;
   u32 *tok_a, *tok_b, *openpos, *slow_list;
@@ -585,8 +588,8 @@ static tape_workspace carve(uint8_t *base, uint32_t n, uint64_t len) {
   w.ctx = take(n1 + 8);
   w.slots = reinterpret_cast<int *>(take(n1 * 4 + 64));
   w.depth = reinterpret_cast<int *>(take(n1 * 4 + 64));
-  w.value_list = reinterpret_cast<u32 *>(take(n1 * 4 + 64));
-  w.number_list = reinterpret_cast<u32 *>(take(n1 * 4 + 64));
+  w.value_list = reinterpret_cast<u64 *>(take(n1 * 8 + 64));
+  w.number_list = reinterpret_cast<u64 *>(take(n1 * 8 + 64));
   w.tok_blocks = blocks_of(n1, TS_BLOCK);
   w.sums = reinterpret_cast<int *>(take(size_t(w.tok_blocks) * TS_SUMS * 4 + 64));
   w.key_a = reinterpret_cast<unsigned short *>(take(n1 * 2 + 64));
@@ -648,9 +651,9 @@ void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t
   hipLaunchKernelGGL(k_tape_match, dim3(blocks_of(n1, TP_THREADS * TM_PER)), dim3(TP_THREADS), 0, s, sorted, m_ptr, w.opens, w.openpos, w.slots, w.ctx, tape, tape_cap, w.res);
   hipLaunchKernelGGL(k_tape_rules, dim3(blocks_of(n1, TP_THREADS * TW_PER)), dim3(TP_THREADS), 0, s, n, max_depth, w.tokc, w.slots, w.depth, w.ctx, tape, tape_cap, w.res);
   const u32 list_grid = grid < 8192u ? grid : 8192u;
-  hipLaunchKernelGGL(k_tape_strings, dim3(list_grid), dim3(TP_THREADS), 0, s, w.value_list, w.m + 4, w.slots, str_offsets, strs, string_buf, tape, tape_cap);
-  hipLaunchKernelGGL(k_tape_atoms, dim3(list_grid), dim3(TP_THREADS), 0, s, buf, len, idx, n, w.tokc, w.value_list, w.m + 5, w.slots, tape, tape_cap, w.res);
-  hipLaunchKernelGGL(k_tape_numbers, dim3(list_grid), dim3(TP_THREADS), 0, s, buf, len, idx, w.slots, w.number_list, w.m + 2, tape, tape_cap, w.slow_list,
+  hipLaunchKernelGGL(k_tape_strings, dim3(list_grid), dim3(TP_THREADS), 0, s, w.value_list, w.m + 4, str_offsets, strs, string_buf, tape, tape_cap);
+  hipLaunchKernelGGL(k_tape_atoms, dim3(list_grid), dim3(TP_THREADS), 0, s, buf, len, idx, n, w.tokc, w.value_list, w.m + 5, tape, tape_cap, w.res);
+  hipLaunchKernelGGL(k_tape_numbers, dim3(list_grid), dim3(TP_THREADS), 0, s, buf, len, idx, w.number_list, w.m + 2, tape, tape_cap, w.slow_list,
                      w.slow_cap, w.res);
   hipLaunchKernelGGL(k_tape_slow_numbers, dim3(64), dim3(64), 0, s, buf, len, idx, w.slots, w.slow_list, w.slow_cap, tape, tape_cap, w.res);
 }
