@@ -41,7 +41,7 @@ struct dev_bytes {
   __device__ __forceinline__ u32 byte(u32 pos) const { return pos < len ? u32(buf[pos]) : 0x20u; }
 };
 // The same bytes through an 8-byte window in registers: a token is read front to back, so one (unaligned) 8-byte load serves eight
-// byte() calls -- the per-byte loads of the first version were what made k_tape_write the longest kernel of the tape
+// byte() calls -- the per-byte loads of the first version were what made the per-token kernel (then k_tape_write) the longest kernel of the tape
 // (profiles/r03_tape_kernel_stats.txt: 1.9 ms of 6.5 per 256 MiB document, numbers parsed with a round trip to L2 per digit).
 struct windowed_bytes {
   const u8 *buf;
@@ -97,7 +97,7 @@ typedef u32 __attribute__((aligned(1))) u32_unaligned_t;
 // the four token bytes i0 ... i0 + 3 (tokc is two bytes off the dword grid: one unaligned load)
 __device__ __forceinline__ u32 four_tokens(const u8 *__restrict__ tokc, u64 i0) { return *reinterpret_cast<const u32_unaligned_t *>(tokc + 2 + i0); }
 
-// tokc holds the token bytes with TWO zero bytes in front and behind: tokc[i + 2] = byte of token i (k_tape_write looks two tokens back
+// tokc holds the token bytes with TWO zero bytes in front and behind: tokc[i + 2] = byte of token i (k_tape_rules looks two tokens back
 // and one ahead).  The same sweep leaves the block totals: sums[k * nblocks + block], k = tape words, sort flags, strings, opens,
 // closes, numbers.
 __global__ __launch_bounds__(TS_THREADS) void k_tok_classify(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, u8 *__restrict__ tokc,
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_openpos(sorted_pairs sorted
 // commas: ctx[token] = kind of their container.  Closing brackets: the two bracket words of the tape
 // (end_container, tape_builder.h:396-407; an empty container is the same formula with count 0, :386-391).
 // Four consecutive sorted elements per thread, the loads of each step of the chain (element -> its container's open -> that open's key and
-// token -> tape positions) issued for all four before any is used: like k_tape_write, this kernel ran at the latency of its chain.
+// token -> tape positions) issued for all four before any is used: with one element per thread this kernel ran at the latency of its chain.
 constexpr u32 TM_PER = 4;
 __global__ __launch_bounds__(TP_THREADS) void k_tape_match(sorted_pairs sorted, const int *__restrict__ m_ptr, const int *__restrict__ opens_before,
                                                           const u32 *__restrict__ openpos, const int *__restrict__ tpos, u8 *__restrict__ ctx, u64 *__restrict__ tape,
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_numbers(const u8 *__restric
 }
 
 // Number tokens with more than 19 significant digits whose two bracketing conversions disagree: the exact decision needs two
-// big integers of 516 bytes each per thread (private memory) -- kept out of k_tape_write, which then needs no scratch at all.
+// big integers of 516 bytes each per thread (private memory) -- kept out of k_tape_numbers, which then needs no scratch at all.
 __global__ __launch_bounds__(64) void k_tape_slow_numbers(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, const int *__restrict__ tpos, const u32 *__restrict__ slow_list,
                                                           u32 slow_cap, u64 *__restrict__ tape, u64 tape_cap, tape_result_dev *__restrict__ res) {
   const u32 count = res->slow_numbers < slow_cap ? res->slow_numbers : slow_cap;
