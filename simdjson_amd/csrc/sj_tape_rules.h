@@ -78,6 +78,40 @@ SJ_HD u32 token_rule(bool first, u32 c, u32 prev, u32 prev2, u32 next, u32 ctx_p
   return 0;
 }
 
+// ---- the token front: what one token contributes to the prefix sums, and where it is listed -----------------------------------------------
+// (sjgpu_tape.hip: k_tok_classify / k_tok_apply; tests/host/test_tape_model.cpp runs the same functions)
+struct tok_packed {
+  u32 a, b, c; // a: tape words | sort flag << 16;  b: string | opening << 16;  c: closing | number << 16  (block sums of 4096 tokens fit the fields)
+};
+SJ_HD tok_packed tok_contribution(u32 ch, bool root) {
+  const u32 open = is_open_char(ch) ? 1u : 0u, close = is_close_char(ch) ? 1u : 0u;
+  tok_packed p;
+  const u32 slots = tape_slots(ch, root); // two words: a number token (visit_primitive's number path)
+  p.a = slots | ((open | close | (ch == ',' ? 1u : 0u)) << 16);
+  p.b = (ch == '"' ? 1u : 0u) | (open << 16);
+  p.c = close | ((slots == 2u ? 1u : 0u) << 16);
+  return p;
+}
+// one-word tokens that are neither strings nor brackets (atoms, and bytes that are no token) among tokens with these counts:
+// tape words = strings + rest + 2 numbers + opens + closes
+SJ_HD int one_word_rest(int words, int strings, int numbers, int opens, int closes) { return words - strings - 2 * numbers - opens - closes; }
+// which list a token goes to: the value kernels of its kind take it from there
+enum : u32 { LIST_NONE = 0, LIST_NUMBERS = 1, LIST_STRINGS = 2, LIST_REST = 3 };
+SJ_HD u32 value_list_of(const tok_packed &p) {
+  if (p.c >> 16) { return LIST_NUMBERS; }
+  if (p.b & 0xFFFFu) { return LIST_STRINGS; }
+  return ((p.a & 0xFFFFu) == 1u && !(p.a >> 16)) ? u32(LIST_REST) : u32(LIST_NONE); // (brackets carry the sort flag, ':' and ',' no word)
+}
+SJ_HD u64 list_entry(u32 tape_position, u32 token) { return (u64(tape_position) << 32) | token; }
+// what an element of the sort is, kept in the four bits of its 16-bit key the level (<= 4095) leaves free: the passes behind the sort
+// then never have to look the token's byte up again
+constexpr u32 KIND_SHIFT = 12, KIND_COMMA = 0, KIND_OPEN_OBJECT = 1, KIND_OPEN_ARRAY = 2, KIND_CLOSE_OBJECT = 3, KIND_CLOSE_ARRAY = 4;
+SJ_HD u32 sort_kind(u32 ch) {
+  return ch == '{' ? KIND_OPEN_OBJECT : (ch == '[' ? KIND_OPEN_ARRAY : (ch == '}' ? KIND_CLOSE_OBJECT : (ch == ']' ? KIND_CLOSE_ARRAY : KIND_COMMA)));
+}
+SJ_HD bool kind_is_open(u32 kind) { return kind == KIND_OPEN_OBJECT || kind == KIND_OPEN_ARRAY; }
+SJ_HD u32 sort_key(u32 level, u32 ch) { return level | (sort_kind(ch) << KIND_SHIFT); }
+
 // ---- the same rule from tables ---------------------------------------------------------------------------------------------------------
 // token_rule spelled out is ~60 boolean operations on per-lane conditions, which the GPU compiler turns into as many scalar mask
 // instructions per token: the kernel that only applies the rule was bound by their issue (profiles/r03_pmc_summary.txt: 250 M scalar

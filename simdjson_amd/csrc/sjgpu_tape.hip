@@ -74,25 +74,8 @@ __device__ __forceinline__ void report_error(tape_result_dev *res, u64 key) { at
 // so here a block of 4096 tokens adds them up while it fetches its token bytes (k_tok_classify) and reads the 4 KiB of bytes once more
 // for the prefixes (k_tok_apply) -- nothing else.  Inside a block the five counters travel packed in three dwords (each field < 2^16).
 constexpr u32 TS_THREADS = 256, TS_ROW = TS_THREADS * 4, TS_ROWS = 4, TS_BLOCK = TS_ROW * TS_ROWS, TS_SUMS = 6;
-struct tok_packed {
-  u32 a, b, c; // a: tape words | sort flag << 16;  b: string | opening << 16;  c: closing | number << 16
-};
-__device__ __forceinline__ tok_packed tok_contribution(u32 ch, bool root) {
-  const u32 open = is_open_char(ch) ? 1u : 0u, close = is_close_char(ch) ? 1u : 0u;
-  tok_packed p;
-  const u32 slots = tape_slots(ch, root); // two words: a number token (visit_primitive's number path, sj_tape_rules.h)
-  p.a = slots | ((open | close | (ch == ',' ? 1u : 0u)) << 16);
-  p.b = (ch == '"' ? 1u : 0u) | (open << 16);
-  p.c = close | ((slots == 2u ? 1u : 0u) << 16);
-  return p;
-}
-// what an element of the sort is, kept in the four bits of its 16-bit key the level (<= 4095) leaves free: the passes behind the sort
-// then never have to look the token's byte up again
-constexpr u32 KIND_SHIFT = 12, KIND_COMMA = 0, KIND_OPEN_OBJECT = 1, KIND_OPEN_ARRAY = 2, KIND_CLOSE_OBJECT = 3, KIND_CLOSE_ARRAY = 4;
-__device__ __forceinline__ u32 sort_kind(u32 ch) {
-  return ch == '{' ? KIND_OPEN_OBJECT : (ch == '[' ? KIND_OPEN_ARRAY : (ch == '}' ? KIND_CLOSE_OBJECT : (ch == ']' ? KIND_CLOSE_ARRAY : KIND_COMMA)));
-}
-__device__ __forceinline__ bool kind_is_open(u32 kind) { return kind == KIND_OPEN_OBJECT || kind == KIND_OPEN_ARRAY; }
+// (tok_packed / tok_contribution, the kinds of the sort's elements and the placement of the value lists live in sj_tape_rules.h: the CPU
+// model of tests/host/test_tape_model.cpp runs the same functions)
 typedef u32 __attribute__((aligned(1))) u32_unaligned_t;
 // the four token bytes i0 ... i0 + 3 (tokc is two bytes off the dword grid: one unaligned load)
 __device__ __forceinline__ u32 four_tokens(const u8 *__restrict__ tokc, u64 i0) { return *reinterpret_cast<const u32_unaligned_t *>(tokc + 2 + i0); }
@@ -195,7 +178,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
   const int slots0 = sums[0 * nblocks + blockIdx.x], sel0 = sums[1 * nblocks + blockIdx.x], strs0 = sums[2 * nblocks + blockIdx.x];
   const int opens0 = sums[3 * nblocks + blockIdx.x], closes0 = sums[4 * nblocks + blockIdx.x];
   const int depth0 = opens0 - closes0, numbers0 = sums[5 * nblocks + blockIdx.x];
-  const int rest0 = slots0 - strs0 - 2 * numbers0 - opens0 - closes0; // one-word tokens that are neither strings nor brackets
+  const int rest0 = one_word_rest(slots0, strs0, numbers0, opens0, closes0); // one-word tokens that are neither strings nor brackets
   u32 ra = 0, rb = 0, rc = 0; // what the rows in front of this one hold (packed)
   int top = 0;                // highest level this thread sent into the sort
 #pragma unroll 1
@@ -229,20 +212,20 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
         tp[j] = slots0 + int(ea & 0xFFFFu);
         dp[j] = d;
         const int strings_before = strs0 + int(eb & 0xFFFFu), numbers_before = numbers0 + int(ec >> 16);
-        const int rest_before = rest0 + int(ea & 0xFFFFu) - int(eb & 0xFFFFu) - 2 * int(ec >> 16) - int(eb >> 16) - int(ec & 0xFFFFu);
+        const int rest_before = rest0 + one_word_rest(int(ea & 0xFFFFu), int(eb & 0xFFFFu), int(ec >> 16), int(eb >> 16), int(ec & 0xFFFFu));
         const int slot = sel0 + int(ea >> 16);
         if (i == n) { *m_out = slot; m_out[2] = numbers_before; m_out[3] = slot + 1; m_out[4] = strings_before; m_out[5] = rest_before; }
         if (i < n) {
-          const u32 words = p[j].a & 0xFFFFu;
-          const u64 entry = (u64(u32(tp[j])) << 32) | u32(i); // a list entry carries the token's tape position: the value kernels need no gather for it
-          if (p[j].c >> 16) { number_list[numbers_before] = entry; }            // k_tape_numbers
-          else if (p[j].b & 0xFFFFu) { value_list[strings_before] = entry; }      // k_tape_strings
-          else if (words == 1u && !(p[j].a >> 16)) { value_list[n - u32(rest_before)] = entry; } // k_tape_atoms (brackets have the sort flag)
+          const u64 entry = list_entry(u32(tp[j]), u32(i)); // a list entry carries the token's tape position: the value kernels need no gather for it
+          const u32 list = value_list_of(p[j]);
+          if (list == LIST_NUMBERS) { number_list[numbers_before] = entry; }               // k_tape_numbers
+          else if (list == LIST_STRINGS) { value_list[strings_before] = entry; }           // k_tape_strings
+          else if (list == LIST_REST) { value_list[n - u32(rest_before)] = entry; }        // k_tape_atoms
         }
         if (i < n && (p[j].a >> 16)) {
           int k = (p[j].b >> 16) ? d : d - 1;
           k = k < 0 ? 0 : (k > int(kmax) ? int(kmax) : k);
-          key[slot] = (unsigned short)(u32(k) | (sort_kind((four >> (8u * j)) & 0xFFu) << KIND_SHIFT));
+          key[slot] = (unsigned short)sort_key(u32(k), (four >> (8u * j)) & 0xFFu);
           tok[slot] = u32(i);
           top = k > top ? k : top;
         }
