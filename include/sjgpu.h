@@ -214,8 +214,9 @@ int sjgpu_depth_scan_device(sjgpu_ctx *ctx, const void *buf_dev, const void *idx
  * What the reference's stage 2 does at every quote of the structural list: stringparsing::parse_string
  * (src/generic/stage2/stringparsing.h:150-193; the virtual dom_parser_implementation::parse_string,
  * include/simdjson/internal/dom_parser_implementation.h:124) into document::string_buf as [u32 length][unescaped bytes][0]
- * (src/generic/stage2/tape_builder.h:187-205, :415-433) -- here for all strings of the list at once, one lane per
- * structural: measure, exclusive scan, write.  idx_dev[0..n] is the list sjgpu_stage1_device left for buf_dev[0..len)
+ * (src/generic/stage2/tape_builder.h:187-205, :415-433) -- here for all strings of the list at once: as a stream compaction of
+ * the document when every string is valid (the records follow each other in document order: sjgpu_string_stream.hip), else one
+ * lane per structural (measure, exclusive scan, write: sjgpu_strings.hip); same bytes either way.  idx_dev[0..n] is the list sjgpu_stage1_device left for buf_dev[0..len)
  * (regular mode, no error) INCLUDING its first sentinel idx_dev[n] = len, which bounds the last token.  string_buf_dev receives the records in document order, byte for byte the reference's
  * document::string_buf (5 (len + 1) / 3 bytes always suffice; the reference allocates ROUNDUP(5 len / 3 + 64, 64));
  * offsets_dev (n + 1 words, may be NULL): offsets_dev[i] = where structural i's record begins -- for a string exactly the
