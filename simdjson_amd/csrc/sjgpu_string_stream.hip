@@ -23,39 +23,27 @@ namespace {
 
 constexpr u32 STRS_WAVES = 4; // waves (= segments) per workgroup
 
-// The document's bytes for the escape decoders, through a 16-byte window in registers: a \\u escape (or a surrogate pair of two) is read
-// front to back, so two unaligned 8-byte loads serve the up to 12 byte() calls of one decode -- with one load per byte the decoders
-// were what the twitter-like buffer spent its time on (0.19 \\u escapes per 64-byte block: k_strs_write 417 us against 160 us for a
-// document without them, first measurement of this file).  Bytes at or beyond len read as 0x20.
-struct plain_doc { // one load per byte: what k_strs_count uses (the window costs it 27 VGPRs and a third of its occupancy: measured slower)
+// The document's bytes for the escape decoders.  A lane that holds a \\u escape reads up to 12 bytes behind it (and a block looks 10 bytes
+// back), one after the other, inside a divergent loop.  A chunk that holds \\u escapes is PARKED in LDS first (4 KiB per wave: in
+// k_strs_write the output window, which is still free at that point) and the decoders read it there; only the few bytes in front of and
+// behind the chunk come from the document.  Measured: k_strs_count 138 -> 122 us per 256 MiB of the synthetic twitter-like text,
+// k_strs_write unchanged (376 us; byte loads through L1 and a 16-byte register window had given 405 and 372) -- the 240 us that escapes
+// cost that kernel (profiles/r03_strings_escape_cost.txt) are not load latency; kept because it takes 40 VGPRs out of the kernel.
+// Bytes at or beyond len read as 0x20 (a parked chunk holds them that way: load_block).
+struct plain_doc {
   const u8 *buf;
   u32 len;
   __device__ __forceinline__ u32 byte(u32 pos) const { return pos < len ? u32(buf[pos]) : 0x20u; }
 };
-struct global_doc {
+struct parked_doc {
+  const u8 *park; // LDS: the bytes [pos0, pos0 + CHUNK_BYTES)
+  u32 pos0;
   const u8 *buf;
   u32 len;
-  mutable u64 lo = 0, hi = 0;
-  mutable u32 at = 0xFFFFFF00u; // position of the window's first byte (nothing loaded yet)
-  typedef u64 __attribute__((aligned(1))) u64_any;
   __device__ __forceinline__ u32 byte(u32 pos) const {
-    u32 d = pos - at;
-    if (d >= 16u) { // also for pos < at (wraps)
-      at = pos;
-      d = 0;
-      if (u64(pos) + 16u <= len) {
-        lo = *reinterpret_cast<const u64_any *>(buf + pos);
-        hi = *reinterpret_cast<const u64_any *>(buf + pos + 8);
-      } else {
-        lo = 0; hi = 0;
-        for (u32 k = 0; k < 8; k++) {
-          lo |= u64(pos + k < len ? u32(buf[pos + k]) : 0x20u) << (8u * k);
-          hi |= u64(pos + 8 + k < len ? u32(buf[pos + 8 + k]) : 0x20u) << (8u * k);
-        }
-      }
-    }
-    const u64 half = d >= 8u ? hi : lo;
-    return u32(half >> (8u * (d & 7u))) & 0xFFu;
+    const u32 d = pos - pos0; // wraps for pos < pos0
+    if (d < CHUNK_BYTES) { return park[d]; }
+    return pos < len ? u32(buf[pos]) : 0x20u;
   }
 };
 
@@ -115,8 +103,10 @@ __device__ __forceinline__ u32 u_tail_before(const u8 *__restrict__ buf, u64 sta
 }
 
 // one chunk: stage 1's escape and quote algebra (scan_chunk, sjgpu_device.h), then what the strings need on top of it
-template <class SRC, class SINK>
-__device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carry &wc, u32 lane, const SRC &src, u32 block_pos, bool allow, SINK &notes) {
+// park: CHUNK_BYTES of LDS of this wave (16-byte aligned), free during the call
+template <class SINK>
+__device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carry &wc, u32 lane, const u8 *__restrict__ buf, u32 len, u32 block_pos, bool allow, u8 *park,
+                                                   SINK &notes) {
   const planes P = transpose64(w);
   const classes c = classify(P);
   const u64 lt = lanemask_lt(lane);
@@ -152,7 +142,15 @@ __device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carr
       u32 prev = u32(__shfl_up(int(top), 1));
       if (lane == 0) { prev = wc.u; }
       out.u_prev = prev;
+      uint4 *row = reinterpret_cast<uint4 *>(park + lane * BLOCK_BYTES);
+      row[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      row[1] = make_uint4(w[4], w[5], w[6], w[7]);
+      row[2] = make_uint4(w[8], w[9], w[10], w[11]);
+      row[3] = make_uint4(w[12], w[13], w[14], w[15]);
+      wave_lds_fence();
+      const parked_doc src{park, block_pos - lane * BLOCK_BYTES, buf, len};
       if (out.U | u64(prev)) { unicode_escapes(src, block_pos, out.U, prev, allow, out.b, notes); }
+      wave_lds_fence(); // the caller may reuse the parking space
     }
     u_out = readlane(top, 63);
   }
@@ -163,11 +161,12 @@ __device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carr
 // ---- pass 1: what every segment contributes, for both carry-ins ------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_count(const u8 *__restrict__ buf, u64 len, u32 nseg, u32 allow_replacement, const u8 *__restrict__ esc_tab,
                                                                strs_summary *__restrict__ summ) {
+  __shared__ __attribute__((aligned(16))) u8 sh_park[STRS_WAVES][CHUNK_BYTES];
   const u32 lane = threadIdx.x & 63u;
   const u32 seg = blockIdx.x * STRS_WAVES + (threadIdx.x >> 6);
   if (seg >= nseg) { return; }
+  u8 *const park = sh_park[threadIdx.x >> 6];
   const u64 seg_start = u64(seg) * SEG_BYTES;
-  const plain_doc src{buf, u32(len)};
   const esc_ref esc(esc_tab);
   const u32 lookback = lookback_issue(buf, seg_start, lane);
   strs_carry wc{0u, 0u, 0u};
@@ -185,7 +184,7 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_count(const u8 *__rest
       wc.u = u_tail_before(buf, seg_start, lane, lookback, esc);
     }
     no_patches none;
-    const strs_chunk m = string_chunk(w, wc, lane, src, u32(pos), allow_replacement != 0, none);
+    const strs_chunk m = string_chunk(w, wc, lane, buf, u32(len), u32(pos), allow_replacement != 0, park, none);
     d0 += u32(popc64(m.b.keep & m.in_string));
     dall += u32(popc64(m.b.keep));
     o0 += u32(popc64(m.quote & m.in_string));
@@ -338,7 +337,7 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__rest
   u8 *const stage = sh_stage[wave];
   u8 *const dump = stage + STRS_WINDOW + lane;
   const u64 seg_start = u64(seg) * SEG_BYTES;
-  const global_doc src{buf, u32(len)};
+  const plain_doc src{buf, u32(len)}; // (the rare lane with more \\u escapes than it kept notes of decodes them a second time, from the document)
   const esc_ref esc(esc_tab);
   const bool allow = allow_replacement != 0;
   const u32 lookback = lookback_issue(buf, seg_start, lane);
@@ -357,7 +356,7 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__rest
       wc.u = u_tail_before(buf, seg_start, lane, lookback, esc);
     }
     escape_notes notes;
-    const strs_chunk m = string_chunk(w, wc, lane, src, u32(pos), allow, notes);
+    const strs_chunk m = string_chunk(w, wc, lane, buf, u32(len), u32(pos), allow, stage, notes); // (parks the chunk in the window, which is free until the scatter)
     const u64 kept = m.b.keep & m.in_string;       // data bytes
     const u64 open = m.quote & m.in_string;         // 4 bytes each: the length, written by k_strs_finalize
     const u64 one = kept | andn(m.quote, m.in_string); // one byte each: data, and the 0 a closing quote turns into
@@ -393,9 +392,9 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__rest
       }
       wave_lds_fence();
       // the few bytes whose value is not the input's: escaped b f n r t, and what \u escapes stand for
-      for (u64 t = m.b.remap & kept; t; t &= t - 1) {
-        const u32 p = ctz64(t);
-        stage[map.at(p)] = u8(simple_escape_value(src.byte(u32(pos) + p)));
+      for (u64 t = m.b.remap & kept; t; t &= t - 1) { // (the scatter put the escaped letter itself there)
+        u8 *const at = stage + map.at(ctz64(t));
+        *at = u8(simple_escape_value(*at));
       }
       if (notes.count) { // (divergent: the lanes that hold \\u escapes)
         window_patches sink{stage, map, kept};
