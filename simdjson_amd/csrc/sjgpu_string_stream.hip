@@ -25,8 +25,7 @@ constexpr u32 STRS_WAVES = 4; // waves (= segments) per workgroup
 
 // The document's bytes for the escape decoders.  A lane that holds a \\u escape reads up to 12 bytes behind it (and a block looks 10 bytes
 // back), one after the other, inside a divergent loop.  A chunk that holds \\u escapes is PARKED in LDS first (4 KiB per wave: in
-// k_strs_write the output window, which is still free at that point) and the decoders read it there; only the few bytes in front of and
-// behind the chunk come from the document.  Measured: k_strs_count 138 -> 122 us per 256 MiB of the synthetic twitter-like text,
+// k_strs_write the output window, which is still free at that point) and the decoders read it there (parked_doc below).  Measured: k_strs_count 138 -> 122 us per 256 MiB of the synthetic twitter-like text,
 // k_strs_write unchanged (376 us; byte loads through L1 and a 16-byte register window had given 405 and 372) -- the 240 us that escapes
 // cost that kernel (profiles/r03_strings_escape_cost.txt) are not load latency; kept because it takes 40 VGPRs out of the kernel.
 // Bytes at or beyond len read as 0x20 (a parked chunk holds them that way: load_block).
@@ -35,17 +34,46 @@ struct plain_doc {
   u32 len;
   __device__ __forceinline__ u32 byte(u32 pos) const { return pos < len ? u32(buf[pos]) : 0x20u; }
 };
+// A parked chunk with PARK_MARGIN bytes of the document in front of it and behind it: everything a decoder of this chunk can ask for
+// (10 bytes back from a block, 12 bytes on from a 'u'), so that byte() is one LDS read without a "not parked: read the document" branch
+// behind it (parity-tested on the GPU; its effect on the time is not measured: the round's GPU budget ended with the test run).
+constexpr u32 PARK_MARGIN = 16, PARK_BYTES = CHUNK_BYTES + 2 * PARK_MARGIN;
 struct parked_doc {
-  const u8 *park; // LDS: the bytes [pos0, pos0 + CHUNK_BYTES)
+  const u8 *park; // LDS: the bytes [pos0 - PARK_MARGIN, pos0 + CHUNK_BYTES + PARK_MARGIN)
   u32 pos0;
-  const u8 *buf;
-  u32 len;
   __device__ __forceinline__ u32 byte(u32 pos) const {
-    const u32 d = pos - pos0; // wraps for pos < pos0
-    if (d < CHUNK_BYTES) { return park[d]; }
-    return pos < len ? u32(buf[pos]) : 0x20u;
+    const u32 d = pos - pos0 + PARK_MARGIN;
+    return park[d < PARK_BYTES ? d : PARK_BYTES - 1u]; // (the clamp is never taken: see above)
   }
 };
+// lane l parks its block; lane 0 the 16 bytes in front of the chunk, lane 63 the 16 bytes behind it (0x20 beyond the document, like load_block)
+__device__ __forceinline__ void park_chunk(u8 *park, const u32 (&w)[16], u32 lane, const u8 *__restrict__ buf, u32 len, u32 chunk_pos) {
+  uint4 *row = reinterpret_cast<uint4 *>(park + PARK_MARGIN + lane * BLOCK_BYTES);
+  row[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  row[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  row[2] = make_uint4(w[8], w[9], w[10], w[11]);
+  row[3] = make_uint4(w[12], w[13], w[14], w[15]);
+  if (lane == 0) {
+    uint4 v = make_uint4(0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u);
+    if (chunk_pos >= PARK_MARGIN) { v = *reinterpret_cast<const uint4 *>(buf + chunk_pos - PARK_MARGIN); } // chunks start on 4 KiB boundaries of an aligned buffer
+    *reinterpret_cast<uint4 *>(park) = v;
+  }
+  if (lane == 63) {
+    const u32 behind = chunk_pos + CHUNK_BYTES;
+    uint4 v;
+    if (u64(behind) + PARK_MARGIN <= len) {
+      v = *reinterpret_cast<const uint4 *>(buf + behind);
+    } else {
+      u32 x[4];
+      for (u32 k = 0; k < 4; k++) {
+        x[k] = 0;
+        for (u32 b = 0; b < 4; b++) { x[k] |= (behind + 4 * k + b < len ? u32(buf[behind + 4 * k + b]) : 0x20u) << (8u * b); }
+      }
+      v = make_uint4(x[0], x[1], x[2], x[3]);
+    }
+    *reinterpret_cast<uint4 *>(park + PARK_MARGIN + CHUNK_BYTES) = v;
+  }
+}
 
 // per segment, from its bytes alone (hypothesis 0 = the segment starts outside a string)
 struct strs_summary {
@@ -103,7 +131,7 @@ __device__ __forceinline__ u32 u_tail_before(const u8 *__restrict__ buf, u64 sta
 }
 
 // one chunk: stage 1's escape and quote algebra (scan_chunk, sjgpu_device.h), then what the strings need on top of it
-// park: CHUNK_BYTES of LDS of this wave (16-byte aligned), free during the call
+// park: PARK_BYTES of LDS of this wave (16-byte aligned), free during the call
 template <class SINK>
 __device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carry &wc, u32 lane, const u8 *__restrict__ buf, u32 len, u32 block_pos, bool allow, u8 *park,
                                                    SINK &notes) {
@@ -142,13 +170,9 @@ __device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carr
       u32 prev = u32(__shfl_up(int(top), 1));
       if (lane == 0) { prev = wc.u; }
       out.u_prev = prev;
-      uint4 *row = reinterpret_cast<uint4 *>(park + lane * BLOCK_BYTES);
-      row[0] = make_uint4(w[0], w[1], w[2], w[3]);
-      row[1] = make_uint4(w[4], w[5], w[6], w[7]);
-      row[2] = make_uint4(w[8], w[9], w[10], w[11]);
-      row[3] = make_uint4(w[12], w[13], w[14], w[15]);
+      park_chunk(park, w, lane, buf, len, block_pos - lane * BLOCK_BYTES);
       wave_lds_fence();
-      const parked_doc src{park, block_pos - lane * BLOCK_BYTES, buf, len};
+      const parked_doc src{park, block_pos - lane * BLOCK_BYTES};
       if (out.U | u64(prev)) { unicode_escapes(src, block_pos, out.U, prev, allow, out.b, notes); }
       wave_lds_fence(); // the caller may reuse the parking space
     }
@@ -161,7 +185,7 @@ __device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carr
 // ---- pass 1: what every segment contributes, for both carry-ins ------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_count(const u8 *__restrict__ buf, u64 len, u32 nseg, u32 allow_replacement, const u8 *__restrict__ esc_tab,
                                                                strs_summary *__restrict__ summ) {
-  __shared__ __attribute__((aligned(16))) u8 sh_park[STRS_WAVES][CHUNK_BYTES];
+  __shared__ __attribute__((aligned(16))) u8 sh_park[STRS_WAVES][PARK_BYTES];
   const u32 lane = threadIdx.x & 63u;
   const u32 seg = blockIdx.x * STRS_WAVES + (threadIdx.x >> 6);
   if (seg >= nseg) { return; }
