@@ -824,6 +824,9 @@ static void launch_fused_wc(int op, const uint8_t *buf, uint64_t len, uint64_t *
   mark(ev, 3, stream);
 }
 
+// test hook (tests/host/test_kernels_emu.cpp lowers it so that small documents take the large-input kernels); never changed by the library
+uint64_t debug_fused_small_below = FUSED_SMALL_BELOW;
+
 // returns the name of the scan kernel it launched (sjgpu_profile_kernel)
 static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *desc, void *out, uint64_t out_words,
                                 scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
@@ -833,7 +836,7 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
   const u32 esc_shift = op == 1 ? ESC_SHIFT_MINIFY : ESC_SHIFT_STAGE1;
   if (!wants_escape_table(len - org.begin, org) || !esc_workspace) { org.esc = nullptr; }
   mark(ev, 0, stream); // slot 0 = everything this call enqueues (table, clears, the scan kernel)
-  if (len - org.begin <= FUSED_SMALL_BELOW && !trace) {
+  if (len - org.begin <= debug_fused_small_below && !trace) {
     if (org.esc) { launch_escape_table(buf, org.begin, len, esc_workspace, stream, nullptr, 0, esc_shift); } // a range of a larger buffer
     launch_fused_wc<1>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles);
     return op == 0 ? "k_fused<0> (16 KiB tiles)" : "k_fused<1> (16 KiB tiles)";

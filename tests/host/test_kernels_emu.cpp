@@ -1,0 +1,325 @@
+// tests/host/test_kernels_emu.cpp -- CPU tier: the stage-1 / minify / validate_utf8 KERNEL SOURCES (sjgpu_kernels.hip, sjgpu_fused.hip,
+// sjgpu_small.hip, compiled as C++ against tests/host/emu) run on documents and are compared with the oracle, launcher by launcher:
+//   split      launch_stage1 / launch_minify          (summarize -> resolve -> emit)
+//   fused      launch_stage1_fused / launch_minify_fused: 16 KiB tiles below the small-input limit, the pipelined 64 KiB-tile kernels
+//              and k_minify_onchip above it (the limit is lowered for the test so that a few hundred KiB take the large-input kernels)
+//   docs       launch_docs (one workgroup per document)
+//   ranges     a document scanned as consecutive ranges of one buffer (the overlapped host path's protocol)
+//   parity     launch_string_parity
+// The documents are adversarial for the carries between spans: backslash runs of every length across 64-byte, 4 KiB, 16 KiB, 64 KiB
+// and 1 MiB boundaries, quotes behind them, control characters, multi-byte UTF-8 (valid and not), dense and empty output.
+// Usage: test_kernels_emu <seed> <documents> [max KiB per document] [what: all|split|fused|docs|ranges]
+#include "sjgpu.h"
+#include "sjgpu_internal.h"
+#include "sj_oracle.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace sjgpu { extern uint64_t debug_fused_small_below; }
+using namespace sjgpu;
+
+static uint64_t rng_state = 1;
+static uint32_t rnd() {
+  rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull;
+  return uint32_t(rng_state >> 33);
+}
+static uint32_t rnd_below(uint32_t n) { return n ? rnd() % n : 0; }
+
+typedef std::vector<uint8_t> bytes;
+static void put(bytes &d, const char *s) { d.insert(d.end(), s, s + strlen(s)); }
+
+// ---- documents ----------------------------------------------------------------------------------------------------------------
+static const uint32_t BOUNDARIES[] = {64, 4096, 16384, 65536, 32768, 1u << 20};
+// pad with `fill` so that the next byte lands at (a multiple of one of the boundaries) + delta
+static void pad_to_boundary(bytes &d, uint8_t fill) {
+  const uint32_t B = BOUNDARIES[rnd_below(4)];
+  static const int deltas[] = {-66, -65, -64, -63, -3, -2, -1, 0, 1, 2, 3, 62, 63, 64, 65};
+  const int delta = deltas[rnd_below(sizeof deltas / sizeof deltas[0])];
+  const size_t at = d.size();
+  size_t target = (at / B + 1) * B + size_t(int(B) + delta) % B;
+  if (target > at + 70000) { target = at + rnd_below(200); }
+  d.insert(d.end(), target - at, fill);
+}
+static void soup(bytes &d, size_t n) { // token soup: every class of byte the scanner distinguishes
+  static const char alphabet[] = "\\\\\"\"\"  \n\t\r,,::[]{}aZ09-.e+\x0c\x1a\x01\x1f\x7f";
+  for (size_t i = 0; i < n; i++) {
+    const uint32_t r = rnd_below(40);
+    if (r == 0) { // a multi-byte character, sometimes broken
+      static const char *const utf[] = {"\xc3\xa9", "\xe2\x82\xac", "\xf0\x9f\x98\x80", "\xe0\xa0\x80", "\xed\x9f\xbf", "\xc0\xaf", "\xed\xa0\x80", "\xf4\x90\x80\x80", "\x80", "\xe2\x82", "\xf0\x9f"};
+      put(d, utf[rnd_below(rnd_below(4) ? 5 : 11)]);
+    } else {
+      d.push_back(uint8_t(alphabet[rnd_below(sizeof alphabet - 1 - (rnd_below(6) ? 5 : 0))])); // control characters are rarer
+    }
+  }
+}
+static void value(bytes &d, int depth) { // a valid JSON value
+  const uint32_t r = rnd_below(depth > 5 ? 4 : 7);
+  if (r == 0) { put(d, "12.5e3"); }
+  else if (r == 1) { put(d, "true"); }
+  else if (r == 2 || r == 3) {
+    d.push_back('"');
+    const uint32_t n = rnd_below(rnd_below(8) ? 20 : 300);
+    for (uint32_t i = 0; i < n; i++) {
+      const uint32_t k = rnd_below(30);
+      if (k == 0) { put(d, "\\\""); }
+      else if (k == 1) { put(d, "\\\\"); }
+      else if (k == 2) { put(d, "\\u00e9"); }
+      else if (k == 3) { put(d, "\xe2\x82\xac"); }
+      else if (k == 4) { put(d, " , : [ { "); }
+      else { d.push_back(uint8_t('a' + rnd_below(26))); }
+    }
+    d.push_back('"');
+  } else if (r == 4) {
+    d.push_back('[');
+    const uint32_t n = rnd_below(6);
+    for (uint32_t i = 0; i < n; i++) { if (i) { put(d, rnd_below(2) ? "," : ", "); } value(d, depth + 1); }
+    d.push_back(']');
+  } else {
+    d.push_back('{');
+    const uint32_t n = rnd_below(5);
+    for (uint32_t i = 0; i < n; i++) { if (i) { put(d, ",\n  "); } put(d, "\"k"); d.push_back(uint8_t('0' + i)); put(d, "\": "); value(d, depth + 1); }
+    d.push_back('}');
+  }
+}
+static bytes make_document(size_t target) {
+  bytes d;
+  const uint32_t kind = rnd_below(8);
+  while (d.size() < target) {
+    switch (kind) {
+    case 0: soup(d, 1 + rnd_below(400)); break;
+    case 1: // valid JSON, one value after the other (NDJSON-like)
+      value(d, 0);
+      d.push_back('\n');
+      break;
+    case 2: case 3: { // backslash runs placed around boundaries, in and out of strings, quotes glued to their ends
+      pad_to_boundary(d, rnd_below(3) ? ' ' : 'x');
+      if (rnd_below(4)) { d.push_back('"'); }
+      static const uint32_t lens[] = {0, 1, 2, 3, 62, 63, 64, 65, 66, 127, 128, 129, 4095, 4096, 4097, 16383, 16384, 16385, 32768, 32769, 65535, 65536, 65537, 20000, 20001};
+      uint32_t run = lens[rnd_below(sizeof lens / sizeof lens[0])];
+      if (rnd_below(3) == 0) { run = rnd_below(70000); }
+      d.insert(d.end(), run, '\\');
+      const uint32_t t = rnd_below(6);
+      if (t == 0) { put(d, "\"a"); } else if (t == 1) { put(d, "\"\""); } else if (t == 2) { put(d, "\" ,"); } else if (t == 3) { put(d, "n\""); } else if (t == 4) { put(d, "\"\\\"1"); }
+      soup(d, rnd_below(40));
+      break;
+    }
+    case 4: { // long strings (two-hypothesis segments), sometimes with a control character inside
+      d.push_back('"');
+      const uint32_t n = rnd_below(50000);
+      for (uint32_t i = 0; i < n; i++) { d.push_back(uint8_t("abc ,:[]{}\\n"[rnd_below(12)])); if (d.back() == '\\') { d.push_back('n'); } }
+      if (rnd_below(4) == 0) { d.push_back('\n'); }
+      put(d, "\", ");
+      break;
+    }
+    case 5: // dense output
+      for (uint32_t i = 0, n = 1 + rnd_below(6000); i < n; i++) { d.push_back(uint8_t("[]{},:1"[rnd_below(7)])); }
+      break;
+    case 6: { // non-ASCII text
+      d.push_back('"');
+      for (uint32_t i = 0, n = rnd_below(3000); i < n; i++) { put(d, rnd_below(2) ? "\xe6\x97\xa5" : "\xd0\x96"); if (rnd_below(300) == 0) { d.push_back(0xE6); } }
+      put(d, "\"\n");
+      break;
+    }
+    default: // one enormous backslash run
+      put(d, "[\"");
+      d.insert(d.end(), target + rnd_below(3), '\\');
+      put(d, rnd_below(2) ? "\", 1]" : "\"\", 1]");
+      break;
+    }
+  }
+  if (rnd_below(3) == 0) { d.resize(rnd_below(uint32_t(d.size())) + 1); } // cut anywhere: ends inside strings, escapes, characters
+  return d;
+}
+
+// ---- one "context" ---------------------------------------------------------------------------------------------------------------
+struct workspace {
+  size_t cap = 0;
+  std::vector<uint4> masks;
+  std::vector<seg_summary> summ;
+  std::vector<seg_prefix> pref;
+  std::vector<uint64_t> result_and_desc; // [result (2 words)][descriptors][ticket]
+  std::vector<uint8_t> esc;
+  std::vector<uint32_t> idx;
+  std::vector<uint8_t> out;
+  uint8_t *in = nullptr; // 16-byte aligned copy of the document, nothing readable... (the kernels must not depend on what lies behind len)
+  std::vector<uint8_t> in_store;
+  scan_result_dev *result() { return reinterpret_cast<scan_result_dev *>(result_and_desc.data()); }
+  uint64_t *desc() { return result_and_desc.data() + 2; }
+  void fit(const bytes &doc) {
+    const size_t len = doc.size();
+    if (len > cap) {
+      cap = len * 2 + 65536;
+      const size_t nseg = num_segments(cap);
+      masks.assign(nseg * (SEG_BYTES / BLOCK_BYTES), uint4{0, 0, 0, 0});
+      summ.assign(nseg + num_groups(cap), seg_summary{0, 0, 0, 0});
+      pref.assign(nseg, seg_prefix{0, 0});
+      result_and_desc.assign(2 + num_fused_tiles(cap) * 4 + 8, 0);
+      esc.assign(ESC_TABLE_BYTES, 0);
+      idx.assign(cap + 16, 0);
+      out.assign(cap + 64, 0);
+      in_store.assign(cap + 64, 0);
+    }
+    in = in_store.data() + ((16 - (reinterpret_cast<uintptr_t>(in_store.data()) & 15)) & 15);
+    memcpy(in, doc.data(), len);
+    memset(in + len, 0x5C, 32); // garbage behind the end: backslashes, to catch a read past len
+  }
+};
+
+static unsigned long n_checked = 0, n_failed = 0;
+static void report(const char *what, const bytes &doc, const char *detail) {
+  n_failed++;
+  fprintf(stderr, "MISMATCH %s: len %zu: %s\n", what, doc.size(), detail);
+  if (n_failed <= 3) {
+    static int dumped = 0;
+    char name[64];
+    snprintf(name, sizeof name, "/tmp/emu_fail_%d.bin", dumped++);
+    if (FILE *f = fopen(name, "wb")) { fwrite(doc.data(), 1, doc.size(), f); fclose(f); fprintf(stderr, "  document saved as %s\n", name); }
+  }
+}
+
+struct expected {
+  std::vector<uint32_t> idx;
+  uint32_t n = 0, flags = 0;
+  bytes mini;
+  int mini_err = 0;
+  int utf8_ok = 1;
+};
+static expected oracle(const bytes &doc) {
+  expected e;
+  e.idx.resize(doc.size() + 8);
+  e.n = sjo_scan(doc.data(), doc.size(), e.idx.data(), &e.flags);
+  e.mini.resize(doc.size() + 8);
+  size_t ml = 0;
+  e.mini_err = sjo_minify(doc.data(), doc.size(), e.mini.data(), &ml);
+  e.mini.resize(ml);
+  e.utf8_ok = sjo_validate_utf8(doc.data(), doc.size());
+  return e;
+}
+
+static void check_stage1(const char *what, const bytes &doc, const expected &e, workspace &w) {
+  const scan_result_dev r = *w.result();
+  n_checked++;
+  char detail[256];
+  const uint32_t got_flags = r.flags & 7u;
+  if (r.flags & ~7u) { snprintf(detail, sizeof detail, "flags %#x", r.flags); report(what, doc, detail); return; }
+  if (got_flags != e.flags) { snprintf(detail, sizeof detail, "flags %#x, oracle %#x (n %u / %u)", got_flags, e.flags, r.n, e.n); report(what, doc, detail); return; }
+  if (e.flags & SJGPU_F_UNESCAPED_CTRL) { return; } // the reference returns before anybody looks at the list
+  if (r.n != e.n) {
+    snprintf(detail, sizeof detail, "n %u, oracle %u", r.n, e.n);
+    report(what, doc, detail);
+    if (getenv("SJ_EMU_DOC")) { for (uint32_t i = 0; i < r.n && i < e.n + 1; i++) { if (i >= e.n || w.idx[i] != e.idx[i]) { fprintf(stderr, "  first difference: idx[%u] = %u, oracle %u\n", i, w.idx[i], i < e.n ? e.idx[i] : 0u); break; } } }
+    return;
+  }
+  for (uint32_t i = 0; i < e.n; i++) {
+    if (w.idx[i] != e.idx[i]) { snprintf(detail, sizeof detail, "idx[%u] = %u, oracle %u (n %u)", i, w.idx[i], e.idx[i], e.n); report(what, doc, detail); return; }
+  }
+  const uint32_t L = uint32_t(doc.size());
+  if (w.idx[e.n] != L || w.idx[e.n + 1] != L || w.idx[e.n + 2] != 0) { report(what, doc, "sentinels"); }
+}
+static void check_minify(const char *what, const bytes &doc, const expected &e, workspace &w) {
+  const scan_result_dev r = *w.result();
+  n_checked++;
+  char detail[256];
+  if (r.flags & ~1u) { snprintf(detail, sizeof detail, "flags %#x", r.flags); report(what, doc, detail); return; }
+  const bool unclosed = (r.flags & 1u) != 0;
+  if (unclosed != (e.mini_err != 0)) { snprintf(detail, sizeof detail, "unclosed %d, oracle error %d", int(unclosed), e.mini_err); report(what, doc, detail); return; }
+  if (unclosed) { return; }
+  if (r.out_len != e.mini.size()) { snprintf(detail, sizeof detail, "out_len %llu, oracle %zu", (unsigned long long)r.out_len, e.mini.size()); report(what, doc, detail); return; }
+  if (memcmp(w.out.data(), e.mini.data(), e.mini.size()) != 0) {
+    size_t i = 0;
+    while (w.out[i] == e.mini[i]) { i++; }
+    snprintf(detail, sizeof detail, "byte %zu differs", i);
+    report(what, doc, detail);
+  }
+}
+
+int main(int argc, char **argv) {
+  rng_state = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1;
+  const long docs = argc > 2 ? atol(argv[2]) : 100;
+  const size_t max_kib = argc > 3 ? size_t(atol(argv[3])) : 200;
+  const std::string what = argc > 4 ? argv[4] : "all";
+  const bool all = what == "all";
+  workspace w;
+  size_t total_bytes = 0;
+  for (long k = 0; k < docs; k++) {
+    // mostly a few segments; some documents cross the 1 MiB groups of the resolve step
+    size_t target = 1 + rnd_below(uint32_t(max_kib * 1024));
+    if (rnd_below(4)) { target = 1 + target % (96 * 1024); }
+    if (rnd_below(10) == 0) { target = rnd_below(300); }
+    bytes doc = make_document(target);
+    if (const char *path = getenv("SJ_EMU_DOC")) { // one document from a file (debugging a reported mismatch)
+      doc.clear();
+      if (FILE *f = fopen(path, "rb")) { int c; while ((c = fgetc(f)) != EOF) { doc.push_back(uint8_t(c)); } fclose(f); }
+    }
+    const size_t len = doc.size();
+    total_bytes += len;
+    const expected e = oracle(doc);
+    w.fit(doc);
+    const scan_origin whole{0, 0, 0, nullptr};
+    if (all || what == "split") {
+      scan_origin org = whole;
+      org.esc = w.esc.data();
+      std::fill(w.idx.begin(), w.idx.begin() + len + 8, 0xDEADBEEFu);
+      launch_stage1(w.in, len, w.masks.data(), w.summ.data(), w.pref.data(), w.idx.data(), len + 3, w.result(), org, nullptr, nullptr);
+      check_stage1("split stage 1", doc, e, w);
+      launch_minify(w.in, len, w.summ.data(), w.pref.data(), w.out.data(), w.result(), org, nullptr, nullptr);
+      check_minify("split minify", doc, e, w);
+      launch_validate_utf8(w.in, len, w.result(), nullptr, nullptr);
+      n_checked++;
+      if (((w.result()->flags & SJGPU_F_UTF8_ERROR) == 0) != (e.utf8_ok != 0)) { report("validate_utf8", doc, "verdict"); }
+    }
+    if (all || what == "fused") {
+      for (int large = 0; large < 2; large++) {
+        debug_fused_small_below = large ? 1 : FUSED_SMALL_BELOW; // 1: every document takes the pipelined 64 KiB-tile kernels
+        scan_origin org = whole;
+        org.esc = w.esc.data();
+        std::fill(w.idx.begin(), w.idx.begin() + len + 8, 0xDEADBEEFu);
+        launch_stage1_fused(w.in, len, w.desc(), w.idx.data(), len + 3, w.result(), org, 6, nullptr, nullptr);
+        check_stage1(large ? "pipelined stage 1" : "fused stage 1 (16 KiB tiles)", doc, e, w);
+        launch_minify_fused(w.in, len, w.desc(), w.out.data(), w.result(), org, 6, nullptr, nullptr);
+        check_minify(large ? "on-chip minify" : "fused minify (16 KiB tiles)", doc, e, w);
+      }
+      debug_fused_small_below = FUSED_SMALL_BELOW;
+    }
+    if ((all || what == "docs") && len <= (size_t(1) << 20)) {
+      scan_result_dev r{0, 0, 0};
+      std::fill(w.idx.begin(), w.idx.begin() + len + 8, 0xDEADBEEFu);
+      launch_docs(0, w.in, nullptr, doc_desc{0, 0, uint32_t(len), 0}, 1, w.idx.data(), &r, nullptr);
+      *w.result() = r;
+      check_stage1("one workgroup per document, stage 1", doc, e, w);
+      launch_docs(1, w.in, nullptr, doc_desc{0, 0, uint32_t(len), 0}, 1, w.out.data(), &r, nullptr);
+      *w.result() = r;
+      check_minify("one workgroup per document, minify", doc, e, w);
+    }
+    if ((all || what == "ranges") && len > RANGE_ALIGN) { // consecutive ranges of one buffer, the state between them as run_streamed carries it
+      for (int fused = 0; fused < 2; fused++) {
+        uint32_t cursor = 0, in_string = 0, flags = 0;
+        std::fill(w.idx.begin(), w.idx.begin() + len + 8, 0xDEADBEEFu);
+        for (size_t b = 0; b < len; b += RANGE_ALIGN) {
+          const size_t end = b + RANGE_ALIGN < len ? b + RANGE_ALIGN : len;
+          const bool last = end == len;
+          scan_origin org{uint64_t(b), cursor, (in_string ? CARRY_IN_STRING : 0u) | CARRY_SHARD | (last ? 0u : CARRY_MORE), w.esc.data()};
+          if (fused) { launch_stage1_fused(w.in, end, w.desc(), w.idx.data(), len + 3, w.result(), org, 6, nullptr, nullptr); }
+          else { launch_stage1(w.in, end, w.masks.data(), w.summ.data(), w.pref.data(), w.idx.data(), len + 3, w.result(), org, nullptr, nullptr); }
+          flags |= w.result()->flags & ~1u;
+          cursor = w.result()->n;
+          in_string = w.result()->flags & 1u;
+        }
+        w.result()->flags = flags | in_string;
+        check_stage1(fused ? "ranges, single pass" : "ranges, split", doc, e, w);
+      }
+    }
+    if (all || what == "parity") {
+      launch_string_parity(w.in, len, w.result(), w.esc.data(), nullptr);
+      n_checked++;
+      if ((w.result()->n & 1u) != (e.flags & 1u)) { report("string parity", doc, "parity"); }
+    }
+    if (n_failed > 20) { break; }
+  }
+  printf("%ld documents, %zu bytes: %lu comparisons with the oracle, %lu mismatches\n", docs, total_bytes, n_checked, n_failed);
+  return n_failed ? 1 : 0;
+}

@@ -1,0 +1,41 @@
+"""CPU tier: the gfx950 KERNEL SOURCES of stage 1 / minify / validate_utf8 run on the CPU -- sjgpu_kernels.hip, sjgpu_fused.hip and
+sjgpu_small.hip compiled as C++ against tests/host/emu (a workgroup = an OS thread, a lane = a fiber, wave operations = exchanges
+between the fibers of a wave) -- and every launcher is compared with the oracle on documents that are adversarial for the carries
+between spans (tests/host/test_kernels_emu.cpp).  What the GPU tier has left to prove is what hipcc and the hardware make of the same
+source."""
+import os
+import subprocess
+
+import pytest
+
+from simdjson_amd import _paths
+
+CSRC = os.path.join(_paths.PKG_DIR, "csrc")
+EMU = os.path.join(_paths.REPO_ROOT, "tests", "host", "emu")
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    out = tmp_path_factory.mktemp("emu")
+    inc = ["-I", EMU, "-I", _paths.INCLUDE_DIR, "-I", CSRC, "-I", _paths.ORACLE_DIR]
+    jobs = []
+    for name in ("sjgpu_kernels", "sjgpu_fused", "sjgpu_small"):
+        jobs.append(subprocess.Popen(["g++", "-std=c++17", "-O1", "-Wno-attributes", "-Wno-unknown-pragmas", "-x", "c++", *inc, "-c",
+                                      os.path.join(CSRC, name + ".hip"), "-o", str(out / (name + ".o"))]))
+    jobs.append(subprocess.Popen(["g++", "-std=c++17", "-O2", *inc, "-c", os.path.join(EMU, "sj_emu.cpp"), "-o", str(out / "sj_emu.o")]))
+    jobs.append(subprocess.Popen(["g++", "-std=c++17", "-O2", "-Wno-attributes", *inc, "-c",
+                                  os.path.join(_paths.REPO_ROOT, "tests", "host", "test_kernels_emu.cpp"), "-o", str(out / "driver.o")]))
+    jobs.append(subprocess.Popen(["gcc", "-O2", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-c", os.path.join(_paths.ORACLE_DIR, "sj_oracle.c"),
+                                  "-o", str(out / "sj_oracle.o")]))
+    assert all(j.wait() == 0 for j in jobs)
+    exe = str(out / "test_kernels_emu")
+    objs = [str(out / f) for f in ("sjgpu_kernels.o", "sjgpu_fused.o", "sjgpu_small.o", "sj_emu.o", "driver.o", "sj_oracle.o")]
+    subprocess.run(["g++", *objs, "-lpthread", "-lm", "-o", exe], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("seed,docs,max_kib", [(1, 150, 200), (2026, 150, 200), (7, 10, 2500)])
+def test_kernel_sources_against_the_oracle(emu, seed, docs, max_kib):
+    p = subprocess.run([emu, str(seed), str(docs), str(max_kib), "all"], capture_output=True, timeout=900)
+    assert p.returncode == 0, (p.stdout.decode()[-500:], p.stderr.decode()[-3000:])
+    assert f"{docs} documents" in p.stdout.decode() and " 0 mismatches" in p.stdout.decode()
