@@ -1,0 +1,232 @@
+// tests/host/test_xcarry_model.cpp -- CPU tier: the escape carry inside the scan, as the kernels do it (simdjson_amd/csrc/sj_xcarry.h).
+// The functions under test are the product's own: span_xword (a span's x word from the facts its scan collects), xs_apply (what a
+// summary does to the state in front of it), xs_expand / xs_then / xs_compact (summaries of tiles, groups and ranges).  Around them a
+// byte-level model of the pipeline: every span scans under its assumption, publishes (count if out, count if in, parity, error bits, x
+// word) -- resolved spans (a control character in their first quarter) one final mask and equal counts, like k_stage1_summarize --,
+// spans are folded into groups, the groups are walked serially, every span obtains (s, x, base) and emits with the one patched bit.
+// Checked against the oracle's sequential scan: the offsets, the unclosed-string and control-character flags, the cursor every span
+// was promised (the counts must add up from summaries alone), and that every group summary has the compact form.
+// Span size and look-back are parameters (8 ... 64 bytes / 2 ... 8) so that every corner is frequent; the kernels use 4-16 KiB / 64.
+// Usage: test_xcarry_model <seed> <documents> [sabotage 1-5: break one rule -- the run must fail]
+#include "sj_oracle.h"
+#include "sj_xcarry.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+using namespace sjgpu;
+typedef std::vector<uint8_t> bytes;
+
+static bool is_ws(uint8_t b) { return b == 0x20 || b == 0x09 || b == 0x0A || b == 0x0D; }
+static bool is_op(uint8_t b) { const uint8_t l = b | 0x20; return b < 0x80 && (l == 0x2C || l == 0x3A || l == 0x7B || l == 0x7D); }
+static bool is_scalar(uint8_t b) { return !is_ws(b) && !is_op(b); }
+
+static int sabotage = 0;
+static unsigned long n_b = 0, n_c = 0, n_x = 0, n_flip = 0, n_patch = 0, n_dep = 0, n_resolved_patch = 0, n_groups_x = 0;
+
+struct span {
+  std::vector<uint8_t> cand, tail, ctrl; // under the assumption, relative to "starts outside a string"
+  u32 parity, c_out, c_in, e_out, e_in, xw;
+  bool resolved;
+  u32 derived;
+};
+
+static span scan_span(const bytes &b, size_t S, size_t N, size_t LB) {
+  span g;
+  span_facts f{};
+  f.bytes = u32(N);
+  u32 e = 0, p = 0;
+  if (S > 0) {
+    size_t run = 0;
+    while (run < LB && b[S - 1 - run] == '\\') { run++; }
+    if (run == LB) { f.kind = SPAN_B; e = 0; p = 1; f.lead_open = 1; }
+    else if (b[S - 1] == '"') {
+      size_t r2 = 0;
+      while (r2 < LB - 1 && b[S - 2 - r2] == '\\') { r2++; }
+      if (r2 == LB - 1) { f.kind = SPAN_C; e = 0; p = 0; }
+      else { e = 0; p = u32(r2 & 1); }
+    } else { e = u32(run & 1); p = is_scalar(b[S - 1]); }
+  }
+  g.cand.assign(N, 0); g.tail.assign(N, 0); g.ctrl.assign(N, 0);
+  u32 s = 0;
+  for (size_t i = 0; i < N; i++) {
+    const uint8_t c = b[S + i];
+    if (f.kind == SPAN_B && f.lead_open && c != '\\') { f.lead_open = 0; f.L = u32(i); }
+    const u32 escaped = e;
+    e = escaped ? 0u : u32(c == '\\');
+    const u32 quote = c == '"' && !escaped;
+    s ^= quote;
+    const u32 scalar = is_scalar(c);
+    g.cand[i] = uint8_t(is_op(c) || (scalar && !p));
+    g.tail[i] = uint8_t(s ^ quote);
+    g.ctrl[i] = uint8_t(c <= 0x1F ? 1 : 0);
+    p = scalar && !quote;
+  }
+  // 1: a control character outside a string, 2: inside one (relative view); in_string = tail ^ quote, and a control character is no quote
+  for (size_t i = 0; i < N; i++) { if (g.ctrl[i]) { g.ctrl[i] = uint8_t(1 + g.tail[i]); } }
+  g.parity = s;
+  f.e_end = e;
+  f.p_end = p;
+  if (f.kind == SPAN_B && !f.lead_open) {
+    f.quote_at_L = b[S + f.L] == '"';
+    f.scalar_behind = f.L + 1 < N && is_scalar(b[S + f.L + 1]);
+  }
+  f.scalar_first = is_scalar(b[S]);
+  size_t t = 0;
+  while (t < LB && b[S + N - 1 - t] == '\\') { t++; }
+  f.next_b = t == LB;
+  if (b[S + N - 1] == '"') {
+    size_t q = 0;
+    while (q < LB - 1 && b[S + N - 2 - q] == '\\') { q++; }
+    f.next_c = q == LB - 1;
+  }
+  // resolved: a control character in the first quarter pins the in-string state (k_stage1_summarize looks at its first chunk)
+  g.resolved = false;
+  g.derived = 0;
+  for (size_t i = 0; i < (N + 3) / 4; i++) {
+    if (g.ctrl[i]) { g.resolved = true; g.derived = u32(g.ctrl[i] - 1); break; }
+  }
+  f.resolved = g.resolved;
+  f.derived = g.derived;
+  g.c_out = g.c_in = g.e_out = g.e_in = 0;
+  bool any_a = false, any_b = false;
+  for (size_t i = 0; i < N; i++) {
+    if (g.resolved) {
+      const bool st = g.cand[i] && !(g.tail[i] ^ g.derived);
+      g.c_out += st; g.c_in += st;
+      any_a |= g.ctrl[i] && ((g.ctrl[i] - 1) ^ g.derived);
+    } else {
+      g.c_out += g.cand[i] && !g.tail[i];
+      g.c_in += g.cand[i] && g.tail[i];
+      any_a |= g.ctrl[i] == 2;
+      any_b |= g.ctrl[i] == 1;
+    }
+  }
+  if (g.resolved) { // k_stage1_summarize's rule: carry-in == derived: error iff any_a; else the resolving character is inside a string
+    g.e_out = g.derived ? 1u : u32(any_a);
+    g.e_in = g.derived ? u32(any_a) : 1u;
+  } else {
+    g.e_out = any_a;
+    g.e_in = any_b;
+  }
+  g.xw = span_xword(f);
+  if (sabotage == 1) { g.xw &= ~XW_F; }
+  if (sabotage == 2) { g.xw &= ~(0xFu << XW_D_SHIFT); }
+  if (sabotage == 3) { g.xw &= ~XW_DEP; }
+  if (sabotage == 4) { g.xw &= ~XW_C; }
+  n_b += f.kind == SPAN_B;
+  n_c += f.kind == SPAN_C;
+  n_dep += (g.xw & XW_DEP) != 0;
+  return g;
+}
+
+struct outcome {
+  std::vector<uint32_t> idx;
+  u32 flags;
+};
+static bool segmented(const bytes &doc, size_t len, size_t N, size_t LB, size_t G, outcome &o) {
+  bytes b = doc;
+  while (b.size() % N) { b.push_back(0x20); }
+  const size_t nseg = b.size() / N;
+  std::vector<span> sp(nseg);
+  for (size_t k = 0; k < nseg; k++) { sp[k] = scan_span(b, k * N, N, LB); }
+  // groups
+  const size_t ngroups = (nseg + G - 1) / G;
+  std::vector<xs_summary> gs(ngroups);
+  for (size_t g = 0; g < ngroups; g++) {
+    xs_fun f = xs_identity();
+    for (size_t k = g * G; k < nseg && k < (g + 1) * G; k++) {
+      f = xs_then(f, xs_expand(sp[k].c_out, sp[k].c_in, sp[k].parity, sp[k].xw, sp[k].e_out, sp[k].e_in));
+    }
+    gs[g] = xs_compact(f);
+    if (!gs[g].exact) { fprintf(stderr, "group %zu has no compact form\n", g); return false; }
+    n_groups_x += (gs[g].xw & XW_LOW_MASK) != 0;
+  }
+  u32 s = 0, x = 0, base = 0, err = 0;
+  o.idx.clear();
+  for (size_t g = 0; g < ngroups; g++) {
+    u32 ss = s, xx = x, bb = base, gerr = 0;
+    for (size_t k = g * G; k < nseg && k < (g + 1) * G; k++) {
+      const span &q = sp[k];
+      const xs_step t = xs_apply(q.parity, q.xw, ss, xx);
+      n_x += xx;
+      n_flip += xx && (q.xw & XW_F);
+      const u32 promised = (t.se ? q.c_in : q.c_out) + u32(t.dcount);
+      const size_t before = o.idx.size();
+      const u32 P = xw_patch_pos(q.xw);
+      const bool patch = xx && xw_d(q.xw, t.se) != 0 && sabotage != 5;
+      n_patch += patch;
+      n_resolved_patch += patch && q.resolved;
+      for (size_t i = 0; i < N; i++) {
+        bool st = q.resolved ? (q.cand[i] && !(q.tail[i] ^ q.derived)) : (q.cand[i] && !(q.tail[i] ^ t.se));
+        if (patch && i == P) { st = !st; }
+        if (st && k * N + i < len) { o.idx.push_back(u32(k * N + i)); }
+      }
+      if (o.idx.size() - before != promised) {
+        fprintf(stderr, "span %zu: promised %u structurals, emitted %zu\n", k, promised, o.idx.size() - before);
+        return false;
+      }
+      gerr |= t.se ? q.e_in : q.e_out;
+      bb += promised;
+      ss = t.s_out;
+      xx = t.x_out;
+    }
+    const xs_step t = xs_apply(gs[g].parity, gs[g].xw, s, x);
+    const u32 gcount = (t.se ? gs[g].c_in : gs[g].c_out) + u32(t.dcount);
+    if (t.s_out != ss || t.x_out != xx || base + gcount != bb || (t.se ? gs[g].e_in : gs[g].e_out) != gerr) {
+      fprintf(stderr, "group %zu: summary says (s %u, x %u, +%u), the spans say (s %u, x %u, +%u)\n", g, t.s_out, t.x_out, gcount, ss, xx, bb - base);
+      return false;
+    }
+    s = ss; x = xx; base = bb; err |= gerr;
+  }
+  o.flags = (s ? 1u : 0u) | (err ? 2u : 0u);
+  return true;
+}
+
+int main(int argc, char **argv) {
+  uint64_t seed = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1;
+  const long docs = argc > 2 ? atol(argv[2]) : 200000;
+  sabotage = argc > 3 ? atoi(argv[3]) : 0;
+  auto rnd = [&]() { seed = seed * 6364136223846793005ull + 1442695040888963407ull; return uint32_t(seed >> 33); };
+  const char alphabet[] = "\\\\\\\\\\\\\\\"\"\"a1 ,{}[]:\n\x01";
+  for (long d = 0; d < docs; d++) {
+    const size_t N = size_t(8) << (rnd() % 4);
+    size_t LB = size_t(2) << (rnd() % 3);
+    if (LB > N) { LB = N; }
+    const size_t Gs[] = {1, 2, 4, 64};
+    const size_t G = Gs[rnd() % 4];
+    const size_t len = 1 + rnd() % (N * 12);
+    bytes doc(len);
+    const uint32_t ctrl_every = rnd() % 3; // documents without control characters keep their spans unresolved
+    for (size_t i = 0; i < len;) {
+      if (rnd() % 3 == 0) {
+        size_t run = 1 + rnd() % (2 * N + 3);
+        while (run-- && i < len) { doc[i++] = '\\'; }
+      } else {
+        uint8_t c = uint8_t(alphabet[rnd() % (sizeof alphabet - 1)]);
+        if (c < 0x20 && ctrl_every == 0) { c = 'b'; }
+        doc[i++] = c;
+      }
+    }
+    std::vector<uint32_t> want(len + 8);
+    uint32_t wflags = 0;
+    const uint32_t wn = sjo_scan(doc.data(), len, want.data(), &wflags);
+    want.resize(wn);
+    outcome got;
+    if (!segmented(doc, len, N, LB, G, got)) { return 3; }
+    // the reference raises UNESCAPED_CHARS and then nobody looks at the indexes: compare them only for documents without that error
+    const bool same_flags = (got.flags & 3u) == (wflags & 3u);
+    if (!same_flags || (!(wflags & 2u) && got.idx != want)) {
+      fprintf(stderr, "N %zu LB %zu G %zu len %zu: %zu structurals flags %u, the sequential scan has %zu flags %u\n", N, LB, G, len, got.idx.size(), got.flags,
+              want.size(), wflags & 3u);
+      for (size_t i = 0; i < len; i++) { fputc(doc[i] == '\n' ? '/' : (doc[i] < 0x20 ? '^' : doc[i]), stderr); }
+      fputc('\n', stderr);
+      return 1;
+    }
+  }
+  printf("%ld documents: spans that assume, summaries that carry x, one patched bit -- the sequential scan (kind B %lu, kind C %lu spans; x = 1 at %lu spans, "
+         "flips %lu, patched bits %lu, of resolved spans %lu, carry-dependent successors %lu, groups with x words %lu)\n", docs, n_b, n_c, n_x, n_flip, n_patch,
+         n_resolved_patch, n_dep, n_groups_x);
+  return 0;
+}
