@@ -57,6 +57,8 @@ enum sjgpu_stage1_mode {
 #define SJGPU_F_UTF8_ERROR      4u /* not well-formed UTF-8 */
 #define SJGPU_F_IDX_OVERFLOW    8u /* index buffer too small; indices beyond it were dropped */
 #define SJGPU_F_INTERNAL        16u /* single-pass pipeline gave up (bounded spin expired); result invalid */
+#define SJGPU_F_RANGE_CARRY     32u /* ranges only (`more` set): the backslash run that ends this range makes the next range's first byte
+                                       escaped (or its leading quote's predecessor): hand it on with the in-string bit, see sjgpu_stage1_range_device */
 
 typedef struct sjgpu_ctx sjgpu_ctx;
 
@@ -331,7 +333,10 @@ int sjgpu_comm_gather_indices(sjgpu_comm *comm, const void *idx_dev, uint32_t n,
  * Scans bytes [begin, end) of buf_dev; bytes [0, begin) must already be resident (escapes, the previous-scalar bit
  * and UTF-8 state are read from them), bytes beyond end need not be.  begin is a multiple of 1 MiB.  `more` != 0:
  * more ranges follow (no end-of-input checks).  in_string and n_before / out_before come from sjgpu_result() of
- * the previous range: (flags & SJGPU_F_UNCLOSED_STRING), n / out_len -- 0, 0 for the first range.  Offsets stay
+ * the previous range: (flags & (SJGPU_F_UNCLOSED_STRING | SJGPU_F_RANGE_CARRY)), n / out_len -- 0, 0 for the first range
+ * (bit 0 of in_string: the range begins inside a string; SJGPU_F_RANGE_CARRY: it begins behind a backslash run of 64 bytes or
+ * more whose parity the previous range knows -- /root/reference/src/generic/stage1/json_escape_scanner.h:50-71's one carried
+ * bit, handed from call to call).  Offsets stay
  * relative to byte 0 and are appended at idx_dev[n_before...]; result.n / out_len are running totals.
  * sjgpu_stage1() and sjgpu_minify() drive exactly this for host buffers of 64 MiB and more (env
  * SJGPU_STREAM_FROM_MB / SJGPU_STREAM_CHUNK_MB), with the device-to-host copies on a second thread. */

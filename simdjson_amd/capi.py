@@ -18,7 +18,7 @@ from . import _paths
 SUCCESS, CAPACITY, MEMALLOC, UTF8_ERROR, EMPTY, UNESCAPED_CHARS, UNCLOSED_STRING, UNEXPECTED_ERROR = 0, 1, 2, 11, 13, 14, 15, 24
 # simdjson::stage1_mode (internal/dom_parser_implementation.h:22-27)
 REGULAR, STREAMING_PARTIAL, STREAMING_FINAL, JSON_SEQUENCE_PARTIAL, JSON_SEQUENCE_FINAL, COMMA_DELIMITED_PARTIAL, COMMA_DELIMITED_FINAL = range(7)
-F_UNCLOSED_STRING, F_UNESCAPED_CTRL, F_UTF8_ERROR, F_IDX_OVERFLOW, F_INTERNAL = 1, 2, 4, 8, 16
+F_UNCLOSED_STRING, F_UNESCAPED_CTRL, F_UTF8_ERROR, F_IDX_OVERFLOW, F_INTERNAL, F_RANGE_CARRY = 1, 2, 4, 8, 16, 32
 
 EXPORTS = [
     "sjgpu_device_count", "sjgpu_ctx_create", "sjgpu_ctx_destroy", "sjgpu_set_capacity", "sjgpu_capacity",

@@ -68,6 +68,9 @@ struct xs_fun {
 // summary: counts c[2] (by effective hypothesis), parity, xw, error bits e[2] (by effective hypothesis)
 SJ_HD xs_fun xs_expand(u32 c_out, u32 c_in, u32 parity, u32 xw, u32 e_out, u32 e_in) {
   xs_fun f;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
   for (u32 i = 0; i < 4; i++) {
     const xs_step t = xs_apply(parity, xw, i & 1u, i >> 1);
     f.cnt[i] = (t.se ? c_in : c_out) + u32(t.dcount);
@@ -77,20 +80,28 @@ SJ_HD xs_fun xs_expand(u32 c_out, u32 c_in, u32 parity, u32 xw, u32 e_out, u32 e
   }
   return f;
 }
+// (selects, not indexed loads: on the device these arrays must stay in registers)
+SJ_HD u32 xs_pick(const u32 (&a)[4], u32 j) { return j == 0u ? a[0] : (j == 1u ? a[1] : (j == 2u ? a[2] : a[3])); }
 // first a, then b
 SJ_HD xs_fun xs_then(const xs_fun &a, const xs_fun &b) {
   xs_fun r;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
   for (u32 i = 0; i < 4; i++) {
     const u32 j = a.s_out[i] | (a.x_out[i] << 1);
-    r.cnt[i] = a.cnt[i] + b.cnt[j];
-    r.s_out[i] = b.s_out[j];
-    r.x_out[i] = b.x_out[j];
-    r.err[i] = a.err[i] | b.err[j];
+    r.cnt[i] = a.cnt[i] + xs_pick(b.cnt, j);
+    r.s_out[i] = xs_pick(b.s_out, j);
+    r.x_out[i] = xs_pick(b.x_out, j);
+    r.err[i] = a.err[i] | xs_pick(b.err, j);
   }
   return r;
 }
 SJ_HD xs_fun xs_identity() {
   xs_fun f;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
   for (u32 i = 0; i < 4; i++) { f.cnt[i] = 0; f.s_out[i] = i & 1u; f.x_out[i] = i >> 1; f.err[i] = 0; }
   return f;
 }
@@ -108,11 +119,11 @@ SJ_HD xs_summary xs_compact(const xs_fun &f) {
   const u32 F = f.s_out[0] ^ f.s_out[2];
   const u32 c = f.x_out[0], dep = f.x_out[0] ^ f.x_out[2];
   // x = 1, s: effective hypothesis s ^ F, count = c[s ^ F] + d[s ^ F]
-  const int d0 = int(f.cnt[2 | F]) - int(r.c_out); // effective hypothesis 0 is reached from s = F
-  const int d1 = int(f.cnt[2 | (1u ^ F)]) - int(r.c_in);
+  const int d0 = int(F ? f.cnt[3] : f.cnt[2]) - int(r.c_out); // effective hypothesis 0 is reached from s = F
+  const int d1 = int(F ? f.cnt[2] : f.cnt[3]) - int(r.c_in);
   r.xw = c | (dep << 1) | (F << 2) | xw_enc_d(d0, d1);
   r.exact = d0 >= -1 && d0 <= 1 && d1 >= -1 && d1 <= 1 && f.s_out[1] == (f.s_out[0] ^ 1u) && f.s_out[3] == (f.s_out[2] ^ 1u) &&
-            f.x_out[1] == f.x_out[0] && f.x_out[3] == f.x_out[2] && f.err[2 | F] == r.e_out && f.err[2 | (1u ^ F)] == r.e_in;
+            f.x_out[1] == f.x_out[0] && f.x_out[3] == f.x_out[2] && (F ? f.err[3] : f.err[2]) == r.e_out && (F ? f.err[2] : f.err[3]) == r.e_in;
   return r;
 }
 

@@ -335,11 +335,8 @@ bool use_fused(const sjgpu_ctx *ctx, size_t len, int op = 1) { // op 0: stage 1,
 }
 
 // `len` is the END of the scan (bytes [org.begin, len) are scanned); a whole document has org = {0, 0, 0}
-// Every scan is handed the context's escape-table workspace; the launchers fill and use it for scans beyond the
-// small-tile limit (launch_escape_table, sjgpu_kernels.hip) and ignore it below.
 void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint32_t *idx, size_t idx_words, hipStream_t s,
                     hipEvent_t *ev, scan_origin org = scan_origin{0, 0, 0}) {
-  org.esc = ctx->esc_tab;
   ctx->enqueue_rc = ensure_scan_workspace(ctx, len - org.begin, !fused);
   if (ctx->enqueue_rc) { return; }
   ctx->last_pipeline = fused ? 1 : 0;
@@ -352,7 +349,6 @@ void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, 
 }
 void enqueue_minify(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint8_t *dst, hipStream_t s, hipEvent_t *ev,
                     scan_origin org = scan_origin{0, 0, 0}) {
-  org.esc = ctx->esc_tab;
   ctx->enqueue_rc = ensure_scan_workspace(ctx, len - org.begin, !fused);
   if (ctx->enqueue_rc) { return; }
   ctx->last_pipeline = fused ? 1 : 0;
@@ -416,7 +412,7 @@ int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *o
     ctx->up[k % ctx->up.size()]->submit(ctx->d_in + b, buf + b, e - b, ctx->ev_in[k]);
   }
   hipError_t he = hipSuccess;
-  uint32_t flags = 0, in_string = carry_in & CARRY_IN_STRING;
+  uint32_t flags = 0, in_string = carry_in & CARRY_IN_STRING, x_carry = 0; // x_carry: SJGPU_F_RANGE_CARRY of the range in front
   uint64_t cursor = 0; // output units produced by the ranges so far
   const bool debug = std::getenv("SJGPU_DEBUG_STREAM") != nullptr;
   double wait_upload_s = 0.0, wait_scan_s = 0.0;
@@ -425,7 +421,7 @@ int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *o
   for (size_t k = 0; k < nranges && he == hipSuccess && rc == 0; k++) {
     const size_t b = k * chunk, e = (b + chunk < len) ? b + chunk : len;
     const bool last = (k + 1 == nranges);
-    const scan_origin org{uint64_t(b), uint32_t(cursor), (in_string ? CARRY_IN_STRING : 0u) | CARRY_SHARD | (last ? 0u : CARRY_MORE)};
+    const scan_origin org{uint64_t(b), uint32_t(cursor), (in_string ? CARRY_IN_STRING : 0u) | (x_carry ? CARRY_X : 0u) | CARRY_SHARD | (last ? 0u : CARRY_MORE)};
     // the event of range k has been recorded (an unrecorded event would not be waited for): it is job k / T of thread k % T
     const auto tw0 = std::chrono::steady_clock::now();
     he = ctx->up[k % ctx->up.size()]->wait_finished(k / ctx->up.size() + 1);
@@ -450,7 +446,7 @@ int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *o
     }
     wait_scan_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw1).count();
     if (he != hipSuccess || rc) { break; }
-    flags |= res.flags & ~uint32_t(SJGPU_F_UNCLOSED_STRING);
+    flags |= res.flags & ~uint32_t(SJGPU_F_UNCLOSED_STRING | SJGPU_F_RANGE_CARRY);
     if (res.flags & (SJGPU_F_INTERNAL | SJGPU_F_IDX_OVERFLOW)) { break; }
     const uint64_t now = (op == 0) ? uint64_t(res.n) : res.out_len;
     const uint64_t upto = now + ((op == 0 && last) ? 3 : 0); // the sentinels travel with the last range
@@ -461,6 +457,7 @@ int run_streamed(sjgpu_ctx *ctx, int op, const uint8_t *buf, size_t len, void *o
     }
     cursor = now;
     in_string = res.flags & SJGPU_F_UNCLOSED_STRING;
+    x_carry = res.flags & SJGPU_F_RANGE_CARRY;
   }
   // nothing may be left in flight when we return: the caller owns buf and out_host
   const auto t_loop = std::chrono::steady_clock::now();
@@ -818,7 +815,7 @@ int sjgpu_stage1_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin,
   if (bad) { return bad; }
   if (!idx_dev || (reinterpret_cast<uintptr_t>(idx_dev) & 15u)) { return SJGPU_E_BADARG; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
-  const scan_origin org{uint64_t(begin), n_before, CARRY_SHARD | (in_string ? CARRY_IN_STRING : 0u) | (more ? CARRY_MORE : 0u)};
+  const scan_origin org{uint64_t(begin), n_before, CARRY_SHARD | ((in_string & 1) ? CARRY_IN_STRING : 0u) | ((in_string & int(SJGPU_F_RANGE_CARRY)) ? CARRY_X : 0u) | (more ? CARRY_MORE : 0u)};
   enqueue_stage1(ctx, use_fused(ctx, end - begin, 0), static_cast<const uint8_t *>(buf_dev), end, static_cast<uint32_t *>(idx_dev), idx_words,
                  pick(ctx, stream), next_events(ctx), org);
   SJ_ENQUEUED(ctx);
@@ -831,7 +828,7 @@ int sjgpu_minify_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin,
   if (bad) { return bad; }
   if (!dst_dev || (reinterpret_cast<uintptr_t>(dst_dev) & 15u)) { return SJGPU_E_BADARG; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
-  const scan_origin org{uint64_t(begin), out_before, CARRY_SHARD | (in_string ? CARRY_IN_STRING : 0u) | (more ? CARRY_MORE : 0u)};
+  const scan_origin org{uint64_t(begin), out_before, CARRY_SHARD | ((in_string & 1) ? CARRY_IN_STRING : 0u) | ((in_string & int(SJGPU_F_RANGE_CARRY)) ? CARRY_X : 0u) | (more ? CARRY_MORE : 0u)};
   enqueue_minify(ctx, use_fused(ctx, end - begin), static_cast<const uint8_t *>(buf_dev), end, static_cast<uint8_t *>(dst_dev),
                  pick(ctx, stream), next_events(ctx), org);
   SJ_ENQUEUED(ctx);
@@ -878,7 +875,7 @@ int sjgpu_debug_trace_pipelined(sjgpu_ctx *ctx, const void *buf_dev, size_t len,
   SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&d_trace), bytes));
   (void)hipMemset(d_trace, 0, bytes);
   *workgroups_out = launch_stage1_pipelined_traced(static_cast<const uint8_t *>(buf_dev), len, ctx->desc, static_cast<uint32_t *>(idx_dev), idx_words,
-                                                  ctx->d_result, ctx->esc_tab, ctx->max_workgroups, nullptr, d_trace, max_records);
+                                                  ctx->d_result, ctx->max_workgroups, nullptr, d_trace, max_records);
   hipError_t e = hipDeviceSynchronize();
   if (e == hipSuccess) { e = hipMemcpy(trace_host, d_trace, bytes, hipMemcpyDeviceToHost); }
   (void)hipFree(d_trace);

@@ -8,6 +8,7 @@
 #include "sjgpu.h"
 #include "sjgpu_internal.h"
 #include "sj_block.h"
+#include "sj_xcarry.h"
 
 namespace sjgpu {
 namespace {
@@ -198,6 +199,125 @@ __device__ __forceinline__ wave_carry segment_carry_from(const u8 *__restrict__ 
 __device__ __forceinline__ wave_carry segment_carry_in(const u8 *__restrict__ buf, u64 start, u32 lane, esc_ref esc) {
   return segment_carry_from(buf, start, lane, lookback_issue(buf, start, lane), esc);
 }
+
+// ---- spans that ASSUME (sj_xcarry.h): the carry-in of a span without table and without walk ----------------------------------
+// Every tile kernel (split and single-pass pipelines) derives a span's carries from the 64 bytes in front of it and nothing else.
+// Two look-backs leave a question open -- 64 backslashes (kind B: is my first byte escaped?), a quote behind 63 backslashes (kind C:
+// is that quote escaped?); the span then assumes "no", scans, and publishes an x word with its summary from which the resolve
+// step (k_resolve_groups / k_resolve_segments, the look-back of the single-pass kernels) learns whether the assumption held and
+// what to repair if not: the other in-string hypothesis, one candidate bit.  All of it is wave-uniform (scalar registers).
+// (one word, so that it costs the kernels one scalar register across their chunk loops: they have none to spare)
+struct span_x {
+  u32 bits; // [1:0] kind (SPAN_EXACT / SPAN_B / SPAN_C); [2] kind B: everything scanned so far is backslashes; [3] / [4]: the span's last 64 bytes
+            // ask kind B / C of its successor (span_note_chunk on the last chunk); [31:8] kind B: length L of the leading run once it has ended
+  __device__ __forceinline__ u32 kind() const { return bits & 3u; }
+  __device__ __forceinline__ u32 lead_open() const { return (bits >> 2) & 1u; }
+  __device__ __forceinline__ u32 next_b() const { return (bits >> 3) & 1u; }
+  __device__ __forceinline__ u32 next_c() const { return (bits >> 4) & 1u; }
+  __device__ __forceinline__ u32 L() const { return bits >> 8; }
+};
+constexpr u32 SX_LEAD_OPEN = 4u, SX_NEXT_B = 8u, SX_NEXT_C = 16u;
+__device__ __forceinline__ bool byte_is_scalar(u32 b) {
+  const bool ws = b == 0x20u || b == 0x09u || b == 0x0Au || b == 0x0Du;
+  const u32 cur = b | 0x20u;
+  const bool op = b < 0x80u && (cur == 0x2Cu || cur == 0x3Au || cur == 0x7Bu || cur == 0x7Du);
+  return !(ws || op);
+}
+// byte = lookback_issue(buf, start, lane); start is 0 or a multiple of the chunk size
+__device__ __forceinline__ wave_carry span_carry_assume(u64 start, u32 lane, u32 byte, span_x &sx) {
+  wave_carry c{0u, 0u, 0u};
+  sx.bits = SPAN_EXACT;
+  if (start == 0) { return c; }
+  const u32 b1 = readlane(byte, 0);
+  const u64 m = __ballot(byte == 0x5Cu);
+  if (m == ~0ull) { // kind B: assume the run in front is even
+    sx.bits = SPAN_B | SX_LEAD_OPEN;
+    c.p = 1u; // a backslash is a scalar
+    return c;
+  }
+  c.e = ctz64(~m) & 1u;
+  if (b1 == 0x22u) {
+    const u64 inv = ~(m >> 1) & (~0ull >> 1); // bit i clear <=> byte start-2-i is a backslash
+    if (inv) { c.p = ctz64(inv) & 1u; }        // an escaped quote is a non-quote scalar
+    else { sx.bits = SPAN_C; }                 // assume the quote is real: c.p = 0
+  } else {
+    c.p = byte_is_scalar(b1) ? 1u : 0u;
+  }
+  return c;
+}
+// per chunk, after its bytes are in w: the leading run of a kind-B span, and on the span's last chunk what the last 64 bytes are.
+// Costs nothing but a scalar test on the chunks of ordinary spans that are not their last.
+__device__ __forceinline__ void span_note_chunk(span_x &sx, const u32 (&w)[16], u32 chunk_off, bool last_chunk, u32 lane) {
+  if (!((sx.bits & SX_LEAD_OPEN) != 0u || last_chunk)) { return; } // wave-uniform
+  u32 acc = 0;
+#pragma unroll
+  for (int j = 0; j < 15; j++) { acc |= w[j] ^ 0x5C5C5C5Cu; }
+  const u32 lastx = w[15] ^ 0x5C5C5C5Cu;
+  if (sx.bits & SX_LEAD_OPEN) {
+    const u64 other = __ballot((acc | lastx) != 0u);
+    if (other) {
+      const u32 fl = ctz64(other);
+      u32 pos = 0;
+#pragma unroll
+      for (int j = 15; j >= 0; j--) { // the lowest dword that holds something else wins
+        const u32 x = w[j] ^ 0x5C5C5C5Cu;
+        if (x) { pos = 4u * u32(j) + (u32(__ffs(int(x)) - 1) >> 3); }
+      }
+      sx.bits = (sx.bits & ~SX_LEAD_OPEN) | ((chunk_off + fl * BLOCK_BYTES + readlane_dyn(pos, fl)) << 8);
+    }
+  }
+  if (last_chunk) {
+    const u32 a63 = readlane(acc, 63), l63 = readlane(lastx, 63);
+    if ((a63 | l63) == 0u) { sx.bits |= SX_NEXT_B; }
+    if (a63 == 0u && l63 == (0x225C5C5Cu ^ 0x5C5C5C5Cu)) { sx.bits |= SX_NEXT_C; }
+  }
+}
+// behind the span's last chunk: its x word.  span_bytes = the span's nominal size; scalars: the scan tracks the previous-scalar bit
+// (stage 1; minify neither has nor needs kind C and the patched bit); resolved / derived: k_stage1_summarize's pinned segments.
+__device__ __forceinline__ u32 span_finish(const span_x &sx, const u8 *__restrict__ buf, u64 start, u32 span_bytes, u64 len, const wave_carry &wc,
+                                           bool scalars, bool resolved = false, u32 derived = 0) {
+  if ((sx.bits & (3u | SX_NEXT_B | SX_NEXT_C)) == 0u) { return 0u; } // wave-uniform; nearly every span of ordinary input
+  span_facts f;
+  f.kind = sx.kind();
+  f.bytes = span_bytes;
+  f.lead_open = sx.lead_open();
+  f.L = sx.L();
+  f.quote_at_L = 0u; f.scalar_behind = 0u; f.scalar_first = 0u;
+  f.next_b = sx.next_b();
+  f.next_c = scalars ? sx.next_c() : 0u;
+  f.e_end = wc.e;
+  f.p_end = scalars ? wc.p : 0u;
+  f.resolved = resolved ? 1u : 0u;
+  f.derived = derived;
+  if (f.kind == SPAN_B && !f.lead_open) {
+    const u64 at = start + f.L; // bytes at or beyond len read as spaces
+    f.quote_at_L = (at < len && buf[at] == 0x22u) ? 1u : 0u;
+    if (scalars && f.quote_at_L && f.L + 1u < span_bytes) { f.scalar_behind = (at + 1 < len && byte_is_scalar(buf[at + 1])) ? 1u : 0u; }
+  } else if (f.kind == SPAN_C && scalars) {
+    f.scalar_first = (start < len && byte_is_scalar(buf[start])) ? 1u : 0u;
+  } else if (f.kind == SPAN_C) {
+    f.kind = SPAN_EXACT;
+  }
+#ifdef SJGPU_SELFTEST_NO_XW // tests/test_kernels_emu.py: with a part of the x words dropped (1 all, 2 the patched bit, 3 dep, 4 F) the adversarial documents must FAIL
+  return span_xword(f) & ~(SJGPU_SELFTEST_NO_XW == 1 ? ~0u : (SJGPU_SELFTEST_NO_XW == 2 ? (0xFu << XW_D_SHIFT) : (SJGPU_SELFTEST_NO_XW == 3 ? XW_DEP : XW_F)));
+#endif
+  return span_xword(f);
+}
+// x = 1 and the effective hypothesis is the one the patch counts under: toggle the candidate bit of span-relative byte P.
+// st[c] = the lane's structural bits of chunk c of the span (final: strings already masked out -- which is why d says when)
+template <u32 NCH>
+__device__ __forceinline__ void span_patch(u64 (&st)[NCH], u32 xw, u32 x, u32 se, u32 lane) {
+  if (x && xw_d(xw, se) != 0) { // wave-uniform
+    const u32 P = xw_patch_pos(xw);
+    const u32 pc = P / CHUNK_BYTES, pl = (P / BLOCK_BYTES) & 63u;
+#pragma unroll
+    for (u32 c = 0; c < NCH; c++) {
+      if (c == pc && lane == pl) { st[c] ^= 1ull << (P & 63u); }
+    }
+  }
+}
+// the count a summary promises under the state in front of it
+__device__ __forceinline__ u32 xs_count(u32 c_out, u32 c_in, const xs_step &t) { return (t.se ? c_in : c_out) + u32(t.dcount); }
 
 // ---- one chunk (64 blocks) through the scanner -----------------------------------------------------------
 struct chunk_masks {

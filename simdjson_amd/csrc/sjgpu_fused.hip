@@ -6,8 +6,10 @@
 // count for BOTH in-string hypotheses) as soon as it has scanned its bytes, then walks back over its
 // predecessors' descriptors until it meets one that already knows its INCLUSIVE prefix, composes, and
 // publishes its own inclusive prefix.  Everything else the reference carries from block to block
-// (escape parity, previous-scalar, UTF-8 look-back) is position-wise and is re-derived from the bytes in
-// front of each wave's span (sjgpu_device.h: segment_carry_in).
+// (escape parity, previous-scalar, UTF-8 look-back) is position-wise and is re-derived from the 64 bytes in
+// front of each wave's span; where those do not settle it (64 backslashes, a quote behind 63) the span assumes,
+// and one more bit -- x, "the assumption of the next tile's first span is wrong" -- travels with the in-string bit
+// through the same descriptors (sj_xcarry.h; sjgpu_device.h: span_carry_assume).
 //
 // MI355X specifics:
 //   * tile = 64 KiB = one 256-thread workgroup = 4 waves x 4 chunks.  Tiles must be big: descriptors live
@@ -35,34 +37,39 @@ constexpr u64 LOOKBACK_TIMEOUT_TICKS = 100ull * 1000 * 1000;                    
 
 // ---- descriptor encoding (one u64 per tile) -------------------------------------------------------------
 //   [63:62] status   0 invalid | 1 aggregate | 2 inclusive | 3 poison
-//   aggregate: [42] quote parity, [41:21] count if the tile starts inside a string, [20:0] count if outside
-//   inclusive: [32] in-string after the tile, [31:0] output cursor after the tile
+//   aggregate: [49:43] the tile's x word (sj_xcarry.h, XW_LOW_BITS), [42] quote parity, [41:21] count if the tile starts inside a
+//              string, [20:0] count if outside
+//   inclusive: [33] x in front of the next tile, [32] in-string after the tile, [31:0] output cursor after the tile
 constexpr u64 ST_AGG = 1, ST_INCL = 2, ST_POISON = 3;
-__device__ __forceinline__ u64 make_agg(u32 q, u32 c_out, u32 c_in) {
-  return (ST_AGG << 62) | (u64(q & 1u) << 42) | (u64(c_in) << 21) | u64(c_out);
+constexpr u32 DESC_XW_SHIFT = 43;
+__device__ __forceinline__ u64 make_agg(u32 q, u32 c_out, u32 c_in, u32 xw) {
+  return (ST_AGG << 62) | (u64(xw & XW_LOW_MASK) << DESC_XW_SHIFT) | (u64(q & 1u) << 42) | (u64(c_in) << 21) | u64(c_out);
 }
-__device__ __forceinline__ u64 make_incl(u32 s, u32 base) { return (ST_INCL << 62) | (u64(s & 1u) << 32) | u64(base); }
+__device__ __forceinline__ u64 make_incl(u32 s, u32 x, u32 base) { return (ST_INCL << 62) | (u64(x & 1u) << 33) | (u64(s & 1u) << 32) | u64(base); }
 
 __device__ __forceinline__ u64 desc_load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void desc_store(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Wave-wide look-back for tile `tile` (all 64 lanes of ONE wave call this).  On success S = in-string at
-// the tile start, B = output cursor at the tile start.
+// the tile start, X = x in front of the tile, B = output cursor at the tile start.
 // State of a walk: F = composition of the aggregates of tiles [end, tile): maps the state at `end` to
-// (parity flip, count).
+// (parity flip, count).  Aggregates whose x word is zero -- all of them, for ordinary input -- compose as they always did; the
+// first one that is not sends the walk to lookback_slow.
 struct lookback_state {
-  u32 fq, fout, fin;
-  long long end;
+  u32 fq, fout, fin, n;
+  int end; // tile numbers fit 32 bits (4 GiB / 32 KiB tiles)
 };
-__device__ __forceinline__ void lookback_load(const u64 *desc, long long end, u32 lane, u64 (&d)[LOOKBACK_LOADS], scan_origin org) {
+__device__ __forceinline__ void lookback_load(const u64 *desc, int end, u32 lane, u64 (&d)[LOOKBACK_LOADS], scan_origin org) {
 #pragma unroll
   for (u32 w = 0; w < LOOKBACK_LOADS; w++) {
-    const long long t = end - 1 - (long long)(w * 64 + lane);
-    d[w] = (t >= 0) ? desc_load(desc + t) : make_incl(org.carry & CARRY_IN_STRING, org.base0); // in front of tile 0: the call's carry-in and cursor
+    const int t = end - 1 - int(w * 64 + lane);
+    // in front of tile 0: the call's carry-in and cursor
+    d[w] = (t >= 0) ? desc_load(desc + t) : make_incl(org.carry & CARRY_IN_STRING, (org.carry & CARRY_X) ? 1u : 0u, org.base0);
   }
 }
-// 1 = finished (S, B valid), 0 = a needed aggregate is not published yet (reload from st.end), -1 = poisoned chain
-__device__ __forceinline__ int lookback_consume(const u64 (&d)[LOOKBACK_LOADS], lookback_state &st, u32 lane, u32 &S, u32 &B) {
+// 1 = finished (S, X, B valid), 0 = a needed aggregate is not published yet (reload from st.end), -1 = poisoned chain,
+// 2 = an aggregate with an x word: lookback_slow
+__device__ __forceinline__ int lookback_consume(const u64 (&d)[LOOKBACK_LOADS], lookback_state &st, u32 lane, u32 &S, u32 &X, u32 &B) {
 #pragma unroll
   for (u32 w = 0; w < LOOKBACK_LOADS; w++) {
     const u32 status = u32(d[w] >> 62);
@@ -74,6 +81,7 @@ __device__ __forceinline__ int lookback_consume(const u64 (&d)[LOOKBACK_LOADS], 
     if (~valid & below) { return 0; }
     // G = composition of the aggregates on lanes k-1 ... 0 (ascending tile order)
     const bool mine = lane < k;
+    if (__ballot(mine && (u32(d[w] >> DESC_XW_SHIFT) & XW_LOW_MASK) != 0u)) { return 2; }
     const u32 q = mine ? u32(d[w] >> 42) & 1u : 0u;
     const u32 c_out = mine ? u32(d[w]) & 0x1FFFFFu : 0u;
     const u32 c_in = mine ? u32(d[w] >> 21) & 0x1FFFFFu : 0u;
@@ -89,10 +97,12 @@ __device__ __forceinline__ int lookback_consume(const u64 (&d)[LOOKBACK_LOADS], 
     st.fout = nf_out;
     st.fin = nf_in;
     st.fq ^= gq;
+    st.n += k < 64u ? k : 64u;
     if (k < 64u) {
       const u32 lo = readlane_dyn(u32(d[w]), k), hi = readlane_dyn(u32(d[w] >> 32), k);
       const u32 s_k = hi & 1u;
       S = s_k ^ st.fq;
+      X = st.n ? 0u : ((hi >> 1) & 1u); // an aggregate without an x word answers "no" for its successor
       B = lo + (s_k ? st.fin : st.fout);
       return 1;
     }
@@ -100,22 +110,133 @@ __device__ __forceinline__ int lookback_consume(const u64 (&d)[LOOKBACK_LOADS], 
   }
   return 0; // whole batch consumed, no inclusive prefix yet: keep walking from st.end
 }
-// `preloaded`: descriptors already requested with lookback_load(desc, tile, ...) some time ago (may be null)
-__device__ __forceinline__ bool lookback(const u64 *desc, u32 tile, u32 lane, u32 &S, u32 &B, scan_origin org,
-                                         const u64 (*preloaded)[LOOKBACK_LOADS] = nullptr) {
-  lookback_state st{0u, 0u, 0u, (long long)tile};
-  if (preloaded) {
-    const int r = lookback_consume(*preloaded, st, lane, S, B);
-    if (r != 0) { return r > 0; }
+// The look-back when x words are about (documents with backslash runs of 64 bytes and more across span boundaries): find the nearest
+// inclusive predecessor, waiting until everything nearer is published, then walk FORWARD from it with the state in hand, one
+// descriptor per step (xs_apply) -- no composition of unknown-state functions, and only documents that need it pay for it.
+__device__ __forceinline__ bool lookback_slow(const u64 *desc, u32 tile, u32 lane, u32 &S, u32 &X, u32 &B, scan_origin org) {
+  const u64 t_start = wall_clock64();
+  int end = int(tile), from = -1;
+  u32 s = org.carry & CARRY_IN_STRING, x = (org.carry & CARRY_X) ? 1u : 0u, base = org.base0; // the state in front of tile 0
+  for (;;) { // phase 1
+    const int t = end - 1 - int(lane);
+    const u64 d = (t >= 0) ? desc_load(desc + t) : make_incl(s, x, base);
+    const u32 status = u32(d >> 62);
+    const u64 incl = __ballot(status == ST_INCL), valid = __ballot(status != 0), poison = __ballot(status == ST_POISON);
+    const u32 k = incl ? ctz64(incl) : 64u;
+    const u64 below = (k == 64u) ? ~0ull : ((1ull << k) - 1ull);
+    const u64 upto = (k == 64u) ? ~0ull : (below | (1ull << k));
+    if (poison & upto) { return false; }
+    if (~valid & below) {
+      if (wall_clock64() - t_start > LOOKBACK_TIMEOUT_TICKS) { return false; }
+      __builtin_amdgcn_s_sleep(4);
+      continue;
+    }
+    if (k < 64u) {
+      const u32 lo = readlane_dyn(u32(d), k), hi = readlane_dyn(u32(d >> 32), k);
+      s = hi & 1u;
+      x = (hi >> 1) & 1u;
+      base = lo;
+      from = end - 1 - int(k); // may be -1: the front of the call
+      break;
+    }
+    end -= 64;
   }
+  for (int t0 = from + 1; t0 < int(tile); t0 += 64) { // phase 2: every one of these is published
+    const int t = t0 + int(lane);
+    const u64 d = (t < int(tile)) ? desc_load(desc + t) : 0ull;
+    const u32 n = u32((int(tile) - t0) < 64 ? (int(tile) - t0) : 64);
+    for (u32 i = 0; i < n; i++) {
+      const u32 lo = readlane_dyn(u32(d), i), hi = readlane_dyn(u32(d >> 32), i);
+      const u32 status = hi >> 30;
+      if (status == ST_INCL) { // its owner has finished in the meantime
+        s = hi & 1u;
+        x = (hi >> 1) & 1u;
+        base = lo;
+      } else if (status == ST_AGG) {
+        const u64 v = (u64(hi) << 32) | lo;
+        const xs_step st = xs_apply(u32(v >> 42) & 1u, u32(v >> DESC_XW_SHIFT) & XW_LOW_MASK, s, x);
+        base += xs_count(u32(v) & 0x1FFFFFu, u32(v >> 21) & 0x1FFFFFu, st);
+        s = st.s_out;
+        x = st.x_out;
+      } else {
+        return false; // poisoned (or torn: cannot be)
+      }
+    }
+  }
+  S = s;
+  X = x;
+  B = base;
+  return true;
+}
+__device__ __forceinline__ bool lookback(const u64 *desc, u32 tile, u32 lane, u32 &S, u32 &X, u32 &B, scan_origin org) {
+  lookback_state st{0u, 0u, 0u, 0u, int(tile)};
   const u64 t_start = wall_clock64();
   for (;;) {
     u64 d[LOOKBACK_LOADS];
     lookback_load(desc, st.end, lane, d, org);
-    const int r = lookback_consume(d, st, lane, S, B);
+    const int r = lookback_consume(d, st, lane, S, X, B);
+    if (r == 2) { return lookback_slow(desc, tile, lane, S, X, B, org); }
     if (r != 0) { return r > 0; }
     if (wall_clock64() - t_start > LOOKBACK_TIMEOUT_TICKS) { return false; }
     __builtin_amdgcn_s_sleep(4);
+  }
+}
+
+// the aggregate of a tile from its waves' summaries ([parity, count if out, count if in, flags, x word] each, in LDS)
+struct tile_agg {
+  u32 q, c_out, c_in, xw;
+};
+template <u32 NW>
+__device__ __forceinline__ tile_agg tile_aggregate(const u32 (*wv)[5]) {
+  tile_agg r{0u, 0u, 0u, 0u};
+  u32 any = 0;
+#pragma unroll
+  for (u32 v = 0; v < NW; v++) { any |= wv[v][4]; }
+  any = u32(__builtin_amdgcn_readfirstlane(int(any)));
+  if (any == 0u) { // ordinary input
+#pragma unroll
+    for (u32 v = 0; v < NW; v++) {
+      const u32 q = wv[v][0], o = wv[v][1], i = wv[v][2];
+      const u32 no = r.c_out + (r.q ? i : o), ni = r.c_in + (r.q ? o : i);
+      r.c_out = no;
+      r.c_in = ni;
+      r.q ^= q;
+    }
+    return r;
+  }
+  // some span of the tile assumed, or tells its successor something: the tile as a function of the four states in front of it,
+  // evaluated state by state (rolled loops: this is the rare road, it must not cost the kernel registers), then the compact form
+  u32 cnt[4], so[4], xo[4];
+#pragma unroll 1
+  for (u32 i = 0; i < 4; i++) {
+    u32 s = i & 1u, x = i >> 1, n = 0;
+#pragma unroll 1
+    for (u32 v = 0; v < NW; v++) {
+      const xs_step t = xs_apply(wv[v][0], wv[v][4] & XW_LOW_MASK, s, x);
+      n += xs_count(wv[v][1], wv[v][2], t);
+      s = t.s_out;
+      x = t.x_out;
+    }
+    // (a rolled loop must not index registers: spell the four stores out)
+    if (i == 0) { cnt[0] = n; so[0] = s; xo[0] = x; }
+    else if (i == 1) { cnt[1] = n; so[1] = s; xo[1] = x; }
+    else if (i == 2) { cnt[2] = n; so[2] = s; xo[2] = x; }
+    else { cnt[3] = n; so[3] = s; xo[3] = x; }
+  }
+  const u32 F = so[0] ^ so[2];
+  r.q = so[0];
+  r.c_out = cnt[0];
+  r.c_in = cnt[1];
+  r.xw = xo[0] | ((xo[0] ^ xo[2]) << 1) | (F << 2) | xw_enc_d(int(F ? cnt[3] : cnt[2]) - int(cnt[0]), int(F ? cnt[2] : cnt[3]) - int(cnt[1]));
+  return r;
+}
+// the state in front of wave `wave`'s span from the state in front of the tile
+__device__ __forceinline__ void wave_state(const u32 (*wv)[5], u32 wave, u32 &s, u32 &x, u32 &base) {
+  for (u32 v = 0; v < wave; v++) {
+    const xs_step t = xs_apply(wv[v][0], wv[v][4], s, x);
+    base += xs_count(wv[v][1], wv[v][2], t);
+    s = t.s_out;
+    x = t.x_out;
   }
 }
 
@@ -141,8 +262,8 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
   constexpr u32 FUSED_WAVE_BYTES = WC * CHUNK_BYTES;
   constexpr u32 FUSED_TILE_BYTES = FUSED_WAVES * FUSED_WAVE_BYTES;
   __shared__ u32 sh_tile;
-  __shared__ u32 sh_wave[FUSED_WAVES][4]; // parity, count_if_out, count_if_in, flags
-  __shared__ u32 sh_prefix[4];            // S, B, ok
+  __shared__ u32 sh_wave[FUSED_WAVES][5]; // parity, count_if_out, count_if_in, flags, x word (sj_xcarry.h)
+  __shared__ u32 sh_prefix[4];            // S, B, ok, X
   __shared__ __attribute__((aligned(16))) u32 sh_stage[FUSED_WAVES][STAGE_WORDS];
   __shared__ u32 sh_lut[MINIFY_LUT_WORDS];
   __shared__ u32 sh_uq[(OP == 0) ? FUSED_WAVES : 1][(OP == 0) ? 64 : 1]; // left-over UTF-8 list entries between tiles
@@ -172,10 +293,11 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
     u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0; // slot 3 = oldest chunk
     u32 n_out = 0, n_in = 0;
     bool f_ci = false, f_co = false; // wave-uniform error facts
-    u32 parity = 0;
+    u32 parity = 0, xw = 0;
     if (wave_start < len) { // wave-uniform
       const u32 lookback = lookback_issue(buf, wave_start, lane); // consumed after chunk 0 has been requested
       wave_carry wc{0u, 0u, 0u};
+      span_x sx;
       if (OP == 0) { utf8_resume(uq, sh_stage[wave], sh_uq[wave], lane); } // the output window is idle while we scan
 #pragma unroll 1
       for (u32 c = 0; c < FUSED_WAVE_CHUNKS; c++) {
@@ -187,9 +309,10 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
           if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
           else { load_block(buf, pos, len, w); }
           if (c == 0) {
-            wc = segment_carry_from(buf, wave_start, lane, lookback, esc_ref(org.esc, OP == 1 ? ESC_SHIFT_MINIFY : ESC_SHIFT_STAGE1));
+            wc = span_carry_assume(wave_start, lane, lookback, sx);
             uq.pending = utf8_pending_from(lookback, lane);
           }
+          span_note_chunk(sx, w, c * CHUNK_BYTES, c == FUSED_WAVE_CHUNKS - 1, lane);
           if (OP == 0) {
             const chunk_masks m = scan_chunk<true, true>(w, wc, lane, &uq, u32(cstart / BLOCK_BYTES));
             a = m.cand;
@@ -211,6 +334,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
         b3 = b2; b2 = b1; b1 = b0; b0 = b;
       }
       parity = wc.s;
+      xw = span_finish(sx, buf, wave_start, FUSED_WAVE_BYTES, len, wc, OP == 0);
       if (OP == 0) { utf8_settle(uq, sh_uq[wave], buf, len, more, lane); }
     }
     SJ_STAMP(2); // wave 0 finished scanning
@@ -224,6 +348,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
         sh_wave[wave][1] = t_out;
         sh_wave[wave][2] = t_in;
         sh_wave[wave][3] = f;
+        sh_wave[wave][4] = xw;
       }
     }
     __syncthreads();
@@ -231,23 +356,16 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
 
     // ---- phase 2 (wave 0): publish the tile aggregate, look back, publish the inclusive prefix ----------
     if (wave == 0) {
-      u32 tq = 0, tout = 0, tin = 0;
-#pragma unroll
-      for (u32 v = 0; v < FUSED_WAVES; v++) {
-        const u32 q = sh_wave[v][0], o = sh_wave[v][1], i = sh_wave[v][2];
-        const u32 no = tout + (tq ? i : o), ni = tin + (tq ? o : i);
-        tout = no;
-        tin = ni;
-        tq ^= q;
-      }
-      if (lane == 0) { desc_store(desc + tile, make_agg(tq, tout, tin)); }
-      u32 S = 0, B = 0;
-      const bool ok = lookback(desc, tile, lane, S, B, org);
+      const tile_agg ta = tile_aggregate<FUSED_WAVES>(sh_wave);
+      if (lane == 0) { desc_store(desc + tile, make_agg(ta.q, ta.c_out, ta.c_in, ta.xw)); }
+      u32 S = 0, X = 0, B = 0;
+      const bool ok = lookback(desc, tile, lane, S, X, B, org);
       SJ_STAMP(4); // look-back done
       if (lane == 0) {
         if (ok) {
-          const u32 total = B + (S ? tin : tout), s_end = S ^ tq;
-          desc_store(desc + tile, make_incl(s_end, total));
+          const xs_step te = xs_apply(ta.q, ta.xw, S, X);
+          const u32 total = B + xs_count(ta.c_out, ta.c_in, te), s_end = te.s_out;
+          desc_store(desc + tile, make_incl(s_end, te.x_out, total));
           if (tile == ntiles - 1) { // the last tile knows the totals: n / out_len, unclosed string, sentinels
             u32 f = s_end ? SJGPU_F_UNCLOSED_STRING : 0u;
             if (OP == 0) {
@@ -263,6 +381,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
             } else {
               result->out_len = (s_end && !(carry & CARRY_SHARD)) ? 0ull : u64(total); // json_minifier.h:42-47
             }
+            if ((carry & CARRY_MORE) && te.x_out) { f |= SJGPU_F_RANGE_CARRY; }
             if (f) { atomicOr(&result->flags, f); }
           }
         } else {
@@ -272,6 +391,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
         sh_prefix[0] = S;
         sh_prefix[1] = B;
         sh_prefix[2] = ok ? 1u : 0u;
+        sh_prefix[3] = X;
       }
     }
     __syncthreads();
@@ -279,19 +399,19 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
 
     // ---- phase 3: every wave derives its own carry-in from the tile prefix and emits ------------------------
     if (sh_prefix[2] == 0u) { continue; } // poisoned chain: nothing to emit (workgroup-uniform)
-    u32 s = sh_prefix[0], base = sh_prefix[1];
-    for (u32 v = 0; v < wave; v++) {
-      base += s ? sh_wave[v][2] : sh_wave[v][1];
-      s ^= sh_wave[v][0];
-    }
+    u32 s = sh_prefix[0], x = sh_prefix[3], base = sh_prefix[1];
+    wave_state(sh_wave, wave, s, x, base);
     if (wave_start >= len) { continue; }
+    const xs_step own = xs_apply(parity, xw, s, x); // which hypothesis holds for my span, and the one bit a wrong assumption toggles
     {
       const u32 f = sh_wave[wave][3];
       u32 g = 0;
-      if (f & (s ? WF_CTRL_IF_IN : WF_CTRL_IF_OUT)) { g |= SJGPU_F_UNESCAPED_CTRL; }
+      if (f & (own.se ? WF_CTRL_IF_IN : WF_CTRL_IF_OUT)) { g |= SJGPU_F_UNESCAPED_CTRL; }
       if (g && lane == 0) { atomicOr(&result->flags, g); }
     }
-    const u64 flip = s ? ~0ull : 0ull;
+    const u64 flip = own.se ? ~0ull : 0ull;
+    const bool patch = OP == 0 && x != 0u && own.dcount != 0; // wave-uniform
+    const u32 patch_at = xw_patch_pos(xw);
     bool overflow = false;
 #pragma unroll 1
     for (u32 c = 0; c < FUSED_WAVE_CHUNKS; c++) {
@@ -305,7 +425,9 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
       if (cstart >= len) { break; }
       const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
       if (OP == 0) {
-        emit_indices(a & ~(b ^ flip), u32(pos), lane, static_cast<u32 *>(out), out_words, base, sh_stage[wave], overflow);
+        u64 st = a & ~(b ^ flip);
+        if (patch && c == patch_at / CHUNK_BYTES && lane == ((patch_at / BLOCK_BYTES) & 63u)) { st ^= 1ull << (patch_at & 63u); }
+        emit_indices(st, u32(pos), lane, static_cast<u32 *>(out), out_words, base, sh_stage[wave], overflow);
       } else {
         u32 w[16];
         load_block(buf, pos, len, w); // second touch of the same 4 KiB: served by L2 / Infinity Cache
@@ -369,9 +491,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   constexpr u32 STAGE_WORDS = (OP == 0) ? emit_stage_words(PIPE_WINDOW) : (MINIFY_STAGE_BYTES / 4);
   constexpr u32 WAVE_BYTES = WC * CHUNK_BYTES;
   __shared__ u32 sh_tile[2];                 // [iteration parity]: the ticket of an iteration is drawn one iteration ahead
-  __shared__ u32 sh_wave[2][FUSED_WAVES][4]; // [iteration parity][wave]: parity, count_if_out, count_if_in, flags
-  __shared__ u32 sh_agg[2][4];               // tile aggregate of the same two tiles (tq, tout, tin)
-  __shared__ u32 sh_prefix[4];               // S, B, ok of the tile being emitted
+  __shared__ u32 sh_wave[2][FUSED_WAVES][5]; // [iteration parity][wave]: parity, count_if_out, count_if_in, flags, x word (sj_xcarry.h)
+  __shared__ u32 sh_agg[2][4];               // tile aggregate of the same two tiles (tq, tout, tin, x word)
+  __shared__ u32 sh_prefix[4];               // S, B, ok, X of the tile being emitted
   __shared__ u64 sh_mask_a[FUSED_WAVES][WC][64], sh_mask_b[FUSED_WAVES][WC][64]; // the pending tile's masks
   __shared__ __attribute__((aligned(16))) u32 sh_stage[FUSED_WAVES][STAGE_WORDS];
   __shared__ u32 sh_lut[MINIFY_LUT_WORDS];
@@ -413,11 +535,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0; // slot 3 = oldest chunk
     if (have) {
       const u64 wave_start = org.begin + u64(tile) * FUSED_TILE_BYTES + u64(wave) * WAVE_BYTES;
-      u32 n_out = 0, n_in = 0, parity = 0;
+      u32 n_out = 0, n_in = 0, parity = 0, xw = 0;
       bool f_ci = false, f_co = false;
       if (wave_start < len) {
         const u32 lookback = lookback_issue(buf, wave_start, lane);
         wave_carry wc{0u, 0u, 0u};
+        span_x sx;
         if (OP == 0) { utf8_resume(uq, sh_stage[wave], sh_uq[wave], lane); } // the output window is idle while we scan
         // one chunk through the scanner; its masks enter the FIFO
         auto scan_one = [&](const u32 (&w)[16], u64 cstart) {
@@ -452,9 +575,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
               if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
               else { load_block(buf, pos, len, w); }
               if (c == 0) {
-                wc = segment_carry_from(buf, wave_start, lane, lookback, esc_ref(org.esc, OP == 1 ? ESC_SHIFT_MINIFY : ESC_SHIFT_STAGE1));
+                wc = span_carry_assume(wave_start, lane, lookback, sx);
                 uq.pending = utf8_pending_from(lookback, lane);
               }
+              span_note_chunk(sx, w, c * CHUNK_BYTES, c == WC - 1, lane);
               scan_one(w, cstart);
             } else {
               a3 = a2; a2 = a1; a1 = a0; a0 = 0;
@@ -463,6 +587,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           }
         }
         parity = wc.s;
+        xw = span_finish(sx, buf, wave_start, WAVE_BYTES, len, wc, OP == 0);
         if (OP == 0) { utf8_settle(uq, sh_uq[wave], buf, len, more, lane); }
       }
       SJ_PSTAMP(2);
@@ -475,6 +600,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         sh_wave[cur][wave][1] = t_out;
         sh_wave[cur][wave][2] = t_in;
         sh_wave[cur][wave][3] = f;
+        sh_wave[cur][wave][4] = xw;
       }
     }
     __syncthreads();
@@ -484,30 +610,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (wave == 0) {
       phase_prio(prio_policy, 1);
       if (have) {
-        u32 tq = 0, tout = 0, tin = 0;
-#pragma unroll
-        for (u32 v = 0; v < FUSED_WAVES; v++) {
-          const u32 q = sh_wave[cur][v][0], o = sh_wave[cur][v][1], i = sh_wave[cur][v][2];
-          const u32 no = tout + (tq ? i : o), ni = tin + (tq ? o : i);
-          tout = no;
-          tin = ni;
-          tq ^= q;
-        }
+        const tile_agg ta = tile_aggregate<FUSED_WAVES>(sh_wave[cur]);
         if (lane == 0) {
-          desc_store(desc + tile, make_agg(tq, tout, tin));
-          sh_agg[cur][0] = tq;
-          sh_agg[cur][1] = tout;
-          sh_agg[cur][2] = tin;
+          desc_store(desc + tile, make_agg(ta.q, ta.c_out, ta.c_in, ta.xw));
+          sh_agg[cur][0] = ta.q;
+          sh_agg[cur][1] = ta.c_out;
+          sh_agg[cur][2] = ta.c_in;
+          sh_agg[cur][3] = ta.xw;
         }
       }
       if (pend) {
-        const u32 tq = sh_agg[cur ^ 1u][0], tout = sh_agg[cur ^ 1u][1], tin = sh_agg[cur ^ 1u][2];
-        u32 S = 0, B = 0;
-        const bool ok = lookback(desc, pend_tile, lane, S, B, org);
+        const u32 tq = sh_agg[cur ^ 1u][0], tout = sh_agg[cur ^ 1u][1], tin = sh_agg[cur ^ 1u][2], txw = sh_agg[cur ^ 1u][3];
+        u32 S = 0, X = 0, B = 0;
+        const bool ok = lookback(desc, pend_tile, lane, S, X, B, org);
         if (lane == 0) {
           if (ok) {
-            const u32 total = B + (S ? tin : tout), s_end = S ^ tq;
-            desc_store(desc + pend_tile, make_incl(s_end, total));
+            const xs_step te = xs_apply(tq, txw, S, X);
+            const u32 total = B + xs_count(tout, tin, te), s_end = te.s_out;
+            desc_store(desc + pend_tile, make_incl(s_end, te.x_out, total));
             if (pend_tile == ntiles - 1) { // the last tile knows the totals
               u32 f = s_end ? SJGPU_F_UNCLOSED_STRING : 0u;
               if (OP == 0) {
@@ -523,6 +643,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
               } else {
                 result->out_len = (s_end && !(carry & CARRY_SHARD)) ? 0ull : u64(total);
               }
+              if ((carry & CARRY_MORE) && te.x_out) { f |= SJGPU_F_RANGE_CARRY; }
               if (f) { atomicOr(&result->flags, f); }
             }
           } else {
@@ -532,6 +653,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           sh_prefix[0] = S;
           sh_prefix[1] = B;
           sh_prefix[2] = ok ? 1u : 0u;
+          sh_prefix[3] = X;
         }
       }
       SJ_PSTAMP(4);
@@ -543,23 +665,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     phase_prio(prio_policy, 2);
     if (pend && sh_prefix[2] != 0u) {
       const u64 wave_start = org.begin + u64(pend_tile) * FUSED_TILE_BYTES + u64(wave) * WAVE_BYTES;
-      u32 s = sh_prefix[0], base = sh_prefix[1];
-      for (u32 v = 0; v < wave; v++) {
-        base += s ? sh_wave[cur ^ 1u][v][2] : sh_wave[cur ^ 1u][v][1];
-        s ^= sh_wave[cur ^ 1u][v][0];
-      }
+      u32 s = sh_prefix[0], x = sh_prefix[3], base = sh_prefix[1];
+      wave_state(sh_wave[cur ^ 1u], wave, s, x, base);
       if (wave_start < len) {
+        const u32 pxw = sh_wave[cur ^ 1u][wave][4];
+        const xs_step own = xs_apply(sh_wave[cur ^ 1u][wave][0], pxw, s, x); // which hypothesis holds for my span, and the bit a wrong assumption toggles
         const u32 f = sh_wave[cur ^ 1u][wave][3];
         u32 g = 0;
-        if (f & (s ? WF_CTRL_IF_IN : WF_CTRL_IF_OUT)) { g |= SJGPU_F_UNESCAPED_CTRL; }
+        if (f & (own.se ? WF_CTRL_IF_IN : WF_CTRL_IF_OUT)) { g |= SJGPU_F_UNESCAPED_CTRL; }
         if (g && lane == 0) { atomicOr(&result->flags, g); }
-        const u64 flip = s ? ~0ull : 0ull;
+        const u64 flip = own.se ? ~0ull : 0ull;
         bool overflow = false;
         if (OP == 0) { // sparse spans leave in one piece, medium ones as two pairs of chunks, dense ones chunk by chunk
           u64 st[4];
 #pragma unroll
           for (u32 c = 0; c < WC; c++) { st[c] = sh_mask_a[wave][c][lane] & ~(sh_mask_b[wave][c][lane] ^ flip); } // zero beyond len
-          const u32 span_count = (carry & CARRY_DEBUG_NO_SPAN_HINT) ? 0u : (s ? sh_wave[cur ^ 1u][wave][2] : sh_wave[cur ^ 1u][wave][1]);
+          span_patch(st, pxw, x, own.se, lane);
+          const u32 span_count = (carry & CARRY_DEBUG_NO_SPAN_HINT) ? 0u : xs_count(sh_wave[cur ^ 1u][wave][1], sh_wave[cur ^ 1u][wave][2], own);
           emit_span4_adaptive<PIPE_WINDOW>(st, u32(wave_start), lane, static_cast<u32 *>(out), out_words, base, sh_stage[wave], overflow, span_count);
         } else {
 #pragma unroll 1
@@ -624,7 +746,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
   constexpr u32 TILE_BYTES = NW * WAVE_BYTES;
   const u32 carry = org.carry;
   __shared__ u32 sh_tile[2];
-  __shared__ u32 sh_wave[2][NW][4]; // [iteration parity][wave]: quote parity, kept if out, kept if in
+  __shared__ u32 sh_wave[2][NW][5]; // [iteration parity][wave]: quote parity, kept if out, kept if in, (unused), x word (sj_xcarry.h)
   __shared__ u32 sh_agg[2][4];
   __shared__ u32 sh_prefix[4];
   __shared__ __attribute__((aligned(16))) u8 sh_bytes[NW][WC][ONCHIP_REGION_BYTES];
@@ -653,7 +775,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     bool park = false;
     if (have) {
       const u64 wave_start = org.begin + u64(tile) * TILE_BYTES + u64(wave) * WAVE_BYTES;
-      u32 n_out = 0, n_in = 0, parity = 0;
+      u32 n_out = 0, n_in = 0, parity = 0, xw = 0;
       if (wave_start < len) {
         park = true;
         const u32 lookback = lookback_issue(buf, wave_start, lane);
@@ -665,7 +787,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
           load_block(buf, pos0, len, wa); // zero beyond the end
           load_block(buf, pos1, len, wb);
         }
-        wave_carry wc = segment_carry_from(buf, wave_start, lane, lookback, esc_ref(org.esc, ESC_SHIFT_MINIFY));
+        span_x sx;
+        wave_carry wc = span_carry_assume(wave_start, lane, lookback, sx);
+        span_note_chunk(sx, wa, 0u, false, lane);
         {
           const chunk_masks m = scan_chunk<false, false>(wa, wc, lane);
           const u64 valid = valid_mask(pos0, len);
@@ -674,6 +798,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
           n_out += u32(popc64(valid & ~(a0 & ~b0))); // dropped: whitespace outside strings (json_scanner.h:46)
           n_in += u32(popc64(valid & ~(a0 & b0)));
         }
+        span_note_chunk(sx, wb, CHUNK_BYTES, true, lane);
         {
           const chunk_masks m = scan_chunk<false, false>(wb, wc, lane);
           const u64 valid = valid_mask(pos1, len);
@@ -683,12 +808,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
           n_in += u32(popc64(valid & ~(a1 & b1)));
         }
         parity = wc.s;
+        xw = span_finish(sx, buf, wave_start, WAVE_BYTES, len, wc, false);
       }
       const u32 t_out = wave_sum(n_out), t_in = wave_sum(n_in);
       if (lane == 0) {
         sh_wave[cur][wave][0] = parity;
         sh_wave[cur][wave][1] = t_out;
         sh_wave[cur][wave][2] = t_in;
+        sh_wave[cur][wave][3] = 0;
+        sh_wave[cur][wave][4] = xw;
       }
     }
     __syncthreads();
@@ -696,33 +824,27 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     // ---- wave 0: publish the new tile's aggregate, then resolve the PENDING tile's prefix -------------------------
     if (wave == 0) {
       if (have) {
-        u32 tq = 0, tout = 0, tin = 0;
-#pragma unroll
-        for (u32 v = 0; v < NW; v++) {
-          const u32 q = sh_wave[cur][v][0], o = sh_wave[cur][v][1], i = sh_wave[cur][v][2];
-          const u32 no = tout + (tq ? i : o), ni = tin + (tq ? o : i);
-          tout = no;
-          tin = ni;
-          tq ^= q;
-        }
+        const tile_agg ta = tile_aggregate<NW>(sh_wave[cur]);
         if (lane == 0) {
-          desc_store(desc + tile, make_agg(tq, tout, tin));
-          sh_agg[cur][0] = tq;
-          sh_agg[cur][1] = tout;
-          sh_agg[cur][2] = tin;
-
+          desc_store(desc + tile, make_agg(ta.q, ta.c_out, ta.c_in, ta.xw));
+          sh_agg[cur][0] = ta.q;
+          sh_agg[cur][1] = ta.c_out;
+          sh_agg[cur][2] = ta.c_in;
+          sh_agg[cur][3] = ta.xw;
         }
       }
       if (pend) {
-        const u32 tq = sh_agg[cur ^ 1u][0], tout = sh_agg[cur ^ 1u][1], tin = sh_agg[cur ^ 1u][2];
-        u32 S = 0, B = 0;
-        const bool ok = lookback(desc, pend_tile, lane, S, B, org);
+        const u32 tq = sh_agg[cur ^ 1u][0], tout = sh_agg[cur ^ 1u][1], tin = sh_agg[cur ^ 1u][2], txw = sh_agg[cur ^ 1u][3];
+        u32 S = 0, X = 0, B = 0;
+        const bool ok = lookback(desc, pend_tile, lane, S, X, B, org);
         if (lane == 0) {
           if (ok) {
-            const u32 total = B + (S ? tin : tout), s_end = S ^ tq;
-            desc_store(desc + pend_tile, make_incl(s_end, total));
+            const xs_step te = xs_apply(tq, txw, S, X);
+            const u32 total = B + xs_count(tout, tin, te), s_end = te.s_out;
+            desc_store(desc + pend_tile, make_incl(s_end, te.x_out, total));
             if (pend_tile == ntiles - 1) { // the last tile knows the totals
               if (s_end) { atomicOr(&result->flags, SJGPU_F_UNCLOSED_STRING); }
+              if ((carry & CARRY_MORE) && te.x_out) { atomicOr(&result->flags, SJGPU_F_RANGE_CARRY); }
               result->out_len = (s_end && !(carry & CARRY_SHARD)) ? 0ull : u64(total); // json_minifier.h:42-47
             }
           } else {
@@ -732,6 +854,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
           sh_prefix[0] = S;
           sh_prefix[1] = B;
           sh_prefix[2] = ok ? 1u : 0u;
+          sh_prefix[3] = X;
         }
       }
     }
@@ -741,12 +864,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     phase_prio(prio_policy, 2);
     if (pend && sh_prefix[2] != 0u) {
       const u64 wave_start = org.begin + u64(pend_tile) * TILE_BYTES + u64(wave) * WAVE_BYTES;
-      u32 s = sh_prefix[0], base = sh_prefix[1];
-      for (u32 v = 0; v < wave; v++) {
-        base += s ? sh_wave[cur ^ 1u][v][2] : sh_wave[cur ^ 1u][v][1];
-        s ^= sh_wave[cur ^ 1u][v][0];
-      }
-      const u64 flip = s ? ~0ull : 0ull;
+      u32 s = sh_prefix[0], x = sh_prefix[3], base = sh_prefix[1];
+      wave_state(sh_wave[cur ^ 1u], wave, s, x, base);
+      const u64 flip = xs_apply(sh_wave[cur ^ 1u][wave][0], sh_wave[cur ^ 1u][wave][4], s, x).se ? ~0ull : 0ull; // the effective hypothesis of my span
 #pragma unroll
       for (u32 c = 0; c < WC; c++) {
         const u64 cstart = wave_start + u64(c) * CHUNK_BYTES;
@@ -832,16 +952,11 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
                                 scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
                                 hipEvent_t *ev, uint64_t *trace = nullptr, uint32_t trace_tiles = 0) {
   static const bool plain = std::getenv("SJGPU_FUSED_PLAIN") != nullptr; // A/B switch: the non-pipelined large-input kernel
-  uint8_t *const esc_workspace = org.esc;
-  const u32 esc_shift = op == 1 ? ESC_SHIFT_MINIFY : ESC_SHIFT_STAGE1;
-  if (!wants_escape_table(len - org.begin, org) || !esc_workspace) { org.esc = nullptr; }
-  mark(ev, 0, stream); // slot 0 = everything this call enqueues (table, clears, the scan kernel)
+  mark(ev, 0, stream); // slot 0 = everything this call enqueues (the clear, the scan kernel)
   if (len - org.begin <= debug_fused_small_below && !trace) {
-    if (org.esc) { launch_escape_table(buf, org.begin, len, esc_workspace, stream, nullptr, 0, esc_shift); } // a range of a larger buffer
     launch_fused_wc<1>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles);
     return op == 0 ? "k_fused<0> (16 KiB tiles)" : "k_fused<1> (16 KiB tiles)";
   } else if (trace || plain) {
-    if (org.esc) { launch_escape_table(buf, org.begin, len, esc_workspace, stream, nullptr, 0, esc_shift); }
     launch_fused_wc<FUSED_WAVE_CHUNKS>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles);
     return op == 0 ? "k_fused<0> (64 KiB tiles)" : "k_fused<1> (64 KiB tiles)";
   } else {
@@ -850,19 +965,14 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
     const u64 tile_bytes = onchip_waves ? u64(onchip_waves) * ONCHIP_WAVE_CHUNKS * CHUNK_BYTES : u64(FUSED_TILE_BYTES);
     const u32 ntiles = u32((len - org.begin + tile_bytes - 1) / tile_bytes);
     u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles);
-    // result, descriptors and ticket lie back to back (sjgpu_capi.hip): the escape-table launch zeroes them on the side
+    // result, descriptors and ticket lie back to back (sjgpu_capi.hip): one clear
     const bool contiguous = reinterpret_cast<uint64_t *>(result + 1) == desc;
     const size_t clear_bytes = sizeof(scan_result_dev) + (size_t(ntiles) + 1) * sizeof(u64);
-    if (org.esc && contiguous) {
-      launch_escape_table(buf, org.begin, len, esc_workspace, stream, result, clear_bytes, esc_shift);
+    if (contiguous) {
+      (void)hipMemsetAsync(result, 0, clear_bytes, stream);
     } else {
-      if (org.esc) { launch_escape_table(buf, org.begin, len, esc_workspace, stream, nullptr, 0, esc_shift); }
-      if (contiguous) {
-        (void)hipMemsetAsync(result, 0, clear_bytes, stream);
-      } else {
-        (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
-        (void)hipMemsetAsync(desc, 0, (size_t(ntiles) + 1) * sizeof(u64), stream);
-      }
+      (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
+      (void)hipMemsetAsync(desc, 0, (size_t(ntiles) + 1) * sizeof(u64), stream);
     }
     // half as many workgroups as tiles at most: every workgroup should own >= 2 tiles for the deferral to work
     const u32 cap = (ntiles + 1) / 2;
@@ -903,12 +1013,11 @@ const char *launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc
 }
 // one traced run of the pipelined stage-1 kernel; trace holds *grid_out x PIPE_TRACE_ITERS x 8 stamps (zero = not reached)
 uint32_t launch_stage1_pipelined_traced(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
-                                        scan_result_dev *result, uint8_t *esc_workspace, uint32_t max_workgroups, hipStream_t stream,
+                                        scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream,
                                         uint64_t *trace, uint32_t max_records) {
-  scan_origin org{0, 0, 0, esc_workspace};
+  scan_origin org{0, 0, 0};
   const u32 ntiles = u32((len + FUSED_TILE_BYTES - 1) / FUSED_TILE_BYTES);
   u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles);
-  launch_escape_table(buf, 0, len, esc_workspace, stream);
   (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
   (void)hipMemsetAsync(desc, 0, (size_t(ntiles) + 1) * sizeof(u64), stream);
   const u32 cap = (ntiles + 1) / 2;

@@ -37,11 +37,11 @@ struct seg_summary {
   uint32_t count_if_out; // structurals (stage1) / kept bytes (minify) if the segment starts outside a string
   uint32_t count_if_in;  // ... inside a string
   uint32_t flags;
-  uint32_t pad;
+  uint32_t xw;           // the x word of the summary (sj_xcarry.h): what a wrong look-back assumption changes, and what the successor's x is
 };
 struct seg_prefix {
   uint32_t base; // exclusive prefix of counts = first output slot of the segment
-  uint32_t in_string;
+  uint32_t in_string; // bit 0: inside a string; bit 1: x, "the look-back assumption of this segment / group is wrong"
 };
 struct scan_result_dev {
   uint32_t n;
@@ -80,6 +80,7 @@ constexpr int PROFILE_EVENTS = PROFILE_SLOTS + 1;
 constexpr uint32_t CARRY_IN_STRING = 1u; // the first byte scanned is inside a string
 constexpr uint32_t CARRY_SHARD = 2u;     // minify: report out_len even if the scan ends inside a string
 constexpr uint32_t CARRY_MORE = 4u;      // the scan does not end at the end of the input: no "sequence open at EOF" check
+constexpr uint32_t CARRY_X = 8u;         // x in front of the first span (sj_xcarry.h): SJGPU_F_RANGE_CARRY of the range in front
 constexpr uint32_t CARRY_DEBUG_LATE_TICKET = 0x100u; // A/B switch of the pipelined kernel (env SJGPU_LATE_TICKET)
 constexpr uint32_t CARRY_DEBUG_NO_SPAN_HINT = 0x200u; // A/B switch: emission counts the span itself (env SJGPU_NO_SPAN_HINT)
 constexpr uint32_t CARRY_DEBUG_QUEUE_UTF8 = 0x400u;   // A/B switch: dense non-ASCII chunks are queued like sparse ones (env SJGPU_UTF8_QUEUE_ONLY)
@@ -90,16 +91,15 @@ struct scan_origin {
   uint64_t begin;
   uint32_t base0;
   uint32_t carry;
-  uint8_t *esc; // escape table: the launchers get the context's workspace (ESC_TABLE_BYTES), fill it for scans beyond
-                // FUSED_SMALL_BELOW bytes and hand nullptr to the kernels of shorter ones; kernels only read it
 };
 constexpr uint64_t RANGE_ALIGN = uint64_t(1) << 20; // one resolve group = 16 large tiles = 64 small tiles
 void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *summ, seg_prefix *pref, uint32_t *idx,
                    uint64_t idx_words, scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev);
 void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_prefix *pref, uint8_t *dst,
                    scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev);
-void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *result, uint8_t *esc_workspace,
-                          hipStream_t stream); // result->n = parity
+// result->n = parity; workspace: one byte per 16 KiB segment of the buffer (the per-segment parities and x words, folded by a second launch)
+void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *result, uint8_t *workspace, hipStream_t stream);
+// (stage 2's string stream only -- the stage-1 / minify kernels carry the escape state in their scan, sj_xcarry.h)
 // Escape table for bytes [begin, len) of buf: esc[s] (s = absolute segment index) = parity of the backslash run that ends in
 // front of byte s * SEG_BYTES, i.e. "that byte is escaped".  One 64-byte read per segment for ordinary input.  esc holds
 // ESC_TABLE_BYTES bytes; entry begin / SEG_BYTES - 1 must be valid (from the previous range of the same buffer) if begin > 0.
@@ -114,14 +114,6 @@ constexpr size_t ESC_TABLE_BYTES = (ESC_TABLE_ENTRIES + 1023) & ~size_t(1023); /
 // result + descriptors + ticket need no memset of their own.
 void launch_escape_table(const uint8_t *buf, uint64_t begin, uint64_t len, uint8_t *esc, hipStream_t stream,
                          void *clear = nullptr, size_t clear_bytes = 0, uint32_t shift = ESC_SHIFT_STAGE1);
-// whole documents up to FUSED_SMALL_BELOW bytes walk over backslash runs (bounded by their size); longer ones get the
-// table -- and so does EVERY range of a larger buffer, however short: the walk of a short range would otherwise run
-// back over all earlier ranges, and a later range resolves its pass entries through the entries of the ranges in
-// front of it, which must therefore all have been written
-inline bool wants_escape_table(uint64_t scanned_bytes) { return scanned_bytes > FUSED_SMALL_BELOW; }
-inline bool wants_escape_table(uint64_t scanned_bytes, const scan_origin &org) {
-  return scanned_bytes > FUSED_SMALL_BELOW || org.begin > 0 || (org.carry & CARRY_MORE) != 0;
-}
 // bytes [begin, len) of buf; begin > 0 (a multiple of 4 KiB): a later range of a resident buffer, the flags add up in *result;
 // more: the input continues behind len
 void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *result, hipStream_t stream, hipEvent_t *ev,
@@ -169,7 +161,7 @@ void launch_docs(int op, const uint8_t *in_base, const doc_desc *docs, doc_desc 
                  scan_result_dev *results, hipStream_t stream);
 
 uint32_t launch_stage1_pipelined_traced(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
-                                        scan_result_dev *result, uint8_t *esc_workspace, uint32_t max_workgroups, hipStream_t stream,
+                                        scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream,
                                         uint64_t *trace, uint32_t max_records); // -> workgroups launched (32 records of 8 stamps each)
 const char *launch_minify_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint8_t *dst, scan_result_dev *result,
                                 scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev);

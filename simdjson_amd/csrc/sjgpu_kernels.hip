@@ -61,6 +61,7 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu
   const u64 lane_off = u64(lane) * BLOCK_BYTES;
   const u32 lookback = lookback_issue(buf, seg_start, lane); // consumed after chunk 0 has been requested
   wave_carry wc{0u, 0u, 0u};
+  span_x sx;
   utf8_queue uq{uq_slots[wave], 0u, 0u, 0u, (org.carry & CARRY_DEBUG_QUEUE_UTF8) ? nullptr : buf, len, more ? 1u : 0u};
   if (org.carry >> 16) { uq.dense_from = (org.carry >> 16) & 0xFFu; } // A/B: env SJGPU_UTF8_DENSE_FROM
   u32 n_a = 0, n_b = 0; // resolved: n_a = final count; else n_a = candidates, n_b = candidates in a string tail
@@ -82,9 +83,10 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu
     if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); } // interior chunk: branch-free loads
     else { load_block(buf, pos, len, w); }
     if (c == 0) { // the look-back's latency hid behind the loads above
-      wc = segment_carry_from(buf, seg_start, lane, lookback, org.esc);
+      wc = span_carry_assume(seg_start, lane, lookback, sx);
       uq.pending = utf8_pending_from(lookback, lane);
     }
+    span_note_chunk(sx, w, c * CHUNK_BYTES, c == SEG_CHUNKS - 1, lane);
     const chunk_masks m = scan_chunk<true, true>(w, wc, lane, &uq, u32(cstart / BLOCK_BYTES));
     if (c == 0) {
       const u64 cm = __ballot(m.ctrl != 0);
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu
     if (any_b) { flags |= SF_CTRL_IF_IN; }
   }
   s.flags = flags;
-  s.pad = 0;
+  s.xw = span_finish(sx, buf, seg_start, SEG_BYTES, len, wc, true, resolved, derived);
   if (lane == 0) { summ[seg] = s; }
 }
 
@@ -187,6 +189,29 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *sh, bool use_xor, u32
   return use_xor ? (incl ^ v) : (incl - v);
 }
 
+// the successor function of a summary, x -> c ^ (dep & x), as two bits: bit 0 = f(0), bit 1 = f(1)
+__device__ __forceinline__ u32 xfun_of(u32 xw) { return (xw & 1u) | (((xw ^ (xw >> 1)) & 1u) << 1); }
+__device__ __forceinline__ u32 xfun_then(u32 a, u32 b) { // first a, then b
+  const u32 r0 = (b >> (a & 1u)) & 1u, r1 = (b >> ((a >> 1) & 1u)) & 1u;
+  return r0 | (r1 << 1);
+}
+constexpr u32 XFUN_ID = 2u;
+// exclusive scan of function composition over the workgroup's threads
+__device__ __forceinline__ u32 block_excl_scan_xfun(u32 v, u32 *sh) {
+  const u32 tid = threadIdx.x;
+  sh[tid] = v;
+  __syncthreads();
+  for (u32 d = 1; d < RESOLVE_THREADS; d <<= 1) {
+    const u32 t = (tid >= d) ? sh[tid - d] : XFUN_ID;
+    __syncthreads();
+    sh[tid] = xfun_then(t, sh[tid]);
+    __syncthreads();
+  }
+  const u32 excl = tid ? sh[tid - 1] : XFUN_ID;
+  __syncthreads();
+  return excl;
+}
+
 // what: 0 = stage1 (writes n, flags and the three sentinels), 1 = minify (writes out_len, flags)
 __global__ __launch_bounds__(RESOLVE_THREADS) void k_resolve_segments(const seg_summary *__restrict__ summ,
                                                                      seg_prefix *__restrict__ pref, u32 nseg, u64 len,
@@ -195,26 +220,39 @@ __global__ __launch_bounds__(RESOLVE_THREADS) void k_resolve_segments(const seg_
                                                                      scan_origin org) {
   const u32 carry = org.carry;
   __shared__ u32 sh[RESOLVE_THREADS];
-  __shared__ u32 sh_flags;
+  __shared__ u32 sh_flags, sh_x_end;
   const u32 tid = threadIdx.x;
   if (tid == 0) { sh_flags = 0; }
   const u32 per = (nseg + RESOLVE_THREADS - 1) / RESOLVE_THREADS;
   const u32 lo = min(tid * per, nseg), hi = min(lo + per, nseg);
-  // pass 1: quote parity
-  u32 par = 0;
-  for (u32 i = lo; i < hi; i++) { par ^= summ[i].flags & SF_PARITY; }
+  // pass 0: x in front of my first summary (sj_xcarry.h: x of the successor = c ^ (dep & x), a scan over functions of one bit)
+  u32 fun = XFUN_ID;
+  for (u32 i = lo; i < hi; i++) { fun = xfun_then(fun, xfun_of(summ[i].xw)); }
+  const u32 x_call = (carry & CARRY_X) ? 1u : 0u; // a later range of a buffer: what the range in front said about its successor
+  const u32 x0 = (block_excl_scan_xfun(fun, sh) >> x_call) & 1u;
+  // pass 1: quote parity (a wrong assumption in front of a quote flips what the summary hands on)
+  u32 par = 0, xx = x0;
+  for (u32 i = lo; i < hi; i++) {
+    const seg_summary v = summ[i];
+    par ^= (v.flags & SF_PARITY) ^ (xx & (v.xw >> 2) & 1u);
+    xx = (v.xw & 1u) ^ (xx & (v.xw >> 1) & 1u);
+  }
+  if (tid == RESOLVE_THREADS - 1) { sh_x_end = xx; }
   u32 final_parity;
   u32 s = block_excl_scan(par, sh, true, final_parity);
   s ^= carry & CARRY_IN_STRING; // a shard of a larger document may begin inside a string
   final_parity ^= carry & CARRY_IN_STRING;
-  // pass 2: counts under the now-known in-string state
+  // pass 2: counts under the now-known state
   u32 cnt = 0, st = s, flags = 0;
+  xx = x0;
   for (u32 i = lo; i < hi; i++) {
-    const seg_summary x = summ[i];
-    cnt += st ? x.count_if_in : x.count_if_out;
-    if (x.flags & (st ? SF_CTRL_IF_IN : SF_CTRL_IF_OUT)) { flags |= SJGPU_F_UNESCAPED_CTRL; }
-    if (x.flags & SF_UTF8) { flags |= SJGPU_F_UTF8_ERROR; }
-    st ^= x.flags & SF_PARITY;
+    const seg_summary v = summ[i];
+    const xs_step t = xs_apply(v.flags & SF_PARITY, v.xw, st, xx);
+    cnt += xs_count(v.count_if_out, v.count_if_in, t);
+    if (v.flags & (t.se ? SF_CTRL_IF_IN : SF_CTRL_IF_OUT)) { flags |= SJGPU_F_UNESCAPED_CTRL; }
+    if (v.flags & SF_UTF8) { flags |= SJGPU_F_UTF8_ERROR; }
+    st = t.s_out;
+    xx = t.x_out;
   }
   u32 total;
   u32 base = block_excl_scan(cnt, sh, false, total) + org.base0; // output continues where the previous range stopped
@@ -222,18 +260,22 @@ __global__ __launch_bounds__(RESOLVE_THREADS) void k_resolve_segments(const seg_
   if (flags) { atomicOr(&sh_flags, flags); }
   // pass 3: per-segment carry-in
   st = s;
+  xx = x0;
   for (u32 i = lo; i < hi; i++) {
-    const seg_summary x = summ[i];
+    const seg_summary v = summ[i];
     seg_prefix p;
     p.base = base;
-    p.in_string = st;
+    p.in_string = st | (xx << 1);
     pref[i] = p;
-    base += st ? x.count_if_in : x.count_if_out;
-    st ^= x.flags & SF_PARITY;
+    const xs_step t = xs_apply(v.flags & SF_PARITY, v.xw, st, xx);
+    base += xs_count(v.count_if_out, v.count_if_in, t);
+    st = t.s_out;
+    xx = t.x_out;
   }
   __syncthreads();
   if (tid == 0) {
     u32 f = sh_flags | (final_parity ? SJGPU_F_UNCLOSED_STRING : 0u);
+    if ((carry & CARRY_MORE) && sh_x_end) { f |= SJGPU_F_RANGE_CARRY; } // the next range of the buffer starts from it
     if (what == 0) {
       if (u64(total) + 3 <= idx_words) { // sentinels (json_structural_indexer.h:284-286)
         idx[total] = u32(len);
@@ -259,43 +301,84 @@ __global__ __launch_bounds__(RESOLVE_THREADS) void k_resolve_segments(const seg_
 // most 4096 of those in one workgroup; the emit kernels redo the in-group part themselves with one
 // coalesced 1 KiB load (segment_prefix below).  Replaces a 180 us single-workgroup scan by ~10 us.
 // =====================================================================================================
+// x in front of the summary of every lane of `below` (= the lanes in front of the place asked about), as base ^ (free & X), X = x in
+// front of lane 0: the nearest lane whose successor does not depend on its own x fixes the chain, the c bits from there on toggle it
+struct lane_x {
+  u32 base, free;
+};
+__device__ __forceinline__ lane_x wave_x_chain(u32 xw, u64 below) {
+  const u64 cm = __ballot((xw & XW_C) != 0u), dm = __ballot((xw & XW_DEP) != 0u);
+  const u64 nd = ~dm & below;
+  const u64 range = nd ? (below & ~((1ull << (63u - clz64(nd))) - 1ull)) : below;
+  lane_x r;
+  r.base = u32(popc64(cm & range)) & 1u;
+  r.free = nd ? 0u : 1u;
+  return r;
+}
+constexpr u32 XW_IDENTITY = XW_DEP; // a summary of nothing: hands x on, counts nothing
+
 __global__ __launch_bounds__(64) void k_resolve_groups(const seg_summary *__restrict__ summ, seg_summary *__restrict__ gsum,
                                                        u32 nseg) {
   const u32 lane = lane_id();
   const u32 seg = blockIdx.x * RESOLVE_GROUP + lane;
-  seg_summary x{0u, 0u, 0u, 0u};
+  seg_summary x{0u, 0u, 0u, XW_IDENTITY};
   if (seg < nseg) { x = summ[seg]; }
-  const u64 qm = __ballot((x.flags & SF_PARITY) != 0);
-  const bool flipped = (popc64(qm & lanemask_lt(lane)) & 1) != 0; // in-string state, relative to the group start
-  const u32 g_out = wave_sum(flipped ? x.count_if_in : x.count_if_out);
-  const u32 g_in = wave_sum(flipped ? x.count_if_out : x.count_if_in);
-  u32 flags = (popc64(qm) & 1) ? SF_PARITY : 0u;
-  if (__ballot((x.flags & (flipped ? SF_CTRL_IF_IN : SF_CTRL_IF_OUT)) != 0)) { flags |= SF_CTRL_IF_OUT; }
-  if (__ballot((x.flags & (flipped ? SF_CTRL_IF_OUT : SF_CTRL_IF_IN)) != 0)) { flags |= SF_CTRL_IF_IN; }
+  const u64 lt = lanemask_lt(lane);
+  const u32 q = (x.flags & SF_PARITY) ? 1u : 0u, F = (x.xw >> 2) & 1u;
+  const lane_x mine = wave_x_chain(x.xw, lt), after = wave_x_chain(x.xw, ~0ull);
+  // the group as a function of the state (S, X) in front of it, then back into the compact form (sj_xcarry.h: xs_compact)
+  u32 cnt[4], err[4], par[2], xo[2];
+#pragma unroll
+  for (u32 X = 0; X < 2; X++) {
+    const u32 xin = mine.base ^ (mine.free & X);
+    const u32 f = xin & F;
+    const u64 qm = __ballot((q ^ f) != 0u);
+    const u32 flipped = u32(popc64(qm & lt)) & 1u; // in-string state in front of my segment, relative to the group start
+    par[X] = u32(popc64(qm)) & 1u;
+    xo[X] = after.base ^ (after.free & X);
+#pragma unroll
+    for (u32 S = 0; S < 2; S++) {
+      const u32 se = S ^ flipped ^ f;
+      const u32 c = (se ? x.count_if_in : x.count_if_out) + u32(xin ? xw_d(x.xw, se) : 0);
+      cnt[S | (X << 1)] = wave_sum(c);
+      err[S | (X << 1)] = __ballot((x.flags & (se ? SF_CTRL_IF_IN : SF_CTRL_IF_OUT)) != 0u) ? 1u : 0u;
+    }
+  }
+  u32 flags = par[0] ? SF_PARITY : 0u;
+  if (err[0]) { flags |= SF_CTRL_IF_OUT; }
+  if (err[1]) { flags |= SF_CTRL_IF_IN; }
   if (__ballot((x.flags & SF_UTF8) != 0)) { flags |= SF_UTF8; }
   if (lane == 0) {
+    const u32 Fg = par[0] ^ par[1];
+    const int d0 = int(Fg ? cnt[3] : cnt[2]) - int(cnt[0]); // x = 1: effective hypothesis 0 is reached from S = Fg
+    const int d1 = int(Fg ? cnt[2] : cnt[3]) - int(cnt[1]);
     seg_summary g;
-    g.count_if_out = g_out;
-    g.count_if_in = g_in;
+    g.count_if_out = cnt[0];
+    g.count_if_in = cnt[1];
     g.flags = flags;
-    g.pad = 0;
+    g.xw = xo[0] | ((xo[0] ^ xo[1]) << 1) | (Fg << 2) | xw_enc_d(d0, d1);
     gsum[blockIdx.x] = g;
   }
 }
 
-// carry-in (in-string bit, output cursor) of segment `seg`: its group's prefix + the segments in front of
+// carry-in (in-string bit, x, output cursor) of segment `seg`: its group's prefix + the segments in front of
 // it inside the group
 __device__ __forceinline__ seg_prefix segment_prefix(const seg_summary *__restrict__ summ, const seg_prefix *__restrict__ gpref,
                                                      u32 seg, u32 lane) {
   const u32 group = seg / RESOLVE_GROUP, r = seg % RESOLVE_GROUP;
   const seg_prefix gp = gpref[group];
-  seg_summary x{0u, 0u, 0u, 0u};
+  seg_summary x{0u, 0u, 0u, XW_IDENTITY};
   if (lane < r) { x = summ[group * RESOLVE_GROUP + lane]; }
-  const u64 qm = __ballot((x.flags & SF_PARITY) != 0);
-  const bool inside = ((popc64(qm & lanemask_lt(lane)) & 1) != 0) != (gp.in_string != 0);
+  const u64 lt = lanemask_lt(lane);
+  const lane_x mine = wave_x_chain(x.xw, lt);
+  const u32 xin = mine.base ^ (mine.free & (gp.in_string >> 1) & 1u);
+  const u32 f = xin & (x.xw >> 2) & 1u;
+  const u64 qm = __ballot(((((x.flags & SF_PARITY) ? 1u : 0u) ^ f)) != 0u);
+  const u32 s = (gp.in_string & 1u) ^ (u32(popc64(qm & lt)) & 1u);
+  const u32 se = s ^ f;
   seg_prefix p;
-  p.base = gp.base + wave_sum(inside ? x.count_if_in : x.count_if_out);
-  p.in_string = gp.in_string ^ (u32(popc64(qm)) & 1u);
+  p.base = gp.base + wave_sum((se ? x.count_if_in : x.count_if_out) + u32(xin ? xw_d(x.xw, se) : 0));
+  p.in_string = readlane_dyn(s | (xin << 1), r); // lane r holds the summary of nothing: the state in front of it is the segment's
   return p;
 }
 
@@ -328,13 +411,17 @@ __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask
     }
   }
   const seg_prefix pf = segment_prefix(summ, gpref, seg, lane);
+  const seg_summary own = summ[seg];
+  const u32 x = pf.in_string >> 1;
+  const xs_step t = xs_apply(own.flags & SF_PARITY, own.xw, pf.in_string & 1u, x); // which hypothesis, and the bit a wrong assumption toggles
   u32 base = pf.base;
-  const u64 flip = pf.in_string ? ~0ull : 0ull;
+  const u64 flip = t.se ? ~0ull : 0ull;
   bool overflow = false;
   u64 st[SEG_CHUNKS];
 #pragma unroll
   for (u32 c = 0; c < SEG_CHUNKS; c++) { st[c] = resolved ? m0[c] : (m0[c] & ~(m1[c] ^ flip)); } // chunks beyond len hold zero masks
-  const u32 span_count = (org.carry & CARRY_DEBUG_NO_SPAN_HINT) ? 0u : (pf.in_string ? summ[seg].count_if_in : summ[seg].count_if_out);
+  span_patch(st, own.xw, x, t.se, lane);
+  const u32 span_count = (org.carry & CARRY_DEBUG_NO_SPAN_HINT) ? 0u : xs_count(own.count_if_out, own.count_if_in, t);
   emit_span4_adaptive<EMIT_WINDOW>(st, u32(seg_start), lane, idx, idx_words, base, stage, overflow, span_count); // sparse segments go out in one piece
   if (__ballot(overflow) && lane == 0) { atomicOr(&result->flags, SJGPU_F_IDX_OVERFLOW); }
 }
@@ -349,6 +436,7 @@ __global__ __launch_bounds__(64) void k_minify_summarize(const u8 *__restrict__ 
   const u64 seg_start = org.begin + u64(seg) * SEG_BYTES;
   const u32 lookback = lookback_issue(buf, seg_start, lane);
   wave_carry wc{0u, 0u, 0u};
+  span_x sx;
   u32 kept_out = 0, kept_in = 0;
   for (u32 c = 0; c < SEG_CHUNKS; c++) {
     const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
@@ -357,19 +445,21 @@ __global__ __launch_bounds__(64) void k_minify_summarize(const u8 *__restrict__ 
     u32 w[16];
     if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
     else { load_block(buf, pos, len, w); }
-    if (c == 0) { wc = segment_carry_from(buf, seg_start, lane, lookback, esc_ref(org.esc, ESC_SHIFT_MINIFY)); }
+    if (c == 0) { wc = span_carry_assume(seg_start, lane, lookback, sx); }
+    span_note_chunk(sx, w, c * CHUNK_BYTES, c == SEG_CHUNKS - 1, lane);
     const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
     const u64 valid = valid_mask(pos, len);
     kept_out += u32(popc64(valid & ~(m.ws & ~m.in_string))); // dropped: whitespace outside strings (json_scanner.h:46)
     kept_in += u32(popc64(valid & ~(m.ws & m.in_string)));
   }
   const u32 a = wave_sum(kept_out), b = wave_sum(kept_in);
+  const u32 xw = span_finish(sx, buf, seg_start, SEG_BYTES, len, wc, false);
   if (lane == 0) {
     seg_summary s;
     s.count_if_out = a;
     s.count_if_in = b;
     s.flags = wc.s ? SF_PARITY : 0u;
-    s.pad = 0;
+    s.xw = xw;
     summ[seg] = s;
   }
 }
@@ -394,9 +484,12 @@ __global__ __launch_bounds__(64) void k_minify_emit(const u8 *__restrict__ buf, 
     u32 w[16];
     if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
     else { load_block(buf, pos, len, w); }
-    if (c == 0) {
-      wc = segment_carry_from(buf, seg_start, lane, lookback, esc_ref(org.esc, ESC_SHIFT_MINIFY));
-      wc.s = pf.in_string; // absolute from here on
+    if (c == 0) { // the same scan as k_minify_summarize's, assumption included; the state it starts from is the EFFECTIVE one: behind the
+                  // quote a wrong assumption misjudged both agree with the truth, in front of it there is nothing but backslashes
+      span_x sx;
+      wc = span_carry_assume(seg_start, lane, lookback, sx);
+      const seg_summary own = summ[seg];
+      wc.s = xs_apply(own.flags & SF_PARITY, own.xw, pf.in_string & 1u, pf.in_string >> 1).se; // absolute from here on
     }
     const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
     emit_bytes(w, valid_mask(pos, len) & ~(m.ws & ~m.in_string), lane, dst, base, stage, lut);
@@ -446,14 +539,13 @@ __global__ __launch_bounds__(64) void k_validate_utf8(const u8 *__restrict__ buf
 // string parity of a shard: 1 iff it holds an odd number of unescaped quotes (read-only pre-pass of the
 // general multi-GPU sharding, SURVEY 8(e): the ranks all-gather these bits, then scan with the right carry-in)
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_string_parity(const u8 *__restrict__ buf, u64 len, u32 nseg,
-                                                      scan_result_dev *__restrict__ result, const u8 *__restrict__ esc) {
+__global__ __launch_bounds__(64) void k_string_parity(const u8 *__restrict__ buf, u64 len, u32 nseg, u8 *__restrict__ seg_bits) {
   const u32 lane = lane_id();
-  u32 parity = 0;
   for (u32 seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const u64 seg_start = u64(seg) * SEG_BYTES;
     const u32 lookback = lookback_issue(buf, seg_start, lane);
     wave_carry wc{0u, 0u, 0u};
+    span_x sx;
     for (u32 c = 0; c < SEG_CHUNKS; c++) {
       const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
       if (cstart >= len) { break; }
@@ -461,12 +553,32 @@ __global__ __launch_bounds__(64) void k_string_parity(const u8 *__restrict__ buf
       u32 w[16];
       if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
       else { load_block(buf, pos, len, w); }
-      if (c == 0) { wc = segment_carry_from(buf, seg_start, lane, lookback, esc); }
+      if (c == 0) { wc = span_carry_assume(seg_start, lane, lookback, sx); }
+      span_note_chunk(sx, w, c * CHUNK_BYTES, c == SEG_CHUNKS - 1, lane);
       (void)scan_chunk<false, false>(w, wc, lane);
     }
-    parity ^= wc.s;
+    const u32 xw = span_finish(sx, buf, seg_start, SEG_BYTES, len, wc, false);
+    if (lane == 0) { seg_bits[seg] = u8(wc.s | ((xw & 7u) << 1)); } // parity under the assumption; c, dep, F
   }
-  if (parity && lane == 0) { atomicXor(&result->n, 1u); }
+}
+// the fold of those bytes: x along the segments, then the parity with the flips x asks for
+__global__ __launch_bounds__(RESOLVE_THREADS) void k_string_parity_fold(const u8 *__restrict__ seg_bits, u32 nseg, scan_result_dev *__restrict__ result) {
+  __shared__ u32 sh[RESOLVE_THREADS];
+  const u32 tid = threadIdx.x;
+  const u32 per = (nseg + RESOLVE_THREADS - 1) / RESOLVE_THREADS;
+  const u32 lo = min(tid * per, nseg), hi = min(lo + per, nseg);
+  u32 fun = XFUN_ID;
+  for (u32 i = lo; i < hi; i++) { fun = xfun_then(fun, xfun_of(u32(seg_bits[i]) >> 1)); }
+  u32 xx = block_excl_scan_xfun(fun, sh) & 1u; // a shard begins behind a clean byte: x = 0 in front of it
+  u32 par = 0;
+  for (u32 i = lo; i < hi; i++) {
+    const u32 v = seg_bits[i], xw = v >> 1;
+    par ^= (v & 1u) ^ (xx & (xw >> 2) & 1u);
+    xx = (xw & 1u) ^ (xx & (xw >> 1) & 1u);
+  }
+  u32 total;
+  (void)block_excl_scan(par, sh, true, total);
+  if (tid == 0) { result->n = total & 1u; }
 }
 
 
@@ -537,9 +649,7 @@ void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *
   if (queue_only) { org.carry |= CARRY_DEBUG_QUEUE_UTF8; }
   static const unsigned dense_from = []() { const char *v = std::getenv("SJGPU_UTF8_DENSE_FROM"); return v ? unsigned(std::atoi(v)) & 0xFFu : 0u; }();
   org.carry |= dense_from << 16;
-  mark(ev, 0, stream); // slot 0 = table + summarize
-  if (wants_escape_table(len - org.begin, org) && org.esc) { launch_escape_table(buf, org.begin, len, org.esc, stream); }
-  else { org.esc = nullptr; }
+  mark(ev, 0, stream);
   u64 *mask0 = reinterpret_cast<u64 *>(masks);
   u64 *mask1 = mask0 + size_t(nseg) * (SEG_BYTES / BLOCK_BYTES); // second plane, only written by unresolved segments
   hipLaunchKernelGGL(k_stage1_summarize, dim3((nseg + SUMM_WAVES - 1) / SUMM_WAVES), dim3(64 * SUMM_WAVES), 0, stream, buf, len, mask0, mask1, summ,
@@ -559,9 +669,7 @@ void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *
 void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_prefix *pref, uint8_t *dst,
                    scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev) {
   const u32 nseg = num_segments(len - org.begin);
-  mark(ev, 0, stream); // slot 0 = table + summarize
-  if (wants_escape_table(len - org.begin, org) && org.esc) { launch_escape_table(buf, org.begin, len, org.esc, stream, nullptr, 0, ESC_SHIFT_MINIFY); }
-  else { org.esc = nullptr; }
+  mark(ev, 0, stream);
   hipLaunchKernelGGL(k_minify_summarize, dim3(nseg), dim3(64), 0, stream, buf, len, summ, org);
   mark(ev, 1, stream);
   const u32 ngroups = (nseg + RESOLVE_GROUP - 1) / RESOLVE_GROUP;
@@ -586,17 +694,13 @@ void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *res
   mark(ev, 3, stream);
 }
 
-void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *result, uint8_t *esc_workspace, hipStream_t stream) {
+void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *result, uint8_t *workspace, hipStream_t stream) {
   (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
   const u32 nseg = num_segments(len);
   if (nseg == 0) { return; }
-  const uint8_t *esc = nullptr;
-  if (wants_escape_table(len)) {
-    launch_escape_table(buf, 0, len, esc_workspace, stream);
-    esc = esc_workspace;
-  }
   const u32 grid = nseg < 8192u ? nseg : 8192u;
-  hipLaunchKernelGGL(k_string_parity, dim3(grid), dim3(64), 0, stream, buf, len, nseg, result, esc);
+  hipLaunchKernelGGL(k_string_parity, dim3(grid), dim3(64), 0, stream, buf, len, nseg, workspace);
+  hipLaunchKernelGGL(k_string_parity_fold, dim3(1), dim3(RESOLVE_THREADS), 0, stream, workspace, nseg, result);
 }
 
 void launch_escape_table(const uint8_t *buf, uint64_t begin, uint64_t len, uint8_t *esc, hipStream_t stream, void *clear,

@@ -87,7 +87,7 @@ static void value(bytes &d, int depth) { // a valid JSON value
 }
 static bytes make_document(size_t target) {
   bytes d;
-  const uint32_t kind = rnd_below(8);
+  const uint32_t kind = rnd_below(11);
   while (d.size() < target) {
     switch (kind) {
     case 0: soup(d, 1 + rnd_below(400)); break;
@@ -105,6 +105,32 @@ static bytes make_document(size_t target) {
       const uint32_t t = rnd_below(6);
       if (t == 0) { put(d, "\"a"); } else if (t == 1) { put(d, "\"\""); } else if (t == 2) { put(d, "\" ,"); } else if (t == 3) { put(d, "n\""); } else if (t == 4) { put(d, "\"\\\"1"); }
       soup(d, rnd_below(40));
+      break;
+    }
+    case 8: case 9: case 10: { // the corners of the escape carry (sj_xcarry.h): a run that begins at least 64 bytes in front of a span boundary
+      // (4, 8 and 16 KiB spans exist) and ends a few bytes behind it, or one byte short of the next boundary, or covers whole spans; behind
+      // it a quote -- real or escaped, that is the question -- and behind the quote a scalar, an operator, whitespace or another quote
+      static const uint32_t spans[] = {4096, 8192, 16384, 65536};
+      const uint32_t N = spans[rnd_below(4)];
+      const size_t at = d.size();
+      const size_t boundary = (at / N + 1) * N;
+      const uint32_t before = 64 + rnd_below(4) * 1 + (rnd_below(3) ? 0 : rnd_below(200)) - (rnd_below(5) == 0 ? 2 : 0); // 62 ... : sometimes just too short
+      size_t start = boundary > before ? boundary - before : 0;
+      if (start < at) { start = at; }
+      const uint8_t fill = kind == 8 ? ' ' : (kind == 9 ? 'x' : '\n');
+      if (rnd_below(2)) { d.insert(d.end(), start - at, fill); }
+      else { if (start > at) { d.push_back('"'); } d.insert(d.end(), start > at ? start - at - 1 : 0, 'y'); } // the run sits inside a string
+      static const int ends[] = {0, 1, 2, 3, 4, 5, 63, 64, 65, 66, -1, -2, -3, -64, -65};
+      const int e = ends[rnd_below(sizeof ends / sizeof ends[0])];
+      const uint32_t whole = rnd_below(3) == 0 ? rnd_below(4) : 0; // whole spans of backslashes in between
+      const size_t stop = size_t(int64_t(boundary + size_t(whole) * N + ((e < 0) ? N : 0)) + e);
+      if (stop > d.size()) { d.insert(d.end(), stop - d.size(), '\\'); }
+      static const char *const tails[] = {"\"a", "\"\"", "\" ,", "\"x\"", "\",1", "\"\n", "n\"", "\"1", "\"\\\"1", "\"", "a", ",", " "};
+      put(d, tails[rnd_below(sizeof tails / sizeof tails[0])]);
+      if (rnd_below(2)) { // (no control characters: one inside a string and nobody compares the document's list)
+        static const char plain[] = "\\\"\"  ,,::[]{}aZ09-.e+";
+        for (uint32_t i = 0, n = rnd_below(30); i < n; i++) { d.push_back(uint8_t(plain[rnd_below(sizeof plain - 1)])); }
+      }
       break;
     }
     case 4: { // long strings (two-hypothesis segments), sometimes with a control character inside
@@ -259,10 +285,9 @@ int main(int argc, char **argv) {
     total_bytes += len;
     const expected e = oracle(doc);
     w.fit(doc);
-    const scan_origin whole{0, 0, 0, nullptr};
+    const scan_origin whole{0, 0, 0};
     if (all || what == "split") {
       scan_origin org = whole;
-      org.esc = w.esc.data();
       std::fill(w.idx.begin(), w.idx.begin() + len + 8, 0xDEADBEEFu);
       launch_stage1(w.in, len, w.masks.data(), w.summ.data(), w.pref.data(), w.idx.data(), len + 3, w.result(), org, nullptr, nullptr);
       check_stage1("split stage 1", doc, e, w);
@@ -276,7 +301,6 @@ int main(int argc, char **argv) {
       for (int large = 0; large < 2; large++) {
         debug_fused_small_below = large ? 1 : FUSED_SMALL_BELOW; // 1: every document takes the pipelined 64 KiB-tile kernels
         scan_origin org = whole;
-        org.esc = w.esc.data();
         std::fill(w.idx.begin(), w.idx.begin() + len + 8, 0xDEADBEEFu);
         launch_stage1_fused(w.in, len, w.desc(), w.idx.data(), len + 3, w.result(), org, 6, nullptr, nullptr);
         check_stage1(large ? "pipelined stage 1" : "fused stage 1 (16 KiB tiles)", doc, e, w);
@@ -297,17 +321,18 @@ int main(int argc, char **argv) {
     }
     if ((all || what == "ranges") && len > RANGE_ALIGN) { // consecutive ranges of one buffer, the state between them as run_streamed carries it
       for (int fused = 0; fused < 2; fused++) {
-        uint32_t cursor = 0, in_string = 0, flags = 0;
+        uint32_t cursor = 0, in_string = 0, x_carry = 0, flags = 0;
         std::fill(w.idx.begin(), w.idx.begin() + len + 8, 0xDEADBEEFu);
         for (size_t b = 0; b < len; b += RANGE_ALIGN) {
           const size_t end = b + RANGE_ALIGN < len ? b + RANGE_ALIGN : len;
           const bool last = end == len;
-          scan_origin org{uint64_t(b), cursor, (in_string ? CARRY_IN_STRING : 0u) | CARRY_SHARD | (last ? 0u : CARRY_MORE), w.esc.data()};
+          scan_origin org{uint64_t(b), cursor, (in_string ? CARRY_IN_STRING : 0u) | (x_carry ? CARRY_X : 0u) | CARRY_SHARD | (last ? 0u : CARRY_MORE)};
           if (fused) { launch_stage1_fused(w.in, end, w.desc(), w.idx.data(), len + 3, w.result(), org, 6, nullptr, nullptr); }
           else { launch_stage1(w.in, end, w.masks.data(), w.summ.data(), w.pref.data(), w.idx.data(), len + 3, w.result(), org, nullptr, nullptr); }
-          flags |= w.result()->flags & ~1u;
+          flags |= w.result()->flags & ~(1u | SJGPU_F_RANGE_CARRY);
           cursor = w.result()->n;
           in_string = w.result()->flags & 1u;
+          x_carry = w.result()->flags & SJGPU_F_RANGE_CARRY;
         }
         w.result()->flags = flags | in_string;
         check_stage1(fused ? "ranges, single pass" : "ranges, split", doc, e, w);

@@ -14,13 +14,11 @@ CSRC = os.path.join(_paths.PKG_DIR, "csrc")
 EMU = os.path.join(_paths.REPO_ROOT, "tests", "host", "emu")
 
 
-@pytest.fixture(scope="module")
-def emu(tmp_path_factory):
-    out = tmp_path_factory.mktemp("emu")
+def _build(out, defines=()):
     inc = ["-I", EMU, "-I", _paths.INCLUDE_DIR, "-I", CSRC, "-I", _paths.ORACLE_DIR]
     jobs = []
     for name in ("sjgpu_kernels", "sjgpu_fused", "sjgpu_small"):
-        jobs.append(subprocess.Popen(["g++", "-std=c++17", "-O1", "-Wno-attributes", "-Wno-unknown-pragmas", "-x", "c++", *inc, "-c",
+        jobs.append(subprocess.Popen(["g++", "-std=c++17", "-O1", "-Wno-attributes", "-Wno-unknown-pragmas", *defines, "-x", "c++", *inc, "-c",
                                       os.path.join(CSRC, name + ".hip"), "-o", str(out / (name + ".o"))]))
     jobs.append(subprocess.Popen(["g++", "-std=c++17", "-O2", *inc, "-c", os.path.join(EMU, "sj_emu.cpp"), "-o", str(out / "sj_emu.o")]))
     jobs.append(subprocess.Popen(["g++", "-std=c++17", "-O2", "-Wno-attributes", *inc, "-c",
@@ -34,8 +32,23 @@ def emu(tmp_path_factory):
     return exe
 
 
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    return _build(tmp_path_factory.mktemp("emu"))
+
+
 @pytest.mark.parametrize("seed,docs,max_kib", [(1, 150, 200), (2026, 150, 200), (7, 10, 2500)])
 def test_kernel_sources_against_the_oracle(emu, seed, docs, max_kib):
     p = subprocess.run([emu, str(seed), str(docs), str(max_kib), "all"], capture_output=True, timeout=900)
     assert p.returncode == 0, (p.stdout.decode()[-500:], p.stderr.decode()[-3000:])
     assert f"{docs} documents" in p.stdout.decode() and " 0 mismatches" in p.stdout.decode()
+
+
+@pytest.mark.parametrize("part", [1, 2, 3, 4])
+def test_the_documents_reach_every_part_of_the_escape_carry(tmp_path, part):
+    """The kernels carry the escape state in their scan (sj_xcarry.h: spans that assume, an x word per summary).  With a part of the x
+    words compiled out -- 1 all of it, 2 the patched candidate bit, 3 the dependence of a successor's x on the span's own, 4 the flip of
+    the in-string hypothesis -- the same documents must FAIL: the comparison above has teeth for every rule."""
+    exe = _build(tmp_path, ("-DSJGPU_SELFTEST_NO_XW=%d" % part,))
+    p = subprocess.run([exe, "1", "150", "200", "all"], capture_output=True, timeout=900)
+    assert p.returncode != 0 and "MISMATCH" in p.stderr.decode(), "the kernels pass without part %d of the x words" % part
