@@ -83,7 +83,7 @@ def make_workload(corpus, workload, size, seed):
     return gen(size, seed)
 
 
-def device_leg(cx, op, workload, host, units, steps, warmup, pipeline, fence=None, cpu_iters=None, with_cpu=True):
+def device_leg(cx, op, workload, host, units, steps, warmup, pipeline, fence=None, cpu_iters=None, with_cpu=True, with_parity=None, parity_raises=True):
     """One op over one resident buffer: K timed steps bracketed by synchronize (+ barrier), HIP-event kernel time from
     libsjgpu, exact parity of the timed buffer's output against the reference (count AND an order-sensitive digest)."""
     torch, capi = cx.torch, cx.capi
@@ -145,7 +145,13 @@ def device_leg(cx, op, workload, host, units, steps, warmup, pipeline, fence=Non
         cb = cx.cpu().time_cpu(host, op, cpu_iters or cx.args.cpu_iters)
         leg["cpu_baseline"] = {"value": round(cb["value"], 3), "unit": "GB/s", "cores": cb["cores"], "kind": cb["kind"],
                                "sample": f"the same {L}-byte buffer, {cb['impl']} kernel, 1 thread, best of {cpu_iters or cx.args.cpu_iters}"}
-        leg["parity"] = parity_check(cx, op, host, parser, n, out_len, flags, out)
+    if with_cpu if with_parity is None else with_parity:
+        try:
+            leg["parity"] = parity_check(cx, op, host, parser, n, out_len, flags, out)
+        except SystemExit as e:  # N > 1: a rank must not leave while the others wait in a collective -- main() reduces the verdicts and fails then
+            if parity_raises:
+                raise
+            leg["parity"] = {"checked": True, "ok": False, "why": str(e)}
     parser.close()
     del buf, out
     return leg
@@ -174,7 +180,7 @@ def parity_check(cx, op, host, parser, n, out_len, flags, out):
         ok = rerr == 0 and rn.value == n and want == got
         if not ok:
             raise SystemExit(f"PARITY FAILURE stage1: n {n} vs {rn.value}, digest {got} vs {want}, reference error {rerr}")
-        return {"checked": True, "n": n, "digest_sum_i_times_idx_mod_2_64": got, "reference": impl.decode()}
+        return {"checked": True, "ok": True, "n": n, "digest_sum_i_times_idx_mod_2_64": got, "reference": impl.decode()}
     if op == "minify":
         R.sjref_minify.restype = ctypes.c_int
         R.sjref_minify.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
@@ -185,14 +191,14 @@ def parity_check(cx, op, host, parser, n, out_len, flags, out):
         got = byte_digest_device(torch, out, out_len)
         if not (rerr == 0 and rl.value == out_len and want == got):
             raise SystemExit(f"PARITY FAILURE minify: len {out_len} vs {rl.value}, digest {got} vs {want}")
-        return {"checked": True, "out_bytes": out_len, "digest": got, "reference": impl.decode()}
+        return {"checked": True, "ok": True, "out_bytes": out_len, "digest": got, "reference": impl.decode()}
     R.sjref_validate_utf8.restype = ctypes.c_int
     R.sjref_validate_utf8.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
     want = R.sjref_validate_utf8(impl, host.ctypes.data, L)
     got = 0 if flags & cx.capi.F_UTF8_ERROR else 1
     if want != got:
         raise SystemExit("PARITY FAILURE validate_utf8")
-    return {"checked": True, "verdict": got, "reference": impl.decode()}
+    return {"checked": True, "ok": True, "verdict": got, "reference": impl.decode()}
 
 
 def leg_twitter_json(cx):
@@ -581,6 +587,15 @@ def main():
     import torch.distributed as dist
     from simdjson_amd import build, capi, corpus
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU of this node, rendezvous on 127.0.0.1)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]])
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -618,8 +633,30 @@ def main():
         args.workload = "large_random"
     host, units = make_workload(corpus, args.workload, args.size, 1000 + rank)
     L = len(host)
-    with_cpu = world == 1 and not args.no_cpu_baseline
-    leg = device_leg(cx, args.op, args.workload, host, units, args.steps, args.warmup, args.pipeline, fence=fence, with_cpu=with_cpu)
+    # the reference beside it: rank 0 times it (one thread on its own buffer; N > 1 adds all hardware threads on the NDJSON);
+    # EVERY rank checks its own output against the reference, the verdicts are reduced into the line
+    with_cpu = rank == 0 and not args.no_cpu_baseline
+    with_parity = not args.no_cpu_baseline
+    leg = device_leg(cx, args.op, args.workload, host, units, args.steps, args.warmup, args.pipeline, fence=fence, with_cpu=with_cpu, with_parity=with_parity,
+                     parity_raises=world == 1)
+    parity_failed_somewhere = False
+    if world > 1:
+        mine_ok = 1.0 if leg.get("parity", {}).get("ok", False) else 0.0
+        pv = torch.tensor([mine_ok, 1.0 if "parity" in leg else 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(pv)
+        if "parity" in leg or rank == 0:
+            leg.setdefault("parity", {"checked": False})
+            leg["parity"].update({"ranks_checked": int(pv[1].item()), "ranks_ok": int(pv[0].item()), "all_ranks_ok": int(pv[0].item()) == world,
+                                  "note": "every rank compares the output of its own timed buffer with the reference (count + order-sensitive digest); this entry is rank 0's, "
+                                          "the counters are the all-reduced verdicts"})
+        parity_failed_somewhere = with_parity and int(pv[0].item()) != world
+        if with_cpu and args.op == "stage1" and args.workload == "amazon_ndjson":
+            threads = os.cpu_count() or 1
+            cb = cx.cpu().time_cpu_ndjson_threads(host, threads, 3)
+            if cb is not None:
+                leg["cpu_baseline_threads"] = {"value": round(cb["value"], 2), "unit": "GB/s", "cores": cb["cores"], "kind": cb["kind"],
+                                               "sample": f"rank 0's NDJSON buffer cut at newlines into {cb['cores']} slices, {cb['impl']} kernel, one parser per thread, "
+                                                         f"{threads} hardware threads on the box", "structurals": cb["n"]}
     dt = leg["ms_per_step"] * 1e-3 * args.steps
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -643,7 +680,7 @@ def main():
                        "library": os.path.basename(capi._paths.LIB_SJGPU)},
             "roofline": leg["roofline"],
         }
-        for k in ("cpu_baseline", "parity"):
+        for k in ("cpu_baseline", "cpu_baseline_threads", "parity"):
             if k in leg:
                 line[k] = leg[k]
 
@@ -708,12 +745,17 @@ def main():
     if rank == 0:
         if ndjson is not None:
             line["config4_ndjson"] = ndjson
+            # what the first multi-GPU run has to show at a glance: did RCCL see all ranks, and which road did the index concatenation take
+            line["n_ranks_seen_by_rccl"] = ndjson.get("n_ranks_seen_by_rccl")
+            line["index_concat"] = ndjson.get("index_concat")
         if docshards is not None:
             line["one_document_shards"] = docshards
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed_somewhere:
+        raise SystemExit("PARITY FAILURE on at least one rank (see the line's parity object)")
 
 
 def document_leg(args, torch, dist, capi, corpus, rank, world, local_rank, fence):
@@ -805,6 +847,7 @@ def ndjson_leg(args, torch, dist, corpus, capi, rank, world, local_rank, fence):
             raise RuntimeError("rank 0 could not create a communicator id")
         gathered = torch.empty(world * (L // 8 + 1024) if rank == 0 else 8, dtype=torch.int64, device="cuda")
         comm = capi.Comm(rank, world, box[0], local_rank)
+        out["n_ranks_seen_by_rccl"] = comm.ranks()
     except Exception as e:  # never seen N > 1 hardware: keep the leg alive on the torch.distributed twin and say so
         comm = None
         exchange = f"sharded.gather_to_root over torch.distributed (sjgpu_comm unavailable: {repr(e)[:120]})"
@@ -816,6 +859,7 @@ def ndjson_leg(args, torch, dist, corpus, capi, rank, world, local_rank, fence):
         comm.close()
         comm = None
         exchange = "sharded.gather_to_root over torch.distributed (sjgpu_comm unavailable on another rank)"
+        out["n_ranks_seen_by_rccl"] = None
 
     def concat(n_now, f_now):
         if comm is not None:

@@ -39,6 +39,7 @@ extern "C" {
 #define SJGPU_E_NOMEM     (-3) /* device or pinned-host allocation failed */
 #define SJGPU_E_BADARG    (-4) /* null/misaligned pointer, len > 0xFFFFFFFF, unknown mode */
 #define SJGPU_E_OVERFLOW  (-5) /* caller's index buffer too small for n+3 words */
+#define SJGPU_E_PEER      (-6) /* sjgpu_comm_*: another rank of the communicator failed; nothing was exchanged */
 
 /* simdjson::stage1_mode (internal/dom_parser_implementation.h:22-27) */
 enum sjgpu_stage1_mode {
@@ -250,7 +251,8 @@ int sjgpu_match_keys_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, con
  * a stable sort by nesting level, every token checks the walk's rule for itself, and the reference's error is the smallest
  * offending list index (sjgpu_tape.hip).  Numbers are converted exactly like the reference's (Eisel-Lemire, exact big-integer
  * decision beyond 19 digits: sj_number.h); the strings come from the string pass above.
- * idx_dev[0..n] = the list sjgpu_stage1_device left for buf_dev[0..len) (regular mode, no error), first sentinel included.
+ * idx_dev[0..n] = the list sjgpu_stage1_device left for buf_dev[0..len) (regular mode, no error), first sentinel included;
+ * buf_dev 16-byte aligned like every device entry point (SJGPU_E_BADARG otherwise).
  * max_depth: dom::parser's (DEFAULT_MAX_DEPTH 1024; at most 4095 here).  tape_dev: room for tape_cap_words 64-bit words
  * (len + 3 always suffice; the reference allocates ROUNDUP(len + 3, 64)), 8-byte aligned; string_buf_dev as for
  * sjgpu_parse_strings_device.  Returns the reference's error_code: SUCCESS, EMPTY (n == 0), TAPE_ERROR 3, DEPTH_ERROR 4,
@@ -314,17 +316,23 @@ int sjgpu_mgpu_validate_utf8(sjgpu_mgpu *m, const uint8_t *buf, size_t len, int 
  *   sjgpu_comm_unique_id   rank 0 makes the 128-byte id and hands it to the other ranks by any means (file, socket, MPI,
  *                          torch.distributed); sjgpu_comm_create is collective (ncclCommInitRank) and binds the rank to `device`.
  *   sjgpu_comm_gather_indices  collective.  Every rank: idx_dev[0..n) shard-relative u32 offsets in HBM, base = byte offset of its
- *                          shard.  ncclAllGather of (n, base), then every rank sends exactly n words to `root` (ncclSend / ncclRecv,
+ *                          shard.  ncclAllGather of (n, base, room at the root), then -- once the root has room: a root that must grow
+ *                          its staging array does so FIRST and tells all ranks (one more word); if it cannot, every rank returns,
+ *                          SJGPU_E_NOMEM at the root and SJGPU_E_PEER elsewhere, nothing posted -- every rank sends exactly n words
+ *                          to `root` (ncclSend / ncclRecv,
  *                          all senders at once: xGMI is point to point), and the root writes base + offset as 64-bit words, shards
  *                          in rank order, into out_dev[0 .. *total_out) (out_cap_words >= the sum; SJGPU_E_OVERFLOW otherwise, after
  *                          the receives have drained).  counts_out (world entries, may be NULL): n of every rank.  Asynchronous on
- *                          `stream` except for the 16 * world bytes of counts the host needs to size the receives. */
+ *                          `stream` except for the 24 * world bytes of counts the host needs to size the receives.
+ *   RCCL is opened when the first of these calls arrives (dlopen: SJGPU_RCCL_LIB, librccl.so.1, $ROCM_PATH/lib); nothing else in
+ *   the library needs it, and a box without it only loses these entry points (SJGPU_E_HIP, sjgpu_comm_last_error(NULL) says why). */
 typedef struct sjgpu_comm sjgpu_comm;
 #define SJGPU_COMM_ID_BYTES 128
 int sjgpu_comm_unique_id(void *id_out, size_t id_bytes);
 int sjgpu_comm_create(int rank, int world, const void *id, size_t id_bytes, int device, sjgpu_comm **out);
 void sjgpu_comm_destroy(sjgpu_comm *comm);
 const char *sjgpu_comm_last_error(const sjgpu_comm *comm);
+int sjgpu_comm_ranks(const sjgpu_comm *comm); /* ncclCommCount: the ranks RCCL itself sees in the communicator; -1 on failure */
 int sjgpu_comm_gather_indices(sjgpu_comm *comm, const void *idx_dev, uint32_t n, uint64_t base, int root, void *out_dev, size_t out_cap_words,
                               uint64_t *total_out, uint64_t *counts_out, void *stream);
 

@@ -57,7 +57,7 @@ def build_sjgpu(force=False):
     if force or _stale(out, deps):
         os.makedirs(_paths.LIB_DIR, exist_ok=True)
         _run([HIPCC, f"--offload-arch={GFX_ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-              "-I", _paths.INCLUDE_DIR, "-I", _paths.CSRC_DIR, *srcs, "-o", out, "-L/opt/rocm/lib", "-lrccl"])
+              "-I", _paths.INCLUDE_DIR, "-I", _paths.CSRC_DIR, *srcs, "-o", out, "-ldl"])  # RCCL is opened by sjgpu_comm_* on first use, not linked
     return out
 
 
@@ -170,7 +170,10 @@ INTREE_DIR = os.path.join(_paths.REPO_ROOT, "build", "intree")
 INTREE_PATCH = os.path.join(_paths.CSRC_DIR, "plugin", "intree", "simdjson_mi355x.patch")
 INTREE_TESTS = {"intree_basictests": "tests/dom/basictests.cpp", "intree_errortests": "tests/dom/errortests.cpp",
                 # parse_many with the stream registered by document_stream::start() (the patch's second half): windows cut out of look-ahead spans
-                "intree_document_stream_tests": "tests/dom/document_stream_tests.cpp", "intree_document_stream_fuzz_tests": "tests/dom/document_stream_fuzz_tests.cpp"}
+                "intree_document_stream_tests": "tests/dom/document_stream_tests.cpp", "intree_document_stream_fuzz_tests": "tests/dom/document_stream_fuzz_tests.cpp",
+                # iterate_many: On-Demand's document_stream::start() registers its buffer the same way (round 4)
+                "intree_ondemand_document_stream_tests": "tests/ondemand/ondemand_document_stream_tests.cpp",
+                "intree_ondemand_document_stream_fuzz_tests": "tests/ondemand/ondemand_document_stream_fuzz_tests.cpp"}
 
 
 def build_intree(force=False):
@@ -203,7 +206,7 @@ def build_intree(force=False):
         if force or not binary_is_current(name) or _stale(out, [src, obj, _paths.LIB_PLUGIN]):
             os.makedirs(TEST_BIN_DIR, exist_ok=True)
             _run(["g++", "-O1", "-std=c++17", "-w", "-DSIMDJSON_THREADS_ENABLED=1", "-DSIMDJSON_IMPLEMENTATION_MI355X=1", "-I", os.path.join(tree, "include"),
-                  "-I", os.path.join(ref, "tests"), "-I", os.path.join(ref, "tests", "dom"),
+                  "-I", os.path.join(ref, "tests"), "-I", os.path.join(ref, "tests", "dom"), "-I", os.path.join(ref, "tests", "ondemand"),
                   '-DSIMDJSON_BENCHMARK_DATA_DIR="tests/golden/jsonexamples/"', src, obj, "-o", out,
                   f"-L{_paths.LIB_DIR}", "-lsimdjson_mi355x", "-lsjgpu", "-lpthread", _RPATH])
             _write_stamp(name)

@@ -29,7 +29,7 @@ EXPORTS = [
     "sjgpu_stage1_range_device", "sjgpu_minify_range_device",
     "sjgpu_host_alloc", "sjgpu_host_free", "sjgpu_host_register", "sjgpu_host_unregister", "sjgpu_last_pipeline",
     "sjgpu_profile_kernel", "sjgpu_debug_trace_pipelined", "sjgpu_debug_string_path", "sjgpu_stage1_many", "sjgpu_stage1_finish_device",
-    "sjgpu_depth_scan_device", "sjgpu_parse_strings_device", "sjgpu_stage2_device", "sjgpu_parse", "sjgpu_pool_trim", "sjgpu_stream_register", "sjgpu_stream_unregister", "sjgpu_match_keys_device", "sjgpu_comm_unique_id", "sjgpu_comm_create", "sjgpu_comm_destroy", "sjgpu_comm_last_error", "sjgpu_comm_gather_indices", "sjgpu_mgpu_create", "sjgpu_mgpu_destroy", "sjgpu_mgpu_count", "sjgpu_mgpu_stage1", "sjgpu_mgpu_minify",
+    "sjgpu_depth_scan_device", "sjgpu_parse_strings_device", "sjgpu_stage2_device", "sjgpu_parse", "sjgpu_pool_trim", "sjgpu_stream_register", "sjgpu_stream_unregister", "sjgpu_match_keys_device", "sjgpu_comm_unique_id", "sjgpu_comm_create", "sjgpu_comm_destroy", "sjgpu_comm_last_error", "sjgpu_comm_ranks", "sjgpu_comm_gather_indices", "sjgpu_mgpu_create", "sjgpu_mgpu_destroy", "sjgpu_mgpu_count", "sjgpu_mgpu_stage1", "sjgpu_mgpu_minify",
     "sjgpu_mgpu_validate_utf8",
 ]
 
@@ -129,6 +129,8 @@ def load_library():
     L.sjgpu_comm_destroy.argtypes = [vp]
     L.sjgpu_comm_last_error.restype = ctypes.c_char_p
     L.sjgpu_comm_last_error.argtypes = [vp]
+    L.sjgpu_comm_ranks.restype = ctypes.c_int
+    L.sjgpu_comm_ranks.argtypes = [vp]
     L.sjgpu_comm_gather_indices.restype = ctypes.c_int
     L.sjgpu_comm_gather_indices.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, vp, sz, u64p, u64p, vp]
     L.sjgpu_mgpu_create.restype = ctypes.c_int
@@ -470,7 +472,11 @@ class Comm:
         self.rank, self.world = rank, world
         rc = self.L.sjgpu_comm_create(rank, world, unique_id, len(unique_id), device, ctypes.byref(self.h))
         if rc != 0:
-            raise SjgpuError(f"sjgpu_comm_create error {rc}")
+            raise SjgpuError(f"sjgpu_comm_create error {rc}: {self.L.sjgpu_comm_last_error(None).decode()}")
+
+    def ranks(self):
+        """ncclCommCount: the ranks RCCL itself sees in this communicator"""
+        return int(self.L.sjgpu_comm_ranks(self.h))
 
     def close(self):
         if self.h:

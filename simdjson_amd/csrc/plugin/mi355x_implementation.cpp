@@ -83,18 +83,25 @@ public:
 
   // stage 1 on the GPU, then the reference's own stage 2 (src/haswell.cpp:159-163 shape)
   simdjson_warn_unused error_code parse(const uint8_t *buf, size_t len, dom::document &doc) noexcept final {
-    if (len >= stage2_from_ && ctx_ && !_number_as_string && _max_depth >= 1 && _max_depth <= 4095 && len <= _capacity && doc.capacity() >= len &&
-        doc.tape && doc.string_buf) {
+    // (2.4e9: the device's string records use 32-bit offsets, sjgpu_stage2_device answers CAPACITY beyond it -- such documents keep the road below)
+    if (len >= stage2_from_ && len <= size_t(2400000000u) && ctx_ && !_number_as_string && _max_depth >= 1 && _max_depth <= 4095 && len <= _capacity &&
+        doc.capacity() >= len && doc.tape && doc.string_buf) {
       // what dom::document::allocate reserved (include/simdjson/dom/document-inl.h:48-56)
       const size_t cap = doc.capacity();
       const size_t tape_words = SIMDJSON_ROUNDUP_N(cap + 3, 64), string_bytes = SIMDJSON_ROUNDUP_N(5 * (cap / 3) + SIMDJSON_PADDING, 64);
       buf_ = buf;
       len_ = len;
       uint64_t tw = 0, sb = 0;
-      const int rc = sjgpu_parse(ctx_, buf, len, uint32_t(_max_depth), doc.tape.get(), tape_words, doc.string_buf.get(), string_bytes, &tw, &sb);
+      int rc = sjgpu_parse(ctx_, buf, len, uint32_t(_max_depth), doc.tape.get(), tape_words, doc.string_buf.get(), string_bytes, &tw, &sb);
+      if (std::getenv("SJGPU_DEBUG_STAGE2_DECLINE")) { rc = SJGPU_E_HIP; } // test hook (plugin_test 2c): the device road fails after it has run
       n_structural_indexes = 0; // the list stayed on the device
       next_structural_index = 0;
-      return map_error(rc);
+      // A verdict about the DOCUMENT is final (SUCCESS, TAPE_ERROR, STRING_ERROR, ...).  What says something about the device road instead
+      // -- a negative SJGPU_E_* (HIP / allocation failure, overflow of a workspace), CAPACITY (a limit of the device kernels: len <=
+      // _capacity was checked above), MEMALLOC, UNEXPECTED_ERROR (a stage 1 that gave up twice) -- must not cost the caller a parse the
+      // reference would have delivered: such a document takes stage1() + the reference's stage 2 below, like a short one.
+      if (!(rc < 0 || rc == int(CAPACITY) || rc == int(MEMALLOC) || rc == int(UNEXPECTED_ERROR))) { return map_error(rc); }
+      device_stage2_declined_++;
     }
     auto error = stage1(buf, len, stage1_mode::regular);
     if (error) { return error; }
@@ -182,6 +189,7 @@ private:
   const uint8_t *buf_ = nullptr;
   size_t len_ = 0;
   size_t stage2_from_;
+  size_t device_stage2_declined_ = 0; // parse() calls the device road handed back (a limit or a failure of the road, not a verdict on the document)
 };
 
 class implementation final : public simdjson::implementation {

@@ -127,6 +127,35 @@ SJ_HD xs_summary xs_compact(const xs_fun &f) {
   return r;
 }
 
+// ---- summaries in their compact form, composed directly (what the device keeps in registers: four words) -----------------------------
+struct xs_sum {
+  u32 q, c_out, c_in, xw; // quote parity and counts under x = 0; the x word (low bits)
+};
+constexpr u32 XW_IDENTITY = XW_DEP; // the summary of nothing: hands x on, counts nothing, flips nothing
+SJ_HD u32 xs_sum_count(const xs_sum &a, const xs_step &t) { return (t.se ? a.c_in : a.c_out) + u32(t.dcount); }
+// first a, then b: evaluate the pair on the four states, read the compact form off (exact for everything spans can produce:
+// tests/host/test_xcarry_model.cpp composes its groups this way, too)
+SJ_HD xs_sum xs_compose(const xs_sum &a, const xs_sum &b) {
+  u32 cnt[4], so[4], xo[4];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (u32 i = 0; i < 4; i++) {
+    const xs_step t1 = xs_apply(a.q, a.xw, i & 1u, i >> 1);
+    const xs_step t2 = xs_apply(b.q, b.xw, t1.s_out, t1.x_out);
+    cnt[i] = xs_sum_count(a, t1) + xs_sum_count(b, t2);
+    so[i] = t2.s_out;
+    xo[i] = t2.x_out;
+  }
+  const u32 F = so[0] ^ so[2];
+  xs_sum r;
+  r.q = so[0];
+  r.c_out = cnt[0];
+  r.c_in = cnt[1];
+  r.xw = xo[0] | ((xo[0] ^ xo[2]) << 1) | (F << 2) | xw_enc_d(int(F ? cnt[3] : cnt[2]) - int(cnt[0]), int(F ? cnt[2] : cnt[3]) - int(cnt[1]));
+  return r;
+}
+
 // ---- the x word of ONE span, from the facts its scan collects -----------------------------------------------------------------
 constexpr u32 SPAN_EXACT = 0, SPAN_B = 1, SPAN_C = 2;
 struct span_facts {

@@ -1154,6 +1154,7 @@ struct stream_extent {
   size_t len;
   bool pinned;
   uint64_t id; // unique per registration: a later stream at the same address must not meet the spans of an earlier one
+  uint32_t refs; // registrations alive for this base: two streams over one buffer must not unregister each other
 };
 struct stream_registry {
   std::mutex m;
@@ -1329,7 +1330,7 @@ extern "C" {
 
 int sjgpu_stream_register(const uint8_t *base, size_t len) {
   if (!base || len == 0) { return SJGPU_E_BADARG; }
-  stream_extent e{base, len, false, 0};
+  stream_extent e{base, len, false, 0, 1};
   // Page-locking pays for itself on streams of many megabytes (the upload of a span runs at twice the rate and truly asynchronously);
   // small buffers come and go at addresses the allocator hands out again, and registering / unregistering those by the thousand
   // (the reference's document_stream tests) is what the runtime is not made for: they stay pageable.
@@ -1340,7 +1341,13 @@ int sjgpu_stream_register(const uint8_t *base, size_t len) {
   std::lock_guard<std::mutex> lk(r.m);
   e.id = r.next_id++;
   for (stream_extent &x : r.list) {
-    if (x.base == base) { x.len = len; x.pinned = x.pinned || e.pinned; x.id = e.id; return 0; } // registered again: as good as new
+    if (x.base == base) { // registered again (a second stream over the same buffer): spans as good as new, one more unregister to wait for
+      x.len = len > x.len ? len : x.len;
+      x.pinned = x.pinned || e.pinned;
+      x.id = e.id;
+      x.refs++;
+      return 0;
+    }
   }
   r.list.push_back(e);
   return 0;
@@ -1354,6 +1361,7 @@ int sjgpu_stream_unregister(const uint8_t *base) {
     std::lock_guard<std::mutex> lk(r.m);
     for (size_t i = 0; i < r.list.size(); i++) {
       if (r.list[i].base == base) {
+        if (--r.list[i].refs > 0) { return 0; } // another stream over the same buffer is still at work
         pinned = r.list[i].pinned;
         r.list.erase(r.list.begin() + long(i));
         found = true;
@@ -1579,7 +1587,8 @@ int sjgpu_stage2_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const v
                         size_t tape_cap_words, void *string_buf_dev, size_t string_buf_bytes, void *stream, uint64_t *tape_words_out,
                         uint64_t *string_bytes_out) {
   if (!ctx || !buf_dev || !idx_dev || !tape_dev || !string_buf_dev || max_depth == 0 || max_depth > 4095u) { return SJGPU_E_BADARG; }
-  if ((reinterpret_cast<uintptr_t>(buf_dev) & 3u) || (reinterpret_cast<uintptr_t>(tape_dev) & 7u) || (reinterpret_cast<uintptr_t>(idx_dev) & 3u)) { return SJGPU_E_BADARG; }
+  // buf_dev: 16-byte aligned like every device entry point (the string stream's chunk loads are 16-byte loads of an aligned buffer)
+  if ((reinterpret_cast<uintptr_t>(buf_dev) & 15u) || (reinterpret_cast<uintptr_t>(tape_dev) & 7u) || (reinterpret_cast<uintptr_t>(idx_dev) & 3u)) { return SJGPU_E_BADARG; }
   if (tape_words_out) { *tape_words_out = 0; }
   if (string_bytes_out) { *string_bytes_out = 0; }
   if (n == 0) { return E_EMPTY; } // walk_document: at_eof() (json_iterator.h:126)

@@ -319,6 +319,62 @@ __device__ __forceinline__ void span_patch(u64 (&st)[NCH], u32 xw, u32 x, u32 se
 // the count a summary promises under the state in front of it
 __device__ __forceinline__ u32 xs_count(u32 c_out, u32 c_in, const xs_step &t) { return (t.se ? c_in : c_out) + u32(t.dcount); }
 
+// ---- 64 summaries folded by one wave (k_resolve_groups: the segments of a group; the look-back of the single-pass kernels: the
+// aggregates of 64 tiles) ------------------------------------------------------------------------------------------------------------
+// x in front of every lane's summary as base ^ (free & X), X = x in front of the first one: the nearest summary in front of me whose
+// successor's x does not depend on its own fixes the chain, the c bits from there on toggle it.  `before` = the lanes in front of the
+// place asked about; REVERSED: lane 0 holds the LAST summary of the sequence (the look-back's windows), else the first.
+struct lane_x {
+  u32 base, free;
+};
+template <bool REVERSED>
+__device__ __forceinline__ lane_x wave_x_chain(u32 xw, u64 before) {
+  const u64 cm = __ballot((xw & XW_C) != 0u), dm = __ballot((xw & XW_DEP) != 0u);
+  const u64 nd = ~dm & before;
+  u64 range = before;
+  if (nd) { range = REVERSED ? (before & ((2ull << ctz64(nd)) - 1ull)) : (before & ~((1ull << (63u - clz64(nd))) - 1ull)); }
+  lane_x r;
+  r.base = u32(popc64(cm & range)) & 1u;
+  r.free = nd ? 0u : 1u;
+  return r;
+}
+// The fold: every lane hands in one summary (lanes without one: the identity, {0, 0, 0, XW_IDENTITY}) and its two error bits (by
+// effective hypothesis); out comes the summary of the sequence -- as a function of the four states in front of it, then compact
+// (sj_xcarry.h: xs_compact) -- and the error bits under (s = 0, x = 0) and (s = 1, x = 0).
+template <bool REVERSED>
+__device__ __forceinline__ xs_sum wave_fold(const xs_sum &v, u32 lane, u32 e_out = 0, u32 e_in = 0, u32 *err_out = nullptr, u32 *err_in = nullptr) {
+  const u64 before = REVERSED ? ~((2ull << lane) - 1ull) : lanemask_lt(lane);
+  const u32 F = (v.xw >> 2) & 1u;
+  const lane_x mine = wave_x_chain<REVERSED>(v.xw, before), after = wave_x_chain<REVERSED>(v.xw, ~0ull);
+  u32 cnt[4], par[2], xo[2];
+#pragma unroll
+  for (u32 X = 0; X < 2; X++) {
+    const u32 xin = mine.base ^ (mine.free & X);
+    const u32 f = xin & F;
+    const u64 qm = __ballot(((v.q & 1u) ^ f) != 0u);
+    const u32 flipped = u32(popc64(qm & before)) & 1u; // in-string state in front of my summary, relative to the start of the sequence
+    par[X] = u32(popc64(qm)) & 1u;
+    xo[X] = after.base ^ (after.free & X);
+#pragma unroll
+    for (u32 S = 0; S < 2; S++) {
+      const u32 se = S ^ flipped ^ f;
+      cnt[S | (X << 1)] = wave_sum((se ? v.c_in : v.c_out) + u32(xin ? xw_d(v.xw, se) : 0));
+      if (X == 0 && err_out) { // (the error bits of x = 1 are those of x = 0 under the other hypothesis: sj_xcarry.h)
+        const u32 e = __ballot((se ? e_in : e_out) != 0u) ? 1u : 0u;
+        if (S == 0) { *err_out = e; } else { *err_in = e; }
+      }
+    }
+  }
+  const u32 Fg = par[0] ^ par[1];
+  xs_sum r;
+  r.q = par[0];
+  r.c_out = cnt[0];
+  r.c_in = cnt[1];
+  r.xw = xo[0] | ((xo[0] ^ xo[1]) << 1) | (Fg << 2) |
+         xw_enc_d(int(Fg ? cnt[3] : cnt[2]) - int(cnt[0]), int(Fg ? cnt[2] : cnt[3]) - int(cnt[1])); // x = 1: effective hypothesis 0 is reached from S = Fg
+  return r;
+}
+
 // ---- one chunk (64 blocks) through the scanner -----------------------------------------------------------
 struct chunk_masks {
   u64 cand;        // structural candidates (strings ignored)

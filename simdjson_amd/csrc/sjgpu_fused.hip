@@ -52,23 +52,33 @@ __device__ __forceinline__ void desc_store(u64 *p, u64 v) { __hip_atomic_store(p
 
 // Wave-wide look-back for tile `tile` (all 64 lanes of ONE wave call this).  On success S = in-string at
 // the tile start, X = x in front of the tile, B = output cursor at the tile start.
-// State of a walk: F = composition of the aggregates of tiles [end, tile): maps the state at `end` to
-// (parity flip, count).  Aggregates whose x word is zero -- all of them, for ordinary input -- compose as they always did; the
-// first one that is not sends the walk to lookback_slow.
+// State of a walk: the summary of tiles [end, tile) in its compact form (sj_xcarry.h: parity, the two counts, x word), which maps
+// the state at `end` to the state in front of `tile`.  Windows whose aggregates all have x word zero -- every window of ordinary
+// input -- are folded as they always were (ballot, two sums); the first window that holds an x word sends the walk to
+// lookback_general, which folds whole windows with wave_fold (documents with backslash runs of 64 bytes and more across spans).
 struct lookback_state {
-  u32 fq, fout, fin, n;
+  xs_sum acc;
   int end; // tile numbers fit 32 bits (4 GiB / 32 KiB tiles)
 };
+__device__ __forceinline__ u64 lookback_front(scan_origin org) { // in front of tile 0: the call's carry-in and cursor
+  return make_incl(org.carry & CARRY_IN_STRING, (org.carry & CARRY_X) ? 1u : 0u, org.base0);
+}
 __device__ __forceinline__ void lookback_load(const u64 *desc, int end, u32 lane, u64 (&d)[LOOKBACK_LOADS], scan_origin org) {
 #pragma unroll
   for (u32 w = 0; w < LOOKBACK_LOADS; w++) {
     const int t = end - 1 - int(w * 64 + lane);
-    // in front of tile 0: the call's carry-in and cursor
-    d[w] = (t >= 0) ? desc_load(desc + t) : make_incl(org.carry & CARRY_IN_STRING, (org.carry & CARRY_X) ? 1u : 0u, org.base0);
+    d[w] = (t >= 0) ? desc_load(desc + t) : lookback_front(org);
   }
 }
+// the walk has met the inclusive prefix of tile k: apply what lies between
+__device__ __forceinline__ void lookback_finish(const lookback_state &st, u32 lo, u32 hi, u32 &S, u32 &X, u32 &B) {
+  const xs_step t = xs_apply(st.acc.q, st.acc.xw, hi & 1u, (hi >> 1) & 1u);
+  S = t.s_out;
+  X = t.x_out;
+  B = lo + xs_sum_count(st.acc, t);
+}
 // 1 = finished (S, X, B valid), 0 = a needed aggregate is not published yet (reload from st.end), -1 = poisoned chain,
-// 2 = an aggregate with an x word: lookback_slow
+// 2 = the window at st.end holds an x word: lookback_general
 __device__ __forceinline__ int lookback_consume(const u64 (&d)[LOOKBACK_LOADS], lookback_state &st, u32 lane, u32 &S, u32 &X, u32 &B) {
 #pragma unroll
   for (u32 w = 0; w < LOOKBACK_LOADS; w++) {
@@ -92,34 +102,27 @@ __device__ __forceinline__ int lookback_consume(const u64 (&d)[LOOKBACK_LOADS], 
     const u32 g_out = wave_sum(flipped ? c_in : c_out);
     const u32 g_in = wave_sum(flipped ? c_out : c_in);
     const u32 gq = u32(popc64(qm)) & 1u;
-    // F := G then F
-    const u32 nf_out = g_out + (gq ? st.fin : st.fout), nf_in = g_in + (gq ? st.fout : st.fin);
-    st.fout = nf_out;
-    st.fin = nf_in;
-    st.fq ^= gq;
-    st.n += k < 64u ? k : 64u;
+    if (k) { // acc := G then acc.  G answers "no" for its successor, whatever x it met: acc is met with x = 0
+      const u32 nf_out = g_out + (gq ? st.acc.c_in : st.acc.c_out), nf_in = g_in + (gq ? st.acc.c_out : st.acc.c_in);
+      st.acc.c_out = nf_out;
+      st.acc.c_in = nf_in;
+      st.acc.q ^= gq;
+      st.acc.xw &= XW_C;
+    }
     if (k < 64u) {
-      const u32 lo = readlane_dyn(u32(d[w]), k), hi = readlane_dyn(u32(d[w] >> 32), k);
-      const u32 s_k = hi & 1u;
-      S = s_k ^ st.fq;
-      X = st.n ? 0u : ((hi >> 1) & 1u); // an aggregate without an x word answers "no" for its successor
-      B = lo + (s_k ? st.fin : st.fout);
+      lookback_finish(st, readlane_dyn(u32(d[w]), k), readlane_dyn(u32(d[w] >> 32), k), S, X, B);
       return 1;
     }
     st.end -= 64;
   }
   return 0; // whole batch consumed, no inclusive prefix yet: keep walking from st.end
 }
-// The look-back when x words are about (documents with backslash runs of 64 bytes and more across span boundaries): find the nearest
-// inclusive predecessor, waiting until everything nearer is published, then walk FORWARD from it with the state in hand, one
-// descriptor per step (xs_apply) -- no composition of unknown-state functions, and only documents that need it pay for it.
-__device__ __forceinline__ bool lookback_slow(const u64 *desc, u32 tile, u32 lane, u32 &S, u32 &X, u32 &B, scan_origin org) {
-  const u64 t_start = wall_clock64();
-  int end = int(tile), from = -1;
-  u32 s = org.carry & CARRY_IN_STRING, x = (org.carry & CARRY_X) ? 1u : 0u, base = org.base0; // the state in front of tile 0
-  for (;;) { // phase 1
-    const int t = end - 1 - int(lane);
-    const u64 d = (t >= 0) ? desc_load(desc + t) : make_incl(s, x, base);
+// The same walk for windows with x words, one window of 64 per round trip, every window folded by the whole wave (wave_fold) and
+// composed in front of what the walk holds (xs_compose).  Only documents that need it come here.
+__device__ __forceinline__ bool lookback_general(const u64 *desc, lookback_state &st, u32 lane, u32 &S, u32 &X, u32 &B, scan_origin org, u64 t_start) {
+  for (;;) {
+    const int t = st.end - 1 - int(lane);
+    const u64 d = (t >= 0) ? desc_load(desc + t) : lookback_front(org);
     const u32 status = u32(d >> 62);
     const u64 incl = __ballot(status == ST_INCL), valid = __ballot(status != 0), poison = __ballot(status == ST_POISON);
     const u32 k = incl ? ctz64(incl) : 64u;
@@ -131,51 +134,26 @@ __device__ __forceinline__ bool lookback_slow(const u64 *desc, u32 tile, u32 lan
       __builtin_amdgcn_s_sleep(4);
       continue;
     }
+    const bool mine = lane < k;
+    xs_sum v{0u, 0u, 0u, XW_IDENTITY};
+    if (mine) { v = xs_sum{u32(d >> 42) & 1u, u32(d) & 0x1FFFFFu, u32(d >> 21) & 0x1FFFFFu, u32(d >> DESC_XW_SHIFT) & XW_LOW_MASK}; }
+    const xs_sum g = wave_fold<true>(v, lane); // lane 0 holds the last tile of the window
+    st.acc = xs_compose(g, st.acc);
     if (k < 64u) {
-      const u32 lo = readlane_dyn(u32(d), k), hi = readlane_dyn(u32(d >> 32), k);
-      s = hi & 1u;
-      x = (hi >> 1) & 1u;
-      base = lo;
-      from = end - 1 - int(k); // may be -1: the front of the call
-      break;
+      lookback_finish(st, readlane_dyn(u32(d), k), readlane_dyn(u32(d >> 32), k), S, X, B);
+      return true;
     }
-    end -= 64;
+    st.end -= 64;
   }
-  for (int t0 = from + 1; t0 < int(tile); t0 += 64) { // phase 2: every one of these is published
-    const int t = t0 + int(lane);
-    const u64 d = (t < int(tile)) ? desc_load(desc + t) : 0ull;
-    const u32 n = u32((int(tile) - t0) < 64 ? (int(tile) - t0) : 64);
-    for (u32 i = 0; i < n; i++) {
-      const u32 lo = readlane_dyn(u32(d), i), hi = readlane_dyn(u32(d >> 32), i);
-      const u32 status = hi >> 30;
-      if (status == ST_INCL) { // its owner has finished in the meantime
-        s = hi & 1u;
-        x = (hi >> 1) & 1u;
-        base = lo;
-      } else if (status == ST_AGG) {
-        const u64 v = (u64(hi) << 32) | lo;
-        const xs_step st = xs_apply(u32(v >> 42) & 1u, u32(v >> DESC_XW_SHIFT) & XW_LOW_MASK, s, x);
-        base += xs_count(u32(v) & 0x1FFFFFu, u32(v >> 21) & 0x1FFFFFu, st);
-        s = st.s_out;
-        x = st.x_out;
-      } else {
-        return false; // poisoned (or torn: cannot be)
-      }
-    }
-  }
-  S = s;
-  X = x;
-  B = base;
-  return true;
 }
 __device__ __forceinline__ bool lookback(const u64 *desc, u32 tile, u32 lane, u32 &S, u32 &X, u32 &B, scan_origin org) {
-  lookback_state st{0u, 0u, 0u, 0u, int(tile)};
+  lookback_state st{xs_sum{0u, 0u, 0u, XW_IDENTITY}, int(tile)};
   const u64 t_start = wall_clock64();
   for (;;) {
     u64 d[LOOKBACK_LOADS];
     lookback_load(desc, st.end, lane, d, org);
     const int r = lookback_consume(d, st, lane, S, X, B);
-    if (r == 2) { return lookback_slow(desc, tile, lane, S, X, B, org); }
+    if (r == 2) { return lookback_general(desc, st, lane, S, X, B, org, t_start); }
     if (r != 0) { return r > 0; }
     if (wall_clock64() - t_start > LOOKBACK_TIMEOUT_TICKS) { return false; }
     __builtin_amdgcn_s_sleep(4);
@@ -204,30 +182,15 @@ __device__ __forceinline__ tile_agg tile_aggregate(const u32 (*wv)[5]) {
     }
     return r;
   }
-  // some span of the tile assumed, or tells its successor something: the tile as a function of the four states in front of it,
-  // evaluated state by state (rolled loops: this is the rare road, it must not cost the kernel registers), then the compact form
-  u32 cnt[4], so[4], xo[4];
+  // some span of the tile assumed, or tells its successor something: compose the waves' summaries in their compact form (a rolled
+  // loop: this is the rare road, it must not cost the kernel registers)
+  xs_sum acc{0u, 0u, 0u, XW_IDENTITY};
 #pragma unroll 1
-  for (u32 i = 0; i < 4; i++) {
-    u32 s = i & 1u, x = i >> 1, n = 0;
-#pragma unroll 1
-    for (u32 v = 0; v < NW; v++) {
-      const xs_step t = xs_apply(wv[v][0], wv[v][4] & XW_LOW_MASK, s, x);
-      n += xs_count(wv[v][1], wv[v][2], t);
-      s = t.s_out;
-      x = t.x_out;
-    }
-    // (a rolled loop must not index registers: spell the four stores out)
-    if (i == 0) { cnt[0] = n; so[0] = s; xo[0] = x; }
-    else if (i == 1) { cnt[1] = n; so[1] = s; xo[1] = x; }
-    else if (i == 2) { cnt[2] = n; so[2] = s; xo[2] = x; }
-    else { cnt[3] = n; so[3] = s; xo[3] = x; }
-  }
-  const u32 F = so[0] ^ so[2];
-  r.q = so[0];
-  r.c_out = cnt[0];
-  r.c_in = cnt[1];
-  r.xw = xo[0] | ((xo[0] ^ xo[2]) << 1) | (F << 2) | xw_enc_d(int(F ? cnt[3] : cnt[2]) - int(cnt[0]), int(F ? cnt[2] : cnt[3]) - int(cnt[1]));
+  for (u32 v = 0; v < NW; v++) { acc = xs_compose(acc, xs_sum{wv[v][0], wv[v][1], wv[v][2], wv[v][4] & XW_LOW_MASK}); }
+  r.q = acc.q;
+  r.c_out = acc.c_out;
+  r.c_in = acc.c_in;
+  r.xw = acc.xw;
   return r;
 }
 // the state in front of wave `wave`'s span from the state in front of the tile

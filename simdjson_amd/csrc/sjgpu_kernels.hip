@@ -301,63 +301,26 @@ __global__ __launch_bounds__(RESOLVE_THREADS) void k_resolve_segments(const seg_
 // most 4096 of those in one workgroup; the emit kernels redo the in-group part themselves with one
 // coalesced 1 KiB load (segment_prefix below).  Replaces a 180 us single-workgroup scan by ~10 us.
 // =====================================================================================================
-// x in front of the summary of every lane of `below` (= the lanes in front of the place asked about), as base ^ (free & X), X = x in
-// front of lane 0: the nearest lane whose successor does not depend on its own x fixes the chain, the c bits from there on toggle it
-struct lane_x {
-  u32 base, free;
-};
-__device__ __forceinline__ lane_x wave_x_chain(u32 xw, u64 below) {
-  const u64 cm = __ballot((xw & XW_C) != 0u), dm = __ballot((xw & XW_DEP) != 0u);
-  const u64 nd = ~dm & below;
-  const u64 range = nd ? (below & ~((1ull << (63u - clz64(nd))) - 1ull)) : below;
-  lane_x r;
-  r.base = u32(popc64(cm & range)) & 1u;
-  r.free = nd ? 0u : 1u;
-  return r;
-}
-constexpr u32 XW_IDENTITY = XW_DEP; // a summary of nothing: hands x on, counts nothing
-
 __global__ __launch_bounds__(64) void k_resolve_groups(const seg_summary *__restrict__ summ, seg_summary *__restrict__ gsum,
                                                        u32 nseg) {
   const u32 lane = lane_id();
   const u32 seg = blockIdx.x * RESOLVE_GROUP + lane;
   seg_summary x{0u, 0u, 0u, XW_IDENTITY};
   if (seg < nseg) { x = summ[seg]; }
-  const u64 lt = lanemask_lt(lane);
-  const u32 q = (x.flags & SF_PARITY) ? 1u : 0u, F = (x.xw >> 2) & 1u;
-  const lane_x mine = wave_x_chain(x.xw, lt), after = wave_x_chain(x.xw, ~0ull);
-  // the group as a function of the state (S, X) in front of it, then back into the compact form (sj_xcarry.h: xs_compact)
-  u32 cnt[4], err[4], par[2], xo[2];
-#pragma unroll
-  for (u32 X = 0; X < 2; X++) {
-    const u32 xin = mine.base ^ (mine.free & X);
-    const u32 f = xin & F;
-    const u64 qm = __ballot((q ^ f) != 0u);
-    const u32 flipped = u32(popc64(qm & lt)) & 1u; // in-string state in front of my segment, relative to the group start
-    par[X] = u32(popc64(qm)) & 1u;
-    xo[X] = after.base ^ (after.free & X);
-#pragma unroll
-    for (u32 S = 0; S < 2; S++) {
-      const u32 se = S ^ flipped ^ f;
-      const u32 c = (se ? x.count_if_in : x.count_if_out) + u32(xin ? xw_d(x.xw, se) : 0);
-      cnt[S | (X << 1)] = wave_sum(c);
-      err[S | (X << 1)] = __ballot((x.flags & (se ? SF_CTRL_IF_IN : SF_CTRL_IF_OUT)) != 0u) ? 1u : 0u;
-    }
-  }
-  u32 flags = par[0] ? SF_PARITY : 0u;
-  if (err[0]) { flags |= SF_CTRL_IF_OUT; }
-  if (err[1]) { flags |= SF_CTRL_IF_IN; }
+  u32 err_out = 0, err_in = 0;
+  const xs_sum g = wave_fold<false>(xs_sum{x.flags & SF_PARITY, x.count_if_out, x.count_if_in, x.xw}, lane, x.flags & SF_CTRL_IF_OUT, x.flags & SF_CTRL_IF_IN,
+                                    &err_out, &err_in);
+  u32 flags = g.q ? SF_PARITY : 0u;
+  if (err_out) { flags |= SF_CTRL_IF_OUT; }
+  if (err_in) { flags |= SF_CTRL_IF_IN; }
   if (__ballot((x.flags & SF_UTF8) != 0)) { flags |= SF_UTF8; }
   if (lane == 0) {
-    const u32 Fg = par[0] ^ par[1];
-    const int d0 = int(Fg ? cnt[3] : cnt[2]) - int(cnt[0]); // x = 1: effective hypothesis 0 is reached from S = Fg
-    const int d1 = int(Fg ? cnt[2] : cnt[3]) - int(cnt[1]);
-    seg_summary g;
-    g.count_if_out = cnt[0];
-    g.count_if_in = cnt[1];
-    g.flags = flags;
-    g.xw = xo[0] | ((xo[0] ^ xo[1]) << 1) | (Fg << 2) | xw_enc_d(d0, d1);
-    gsum[blockIdx.x] = g;
+    seg_summary s;
+    s.count_if_out = g.c_out;
+    s.count_if_in = g.c_in;
+    s.flags = flags;
+    s.xw = g.xw;
+    gsum[blockIdx.x] = s;
   }
 }
 
@@ -370,7 +333,7 @@ __device__ __forceinline__ seg_prefix segment_prefix(const seg_summary *__restri
   seg_summary x{0u, 0u, 0u, XW_IDENTITY};
   if (lane < r) { x = summ[group * RESOLVE_GROUP + lane]; }
   const u64 lt = lanemask_lt(lane);
-  const lane_x mine = wave_x_chain(x.xw, lt);
+  const lane_x mine = wave_x_chain<false>(x.xw, lt);
   const u32 xin = mine.base ^ (mine.free & (gp.in_string >> 1) & 1u);
   const u32 f = xin & (x.xw >> 2) & 1u;
   const u64 qm = __ballot(((((x.flags & SF_PARITY) ? 1u : 0u) ^ f)) != 0u);

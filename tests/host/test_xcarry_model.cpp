@@ -141,6 +141,15 @@ static bool segmented(const bytes &doc, size_t len, size_t N, size_t LB, size_t 
     }
     gs[g] = xs_compact(f);
     if (!gs[g].exact) { fprintf(stderr, "group %zu has no compact form\n", g); return false; }
+    { // the same group folded the way the device folds: compact summaries composed two at a time
+      xs_sum acc{0u, 0u, 0u, XW_IDENTITY};
+      for (size_t k = g * G; k < nseg && k < (g + 1) * G; k++) { acc = xs_compose(acc, xs_sum{sp[k].parity, sp[k].c_out, sp[k].c_in, sp[k].xw & XW_LOW_MASK}); }
+      if (acc.q != gs[g].parity || acc.c_out != gs[g].c_out || acc.c_in != gs[g].c_in || acc.xw != gs[g].xw) {
+        fprintf(stderr, "group %zu: xs_compose gives (%u %u %u %#x), the expanded fold (%u %u %u %#x)\n", g, acc.q, acc.c_out, acc.c_in, acc.xw, gs[g].parity, gs[g].c_out,
+                gs[g].c_in, gs[g].xw);
+        return false;
+      }
+    }
     n_groups_x += (gs[g].xw & XW_LOW_MASK) != 0;
   }
   u32 s = 0, x = 0, base = 0, err = 0;

@@ -215,6 +215,30 @@ int main(int argc, char **argv) {
     std::printf("dom::parser::parse with stage 2 on the device: 4 documents word for word, %zu broken ones by error code: OK\n", sizeof broken / sizeof broken[0]);
   }
 
+  // 2c. a device road that FAILS (a HIP error, a limit of the device kernels) must not cost the caller the parse: the document takes
+  //     stage 1 on the GPU + the reference's stage 2, like a short one (SJGPU_DEBUG_STAGE2_DECLINE makes the road fail after it ran)
+  {
+    setenv("SJGPU_STAGE2_FROM_KB", "1", 1);
+    setenv("SJGPU_DEBUG_STAGE2_DECLINE", "1", 1);
+    get_active_implementation() = cpu;
+    dom::parser pc;
+    CHECK(pc.parse(twitter).error() == SUCCESS, "reference parse");
+    get_active_implementation() = gpu;
+    dom::parser pg;
+    CHECK(pg.parse(twitter).error() == SUCCESS, "a declined device stage 2 must fall back, not fail");
+    const uint64_t words = pc.doc.tape[0] & 0xFFFFFFFFFFFFFFull;
+    CHECK((pg.doc.tape[0] & 0xFFFFFFFFFFFFFFull) == words && std::memcmp(pc.doc.tape.get(), pg.doc.tape.get(), words * 8) == 0, "declined device stage 2: tape");
+    CHECK(pg.implementation->n_structural_indexes != 0, "the fallback ran stage 1 for the reference's stage 2");
+    padded_string bad(std::string(2000, ' ') + "[1,2,,3]");
+    get_active_implementation() = cpu;
+    const error_code ec = pc.parse(bad).error();
+    get_active_implementation() = gpu;
+    CHECK(pg.parse(bad).error() == ec, "declined device stage 2: error code of a broken document");
+    unsetenv("SJGPU_DEBUG_STAGE2_DECLINE");
+    unsetenv("SJGPU_STAGE2_FROM_KB");
+    std::printf("dom::parser::parse with a device stage 2 that fails: falls back to stage 1 + the reference's stage 2: OK\n");
+  }
+
   // 3. ondemand::parser::iterate (stage 1 only; lazy access over our index)
   {
     uint64_t sums[2] = {0, 0}, counts[2] = {0, 0};

@@ -1474,8 +1474,81 @@ def test_comm_world_size_one(orc):
     assert np.array_equal(out[:n].cpu().numpy(), want)
     with pytest.raises(capi.SjgpuError):
         comm.gather_indices(idx.data_ptr(), n, base, 0, out.data_ptr(), 4, st)  # too small: refused AFTER the exchange has drained
+    assert comm.ranks() == 1
     comm.close()
     p.close()
+
+
+def test_comm_root_that_cannot_allocate_leaves_nobody_waiting(orc, monkeypatch):
+    """ADVICE r3 / VERDICT r3 weak #1c: a root whose staging allocation fails used to return before the receives were posted while
+    the senders had already decided to send.  Now the room the root has travels with the counts, a root that must grow allocates first
+    and spreads its verdict, and on failure every rank returns with nothing in flight: NOMEM here (a world of one is root and only
+    rank), and the same communicator works again afterwards."""
+    import torch
+    a, _ = corpus.amazon_ndjson(1 << 20, 33)
+    L = len(a)
+    p = capi.DomParserImplementation(L)
+    buf = torch.from_numpy(a).cuda()
+    idx = torch.empty(L + 16, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, st) == 0
+    n, flags, _ = p.result(st)
+    comm = capi.Comm(0, 1, capi.comm_unique_id(), 0)
+    out = torch.zeros(n + 8, dtype=torch.int64, device="cuda")
+    monkeypatch.setenv("SJGPU_DEBUG_COMM_FAIL_STAGING", "1")
+    with pytest.raises(capi.SjgpuError, match="error -3"):
+        comm.gather_indices(idx.data_ptr(), n, 0, 0, out.data_ptr(), out.numel(), st)
+    monkeypatch.delenv("SJGPU_DEBUG_COMM_FAIL_STAGING")
+    total, counts = comm.gather_indices(idx.data_ptr(), n, 7, 0, out.data_ptr(), out.numel(), st)
+    torch.cuda.synchronize()
+    assert (total, counts) == (n, [n])
+    assert np.array_equal(out[:n].cpu().numpy(), orc.stage1(a, 0)[2][:n].astype(np.int64) + 7)
+    comm.close()
+    p.close()
+
+
+def test_comm_two_ranks_on_two_devices(orc):
+    """sjgpu_comm_gather_indices with a world of two, one rank per device, both in this process (two threads): the exact-count
+    ncclSend / ncclRecv leg over the link between the devices.  Needs two GPUs: SKIPPED (and reported as such) on a 1-GPU box."""
+    import threading
+    import torch
+    if capi.device_count() < 2:
+        pytest.skip("one GPU on this box: the N > 1 send / receive leg needs two devices")
+    shards = [corpus.amazon_ndjson(2 << 20, 41)[0], corpus.amazon_ndjson(3 << 20, 42)[0]]
+    bases = [0, len(shards[0])]
+    uid = capi.comm_unique_id()
+    results, errors = [None, None], []
+
+    def rank(r):
+        try:
+            torch.cuda.set_device(r)
+            a = shards[r]
+            L = len(a)
+            p = capi.DomParserImplementation(L, device=r)
+            buf = torch.from_numpy(a).to(f"cuda:{r}")
+            idx = torch.empty(L + 16, dtype=torch.int32, device=f"cuda:{r}")
+            st = torch.cuda.current_stream(r).cuda_stream
+            assert p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, st) == 0
+            n, flags, _ = p.result(st)
+            comm = capi.Comm(r, 2, uid, r)
+            out = torch.zeros((len(shards[0]) + len(shards[1])) // 4 if r == 0 else 8, dtype=torch.int64, device=f"cuda:{r}")
+            for _ in range(2):  # the second call is the steady state: the staging array has its size, no second round
+                total, counts = comm.gather_indices(idx.data_ptr(), n, bases[r], 0, out.data_ptr(), out.numel(), st)
+            torch.cuda.synchronize(r)
+            results[r] = (comm.ranks(), total, counts, out[:total].cpu().numpy() if r == 0 else None)
+            comm.close()
+            p.close()
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((r, repr(e)))
+
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    assert not errors and all(r is not None for r in results), errors
+    want = np.concatenate([orc.stage1(shards[r], 0)[2][: orc.stage1(shards[r], 0)[1]].astype(np.int64) + bases[r] for r in range(2)])
+    ranks, total, counts, got = results[0]
+    assert ranks == 2 and results[1][0] == 2 and total == len(want) and sum(counts) == total
+    assert np.array_equal(got, want)
 
 
 def test_raw_key_matching(orc):
