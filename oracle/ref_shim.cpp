@@ -199,6 +199,30 @@ double sjref_bench_stage2(const char *impl_name, const uint8_t *buf, size_t len,
   return best;
 }
 
+// dom::parser::parse the way the reference's benchmarker times it (/root/reference/benchmark/benchmarker.h:315-346: one parser and
+// one document allocated up front, the same buffer parsed again and again): stage 1 + stage 2 of the named kernel on one core, best
+// seconds over `iters` runs after a warm one; negative on failure.  bench.py's plugin_host_path.dom_parse leg times the plug-in's
+// two roads beside it.
+double sjref_bench_parse(const char *impl_name, const uint8_t *buf, size_t len, int iters, int *err_out) {
+  auto impl = find_impl(impl_name);
+  if (!impl) { return -1.0; }
+  std::unique_ptr<dom_parser_implementation> p;
+  if (impl->create_dom_parser_implementation(len ? len : 1, 1024, p) != simdjson::SUCCESS) { return -2.0; }
+  simdjson::dom::document doc;
+  if (doc.allocate(len) != simdjson::SUCCESS) { return -2.0; }
+  double best = 1e300;
+  simdjson::error_code err = simdjson::SUCCESS;
+  for (int it = 0; it < iters + 1; it++) {
+    auto t0 = std::chrono::steady_clock::now();
+    err = p->parse(buf, len, doc);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (it > 0 && dt < best) { best = dt; }
+    if (err != simdjson::SUCCESS) { break; }
+  }
+  if (err_out) { *err_out = int(err); }
+  return best;
+}
+
 // On-Demand's raw key comparison: ondemand::raw_json_string::unsafe_is_equal(length, target) of the builtin kernel
 // (/root/reference/include/simdjson/generic/ondemand/raw_json_string-inl.h:66-69).  raw points behind the opening quote.
 int sjref_raw_key_equal(const uint8_t *raw, size_t length, const uint8_t *target, size_t m) {

@@ -17,6 +17,17 @@ __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ u64 lanemask_lt(u32 lane) { return (1ull << lane) - 1ull; }
 __device__ __forceinline__ u32 readlane(u32 v, int l) { return u32(__builtin_amdgcn_readlane(int(v), l)); }
 __device__ __forceinline__ u32 readlane_dyn(u32 v, u32 l) { return u32(__builtin_amdgcn_readlane(int(v), int(l))); }
+// v_ffbl_b32 as the hardware has it: the lowest set bit, 0xFFFFFFFF for zero -- no select around it (__ffs defines the zero case
+// and costs one), no undefined behaviour the compiler could build on (__builtin_ctz)
+__device__ __forceinline__ u32 ffbl_raw(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u32 r;
+  asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+#else
+  return x ? u32(__builtin_ctz(x)) : 0xFFFFFFFFu;
+#endif
+}
 __device__ __forceinline__ u32 clz64(u64 x) { return u32(__clzll((long long)x)); }      // x != 0
 __device__ __forceinline__ u32 ctz64(u64 x) { return u32(__ffsll((long long)x) - 1); } // x != 0
 
@@ -417,7 +428,8 @@ __device__ __forceinline__ u32 utf8_pending_from(u32 lookback_byte, u32 lane) {
   return (__ballot(lane < 3u && lookback_byte >= 0x80u) != 0) ? 1u : 0u;
 }
 // a chunk with many non-ASCII blocks, checked in line from its bit planes (what k_validate_utf8 does for every chunk)
-__device__ __forceinline__ void utf8_dense_chunk(utf8_queue &uq, const planes &P, u32 block0, u32 lane) {
+template <class Q>
+__device__ __forceinline__ void utf8_dense_chunk(Q &uq, const planes &P, u32 block0, u32 lane) {
   const utf8_leads L = utf8_classify(P);
   const u32 co = utf8_carry_out(L);
   u32 ci = __shfl_up(co, 1);
@@ -526,13 +538,101 @@ __device__ __forceinline__ void utf8_drain_rest(utf8_queue &uq, const u8 *__rest
   if (uq.count) { utf8_drain(uq, buf, len, more, lane, uq.count); }
 }
 
+// ---- the same list with the BLOCKS parked in LDS (k_stage1_summarize, round 4) -----------------------------------------------------
+// utf8_queue keeps the indexes of the noted blocks and fetches their bytes again when 64 have gathered -- by then ~130 KiB of
+// other waves' tiles have gone through the 4 MiB L2 of the XCD, the lines are gone, and every noted block costs a 128-byte line
+// of HBM traffic (amazon NDJSON: 11 % of the blocks, 0.23 GB per GiB on top of 1.07: profiles/r03_pmc_summary.txt).  The lane that
+// notes a block HOLDS its 64 bytes; here it parks them (with the dword in front and the block's number: an 80-byte row) and the
+// check reads LDS.  Rows are drained UTF8P_DRAIN_AT at a time (48 of 64 lanes busy: the price of 23 KiB of LDS per workgroup at six
+// workgroups per CU); a chunk that notes more than UTF8_DENSE_FROM blocks is checked in line as before, so at most
+// UTF8P_DRAIN_AT - 1 + UTF8_DENSE_FROM rows are ever parked.
+constexpr u32 UTF8P_ROW_WORDS = 20; // [0..15] the block, [16] the dword in front of it, [17] its number; 80 bytes: rows stay 16-byte aligned
+constexpr u32 UTF8P_DRAIN_AT = 48;
+constexpr u32 UTF8P_ROWS = UTF8P_DRAIN_AT - 1 + UTF8_DENSE_FROM + 1;
+struct utf8_park {
+  u32 *rows;   // LDS, UTF8P_ROWS x UTF8P_ROW_WORDS words owned by this wave
+  u32 count;   // wave-uniform
+  u32 pending; // wave-uniform: the last three bytes in front of the next block hold a non-ASCII byte
+  u32 error;   // wave-uniform, sticky
+  u32 prev_tail; // wave-uniform: the last dword in front of the next chunk
+  const u8 *buf;
+  u64 len;
+  u32 more;
+  u32 dense_from;
+};
+// state at the start of a span, from the look-back bytes (lane i holds byte start-1-i)
+__device__ __forceinline__ void utf8_park_begin(utf8_park &uq, u32 lookback_byte, u32 lane) {
+  uq.pending = utf8_pending_from(lookback_byte, lane);
+  uq.prev_tail = readlane(lookback_byte, 3) | (readlane(lookback_byte, 2) << 8) | (readlane(lookback_byte, 1) << 16) | (readlane(lookback_byte, 0) << 24);
+}
+// true iff the parked block is ill-formed given the dword in front of it (utf8_check_block on a row)
+__device__ __forceinline__ bool utf8_check_row(const u32 *row, u64 len, bool more) {
+  const u64 pos = u64(row[17]) * BLOCK_BYTES;
+  if (pos >= len) { return false; } // nothing but padding (noted because the block in front ends in a non-ASCII byte)
+  u32 prev = row[16];
+  u32 bad = 0;
+#pragma unroll 1
+  for (u32 h = 0; h < 2; h++) {
+    const uint4 a = *reinterpret_cast<const uint4 *>(row + 8u * h), b = *reinterpret_cast<const uint4 *>(row + 8u * h + 4u);
+    const u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    u32 q[8];
+    s2p32(w, q);
+    const utf8_leads_t<u32> L = utf8_classify_planes<u32>(q);
+    bad |= utf8_errors_planes<u32>(q, L, utf8_carry_from_bytes((prev >> 8) & 0xFFu, (prev >> 16) & 0xFFu, prev >> 24));
+    if (!more && pos + 32u * h + 32u >= len && (utf8_carry_out(L) & UTF8_CARRY_OPEN)) { bad |= 1u; } // a sequence still open where the input ends
+    prev = w[7];
+  }
+  return bad != 0;
+}
+// validate the n NEWEST parked rows (n <= 64 and n <= count), one per lane
+__device__ __forceinline__ void utf8_park_drain(utf8_park &uq, u32 lane, u32 n) {
+  wave_lds_fence();
+  bool bad = false;
+  if (lane < n) { bad = utf8_check_row(uq.rows + (uq.count - n + lane) * UTF8P_ROW_WORDS, uq.len, uq.more != 0u); }
+  if (__ballot(bad)) { uq.error = 1u; }
+  uq.count -= n;
+  wave_lds_fence();
+}
+// one chunk: P = the lane's bit planes, w = its 16 dwords (bytes beyond the input already read as spaces), block0 = number of lane 0's block
+__device__ __forceinline__ void utf8_park_chunk(utf8_park &uq, const planes &P, const u32 (&w)[16], u32 block0, u32 lane) {
+  const u64 m = __ballot(P.b[7] != 0);
+  const u32 tail_prev = uq.prev_tail;
+  uq.prev_tail = readlane(w[15], 63);
+  if (m | u64(uq.pending)) { // wave-uniform; ASCII chunks stop here
+    const u64 t = __ballot((w[15] & 0x80808000u) != 0); // bytes 61..63 of the block
+    const u64 need = m | (t << 1) | u64(uq.pending);
+    uq.pending = u32(t >> 63);
+    if (uq.buf && u32(popc64(need)) > uq.dense_from) { // wave-uniform
+      utf8_dense_chunk(uq, P, block0, lane);
+      return;
+    }
+    u32 prev = u32(__shfl_up(int(w[15]), 1));
+    if (lane == 0) { prev = tail_prev; }
+    const u32 k = __builtin_amdgcn_mbcnt_hi(u32(need >> 32), __builtin_amdgcn_mbcnt_lo(u32(need), 0u));
+    if ((need >> lane) & 1ull) {
+      u32 *row = uq.rows + (uq.count + k) * UTF8P_ROW_WORDS;
+      uint4 *r4 = reinterpret_cast<uint4 *>(row);
+      r4[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      r4[1] = make_uint4(w[4], w[5], w[6], w[7]);
+      r4[2] = make_uint4(w[8], w[9], w[10], w[11]);
+      r4[3] = make_uint4(w[12], w[13], w[14], w[15]);
+      row[16] = prev;
+      row[17] = block0 + lane;
+    }
+    uq.count += u32(popc64(need));
+    if (uq.count >= UTF8P_DRAIN_AT) { utf8_park_drain(uq, lane, uq.count < 64u ? uq.count : 64u); } // (never more than 71 parked: one round leaves < 48)
+  }
+}
+
 // uq (WANT_UTF8 only): the wave's UTF-8 list; block0 = index of lane 0's block (byte offset of the chunk / 64)
-template <bool WANT_STRUCTURALS, bool WANT_UTF8>
-__device__ __forceinline__ chunk_masks scan_chunk(const u32 (&w)[16], wave_carry &wc, u32 lane, utf8_queue *uq = nullptr, u32 block0 = 0) {
+__device__ __forceinline__ void utf8_note(utf8_queue &uq, const planes &P, const u32 (&w)[16], u32 block0, u32 lane) { utf8_note_chunk(uq, P, w[15], block0, lane); }
+__device__ __forceinline__ void utf8_note(utf8_park &uq, const planes &P, const u32 (&w)[16], u32 block0, u32 lane) { utf8_park_chunk(uq, P, w, block0, lane); }
+template <bool WANT_STRUCTURALS, bool WANT_UTF8, class Q = utf8_queue>
+__device__ __forceinline__ chunk_masks scan_chunk(const u32 (&w)[16], wave_carry &wc, u32 lane, Q *uq = nullptr, u32 block0 = 0) {
   const planes P = transpose64(w);
   const u64 lt = lanemask_lt(lane);
   chunk_masks out;
-  if (WANT_UTF8) { utf8_note_chunk(*uq, P, w[15], block0, lane); }
+  if (WANT_UTF8) { utf8_note(*uq, P, w, block0, lane); }
   const classes c = classify(P);
 
   // escapes: each block is "pass" (64 backslashes) or sets the carry by itself; a lane's carry-in is
@@ -617,18 +717,18 @@ __device__ __forceinline__ void emit_indices(u64 structural, u32 pos32, u32 lane
       mx = max(mx, u32(__builtin_amdgcn_update_dpp(0, int(mx), 0x142, 0xa, 0xf, false)));
       mx = max(mx, u32(__builtin_amdgcn_update_dpp(0, int(mx), 0x143, 0xc, 0xf, false)));
       const u32 trips = readlane(mx, 63);
-      u32 a_lo = nlo ? (off + skew) : EMIT_DUMP_SLOT, a_hi = nhi ? (off + skew + nlo) : EMIT_DUMP_SLOT;
-      u32 v_lo = 0, v_hi = 0;
+      // six instructions and one LDS store per chain and trip (see emit_span): a chain that has run dry stores to the dump slot
+      u32 a_lo = 4u * (off + skew), a_hi = 4u * (off + skew + nlo); // byte addresses
+      const u32 pos_hi = pos32 + 32u;
+      char *const stage_b = reinterpret_cast<char *>(stage);
 #pragma unroll 2
       for (u32 t = 0; t < trips; t++) {
-        if (lo) { v_lo = pos32 + u32(__ffs(int(lo)) - 1); }
-        if (hi) { v_hi = pos32 + 32u + u32(__ffs(int(hi)) - 1); }
-        stage[a_lo] = v_lo;
-        stage[a_hi] = v_hi;
+        *reinterpret_cast<u32 *>(stage_b + (lo ? a_lo : 4u * EMIT_DUMP_SLOT)) = pos32 + ffbl_raw(lo);
+        *reinterpret_cast<u32 *>(stage_b + (hi ? a_hi : 4u * EMIT_DUMP_SLOT)) = pos_hi + ffbl_raw(hi);
         lo &= lo - 1;
         hi &= hi - 1;
-        a_lo += lo ? 1u : 0u; // stay on the last slot once the chain is exhausted
-        a_hi += hi ? 1u : 0u;
+        a_lo += 4u;
+        a_hi += 4u;
       }
     } else if (total > 2u * EMIT_WINDOW) {
       // Dense chunk (minified small objects, arrays of digits, nesting: up to one offset per byte).  The per-lane
@@ -750,17 +850,22 @@ __device__ __forceinline__ bool emit_span(const u64 *m, u32 pos0, u32 lane, u32 
   mx = max(mx, u32(__builtin_amdgcn_update_dpp(0, int(mx), 0x143, 0xc, 0xf, false)));
   const u32 trips = readlane(mx, 63);
   const u32 lane_pos = pos0 + lane * BLOCK_BYTES;
-  u32 v[NH];
+  // Six instructions and one LDS store per chain and trip (it was eight: profiles/r04_emit_chains.txt): a chain that has run dry stores
+  // (garbage) to the dump slot instead of rewriting its last slot, so the value needs no select and the slot advances unconditionally.
+  u32 vbase[NH];
 #pragma unroll
-  for (u32 k = 0; k < NH; k++) { v[k] = 0; }
+  for (u32 k = 0; k < NH; k++) {
+    vbase[k] = lane_pos + (k >> 1) * CHUNK_BYTES + (k & 1u) * 32u;
+    a[k] *= 4u; // byte addresses from here on: no shift per store
+  }
 #pragma unroll 1
   for (u32 t = 0; t < trips; t++) {
 #pragma unroll
     for (u32 k = 0; k < NH; k++) {
-      if (h[k]) { v[k] = lane_pos + (k >> 1) * CHUNK_BYTES + (k & 1u) * 32u + u32(__ffs(int(h[k])) - 1); }
-      stage[a[k]] = v[k];
-      h[k] &= h[k] - 1;
-      a[k] += h[k] ? 1u : 0u; // stay on the last slot once the chain is exhausted
+      const u32 bits = h[k];
+      *reinterpret_cast<u32 *>(reinterpret_cast<char *>(stage) + (bits ? a[k] : 4u * DUMP)) = vbase[k] + ffbl_raw(bits); // (an empty chain's value lands in the dump slot)
+      h[k] = bits & (bits - 1u);
+      a[k] += 4u;
     }
   }
   wave_lds_fence();

@@ -39,7 +39,7 @@ namespace {
 // noted but not yet validated when their segments end.  A wave of its own would validate a handful of blocks with a
 // handful of lanes (one or two non-ASCII blocks per chunk is what NDJSON / pretty-printed text hold) -- ~75 of its
 // ~415 VALU instructions per chunk (profiles/r02_pmc_ndjson.txt: this kernel issues 81 % of the time).  The four
-// hand their left-overs to wave 0 through LDS and leave; wave 0 validates them together.
+// leave their left-over rows where they are and go; wave 0 validates all of them together.
 constexpr u32 SUMM_WAVES = 4;
 __global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_stage1_summarize(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ mask0,
                                                                      u64 *__restrict__ mask1, seg_summary *__restrict__ summ,
@@ -47,13 +47,12 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu
   const u32 lane = lane_id();
   const u32 wave = threadIdx.x >> 6;
   const u32 seg = blockIdx.x * SUMM_WAVES + wave; // relative to the scan's origin: workspace index
-  __shared__ u32 uq_slots[SUMM_WAVES][UTF8Q_SLOTS];
-  __shared__ u32 sh_left[SUMM_WAVES * 64];
-  __shared__ u32 sh_left_count;
-  if (threadIdx.x == 0) { sh_left_count = 0; }
+  __shared__ __attribute__((aligned(16))) u32 park[SUMM_WAVES][UTF8P_ROWS * UTF8P_ROW_WORDS]; // the blocks the UTF-8 check still has to look at (utf8_park)
+  __shared__ u32 sh_left[SUMM_WAVES]; // rows every wave has left when its segment ends
   const bool more = (org.carry & CARRY_MORE) != 0;
   if (seg >= nseg) { // past the last segment (wave-uniform; wave 0 always has one): only the rendezvous below
-    __syncthreads();
+    if (lane == 0) { sh_left[wave] = 0; }
+    lds_writes_done();
     __syncthreads();
     return;
   }
@@ -62,8 +61,9 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu
   const u32 lookback = lookback_issue(buf, seg_start, lane); // consumed after chunk 0 has been requested
   wave_carry wc{0u, 0u, 0u};
   span_x sx;
-  utf8_queue uq{uq_slots[wave], 0u, 0u, 0u, (org.carry & CARRY_DEBUG_QUEUE_UTF8) ? nullptr : buf, len, more ? 1u : 0u};
-  if (org.carry >> 16) { uq.dense_from = (org.carry >> 16) & 0xFFu; } // A/B: env SJGPU_UTF8_DENSE_FROM
+  // (the in-line check of dense chunks is part of the design here: it bounds the rows a chunk can park)
+  utf8_park uq{park[wave], 0u, 0u, 0u, 0x20202020u, buf, len, more ? 1u : 0u, UTF8_DENSE_FROM};
+  if (((org.carry >> 16) & 0xFFu) != 0u && ((org.carry >> 16) & 0xFFu) < UTF8_DENSE_FROM) { uq.dense_from = (org.carry >> 16) & 0xFFu; } // A/B: env SJGPU_UTF8_DENSE_FROM (downwards only)
   u32 n_a = 0, n_b = 0; // resolved: n_a = final count; else n_a = candidates, n_b = candidates in a string tail
   bool any_a = false, any_b = false; // wave-uniform: a control character offends under hypothesis a / b (folded per chunk: two
                                      // compares instead of four VGPRs of masks carried through the segment)
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu
     else { load_block(buf, pos, len, w); }
     if (c == 0) { // the look-back's latency hid behind the loads above
       wc = span_carry_assume(seg_start, lane, lookback, sx);
-      uq.pending = utf8_pending_from(lookback, lane);
+      utf8_park_begin(uq, lookback, lane);
     }
     span_note_chunk(sx, w, c * CHUNK_BYTES, c == SEG_CHUNKS - 1, lane);
     const chunk_masks m = scan_chunk<true, true>(w, wc, lane, &uq, u32(cstart / BLOCK_BYTES));
@@ -112,7 +112,6 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu
       keep0[c] = m.cand;
       keep1[c] = m.string_tail;
     }
-    utf8_drain_if_full(uq, buf, len, more, lane);
   }
   {
     const size_t at = (size_t(seg) * 64 + lane) * 2; // in 16-byte units: [segment][lane][chunk]
@@ -125,21 +124,20 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu
       p1[1] = make_uint4(u32(keep1[2]), u32(keep1[2] >> 32), u32(keep1[3]), u32(keep1[3] >> 32));
     }
   }
-  // left-overs (fewer than 64 after the last utf8_drain_if_full) go to wave 0, which validates them with full lanes
-  __syncthreads(); // sh_left_count is zero
-  {
-    wave_lds_fence();
-    u32 at = 0;
-    if (lane == 0 && uq.count) { at = atomicAdd(&sh_left_count, uq.count); }
-    at = readlane(at, 0);
-    if (lane < uq.count) { sh_left[at + lane] = uq.slots[lane]; }
-  }
+  // left-overs (fewer than UTF8P_DRAIN_AT per wave) are validated by wave 0 with full lanes, straight from the four waves' rows
+  if (lane == 0) { sh_left[wave] = uq.count; }
+  lds_writes_done();
   __syncthreads();
   if (wave == 0) {
-    const u32 total = sh_left_count;
+    const u32 n0 = sh_left[0], n1 = n0 + sh_left[1], n2 = n1 + sh_left[2], total = n2 + sh_left[3];
     for (u32 done = 0; done < total; done += 64) {
+      const u32 g = done + lane;
       bool bad = false;
-      if (done + lane < total) { bad = utf8_check_block(buf, len, more, sh_left[done + lane]); } // incl. a sequence open at the end of the input
+      if (g < total) {
+        const u32 v = (g >= n0) + (g >= n1) + (g >= n2);
+        const u32 r = g - (v == 0 ? 0u : (v == 1 ? n0 : (v == 2 ? n1 : n2)));
+        bad = utf8_check_row(park[v] + r * UTF8P_ROW_WORDS, len, more); // incl. a sequence open at the end of the input
+      }
       if (__ballot(bad)) { uq.error = 1u; }
     }
   }
