@@ -473,7 +473,7 @@ def leg_dom_parse(cx, R, impl):
     reference benchmarker's method (benchmark/benchmarker.h:315-346: parser and document allocated once, best of several parses of the same
     buffer), beside the two roads the plug-in's parse() has -- (A) stage 1 on the GPU + the reference's stage 2 on its list (what documents
     below SJGPU_STAGE2_FROM_KB take; timed as sjgpu_stage1 on the host buffer + the reference's stage2() alone: the shim lends the list, nothing
-    is copied in between) and (B) sjgpu_parse, stage 2 on the device too (from SJGPU_STAGE2_FROM_KB = 4096 on).  The sweep is what the
+    is copied in between) and (B) sjgpu_parse, stage 2 on the device too (from SJGPU_STAGE2_FROM_KB = 2048 on).  The sweep is what the
     threshold rests on."""
     import ctypes
     capi = cx.capi
@@ -483,7 +483,7 @@ def leg_dom_parse(cx, R, impl):
     R.sjref_bench_stage2.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     L = capi.load_library()
     rows = {}
-    for label, size in (("0.6MiB", 630_000), ("4MiB", 4 << 20), ("64MiB", 64 << 20), ("256MiB", 256 << 20)):
+    for label, size in (("0.6MiB", 630_000), ("1MiB", 1 << 20), ("2MiB", 2 << 20), ("4MiB", 4 << 20), ("64MiB", 64 << 20), ("256MiB", 256 << 20)):
         doc, _ = cx.corpus.twitter_like(size, 91)
         n = len(doc)
         padded = np.concatenate([doc, np.full(64, 0x20, np.uint8)])  # SIMDJSON_PADDING readable bytes behind the document
@@ -517,7 +517,7 @@ def leg_dom_parse(cx, R, impl):
                        "reference_GBps": round(n / t_ref / 1e9, 3), "road_a_GBps": round(n / road_a / 1e9, 3), "road_b_GBps": round(n / best_parse / 1e9, 3),
                        "faster_road": "b" if best_parse < road_a else "a", "tape_words": int(tw.value)}
         del tape, sbuf
-    return {"documents": "twitter-like, seed 91", "reference_kernel": impl.decode(), "threshold_SJGPU_STAGE2_FROM_KB": 4096, "sizes": rows,
+    return {"documents": "twitter-like, seed 91", "reference_kernel": impl.decode(), "threshold_SJGPU_STAGE2_FROM_KB": 2048, "sizes": rows,
             "note": "wall time per parse, host (pageable) buffers on both sides, best of the repetitions; road B includes the upload of the document and the download of "
                     "tape and string buffer (PCIe), road A the upload and the download of the structural list"}
 

@@ -113,7 +113,10 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu
       keep1[c] = m.string_tail;
     }
   }
-  {
+  // A segment without a single candidate (the inside of a long string, of a backslash run, of whitespace) publishes two zero counts and
+  // writes NO masks: k_stage1_emit takes the zeros from the summary (escape_heavy: 0.27 GB of masks written and 0.28 GB read back for 300 000
+  // structurals in a GiB -- profiles/r04_pmc_summary.txt -- are gone; ordinary input has no such segments and pays one ballot)
+  if (__ballot(n_a != 0u)) {
     const size_t at = (size_t(seg) * 64 + lane) * 2; // in 16-byte units: [segment][lane][chunk]
     uint4 *p0 = reinterpret_cast<uint4 *>(mask0) + at;
     p0[0] = make_uint4(u32(keep0[0]), u32(keep0[0] >> 32), u32(keep0[1]), u32(keep0[1] >> 32));
@@ -356,9 +359,12 @@ __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask
   const u64 seg_start = org.begin + u64(seg) * SEG_BYTES;
   // Independent loads first, consumers later: the four chunks' masks (8 bytes per lane each) are requested before
   // the group-prefix fold, so the segment pays ONE round trip to HBM, not one per chunk plus one for the prefix.
-  const bool resolved = (summ[seg].flags & SF_RESOLVED) != 0; // masks are already final
-  u64 m0[SEG_CHUNKS], m1[SEG_CHUNKS] = {0, 0, 0, 0};
-  {
+  const seg_summary own = summ[seg];
+  const bool resolved = (own.flags & SF_RESOLVED) != 0; // masks are already final
+  const bool empty = own.count_if_out == 0u && own.count_if_in == 0u; // no candidate at all: k_stage1_summarize wrote no masks
+  if (empty && ((own.xw >> XW_D_SHIFT) & 0xFu) == 0u) { return; }  // ... and no bit a wrong assumption could add: nothing to emit
+  u64 m0[SEG_CHUNKS] = {0, 0, 0, 0}, m1[SEG_CHUNKS] = {0, 0, 0, 0};
+  if (!empty) {
     const size_t at = (size_t(seg) * 64 + lane) * 2; // [segment][lane][chunk]; chunks beyond len hold zero masks
     const uint4 *p0 = reinterpret_cast<const uint4 *>(mask0) + at;
     const uint4 x = p0[0], y = p0[1];
@@ -372,7 +378,6 @@ __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask
     }
   }
   const seg_prefix pf = segment_prefix(summ, gpref, seg, lane);
-  const seg_summary own = summ[seg];
   const u32 x = pf.in_string >> 1;
   const xs_step t = xs_apply(own.flags & SF_PARITY, own.xw, pf.in_string & 1u, x); // which hypothesis, and the bit a wrong assumption toggles
   u32 base = pf.base;

@@ -19,7 +19,7 @@
 //   (the string buffer: sjgpu_strings.hip / sjgpu_string_stream.hip, which take the string ordinals from here)
 //   radix passes      stable LSD radix sort on the level, 6 bits per pass: histogram, scan, scatter   1 wave / 2048 elements;
 //                     the second pass only runs for documents nested 64 deep and more
-//   k_tape_opens + scan + k_tape_openpos   container ordinal per sorted element, sorted position of every open
+//   (container ordinal per sorted element and sorted position of every open: written by the sort's last scatter from a second histogram)
 //   k_tape_match      commas learn their container's kind; closes write BOTH bracket words (count, partner index), kinds checked
 //   k_tape_rules      per token: the walk's rule and the nesting limit; root words
 //   k_tape_strings / k_tape_atoms / k_tape_numbers    the value words, one listed token per lane (lists by k_tok_apply)
@@ -248,32 +248,45 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
 // m = number of elements = selpos[n] (device memory).  hist is digit-major: hist[d * tiles + t], so that ONE exclusive scan of the
 // whole table yields, for every (digit, tile), where that tile's elements with that digit begin in the output.
 // second pass (shift > 0): nothing to do when every level fits into the first digit; the first pass tells the second's scan how long it is
+// Round 4: a SECOND table behind the first counts the opening brackets per (digit, tile): scanned with the first (one scan over both), it
+// tells the scatter how many opening brackets lie in front of every sorted element -- the container ordinals -- so that the pass over the
+// sorted keys, the scan over m + 1 flags and the pass that listed the opens' positions (k_tape_opens / k_tape_openpos, 110 us per
+// twitter-like call) are gone: the last scatter writes both arrays on its way.
 __global__ __launch_bounds__(64) void k_radix_hist(const unsigned short *__restrict__ key, const int *__restrict__ m_ptr, u32 shift, u32 tiles, int *__restrict__ hist,
                                                    const int *__restrict__ max_level, u32 *__restrict__ second_scan_len) {
-  __shared__ u32 cnt[RADIX_BINS];
+  __shared__ u32 cnt[2][RADIX_BINS];
   const u32 lane = threadIdx.x, tile = blockIdx.x;
   const bool one_pass = u32(*max_level) < RADIX_BINS;
-  if (shift == 0 && tile == 0 && lane == 0) { *second_scan_len = one_pass ? 0u : tiles * RADIX_BINS; }
+  if (shift == 0 && tile == 0 && lane == 0) { *second_scan_len = one_pass ? 0u : 2u * tiles * RADIX_BINS; }
   if (shift != 0 && one_pass) { return; }
   const u32 m = u32(*m_ptr);
-  cnt[lane] = 0;
+  cnt[0][lane] = 0;
+  cnt[1][lane] = 0;
   wave_lds_fence();
   const u32 base = tile * RADIX_TILE;
   for (u32 r = 0; r < RADIX_TILE; r += 64) {
     const u32 j = base + r + lane;
-    if (j < m) { atomicAdd(&cnt[(key[j] >> shift) & (RADIX_BINS - 1)], 1u); }
+    if (j < m) {
+      const u32 k = key[j];
+      const u32 d = (k >> shift) & (RADIX_BINS - 1);
+      atomicAdd(&cnt[0][d], 1u);
+      if (kind_is_open(k >> KIND_SHIFT)) { atomicAdd(&cnt[1][d], 1u); }
+    }
   }
   wave_lds_fence();
-  hist[lane * tiles + tile] = int(cnt[lane]);
+  hist[lane * tiles + tile] = int(cnt[0][lane]);
+  hist[(RADIX_BINS + lane) * tiles + tile] = int(cnt[1][lane]);
 }
 __global__ __launch_bounds__(64) void k_radix_scatter(const unsigned short *__restrict__ key_in, const u32 *__restrict__ tok_in, const int *__restrict__ m_ptr, u32 shift,
                                                       u32 tiles, const int *__restrict__ hist, unsigned short *__restrict__ key_out, u32 *__restrict__ tok_out,
-                                                      const int *__restrict__ max_level) {
-  __shared__ u32 next[RADIX_BINS]; // where the next element of each digit goes
+                                                      const int *__restrict__ max_level, int *__restrict__ opens_before, u32 *__restrict__ openpos) {
+  __shared__ u32 next[RADIX_BINS];  // where the next element of each digit goes
+  __shared__ u32 onext[RADIX_BINS]; // opening brackets in front of it (the scan ran over both tables: the first one's total, m, is in every entry of the second)
   const u32 lane = threadIdx.x, tile = blockIdx.x;
   if (shift != 0 && u32(*max_level) < RADIX_BINS) { return; }
   const u32 m = u32(*m_ptr);
   next[lane] = u32(hist[lane * tiles + tile]);
+  onext[lane] = u32(hist[(RADIX_BINS + lane) * tiles + tile]) - m;
   wave_lds_fence();
   const u32 base = tile * RADIX_TILE;
   for (u32 r = 0; r < RADIX_TILE; r += 64) { // 64 consecutive elements per step, in order: the sort is stable
@@ -288,13 +301,22 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const unsigned short *__re
       peers &= ((d >> b) & 1u) ? ones : ~ones;
     }
     const u32 rank = u32(popc64(peers & lanemask_lt(lane)));
+    const bool open = live && kind_is_open(k >> KIND_SHIFT);
+    const u64 open_peers = peers & __ballot(open);
     if (live) {
       const u32 at = next[d] + rank;
       key_out[at] = (unsigned short)k;
       tok_out[at] = tok_in[j];
+      // (valid in the order of the LAST pass that runs; an earlier pass's values are overwritten by it)
+      const u32 ob = onext[d] + u32(popc64(open_peers & lanemask_lt(lane))); // opening brackets in front of the element
+      opens_before[at] = int(ob);
+      if (open) { openpos[ob] = at; }
     }
     wave_lds_fence();
-    if (live && rank == 0) { next[d] += u32(popc64(peers)); } // one lane per digit present
+    if (live && rank == 0) { // one lane per digit present
+      next[d] += u32(popc64(peers));
+      onext[d] += u32(popc64(open_peers));
+    }
     wave_lds_fence();
   }
 }
@@ -311,22 +333,8 @@ struct sorted_pairs {
 };
 
 // ---- containers -------------------------------------------------------------------------------------------------------------------------
-// opens[j] = 1 where the sorted element j is an opening bracket (the scan turns it into "opens in front of j"); opens[m] = 0
-__global__ __launch_bounds__(TP_THREADS) void k_tape_opens(sorted_pairs sorted, const int *__restrict__ m_ptr, u32 n, int *__restrict__ opens) {
-  const unsigned short *__restrict__ key = sorted.key();
-  const u64 j = u64(blockIdx.x) * TP_THREADS + threadIdx.x;
-  const u32 m = u32(*m_ptr);
-  if (j > m) { return; }
-  opens[j] = (j < m && kind_is_open(u32(key[j]) >> KIND_SHIFT)) ? 1 : 0; // entry m: the scan (over m + 1 entries) leaves the number of containers there
-}
-// openpos[k] = sorted position of the k-th opening bracket
-__global__ __launch_bounds__(TP_THREADS) void k_tape_openpos(sorted_pairs sorted, const int *__restrict__ m_ptr, const int *__restrict__ opens_before, u32 *__restrict__ openpos) {
-  const unsigned short *__restrict__ key = sorted.key();
-  const u64 j = u64(blockIdx.x) * TP_THREADS + threadIdx.x;
-  const u32 m = u32(*m_ptr);
-  if (j >= m) { return; }
-  if (kind_is_open(u32(key[j]) >> KIND_SHIFT)) { openpos[opens_before[j]] = u32(j); }
-}
+// (opens_before[j] = opening brackets in front of sorted element j and openpos[k] = sorted position of the k-th opening bracket come from the
+// sort's last scatter)
 // commas: ctx[token] = kind of their container.  Closing brackets: the two bracket words of the tape
 // (end_container, tape_builder.h:396-407; an empty container is the same formula with count 0, :386-391).
 // Four consecutive sorted elements per thread, the loads of each step of the chain (element -> its container's open -> that open's key and
@@ -582,8 +590,8 @@ static tape_workspace carve(uint8_t *base, uint32_t n, uint64_t len) {
   w.openpos = reinterpret_cast<u32 *>(take(n1 * 4 + 64));
   w.opens = reinterpret_cast<int *>(take(n1 * 4 + 64));
   w.slow_list = reinterpret_cast<u32 *>(take(size_t(w.slow_cap) * 4 + 64));
-  w.hist = reinterpret_cast<int *>(take(size_t(w.tiles) * RADIX_BINS * 4 + 64));
-  const size_t longest = n1 > size_t(w.tiles) * RADIX_BINS ? n1 : size_t(w.tiles) * RADIX_BINS;
+  w.hist = reinterpret_cast<int *>(take(size_t(w.tiles) * RADIX_BINS * 2 * 4 + 64)); // two tables: elements, opening brackets
+  const size_t longest = n1 > size_t(w.tiles) * RADIX_BINS * 2 ? n1 : size_t(w.tiles) * RADIX_BINS * 2;
   w.partial = reinterpret_cast<int *>(take((longest / 4096 + 80) * 4));
   w.bytes = at;
   return w;
@@ -600,7 +608,7 @@ const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *i
   (void)hipMemsetAsync(w.res, 0, sizeof(tape_result_dev), s);
   (void)hipMemsetAsync(&w.res->error_key, 0xFF, sizeof(u64), s); // NO_ERROR_KEY
   (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.n_words), int(n1), 1, s);
-  (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.n_words + 1), int(w.tiles * RADIX_BINS), 1, s);
+  (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.n_words + 1), int(2 * w.tiles * RADIX_BINS), 1, s);
   (void)hipMemsetAsync(w.ctx, 0, size_t(n1) + 8, s);
   const u32 kmax = max_depth < 4095u ? max_depth : 4095u;
   hipLaunchKernelGGL(k_tok_classify, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, buf, len, idx, n, w.tokc, w.sums, w.tok_blocks);
@@ -621,16 +629,13 @@ void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t
   // two passes of six bits cover levels up to 4095; the second one only runs for documents nested 64 deep and more
   const int *max_level = w.m + 1;
   hipLaunchKernelGGL(k_radix_hist, dim3(w.tiles), dim3(64), 0, s, w.key_a, m_ptr, 0u, w.tiles, w.hist, max_level, w.n_words + 2);
-  enqueue_scan(w.hist, w.tiles * RADIX_BINS, w.n_words + 1, w.partial, s);
-  hipLaunchKernelGGL(k_radix_scatter, dim3(w.tiles), dim3(64), 0, s, w.key_a, w.tok_a, m_ptr, 0u, w.tiles, w.hist, w.key_b, w.tok_b, max_level);
+  enqueue_scan(w.hist, 2 * w.tiles * RADIX_BINS, w.n_words + 1, w.partial, s);
+  hipLaunchKernelGGL(k_radix_scatter, dim3(w.tiles), dim3(64), 0, s, w.key_a, w.tok_a, m_ptr, 0u, w.tiles, w.hist, w.key_b, w.tok_b, max_level, w.opens, w.openpos);
   hipLaunchKernelGGL(k_radix_hist, dim3(w.tiles), dim3(64), 0, s, w.key_b, m_ptr, RADIX_BITS, w.tiles, w.hist, max_level, w.n_words + 2);
-  enqueue_scan(w.hist, w.tiles * RADIX_BINS, w.n_words + 2, w.partial, s);
-  hipLaunchKernelGGL(k_radix_scatter, dim3(w.tiles), dim3(64), 0, s, w.key_b, w.tok_b, m_ptr, RADIX_BITS, w.tiles, w.hist, w.key_a, w.tok_a, max_level);
+  enqueue_scan(w.hist, 2 * w.tiles * RADIX_BINS, w.n_words + 2, w.partial, s);
+  hipLaunchKernelGGL(k_radix_scatter, dim3(w.tiles), dim3(64), 0, s, w.key_b, w.tok_b, m_ptr, RADIX_BITS, w.tiles, w.hist, w.key_a, w.tok_a, max_level, w.opens, w.openpos);
   const sorted_pairs sorted{w.key_a, w.key_b, w.tok_a, w.tok_b, max_level};
-  // containers
-  hipLaunchKernelGGL(k_tape_opens, dim3(grid), dim3(TP_THREADS), 0, s, sorted, m_ptr, n, w.opens);
-  enqueue_scan(w.opens, n1, reinterpret_cast<const u32 *>(w.m + 3), w.partial, s); // over the m + 1 sorted elements only (m is known on the device)
-  hipLaunchKernelGGL(k_tape_openpos, dim3(grid), dim3(TP_THREADS), 0, s, sorted, m_ptr, w.opens, w.openpos);
+  // containers: the ordinals came with the last scatter
   hipLaunchKernelGGL(k_tape_match, dim3(blocks_of(n1, TP_THREADS * TM_PER)), dim3(TP_THREADS), 0, s, sorted, m_ptr, w.opens, w.openpos, w.slots, w.ctx, tape, tape_cap, w.res);
   hipLaunchKernelGGL(k_tape_rules, dim3(blocks_of(n1, TP_THREADS * TW_PER)), dim3(TP_THREADS), 0, s, n, max_depth, w.tokc, w.slots, w.depth, w.ctx, tape, tape_cap, w.res);
   const u32 list_grid = grid < 8192u ? grid : 8192u;
