@@ -123,7 +123,7 @@ def device_leg(cx, op, workload, host, units, steps, warmup, pipeline, fence=Non
     dt = time.perf_counter() - t0
     ms_sum, calls = parser.profile_read()
     parser.profile_enable(False)
-    # slot 0 = escape table + clears + (first) scan kernel; slots 1, 2 hold the resolve and emit kernels of the split pipeline.
+    # slot 0 = clears + (first) scan kernel; slots 1, 2 hold the resolve and emit kernels of the split pipeline.
     # A single-pass call leaves them empty, and an empty event pair still measures ~5 us of event bookkeeping: not counted.
     single_kernel = "+" not in kernel
     gpu_ms = (ms_sum[0] if single_kernel else sum(ms_sum)) / max(calls, 1)
@@ -138,7 +138,7 @@ def device_leg(cx, op, workload, host, units, steps, warmup, pipeline, fence=Non
                      "kernel_ms_slots": [round(m / max(calls, 1), 4) for m in ms_sum],
                      "traffic": cx.traffic.get(tkey), "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this "
                      "command, separate passes (scripts/gpu_pmc.sh); null = not collected for this workload",
-                     "timing": "hipEvent pairs around what one call enqueues on the launch stream (slot 0: escape table, clears and the scan kernel; slots 1-2: resolve and emit "
+                     "timing": "hipEvent pairs around what one call enqueues on the launch stream (slot 0: clears and the scan kernel; slots 1-2: resolve and emit "
                                "kernels of the split pipeline, empty and not counted for a single-pass call), mean over the timed steps"},
     }
     if with_cpu:

@@ -152,8 +152,8 @@ int sjgpu_debug_string_path(const sjgpu_ctx *ctx);
 /* Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).  While enabled,
  * each *_device call brackets every kernel it enqueues with events (up to 4096 calls are retained);
  * sjgpu_profile_read waits for the stream, adds the elapsed milliseconds per kernel slot into
- * ms_sum[0..2] (split pipeline: [escape table +] summarize, resolve, emit; single pass: slot 0 = everything the
- * call enqueues -- escape table, workspace clears, the scan kernel; validate_utf8: slot 0), stores the number of
+ * ms_sum[0..2] (split pipeline: summarize, resolve, emit; single pass: slot 0 = everything the
+ * call enqueues -- workspace clears, the scan kernel; validate_utf8: slot 0), stores the number of
  * calls accumulated and resets.  sjgpu_profile_kernel names the dominant kernel of the last enqueued call. */
 int sjgpu_profile_enable(sjgpu_ctx *ctx, int on);
 int sjgpu_profile_read(sjgpu_ctx *ctx, double *ms_sum, uint32_t *calls);

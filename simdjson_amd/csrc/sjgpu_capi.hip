@@ -115,7 +115,7 @@ struct sjgpu_ctx {
   seg_summary *summ = nullptr;
   seg_prefix *pref = nullptr;
   uint64_t *desc = nullptr; // single-pass pipeline: tile descriptors + ticket
-  uint8_t *esc_tab = nullptr; // escape table (launch_escape_table), ESC_TABLE_BYTES whatever the capacity
+  uint8_t *esc_tab = nullptr; // SEGMENT_BYTES_TABLE bytes: one byte per 16 KiB segment, the scratch of sjgpu_string_parity_device (rounds 1-3: the escape table)
   int pipeline = 2; // 0 split, 1 single pass, 2 auto (use_fused below)
   // AUTO remembers how dense the output of the last large stage-1 scan was (offsets per 1000 input bytes): on sparse
   // output the split pipeline is the faster one, and streams of documents / batches look like their predecessors
@@ -638,8 +638,8 @@ extern "C" int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out) {
   }
   if (e == hipSuccess) { e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking); }
   if (e == hipSuccess) { e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_result), sizeof(scan_result_dev), hipHostMallocDefault); }
-  if (e == hipSuccess) { e = hipMalloc(reinterpret_cast<void **>(&ctx->esc_tab), ESC_TABLE_BYTES); }
-  if (e == hipSuccess) { e = hipMemset(ctx->esc_tab, 0, ESC_TABLE_BYTES); } // entry 0 and the pass flag start at zero
+  if (e == hipSuccess) { e = hipMalloc(reinterpret_cast<void **>(&ctx->esc_tab), SEGMENT_BYTES_TABLE); }
+  if (e == hipSuccess) { e = hipMemset(ctx->esc_tab, 0, SEGMENT_BYTES_TABLE); } // entry 0 and the pass flag start at zero
   if (e != hipSuccess) {
     int rc = fail(nullptr, e, "ctx_create");
     really_destroy(ctx);

@@ -123,48 +123,11 @@ struct wave_carry {
   u32 p;    // previous byte is a non-quote scalar
 };
 
-// ---- escape table (k_escape_table, sjgpu_kernels.hip) -------------------------------------------------------
-// esc[s] = 0 / 1: byte s * SEG_BYTES is not / is escaped; ESC_PASS: the segment in front of it is nothing but backslashes,
-// so the answer is that of esc[s - 1].  Pass entries only exist inside backslash runs of 16 KiB and more; readers
-// resolve them here, 256 entries per step (entry 0 is always 0, so the walk ends).  All lanes call with the same s.
-constexpr u32 ESC_PASS = 2;
-// The table a kernel was handed plus the spacing of its entries (2^shift bytes): 16 KiB for the stage-1 kernels, whose
-// waves start on 16 KiB boundaries, 8 KiB for the minify kernels (k_minify_onchip's waves own 8 KiB).  A bare pointer
-// converts to the 16 KiB flavour; null = no table for this call.
-struct esc_ref {
-  const u8 *tab;
-  u32 shift;
-  __device__ __forceinline__ esc_ref(const u8 *t = nullptr, u32 sh = ESC_SHIFT_STAGE1) : tab(t), shift(sh) {}
-  __device__ __forceinline__ bool at_entry(u64 pos) const { return tab && (pos & ((u64(1) << shift) - 1)) == 0; }
-};
-__device__ __forceinline__ u32 escape_lookup(const u8 *__restrict__ esc, u64 s, u32 lane) {
-  const u32 v = esc[s];
-  if (v != ESC_PASS) { return v & 1u; } // wave-uniform; the only path ordinary documents take
-  u64 top = s; // entries [0, top) are still candidates
-  while (top > 0) {
-    const u64 base = (top - 1) & ~u64(255);
-    const u32 w = *reinterpret_cast<const u32 *>(esc + base + 4u * lane); // entries base + 4 lane .. + 3
-    u32 found = 0, val = 0;
-#pragma unroll
-    for (u32 j = 0; j < 4; j++) { // ascending, so the highest setting entry below top wins
-      const u32 e = (w >> (8u * j)) & 0xFFu;
-      if (base + 4u * lane + j < top && e != ESC_PASS) { found = 1; val = e; }
-    }
-    const u64 m = __ballot(found != 0);
-    if (m) { return readlane_dyn(val, 63u - clz64(m)) & 1u; }
-    top = base;
-  }
-  return 0u;
-}
-
-// parity of the maximal backslash run ending at byte end-1 (0 if end == 0 or no run).
-// esc (may be null): the escape table of the call, esc[s] = that parity for end = s * SEG_BYTES, computed exactly by
-// k_escape_local / k_escape_resolve before the scan.  With it the walk stops at the first segment boundary it reaches
-// (<= 256 steps); without it the walk is as long as the run -- quadratic over a document that is one long backslash run,
-// which is why every call beyond FUSED_SMALL_BELOW bytes gets the table.  `end` is a multiple of 64 at every call site.
-__device__ __forceinline__ u32 backslash_run_parity(const u8 *__restrict__ buf, u64 end, u32 lane, esc_ref esc) {
+// parity of the maximal backslash run ending at byte end-1 (0 if end == 0 or no run): a walk as long as the run.  Only k_docs (one
+// workgroup per document of at most 64 KiB, sjgpu_small.hip) still walks; every tile kernel starts its spans from 64 bytes of look-back
+// and carries what those leave open through its summaries (span_carry_assume below, sj_xcarry.h).  `end` is a multiple of 64.
+__device__ __forceinline__ u32 backslash_run_parity(const u8 *__restrict__ buf, u64 end, u32 lane) {
   for (;;) {
-    if (esc.at_entry(end)) { return escape_lookup(esc.tab, end >> esc.shift, lane); } // wave-uniform
     const u32 byte = (end > lane) ? u32(buf[end - 1 - lane]) : 0u;
     const u64 m = __ballot(byte == 0x5Cu);
     if (~m) { return ctz64(~m) & 1u; }
@@ -182,23 +145,20 @@ __device__ __forceinline__ u32 lookback_issue(const u8 *__restrict__ buf, u64 st
   return (start > lane) ? u32(buf[start - 1 - lane]) : 0x20u; // lane i holds byte start-1-i (0x20 in front of the input)
 }
 // parity of the backslash run ending at byte start-1-skip, from m = ballot(lane's look-back byte is a backslash)
-__device__ __forceinline__ u32 run_parity_from_mask(const u8 *__restrict__ buf, u64 start, u32 lane, u64 m, u32 skip,
-                                                    esc_ref esc) {
+__device__ __forceinline__ u32 run_parity_from_mask(const u8 *__restrict__ buf, u64 start, u32 lane, u64 m, u32 skip) {
   const u64 inv = ~(m >> skip) & (~0ull >> skip); // bit i clear <=> byte start-1-skip-i is a backslash
   if (inv) { return ctz64(inv) & 1u; }
   // every byte we hold is a backslash (so start >= 64): keep walking from byte start-65
-  return ((64u - skip) + backslash_run_parity(buf, start - 64, lane, esc)) & 1u;
+  return ((64u - skip) + backslash_run_parity(buf, start - 64, lane)) & 1u;
 }
-__device__ __forceinline__ wave_carry segment_carry_from(const u8 *__restrict__ buf, u64 start, u32 lane, u32 byte,
-                                                         esc_ref esc) {
+__device__ __forceinline__ wave_carry segment_carry_from(const u8 *__restrict__ buf, u64 start, u32 lane, u32 byte) {
   wave_carry c{0u, 0u, 0u};
   if (start == 0) { return c; }
   const u32 b1 = readlane(byte, 0);
   const u64 m = __ballot(byte == 0x5Cu);
-  // a span that starts on a segment boundary reads its escape carry-in straight from the table (no walk at all)
-  c.e = esc.at_entry(start) ? escape_lookup(esc.tab, start >> esc.shift, lane) : run_parity_from_mask(buf, start, lane, m, 0, esc);
+  c.e = run_parity_from_mask(buf, start, lane, m, 0);
   if (b1 == 0x22u) {
-    c.p = run_parity_from_mask(buf, start, lane, m, 1, esc);
+    c.p = run_parity_from_mask(buf, start, lane, m, 1);
   } else {
     const bool ws = b1 == 0x20u || b1 == 0x09u || b1 == 0x0Au || b1 == 0x0Du;
     const u32 cur = b1 | 0x20u;
@@ -206,9 +166,6 @@ __device__ __forceinline__ wave_carry segment_carry_from(const u8 *__restrict__ 
     c.p = (ws || op) ? 0u : 1u;
   }
   return c;
-}
-__device__ __forceinline__ wave_carry segment_carry_in(const u8 *__restrict__ buf, u64 start, u32 lane, esc_ref esc) {
-  return segment_carry_from(buf, start, lane, lookback_issue(buf, start, lane), esc);
 }
 
 // ---- spans that ASSUME (sj_xcarry.h): the carry-in of a span without table and without walk ----------------------------------

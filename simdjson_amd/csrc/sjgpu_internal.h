@@ -99,21 +99,10 @@ void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_pref
                    scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev);
 // result->n = parity; workspace: one byte per 16 KiB segment of the buffer (the per-segment parities and x words, folded by a second launch)
 void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *result, uint8_t *workspace, hipStream_t stream);
-// (stage 2's string stream only -- the stage-1 / minify kernels carry the escape state in their scan, sj_xcarry.h)
-// Escape table for bytes [begin, len) of buf: esc[s] (s = absolute segment index) = parity of the backslash run that ends in
-// front of byte s * SEG_BYTES, i.e. "that byte is escaped".  One 64-byte read per segment for ordinary input.  esc holds
-// ESC_TABLE_BYTES bytes; entry begin / SEG_BYTES - 1 must be valid (from the previous range of the same buffer) if begin > 0.
-// Entries are 2^shift bytes apart: ESC_SHIFT_STAGE1 for every stage-1 kernel (waves start on 16 KiB boundaries),
-// ESC_SHIFT_MINIFY for every minify kernel (k_minify_onchip's waves start on 8 KiB boundaries).  One operation uses one
-// spacing for all ranges of a buffer, so the "previous range" entries it reads are its own.
-constexpr uint32_t ESC_SHIFT_STAGE1 = 14, ESC_SHIFT_MINIFY = 13;
-static_assert((uint64_t(1) << ESC_SHIFT_STAGE1) == SEG_BYTES, "stage-1 waves start on segment boundaries");
-constexpr size_t ESC_TABLE_ENTRIES = ((uint64_t(1) << 32) >> ESC_SHIFT_MINIFY) + 1;
-constexpr size_t ESC_TABLE_BYTES = (ESC_TABLE_ENTRIES + 1023) & ~size_t(1023); // readers load whole aligned dwords
-// clear / clear_bytes (optional, a multiple of 8): memory the same launch zeroes, so that the single-pass pipeline's
-// result + descriptors + ticket need no memset of their own.
-void launch_escape_table(const uint8_t *buf, uint64_t begin, uint64_t len, uint8_t *esc, hipStream_t stream,
-                         void *clear = nullptr, size_t clear_bytes = 0, uint32_t shift = ESC_SHIFT_STAGE1);
+// (rounds 1-3 built an escape table in front of every large scan -- one byte per 16 KiB boundary: is the byte behind it escaped? -- by walking
+// back over the backslash run in front; round 4 carries that bit through the summaries instead, sj_xcarry.h, and the table is gone.)
+// one byte per 16 KiB segment of a 4 GiB buffer: the per-segment scratch of launch_string_parity
+constexpr size_t SEGMENT_BYTES_TABLE = ((uint64_t(1) << 32) / SEG_BYTES + 1024) & ~size_t(1023);
 // bytes [begin, len) of buf; begin > 0 (a multiple of 4 KiB): a later range of a resident buffer, the flags add up in *result;
 // more: the input continues behind len
 void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *result, hipStream_t stream, hipEvent_t *ev,
@@ -183,7 +172,6 @@ struct strings_scratch {
   uint32_t *outq;    // n + 2: where the k-th string's record begins
   void *seg_summary; // per 16 KiB segment of the document
   void *seg_base;
-  uint8_t *esc;      // escape table of the document (launch_escape_table)
   size_t bytes;
 };
 strings_scratch carve_strings_scratch(void *base, uint32_t n, uint64_t len);

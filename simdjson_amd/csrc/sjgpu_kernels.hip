@@ -548,57 +548,6 @@ __global__ __launch_bounds__(RESOLVE_THREADS) void k_string_parity_fold(const u8
 }
 
 
-// =====================================================================================================
-// escape table: esc[s] = "byte s * SEG_BYTES is escaped" = parity of the backslash run ending in front of it.
-// The scan kernels derive a span's escape carry-in by looking back over the bytes in front of it; over one long
-// backslash run that walk would be as long as the run, for EVERY span inside it (quadratic: a 1 GiB document of
-// backslashes would take minutes).  Here every boundary looks back over at most ONE segment, 1 KiB per step; a
-// segment that is nothing but backslashes hands its own carry-in on (16 KiB is even) and is recorded as ESC_PASS,
-// which the readers resolve on demand (escape_lookup, sjgpu_device.h).  Ordinary input: one 64-byte read per segment.
-// =====================================================================================================
-constexpr u32 ESC_PER_WAVE = 8; // boundaries per wave: fewer, fatter workgroups (the kernel is dispatch-bound otherwise)
-
-// state of the boundary in front of which `top` points, from the 1 KiB below it; ESC_PASS if those are all backslashes
-__device__ __forceinline__ u32 escape_step(const u8 *top, u32 lane) {
-  const uint4 v = *reinterpret_cast<const uint4 *>(top - 16u * (lane + 1u)); // lane 0 nearest to the boundary
-  const u32 x[4] = {v.x ^ 0x5C5C5C5Cu, v.y ^ 0x5C5C5C5Cu, v.z ^ 0x5C5C5C5Cu, v.w ^ 0x5C5C5C5Cu}; // zero bytes = backslashes
-  const u64 other = __ballot((x[0] | x[1] | x[2] | x[3]) != 0);
-  if (other == 0) { return ESC_PASS; }
-  // the nearest lane that holds something else: its backslashes above that byte end the run; everything nearer to
-  // the boundary is 16-byte groups of backslashes (an even number)
-  const u32 f = ctz64(other);
-  const u32 hi = x[3] ? x[3] : (x[2] ? x[2] : (x[1] ? x[1] : x[0])); // highest-addressed dword that is not all backslashes
-  const u32 above = u32(__clz(int(hi))) >> 3;                        // backslashes above its last other byte (0..3)
-  return readlane_dyn(above, f) & 1u;                                // whole dwords above it add 4 each: parity unchanged
-}
-
-__global__ __launch_bounds__(256) void k_escape_table(const u8 *__restrict__ buf, u64 s0, u32 nseg, u8 *__restrict__ esc,
-                                                      u64 *__restrict__ clear, u32 clear_words, u32 shift) {
-  for (u32 i = blockIdx.x * 256u + threadIdx.x; i < clear_words; i += gridDim.x * 256u) { clear[i] = 0; }
-  const u32 lane = threadIdx.x & 63u;
-  const u32 r0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * ESC_PER_WAVE;
-  u32 state[ESC_PER_WAVE];
-#pragma unroll
-  for (u32 i = 0; i < ESC_PER_WAVE; i++) { // the last 64 bytes in front of every boundary: independent loads, in flight together
-    const u64 s = s0 + r0 + i;
-    state[i] = 0u; // nothing in front of byte 0
-    if (r0 + i < nseg && s > 0) {
-      const u64 m = __ballot(buf[(s << shift) - 1u - lane] == 0x5Cu);
-      state[i] = ~m ? (ctz64(~m) & 1u) : ESC_PASS;
-    }
-  }
-#pragma unroll
-  for (u32 i = 0; i < ESC_PER_WAVE; i++) {
-    if (r0 + i >= nseg) { break; }
-    const u64 s = s0 + r0 + i;
-    u32 st = state[i];
-    for (u32 k = 0; st == ESC_PASS && k < (1u << shift) / 1024u; k++) { // rare: a run of 64 backslashes and more, 1 KiB per step
-      st = escape_step(buf + (s << shift) - u64(k) * 1024u, lane);
-    }
-    if (lane == 0) { esc[s] = u8(st); }
-  }
-}
-
 } // namespace
 
 // ---- launchers ----------------------------------------------------------------------------------------
@@ -667,16 +616,6 @@ void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *res
   const u32 grid = nseg < 8192u ? nseg : 8192u;
   hipLaunchKernelGGL(k_string_parity, dim3(grid), dim3(64), 0, stream, buf, len, nseg, workspace);
   hipLaunchKernelGGL(k_string_parity_fold, dim3(1), dim3(RESOLVE_THREADS), 0, stream, workspace, nseg, result);
-}
-
-void launch_escape_table(const uint8_t *buf, uint64_t begin, uint64_t len, uint8_t *esc, hipStream_t stream, void *clear,
-                         size_t clear_bytes, uint32_t shift) {
-  const u32 nseg = u32((len - begin + (u64(1) << shift) - 1) >> shift); // entries: one per 2^shift bytes of the range
-  if (nseg == 0) { return; }
-  const u64 s0 = begin >> shift;
-  const u32 per_wg = 4u * ESC_PER_WAVE;
-  hipLaunchKernelGGL(k_escape_table, dim3((nseg + per_wg - 1) / per_wg), dim3(256), 0, stream, buf, s0, nseg, esc,
-                     static_cast<u64 *>(clear), u32(clear_bytes / 8), shift);
 }
 
 } // namespace sjgpu

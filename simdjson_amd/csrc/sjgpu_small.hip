@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_docs(const u8 *__restrict__ in_base, co
     if (live) {
       const u32 lookback = lookback_issue(buf, cstart, lane);
       load_block(buf, pos, len, w);
-      wave_carry wc = segment_carry_from(buf, cstart, lane, lookback, nullptr);
+      wave_carry wc = segment_carry_from(buf, cstart, lane, lookback); // the one kernel that walks: its documents are at most 64 KiB
       if (OP != 1) { uq.pending = utf8_pending_from(lookback, lane); }
       if (OP == 0) {
         const chunk_masks m = scan_chunk<true, true>(w, wc, lane, &uq, u32(cstart / BLOCK_BYTES));

@@ -79,7 +79,8 @@ __device__ __forceinline__ void park_chunk(u8 *park, const u32 (&w)[16], u32 lan
 struct strs_summary {
   u32 bytes0, bytes1; // output bytes if it starts outside / inside a string
   u32 opens0, quotes; // opening quotes if it starts outside; real quotes
-  u32 flags;          // bit 0: odd number of quotes; bit 1 / 2: an escape the reference rejects inside a string if it starts outside / inside
+  u32 flags;          // bit 0: odd number of quotes; bit 1 / 2: an escape the reference rejects inside a string if it starts outside / inside;
+                      // bit 3: the look-back does not settle the segment's carries (segment_carries): the stream declines the document
   u32 pad[3];
 };
 struct strs_base {
@@ -116,18 +117,34 @@ struct strs_chunk {
 };
 
 // escaped 'u' among the 10 bytes in front of a segment (bit k = byte start - 10 + k): byte q is one iff it is a 'u' behind a
-// backslash run of odd length
-__device__ __forceinline__ u32 u_tail_before(const u8 *__restrict__ buf, u64 start, u32 lane, u32 lookback, esc_ref esc) {
+// backslash run of odd length.  The 64 bytes of look-back are all a segment ever reads of what lies in front of it (round 4: no
+// escape table, no walk); a run that fills them to the brim leaves the answer open -- *ambiguous is set and the stream DECLINES the
+// document (below).
+__device__ __forceinline__ u32 u_tail_before(u64 start, u32 lookback, bool *ambiguous) {
   if (start == 0) { return 0; }
   const u64 um = __ballot(lookback == u32('u')) & 0x3FFull; // lane i holds byte start - 1 - i
   if (!um) { return 0; }
   const u64 m = __ballot(lookback == 0x5Cu);
   u32 r = 0;
   for (u64 t = um; t; t &= t - 1) { // wave-uniform
-    const u32 j = ctz64(t);
-    if (run_parity_from_mask(buf, start, lane, m, j + 1u, esc)) { r |= 1u << (9u - j); }
+    const u32 j = ctz64(t), skip = j + 1u;
+    const u64 inv = ~(m >> skip) & (~0ull >> skip); // bit i clear <=> byte start-1-skip-i is a backslash
+    if (!inv) { *ambiguous = true; continue; }
+    if (ctz64(inv) & 1u) { r |= 1u << (9u - j); }
   }
   return r;
+}
+// The carries of a segment from its look-back: exact, or -- 64 backslashes in front, or a 'u' of the last ten bytes behind a run that
+// reaches the look-back's end -- open.  Stage 1 carries such questions through its summaries (sj_xcarry.h); here an escaped byte
+// changes what the OUTPUT holds, not one bit of a mask, so the stream simply leaves documents that raise one to the per-string kernels
+// (sjgpu_strings.hip walk every string from its opening quote and never ask): same buffer, the slower road, for documents with a
+// backslash run of 54 bytes and more that ends within ten bytes of a 16 KiB boundary.
+__device__ __forceinline__ bool segment_carries(u64 start, u32 lane, u32 lookback, strs_carry &wc) {
+  span_x sx;
+  wc.e = span_carry_assume(start, lane, lookback, sx).e;
+  bool ambiguous = sx.kind() == SPAN_B;
+  wc.u = u_tail_before(start, lookback, &ambiguous);
+  return ambiguous;
 }
 
 // one chunk: stage 1's escape and quote algebra (scan_chunk, sjgpu_device.h), then what the strings need on top of it
@@ -183,17 +200,16 @@ __device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carr
 }
 
 // ---- pass 1: what every segment contributes, for both carry-ins ------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_count(const u8 *__restrict__ buf, u64 len, u32 nseg, u32 allow_replacement, const u8 *__restrict__ esc_tab,
-                                                               strs_summary *__restrict__ summ) {
+__global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_count(const u8 *__restrict__ buf, u64 len, u32 nseg, u32 allow_replacement, strs_summary *__restrict__ summ) {
   __shared__ __attribute__((aligned(16))) u8 sh_park[STRS_WAVES][PARK_BYTES];
   const u32 lane = threadIdx.x & 63u;
   const u32 seg = blockIdx.x * STRS_WAVES + (threadIdx.x >> 6);
   if (seg >= nseg) { return; }
   u8 *const park = sh_park[threadIdx.x >> 6];
   const u64 seg_start = u64(seg) * SEG_BYTES;
-  const esc_ref esc(esc_tab);
   const u32 lookback = lookback_issue(buf, seg_start, lane);
   strs_carry wc{0u, 0u, 0u};
+  bool ambiguous = false;
   u32 d0 = 0, dall = 0, o0 = 0, qall = 0;
   u64 bad0 = 0, bad1 = 0;
   for (u32 c = 0; c < SEG_CHUNKS; c++) {
@@ -203,10 +219,7 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_count(const u8 *__rest
     u32 w[16];
     if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
     else { load_block(buf, pos, len, w); }
-    if (c == 0) {
-      wc.e = segment_carry_from(buf, seg_start, lane, lookback, esc).e;
-      wc.u = u_tail_before(buf, seg_start, lane, lookback, esc);
-    }
+    if (c == 0) { ambiguous = segment_carries(seg_start, lane, lookback, wc); }
     no_patches none;
     const strs_chunk m = string_chunk(w, wc, lane, buf, u32(len), u32(pos), allow_replacement != 0, park, none);
     d0 += u32(popc64(m.b.keep & m.in_string));
@@ -227,7 +240,7 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_count(const u8 *__rest
     s.bytes1 = (dall - d0) + 4u * (qall - o0) + o0;
     s.opens0 = o0;
     s.quotes = qall;
-    s.flags = (qall & 1u) | (any0 ? 2u : 0u) | (any1 ? 4u : 0u);
+    s.flags = (qall & 1u) | (any0 ? 2u : 0u) | (any1 ? 4u : 0u) | (ambiguous ? 8u : 0u);
     s.pad[0] = 0; s.pad[1] = 0; s.pad[2] = 0;
     summ[seg] = s;
   }
@@ -277,7 +290,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_strs_resolve(const strs_summary
     const u32 o0 = block_excl_scan1024(my_opens, sh, opens_total);
     if (i < nseg) {
       base[i] = strs_base{u32(bytes_run + b0), opens_run + o0, s, 0u};
-      bad |= s ? (v.flags >> 2) & 1u : (v.flags >> 1) & 1u;
+      bad |= (s ? (v.flags >> 2) & 1u : (v.flags >> 1) & 1u) | ((v.flags >> 3) & 1u);
     }
     s_run = (s_run + par_total) & 1u;
     bytes_run += bytes_total;
@@ -350,7 +363,7 @@ struct window_patches {
   }
 };
 
-__global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__restrict__ buf, u64 len, u32 nseg, u32 allow_replacement, const u8 *__restrict__ esc_tab,
+__global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__restrict__ buf, u64 len, u32 nseg, u32 allow_replacement,
                                                                const strs_base *__restrict__ base, const strs_ctrl *__restrict__ ctrl, u8 *__restrict__ out,
                                                                u32 *__restrict__ outq) {
   __shared__ __attribute__((aligned(16))) u8 sh_stage[STRS_WAVES][STRS_STAGE_BYTES];
@@ -362,7 +375,6 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__rest
   u8 *const dump = stage + STRS_WINDOW + lane;
   const u64 seg_start = u64(seg) * SEG_BYTES;
   const plain_doc src{buf, u32(len)}; // (the rare lane with more \\u escapes than it kept notes of decodes them a second time, from the document)
-  const esc_ref esc(esc_tab);
   const bool allow = allow_replacement != 0;
   const u32 lookback = lookback_issue(buf, seg_start, lane);
   const strs_base sb = base[seg];
@@ -376,8 +388,7 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__rest
     if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
     else { load_block(buf, pos, len, w); }
     if (c == 0) {
-      wc.e = segment_carry_from(buf, seg_start, lane, lookback, esc).e;
-      wc.u = u_tail_before(buf, seg_start, lane, lookback, esc);
+      (void)segment_carries(seg_start, lane, lookback, wc); // (no segment of a document this kernel writes is ambiguous: k_strs_decide)
     }
     escape_notes notes;
     const strs_chunk m = string_chunk(w, wc, lane, buf, u32(len), u32(pos), allow, stage, notes); // (parks the chunk in the window, which is free until the scatter)
@@ -481,8 +492,7 @@ void enqueue_string_stream(const uint8_t *buf, uint64_t len, const uint32_t *idx
   strs_summary *summ = static_cast<strs_summary *>(w.seg_summary);
   strs_base *base = static_cast<strs_base *>(w.seg_base);
   if (nseg) {
-    launch_escape_table(buf, 0, len, w.esc, s);
-    hipLaunchKernelGGL(k_strs_count, dim3((nseg + STRS_WAVES - 1) / STRS_WAVES), dim3(64 * STRS_WAVES), 0, s, buf, len, nseg, a, w.esc, summ);
+    hipLaunchKernelGGL(k_strs_count, dim3((nseg + STRS_WAVES - 1) / STRS_WAVES), dim3(64 * STRS_WAVES), 0, s, buf, len, nseg, a, summ);
   }
   hipLaunchKernelGGL(k_strs_resolve, dim3(1), dim3(RES_THREADS), 0, s, summ, nseg, base, ctrl);
   const bool own_ordinals = listed == nullptr; // else the caller has counted the string tokens (launch_tape_front) and finishes the records itself
@@ -493,7 +503,7 @@ void enqueue_string_stream(const uint8_t *buf, uint64_t len, const uint32_t *idx
   }
   hipLaunchKernelGGL(k_strs_decide, dim3(1), dim3(1), 0, s, ctrl, listed, n, out_cap, w.outq, res);
   if (nseg) {
-    hipLaunchKernelGGL(k_strs_write, dim3((nseg + STRS_WAVES - 1) / STRS_WAVES), dim3(64 * STRS_WAVES), 0, s, buf, len, nseg, a, w.esc, base, ctrl, out, w.outq);
+    hipLaunchKernelGGL(k_strs_write, dim3((nseg + STRS_WAVES - 1) / STRS_WAVES), dim3(64 * STRS_WAVES), 0, s, buf, len, nseg, a, base, ctrl, out, w.outq);
   }
   if (own_ordinals) {
     hipLaunchKernelGGL(k_strs_finalize, dim3(u32((u64(n1) + TOK_THREADS - 1) / TOK_THREADS)), dim3(TOK_THREADS), 0, s, w.kord, n, w.outq, ctrl, offsets, out);

@@ -489,7 +489,6 @@ strings_scratch carve_strings_scratch(void *base, uint32_t n, uint64_t len) {
   w.outq = reinterpret_cast<uint32_t *>(b + at); at += up256((size_t(n) + 2) * 4);
   w.seg_summary = b + at; at += up256(nseg * STRS_SUMMARY_BYTES);
   w.seg_base = b + at; at += up256(nseg * STRS_BASE_BYTES);
-  w.esc = b + at; at += up256(nseg + 64);
   w.bytes = at;
   return w;
 }

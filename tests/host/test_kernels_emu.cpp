@@ -184,7 +184,7 @@ struct workspace {
       summ.assign(nseg + num_groups(cap), seg_summary{0, 0, 0, 0});
       pref.assign(nseg, seg_prefix{0, 0});
       result_and_desc.assign(2 + num_fused_tiles(cap) * 4 + 8, 0);
-      esc.assign(ESC_TABLE_BYTES, 0);
+      esc.assign(SEGMENT_BYTES_TABLE, 0); // launch_string_parity: one byte per segment
       idx.assign(cap + 16, 0);
       out.assign(cap + 64, 0);
       in_store.assign(cap + 64, 0);
