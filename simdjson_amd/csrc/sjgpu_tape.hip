@@ -13,16 +13,17 @@
 // The first error of the serial walk is the smallest (list index, rank) over all tokens that break their rule: one atomicMin.
 //
 // Passes (all asynchronous on the caller's stream; one 32-byte result is read back by the caller):
-//   k_tok_classify / k_tok_scan_sums / k_tok_apply   the byte of every token; tape position and nesting depth of every token in one sweep
-//                     over those bytes; (level, kind, token) of every bracket and comma into the sort's input; strings, atoms and
-//                     numbers into lists
-//   (the string buffer: sjgpu_strings.hip / sjgpu_string_stream.hip, which take the string ordinals from here)
+//   k_tok_classify / k_tok_scan_sums   the byte of every token, the block totals of the six per-token counters
+//   (the string buffer: sjgpu_strings.hip / sjgpu_string_stream.hip, which take the number of string tokens from here)
+//   k_tok_apply       tape position and nesting depth of every token in one sweep over the token bytes; the tape words of the strings (the
+//                     k-th string token's record is the k-th of the buffer) and of the atoms; (level, kind, token) of every bracket and
+//                     comma into the sort's input; numbers and atoms into lists
 //   radix passes      stable LSD radix sort on the level, 6 bits per pass: histogram, scan, scatter   1 wave / 2048 elements;
 //                     the second pass only runs for documents nested 64 deep and more
 //   (container ordinal per sorted element and sorted position of every open: written by the sort's last scatter from a second histogram)
 //   k_tape_match      commas learn their container's kind; closes write BOTH bracket words (count, partner index), kinds checked
 //   k_tape_rules      per token: the walk's rule and the nesting limit; root words
-//   k_tape_strings / k_tape_atoms / k_tape_numbers    the value words, one listed token per lane (lists by k_tok_apply)
+//   k_tape_atoms / k_tape_numbers    the spelling of true / false / null; the number words, one listed token per lane (lists by k_tok_apply)
 //   k_tape_slow_numbers  the handful of number tokens whose rounding needs exact big-integer arithmetic (sj_number.h)
 // Parity: tests/test_gpu_parity.py::test_tape_* against the live reference's dom::parser::parse (tape and string_buf word for word,
 // error codes of broken documents); the same steps run on the CPU in tests/host/test_tape_model.cpp.
@@ -134,8 +135,9 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_classify(const u8 *__restric
     sums[5 * nblocks + blockIdx.x] = int(numbers);
   }
 }
-// one workgroup per row: the block totals become exclusive prefixes, in place
-__global__ __launch_bounds__(1024) void k_tok_scan_sums(int *__restrict__ sums, u32 nblocks) {
+// one workgroup per row: the block totals become exclusive prefixes, in place; totals[k] = the sum of row k (row 2: the string tokens of
+// the list, which the string pass -- it runs between this kernel and k_tok_apply -- takes instead of counting them itself)
+__global__ __launch_bounds__(1024) void k_tok_scan_sums(int *__restrict__ sums, u32 nblocks, int *__restrict__ totals) {
   __shared__ int sh[1024];
   const u32 per = (nblocks + 1023) / 1024;
   const u32 lo = min(threadIdx.x * per, nblocks), hi = min(lo + per, nblocks);
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(1024) void k_tok_scan_sums(int *__restrict__ sums, 
       __syncthreads();
     }
     int run = sh[threadIdx.x] - sum;
+    if (threadIdx.x == 1023) { totals[k] = sh[1023]; }
     for (u32 i = lo; i < hi; i++) {
       const int x = row[i];
       row[i] = run;
@@ -171,7 +174,16 @@ __global__ __launch_bounds__(1024) void k_tok_scan_sums(int *__restrict__ sums, 
 // the members of -- clamped to [0, kmax] (beyond the nesting limit an error is already certain); *m_out = how many went in
 __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__ tokc, u32 n, u32 kmax, const int *__restrict__ sums, u32 nblocks, int *__restrict__ tpos,
                                                          int *__restrict__ depth, u64 *__restrict__ value_list, unsigned short *__restrict__ key, u32 *__restrict__ tok,
-                                                         int *__restrict__ m_out, int *__restrict__ max_level, u64 *__restrict__ number_list) {
+                                                         int *__restrict__ m_out, int *__restrict__ max_level, u64 *__restrict__ number_list,
+                                                         const u32 *__restrict__ str_offsets, strings_handoff strs, u8 *__restrict__ string_buf, u64 *__restrict__ tape,
+                                                         u64 tape_cap) {
+  // Round 4: the string buffer exists when this kernel runs, and the tape words of the string tokens and of the atoms are written HERE,
+  // where the token's tape position and its ordinal among the strings sit in registers -- on_start_string (tape_builder.h:415-419): the payload
+  // of the word is where the record begins; when the stream compaction wrote the buffer the k-th string token's record begins at outq[k] and
+  // its length word is still missing (a record ends where the next begins: [u32 length][bytes][0], on_end_string :428-433), otherwise the
+  // per-string kernels left the offsets per token.  k_tape_strings, the list it read and the tape stores of k_tape_atoms (which still checks
+  // the spelling of true / false / null) are gone.
+  const bool stream_strings = strs.go_stream != nullptr && *strs.go_stream != 0; // uniform
   __shared__ u32 sh[3][TS_THREADS / 64];
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u64 block0 = u64(blockIdx.x) * TS_BLOCK;
@@ -205,6 +217,21 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
     __syncthreads();
     if (i0 <= n) {
       int tp[4], dp[4];
+      // where the records of this thread's string tokens begin: its (at most four) strings have consecutive ordinals, so the five words are
+      // requested HERE, all at once, not one by one inside the loop below (as dependent loads they made this kernel 120 us longer than the
+      // separate pass over a list of string tokens had been: profiles/r04_tape_kernel_stats.txt)
+      const u32 k0 = u32(strs0) + (eb & 0xFFFFu);
+      u32 oq[5] = {0u, 0u, 0u, 0u, 0u}, so[4] = {0u, 0u, 0u, 0u};
+      if (((tb & 0xFFFFu) != 0u)) { // this thread holds string tokens
+        if (stream_strings) {
+#pragma unroll
+          for (u32 q = 0; q < 5; q++) { if (u64(k0) + q <= u64(n) + 1u) { oq[q] = strs.outq[k0 + q]; } } // (outq has n + 2 entries)
+        } else {
+#pragma unroll
+          for (u32 q = 0; q < 4; q++) { if (i0 + q < n) { so[q] = str_offsets[i0 + q]; } }
+        }
+      }
+      u32 sk = 0; // strings of this thread so far
 #pragma unroll
       for (u32 j = 0; j < 4; j++) {
         const u64 i = i0 + j;
@@ -218,9 +245,22 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
         if (i < n) {
           const u64 entry = list_entry(u32(tp[j]), u32(i)); // a list entry carries the token's tape position: the value kernels need no gather for it
           const u32 list = value_list_of(p[j]);
+          const u64 at = u64(u32(tp[j])) + 1u;
           if (list == LIST_NUMBERS) { number_list[numbers_before] = entry; }               // k_tape_numbers
-          else if (list == LIST_STRINGS) { value_list[strings_before] = entry; }           // k_tape_strings
-          else if (list == LIST_REST) { value_list[n - u32(rest_before)] = entry; }        // k_tape_atoms
+          else if (list == LIST_STRINGS) {
+            // (sk is a compile-time-bounded counter: selects, not indexed registers)
+            const u32 begin = sk == 0 ? oq[0] : (sk == 1 ? oq[1] : (sk == 2 ? oq[2] : oq[3]));
+            const u32 next = sk == 0 ? oq[1] : (sk == 1 ? oq[2] : (sk == 2 ? oq[3] : oq[4]));
+            u32 payload = begin;
+            if (stream_strings) { *reinterpret_cast<u32_unaligned_t *>(string_buf + payload) = next - payload - 5u; }
+            else { payload = so[j]; }
+            if (at < tape_cap) { tape[at] = tape_word32('"', payload); }
+            sk++;
+          } else if (list == LIST_REST) {
+            value_list[n - u32(rest_before)] = entry;                                       // k_tape_atoms: the spelling
+            const u32 ch = (four >> (8u * j)) & 0xFFu;
+            if ((ch == 't' || ch == 'f' || ch == 'n') && at < tape_cap) { tape[at] = tape_word32(ch, 0); } // visit_true_atom ..., tape_builder.h:278-329
+          }
         }
         if (i < n && (p[j].a >> 16)) {
           int k = (p[j].b >> 16) ? d : d - 1;
@@ -460,33 +500,10 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_rules(u32 n, u32 max_depth,
   }
 }
 
-// the string tokens, one per lane: on_start_string (tape_builder.h:415-419): the payload of the word is where the string's record begins.
-// When the string buffer came from the stream compaction (sjgpu_string_stream.hip) the records are known by ORDINAL -- the k-th string
-// token is entry k of the list and its record begins at outq[k] -- and their length words are still missing: a record ends where the
-// next one begins ([u32 length][bytes][0]: on_end_string, :428-433).  Otherwise the per-string kernels left the offsets per token.
-__global__ __launch_bounds__(TP_THREADS) void k_tape_strings(const u64 *__restrict__ value_list, const int *__restrict__ count_ptr,
-                                                            const u32 *__restrict__ str_offsets, strings_handoff strs, u8 *__restrict__ string_buf, u64 *__restrict__ tape,
-                                                            u64 tape_cap) {
-  const u32 count = u32(*count_ptr);
-  const bool stream_strings = strs.go_stream != nullptr && *strs.go_stream != 0; // uniform
-  for (u64 k = u64(blockIdx.x) * TP_THREADS + threadIdx.x; k < count; k += u64(gridDim.x) * TP_THREADS) {
-    const u64 entry = value_list[k];
-    u32 payload;
-    if (stream_strings) {
-      payload = strs.outq[k];
-      *reinterpret_cast<u32_unaligned_t *>(string_buf + payload) = strs.outq[k + 1] - payload - 5u;
-    } else {
-      payload = str_offsets[u32(entry)];
-    }
-    const u64 at = (entry >> 32) + 1u;
-    if (at < tape_cap) { tape[at] = tape_word32('"', payload); }
-  }
-}
-// the other one-word tokens (listed from the back of value_list): true / false / null (visit_true_atom ..., tape_builder.h:278-329) -- any
-// other byte here is no token at all and k_tape_rules has said so
+// the other one-word tokens (listed from the back of value_list): true / false / null -- their words are on the tape (k_tok_apply), here their
+// SPELLING is checked against the document; any other byte here is no token at all and k_tape_rules has said so
 __global__ __launch_bounds__(TP_THREADS) void k_tape_atoms(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, const u8 *__restrict__ tokc,
-                                                          const u64 *__restrict__ value_list, const int *__restrict__ count_ptr, u64 *__restrict__ tape, u64 tape_cap,
-                                                          tape_result_dev *__restrict__ res) {
+                                                          const u64 *__restrict__ value_list, const int *__restrict__ count_ptr, tape_result_dev *__restrict__ res) {
   const u32 count = u32(*count_ptr);
   for (u64 k = u64(blockIdx.x) * TP_THREADS + threadIdx.x; k < count; k += u64(gridDim.x) * TP_THREADS) {
     const u64 entry = value_list[n - u32(k)];
@@ -497,8 +514,6 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_atoms(const u8 *__restrict_
     const bool ok = c == 't' ? atom_matches(src, idx[i], 't', 'r', 'u', 'e', 0)
                              : (c == 'f' ? atom_matches(src, idx[i], 'f', 'a', 'l', 's', 'e') : atom_matches(src, idx[i], 'n', 'u', 'l', 'l', 0));
     if (!ok) { report_error(res, error_key(i, 2, c == 't' ? SJ_T_ATOM_ERROR : (c == 'f' ? SJ_F_ATOM_ERROR : SJ_N_ATOM_ERROR))); }
-    const u64 at = (entry >> 32) + 1u;
-    if (at < tape_cap) { tape[at] = tape_word32(c, 0); }
   }
 }
 
@@ -556,6 +571,7 @@ struct tape_workspace {
   u64 *value_list;           // (tape position << 32 | token): string tokens from the front, the other one-word tokens from the back
   int *m;                    // brackets and commas = elements of the sort
   int *sums;                 // k_tok_classify's block totals (6 rows)
+  int *totals;               // ... and the sums of the rows (k_tok_scan_sums): [2] = the string tokens of the list
   u64 *number_list;          // the number tokens, same form
   u32 tok_blocks;
   unsigned short *key_a, *key_b;
@@ -572,7 +588,8 @@ static tape_workspace carve(uint8_t *base, uint32_t n, uint64_t len) {
   w.tiles = blocks_of(n1, RADIX_TILE);
   w.slow_cap = u32(len / 20 + 64 < n1 ? len / 20 + 64 : n1);
   w.res = reinterpret_cast<tape_result_dev *>(take(sizeof(tape_result_dev)));
-  w.n_words = reinterpret_cast<u32 *>(take(64));
+  w.n_words = reinterpret_cast<u32 *>(take(128)); // (behind the result: launch_tape_front clears both with one memset)
+  w.totals = reinterpret_cast<int *>(w.n_words) + 16; // [16 .. 21]
   w.m = reinterpret_cast<int *>(w.n_words) + 8; // [8] = m, [9] = highest level in the sort, [10] = number tokens, [11] = m + 1 (length of the opens scan), [12] = string tokens,
   // [13] = other one-word tokens; n_words[2] = length of the second pass's scan
   w.tokc = take(n1 + 8);
@@ -600,32 +617,36 @@ size_t tape_workspace_bytes(uint32_t n, uint64_t len) { return carve(nullptr, n,
 
 // Stage 2 in two halves, the string buffer in between (sjgpu_capi.hip: sjgpu_stage2_device).  idx[0 .. n] (n >= 1; idx[n] = len, stage 1's first
 // sentinel); workspace: tape_workspace_bytes(n, len), its first bytes are the tape_result_dev afterwards.
-// launch_tape_front: the byte, tape position and depth of every token, the lists of value tokens, the sort's input.  Returns (a device pointer
-// to) the number of string tokens, which the string pass takes instead of counting them itself.
+// launch_tape_front: the byte of every token and the block totals of the six per-token counters.  Returns (a device pointer to) the number of
+// string tokens, which the string pass takes instead of counting them itself.  launch_tape (behind the string pass): tape position and depth of
+// every token, the string and atom words, the lists of the other value tokens, the sort, the brackets, the rules, the numbers.
 const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, void *workspace, hipStream_t s) {
+  (void)max_depth;
   const tape_workspace w = carve(static_cast<uint8_t *>(workspace), n, len);
   const u32 n1 = n + 1;
-  (void)hipMemsetAsync(w.res, 0, sizeof(tape_result_dev), s);
+  // one clear for the result and the control words behind it (they share the first 512 bytes of the workspace), then the three words that are not zero
+  (void)hipMemsetAsync(w.res, 0, size_t(reinterpret_cast<uint8_t *>(w.n_words + 16) - reinterpret_cast<uint8_t *>(w.res)), s);
   (void)hipMemsetAsync(&w.res->error_key, 0xFF, sizeof(u64), s); // NO_ERROR_KEY
   (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.n_words), int(n1), 1, s);
   (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.n_words + 1), int(2 * w.tiles * RADIX_BINS), 1, s);
   (void)hipMemsetAsync(w.ctx, 0, size_t(n1) + 8, s);
-  const u32 kmax = max_depth < 4095u ? max_depth : 4095u;
   hipLaunchKernelGGL(k_tok_classify, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, buf, len, idx, n, w.tokc, w.sums, w.tok_blocks);
-  hipLaunchKernelGGL(k_tok_scan_sums, dim3(TS_SUMS), dim3(1024), 0, s, w.sums, w.tok_blocks);
-  (void)hipMemsetAsync(w.m, 0, 6 * sizeof(int), s);
-  hipLaunchKernelGGL(k_tok_apply, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, w.tokc, n, kmax, w.sums, w.tok_blocks, w.slots, w.depth, w.value_list, w.key_a, w.tok_a, w.m, w.m + 1, w.number_list);
-  return w.m + 4; // the number of string tokens (device)
+  hipLaunchKernelGGL(k_tok_scan_sums, dim3(TS_SUMS), dim3(1024), 0, s, w.sums, w.tok_blocks, w.totals);
+  return w.totals + 2; // the number of string tokens (device)
 }
 
-// launch_tape: the rest.  str_offsets: what the per-string kernels left (n + 1 words), read when they wrote the buffer; strs: where the records
-// of the stream compaction begin, read when IT wrote the buffer (the flag decides on the device); string_buf: the buffer, for the length words.
+// launch_tape: the rest, behind the string pass.  str_offsets: what the per-string kernels left (n + 1 words), read when they wrote the buffer;
+// strs: where the records of the stream compaction begin, read when IT wrote the buffer (the flag decides on the device); string_buf: the
+// buffer, for the length words.
 void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, const uint32_t *str_offsets, strings_handoff strs,
                  uint8_t *string_buf, uint64_t *tape, uint64_t tape_cap, void *workspace, hipStream_t s) {
   const tape_workspace w = carve(static_cast<uint8_t *>(workspace), n, len);
   const u32 n1 = n + 1;
   const u32 grid = blocks_of(n1, TP_THREADS);
   const int *m_ptr = w.m;
+  const u32 kmax = max_depth < 4095u ? max_depth : 4095u;
+  hipLaunchKernelGGL(k_tok_apply, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, w.tokc, n, kmax, w.sums, w.tok_blocks, w.slots, w.depth, w.value_list, w.key_a, w.tok_a, w.m, w.m + 1,
+                     w.number_list, str_offsets, strs, string_buf, tape, tape_cap);
   // two passes of six bits cover levels up to 4095; the second one only runs for documents nested 64 deep and more
   const int *max_level = w.m + 1;
   hipLaunchKernelGGL(k_radix_hist, dim3(w.tiles), dim3(64), 0, s, w.key_a, m_ptr, 0u, w.tiles, w.hist, max_level, w.n_words + 2);
@@ -639,8 +660,7 @@ void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t
   hipLaunchKernelGGL(k_tape_match, dim3(blocks_of(n1, TP_THREADS * TM_PER)), dim3(TP_THREADS), 0, s, sorted, m_ptr, w.opens, w.openpos, w.slots, w.ctx, tape, tape_cap, w.res);
   hipLaunchKernelGGL(k_tape_rules, dim3(blocks_of(n1, TP_THREADS * TW_PER)), dim3(TP_THREADS), 0, s, n, max_depth, w.tokc, w.slots, w.depth, w.ctx, tape, tape_cap, w.res);
   const u32 list_grid = grid < 8192u ? grid : 8192u;
-  hipLaunchKernelGGL(k_tape_strings, dim3(list_grid), dim3(TP_THREADS), 0, s, w.value_list, w.m + 4, str_offsets, strs, string_buf, tape, tape_cap);
-  hipLaunchKernelGGL(k_tape_atoms, dim3(list_grid), dim3(TP_THREADS), 0, s, buf, len, idx, n, w.tokc, w.value_list, w.m + 5, tape, tape_cap, w.res);
+  hipLaunchKernelGGL(k_tape_atoms, dim3(list_grid), dim3(TP_THREADS), 0, s, buf, len, idx, n, w.tokc, w.value_list, w.m + 5, w.res);
   hipLaunchKernelGGL(k_tape_numbers, dim3(list_grid), dim3(TP_THREADS), 0, s, buf, len, idx, w.number_list, w.m + 2, tape, tape_cap, w.slow_list,
                      w.slow_cap, w.res);
   hipLaunchKernelGGL(k_tape_slow_numbers, dim3(64), dim3(64), 0, s, buf, len, idx, w.slots, w.slow_list, w.slow_cap, tape, tape_cap, w.res);
