@@ -171,6 +171,31 @@ SJ_HD u32 token_rule_tables(const rule_tables &T, bool first, u32 c, u32 prev, u
   return 0;
 }
 
+// ---- the kinds of the open containers as a BIT STACK (round 4) --------------------------------------------------------------------------
+// What a comma needs to know -- is the innermost open container an object or an array? -- the sort by nesting level answers for every
+// comma (k_tape_match), at the price of a one-byte scatter per comma and a pass over every token behind it (k_tape_rules).  For documents
+// nested less than 64 deep it is also a PREFIX SCAN: the walk's stack of container kinds is a word with one bit per depth (bit d: the
+// container opened at depth d is an object); an opening bracket at depth d overwrites bit d, nothing else writes, and "the later one
+// wins" composes associatively.  A closed container leaves its bit stale, which nobody reads before the next opening bracket at that depth
+// rewrites it -- up to the document's first error, which is all that counts (the smallest offending index decides).
+struct kind_stack {
+  u64 mask, value; // bits written by the tokens summarised; their values
+};
+SJ_HD kind_stack kinds_then(const kind_stack &a, const kind_stack &b) { return kind_stack{a.mask | b.mask, (a.value & ~b.mask) | b.value}; } // first a, then b
+SJ_HD kind_stack kinds_of_token(u32 c, int depth_in_front) {
+  if ((c != '{' && c != '[') || depth_in_front < 0 || depth_in_front >= 64) { return kind_stack{0, 0}; }
+  const u64 bit = u64(1) << depth_in_front;
+  return kind_stack{bit, c == '{' ? bit : u64(0)};
+}
+// the kind of the container a ',' at this depth (in front of it) separates the members of; *deep is set when the stack word cannot say
+SJ_HD u32 kinds_ctx(const kind_stack &in_front, int depth_in_front, bool *deep) {
+  const int d = depth_in_front - 1;
+  if (d < 0) { return CTX_NONE; }
+  if (d >= 64) { *deep = true; return CTX_NONE; }
+  if (!((in_front.mask >> d) & 1u)) { return CTX_NONE; }
+  return ((in_front.value >> d) & 1u) ? u32(CTX_OBJECT) : u32(CTX_ARRAY);
+}
+
 // A ',' where the walk expects a VALUE (behind '[', ':' or an array's ',') is not a separator: visit_primitive hands it to
 // parse_number like every byte below ':' and the document ends with NUMBER_ERROR (content rank), e.g. "[ ,1]" or {"a":,}.
 SJ_HD bool comma_in_value_position(u64 i, u32 prev, u32 ctx_prev) {

@@ -24,6 +24,7 @@ struct doc_bytes {
 };
 
 // returns the error code; tape filled when it is SUCCESS.  The steps and the arrays are those of sjgpu_tape.hip (kernel names in the comments).
+static unsigned long n_stack_documents = 0; // documents whose container kinds came from the bit stack
 static u32 model(const uint8_t *buf, u32 len, const uint32_t *idx, u32 n, u32 max_depth, const uint32_t *str_offsets, u32 first_bad_string,
                  std::vector<u64> &tape) {
   if (n == 0) { return SJ_EMPTY; }
@@ -96,6 +97,20 @@ static u32 model(const uint8_t *buf, u32 len, const uint32_t *idx, u32 n, u32 ma
     const u64 count = (i == io + 1) ? 0 : (j - jo > 0xFFFFFFu ? 0xFFFFFFu : j - jo);
     tape[close_at] = tape_word(kind == KIND_CLOSE_OBJECT ? u32('}') : u32(']'), open_at);
     tape[open_at] = tape_word(object ? u32('{') : u32('['), (count << 32) | (close_at + 1));
+  }
+  // round 4: the same container kinds from the bit stack (kinds_then over the tokens, sj_tape_rules.h) -- for documents nested less than 64
+  // deep the device takes them from there, checks the rule where it computes tape positions and never writes ctx.  They must agree with the
+  // sort's answer wherever it matters: the rules below run on the stack's kinds when it can speak for the whole document.
+  {
+    kind_stack st{0, 0};
+    bool deep = false;
+    std::vector<uint8_t> ctx2(n + 1, CTX_NONE);
+    for (u32 i = 0; i < n; i++) {
+      const int d = depth[i] > 0x7FFFFFFFll ? 0x7FFFFFFF : (depth[i] < -0x7FFFFFFFll ? -0x7FFFFFFF : int(depth[i]));
+      if (C(i) == ',') { ctx2[i] = uint8_t(kinds_ctx(st, d, &deep)); }
+      st = kinds_then(st, kinds_of_token(C(i), d));
+    }
+    if (!deep) { ctx = ctx2; n_stack_documents++; }
   }
   // k_tape_rules: the rule from the tables a workgroup builds
   unsigned short props[256], accepts[ST_COUNT];
@@ -187,6 +202,6 @@ int main(int argc, char **argv) {
   }
   printf("%lu documents, %lu valid;", docs, valid);
   for (int k = 0; k < 16; k++) { if (codes[k]) { printf(" code %d: %lu", k, codes[k]); } }
-  printf("\n");
+  printf(" (container kinds from the bit stack: %lu documents)\n", n_stack_documents);
   return 0;
 }
