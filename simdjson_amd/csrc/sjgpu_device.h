@@ -678,7 +678,7 @@ __device__ __forceinline__ void emit_indices(u64 structural, u32 pos32, u32 lane
       u32 a_lo = 4u * (off + skew), a_hi = 4u * (off + skew + nlo); // byte addresses
       const u32 pos_hi = pos32 + 32u;
       char *const stage_b = reinterpret_cast<char *>(stage);
-#pragma unroll 2
+#pragma unroll 1 // (ffbl_raw is inline assembly: convergent to the compiler, which then refuses to unroll a loop of unknown length)
       for (u32 t = 0; t < trips; t++) {
         *reinterpret_cast<u32 *>(stage_b + (lo ? a_lo : 4u * EMIT_DUMP_SLOT)) = pos32 + ffbl_raw(lo);
         *reinterpret_cast<u32 *>(stage_b + (hi ? a_hi : 4u * EMIT_DUMP_SLOT)) = pos_hi + ffbl_raw(hi);
