@@ -120,8 +120,8 @@ int sjgpu_result(sjgpu_ctx *ctx, void *stream, sjgpu_scan_result *out);
  *   FUSED  one kernel, chained scan between tiles: reads every byte once, one launch -- fastest on small inputs
  *          and, in its pipelined form (look-back + emission of a tile deferred behind the scan of the next), on
  *          large ones;
- *   AUTO   FUSED up to 8 MiB (16 KiB tiles) and from 192 MiB (pipelined 64 KiB tiles), SPLIT in between -- and, for
- *          stage 1 from 192 MiB, also when the previous large scan of this context produced fewer than 0.2 offsets
+ *   AUTO   FUSED up to 8 MiB (16 KiB tiles) and from 640 MiB (pipelined 64 KiB tiles), SPLIT in between -- and, for
+ *          stage 1 from 640 MiB, also when the previous large scan of this context produced fewer than 0.2 offsets
  *          per byte (sparse output: NDJSON, pretty-printed text), where SPLIT is 3-8 % faster.
  * All produce identical bytes; a single-pass call that raises SJGPU_F_INTERNAL is re-run split by the
  * host-buffer entry points, device-resident callers see the flag in sjgpu_result(). */

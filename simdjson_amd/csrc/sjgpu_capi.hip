@@ -325,13 +325,18 @@ hipStream_t pick(sjgpu_ctx *, void *stream) { return static_cast<hipStream_t>(st
 // loses 3-8 % on sparse output (twitter-like 0.12 offsets per byte: 2 180-2 250 vs 2 260-2 320 GB/s; amazon NDJSON 0.06:
 // 2 290-2 440 vs 2 580-2 620), so for stage 1 AUTO goes by the density the previous large scan of this context saw.
 constexpr size_t AUTO_FUSED_BELOW = size_t(8) << 20;
-constexpr size_t AUTO_FUSED_FROM = size_t(192) << 20;
+// (round 4, profiles/r04_pipeline_sweep.txt: with the table launch gone and the emission's shorter chains the split pipeline is the faster one
+// on dense output up to 512 MiB -- 287 against 296 us there, 165 against 175 at 256 MiB -- and the single-pass kernel from 768 MiB on: 408
+// against 422 us, 521 against 556 at 1 GiB; its fixed cost, one iteration to fill and one to drain, is ~35 us.  Was 192 MiB.)
+constexpr size_t AUTO_FUSED_FROM = size_t(640) << 20;
+constexpr size_t AUTO_FUSED_FROM_MINIFY = size_t(192) << 20;
 constexpr size_t DIRECT_HOST_MAX = size_t(2) << 20; // sjgpu_stage1 on host buffers: up to here the kernels write the offsets into host memory themselves
 constexpr uint32_t AUTO_DENSE_PERMILLE = 200;
 bool use_fused(const sjgpu_ctx *ctx, size_t len, int op = 1) { // op 0: stage 1, 1: minify
   if (ctx->pipeline != 2) { return ctx->pipeline == 1; }
   if (len <= AUTO_FUSED_BELOW) { return true; }
-  return len >= AUTO_FUSED_FROM && (op != 0 || ctx->density_permille >= AUTO_DENSE_PERMILLE);
+  if (op != 0) { return len >= AUTO_FUSED_FROM_MINIFY; } // minify: the on-chip kernel reads its input once, the split pipeline twice
+  return len >= AUTO_FUSED_FROM && ctx->density_permille >= AUTO_DENSE_PERMILLE;
 }
 
 // `len` is the END of the scan (bytes [org.begin, len) are scanned); a whole document has org = {0, 0, 0}
@@ -634,6 +639,10 @@ extern "C" int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) {
       ctx->max_workgroups = uint32_t(cus) * 8u; // more than can be resident; surplus workgroups just start later
+    }
+    if (const char *v = std::getenv("SJGPU_MAX_WORKGROUPS")) { // A/B switch: the grid of the single-pass kernels
+      const unsigned long g = std::strtoul(v, nullptr, 10);
+      if (g >= 64 && g <= 65536) { ctx->max_workgroups = uint32_t(g); }
     }
   }
   if (e == hipSuccess) { e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking); }
