@@ -1,0 +1,30 @@
+"""A/B: the pipelined single-pass kernel with 64 KiB tiles (default) and with 32 KiB tiles (SJGPU_PIPE_WC=2); each variant in its own process."""
+import os, sys, time, json, subprocess
+if len(sys.argv) > 1:
+    sys.path.insert(0, os.getcwd())
+    import torch
+    from simdjson_amd import capi, corpus
+    out = {"pipe_wc": os.environ.get("SJGPU_PIPE_WC", "4")}
+    for kind, gen, size in (("large_random", corpus.large_random, 256 << 20), ("large_random", corpus.large_random, 512 << 20), ("large_random", corpus.large_random, 1 << 30),
+                            ("deep_nesting", corpus.deep_nesting_doc, 1 << 30), ("amazon_ndjson", corpus.amazon_ndjson, 1 << 30)):
+        a, _ = gen(size, 1000)
+        L = len(a)
+        p = capi.DomParserImplementation(L)
+        p.set_pipeline("fused")
+        buf = torch.from_numpy(a).cuda(); idx = torch.empty(L + 16, dtype=torch.int32, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        for _ in range(3): p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, st)
+        torch.cuda.synchronize()
+        dt = 1e9
+        for _trial in range(4):
+            t0 = time.perf_counter()
+            for _ in range(15): p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, st)
+            torch.cuda.synchronize()
+            dt = min(dt, (time.perf_counter() - t0) / 15)
+        out[f"{kind}_{size >> 20}MiB_us"] = round(dt * 1e6, 1)
+        out["kernel"] = p.profile_kernel()
+        p.close(); del buf, idx
+    print(json.dumps(out), flush=True)
+else:
+    for wc in ("4", "2", "4", "2"):
+        subprocess.run([sys.executable, __file__, "x"], env=dict(os.environ, SJGPU_PIPE_WC=wc))

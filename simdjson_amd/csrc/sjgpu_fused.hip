@@ -443,14 +443,18 @@ __device__ __forceinline__ void phase_prio(u32 policy, u32 phase /* 0 scan, 1 lo
   const u32 table[6][3] = {{0, 0, 0}, {0, 3, 3}, {3, 0, 0}, {0, 3, 0}, {0, 0, 3}, {1, 3, 2}};
   set_prio(table[policy < 6 ? policy : 0][phase]);
 }
-template <int OP, bool TRACE = false>
+// PWC: chunks per wave and tile: 4 (64 KiB tiles) or 2 (32 KiB tiles: half the fixed cost of filling and draining the pipeline -- one iteration
+// each --, twice the descriptors, look-backs and barriers per byte; A/B: env SJGPU_PIPE_WC)
+template <int OP, bool TRACE = false, u32 PWC = FUSED_WAVE_CHUNKS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fused_pipelined(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc,
                                                          u32 *__restrict__ ticket, u32 ntiles, void *__restrict__ out,
                                                          u64 out_words, scan_result_dev *__restrict__ result, scan_origin org,
                                                          u64 *__restrict__ trace = nullptr) {
 #define SJ_PSTAMP(k) do { if (TRACE && threadIdx.x == 0 && iter < PIPE_TRACE_ITERS) { trace[(u64(blockIdx.x) * PIPE_TRACE_ITERS + iter) * TRACE_STAMPS + (k)] = wall_clock64(); } } while (0)
   const u32 carry = org.carry;
-  constexpr u32 WC = FUSED_WAVE_CHUNKS;
+  constexpr u32 WC = PWC;
+  static_assert(WC == 2 || WC == 4, "the mask FIFO is written for 2 or 4 chunks per wave");
+  constexpr u32 TILE_BYTES = FUSED_WAVES * WC * CHUNK_BYTES;
   constexpr u32 STAGE_WORDS = (OP == 0) ? emit_stage_words(PIPE_WINDOW) : (MINIFY_STAGE_BYTES / 4);
   constexpr u32 WAVE_BYTES = WC * CHUNK_BYTES;
   __shared__ u32 sh_tile[2];                 // [iteration parity]: the ticket of an iteration is drawn one iteration ahead
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     phase_prio(prio_policy, 0);
     u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0; // slot 3 = oldest chunk
     if (have) {
-      const u64 wave_start = org.begin + u64(tile) * FUSED_TILE_BYTES + u64(wave) * WAVE_BYTES;
+      const u64 wave_start = org.begin + u64(tile) * TILE_BYTES + u64(wave) * WAVE_BYTES;
       u32 n_out = 0, n_in = 0, parity = 0, xw = 0;
       bool f_ci = false, f_co = false;
       if (wave_start < len) {
@@ -627,7 +631,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // ---- every wave: emit its share of the pending tile from the LDS masks -----------------------------------------
     phase_prio(prio_policy, 2);
     if (pend && sh_prefix[2] != 0u) {
-      const u64 wave_start = org.begin + u64(pend_tile) * FUSED_TILE_BYTES + u64(wave) * WAVE_BYTES;
+      const u64 wave_start = org.begin + u64(pend_tile) * TILE_BYTES + u64(wave) * WAVE_BYTES;
       u32 s = sh_prefix[0], x = sh_prefix[3], base = sh_prefix[1];
       wave_state(sh_wave[cur ^ 1u], wave, s, x, base);
       if (wave_start < len) {
@@ -640,12 +644,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const u64 flip = own.se ? ~0ull : 0ull;
         bool overflow = false;
         if (OP == 0) { // sparse spans leave in one piece, medium ones as two pairs of chunks, dense ones chunk by chunk
-          u64 st[4];
+          u64 st[WC];
 #pragma unroll
           for (u32 c = 0; c < WC; c++) { st[c] = sh_mask_a[wave][c][lane] & ~(sh_mask_b[wave][c][lane] ^ flip); } // zero beyond len
           span_patch(st, pxw, x, own.se, lane);
           const u32 span_count = (carry & CARRY_DEBUG_NO_SPAN_HINT) ? 0u : xs_count(sh_wave[cur ^ 1u][wave][1], sh_wave[cur ^ 1u][wave][2], own);
-          emit_span4_adaptive<PIPE_WINDOW>(st, u32(wave_start), lane, static_cast<u32 *>(out), out_words, base, sh_stage[wave], overflow, span_count);
+          if constexpr (WC == 4) {
+            emit_span4_adaptive<PIPE_WINDOW>(st, u32(wave_start), lane, static_cast<u32 *>(out), out_words, base, sh_stage[wave], overflow, span_count);
+          } else { // two chunks: in one piece when they fit the window, else chunk by chunk
+            if (!(span_count <= PIPE_WINDOW && emit_span<PIPE_WINDOW, 2>(st, u32(wave_start), lane, static_cast<u32 *>(out), out_words, base, sh_stage[wave], overflow))) {
+              emit_indices<PIPE_WINDOW>(st[0], u32(wave_start) + lane * BLOCK_BYTES, lane, static_cast<u32 *>(out), out_words, base, sh_stage[wave], overflow);
+              emit_indices<PIPE_WINDOW>(st[1], u32(wave_start) + CHUNK_BYTES + lane * BLOCK_BYTES, lane, static_cast<u32 *>(out), out_words, base, sh_stage[wave], overflow);
+            }
+          }
         } else {
 #pragma unroll 1
           for (u32 c = 0; c < WC; c++) {
@@ -664,11 +675,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     SJ_PSTAMP(6);
     // ---- the tile scanned in this iteration becomes the pending one: park its masks in (this wave's rows of) LDS ----
-    if (have) {
-      sh_mask_a[wave][0][lane] = a3; sh_mask_b[wave][0][lane] = b3;
-      sh_mask_a[wave][1][lane] = a2; sh_mask_b[wave][1][lane] = b2;
-      sh_mask_a[wave][2][lane] = a1; sh_mask_b[wave][2][lane] = b1;
-      sh_mask_a[wave][3][lane] = a0; sh_mask_b[wave][3][lane] = b0;
+    if (have) { // chunk c sits in FIFO slot WC - 1 - c
+      if constexpr (WC == 4) {
+        sh_mask_a[wave][0][lane] = a3; sh_mask_b[wave][0][lane] = b3;
+        sh_mask_a[wave][1][lane] = a2; sh_mask_b[wave][1][lane] = b2;
+        sh_mask_a[wave][2][lane] = a1; sh_mask_b[wave][2][lane] = b1;
+        sh_mask_a[wave][3][lane] = a0; sh_mask_b[wave][3][lane] = b0;
+      } else {
+        sh_mask_a[wave][0][lane] = a1; sh_mask_b[wave][0][lane] = b1;
+        sh_mask_a[wave][1][lane] = a0; sh_mask_b[wave][1][lane] = b0;
+      }
     }
     pend_tile = have ? tile : NO_TILE;
     if (threadIdx.x == 0 && early) { sh_tile[cur ^ 1u] = have ? next_ticket : NO_TILE; } // visible behind the barrier at the loop top
@@ -957,6 +973,20 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
       mark(ev, 2, stream);
       mark(ev, 3, stream);
       return "k_minify_onchip<4>";
+    }
+    static const unsigned pipe_wc = []() { const char *v = std::getenv("SJGPU_PIPE_WC"); return v ? unsigned(std::atoi(v)) : 4u; }(); // A/B switch: 2 = 32 KiB tiles
+    if (op == 0 && pipe_wc == 2u) {
+      const u32 nt2 = u32((len - org.begin + FUSED_TILE_BYTES / 2 - 1) / (FUSED_TILE_BYTES / 2));
+      u32 *ticket2 = reinterpret_cast<u32 *>(desc + nt2);
+      const size_t clear2 = sizeof(scan_result_dev) + (size_t(nt2) + 1) * sizeof(u64);
+      if (contiguous) { (void)hipMemsetAsync(result, 0, clear2, stream); } else { (void)hipMemsetAsync(desc, 0, (size_t(nt2) + 1) * sizeof(u64), stream); }
+      const u32 cap2 = (nt2 + 1) / 2;
+      hipLaunchKernelGGL((k_fused_pipelined<0, false, 2>), dim3(cap2 < max_workgroups ? cap2 : max_workgroups), dim3(256), 0, stream, buf, len, desc, ticket2, nt2, out, out_words,
+                         result, org);
+      mark(ev, 1, stream);
+      mark(ev, 2, stream);
+      mark(ev, 3, stream);
+      return "k_fused_pipelined<0> (32 KiB tiles)";
     }
     if (op == 0) {
       hipLaunchKernelGGL((k_fused_pipelined<0>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result, org);
