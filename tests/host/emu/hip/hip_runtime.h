@@ -38,12 +38,19 @@ struct uint4 { uint32_t x, y, z, w; };
 struct uint2 { uint32_t x, y; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+struct int4 { int32_t x, y, z, w; };
+static inline int4 make_int4(int32_t x, int32_t y, int32_t z, int32_t w) { return int4{x, y, z, w}; }
 
 typedef void *hipStream_t;
 typedef void *hipEvent_t;
 enum hipError_t { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorUnknown = 999 };
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
+typedef void *hipDeviceptr_t;
+static inline hipError_t hipMemsetD32Async(hipDeviceptr_t p, int v, size_t count, hipStream_t) {
+  for (size_t i = 0; i < count; i++) { static_cast<int32_t *>(p)[i] = v; }
+  return hipSuccess;
+}
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
 
@@ -169,6 +176,8 @@ static inline void __builtin_amdgcn_s_waitcnt(int) {}
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_s_sleep(int) { sj_emu::yield_all(); }
 static inline void __syncthreads() { sj_emu::block_sync(); }
+namespace sj_emu { int block_or(int pred); }
+static inline int __syncthreads_or(int pred) { return sj_emu::block_or(pred); }
 // 100 MHz on the device; here wall time at 1 MHz, so that the kernels' one-second give-up limits become 100 s
 static inline uint64_t wall_clock64() {
   return uint64_t(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count());

@@ -74,6 +74,7 @@ struct workgroup {
   unsigned nthreads = 0, live = 0;
   unsigned bar_arrived = 0;
   uint64_t bar_completed = 0;
+  int bar_or[2] = {0, 0}; // __syncthreads_or: the predicates of the barrier in flight, by its parity
   std::vector<fiber> fibers;
   std::vector<wave_state> waves;
   std::vector<char *> stacks; // kept between workgroups of this OS thread
@@ -131,13 +132,14 @@ void run_workgroup(workgroup &g, unsigned b, dim3 grid, dim3 block, const std::f
   g.bid = dim3(b);
   g.grid = grid;
   g.nthreads = block.x;
-  if (g.nthreads == 0 || g.nthreads > MAX_THREADS || (g.nthreads & 63u)) { std::fprintf(stderr, "sj_emu: block size %u\n", g.nthreads); std::abort(); }
+  if (g.nthreads == 0 || g.nthreads > MAX_THREADS) // (a last wave with fewer than 64 lanes: the missing lanes read as zero, like lanes that have left)
+    { std::fprintf(stderr, "sj_emu: block size %u\n", g.nthreads); std::abort(); }
   g.live = g.nthreads;
   g.bar_arrived = 0;
   g.bar_completed = 0;
   g.body = &body;
   g.fibers.assign(g.nthreads, fiber());
-  g.waves.assign(g.nthreads / 64, wave_state());
+  g.waves.assign((g.nthreads + 63) / 64, wave_state());
   while (g.stacks.size() < g.nthreads) {
     void *p = mmap(nullptr, STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (p == MAP_FAILED) { std::perror("sj_emu: mmap"); std::abort(); }
@@ -199,6 +201,19 @@ void block_sync() {
     g.bar_completed++;
   }
   while (g.bar_completed == gen) { switch_away(); }
+}
+int block_or(int pred) { // __syncthreads_or: a barrier that also ORs a predicate over the workgroup
+  workgroup &g = *wg;
+  const uint64_t gen = g.bar_completed;
+  const unsigned p = unsigned(gen & 1u);
+  if (g.bar_arrived == 0) { g.bar_or[p] = 0; } // the first to arrive clears the slot (the barrier two back has been read by everybody)
+  if (pred) { g.bar_or[p] = 1; }
+  if (++g.bar_arrived == g.live) {
+    g.bar_arrived = 0;
+    g.bar_completed++;
+  }
+  while (g.bar_completed == gen) { switch_away(); }
+  return g.bar_or[p];
 }
 void yield_all() {
   switch_away();

@@ -1,0 +1,98 @@
+"""CPU tier: the gfx950 KERNEL SOURCES of stage 2 -- sjgpu_tape.hip, sjgpu_string_stream.hip, sjgpu_strings.hip and the scans of
+sjgpu_finish.hip, compiled as C++ against tests/host/emu (a workgroup = an OS thread, a lane = a fiber) -- run the three launches of
+sjgpu_stage2_device on whole documents and are compared with the oracle's serial walk (tests/host/test_tape_emu.cpp): error code
+always, tape and string buffer byte for byte when the document is valid.  tests/test_tape_model.py checks the construction; this
+checks the kernels as written.  The GPU tier is left with what hipcc and the hardware make of the same source."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import jsongen
+from simdjson_amd import _paths
+
+CSRC = os.path.join(_paths.PKG_DIR, "csrc")
+EMU = os.path.join(_paths.REPO_ROOT, "tests", "host", "emu")
+KERNEL_TUS = ("sjgpu_tape", "sjgpu_strings", "sjgpu_string_stream", "sjgpu_finish")
+
+
+def build(out, defines=()):
+    inc = ["-I", EMU, "-I", _paths.INCLUDE_DIR, "-I", CSRC, "-I", _paths.ORACLE_DIR]
+    jobs = []
+    for name in KERNEL_TUS:
+        jobs.append(subprocess.Popen(["g++", "-std=c++17", "-O1", "-Wno-attributes", "-Wno-unknown-pragmas", *defines, "-x", "c++", *inc, "-c",
+                                      os.path.join(CSRC, name + ".hip"), "-o", str(out / (name + ".o"))]))
+    jobs.append(subprocess.Popen(["g++", "-std=c++17", "-O2", *inc, "-c", os.path.join(EMU, "sj_emu.cpp"), "-o", str(out / "sj_emu.o")]))
+    jobs.append(subprocess.Popen(["g++", "-std=c++17", "-O2", "-Wno-attributes", *inc, "-c",
+                                  os.path.join(_paths.REPO_ROOT, "tests", "host", "test_tape_emu.cpp"), "-o", str(out / "driver.o")]))
+    for name in ("sj_oracle", "sj_oracle_stage2"):
+        jobs.append(subprocess.Popen(["gcc", "-O2", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-c", os.path.join(_paths.ORACLE_DIR, name + ".c"),
+                                      "-o", str(out / (name + ".o"))]))
+    assert all(j.wait() == 0 for j in jobs)
+    exe = str(out / "test_tape_emu")
+    objs = [str(out / (f + ".o")) for f in (*KERNEL_TUS, "sj_emu", "driver", "sj_oracle", "sj_oracle_stage2")]
+    subprocess.run(["g++", *objs, "-lpthread", "-lm", "-o", exe], check=True)
+    return exe
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    exe = build(tmp_path_factory.mktemp("tape_emu"))
+
+    def run(docs, max_depth=1024, force_walk=0, expect_ok=True):
+        blob = b"".join(struct.pack("<I", len(d)) + d for d in docs)
+        p = subprocess.run([exe, str(max_depth), str(force_walk)], input=blob, capture_output=True, timeout=1500)
+        if expect_ok:
+            assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+            assert " 0 mismatches" in p.stdout.decode()
+        return p.stdout.decode()
+    return run
+
+
+def _big(rng, lo, hi, sep=b",\n"):
+    return b"[" + sep.join(jsongen.random_document(rng) for _ in range(int(rng.integers(lo, hi)))) + b"]"
+
+
+def test_fixtures(emu):
+    docs = [open(os.path.join(_paths.REPO_ROOT, "tests", "golden", "jsonexamples", name), "rb").read() for name in ("twitter.json", "citm_catalog.json")]
+    assert "2 documents, 2 valid" in emu(docs)
+    assert "2 documents, 2 valid" in emu(docs, force_walk=1)  # the per-string kernels write the same buffer
+
+
+def test_small_documents_valid_and_broken(emu):
+    rng = np.random.default_rng(11)
+    assert "400 documents, 400 valid" in emu([jsongen.random_document(rng) for _ in range(400)])
+    out = emu([jsongen.mutate(rng, jsongen.random_document(rng, max_depth=4)) for _ in range(2500)])
+    for code in (3, 5, 6, 7, 8, 9):
+        assert f"code {code}:" in out, out
+
+
+def test_documents_of_many_blocks(emu):
+    """token blocks of 4 096, sort tiles of 2 048 elements, string segments of 16 KiB: documents that span dozens of each, valid and broken"""
+    rng = np.random.default_rng(12)
+    docs = [_big(rng, 50, 600) for _ in range(30)] + [_big(rng, 3000, 6000) for _ in range(2)]
+    assert f"{len(docs)} documents, {len(docs)} valid" in emu(docs)
+    out = emu([jsongen.mutate(rng, _big(rng, 50, 400, b",")) for _ in range(80)])
+    assert "code 3:" in out and "code 0:" in out, out
+
+
+def test_hand_written_cases_numbers_and_depth_limits(emu):
+    docs = []
+    for t in jsongen.number_corner_cases()[::7]:
+        t = t.encode()
+        docs += [b"[" + t + b"]", t, b'{"k":' + t + b" }"]
+    docs += [b"[,]", b"[ ,1]", b'{"a":,}', b"[1,,2]", b'{"a":1,,}', b'{"a":1 "b":2}', b'{"a" "b"}', b'{"a"}', b"[1 2]", b"[}", b"{]", b"[1}", b'{"a":1]', b"]", b"}", b"[]]", b"{}}",
+             b"[[]", b"[[1]", b'{"a":{}', b"[", b"{", b'"a" "b"', b"1 2", b"[] []", b"nul", b"truex", b"[truex]", b"!", b"[!]", b'{"a":!}', b"[1]x", b'{x:1}', b"[:]", b'{"a"::1}',
+             b'["\\q"]', b'{"\\q":1}', b'["a","\\ud800"]', b"[-]", b"[0123]", b'[1,"a",true,null,false,{},[],{"b":[]}]', b'{"a":[],"b":{},"c":[[],[[]],{}]}']
+    emu(docs)
+    for max_depth in (1, 2, 3, 16):
+        docs = []
+        for depth in (1, 2, 3, 4, 15, 16, 17, 70, 130):
+            for inner in (b"", b"1", b"{}", b'{"a":[]}'):
+                docs.append(b"[" * depth + inner + b"]" * depth)
+                docs.append(b'{"a":' * depth + (inner or b"0") + b"}" * depth)
+        emu(docs, max_depth)
+    deep = [b"[" * d + b"1" + b"]" * d for d in (63, 64, 65, 200, 1023)] + [b'{"a":[' * 100 + b"{}" + b"]}" * 100]  # both sort paths
+    emu(deep)
