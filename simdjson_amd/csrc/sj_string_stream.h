@@ -8,7 +8,7 @@
 //   * every escape replaced by what it stands for: "\n" -> one byte, "é" -> two, a surrogate pair (12 bytes) -> four.
 // That is the shape of minify: a lane owns 64 bytes, works on 64-bit masks, and the position of a byte in the output is a
 // prefix sum.  Which bytes are escaped and which quotes are real is stage 1's escape / quote algebra (sj_block.h); new here
-// is only the bookkeeping of \u escapes, which may reach over the end of a block (the next block looks back 10 bytes).
+// is only the bookkeeping of \u escapes, whose bytes reach over block boundaries: masks, too (unicode_masks below).
 // An escape the reference rejects (stringparsing.h:22-43 escape_map, :50-96 handle_unicode_codepoint) is reported as a mask;
 // the kernels fall back to the per-string walk of sjgpu_strings.hip for such documents, so this path only ever produces
 // buffers of documents whose strings are all valid -- byte for byte the reference's.
@@ -34,58 +34,103 @@ SJ_HD u32 simple_escape_value(u32 c) { // escape_map, stringparsing.h:22-43 (0 =
   default: return 0u;
   }
 }
-// jsoncharutils::hex_to_u32_nocheck (/root/reference/include/simdjson/generic/jsoncharutils.h:31-38): 0xFFFFFFFF = not hex
-template <class SRC> SJ_HD u32 hex4_at(const SRC &src, u32 pos) {
-  u32 v = 0;
-  for (u32 k = 0; k < 4; k++) {
-    const u32 c = src.byte(pos + k);
-    u32 d;
-    if (c - u32('0') <= 9u) { d = c - u32('0'); }
-    else if ((c | 0x20u) - u32('a') <= 5u) { d = (c | 0x20u) - u32('a') + 10u; }
-    else { return 0xFFFFFFFFu; }
-    v = (v << 4) | d;
-  }
-  return v;
-}
-
-// One \u escape whose 'u' sits at upos (handle_unicode_codepoint, stringparsing.h:50-96; codepoint_to_utf8, jsoncharutils.h:52-80).
-struct u_escape {
-  u32 len;    // bytes it stands for: 1 ... 4 (0 when rejected)
-  u32 span;   // bytes behind the 'u' that belong to it: 4 hex digits, or 10 when a low surrogate's escape was consumed with it
-  u32 packed; // those bytes, the first one in the low bits
-  bool bad;   // the reference rejects the string
+// ---- \u escapes, without a walk (round 4) -----------------------------------------------------------------------------------------------
+// handle_unicode_codepoint (stringparsing.h:50-96) with codepoint_to_utf8 (jsoncharutils.h:52-80) turns "\uXXXX" into 1 - 3 bytes and a
+// surrogate pair "\uD8..\uDC.." into 4.  Rounds 2-3 walked a lane's escapes front to back with a decoder (a divergent loop that read the
+// document byte by byte: 240 us of k_strs_write's 370 on the synthetic twitter-like text, profiles/r03_strings_escape_cost.txt).  Nothing
+// in the result needs the walk:
+//   * WHICH bytes of an escape stay is a function of its first three hex digits: the bytes an escape stands for are put on its LAST hex
+//     digits -- 1 byte: the 4th; 2 bytes: 3rd, 4th; 3 bytes: 2nd ... 4th; a pair: the high escape's 4th digit and the low escape's 2nd ... 4th --
+//     so that every output byte is a function of document bytes AT OR IN FRONT of its own position (UTF-8's first byte needs the leading
+//     digits only) and "is the byte at position q kept" is a mask computed from look-back alone: shifts of the escaped-'u' mask ANDed with
+//     digit classes.  The stream comes out the same: between the backslash and the last digit nothing else is kept.
+//   * WHAT a kept byte becomes is computed by whoever owns the byte, from at most ten bytes in front of it (u_escape_byte).
+//   * a rejected escape (a digit that is no hex digit, a lone low surrogate, a high one without a low one behind it) is a mask, too.  It is
+//     raised wherever the pattern occurs, inside a string or not: a backslash outside a string makes the document invalid anyway (stage 2
+//     rejects the token), and all a raised flag does is send the document down the per-string road, which is always right.
+// Masks shift towards higher positions only; what comes in at the bottom is what left the block in front at the top (u_tops), handed
+// over in four stages because a shifted mask is ANDed with a class before it is shifted again.
+SJ_HD u32 hex_digit_value(u32 c) { return (c & 0xFu) + 9u * (c >> 6); } // of a byte that IS a hex digit
+SJ_HD bool byte_is_hex(u32 c) { return c - u32('0') <= 9u || (c | 0x20u) - u32('a') <= 5u; }
+SJ_HD bool byte_is_octal(u32 c) { return c - u32('0') <= 7u; }
+SJ_HD bool byte_is_d(u32 c) { return (c | 0x20u) == u32('d'); }
+SJ_HD bool byte_is_89ab(u32 c) { return c == '8' || c == '9' || (c | 0x20u) == u32('a') || (c | 0x20u) == u32('b'); }
+SJ_HD bool byte_is_cdef(u32 c) { return (c | 0x20u) - u32('c') <= 3u; }
+struct hex_classes {
+  u64 hex, zero, oct, d, s8b, scf; // [0-9a-fA-F], '0', [0-7], [dD], [89abAB], [c-fC-F]
 };
-template <class SRC> SJ_HD u_escape decode_u_escape(const SRC &src, u32 upos, bool allow_replacement) {
-  u_escape e{0u, 4u, 0u, false};
-  u32 cp = hex4_at(src, upos + 1);
-  if (cp >= 0xd800u && cp < 0xdc00u) {
-    if (src.byte(upos + 5) != '\\' || src.byte(upos + 6) != 'u') {
-      if (!allow_replacement) { e.bad = true; return e; }
-      cp = 0xfffdu;
-    } else {
-      const u32 low = hex4_at(src, upos + 7) - 0xdc00u;
-      if (low >> 10) {
-        if (!allow_replacement) { e.bad = true; return e; }
-        cp = 0xfffdu; // the second escape is not consumed: it is looked at again on its own
-      } else {
-        cp = (((cp - 0xd800u) << 10) | low) + 0x10000u;
-        e.span = 10;
-      }
-    }
-  } else if (cp >= 0xdc00u && cp <= 0xdfffu) {
-    if (!allow_replacement) { e.bad = true; return e; }
-    cp = 0xfffdu;
+SJ_HD hex_classes classify_hex(const planes &P) {
+  const u64 b0 = P.b[0], b1 = P.b[1], b2 = P.b[2], b3 = P.b[3], b4 = P.b[4], b5 = P.b[5], b6 = P.b[6], b7 = P.b[7];
+  const u64 row3 = ~b7 & ~b6 & b5 & b4;  // 0x30 ... 0x3F
+  const u64 al = ~b7 & b6 & ~b4 & ~b3;   // 0x40 ... 0x47, 0x60 ... 0x67
+  const u64 low_any = b2 | b1 | b0, low_all = b2 & b1 & b0;
+  hex_classes h;
+  h.oct = row3 & ~b3;
+  h.zero = h.oct & ~low_any;
+  h.hex = (row3 & (~b3 | (~b2 & ~b1))) | (al & low_any & ~low_all);
+  h.d = al & b2 & ~b1 & ~b0;
+  h.s8b = (row3 & b3 & ~b2 & ~b1) | (al & ~b2 & (b1 ^ b0));
+  h.scf = al & ((~b2 & b1 & b0) | (b2 & ~(b1 & b0)));
+  return h;
+}
+struct u_tops {
+  u32 a, b, c, d; // a: the four highest bits of U; b: the highest bit of z1 | d1 << 1 | h1 << 2; c: of zz2 | h2 << 1, and hi2's six highest << 2; d: of h3
+  SJ_HD bool any() const { return (a | b | c | d) != 0u; }
+};
+struct u_masks {
+  u64 drop;       // bytes of \u escapes that leave nothing behind
+  u64 bad;        // an escape the reference rejects ends / is recognised here
+  u64 k2, k3, k4; // kept bytes on the 2nd / 3rd / 4th hex digit of an escape: their values come from u_escape_byte(position, 2 / 3 / 4)
+};
+// U = the escaped 'u' of the block; exch(stage, mine) hands `mine` (what leaves this block at the top) on and returns what left the block in front
+template <class EXCH> SJ_HD u_masks unicode_masks(u64 U, const hex_classes &h, EXCH &&exch) {
+  const u32 pa = exch(0u, u32(U >> 60));
+  const u64 A1 = (U << 1) | u64(pa >> 3), U2 = (U << 2) | u64(pa >> 2), U3 = (U << 3) | u64(pa >> 1), U4 = (U << 4) | u64(pa);
+  const u64 z1 = A1 & h.zero, d1 = A1 & h.d, h1 = A1 & h.hex; // the first digit: '0', 'd', any
+  const u32 pb = exch(1u, u32(z1 >> 63) | (u32(d1 >> 63) << 1) | (u32(h1 >> 63) << 2));
+  const u64 z1s = (z1 << 1) | u64(pb & 1u), d1s = (d1 << 1) | u64((pb >> 1) & 1u), h1s = (h1 << 1) | u64((pb >> 2) & 1u);
+  const u64 zz2 = z1s & h.zero; // "00": below 0x100
+  const u64 zo2 = z1s & h.oct;  // "0[0-7]": below 0x800, at most two bytes
+  const u64 hi2 = d1s & h.s8b;  // a high surrogate
+  const u64 lo2 = d1s & h.scf;  // a low one
+  const u64 h2 = h1s & h.hex;
+  const u32 pc = exch(2u, u32(zz2 >> 63) | (u32(h2 >> 63) << 1) | (u32(hi2 >> 58) << 2));
+  const u64 one3 = ((zz2 << 1) | u64(pc & 1u)) & h.oct; // "00[0-7]": below 0x80, one byte
+  const u64 h3 = ((h2 << 1) | u64((pc >> 1) & 1u)) & h.hex;
+  const u64 hi3 = (hi2 << 1) | u64((pc >> 7) & 1u);
+  const u64 hi8 = (hi2 << 6) | u64((pc >> 2) & 63u); // where the low escape behind a high one has its second digit
+  const u32 pd = exch(3u, u32(h3 >> 63));
+  const u64 h4 = ((h3 << 1) | u64(pd & 1u)) & h.hex;
+  u_masks m;
+  m.drop = U | A1 | zo2 | hi2 | one3 | hi3;
+  m.bad = (U4 & ~h4) | (lo2 & ~hi8) | (hi8 & ~lo2);
+  m.k2 = U2 & ~(zo2 | hi2);
+  m.k3 = U3 & ~(one3 | hi3);
+  m.k4 = U4;
+  return m;
+}
+// the byte kept at document position q, the k-th hex digit (2 ... 4) of an escape the reference accepts (codepoint_to_utf8 of the code point
+// -- of the surrogate pair's for the high escape's last digit and the low escape's last three); reads src at q - 10 ... q only
+template <class SRC> SJ_HD u32 u_escape_byte(const SRC &src, u32 q, u32 k) {
+  const u32 p = q - k; // the 'u'
+  const u32 d1 = hex_digit_value(src.byte(p + 1)), d2 = hex_digit_value(src.byte(p + 2));
+  const bool surrogate = d1 == 0xDu && (d2 & 8u) != 0u, low = surrogate && (d2 & 4u) != 0u;
+  if (k == 2u) {
+    if (!low) { return 0xE0u | d1; }
+    // second byte of the pair: bits 12 ... 17 of 0x10000 + (h << 10 | l) = bits 2 ... 7 of h + 0x40; the high escape's digits sit at p - 5 ... p - 2
+    const u32 x = (((hex_digit_value(src.byte(p - 4)) & 3u) << 8) | (hex_digit_value(src.byte(p - 3)) << 4) | hex_digit_value(src.byte(p - 2))) + 0x40u;
+    return 0x80u | ((x >> 2) & 63u);
   }
-  if (cp <= 0x7Fu) { e.len = 1; e.packed = cp; }
-  else if (cp <= 0x7FFu) { e.len = 2; e.packed = ((cp >> 6) + 192u) | (((cp & 63u) + 128u) << 8); }
-  else if (cp <= 0xFFFFu) { e.len = 3; e.packed = ((cp >> 12) + 224u) | ((((cp >> 6) & 63u) + 128u) << 8) | (((cp & 63u) + 128u) << 16); }
-  else if (cp <= 0x10FFFFu) {
-    e.len = 4;
-    e.packed = ((cp >> 18) + 240u) | ((((cp >> 12) & 63u) + 128u) << 8) | ((((cp >> 6) & 63u) + 128u) << 16) | (((cp & 63u) + 128u) << 24);
-  } else {
-    e.bad = true; // not hex
+  const u32 d3 = hex_digit_value(src.byte(p + 3));
+  if (k == 3u) {
+    if (low) { return 0x80u | ((hex_digit_value(src.byte(p - 2)) & 3u) << 4) | ((d2 & 3u) << 2) | (d3 >> 2); } // third byte of the pair
+    if (d1 == 0u && d2 < 8u) { return 0xC0u | (d2 << 2) | (d3 >> 2); }
+    return 0x80u | (((d2 << 2) | (d3 >> 2)) & 63u);
   }
-  return e;
+  const u32 d4 = hex_digit_value(src.byte(p + 4));
+  if (surrogate && !low) { return 0xF0u | (((((d2 & 3u) << 8) | (d3 << 4) | d4) + 0x40u) >> 8); } // first byte of the pair
+  if (d1 == 0u && d2 == 0u && d3 < 8u) { return (d3 << 4) | d4; }
+  return 0x80u | ((d3 & 3u) << 4) | d4;
 }
 
 // ---- byte classes the escapes need, from the bit planes of a block ------------------------------------------------------------------
@@ -112,23 +157,15 @@ SJ_HD escape_classes classify_escapes(const planes &P) {
   return c;
 }
 
-// bits lo ... hi of a block (block-relative positions, any sign; clipped to 0 ... 63)
-SJ_HD u64 bits_between(int lo, int hi) {
-  if (lo < 0) { lo = 0; }
-  if (hi > 63) { hi = 63; }
-  if (lo > hi) { return 0; }
-  const u64 upto_hi = hi == 63 ? ~u64(0) : ((u64(1) << (hi + 1)) - 1);
-  return upto_hi & ~((u64(1) << lo) - 1);
-}
-
 // ---- one block --------------------------------------------------------------------------------------------------------------------------
 // What a block contributes, apart from its quotes: `keep` = the bytes that stand for ONE output byte each if they lie inside a
-// string (plain text, the character behind a backslash, the first len bytes of a \u escape); everything else inside a string
+// string (plain text, the character behind a backslash, the last hex digits of a \u escape); everything else inside a string
 // (the backslashes, the rest of a \u escape) is dropped.  Quotes are in neither.
 struct string_block {
   u64 keep;
   u64 bad;   // escapes the reference rejects (to be taken seriously inside strings only)
   u64 remap; // kept bytes whose value changes: escaped b f n r t
+  u64 bad_u; // \u escapes it rejects (unicode_masks: to be taken seriously wherever they are)
 };
 // escapes other than \u: from masks alone.  escaped = stage 1's escaped mask, quote = the real quotes.
 SJ_HD string_block simple_escapes(u64 backslash, u64 escaped, u64 quote, const escape_classes &c) {
@@ -136,45 +173,16 @@ SJ_HD string_block simple_escapes(u64 backslash, u64 escaped, u64 quote, const e
   b.keep = ~(andn(backslash, escaped) | quote); // not an escaping backslash, not a real quote
   b.bad = escaped & ~(c.u | c.same | c.remap);
   b.remap = escaped & c.remap;
+  b.bad_u = 0;
   return b;
 }
 // no backslash in sight: everything but the quotes
-SJ_HD string_block no_escapes(u64 quote) { return string_block{~quote, 0, 0}; }
+SJ_HD string_block no_escapes(u64 quote) { return string_block{~quote, 0, 0, 0}; }
 
-// \u escapes: the ones whose 'u' lies in this block (U) and the ones up to 10 bytes in front of it whose bytes may reach into it
-// (u_prev: bit k = byte block_pos - 10 + k is an escaped 'u').  The reference consumes a valid low-surrogate escape together with
-// the high one in front of it (stringparsing.h:64-81), so the candidates are walked front to back and a consumed one is skipped.
-// sink.escape(rel, len, packed): the escape whose 'u' sits at block position rel (-10 ... 63) stands for len bytes (packed, first one low),
-// which are the kept bytes at positions rel ... rel + len - 1.
-template <class SRC, class SINK>
-SJ_HD void unicode_escapes(const SRC &src, u32 block_pos, u64 U, u32 u_prev, bool allow_replacement, string_block &b, SINK &sink) {
-  int consumed_at = -100; // block-relative position of the 'u' of a low-surrogate escape that went with its high one
-  for (int pass = 0; pass < 2; pass++) {
-    u64 todo = pass == 0 ? u64(u_prev & 0x3FFu) : U;
-    const int origin = pass == 0 ? -10 : 0;
-    while (todo) {
-      const int k = __builtin_ctzll(todo);
-      todo &= todo - 1;
-      const int rel = origin + k;
-      if (rel == consumed_at) { continue; }
-      if (rel < 0 && block_pos < u32(-rel)) { continue; } // in front of the document (cannot happen: u_prev is zero there)
-      const u_escape e = decode_u_escape(src, block_pos + u32(rel), allow_replacement);
-      b.keep = (b.keep & ~bits_between(rel - 1, rel + int(e.span))) | bits_between(rel, rel + int(e.len) - 1);
-      if (e.bad && rel >= 0) { b.bad |= u64(1) << rel; }
-      if (e.len) { sink.escape(rel, e.len, e.packed); }
-      if (e.span == 10u) { consumed_at = rel + 6; }
-    }
-  }
-}
-struct no_patches {
-  SJ_HD void escape(int, u32, u32) {}
-};
-// the bytes of one escape that fall into the block, one call of f(position 0 ... 63, byte) each
-template <class F> SJ_HD void for_each_escape_byte(int rel, u32 len, u32 packed, F &&f) {
-  for (u32 j = 0; j < len; j++) {
-    const int p = rel + int(j);
-    if (p >= 0 && p < 64) { f(u32(p), (packed >> (8u * j)) & 0xFFu); }
-  }
+// the \u escapes of a block on top of the simple ones
+SJ_HD void apply_unicode(string_block &b, const u_masks &m) {
+  b.keep &= ~m.drop;
+  b.bad_u = m.bad;
 }
 
 // output bytes of a block given which of its bytes are inside strings (in_string: stage 1's mask, opening quote included,

@@ -23,57 +23,15 @@ namespace {
 
 constexpr u32 STRS_WAVES = 4; // waves (= segments) per workgroup
 
-// The document's bytes for the escape decoders.  A lane that holds a \\u escape reads up to 12 bytes behind it (and a block looks 10 bytes
-// back), one after the other, inside a divergent loop.  A chunk that holds \\u escapes is PARKED in LDS first (4 KiB per wave: in
-// k_strs_write the output window, which is still free at that point) and the decoders read it there (parked_doc below).  Measured: k_strs_count 138 -> 122 us per 256 MiB of the synthetic twitter-like text,
-// k_strs_write unchanged (376 us; byte loads through L1 and a 16-byte register window had given 405 and 372) -- the 240 us that escapes
-// cost that kernel (profiles/r03_strings_escape_cost.txt) are not load latency; kept because it takes 40 VGPRs out of the kernel.
-// Bytes at or beyond len read as 0x20 (a parked chunk holds them that way: load_block).
+// The document's bytes for u_escape_byte (sj_string_stream.h): the value of a kept byte of a \\u escape is a function of at most ten bytes in
+// front of it, which the workgroup has just loaded (L1 / L2).  Bytes at or beyond len read as 0x20, like load_block's.
+// (Rounds 2-3 walked every lane's escapes with a decoder inside a divergent loop and parked the chunk in LDS for it; round 4 has no walk:
+// which bytes stay is mask algebra -- unicode_masks --, and the values are computed one kept byte per lane.)
 struct plain_doc {
   const u8 *buf;
   u32 len;
   __device__ __forceinline__ u32 byte(u32 pos) const { return pos < len ? u32(buf[pos]) : 0x20u; }
 };
-// A parked chunk with PARK_MARGIN bytes of the document in front of it and behind it: everything a decoder of this chunk can ask for
-// (10 bytes back from a block, 12 bytes on from a 'u'), so that byte() is one LDS read without a "not parked: read the document" branch
-// behind it (parity-tested on the GPU; its effect on the time is not measured: the round's GPU budget ended with the test run).
-constexpr u32 PARK_MARGIN = 16, PARK_BYTES = CHUNK_BYTES + 2 * PARK_MARGIN;
-struct parked_doc {
-  const u8 *park; // LDS: the bytes [pos0 - PARK_MARGIN, pos0 + CHUNK_BYTES + PARK_MARGIN)
-  u32 pos0;
-  __device__ __forceinline__ u32 byte(u32 pos) const {
-    const u32 d = pos - pos0 + PARK_MARGIN;
-    return park[d < PARK_BYTES ? d : PARK_BYTES - 1u]; // (the clamp is never taken: see above)
-  }
-};
-// lane l parks its block; lane 0 the 16 bytes in front of the chunk, lane 63 the 16 bytes behind it (0x20 beyond the document, like load_block)
-__device__ __forceinline__ void park_chunk(u8 *park, const u32 (&w)[16], u32 lane, const u8 *__restrict__ buf, u32 len, u32 chunk_pos) {
-  uint4 *row = reinterpret_cast<uint4 *>(park + PARK_MARGIN + lane * BLOCK_BYTES);
-  row[0] = make_uint4(w[0], w[1], w[2], w[3]);
-  row[1] = make_uint4(w[4], w[5], w[6], w[7]);
-  row[2] = make_uint4(w[8], w[9], w[10], w[11]);
-  row[3] = make_uint4(w[12], w[13], w[14], w[15]);
-  if (lane == 0) {
-    uint4 v = make_uint4(0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u);
-    if (chunk_pos >= PARK_MARGIN) { v = *reinterpret_cast<const uint4 *>(buf + chunk_pos - PARK_MARGIN); } // chunks start on 4 KiB boundaries of an aligned buffer
-    *reinterpret_cast<uint4 *>(park) = v;
-  }
-  if (lane == 63) {
-    const u32 behind = chunk_pos + CHUNK_BYTES;
-    uint4 v;
-    if (u64(behind) + PARK_MARGIN <= len) {
-      v = *reinterpret_cast<const uint4 *>(buf + behind);
-    } else {
-      u32 x[4];
-      for (u32 k = 0; k < 4; k++) {
-        x[k] = 0;
-        for (u32 b = 0; b < 4; b++) { x[k] |= (behind + 4 * k + b < len ? u32(buf[behind + 4 * k + b]) : 0x20u) << (8u * b); }
-      }
-      v = make_uint4(x[0], x[1], x[2], x[3]);
-    }
-    *reinterpret_cast<uint4 *>(park + PARK_MARGIN + CHUNK_BYTES) = v;
-  }
-}
 
 // per segment, from its bytes alone (hypothesis 0 = the segment starts outside a string)
 struct strs_summary {
@@ -91,67 +49,55 @@ struct strs_base {
 };
 
 struct strs_carry {
-  u32 e; // first byte of the next chunk is escaped
-  u32 s; // inside a string (relative to the segment start in k_strs_count, absolute in k_strs_write)
-  u32 u; // the last 10 bytes: bit k = byte (next chunk) - 10 + k is an escaped 'u'
-};
-// what the first \\u escapes of a lane stand for, kept from the decode that sized them so that k_strs_write need not decode them again
-// when it knows where their bytes go (a lane with more of them decodes a second time)
-struct escape_notes {
-  static constexpr u32 ROOM = 2;
-  u32 count = 0;
-  int rel0 = 0, rel1 = 0;
-  u32 len0 = 0, len1 = 0, packed0 = 0, packed1 = 0; // (named, not indexed: an indexed array would be parked in LDS)
-  __device__ __forceinline__ void escape(int r, u32 len, u32 pk) {
-    const bool first = count == 0, second = count == 1; // selects of values: stores through a chosen address would put the notes on the stack
-    rel0 = first ? r : rel0; len0 = first ? len : len0; packed0 = first ? pk : packed0;
-    rel1 = second ? r : rel1; len1 = second ? len : len1; packed1 = second ? pk : packed1;
-    count++;
-  }
+  u32 e;    // first byte of the next chunk is escaped
+  u32 s;    // inside a string (relative to the segment start in k_strs_count, absolute in k_strs_write)
+  u_tops t; // what the \\u algebra of the chunk's last block hands to the next chunk's first (sj_string_stream.h)
 };
 struct strs_chunk {
   u64 quote, in_string; // real quotes; stage 1's in-string mask (opening quote included, closing excluded)
   string_block b;
-  u64 U;      // escaped 'u' of the lane's block
-  u32 u_prev; // ... of the 10 bytes in front of it
+  u64 k2, k3, k4; // kept bytes of \\u escapes (on their 2nd / 3rd / 4th hex digit): the values come from u_escape_byte
 };
 
-// escaped 'u' among the 10 bytes in front of a segment (bit k = byte start - 10 + k): byte q is one iff it is a 'u' behind a
-// backslash run of odd length.  The 64 bytes of look-back are all a segment ever reads of what lies in front of it (round 4: no
-// escape table, no walk); a run that fills them to the brim leaves the answer open -- *ambiguous is set and the stream DECLINES the
-// document (below).
-__device__ __forceinline__ u32 u_tail_before(u64 start, u32 lookback, bool *ambiguous) {
-  if (start == 0) { return 0; }
-  const u64 um = __ballot(lookback == u32('u')) & 0x3FFull; // lane i holds byte start - 1 - i
-  if (!um) { return 0; }
-  const u64 m = __ballot(lookback == 0x5Cu);
-  u32 r = 0;
-  for (u64 t = um; t; t &= t - 1) { // wave-uniform
-    const u32 j = ctz64(t), skip = j + 1u;
-    const u64 inv = ~(m >> skip) & (~0ull >> skip); // bit i clear <=> byte start-1-skip-i is a backslash
-    if (!inv) { *ambiguous = true; continue; }
-    if (ctz64(inv) & 1u) { r |= 1u << (9u - j); }
-  }
-  return r;
-}
-// The carries of a segment from its look-back: exact, or -- 64 backslashes in front, or a 'u' of the last ten bytes behind a run that
-// reaches the look-back's end -- open.  Stage 1 carries such questions through its summaries (sj_xcarry.h); here an escaped byte
-// changes what the OUTPUT holds, not one bit of a mask, so the stream simply leaves documents that raise one to the per-string kernels
-// (sjgpu_strings.hip walk every string from its opening quote and never ask): same buffer, the slower road, for documents with a
-// backslash run of 54 bytes and more that ends within ten bytes of a 16 KiB boundary.
+__device__ __forceinline__ u64 brev64(u64 x) { return u64(__brevll((unsigned long long)x)); }
+// The carries of a segment from its look-back (lane i holds byte start - 1 - i): the escape bit like stage 1's spans (span_carry_assume), and
+// what the \\u algebra of the 64 bytes in front would hand over -- those bytes are run through the same unicode_masks as a block of their own,
+// whose own carry-in cannot reach its last ten positions.  Two things leave a question open: 64 backslashes in front (SPAN_B), and an escaped
+// 'u' among the last ten bytes whose backslash run reaches the look-back's first byte (its escaped mask then depends on what lies further
+// back).  Stage 1 carries such questions through its summaries (sj_xcarry.h); here an escaped byte changes what the OUTPUT holds, not one bit
+// of a mask, so the stream simply leaves documents that raise one to the per-string kernels (sjgpu_strings.hip walk every string from its
+// opening quote and never ask): same buffer, the slower road, for documents with a backslash run of 54 bytes and more that ends within ten
+// bytes of a 16 KiB boundary.
 __device__ __forceinline__ bool segment_carries(u64 start, u32 lane, u32 lookback, strs_carry &wc) {
   span_x sx;
   wc.e = span_carry_assume(start, lane, lookback, sx).e;
   bool ambiguous = sx.kind() == SPAN_B;
-  wc.u = u_tail_before(start, lookback, &ambiguous);
+  wc.t = u_tops{0u, 0u, 0u, 0u};
+  if (start == 0) { return ambiguous; }
+  const u64 cu = brev64(__ballot(lookback == u32('u'))); // bit i = byte start - 64 + i
+  if ((cu >> 54) == 0) { return ambiguous; }             // (wave-uniform) no 'u' that an escape reaching the boundary could begin with
+  const u64 bs = brev64(__ballot(lookback == 0x5Cu));
+  u64 unused;
+  const u64 U = escaped_mask(bs, 0, unused) & cu, U_other = escaped_mask(bs, 1, unused) & cu;
+  if ((U ^ U_other) >> 54) { ambiguous = true; }
+  hex_classes h;
+  h.hex = brev64(__ballot(byte_is_hex(lookback)));
+  h.zero = brev64(__ballot(lookback == u32('0')));
+  h.oct = brev64(__ballot(byte_is_octal(lookback)));
+  h.d = brev64(__ballot(byte_is_d(lookback)));
+  h.s8b = brev64(__ballot(byte_is_89ab(lookback)));
+  h.scf = brev64(__ballot(byte_is_cdef(lookback)));
+  u_tops out{0u, 0u, 0u, 0u};
+  (void)unicode_masks(U, h, [&](u32 stage, u32 mine) -> u32 {
+    if (stage == 0u) { out.a = mine; } else if (stage == 1u) { out.b = mine; } else if (stage == 2u) { out.c = mine; } else { out.d = mine; }
+    return 0u;
+  });
+  wc.t = out;
   return ambiguous;
 }
 
 // one chunk: stage 1's escape and quote algebra (scan_chunk, sjgpu_device.h), then what the strings need on top of it
-// park: PARK_BYTES of LDS of this wave (16-byte aligned), free during the call
-template <class SINK>
-__device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carry &wc, u32 lane, const u8 *__restrict__ buf, u32 len, u32 block_pos, bool allow, u8 *park,
-                                                   SINK &notes) {
+__device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carry &wc, u32 lane) {
   const planes P = transpose64(w);
   const classes c = classify(P);
   const u64 lt = lanemask_lt(lane);
@@ -175,40 +121,41 @@ __device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carr
   wc.s ^= u32(popc64(parm)) & 1u;
   out.in_string = prefix_xor(out.quote) ^ (0 - u64(s_in));
   out.b = no_escapes(out.quote);
-  out.U = 0;
-  out.u_prev = 0;
-  u32 u_out = 0;
-  if (any_backslash || wc.u) { // wave-uniform; a backslash in the last byte of a block escapes nothing INSIDE the block but is dropped
+  out.k2 = 0; out.k3 = 0; out.k4 = 0;
+  const bool pending = wc.t.any(); // wave-uniform: an escape that began in the chunk in front is not finished
+  if (any_backslash || pending) { // a backslash in the last byte of a block escapes nothing INSIDE the block but is dropped
     const escape_classes ec = classify_escapes(P);
     out.b = simple_escapes(c.backslash, escaped, out.quote, ec);
-    out.U = escaped & ec.u;
-    const u32 top = u32(out.U >> 54);
-    if (__ballot(out.U != 0) | u64(wc.u)) { // wave-uniform: a \u escape somewhere in the chunk or just in front of it
-      u32 prev = u32(__shfl_up(int(top), 1));
-      if (lane == 0) { prev = wc.u; }
-      out.u_prev = prev;
-      park_chunk(park, w, lane, buf, len, block_pos - lane * BLOCK_BYTES);
-      wave_lds_fence();
-      const parked_doc src{park, block_pos - lane * BLOCK_BYTES};
-      if (out.U | u64(prev)) { unicode_escapes(src, block_pos, out.U, prev, allow, out.b, notes); }
-      wave_lds_fence(); // the caller may reuse the parking space
+    const u64 U = escaped & ec.u;
+    u_tops next{0u, 0u, 0u, 0u};
+    if (__ballot(U != 0) | u64(pending)) { // wave-uniform: a \\u escape somewhere in the chunk or reaching into it
+      const u_tops in = wc.t;
+      const u_masks um = unicode_masks(U, classify_hex(P), [&](u32 stage, u32 mine) -> u32 {
+        u32 prev = u32(__shfl_up(int(mine), 1));
+        const u32 last = readlane(mine, 63);
+        if (stage == 0u) { next.a = last; if (lane == 0) { prev = in.a; } }
+        else if (stage == 1u) { next.b = last; if (lane == 0) { prev = in.b; } }
+        else if (stage == 2u) { next.c = last; if (lane == 0) { prev = in.c; } }
+        else { next.d = last; if (lane == 0) { prev = in.d; } }
+        return prev;
+      });
+      apply_unicode(out.b, um);
+      out.k2 = um.k2; out.k3 = um.k3; out.k4 = um.k4;
     }
-    u_out = readlane(top, 63);
+    wc.t = next;
   }
-  wc.u = u_out;
   return out;
 }
 
 // ---- pass 1: what every segment contributes, for both carry-ins ------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_count(const u8 *__restrict__ buf, u64 len, u32 nseg, u32 allow_replacement, strs_summary *__restrict__ summ) {
-  __shared__ __attribute__((aligned(16))) u8 sh_park[STRS_WAVES][PARK_BYTES];
+  (void)allow_replacement; // (a lone surrogate is flagged whatever the option says: the per-string road knows the replacement character)
   const u32 lane = threadIdx.x & 63u;
   const u32 seg = blockIdx.x * STRS_WAVES + (threadIdx.x >> 6);
   if (seg >= nseg) { return; }
-  u8 *const park = sh_park[threadIdx.x >> 6];
   const u64 seg_start = u64(seg) * SEG_BYTES;
   const u32 lookback = lookback_issue(buf, seg_start, lane);
-  strs_carry wc{0u, 0u, 0u};
+  strs_carry wc{0u, 0u, u_tops{0u, 0u, 0u, 0u}};
   bool ambiguous = false;
   u32 d0 = 0, dall = 0, o0 = 0, qall = 0;
   u64 bad0 = 0, bad1 = 0;
@@ -220,14 +167,13 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_count(const u8 *__rest
     if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
     else { load_block(buf, pos, len, w); }
     if (c == 0) { ambiguous = segment_carries(seg_start, lane, lookback, wc); }
-    no_patches none;
-    const strs_chunk m = string_chunk(w, wc, lane, buf, u32(len), u32(pos), allow_replacement != 0, park, none);
+    const strs_chunk m = string_chunk(w, wc, lane);
     d0 += u32(popc64(m.b.keep & m.in_string));
     dall += u32(popc64(m.b.keep));
     o0 += u32(popc64(m.quote & m.in_string));
     qall += u32(popc64(m.quote));
-    bad0 |= m.b.bad & m.in_string & ~m.quote;
-    bad1 |= m.b.bad & ~m.in_string & ~m.quote;
+    bad0 |= (m.b.bad & m.in_string & ~m.quote) | m.b.bad_u;
+    bad1 |= (m.b.bad & ~m.in_string & ~m.quote) | m.b.bad_u;
   }
   d0 = wave_sum(d0);
   dall = wave_sum(dall);
@@ -352,33 +298,32 @@ struct window_map {
     return lane_off + u32(popc64(one & below)) + 4u * u32(popc64(open & below));
   }
 };
-struct window_patches {
-  u8 *stage;
-  window_map map;
-  u64 kept; // data bytes of the lane
-  __device__ __forceinline__ void escape(int rel, u32 len, u32 packed) {
-    for_each_escape_byte(rel, len, packed, [&](u32 p, u32 v) {
-      if ((kept >> p) & 1u) { stage[map.at(p)] = u8(v); }
-    });
-  }
-};
+// The bytes whose value is not the document's -- escaped b f n r t, and the kept bytes of \\u escapes -- are PATCHED in the window after the
+// scatter, one byte per lane: the lanes that own such bytes list them (window offset, position in the chunk, which hex digit of its escape the
+// byte sits on), at most PATCH_PER_LANE each per round, and the wave works the list off 64 entries at a time.  Text without escapes lists
+// nothing; the synthetic twitter-like text ~20 entries per chunk (one round, one pass); a string of nothing but \\uXXXX 2 048 (four rounds).
+constexpr u32 PATCH_PER_LANE = 8, PATCH_LIST = 64 * PATCH_PER_LANE;
+enum : u32 { PATCH_REMAP = 3u }; // roles 0 ... 2: the byte sits on hex digit 2 ... 4 of a \\u escape
+__device__ __forceinline__ u32 patch_entry(u32 window_offset, u32 chunk_offset, u32 role) { return (window_offset << 14) | (chunk_offset << 2) | role; }
 
 __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__restrict__ buf, u64 len, u32 nseg, u32 allow_replacement,
                                                                const strs_base *__restrict__ base, const strs_ctrl *__restrict__ ctrl, u8 *__restrict__ out,
                                                                u32 *__restrict__ outq) {
   __shared__ __attribute__((aligned(16))) u8 sh_stage[STRS_WAVES][STRS_STAGE_BYTES];
+  __shared__ u32 sh_patch[STRS_WAVES][PATCH_LIST];
+  (void)allow_replacement;
   if (ctrl->go_stream == 0) { return; }
   const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const u32 seg = blockIdx.x * STRS_WAVES + wave;
   if (seg >= nseg) { return; }
   u8 *const stage = sh_stage[wave];
+  u32 *const plist = sh_patch[wave];
   u8 *const dump = stage + STRS_WINDOW + lane;
   const u64 seg_start = u64(seg) * SEG_BYTES;
-  const plain_doc src{buf, u32(len)}; // (the rare lane with more \\u escapes than it kept notes of decodes them a second time, from the document)
-  const bool allow = allow_replacement != 0;
+  const plain_doc src{buf, u32(len)};
   const u32 lookback = lookback_issue(buf, seg_start, lane);
   const strs_base sb = base[seg];
-  strs_carry wc{0u, sb.in_string, 0u};
+  strs_carry wc{0u, sb.in_string, u_tops{0u, 0u, 0u, 0u}};
   u32 out_base = sb.out, ordinal = sb.ordinal;
   for (u32 c = 0; c < SEG_CHUNKS; c++) {
     const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
@@ -390,8 +335,7 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__rest
     if (c == 0) {
       (void)segment_carries(seg_start, lane, lookback, wc); // (no segment of a document this kernel writes is ambiguous: k_strs_decide)
     }
-    escape_notes notes;
-    const strs_chunk m = string_chunk(w, wc, lane, buf, u32(len), u32(pos), allow, stage, notes); // (parks the chunk in the window, which is free until the scatter)
+    const strs_chunk m = string_chunk(w, wc, lane);
     const u64 kept = m.b.keep & m.in_string;       // data bytes
     const u64 open = m.quote & m.in_string;         // 4 bytes each: the length, written by k_strs_finalize
     const u64 one = kept | andn(m.quote, m.in_string); // one byte each: data, and the 0 a closing quote turns into
@@ -426,20 +370,28 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__rest
         }
       }
       wave_lds_fence();
-      // the few bytes whose value is not the input's: escaped b f n r t, and what \u escapes stand for
-      for (u64 t = m.b.remap & kept; t; t &= t - 1) { // (the scatter put the escaped letter itself there)
-        u8 *const at = stage + map.at(ctz64(t));
-        *at = u8(simple_escape_value(*at));
-      }
-      if (notes.count) { // (divergent: the lanes that hold \\u escapes)
-        window_patches sink{stage, map, kept};
-        if (notes.count <= escape_notes::ROOM) {
-          sink.escape(notes.rel0, notes.len0, notes.packed0);
-          if (notes.count == 2) { sink.escape(notes.rel1, notes.len1, notes.packed1); }
-        } else {
-          string_block ignored = m.b;
-          unicode_escapes(src, u32(pos), m.U, m.u_prev, allow, ignored, sink);
+      // the few bytes whose value is not the input's: escaped b f n r t, and what \\u escapes stand for -- listed by their owners, worked off one per lane
+      const u64 k2 = m.k2 & kept, k3 = m.k3 & kept, k4 = m.k4 & kept, rm = m.b.remap & kept;
+      u64 todo = k2 | k3 | k4 | rm;
+      while (__ballot(todo != 0)) { // wave-uniform
+        const u32 mine = min(u32(popc64(todo)), PATCH_PER_LANE);
+        const u32 pincl = wave_incl_scan(mine);
+        const u32 entries = readlane(pincl, 63);
+        u32 slot = pincl - mine;
+        for (u32 r = 0; r < mine; r++) {
+          const u32 i = ctz64(todo);
+          todo &= todo - 1;
+          const u32 role = ((k2 >> i) & 1u) ? 0u : (((k3 >> i) & 1u) ? 1u : (((k4 >> i) & 1u) ? 2u : u32(PATCH_REMAP)));
+          plist[slot++] = patch_entry(map.at(i), lane * BLOCK_BYTES + i, role);
         }
+        wave_lds_fence();
+        for (u32 e = lane; e < entries; e += 64) {
+          const u32 entry = plist[e];
+          const u32 role = entry & 3u, q = u32(cstart) + ((entry >> 2) & 0xFFFu);
+          u8 *const at = stage + (entry >> 14);
+          *at = u8(role == PATCH_REMAP ? simple_escape_value(*at) : u_escape_byte(src, q, role + 2u)); // (the scatter put the escaped letter itself there)
+        }
+        wave_lds_fence();
       }
       wave_lds_fence();
       // the window leaves as 16-byte stores (emit_bytes' write-out); the 4-byte holes of the lengths carry whatever the window held

@@ -82,6 +82,11 @@ static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x
 static inline int __ffs(int x) { return __builtin_ffs(x); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 static inline int __clz(int x) { return x ? __builtin_clz(unsigned(x)) : 32; }
+static inline unsigned long long __brevll(unsigned long long x) {
+  unsigned long long r = 0;
+  for (int i = 0; i < 64; i++) { r |= ((x >> i) & 1ull) << (63 - i); }
+  return r;
+}
 static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
 static inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
 static inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned sh) { return unsigned(((uint64_t(hi) << 32) | lo) >> (8u * (sh & 3u))); }

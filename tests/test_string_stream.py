@@ -25,9 +25,14 @@ def model(tmp_path_factory):
         blob = b"".join(struct.pack("<I", len(d)) + bytes(d) for d in docs)
         p = subprocess.run([exe, str(allow)], input=blob, capture_output=True)
         assert p.returncode == 0, p.stderr.decode(errors="replace")[:2000]
-        m = re.match(r"(\d+) documents, (\d+) byte for byte, (\d+) rejected, (\d+) with unlisted quotes", p.stdout.decode())
+        m = re.match(r"(\d+) documents, (\d+) byte for byte, (\d+) rejected, (\d+) with unlisted quotes, (\d+) declined", p.stdout.decode())
         assert m, p.stdout
-        return tuple(int(x) for x in m.groups())
+        total, exact, rejected, unlisted, declined = (int(x) for x in m.groups())
+        # declined: a \\u pattern the reference rejects somewhere in a document whose listed strings are all valid -- a lone surrogate under
+        # allow_replacement, or an escape outside every string; the kernels send such a document down the per-string road.  Counted with
+        # the rejected ones: what matters is that none of them is written by the stream.
+        run.declined = declined
+        return total, exact, rejected + declined, unlisted
     return run
 
 
@@ -59,9 +64,9 @@ def test_escapes_at_every_offset(model):
             bad.append(b'["ok","' + b'a' * pre + esc + b'tail",1]')
     total, exact, rejected, unlisted = model(bad)
     assert rejected == total
-    # with replacement characters the surrogate cases are valid strings
+    # with replacement characters the surrogate cases are valid strings: the stream declines them (the per-string road substitutes)
     total, exact, rejected, unlisted = model(bad, allow=1)
-    assert exact + rejected == total and exact > total // 2
+    assert exact + rejected == total and model.declined > total // 2
 
 
 def test_hand_written_bodies(model):

@@ -96,3 +96,34 @@ def test_hand_written_cases_numbers_and_depth_limits(emu):
         emu(docs, max_depth)
     deep = [b"[" * d + b"1" + b"]" * d for d in (63, 64, 65, 200, 1023)] + [b'{"a":[' * 100 + b"{}" + b"]}" * 100]  # both sort paths
     emu(deep)
+
+
+ESCAPES = [b'\\n', b'\\u0041', b'\\u00e9', b'\\u20ac', b'\\ud83d\\ude00', b'\\"', b'\\\\', b'\\t\\r\\b\\f', b'\\ud83d\\ude00\\ud83d\\ude00', b'\\u0041\\u0042\\u0043', b'\\\\u0041',
+           b'\\\\\\u0041', b'\\uD7FF\\uE000', b'\\u07ff\\u0800\\u007f\\u0080', b'\\uDBFF\\uDFFF\\uD800\\uDC00']
+
+
+def test_escapes_across_chunks_and_segments(emu):
+    """The string stream decides which bytes of a \\\\u escape stay by mask algebra with a hand-over from block to block, chunk to chunk (the
+    wave's carry) and segment to segment (from the look-back bytes): every escape at every offset around 4 KiB, 16 KiB and 32 KiB, dense runs
+    of escapes over several segments; rejected escapes at the same places must send the document down the per-string road."""
+    rng = np.random.default_rng(13)
+    docs = []
+    for boundary in (4096, 16384, 32768):
+        for delta in range(-14, 4):
+            for esc in ESCAPES:
+                docs.append(b'["' + b"a" * (boundary + delta - 2) + esc + b'tail","' + esc * 3 + b'"]')
+    for _ in range(6):
+        parts, size = [], 0
+        while size < 70000:
+            parts.append(ESCAPES[int(rng.integers(0, len(ESCAPES)))] if rng.integers(0, 12) else b"x" * int(rng.integers(1, 70)))
+            size += len(parts[-1])
+        docs.append(b'{"k":"' + b"".join(parts) + b'","n":[1,2,"' + b"".join(parts[:50]) + b'"]}')
+    out = emu(docs)
+    assert f"{len(docs)} documents, {len(docs)} valid" in out and f"stream {len(docs)}," in out, out
+    bad = []
+    for boundary in (4096, 16384):
+        for delta in range(-14, 4):
+            for esc in (b'\\q', b'\\ud800', b'\\udc00x', b'\\u12G4', b'\\ud83d\\u0041', b'\\ud800\\ud800\\udc00', b'\\udc00\\udc00', b'\\ud83dxude00', b'\\ud83d\\nde00'):
+                bad.append(b'["ok","' + b"a" * (boundary + delta - 7) + esc + b'tail",1]')
+    out = emu(bad)
+    assert f"code 5: {len(bad)}" in out and f"per-string {len(bad)})" in out, out
