@@ -1523,7 +1523,7 @@ int sjgpu_stage1_finish_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
 int sjgpu_depth_scan_device(sjgpu_ctx *ctx, const void *buf_dev, const void *idx_dev, uint32_t n, void *depth_dev, void *stream) {
   if (!ctx || !buf_dev || !idx_dev || !depth_dev) { return SJGPU_E_BADARG; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
-  int rc = ensure_tmp(ctx, 64 + 4 * (size_t(n) / 4096 + 8));
+  int rc = ensure_tmp(ctx, depth_scan_scratch_bytes(n));
   if (rc) { return rc; }
   launch_depth_scan(static_cast<const uint8_t *>(buf_dev), static_cast<const uint32_t *>(idx_dev), n, static_cast<int32_t *>(depth_dev), ctx->d_tmp,
                     pick(ctx, stream));

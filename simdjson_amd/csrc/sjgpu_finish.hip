@@ -161,50 +161,174 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bracket_delta(const u8 *__restr
   delta[i] = is_open(k) ? 1 : (is_close(k) ? -1 : 0);
 }
 
+// ---- the boundary search of the streaming modes -------------------------------------------------------------------------------------------
+// The reference walks the list BACKWARDS and stops at the first hit (find_next_document_index.h:39-98): O(last document).  Rounds 2-3 ran a map over
+// the whole list instead -- 65 M gathers and 254 000 workgroups to find what the last thousand entries of an NDJSON list settle (0.55 ms per GiB of
+// amazon NDJSON, bench.py leg next_f2_finish_device).  Now a bounded grid walks the list from its END in chunks of 1024 entries and a workgroup
+// leaves as soon as a boundary behind its chunk is known; the balance runs from that boundary on, over as many chunks as there are; the last
+// workgroup to arrive resolves.  One launch prepares the state (it replaced three memsets).  A list without any boundary (one large document) still
+// costs the whole map -- as it does the reference.
+constexpr u32 LB_PER = 4, LB_CHUNK = FIN_THREADS * LB_PER, LB_GRID_MAX = 1024, LB_HEAD = 32;
+__global__ void k_finish_init(finish_state *__restrict__ st, u32 n, u32 len) {
+  finish_state z{};
+  z.n_in = n; z.n_cur = n; z.n_report = n;
+  z.next_start = len;
+  *st = z; // verdict = FIN_SEARCH, all reductions at their identity
+}
 // Last "value directly following a value" among structurals [1, n): atomicMax of its list index + 1 (0 = none).
-// Workgroups walk the list from its END (blockIdx reversed) and a wave only posts a candidate that beats what is already there:
-// in NDJSON every line is such a boundary, and a million atomicMax on one word cost 11 ms of a 1 GiB stream's finish
-// (bench.py leg next_f2_finish_device, round 3) -- now the first workgroups to run settle it and the rest read one cached word.
+// Chunks first_chunk, first_chunk + 1, ... counted from the END of the list, at most chunk_limit of them: the search is two launches -- the last
+// LB_HEAD chunks by as many workgroups, then the rest, whose workgroups find the answer waiting and leave (all workgroups of ONE launch start before
+// the first has fetched a byte: a thousand of them posting candidates to one word cost 29 us where 3 are needed).
 __global__ __launch_bounds__(FIN_THREADS) void k_last_boundary(const u8 *__restrict__ buf, const u32 *__restrict__ idx, const u32 *__restrict__ n_ptr,
-                                                             finish_state *__restrict__ st) {
+                                                             finish_state *__restrict__ st, u32 first_chunk, u32 chunk_limit) {
   const u32 n = *n_ptr;
-  const u64 block = u64(gridDim.x - 1u - blockIdx.x);
-  const u64 i = block * FIN_THREADS + threadIdx.x;
-  bool b = false;
-  if (i >= 1 && i < n) {
-    const u32 cur = classify_byte(buf[idx[i]]), before = classify_byte(buf[idx[i - 1]]);
-    b = !is_sep(cur) && !is_close(cur) && !is_open(before) && !is_sep(before);
-  }
-  const u64 m = __ballot(b);
-  if (m && (threadIdx.x & 63u) == 0) {
-    const u32 cand = u32(block * FIN_THREADS + (threadIdx.x & ~63u) + 63u - clz64(m)) + 1u;
-    if (cand > __hip_atomic_load(&st->boundary_plus1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicMax(&st->boundary_plus1, cand); }
+  if (n < 2) { return; }
+  const u32 all_chunks = (n + LB_CHUNK - 1) / LB_CHUNK;
+  const u64 stop = u64(first_chunk) + chunk_limit;
+  const u32 nchunks = stop < all_chunks ? u32(stop) : all_chunks;
+  const bool aligned16 = (reinterpret_cast<uintptr_t>(idx) & 15u) == 0;
+  for (u64 c = u64(first_chunk) + blockIdx.x; c < nchunks; c += gridDim.x) {
+    const u64 lo = (u64(all_chunks) - 1u - c) * LB_CHUNK; // chunks are counted from the end, aligned to the list's start
+    // a boundary at or behind this chunk's end is known: nothing in this chunk -- or in the ones this workgroup would take next -- can beat it
+    if (u64(__hip_atomic_load(&st->boundary_plus1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > lo + LB_CHUNK) { return; }
+    const u64 i0 = lo + u64(threadIdx.x) * LB_PER;
+    u32 best = 0; // highest boundary of this thread, + 1
+    if (i0 < n) {
+      u32 pos[LB_PER], cls[LB_PER + 1];
+      if (i0 + LB_PER <= n && aligned16) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(idx + i0);
+        pos[0] = q.x; pos[1] = q.y; pos[2] = q.z; pos[3] = q.w;
+      } else {
+#pragma unroll
+        for (u32 j = 0; j < LB_PER; j++) { pos[j] = idx[i0 + j < n ? i0 + j : i0]; }
+      }
+      const u32 before = idx[i0 ? i0 - 1 : 0]; // the entry in front of the thread's first (entry 0 has none: never a boundary)
+      cls[0] = classify_byte(buf[before]);
+#pragma unroll
+      for (u32 j = 0; j < LB_PER; j++) { cls[j + 1] = classify_byte(buf[pos[j]]); }
+#pragma unroll
+      for (u32 j = 0; j < LB_PER; j++) {
+        const u64 i = i0 + j;
+        const u32 cur = cls[j + 1], prev = cls[j];
+        const bool b = i >= 1 && i < n && !is_sep(cur) && !is_close(cur) && !is_open(prev) && !is_sep(prev);
+        best = b ? u32(i) + 1u : best;
+      }
+    }
+    const u32 cand = wave_max(best);
+    if (cand && (threadIdx.x & 63u) == 0 && cand > __hip_atomic_load(&st->boundary_plus1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      atomicMax(&st->boundary_plus1, cand);
+    }
   }
 }
-// Bracket balance of the structurals from the last boundary (or 0) to n, braces and square brackets separately.
+// complete_prefix(v, n) of stage1_finish.cpp from the two reductions
+__device__ __forceinline__ void resolve_prefix(finish_state *__restrict__ st, u32 n) {
+  if (st->verdict != FIN_SEARCH) { return; } // the filter has already decided (k_after_filter / k_count_below)
+  const int ob = __hip_atomic_load(&st->obj_balance, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int ab = __hip_atomic_load(&st->arr_balance, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool balanced = ob == 0 && ab == 0;
+  st->keep = (n == 0) ? 0u : (balanced ? n : (st->boundary_plus1 ? st->boundary_plus1 - 1 : 0u));
+}
+// Bracket balance of the structurals from the last boundary (or 0) to n, braces and square brackets separately; the workgroup that arrives
+// last resolves (st->arrivals counts them).
 __global__ __launch_bounds__(FIN_THREADS) void k_tail_balance(const u8 *__restrict__ buf, const u32 *__restrict__ idx, const u32 *__restrict__ n_ptr,
                                                             finish_state *__restrict__ st) {
   const u32 n = *n_ptr;
   const u32 from = st->boundary_plus1 ? st->boundary_plus1 - 1 : 0;
-  const u64 i = u64(from) + u64(blockIdx.x) * FIN_THREADS + threadIdx.x;
+  // the workgroups that have entries to count (the first always "has"): the others leave without a word -- arrivals at ONE counter are served
+  // one after the other, a thousand of them took 20 us
+  const u32 span_groups = n > from ? (n - from + FIN_THREADS - 1) / FIN_THREADS : 0u;
+  const u32 active = span_groups == 0 ? 1u : (span_groups < gridDim.x ? span_groups : gridDim.x);
+  if (blockIdx.x >= active) { return; }
   int o = 0, a = 0;
-  if (i < n) {
+  for (u64 i = u64(from) + u64(blockIdx.x) * FIN_THREADS + threadIdx.x; i < n; i += u64(active) * FIN_THREADS) {
     const u32 k = classify_byte(buf[idx[i]]);
-    o = (k == C_OBJ_OPEN) - (k == C_OBJ_CLOSE);
-    a = (k == C_ARR_OPEN) - (k == C_ARR_CLOSE);
+    o += (k == C_OBJ_OPEN) - (k == C_OBJ_CLOSE);
+    a += (k == C_ARR_OPEN) - (k == C_ARR_CLOSE);
   }
   const int so = int(wave_sum(u32(o))), sa = int(wave_sum(u32(a)));
   if ((threadIdx.x & 63u) == 0) {
     if (so) { atomicAdd(&st->obj_balance, so); }
     if (sa) { atomicAdd(&st->arr_balance, sa); }
   }
+  __syncthreads(); // every wave's contribution has been issued
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&st->arrivals, 1u) == active - 1u) {
+      __threadfence();
+      resolve_prefix(st, n);
+    }
+  }
 }
-// complete_prefix(v, n) of stage1_finish.cpp from the two reductions above
-__global__ void k_resolve_prefix(finish_state *__restrict__ st, const u32 *__restrict__ n_ptr) {
-  if (st->verdict != FIN_SEARCH) { return; } // the filter has already decided (k_after_filter / k_count_below)
-  const u32 n = *n_ptr;
-  const bool balanced = st->obj_balance == 0 && st->arr_balance == 0;
-  st->keep = (n == 0) ? 0u : (balanced ? n : (st->boundary_plus1 ? st->boundary_plus1 - 1 : 0u));
+
+// ---- nesting depth: a map that leaves 2 bits per entry, a scan of tile totals, a pass that writes ---------------------------------------------
+// Rounds 2-3: k_bracket_delta wrote an int per entry and the generic scan read and wrote that array twice more (0.49 ms per 65 M entries of
+// amazon NDJSON).  What the shapes cost was measured in isolation (scripts/micro/gather_lab.hip, profiles/r04_gather_lab.txt, 64 M entries over
+// 1 GiB): the bare map -- list word, token byte, something out -- takes 264-279 us (5.8 TB/s: the whole document comes in, line by line, to yield
+// one byte per 16); a single pass with decoupled look-back pays 17 ns per TILE for its ticket and its walk whatever the tile does (290 us for
+// 16 384 tiles of 4096: 0.42-0.58 ms measured, no gain; tiles of 16 384 need 214 VGPRs and ran at 0.74 ms); four consecutive entries per thread
+// (16-byte list loads) make a wave's gather reach over 4 KiB with two lanes per line and come back to every line four times: +95 us.  So: the map
+// keeps its one entry per lane and row, leaves the deltas as 2-bit codes (one dword per thread and tile: 0.25 B per entry instead of 4) and the
+// tile totals; one workgroup scans the totals; the writing pass turns codes into depths with ballots.
+constexpr u32 DP_ROWS = 16, DP_TILE = DP_ROWS * FIN_THREADS;
+static_assert(DP_TILE == FIN_BLOCK, "k_scan_partials' callers count tiles of FIN_BLOCK entries");
+// codes[tile * 256 + thread]: bits 2 r = the entry of row r (tile * 4096 + r * 256 + thread): 1 opens, 2 closes; partial[tile] = opens - closes
+__global__ __launch_bounds__(FIN_THREADS) void k_depth_codes(const u8 *__restrict__ buf, const u32 *__restrict__ idx, u32 n, u32 *__restrict__ codes,
+                                                           int *__restrict__ partial) {
+  __shared__ int sh[FIN_THREADS / 64];
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const u64 tile0 = u64(blockIdx.x) * DP_TILE;
+  u32 pos[DP_ROWS];
+#pragma unroll
+  for (u32 row = 0; row < DP_ROWS; row++) {
+    const u64 e = tile0 + u64(row) * FIN_THREADS + tid;
+    pos[row] = e < n ? idx[e] : 0xFFFFFFFFu;
+  }
+  u32 c = 0;
+  int sum = 0; // of this wave's entries (wave-uniform)
+#pragma unroll
+  for (u32 row = 0; row < DP_ROWS; row++) {
+    u32 code = 0;
+    if (pos[row] != 0xFFFFFFFFu) {
+      const u32 kk = classify_byte(buf[pos[row]]);
+      code = is_open(kk) ? 1u : (is_close(kk) ? 2u : 0u);
+    }
+    c |= code << (2u * row);
+    sum += int(popc64(__ballot(code == 1u))) - int(popc64(__ballot(code == 2u)));
+  }
+  codes[u64(blockIdx.x) * FIN_THREADS + tid] = c;
+  if (lane == 0) { sh[wave] = sum; }
+  __syncthreads();
+  if (tid == 0) { partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3]; }
+}
+// depth[e] for e in [0, n]: partial holds the exclusive prefixes of the tile totals now
+__global__ __launch_bounds__(FIN_THREADS) void k_depth_write(const u32 *__restrict__ codes, const int *__restrict__ partial, u32 n, int *__restrict__ depth) {
+  constexpr u32 WAVES = FIN_THREADS / 64;
+  static_assert(DP_ROWS * WAVES == 64, "the (row, wave) totals of a tile are scanned by one wave");
+  __shared__ int sh_w[DP_ROWS * WAVES];
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const u64 n1 = u64(n) + 1, tile0 = u64(blockIdx.x) * DP_TILE;
+  const u32 c = codes[u64(blockIdx.x) * FIN_THREADS + tid];
+  const int front = partial[blockIdx.x];
+  const u64 below = lanemask_lt(lane);
+  int mine[DP_ROWS]; // opens - closes among the lanes in front of this one, per row
+#pragma unroll
+  for (u32 row = 0; row < DP_ROWS; row++) {
+    const u32 code = (c >> (2u * row)) & 3u;
+    const u64 opens = __ballot(code == 1u), closes = __ballot(code == 2u);
+    mine[row] = int(popc64(opens & below)) - int(popc64(closes & below));
+    if (lane == 0) { sh_w[row * WAVES + wave] = int(popc64(opens)) - int(popc64(closes)); }
+  }
+  __syncthreads();
+  if (wave == 0) { // the 64 (row, wave) totals in row-major order = list order: exclusive prefixes inside the tile
+    const int x = sh_w[lane];
+    sh_w[lane] = int(wave_incl_scan(u32(x))) - x;
+  }
+  __syncthreads();
+#pragma unroll
+  for (u32 row = 0; row < DP_ROWS; row++) {
+    const u64 e = tile0 + u64(row) * FIN_THREADS + tid;
+    if (e < n1) { depth[e] = front + sh_w[row * WAVES + wave] + mine[row]; }
+  }
 }
 
 // ---- comma-delimited: keep flag per structural, last root comma ------------------------------------------------------------
@@ -365,11 +489,14 @@ size_t finish_workspace_bytes(uint32_t n) {
 
 // boundary search over the first st->n_cur entries of `list`
 static void enqueue_prefix_search(const uint8_t *buf, const uint32_t *list, uint32_t n_max, finish_state *st, hipStream_t s) {
-  const u32 nb = blocks_for(n_max, FIN_THREADS);
-  if (nb == 0) { return; }
-  hipLaunchKernelGGL(k_last_boundary, dim3(nb), dim3(FIN_THREADS), 0, s, buf, list, &st->n_cur, st);
-  hipLaunchKernelGGL(k_tail_balance, dim3(nb), dim3(FIN_THREADS), 0, s, buf, list, &st->n_cur, st);
-  hipLaunchKernelGGL(k_resolve_prefix, dim3(1), dim3(1), 0, s, st, &st->n_cur);
+  if (n_max == 0) { return; }
+  const u32 chunks = blocks_for(n_max, LB_CHUNK), grid = chunks < LB_GRID_MAX ? chunks : LB_GRID_MAX;
+  hipLaunchKernelGGL(k_last_boundary, dim3(chunks < LB_HEAD ? chunks : LB_HEAD), dim3(FIN_THREADS), 0, s, buf, list, &st->n_cur, st, 0u, LB_HEAD);
+  if (chunks > LB_HEAD) {
+    const u32 rest = chunks - LB_HEAD;
+    hipLaunchKernelGGL(k_last_boundary, dim3(rest < LB_GRID_MAX ? rest : LB_GRID_MAX), dim3(FIN_THREADS), 0, s, buf, list, &st->n_cur, st, LB_HEAD, 0xFFFFFFFFu);
+  }
+  hipLaunchKernelGGL(k_tail_balance, dim3(grid), dim3(FIN_THREADS), 0, s, buf, list, &st->n_cur, st);
 }
 
 void launch_finish(int mode, const uint8_t *buf, uint64_t len, uint32_t *idx, uint32_t n, void *workspace, hipStream_t s) {
@@ -381,9 +508,7 @@ void launch_finish(int mode, const uint8_t *buf, uint64_t len, uint32_t *idx, ui
   u32 *tmp = reinterpret_cast<u32 *>(w + 256 + nn * 8);
   u8 *flags = w + 256 + nn * 12;
   int *partial = reinterpret_cast<int *>(w + 256 + nn * 12 + ((nn + 255) & ~size_t(255)));
-  (void)hipMemsetAsync(st, 0, sizeof(finish_state), s); // verdict = FIN_SEARCH, all reductions at their identity
-  (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&st->n_in), int(n), 3, s); // n_in, n_cur, n_report
-  (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&st->next_start), int(u32(len)), 1, s);
+  hipLaunchKernelGGL(k_finish_init, dim3(1), dim3(1), 0, s, st, n, u32(len));
   const bool rs = mode == SJGPU_JSON_SEQUENCE_PARTIAL || mode == SJGPU_JSON_SEQUENCE_FINAL;
   const bool comma = mode == SJGPU_COMMA_DELIMITED_PARTIAL || mode == SJGPU_COMMA_DELIMITED_FINAL;
   const bool final_batch = mode == SJGPU_STREAMING_FINAL || mode == SJGPU_JSON_SEQUENCE_FINAL || mode == SJGPU_COMMA_DELIMITED_FINAL;
@@ -411,22 +536,24 @@ void launch_finish(int mode, const uint8_t *buf, uint64_t len, uint32_t *idx, ui
     hipLaunchKernelGGL(k_count_below, dim3(nb), dim3(FIN_THREADS), 0, s, tmp, st);
   }
   hipLaunchKernelGGL(k_copy_back, dim3(nb), dim3(FIN_THREADS), 0, s, tmp, &st->kept, idx);
-  // the boundary search of the modes that still need one runs on the compacted list; k_resolve_prefix's answer is only
+  // the boundary search of the modes that still need one runs on the compacted list; the resolution's answer is only
   // taken when the verdict says so (finish_state::verdict)
   enqueue_prefix_search(buf, idx, n, st, s);
 }
 
 // depth[i] = nesting depth in front of structural i, i in [0, n]  (depth[n] = depth behind the last one); scratch holds
-// blocks_for(n + 1) + 1 ints and one u32
+// depth_scan_scratch_bytes(n) bytes: the tile totals and one dword of codes per thread and tile
+size_t depth_scan_scratch_bytes(uint32_t n) {
+  const size_t tiles = blocks_for(u64(n) + 1, DP_TILE);
+  return 256 + ((tiles + 64) * 4 + 255) / 256 * 256 + tiles * FIN_THREADS * 4;
+}
 void launch_depth_scan(const uint8_t *buf, const uint32_t *idx, uint32_t n, int32_t *depth, void *scratch, hipStream_t s) {
-  u32 *n_ptr = static_cast<u32 *>(scratch);
-  int *partial = reinterpret_cast<int *>(n_ptr + 4);
-  const u32 n1 = n + 1;
-  (void)hipMemsetAsync(depth + n, 0, sizeof(int32_t), s); // the extra slot carries no delta
-  (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(n_ptr), int(n), 1, s);
-  (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(n_ptr + 1), int(n1), 1, s);
-  if (n) { hipLaunchKernelGGL(k_bracket_delta, dim3(blocks_for(n, FIN_THREADS)), dim3(FIN_THREADS), 0, s, buf, idx, n_ptr, depth); }
-  enqueue_scan(depth, n1, n_ptr + 1, partial, s);
+  const u32 tiles = blocks_for(u64(n) + 1, DP_TILE);
+  int *partial = reinterpret_cast<int *>(static_cast<u8 *>(scratch) + 256);
+  u32 *codes = reinterpret_cast<u32 *>(static_cast<u8 *>(scratch) + 256 + ((size_t(tiles) + 64) * 4 + 255) / 256 * 256);
+  hipLaunchKernelGGL(k_depth_codes, dim3(tiles), dim3(FIN_THREADS), 0, s, buf, idx, n, codes, partial);
+  hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partial, tiles);
+  hipLaunchKernelGGL(k_depth_write, dim3(tiles), dim3(FIN_THREADS), 0, s, codes, partial, n, depth);
 }
 
 } // namespace sjgpu

@@ -123,13 +123,15 @@ struct finish_state {            // device-resident, zero-initialised; read back
   uint32_t separators, last_sep_index_plus1, last_sep_pos_plus1; // root commas / record separators seen
   uint32_t boundary_plus1;        // list index + 1 of the last value that directly follows a value
   int32_t obj_balance, arr_balance;
-  uint32_t pad[3];
+  uint32_t arrivals;              // workgroups of k_tail_balance that have added their part (the last one resolves)
+  uint32_t pad[2];
 };
 size_t finish_workspace_bytes(uint32_t n);
 // modes 1..6 of sjgpu_stage1_mode on the n raw structurals idx[0..n) (n > 0) of buf[0..len): filters the list in place
 // (json_sequence / comma_delimited) and leaves the decision in the finish_state at the start of `workspace`
 void launch_finish(int mode, const uint8_t *buf, uint64_t len, uint32_t *idx, uint32_t n, void *workspace, hipStream_t stream);
-// depth[i] = nesting depth in front of structural i for i in [0, n], depth[n] = behind the last; scratch: 64 + 4 * (n / 4096 + 2) bytes
+// depth[i] = nesting depth in front of structural i for i in [0, n], depth[n] = behind the last; scratch: depth_scan_scratch_bytes(n)
+size_t depth_scan_scratch_bytes(uint32_t n);
 void launch_depth_scan(const uint8_t *buf, const uint32_t *idx, uint32_t n, int32_t *depth, void *scratch, hipStream_t stream);
 
 // ---- one workgroup per document (sjgpu_small.hip) ---------------------------------------------------------------------

@@ -46,6 +46,42 @@ int main(int argc, char **argv) {
       padded.resize(size_t(len) + 64, 0x20);
       const int e1 = sjo_stage1(padded.data(), len, SJO_REGULAR, len ? len : 1, idx, &n);
       if (e1 || n == 0) { continue; }
+      // ---- the list passes of sjgpu_finish.hip: the one-pass depth scan and the boundary search of the streaming modes, against a serial count --------
+      {
+        std::vector<uint8_t> scratch_store, depth_store;
+        uint8_t *scratch = static_cast<uint8_t *>(aligned(scratch_store, depth_scan_scratch_bytes(n), 0xA5));
+        int32_t *depth = static_cast<int32_t *>(aligned(depth_store, (size_t(n) + 1) * 4, 0x77));
+        launch_depth_scan(doc, idx, n, depth, scratch, nullptr);
+        int run = 0;
+        uint32_t boundary = 0; // the last list index whose token directly follows a value (0: none)
+        for (uint32_t i = 0; i <= n; i++) {
+          if (depth[i] != run) { fprintf(stderr, "MISMATCH: depth[%u] = %d, a serial count says %d (document %lu, %u structurals)\n", i, depth[i], run, docs, n); return 1; }
+          if (i < n) {
+            const uint8_t c = doc[idx[i]];
+            run += (c == '{' || c == '[') - (c == '}' || c == ']');
+            if (i >= 1) {
+              const uint8_t b = doc[idx[i - 1]];
+              if (c != ':' && c != ',' && c != '}' && c != ']' && b != '{' && b != '[' && b != ':' && b != ',') { boundary = i; }
+            }
+          }
+        }
+        int ob = 0, ab = 0;
+        for (uint32_t i = boundary; i < n; i++) {
+          const uint8_t c = doc[idx[i]];
+          ob += (c == '{') - (c == '}');
+          ab += (c == '[') - (c == ']');
+        }
+        const uint32_t keep = (ob == 0 && ab == 0) ? n : boundary; // complete_prefix of stage1_finish.cpp (find_next_document_index.h:39-98)
+        std::vector<uint8_t> fin_store;
+        uint8_t *fin = static_cast<uint8_t *>(aligned(fin_store, finish_workspace_bytes(n), 0xA5));
+        launch_finish(SJGPU_STREAMING_FINAL, doc, len, idx, n, fin, nullptr);
+        const finish_state fs = *reinterpret_cast<const finish_state *>(fin);
+        if (fs.keep != keep || fs.boundary_plus1 != (boundary ? boundary + 1 : 0)) {
+          fprintf(stderr, "MISMATCH: the boundary search keeps %u of %u structurals (boundary + 1 = %u), a serial walk %u (boundary %u) (document %lu)\n", fs.keep, n,
+                  fs.boundary_plus1, keep, boundary, docs);
+          return 1;
+        }
+      }
       std::vector<uint64_t> want(size_t(len) + 8);
       std::vector<uint8_t> want_s(5 * (size_t(len) / 3) + 128);
       uint64_t tw = 0, sb = 0;
