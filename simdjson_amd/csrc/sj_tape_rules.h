@@ -104,13 +104,18 @@ SJ_HD u32 value_list_of(const tok_packed &p) {
 }
 SJ_HD u64 list_entry(u32 tape_position, u32 token) { return (u64(tape_position) << 32) | token; }
 // what an element of the sort is, kept in the four bits of its 16-bit key the level (<= 4095) leaves free: the passes behind the sort
-// then never have to look the token's byte up again
-constexpr u32 KIND_SHIFT = 12, KIND_COMMA = 0, KIND_OPEN_OBJECT = 1, KIND_OPEN_ARRAY = 2, KIND_CLOSE_OBJECT = 3, KIND_CLOSE_ARRAY = 4;
-SJ_HD u32 sort_kind(u32 ch) {
-  return ch == '{' ? KIND_OPEN_OBJECT : (ch == '[' ? KIND_OPEN_ARRAY : (ch == '}' ? KIND_CLOSE_OBJECT : (ch == ']' ? KIND_CLOSE_ARRAY : KIND_COMMA)));
+// then never have to look the token's byte up again.  A comma also carries what it can say about its two followers before anybody knows its
+// container -- would an object be content with them, would an array (comma_fine_bits, below) -- so that k_tape_match, which learns the container's
+// kind, has nothing to fetch for it unless the document is broken there.  What travels WITH the key (the sort's 32-bit payload): a bracket's tape
+// position (the two bracket words are written from payloads alone), a comma's list index (for the error key of the rare broken follower).
+constexpr u32 KIND_SHIFT = 12, KIND_OPEN_OBJECT = 1, KIND_OPEN_ARRAY = 2, KIND_CLOSE_OBJECT = 3, KIND_CLOSE_ARRAY = 4, KIND_COMMA = 8; // commas: 8 ... 11
+constexpr u32 COMMA_FINE_IN_OBJECT = 1, COMMA_FINE_IN_ARRAY = 2;
+SJ_HD u32 sort_kind(u32 ch, u32 comma_bits) {
+  return ch == '{' ? KIND_OPEN_OBJECT : (ch == '[' ? KIND_OPEN_ARRAY : (ch == '}' ? KIND_CLOSE_OBJECT : (ch == ']' ? KIND_CLOSE_ARRAY : KIND_COMMA + comma_bits)));
 }
 SJ_HD bool kind_is_open(u32 kind) { return kind == KIND_OPEN_OBJECT || kind == KIND_OPEN_ARRAY; }
-SJ_HD u32 sort_key(u32 level, u32 ch) { return level | (sort_kind(ch) << KIND_SHIFT); }
+SJ_HD bool kind_is_comma(u32 kind) { return kind >= KIND_COMMA; }
+SJ_HD u32 sort_key(u32 level, u32 ch, u32 comma_bits) { return level | (sort_kind(ch, comma_bits) << KIND_SHIFT); }
 
 // ---- the same rule from tables ---------------------------------------------------------------------------------------------------------
 // token_rule spelled out is ~60 boolean operations on per-lane conditions, which the GPU compiler turns into as many scalar mask
@@ -169,6 +174,79 @@ SJ_HD u32 token_rule_tables(const rule_tables &T, bool first, u32 c, u32 prev, u
     return SJ_DEPTH_ERROR;
   }
   return 0;
+}
+
+// ---- the rule without a ctx array and without a depth array (round 4) ------------------------------------------------------------------------
+// Two of the rule's inputs used to be arrays of their own: ctx (the kind of the container a ',' sits in: one byte per token, cleared per call,
+// scattered by k_tape_match one byte per comma -- a sector of HBM traffic each -- and read back by k_tape_rules) and depth (4 B per token, written
+// by k_tok_apply for k_tape_rules to read).  Neither needs to exist:
+//   * a container kind matters to two tokens only: the one BEHIND a ',' and the one behind a '"' that stands behind a ','.  Both are the comma's
+//     followers, so the COMMA judges them (comma_followers_rule) when k_tape_match visits it with its container's kind in hand; every other token
+//     judges itself from the two bytes in front of it (token_rule_self).  A comma k_tape_match finds no container for judges nobody -- and needs
+//     not: it stands at depth <= 0 and is itself the smaller error (depth_rule), or beyond the nesting limit, where the bracket that went too deep is.
+//   * the depth decides two things -- "the root value has ended" (depth <= 0) and the nesting limit -- and both are said where the depth is
+//     computed (k_tok_apply: depth_rule).
+// The verdicts are keys; their minimum is the one token_rule / token_rule_tables give (tests/host/test_tape_rules.cpp: every combination; the
+// model of tests/host/test_tape_model.cpp and the kernels run THIS form).
+SJ_HD bool judged_by_comma(u32 prev, u32 prev2) { return prev == ',' || (prev == '"' && prev2 == ','); }
+// what the depth in front of token i says: 0, SJ_TAPE_ERROR (rank 0: the root value has ended) or SJ_DEPTH_ERROR (rank 1)
+SJ_HD u32 depth_rule(bool first, u32 c, u32 next, int depth, u32 max_depth, u32 *rank) {
+  *rank = 0;
+  if (!first && depth <= 0) { return SJ_TAPE_ERROR; }
+  if (is_open_char(c) && next != c + 2u && max_depth <= 0x7FFFFFFFu && depth >= int(max_depth) - 1) { // ('{' + 2 = '}', '[' + 2 = ']')
+    *rank = 1;
+    return SJ_DEPTH_ERROR;
+  }
+  return 0;
+}
+// what a token can say about itself (depth > 0 assumed unless first; the followers of a comma are not judged here): 0, SJ_TAPE_ERROR (rank 0)
+// or SJ_NUMBER_ERROR (rank 2: a ',' where '[' or ':' wants a value)
+SJ_HD u32 token_rule_self(const rule_tables &T, bool first, u32 c, u32 prev, u32 prev2, u32 *rank) {
+  *rank = 0;
+  if (!first && judged_by_comma(prev, prev2)) { return 0; }
+  const u32 pc = T.props[c & 0xFFu];
+  u32 st = T.state_behind[prev & 0xFFu];
+  st = st == ST_BEHIND_QUOTE ? ((prev2 == '{') ? u32(ST_BEHIND_KEY) : u32(ST_BEHIND_VALUE)) : st;
+  st = first ? u32(ST_ROOT) : st;
+  if ((pc & T.accepts[st]) == 0u) { return SJ_TAPE_ERROR; }
+  if (!first && c == ',' && (prev == '[' || prev == ':')) { *rank = 2; return SJ_NUMBER_ERROR; }
+  return 0;
+}
+// a ',' at list index j inside a container of kind ctx (CTX_OBJECT / CTX_ARRAY) judges the tokens behind it: c1 = token j + 1, c2 = token j + 2
+// (have1 / have2: they exist).  Up to three keys: k[0] token j + 1 is not what the container wants (TAPE_ERROR), k[1] it is a ',' in an array's value
+// position (NUMBER_ERROR), k[2] token j + 2 does not follow the string at j + 1 the way a key / a value is followed.  NO_ERROR_KEY where there is none.
+struct follower_keys { u64 k[3]; };
+SJ_HD follower_keys comma_followers_rule(u64 j, u32 ctx, u32 c1, bool have1, u32 c2, bool have2) {
+  follower_keys f{{NO_ERROR_KEY, NO_ERROR_KEY, NO_ERROR_KEY}};
+  if (!have1 || (ctx != CTX_OBJECT && ctx != CTX_ARRAY)) { return f; }
+  const bool object = ctx == CTX_OBJECT;
+  const bool ok1 = object ? c1 == '"' : starts_value(c1, false);       // object_continue wants a key, array_continue a value
+  if (!ok1) { f.k[0] = error_key(j + 1, 0, SJ_TAPE_ERROR); }
+  if (!object && c1 == ',') { f.k[1] = error_key(j + 1, 2, SJ_NUMBER_ERROR); } // comma_in_value_position
+  if (have2 && c1 == '"') {
+    const bool ok2 = object ? c2 == ':' : (c2 == ',' || is_close_char(c2)); // behind a key / behind a value
+    if (!ok2) { f.k[2] = error_key(j + 2, 0, SJ_TAPE_ERROR); }
+  }
+  return f;
+}
+
+// what the comma at list index j knows about its followers without its container: COMMA_FINE_IN_OBJECT / COMMA_FINE_IN_ARRAY = a container of that
+// kind would raise nothing (derived from comma_followers_rule itself: the two cannot drift apart)
+SJ_HD u32 comma_fine_bits(u64 j, u32 c1, bool have1, u32 c2, bool have2) {
+  const follower_keys o = comma_followers_rule(j, CTX_OBJECT, c1, have1, c2, have2), a = comma_followers_rule(j, CTX_ARRAY, c1, have1, c2, have2);
+  const bool fine_o = o.k[0] == NO_ERROR_KEY && o.k[1] == NO_ERROR_KEY && o.k[2] == NO_ERROR_KEY;
+  const bool fine_a = a.k[0] == NO_ERROR_KEY && a.k[1] == NO_ERROR_KEY && a.k[2] == NO_ERROR_KEY;
+  return (fine_o ? COMMA_FINE_IN_OBJECT : 0u) | (fine_a ? COMMA_FINE_IN_ARRAY : 0u);
+}
+// the list index of the token that writes the tape word at position p (a bracket: one word): tape positions do not decrease along the list and
+// tokens without a word (':' ',') share theirs with the token behind them, so it is the LAST index whose position is p.  tpos: n + 1 entries.
+template <class TPOS> SJ_HD u32 token_at_tape_position(const TPOS &tpos, u32 n, u32 p) {
+  u32 lo = 0, hi = n; // the first index in [0, n] whose position exceeds p (tpos[n] = the total > p)
+  while (lo < hi) {
+    const u32 mid = lo + (hi - lo) / 2;
+    if (u32(tpos[mid]) > p) { hi = mid; } else { lo = mid + 1; }
+  }
+  return lo ? lo - 1 : 0u;
 }
 
 // ---- the kinds of the open containers as a BIT STACK (round 4) --------------------------------------------------------------------------

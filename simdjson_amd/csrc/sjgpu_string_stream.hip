@@ -202,6 +202,18 @@ struct strs_ctrl {
   u32 bad;       // a rejected escape inside a string, or the document ends inside one
   u64 total;     // output bytes
 };
+__global__ void k_strs_init(strings_result_dev *__restrict__ res, strs_ctrl *__restrict__ ctrl, u32 n1) {
+  if (threadIdx.x == 0) {
+    strings_result_dev r{};
+    r.first_bad = 0xFFFFFFFFu; // NO_STRING
+    *res = r;
+    strs_ctrl c{};
+    c.n1_scan = n1;
+    *ctrl = c;
+    u32 *tail = reinterpret_cast<u32 *>(ctrl) + sizeof(strs_ctrl) / 4; // the control block has 64 bytes
+    for (u32 k = 0; k < (64 - sizeof(strs_ctrl)) / 4; k++) { tail[k] = 0u; }
+  }
+}
 constexpr u32 RES_THREADS = 1024, RES_WAVES = RES_THREADS / 64;
 // exclusive prefix over the workgroup of one value per thread (wave scans + one pass over the 16 wave totals); total = the sum
 __device__ __forceinline__ u32 block_excl_scan1024(u32 v, u32 *sh /*[RES_WAVES]*/, u32 &total) {
@@ -431,7 +443,7 @@ __global__ __launch_bounds__(TOK_THREADS) void k_strs_finalize(const int *__rest
 
 } // namespace
 
-// scratch of the stream (carved by sjgpu_strings.hip): see strings_scratch in sjgpu_internal.h
+// scratch of the stream (carved by sjgpu_strings.hip): see strings_scratch in sjgpu_internal.h; clears `res` (first_bad = none) and the control block
 void enqueue_string_stream(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
                            uint32_t *offsets, strings_result_dev *res, const strings_scratch &w, hipStream_t s, const int *listed) {
   strs_ctrl *ctrl = static_cast<strs_ctrl *>(w.ctrl);
@@ -439,8 +451,8 @@ void enqueue_string_stream(const uint8_t *buf, uint64_t len, const uint32_t *idx
   static_assert(sizeof(strs_summary) == STRS_SUMMARY_BYTES && sizeof(strs_base) == STRS_BASE_BYTES, "strings_scratch_bytes counts on these");
   const u32 nseg = num_segments(len), n1 = n + 1;
   const u32 a = allow_replacement ? 1u : 0u;
-  (void)hipMemsetAsync(ctrl, 0, 64, s);
-  (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&ctrl->n1_scan), int(n1), 1, s);
+  // the result and the control block in one small launch (rounds 3-4a: four memsets, i.e. four launches of the runtime's fill kernel)
+  hipLaunchKernelGGL(k_strs_init, dim3(1), dim3(64), 0, s, res, ctrl, n1);
   strs_summary *summ = static_cast<strs_summary *>(w.seg_summary);
   strs_base *base = static_cast<strs_base *>(w.seg_base);
   if (nseg) {

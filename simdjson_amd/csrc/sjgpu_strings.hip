@@ -502,8 +502,6 @@ strings_handoff launch_parse_strings(const uint8_t *buf, uint64_t len, const uin
                                      uint32_t *offsets, strings_result_dev *res, void *scratch, hipStream_t s, const int *listed) {
   const strings_scratch w = carve_strings_scratch(scratch, n, len);
   const u32 n1 = n + 1;
-  (void)hipMemsetAsync(res, 0, sizeof(strings_result_dev), s);
-  (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&res->first_bad), int(NO_STRING), 1, s);
   enqueue_string_stream(buf, len, idx, n, allow_replacement, out, out_cap, offsets, res, w, s, listed);
   const u32 *ctrl = static_cast<const u32 *>(w.ctrl); // strs_ctrl: [1] = entries of this path's scan, [3] = it runs
   const char *sw = std::getenv("SJGPU_STRING_STREAM"); // A/B switch, read per call (the tests flip it)

@@ -15,14 +15,16 @@
 // Passes (all asynchronous on the caller's stream; one 32-byte result is read back by the caller):
 //   k_tok_classify / k_tok_scan_sums   the byte of every token, the block totals of the six per-token counters
 //   (the string buffer: sjgpu_strings.hip / sjgpu_string_stream.hip, which take the number of string tokens from here)
-//   k_tok_apply       tape position and nesting depth of every token in one sweep over the token bytes; the tape words of the strings (the
+//   k_tok_apply       tape position and nesting depth of every token in one sweep over the token bytes (the depth stays in registers: what it
+//                     decides -- the root value has ended, the nesting limit -- is said here); the tape words of the strings (the
 //                     k-th string token's record is the k-th of the buffer) and of the atoms; (level, kind, token) of every bracket and
 //                     comma into the sort's input; numbers and atoms into lists
 //   radix passes      stable LSD radix sort on the level, 6 bits per pass: histogram, scan, scatter   1 wave / 2048 elements;
 //                     the second pass only runs for documents nested 64 deep and more
 //   (container ordinal per sorted element and sorted position of every open: written by the sort's last scatter from a second histogram)
-//   k_tape_match      commas learn their container's kind; closes write BOTH bracket words (count, partner index), kinds checked
-//   k_tape_rules      per token: the walk's rule and the nesting limit; root words
+//   k_tape_match      commas judge the two tokens behind them by their container's kind; closes write BOTH bracket words (count, partner
+//                     index), kinds checked
+//   k_tape_rules      per token: the part of the walk's rule a token can check from the two bytes in front of it; root words
 //   k_tape_atoms / k_tape_numbers    the spelling of true / false / null; the number words, one listed token per lane (lists by k_tok_apply)
 //   k_tape_slow_numbers  the handful of number tokens whose rounding needs exact big-integer arithmetic (sj_number.h)
 // Parity: tests/test_gpu_parity.py::test_tape_* against the live reference's dom::parser::parse (tape and string_buf word for word,
@@ -67,6 +69,18 @@ struct windowed_bytes {
 
 __device__ __forceinline__ void report_error(tape_result_dev *res, u64 key) { atomicMin(reinterpret_cast<unsigned long long *>(&res->error_key), (unsigned long long)key); }
 
+// the result and the control words: `words` dwords from res on are cleared, then the three that are not zero
+__global__ void k_tape_init(tape_result_dev *__restrict__ res, u32 *__restrict__ n_words, u32 words, u32 n1, u32 scan_len) {
+  u32 *w = reinterpret_cast<u32 *>(res);
+  for (u32 k = threadIdx.x; k < words; k += 64u) { w[k] = 0u; } // (launched with 64 threads)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    res->error_key = NO_ERROR_KEY;
+    n_words[0] = n1;
+    n_words[1] = scan_len;
+  }
+}
+
 // ---- the token front: every prefix sum the tape needs, in one sweep over the token bytes ----------------------------------------------
 // Per token (sj_tape_rules.h): tape words (0 / 1 / 2), "goes into the sort" (brackets and commas), "is a string", opening, closing.
 // Their exclusive prefix sums are the token's tape position, its slot in the sort's input, its ordinal among the strings and
@@ -90,31 +104,25 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_classify(const u8 *__restric
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u64 block0 = u64(blockIdx.x) * TS_BLOCK;
   if (blockIdx.x == 0 && tid == 0) { tokc[0] = 0; tokc[1] = 0; tokc[n + 2] = 0; tokc[n + 3] = 0; }
-  const bool aligned16 = (reinterpret_cast<uintptr_t>(idx) & 15u) == 0;
+  // One token per lane and row, sixteen rows of 256: the 64 lanes of a wave fetch the bytes of 64 CONSECUTIVE tokens with one instruction.  Rounds 3-4a
+  // gave a thread four consecutive tokens (one 16-byte list load): a wave's gather then reached over four times the span with a quarter of the lanes
+  // per cache line and came back to every line four times (scripts/micro/gather_lab.hip: +34 % on a sparse list).
+  constexpr u32 CL_ROWS = TS_BLOCK / TS_THREADS;
+  u32 pos[CL_ROWS];
+#pragma unroll
+  for (u32 row = 0; row < CL_ROWS; row++) {
+    const u64 i = block0 + u64(row) * TS_THREADS + tid;
+    pos[row] = i < n ? idx[i] : 0xFFFFFFFFu;
+  }
   u32 a = 0, b = 0, c = 0;
 #pragma unroll
-  for (u32 row = 0; row < TS_ROWS; row++) {
-    const u64 i0 = block0 + u64(row) * TS_ROW + 4u * tid;
-    if (i0 < n) {
-      u32 pos[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-      if (i0 + 3 < n && aligned16) { // (stage 1 writes 16-byte aligned lists; the C API only asks for 4 here)
-        const uint4 q = *reinterpret_cast<const uint4 *>(idx + i0);
-        pos[0] = q.x; pos[1] = q.y; pos[2] = q.z; pos[3] = q.w;
-      } else {
-        for (u32 j = 0; j < 4; j++) { if (i0 + j < n) { pos[j] = idx[i0 + j]; } }
-      }
-      u32 four = 0;
-#pragma unroll
-      for (u32 j = 0; j < 4; j++) {
-        if (i0 + j < n) {
-          const u32 ch = pos[j] < len ? u32(buf[pos[j]]) : 0x20u;
-          four |= ch << (8u * j);
-          const tok_packed p = tok_contribution(ch, i0 + j == 0);
-          a += p.a; b += p.b; c += p.c;
-        }
-      }
-      if (i0 + 3 < n) { *reinterpret_cast<u32_unaligned_t *>(tokc + 2 + i0) = four; }
-      else { for (u32 j = 0; j < 4; j++) { if (i0 + j < n) { tokc[2 + i0 + j] = u8(four >> (8u * j)); } } }
+  for (u32 row = 0; row < CL_ROWS; row++) {
+    const u64 i = block0 + u64(row) * TS_THREADS + tid;
+    if (i < n) {
+      const u32 ch = pos[row] < len ? u32(buf[pos[row]]) : 0x20u;
+      tokc[2 + i] = u8(ch);
+      const tok_packed p = tok_contribution(ch, i == 0);
+      a += p.a; b += p.b; c += p.c;
     }
   }
   a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); // a wave: at most 64 x 16 tokens x 2 words: the fields do not overflow
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(1024) void k_tok_scan_sums(int *__restrict__ sums, 
     __syncthreads();
   }
 }
-// tpos[i], depth[i] for i in [0, n] (entry n = the totals).  The tokens that write a value word are LISTED by kind, so that each kind is
+// tpos[i] for i in [0, n] (entry n = the total).  The tokens that write a value word are LISTED by kind, so that each kind is
 // finished by a dense kernel of its own instead of a branch of a per-token kernel: numbers (number_list, m_out[2] of them), strings
 // (value_list from the front: the k-th string token, m_out[4] of them = its ordinal in the string buffer) and the one-word rest -- atoms, and
 // bytes that are no token at all -- (value_list from the back: entry n - k, m_out[5] of them; their count in front of a token follows from the
@@ -172,11 +180,14 @@ __global__ __launch_bounds__(1024) void k_tok_scan_sums(int *__restrict__ sums, 
 // and commas go straight into the sort's input with
 // their level: the depth in front of an opening bracket, the depth behind a closing one, and that of the container a comma separates
 // the members of -- clamped to [0, kmax] (beyond the nesting limit an error is already certain); *m_out = how many went in
-__global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__ tokc, u32 n, u32 kmax, const int *__restrict__ sums, u32 nblocks, int *__restrict__ tpos,
-                                                         int *__restrict__ depth, u64 *__restrict__ value_list, unsigned short *__restrict__ key, u32 *__restrict__ tok,
+__global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__ tokc, u32 n, u32 kmax, u32 max_depth, const int *__restrict__ sums, u32 nblocks,
+                                                         int *__restrict__ tpos, u64 *__restrict__ value_list, unsigned short *__restrict__ key, u32 *__restrict__ tok,
                                                          int *__restrict__ m_out, int *__restrict__ max_level, u64 *__restrict__ number_list,
                                                          const u32 *__restrict__ str_offsets, strings_handoff strs, u8 *__restrict__ string_buf, u64 *__restrict__ tape,
-                                                         u64 tape_cap) {
+                                                         u64 tape_cap, tape_result_dev *__restrict__ res) {
+  // Round 4, second half: the nesting depth is not written anywhere.  What it decides -- "the root value has ended" and the nesting limit
+  // (depth_rule, sj_tape_rules.h) and "the list ends inside a container" -- is said HERE, where it sits in a register; the levels of the brackets and
+  // commas go into the sort's keys as before.  (k_tape_rules read 4 B per token for it, this kernel wrote them.)
   // Round 4: the string buffer exists when this kernel runs, and the tape words of the string tokens and of the atoms are written HERE,
   // where the token's tape position and its ordinal among the strings sit in registers -- on_start_string (tape_builder.h:415-419): the payload
   // of the word is where the record begins; when the stream compaction wrote the buffer the k-th string token's record begins at outq[k] and
@@ -197,7 +208,11 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
   for (u32 row = 0; row < TS_ROWS; row++) {
     const u64 i0 = block0 + u64(row) * TS_ROW + 4u * tid;
     u32 four = 0;
-    if (i0 < n) { four = four_tokens(tokc, i0); }
+    u32 behind2 = 0; // the two tokens behind this thread's four (depth_rule looks at the token behind an opening bracket, a comma at its two followers)
+    typedef unsigned short __attribute__((aligned(1))) u16_unaligned_t;
+    if (i0 < n) { four = four_tokens(tokc, i0); behind2 = *reinterpret_cast<const u16_unaligned_t *>(tokc + 2 + i0 + 4); } // (tokc has room for n + 9 bytes;
+    // what lies behind token n - 1 is only looked at where it is zeros)
+    const u32 six_lo = four, six_hi = behind2; // tokens i0 ... i0 + 5, byte by byte
     tok_packed p[4];
     u32 ta = 0, tb = 0, tc = 0;
 #pragma unroll
@@ -216,7 +231,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
     }
     __syncthreads();
     if (i0 <= n) {
-      int tp[4], dp[4];
+      int tp[4];
       // where the records of this thread's string tokens begin: its (at most four) strings have consecutive ordinals, so the five words are
       // requested HERE, all at once, not one by one inside the loop below (as dependent loads they made this kernel 120 us longer than the
       // separate pass over a list of string tokens had been: profiles/r04_tape_kernel_stats.txt)
@@ -237,7 +252,13 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
         const u64 i = i0 + j;
         const int d = depth0 + int(eb >> 16) - int(ec & 0xFFFFu);
         tp[j] = slots0 + int(ea & 0xFFFFu);
-        dp[j] = d;
+        {
+          const u32 ch = (four >> (8u * j)) & 0xFFu, next = j < 3 ? (six_lo >> (8u * (j + 1))) & 0xFFu : six_hi & 0xFFu;
+          u32 rank = 0;
+          const u32 g = i < n ? depth_rule(i == 0, ch, i + 1 < n ? next : 0u, d, max_depth, &rank) : 0u;
+          if (g) { report_error(res, error_key(i, rank, g)); }
+          if (i == n && d != 0) { report_error(res, error_key(n, 0, SJ_TAPE_ERROR)); } // the walk meets the sentinel inside a container
+        }
         const int strings_before = strs0 + int(eb & 0xFFFFu), numbers_before = numbers0 + int(ec >> 16);
         const int rest_before = rest0 + one_word_rest(int(ea & 0xFFFFu), int(eb & 0xFFFFu), int(ec >> 16), int(eb >> 16), int(ec & 0xFFFFu));
         const int slot = sel0 + int(ea >> 16);
@@ -265,17 +286,21 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
         if (i < n && (p[j].a >> 16)) {
           int k = (p[j].b >> 16) ? d : d - 1;
           k = k < 0 ? 0 : (k > int(kmax) ? int(kmax) : k);
-          key[slot] = (unsigned short)sort_key(u32(k), (four >> (8u * j)) & 0xFFu);
-          tok[slot] = u32(i);
+          // a bracket travels with its tape position, a comma with its list index and with what it knows about its two followers (sj_tape_rules.h)
+          const u32 ch = (four >> (8u * j)) & 0xFFu;
+          const bool comma = ch == ',';
+          const u32 c1 = j < 3 ? (six_lo >> (8u * (j + 1))) & 0xFFu : six_hi & 0xFFu, c2 = j < 2 ? (six_lo >> (8u * (j + 2))) & 0xFFu : (six_hi >> (8u * (j - 2))) & 0xFFu;
+          const u32 fine = comma ? comma_fine_bits(i, c1, i + 1 < n, c2, i + 2 < n) : 0u;
+          key[slot] = (unsigned short)sort_key(u32(k), ch, fine);
+          tok[slot] = comma ? u32(i) : u32(tp[j]);
           top = k > top ? k : top;
         }
         ea += p[j].a; eb += p[j].b; ec += p[j].c;
       }
       if (i0 + 3 <= n) {
         *reinterpret_cast<int4 *>(tpos + i0) = make_int4(tp[0], tp[1], tp[2], tp[3]);
-        *reinterpret_cast<int4 *>(depth + i0) = make_int4(dp[0], dp[1], dp[2], dp[3]);
       } else {
-        for (u32 j = 0; j < 4 && i0 + j <= n; j++) { tpos[i0 + j] = tp[j]; depth[i0 + j] = dp[j]; }
+        for (u32 j = 0; j < 4 && i0 + j <= n; j++) { tpos[i0 + j] = tp[j]; }
       }
     }
   }
@@ -375,14 +400,16 @@ struct sorted_pairs {
 // ---- containers -------------------------------------------------------------------------------------------------------------------------
 // (opens_before[j] = opening brackets in front of sorted element j and openpos[k] = sorted position of the k-th opening bracket come from the
 // sort's last scatter)
-// commas: ctx[token] = kind of their container.  Closing brackets: the two bracket words of the tape
+// commas: judge the two tokens behind them by their container's kind (rounds 3-4a: wrote that kind to a byte array for k_tape_rules to read --
+// a one-byte scatter per comma).  Closing brackets: the two bracket words of the tape
 // (end_container, tape_builder.h:396-407; an empty container is the same formula with count 0, :386-391).
 // Four consecutive sorted elements per thread, the loads of each step of the chain (element -> its container's open -> that open's key and
-// token -> tape positions) issued for all four before any is used: with one element per thread this kernel ran at the latency of its chain.
+// payload) issued for all four before any is used: with one element per thread this kernel ran at the latency of its chain.  Rounds 3-4a had two more
+// steps -- the tape positions of the close and of its open, gathered from the per-token array, and a byte scattered (then: two gathered) per comma.
 constexpr u32 TM_PER = 4;
 __global__ __launch_bounds__(TP_THREADS) void k_tape_match(sorted_pairs sorted, const int *__restrict__ m_ptr, const int *__restrict__ opens_before,
-                                                          const u32 *__restrict__ openpos, const int *__restrict__ tpos, u8 *__restrict__ ctx, u64 *__restrict__ tape,
-                                                          u64 tape_cap, tape_result_dev *__restrict__ res) {
+                                                          const u32 *__restrict__ openpos, const int *__restrict__ tpos, const u8 *__restrict__ tokc, u32 n,
+                                                          u64 *__restrict__ tape, u64 tape_cap, tape_result_dev *__restrict__ res) {
   const unsigned short *__restrict__ key = sorted.key();
   const u32 *__restrict__ tok = sorted.tok();
   const u64 j0 = (u64(blockIdx.x) * TP_THREADS + threadIdx.x) * TM_PER;
@@ -407,30 +434,31 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_match(sorted_pairs sorted, 
 #pragma unroll
   for (u32 e = 0; e < TM_PER; e++) {
     ko[e] = key[jo[e]];
-    io[e] = tok[jo[e]];
+    io[e] = tok[jo[e]]; // the opening bracket's tape position
     live[e] = live[e] && ((ko[e] ^ kj[e]) & ((1u << KIND_SHIFT) - 1)) == 0; // else: no container of this level in front, the token's own rule reports it
-  }
-  int open_pos[TM_PER], close_pos[TM_PER];
-#pragma unroll
-  for (u32 e = 0; e < TM_PER; e++) {
-    const bool closes = live[e] && (kj[e] >> KIND_SHIFT) != KIND_COMMA;
-    open_pos[e] = tpos[closes ? io[e] : 0u];
-    close_pos[e] = tpos[closes ? ti[e] : 0u];
   }
 #pragma unroll
   for (u32 e = 0; e < TM_PER; e++) {
     if (!live[e]) { continue; }
     const u32 kind = kj[e] >> KIND_SHIFT;
     const bool object = (ko[e] >> KIND_SHIFT) == KIND_OPEN_OBJECT;
-    const u32 i = ti[e];
-    if (kind == KIND_COMMA) {
-      ctx[i] = u8(object ? CTX_OBJECT : CTX_ARRAY);
+    if (kind_is_comma(kind)) {
+      // the comma judges its two followers: nobody else knows what its container wants there (sj_tape_rules.h).  It said what it could when it was sent
+      // into the sort -- fine in an object, fine in an array -- and has nothing to fetch unless the document is broken here
+      if ((kind - KIND_COMMA) & (object ? COMMA_FINE_IN_OBJECT : COMMA_FINE_IN_ARRAY)) { continue; }
+      const u32 i = ti[e];
+      typedef unsigned short __attribute__((aligned(1))) u16_unaligned_t;
+      const u32 behind = u32(*reinterpret_cast<const u16_unaligned_t *>(tokc + i + 3)); // (tokc[i + 2] = token i; two zero bytes end the array)
+      const follower_keys f = comma_followers_rule(i, object ? CTX_OBJECT : CTX_ARRAY, behind & 0xFFu, i + 1 < n, behind >> 8, i + 2 < n);
+      const u64 k01 = f.k[0] < f.k[1] ? f.k[0] : f.k[1], k = k01 < f.k[2] ? k01 : f.k[2];
+      if (k != NO_ERROR_KEY) { report_error(res, k); }
       continue;
     }
-    if ((kind == KIND_CLOSE_OBJECT) != object) { report_error(res, error_key(i, 0, SJ_TAPE_ERROR)); }
-    const u64 open_at = 1 + u64(u32(open_pos[e])), close_at = 1 + u64(u32(close_pos[e]));
+    const u32 open_tp = io[e], close_tp = ti[e]; // tape positions travel with the brackets: nothing to gather
+    if ((kind == KIND_CLOSE_OBJECT) != object) { report_error(res, error_key(token_at_tape_position(tpos, n, close_tp), 0, SJ_TAPE_ERROR)); }
+    const u64 open_at = 1 + u64(open_tp), close_at = 1 + u64(close_tp);
     const u64 between = (j0 + e) - jo[e]; // commas + 1
-    const u64 count = (i == io[e] + 1) ? 0 : (between > 0xFFFFFFull ? 0xFFFFFFull : between);
+    const u64 count = (close_tp == open_tp + 1) ? 0 : (between > 0xFFFFFFull ? 0xFFFFFFull : between);
     if (close_at < tape_cap) {
       tape[close_at] = tape_word(kind == KIND_CLOSE_OBJECT ? u32('}') : u32(']'), open_at);
       tape[open_at] = tape_word(object ? u32('{') : u32('['), (count << 32) | (close_at + 1));
@@ -448,15 +476,13 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_match(sorted_pairs sorted, 
 constexpr u32 TW_PER = 4;
 // byte k (0 ... 7) of the eight bytes {hi:lo}, k known at compile time
 __device__ __forceinline__ u32 byte_of(u32 lo, u32 hi, u32 k) { return ((k < 4u ? lo : hi) >> (8u * (k & 3u))) & 0xFFu; }
-__device__ __forceinline__ void check_token(const rule_tables &T, u32 i, u32 c, u32 prev, u32 prev2, u32 next, u32 ctx_prev, u32 ctx_prev2, int depth, u32 max_depth,
-                                            tape_result_dev *__restrict__ res) {
+__device__ __forceinline__ void check_token(const rule_tables &T, u32 i, u32 c, u32 prev, u32 prev2, tape_result_dev *__restrict__ res) {
   u32 rank = 0;
-  const u32 g = token_rule_tables(T, i == 0, c, prev, prev2, next, ctx_prev, ctx_prev2, depth, max_depth, &rank); // (sj_tape_rules.h: the rule from tables)
+  const u32 g = token_rule_self(T, i == 0, c, prev, prev2, &rank); // (sj_tape_rules.h: the token's own verdict; the depth's is k_tok_apply's, the commas' k_tape_match's)
   if (g) { report_error(res, error_key(i, rank, g)); }
-  if (c == ',' && comma_in_value_position(i, prev, ctx_prev)) { report_error(res, error_key(i, 2, SJ_NUMBER_ERROR)); }
 }
-__global__ __launch_bounds__(TP_THREADS) void k_tape_rules(u32 n, u32 max_depth, const u8 *__restrict__ tokc, const int *__restrict__ tpos, const int *__restrict__ depth,
-                                                          const u8 *__restrict__ ctx, u64 *__restrict__ tape, u64 tape_cap, tape_result_dev *__restrict__ res) {
+__global__ __launch_bounds__(TP_THREADS) void k_tape_rules(u32 n, const u8 *__restrict__ tokc, const int *__restrict__ tpos, u64 *__restrict__ tape, u64 tape_cap,
+                                                          tape_result_dev *__restrict__ res) {
   __shared__ unsigned short sh_props[256], sh_accepts[16];
   __shared__ u8 sh_state[256];
   static_assert(TP_THREADS == 256 && ST_COUNT <= 16, "one table entry per thread");
@@ -466,7 +492,7 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_rules(u32 n, u32 max_depth,
   const u64 first = (u64(blockIdx.x) * TP_THREADS + threadIdx.x) * TW_PER;
   if (first > n) { return; }
   const u32 i0 = u32(first);
-  if (n - i0 < TW_PER) { // the thread that holds "behind the last token": the root words and the checks that belong to no token
+  if (n - i0 < TW_PER) { // the thread that holds "behind the last token": the root words and the check that belongs to no token
     const u64 words = u64(u32(tpos[n])) + 2;
     res->tape_words = words;
     if (words <= tape_cap) {
@@ -477,26 +503,20 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_rules(u32 n, u32 max_depth,
     }
     const u32 c0 = tokc[2], last = tokc[n + 1];
     if ((c0 == '{' && last != '}') || (c0 == '[' && last != ']')) { report_error(res, error_key(0, 0, SJ_TAPE_ERROR)); } // json_iterator.h:138-143
-    if (depth[n] != 0) { report_error(res, error_key(n, 0, SJ_TAPE_ERROR)); } // the walk meets the sentinel inside a container
   }
-  if (i0 >= 2 && n - i0 >= TW_PER) { // the common case: four whole tokens, everything in wide loads
+  if (i0 >= 2 && n - i0 >= TW_PER) { // the common case: four whole tokens, one wide load
     typedef u64 __attribute__((aligned(1))) u64_unaligned_t;
     const u64 around8 = *reinterpret_cast<const u64_unaligned_t *>(tokc + i0);   // bytes of tokens i0 - 2 ... i0 + 5
-    const u64 kinds8 = *reinterpret_cast<const u64_unaligned_t *>(ctx + i0 - 2); // container kinds of tokens i0 - 2 ... i0 + 5 (zero where no comma)
-    const uint2 around = make_uint2(u32(around8), u32(around8 >> 32)), kinds = make_uint2(u32(kinds8), u32(kinds8 >> 32));
-    const int4 d = *reinterpret_cast<const int4 *>(depth + i0);
-    const int dd[4] = {d.x, d.y, d.z, d.w};
+    const uint2 around = make_uint2(u32(around8), u32(around8 >> 32));
 #pragma unroll
     for (u32 j = 0; j < TW_PER; j++) {
-      check_token(T, i0 + j, byte_of(around.x, around.y, j + 2), byte_of(around.x, around.y, j + 1), byte_of(around.x, around.y, j), byte_of(around.x, around.y, j + 3),
-                  byte_of(kinds.x, kinds.y, j + 1), byte_of(kinds.x, kinds.y, j), dd[j], max_depth, res);
+      check_token(T, i0 + j, byte_of(around.x, around.y, j + 2), byte_of(around.x, around.y, j + 1), byte_of(around.x, around.y, j), res);
     }
     return;
   }
   for (u32 i = i0; i - i0 < TW_PER && i < n; i++) { // the first and the last tokens of the list: one by one
     const u32 around = *reinterpret_cast<const u32_unaligned_t *>(tokc + i); // the bytes of tokens i - 2 ... i + 1 (two zero bytes lead the array)
-    check_token(T, i, (around >> 16) & 0xFFu, (around >> 8) & 0xFFu, around & 0xFFu, around >> 24, i >= 1 ? u32(ctx[i - 1]) : 0u, i >= 2 ? u32(ctx[i - 2]) : 0u, depth[i],
-                max_depth, res);
+    check_token(T, i, (around >> 16) & 0xFFu, (around >> 8) & 0xFFu, around & 0xFFu, res);
   }
 }
 
@@ -566,8 +586,8 @@ static inline u32 blocks_of(u64 n, u32 per) { return u32((n + per - 1) / per); }
 struct tape_workspace {
   tape_result_dev *res;
   u32 *n_words;       // [0] = n + 1 (scan lengths), [1] = n (upper bound of the sorted elements + 1 for the opens scan), [2] = hist length per pass
-  u8 *tokc, *ctx;
-  int *slots, *depth;        // tape position, nesting depth of every token (entry n: the totals)
+  u8 *tokc;
+  int *slots;                // tape position of every token (entry n: the total)
   u64 *value_list;           // (tape position << 32 | token): string tokens from the front, the other one-word tokens from the back
   int *m;                    // brackets and commas = elements of the sort
   int *sums;                 // k_tok_classify's block totals (6 rows)
@@ -593,9 +613,7 @@ static tape_workspace carve(uint8_t *base, uint32_t n, uint64_t len) {
   w.m = reinterpret_cast<int *>(w.n_words) + 8; // [8] = m, [9] = highest level in the sort, [10] = number tokens, [11] = m + 1 (length of the opens scan), [12] = string tokens,
   // [13] = other one-word tokens; n_words[2] = length of the second pass's scan
   w.tokc = take(n1 + 8);
-  w.ctx = take(n1 + 8);
   w.slots = reinterpret_cast<int *>(take(n1 * 4 + 64));
-  w.depth = reinterpret_cast<int *>(take(n1 * 4 + 64));
   w.value_list = reinterpret_cast<u64 *>(take(n1 * 8 + 64));
   w.number_list = reinterpret_cast<u64 *>(take(n1 * 8 + 64));
   w.tok_blocks = blocks_of(n1, TS_BLOCK);
@@ -624,12 +642,10 @@ const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *i
   (void)max_depth;
   const tape_workspace w = carve(static_cast<uint8_t *>(workspace), n, len);
   const u32 n1 = n + 1;
-  // one clear for the result and the control words behind it (they share the first 512 bytes of the workspace), then the three words that are not zero
-  (void)hipMemsetAsync(w.res, 0, size_t(reinterpret_cast<uint8_t *>(w.n_words + 16) - reinterpret_cast<uint8_t *>(w.res)), s);
-  (void)hipMemsetAsync(&w.res->error_key, 0xFF, sizeof(u64), s); // NO_ERROR_KEY
-  (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.n_words), int(n1), 1, s);
-  (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.n_words + 1), int(2 * w.tiles * RADIX_BINS), 1, s);
-  (void)hipMemsetAsync(w.ctx, 0, size_t(n1) + 8, s);
+  // one small kernel for the result and the control words behind it (they share the first 512 bytes of the workspace): all zero but three words
+  // (rounds 3-4a: four memsets -- four launches of the runtime's fill kernel, 4 us each)
+  hipLaunchKernelGGL(k_tape_init, dim3(1), dim3(64), 0, s, w.res, w.n_words, u32(reinterpret_cast<uint8_t *>(w.n_words + 16) - reinterpret_cast<uint8_t *>(w.res)) / 4u, n1,
+                     2u * w.tiles * RADIX_BINS);
   hipLaunchKernelGGL(k_tok_classify, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, buf, len, idx, n, w.tokc, w.sums, w.tok_blocks);
   hipLaunchKernelGGL(k_tok_scan_sums, dim3(TS_SUMS), dim3(1024), 0, s, w.sums, w.tok_blocks, w.totals);
   return w.totals + 2; // the number of string tokens (device)
@@ -645,8 +661,8 @@ void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t
   const u32 grid = blocks_of(n1, TP_THREADS);
   const int *m_ptr = w.m;
   const u32 kmax = max_depth < 4095u ? max_depth : 4095u;
-  hipLaunchKernelGGL(k_tok_apply, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, w.tokc, n, kmax, w.sums, w.tok_blocks, w.slots, w.depth, w.value_list, w.key_a, w.tok_a, w.m, w.m + 1,
-                     w.number_list, str_offsets, strs, string_buf, tape, tape_cap);
+  hipLaunchKernelGGL(k_tok_apply, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, w.tokc, n, kmax, max_depth, w.sums, w.tok_blocks, w.slots, w.value_list, w.key_a, w.tok_a, w.m, w.m + 1,
+                     w.number_list, str_offsets, strs, string_buf, tape, tape_cap, w.res);
   // two passes of six bits cover levels up to 4095; the second one only runs for documents nested 64 deep and more
   const int *max_level = w.m + 1;
   hipLaunchKernelGGL(k_radix_hist, dim3(w.tiles), dim3(64), 0, s, w.key_a, m_ptr, 0u, w.tiles, w.hist, max_level, w.n_words + 2);
@@ -657,8 +673,8 @@ void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t
   hipLaunchKernelGGL(k_radix_scatter, dim3(w.tiles), dim3(64), 0, s, w.key_b, w.tok_b, m_ptr, RADIX_BITS, w.tiles, w.hist, w.key_a, w.tok_a, max_level, w.opens, w.openpos);
   const sorted_pairs sorted{w.key_a, w.key_b, w.tok_a, w.tok_b, max_level};
   // containers: the ordinals came with the last scatter
-  hipLaunchKernelGGL(k_tape_match, dim3(blocks_of(n1, TP_THREADS * TM_PER)), dim3(TP_THREADS), 0, s, sorted, m_ptr, w.opens, w.openpos, w.slots, w.ctx, tape, tape_cap, w.res);
-  hipLaunchKernelGGL(k_tape_rules, dim3(blocks_of(n1, TP_THREADS * TW_PER)), dim3(TP_THREADS), 0, s, n, max_depth, w.tokc, w.slots, w.depth, w.ctx, tape, tape_cap, w.res);
+  hipLaunchKernelGGL(k_tape_match, dim3(blocks_of(n1, TP_THREADS * TM_PER)), dim3(TP_THREADS), 0, s, sorted, m_ptr, w.opens, w.openpos, w.slots, w.tokc, n, tape, tape_cap, w.res);
+  hipLaunchKernelGGL(k_tape_rules, dim3(blocks_of(n1, TP_THREADS * TW_PER)), dim3(TP_THREADS), 0, s, n, w.tokc, w.slots, tape, tape_cap, w.res);
   const u32 list_grid = grid < 8192u ? grid : 8192u;
   hipLaunchKernelGGL(k_tape_atoms, dim3(list_grid), dim3(TP_THREADS), 0, s, buf, len, idx, n, w.tokc, w.value_list, w.m + 5, w.res);
   hipLaunchKernelGGL(k_tape_numbers, dim3(list_grid), dim3(TP_THREADS), 0, s, buf, len, idx, w.number_list, w.m + 2, tape, tape_cap, w.slow_list,

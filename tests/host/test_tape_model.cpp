@@ -2,7 +2,7 @@
 // the CPU with the very same per-token functions (sj_tape_rules.h, sj_number.h) and the same intermediate arrays -- the packed
 // per-token counters and their prefix sums, the lists of value tokens with their tape positions, the brackets and commas (level and kind
 // in one key) sorted stably by nesting level, "which container am I in" from a count of the opening brackets in front, the walk's rule
-// from its tables, per-token verdicts reduced to the smallest error key -- and compared
+// in its split form (the depth's verdict, the token's own from the tables, the commas' verdicts on their followers), all reduced to the smallest error key -- and compared
 // with the oracle's serial walk (oracle/sj_oracle_stage2.c, itself pinned against the reference): error code always, every tape
 // word when the document is valid.  What this cannot cover is the GPU plumbing (scans, radix sort, atomics); that is what
 // tests/test_gpu_parity.py::test_tape_* is for.
@@ -24,7 +24,6 @@ struct doc_bytes {
 };
 
 // returns the error code; tape filled when it is SUCCESS.  The steps and the arrays are those of sjgpu_tape.hip (kernel names in the comments).
-static unsigned long n_stack_documents = 0; // documents whose container kinds came from the bit stack
 static u32 model(const uint8_t *buf, u32 len, const uint32_t *idx, u32 n, u32 max_depth, const uint32_t *str_offsets, u32 first_bad_string,
                  std::vector<u64> &tape) {
   if (n == 0) { return SJ_EMPTY; }
@@ -59,7 +58,10 @@ static u32 model(const uint8_t *buf, u32 len, const uint32_t *idx, u32 n, u32 ma
       long long k = (p.b >> 16) ? depth[i] : depth[i] - 1;
       if (k < 0) { k = 0; }
       if (k > kmax) { k = kmax; }
-      sort_in.push_back({sort_key(u32(k), C(i)), i});
+      // a bracket travels with its tape position, a comma with its list index and with what it knows about its followers
+      const bool comma = C(i) == ',';
+      const u32 fine = comma ? comma_fine_bits(i, C((long long)i + 1), i + 1 < n, C((long long)i + 2), i + 2 < n) : 0u;
+      sort_in.push_back({sort_key(u32(k), C(i), fine), comma ? i : u32(words)});
       if (u32(k) > top) { top = u32(k); }
     }
     words += p.a & 0xFFFFu; strs += p.b & 0xFFFFu; opens += p.b >> 16; closes += p.c & 0xFFFFu; numbers += p.c >> 16;
@@ -83,34 +85,26 @@ static u32 model(const uint8_t *buf, u32 len, const uint32_t *idx, u32 n, u32 ma
   u64 errkey = NO_ERROR_KEY;
   auto report = [&](u64 k) { if (k < errkey) { errkey = k; } };
   // k_tape_match
-  std::vector<uint8_t> ctx(n + 1, CTX_NONE);
   for (u32 j = 0; j < m; j++) {
-    const u32 kj = sorted[j].first, kind = kj >> KIND_SHIFT, i = sorted[j].second;
+    const u32 kj = sorted[j].first, kind = kj >> KIND_SHIFT, mine = sorted[j].second;
     if (kind_is_open(kind) || cid[j] == 0) { continue; }
     const u32 jo = openpos[cid[j] - 1], ko = sorted[jo].first;
     if (((ko ^ kj) & 0xFFFu) != 0) { continue; } // no container of my level in front of me: an error elsewhere says so
     const bool object = (ko >> KIND_SHIFT) == KIND_OPEN_OBJECT;
-    if (kind == KIND_COMMA) { ctx[i] = object ? CTX_OBJECT : CTX_ARRAY; continue; }
-    if ((kind == KIND_CLOSE_OBJECT) != object) { report(error_key(i, 0, SJ_TAPE_ERROR)); }
-    const u32 io = sorted[jo].second;
-    const u64 open_at = 1 + u64(tpos[io]), close_at = 1 + u64(tpos[i]);
-    const u64 count = (i == io + 1) ? 0 : (j - jo > 0xFFFFFFu ? 0xFFFFFFu : j - jo);
+    if (kind_is_comma(kind)) { // the comma judges the two tokens behind it: nobody else knows what its container wants there
+      if ((kind - KIND_COMMA) & (object ? COMMA_FINE_IN_OBJECT : COMMA_FINE_IN_ARRAY)) { continue; } // it said so when it was sent into the sort
+      const u32 i = mine;
+      const follower_keys f = comma_followers_rule(i, object ? CTX_OBJECT : CTX_ARRAY, C((long long)i + 1), i + 1 < n, C((long long)i + 2), i + 2 < n);
+      if (f.k[0] == NO_ERROR_KEY && f.k[1] == NO_ERROR_KEY && f.k[2] == NO_ERROR_KEY) { fprintf(stderr, "a comma that is not fine raises nothing\n"); return 97; }
+      for (u64 k : f.k) { report(k); }
+      continue;
+    }
+    const u32 open_tp = sorted[jo].second, close_tp = mine; // tape positions travel with the brackets
+    if ((kind == KIND_CLOSE_OBJECT) != object) { report(error_key(token_at_tape_position(tpos, n, close_tp), 0, SJ_TAPE_ERROR)); }
+    const u64 open_at = 1 + u64(open_tp), close_at = 1 + u64(close_tp);
+    const u64 count = (close_tp == open_tp + 1) ? 0 : (j - jo > 0xFFFFFFu ? 0xFFFFFFu : j - jo);
     tape[close_at] = tape_word(kind == KIND_CLOSE_OBJECT ? u32('}') : u32(']'), open_at);
     tape[open_at] = tape_word(object ? u32('{') : u32('['), (count << 32) | (close_at + 1));
-  }
-  // round 4: the same container kinds from the bit stack (kinds_then over the tokens, sj_tape_rules.h) -- for documents nested less than 64
-  // deep the device takes them from there, checks the rule where it computes tape positions and never writes ctx.  They must agree with the
-  // sort's answer wherever it matters: the rules below run on the stack's kinds when it can speak for the whole document.
-  {
-    kind_stack st{0, 0};
-    bool deep = false;
-    std::vector<uint8_t> ctx2(n + 1, CTX_NONE);
-    for (u32 i = 0; i < n; i++) {
-      const int d = depth[i] > 0x7FFFFFFFll ? 0x7FFFFFFF : (depth[i] < -0x7FFFFFFFll ? -0x7FFFFFFF : int(depth[i]));
-      if (C(i) == ',') { ctx2[i] = uint8_t(kinds_ctx(st, d, &deep)); }
-      st = kinds_then(st, kinds_of_token(C(i), d));
-    }
-    if (!deep) { ctx = ctx2; n_stack_documents++; }
   }
   // k_tape_rules: the rule from the tables a workgroup builds
   unsigned short props[256], accepts[ST_COUNT];
@@ -122,12 +116,12 @@ static u32 model(const uint8_t *buf, u32 len, const uint32_t *idx, u32 n, u32 ma
     if ((c0 == '{' && last != '}') || (c0 == '[' && last != ']')) { report(error_key(0, 0, SJ_TAPE_ERROR)); } // json_iterator.h:138-143: in front of everything else
   }
   for (u32 i = 0; i < n; i++) {
-    const int d = depth[i] > 0x7FFFFFFFll ? 0x7FFFFFFF : int(depth[i]);
+    const int d = depth[i] > 0x7FFFFFFFll ? 0x7FFFFFFF : (depth[i] < -0x7FFFFFFFll ? -0x7FFFFFFF : int(depth[i]));
     u32 rank = 0;
-    const u32 g = token_rule_tables(T, i == 0, C(i), C((long long)i - 1), C((long long)i - 2), C((long long)i + 1), i >= 1 ? ctx[i - 1] : 0u, i >= 2 ? ctx[i - 2] : 0u, d,
-                                    max_depth, &rank);
+    u32 g = depth_rule(i == 0, C(i), C((long long)i + 1), d, max_depth, &rank); // k_tok_apply: where the depth is computed
     if (g) { report(error_key(i, rank, g)); }
-    if (C(i) == ',' && comma_in_value_position(i, C((long long)i - 1), i >= 1 ? ctx[i - 1] : 0u)) { report(error_key(i, 2, SJ_NUMBER_ERROR)); }
+    g = token_rule_self(T, i == 0, C(i), C((long long)i - 1), C((long long)i - 2), &rank); // k_tape_rules: no ctx, no depth
+    if (g) { report(error_key(i, rank, g)); }
   }
   if (depth[n] != 0) { report(error_key(n, 0, SJ_TAPE_ERROR)); } // the walk runs into the sentinel inside a container
   // k_tape_strings: entry k is the k-th string of the string buffer (the oracle's offsets of the string tokens, in order)
@@ -202,6 +196,6 @@ int main(int argc, char **argv) {
   }
   printf("%lu documents, %lu valid;", docs, valid);
   for (int k = 0; k < 16; k++) { if (codes[k]) { printf(" code %d: %lu", k, codes[k]); } }
-  printf(" (container kinds from the bit stack: %lu documents)\n", n_stack_documents);
+  printf("\n");
   return 0;
 }

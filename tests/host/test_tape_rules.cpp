@@ -3,6 +3,9 @@
 // kernel k_tape_rules applies: byte properties, a state per byte in front, an accept mask per state).  Compared on every byte value for the
 // token itself, on every byte that any rule distinguishes (and a few it does not) for the two tokens in front and the one behind, on every
 // container kind, and on depths around 0 and around the nesting limit.
+// Round 4: the form the kernels run has neither a ctx nor a depth array -- the depth's verdict (depth_rule), the token's own (token_rule_self) and
+// the verdict of the comma one or two tokens in front (comma_followers_rule) -- and the MINIMUM of their keys must be the key token_rule gives,
+// for every combination in which the comma has a container (a comma without one judges nobody: see sj_tape_rules.h for why that is enough).
 #include "sj_tape_rules.h"
 
 #include <cstdio>
@@ -32,6 +35,32 @@ int main() {
                     const u32 e1 = token_rule(first != 0, c, prev, prev2, next, ctx_prev, ctx_prev2, depth, max_depth, &r1);
                     const u32 e2 = token_rule_tables(T, first != 0, c, prev, prev2, next, ctx_prev, ctx_prev2, depth, max_depth, &r2);
                     checked++;
+                    {
+                      const u64 i = first ? 0 : 7; // (any index: the keys only compare at equal index)
+                      u64 want = e1 ? error_key(i, r1, e1) : NO_ERROR_KEY;
+                      if (c == ',' && comma_in_value_position(i, prev, ctx_prev)) { const u64 k = error_key(i, 2, SJ_NUMBER_ERROR); want = k < want ? k : want; }
+                      const bool by_comma = !first && judged_by_comma(prev, prev2);
+                      const u32 kind = prev == ',' ? ctx_prev : ctx_prev2; // of the comma that judges this token
+                      if (!(by_comma && depth > 0 && kind == CTX_NONE)) {
+                        u64 got = NO_ERROR_KEY;
+                        u32 r = 9;
+                        u32 e = depth_rule(first != 0, c, next, depth, max_depth, &r);
+                        if (e) { const u64 k = error_key(i, r, e); got = k < got ? k : got; }
+                        e = token_rule_self(T, first != 0, c, prev, prev2, &r);
+                        if (e) { const u64 k = error_key(i, r, e); got = k < got ? k : got; }
+                        if (by_comma) {
+                          // the comma sits at i - 1 (this token is its first follower) or at i - 2 (this token follows the string behind it)
+                          const follower_keys f = prev == ',' ? comma_followers_rule(i - 1, kind, c, true, next, true) : comma_followers_rule(i - 2, kind, '"', true, c, true);
+                          const u64 mine[2] = {prev == ',' ? f.k[0] : f.k[2], prev == ',' ? f.k[1] : NO_ERROR_KEY};
+                          for (u64 k : mine) { got = k < got ? k : got; }
+                        }
+                        if (got != want) {
+                          fprintf(stderr, "c %02x prev %02x prev2 %02x next %02x ctx %u %u depth %d limit %u first %d: rule key %llx, the split form %llx\n", c, prev, prev2, next,
+                                  ctx_prev, ctx_prev2, depth, max_depth, first, (unsigned long long)want, (unsigned long long)got);
+                          return 1;
+                        }
+                      }
+                    }
                     if (e1 != e2 || r1 != r2) {
                       fprintf(stderr, "c %02x prev %02x prev2 %02x next %02x ctx %u %u depth %d limit %u first %d: rule says %u (rank %u), tables say %u (rank %u)\n", c, prev, prev2,
                               next, ctx_prev, ctx_prev2, depth, max_depth, first, e1, r1, e2, r2);

@@ -48,6 +48,9 @@ def test_every_leg_is_there_and_none_failed():
     for name in ("config2_minify", "config2_validate_utf8", "config3_amazon_ndjson", "config4_deep_nesting", "config4_escape_heavy", "next_f2_finish_device",
                  "next_f3_depth_scan", "next_f3_parse_strings"):
         r = legs[name]["roofline"]
+        if r["bound"] == "latency":  # finish(): the boundary search stops at the first hit from the end -- four launches and a wait, no bandwidth to quote
+            assert name == "next_f2_finish_device" and r["frac"] is None and legs[name]["ms_per_call"] < 0.2 and r["whole_list_bytes"] > 0
+            continue
         assert r["peak"] == 8000.0 and 0 < r["frac"] < 1, name
     for kind, leg in legs["next_f3_tape"].items():
         assert 0 < leg["roofline"]["frac"] < 1 and "word for word" in leg["parity"] and leg["cpu_baseline"]["kind"] == "reference", kind
