@@ -1612,17 +1612,28 @@ int sjgpu_stage2_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const v
   strings_result_dev *sres = reinterpret_cast<strings_result_dev *>(ws);
   uint32_t *offsets = reinterpret_cast<uint32_t *>(ws + offs_at);
   hipStream_t s = pick(ctx, stream);
-  const int *string_tokens = launch_tape_front(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, max_depth, ws + tape_at, s);
-  const strings_handoff strs = launch_parse_strings(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, false,
-                                                    static_cast<uint8_t *>(string_buf_dev), string_buf_bytes, offsets, sres, ws + scratch_at, s, string_tokens);
-  launch_tape(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, max_depth, offsets, strs, static_cast<uint8_t *>(string_buf_dev),
-              static_cast<uint64_t *>(tape_dev), tape_cap_words, ws + tape_at, s);
-  SJ_TRY(ctx, hipGetLastError());
+  // Optimistic: the string buffer by the stream compaction alone, the sort in one pass -- what nearly every document needs.  A document the stream declines
+  // (a string the reference rejects, quotes glued to scalars, a look-back that settles nothing) or one nested 64 deep and more says so in its results and is
+  // run again with the per-string kernels / the sort's second pass enqueued: ten launches that nearly always did nothing are gone from the common call.
   strings_result_dev hs;
   tape_result_dev ht;
-  SJ_TRY(ctx, hipMemcpyAsync(&hs, sres, sizeof(hs), hipMemcpyDeviceToHost, s));
-  SJ_TRY(ctx, hipMemcpyAsync(&ht, ws + tape_at, sizeof(ht), hipMemcpyDeviceToHost, s));
-  SJ_TRY(ctx, hipStreamSynchronize(s));
+  int roads = STRINGS_STREAM_ONLY;
+  bool deep = false;
+  for (;;) {
+    const int *string_tokens = launch_tape_front(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, max_depth, ws + tape_at, s);
+    const strings_handoff strs = launch_parse_strings(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, false,
+                                                      static_cast<uint8_t *>(string_buf_dev), string_buf_bytes, offsets, sres, ws + scratch_at, s, string_tokens, roads);
+    launch_tape(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, max_depth, offsets, strs, static_cast<uint8_t *>(string_buf_dev),
+                static_cast<uint64_t *>(tape_dev), tape_cap_words, ws + tape_at, s, deep);
+    SJ_TRY(ctx, hipGetLastError());
+    SJ_TRY(ctx, hipMemcpyAsync(&hs, sres, sizeof(hs), hipMemcpyDeviceToHost, s));
+    SJ_TRY(ctx, hipMemcpyAsync(&ht, ws + tape_at, sizeof(ht), hipMemcpyDeviceToHost, s));
+    SJ_TRY(ctx, hipStreamSynchronize(s));
+    bool again = false;
+    if (roads == STRINGS_STREAM_ONLY && hs.path == 2 && !hs.overflow) { roads = STRINGS_WALK_ONLY; again = true; }
+    if (!deep && ht.max_level >= TAPE_ONE_PASS_LEVELS) { deep = true; again = true; }
+    if (!again) { break; }
+  }
   ctx->last_string_path = hs.path;
   // the first offender in list order decides; a string's content ranks behind its own position in the grammar (sj_tape_rules.h)
   uint64_t key = ht.error_key;

@@ -191,23 +191,33 @@ struct strings_handoff {
 // listed (optional): device pointer to the number of string tokens of the list, counted by the caller (launch_tape_front) -- the pass then
 // neither counts them itself nor writes offsets / length words for the stream's records (the caller does, from the handoff: the k-th string
 // token's record begins at outq[k])
+// roads: which of the two roads to the buffer are enqueued.  STRINGS_BOTH: the stream compaction and, behind it, the per-string kernels, which return at once
+// when the stream took the document (the decision is taken on the device: stand-alone sjgpu_parse_strings_device).  STRINGS_STREAM_ONLY: the stream alone --
+// a document it declines comes back with res->path == 2 and NOTHING written, and the caller enqueues the pass again with STRINGS_WALK_ONLY (the verdict
+// overridden: the per-string kernels write).  sjgpu_stage2_device takes that optimistic route: five launches that nearly always do nothing are not enqueued.
+enum : int { STRINGS_BOTH = 0, STRINGS_STREAM_ONLY = 1, STRINGS_WALK_ONLY = 2 };
 strings_handoff launch_parse_strings(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
-                                     uint32_t *offsets, strings_result_dev *res, void *scratch, hipStream_t s, const int *listed = nullptr);
+                                     uint32_t *offsets, strings_result_dev *res, void *scratch, hipStream_t s, const int *listed = nullptr, int roads = STRINGS_BOTH);
 // ---- the tape (sjgpu_tape.hip) ----------------------------------------------------------------------------------
 struct tape_result_dev {
   uint64_t error_key;   // smallest (list index << 8 | rank << 4 | error_code) over all offending tokens, ~0 = none (sj_tape_rules.h)
   uint64_t tape_words;  // words of the finished tape (both root words included)
   uint32_t slow_numbers; // number tokens that took the big-integer decision
   uint32_t overflow;    // the caller's tape was too small
+  uint32_t max_level;   // the highest nesting level among the brackets and commas: 64 and more needs the sort's second pass (launch_tape's `deep`)
+  uint32_t pad;
 };
+constexpr uint32_t TAPE_ONE_PASS_LEVELS = 64; // levels one pass of the sort tells apart
 size_t tape_workspace_bytes(uint32_t n, uint64_t len);
 // stage 2 of buf[0..len) from its structural list idx[0..n] (idx[n] = len), in two halves around the string pass: launch_tape_front leaves
 // the token bytes, tape positions, depths, value lists and the sort's input in the workspace and returns the number of string tokens (device);
 // launch_tape writes the reference's tape (and the length words of the string records when the stream compaction wrote them).
 // workspace: tape_workspace_bytes(n, len), its first bytes are the tape_result_dev afterwards
 const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, void *workspace, hipStream_t s);
+// deep: enqueue the sort's second pass (documents nested 64 deep and more).  Without it a deeper document comes back with max_level >= 64 in the result and
+// a tape that is NOT valid: the caller runs the three launches again with deep = true (sjgpu_stage2_device: optimistic, five launches saved on nearly every call).
 void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, const uint32_t *str_offsets, strings_handoff strs,
-                 uint8_t *string_buf, uint64_t *tape, uint64_t tape_cap, void *workspace, hipStream_t s);
+                 uint8_t *string_buf, uint64_t *tape, uint64_t tape_cap, void *workspace, hipStream_t s, bool deep = true);
 // On-Demand's raw key comparison over the whole list (sjgpu_strings.hip); names_block: [u32 lens[K]][name bytes back to back] in device memory
 void launch_match_keys(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, const uint8_t *names_block, uint32_t K, uint32_t *out, uint32_t *matches,
                        hipStream_t s);

@@ -499,13 +499,14 @@ size_t strings_scratch_bytes(uint32_t n, uint64_t len) { return carve_strings_sc
 // listed, the per-string kernels above for the rest (the decision is taken on the device: the kernels of the road not taken return
 // at once, its scan runs over zero entries).
 strings_handoff launch_parse_strings(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, bool allow_replacement, uint8_t *out, uint64_t out_cap,
-                                     uint32_t *offsets, strings_result_dev *res, void *scratch, hipStream_t s, const int *listed) {
+                                     uint32_t *offsets, strings_result_dev *res, void *scratch, hipStream_t s, const int *listed, int roads) {
   const strings_scratch w = carve_strings_scratch(scratch, n, len);
   const u32 n1 = n + 1;
   enqueue_string_stream(buf, len, idx, n, allow_replacement, out, out_cap, offsets, res, w, s, listed);
   const u32 *ctrl = static_cast<const u32 *>(w.ctrl); // strs_ctrl: [1] = entries of this path's scan, [3] = it runs
   const char *sw = std::getenv("SJGPU_STRING_STREAM"); // A/B switch, read per call (the tests flip it)
-  if (sw && sw[0] == '0') { // force the per-string kernels: overwrite the verdict
+  if (roads == STRINGS_STREAM_ONLY && !(sw && sw[0] == '0')) { return strings_handoff{w.outq, ctrl + 2}; } // a declined document comes back with path == 2
+  if ((sw && sw[0] == '0') || roads == STRINGS_WALK_ONLY) { // force the per-string kernels: overwrite the verdict
     u32 *c = static_cast<u32 *>(w.ctrl);
     (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c), int(n1), 2, s);
     (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c + 2), 0, 1, s);

@@ -37,6 +37,7 @@ namespace {
 
 constexpr u32 TP_THREADS = 256;
 constexpr u32 RADIX_BITS = 6, RADIX_BINS = 1u << RADIX_BITS, RADIX_TILE = 2048; // one wave sorts one tile
+static_assert(RADIX_BINS == TAPE_ONE_PASS_LEVELS, "sjgpu_stage2_device decides from max_level whether the second pass is needed");
 
 struct dev_bytes {
   const u8 *buf;
@@ -64,6 +65,34 @@ struct windowed_bytes {
       return u32(window) & 0xFFu;
     }
     return u32(window >> (8u * d)) & 0xFFu;
+  }
+};
+
+// The same through a 32-byte window, all of it requested at once: a number token of the twitter-like text is 19 bytes long (an 18-digit id and the
+// byte that ends it) -- three dependent round trips through the 8-byte window, one here.  k_tape_numbers: one token per lane, waiting for memory
+// 93 % of its cycles (profiles/r04_pmc_summary.txt).
+struct wide_window_bytes {
+  const u8 *buf;
+  u32 len;
+  mutable u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+  mutable u32 at = 0xFFFFFF00u;
+  typedef u64 __attribute__((aligned(1))) u64_unaligned;
+  __device__ __forceinline__ u32 byte(u32 pos) const {
+    u32 d = pos - at;
+    if (d >= 32u) {
+      at = pos;
+      d = 0;
+      if (u64(pos) + 32u <= len) {
+        const u64_unaligned *p = reinterpret_cast<const u64_unaligned *>(buf + pos);
+        w0 = p[0]; w1 = p[1]; w2 = p[2]; w3 = p[3];
+      } else {
+        u64 w[4] = {0, 0, 0, 0};
+        for (u32 k = 0; k < 32; k++) { w[k >> 3] |= u64(pos + k < len ? u32(buf[pos + k]) : 0x20u) << (8u * (k & 7u)); }
+        w0 = w[0]; w1 = w[1]; w2 = w[2]; w3 = w[3];
+      }
+    }
+    const u64 lo = d < 8u ? w0 : w1, hi = d < 24u ? w2 : w3;
+    return u32((d < 16u ? lo : hi) >> (8u * (d & 7u))) & 0xFFu;
   }
 };
 
@@ -415,6 +444,7 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_match(sorted_pairs sorted, 
   const u64 j0 = (u64(blockIdx.x) * TP_THREADS + threadIdx.x) * TM_PER;
   const u32 m = u32(*m_ptr);
   if (j0 >= m) { return; }
+  if (key == nullptr) { return; } // a document that needs the sort's second pass, which was not enqueued: the caller runs the tape again (launch_tape)
   u32 kj[TM_PER], cid[TM_PER], ti[TM_PER];
   bool live[TM_PER];
 #pragma unroll
@@ -481,8 +511,8 @@ __device__ __forceinline__ void check_token(const rule_tables &T, u32 i, u32 c, 
   const u32 g = token_rule_self(T, i == 0, c, prev, prev2, &rank); // (sj_tape_rules.h: the token's own verdict; the depth's is k_tok_apply's, the commas' k_tape_match's)
   if (g) { report_error(res, error_key(i, rank, g)); }
 }
-__global__ __launch_bounds__(TP_THREADS) void k_tape_rules(u32 n, const u8 *__restrict__ tokc, const int *__restrict__ tpos, u64 *__restrict__ tape, u64 tape_cap,
-                                                          tape_result_dev *__restrict__ res) {
+__global__ __launch_bounds__(TP_THREADS) void k_tape_rules(u32 n, const u8 *__restrict__ tokc, const int *__restrict__ tpos, const int *__restrict__ max_level,
+                                                          u64 *__restrict__ tape, u64 tape_cap, tape_result_dev *__restrict__ res) {
   __shared__ unsigned short sh_props[256], sh_accepts[16];
   __shared__ u8 sh_state[256];
   static_assert(TP_THREADS == 256 && ST_COUNT <= 16, "one table entry per thread");
@@ -495,6 +525,7 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_rules(u32 n, const u8 *__re
   if (n - i0 < TW_PER) { // the thread that holds "behind the last token": the root words and the check that belongs to no token
     const u64 words = u64(u32(tpos[n])) + 2;
     res->tape_words = words;
+    res->max_level = u32(*max_level);
     if (words <= tape_cap) {
       tape[0] = tape_word('r', words);           // visit_document_end, tape_builder.h:160-165
       tape[words - 1] = tape_word('r', 0);
@@ -545,7 +576,7 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_numbers(const u8 *__restric
   for (u64 k = u64(blockIdx.x) * TP_THREADS + threadIdx.x; k < count; k += u64(gridDim.x) * TP_THREADS) {
     const u64 entry = number_list[k];
     const u32 i = u32(entry);
-    const windowed_bytes src{buf, u32(len)};
+    const wide_window_bytes src{buf, u32(len)};
     const number_value v = parse_number_token(src, idx[i], static_cast<bigint *>(nullptr));
     if (v.error) { report_error(res, error_key(i, 2, v.error)); continue; }
     const u64 at = (entry >> 32) + 1u;
@@ -655,7 +686,7 @@ const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *i
 // strs: where the records of the stream compaction begin, read when IT wrote the buffer (the flag decides on the device); string_buf: the
 // buffer, for the length words.
 void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, const uint32_t *str_offsets, strings_handoff strs,
-                 uint8_t *string_buf, uint64_t *tape, uint64_t tape_cap, void *workspace, hipStream_t s) {
+                 uint8_t *string_buf, uint64_t *tape, uint64_t tape_cap, void *workspace, hipStream_t s, bool deep) {
   const tape_workspace w = carve(static_cast<uint8_t *>(workspace), n, len);
   const u32 n1 = n + 1;
   const u32 grid = blocks_of(n1, TP_THREADS);
@@ -668,13 +699,17 @@ void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t
   hipLaunchKernelGGL(k_radix_hist, dim3(w.tiles), dim3(64), 0, s, w.key_a, m_ptr, 0u, w.tiles, w.hist, max_level, w.n_words + 2);
   enqueue_scan(w.hist, 2 * w.tiles * RADIX_BINS, w.n_words + 1, w.partial, s);
   hipLaunchKernelGGL(k_radix_scatter, dim3(w.tiles), dim3(64), 0, s, w.key_a, w.tok_a, m_ptr, 0u, w.tiles, w.hist, w.key_b, w.tok_b, max_level, w.opens, w.openpos);
-  hipLaunchKernelGGL(k_radix_hist, dim3(w.tiles), dim3(64), 0, s, w.key_b, m_ptr, RADIX_BITS, w.tiles, w.hist, max_level, w.n_words + 2);
-  enqueue_scan(w.hist, 2 * w.tiles * RADIX_BINS, w.n_words + 2, w.partial, s);
-  hipLaunchKernelGGL(k_radix_scatter, dim3(w.tiles), dim3(64), 0, s, w.key_b, w.tok_b, m_ptr, RADIX_BITS, w.tiles, w.hist, w.key_a, w.tok_a, max_level, w.opens, w.openpos);
-  const sorted_pairs sorted{w.key_a, w.key_b, w.tok_a, w.tok_b, max_level};
+  if (deep) {
+    hipLaunchKernelGGL(k_radix_hist, dim3(w.tiles), dim3(64), 0, s, w.key_b, m_ptr, RADIX_BITS, w.tiles, w.hist, max_level, w.n_words + 2);
+    enqueue_scan(w.hist, 2 * w.tiles * RADIX_BINS, w.n_words + 2, w.partial, s);
+    hipLaunchKernelGGL(k_radix_scatter, dim3(w.tiles), dim3(64), 0, s, w.key_b, w.tok_b, m_ptr, RADIX_BITS, w.tiles, w.hist, w.key_a, w.tok_a, max_level, w.opens, w.openpos);
+  }
+  // (without the second pass a document nested 64 deep and more is NOT sorted: k_tape_match then leaves at once -- key_two == nullptr says so -- and the
+  // caller, who finds max_level in the result, comes back with deep = true)
+  const sorted_pairs sorted{deep ? w.key_a : nullptr, w.key_b, deep ? w.tok_a : nullptr, w.tok_b, max_level};
   // containers: the ordinals came with the last scatter
   hipLaunchKernelGGL(k_tape_match, dim3(blocks_of(n1, TP_THREADS * TM_PER)), dim3(TP_THREADS), 0, s, sorted, m_ptr, w.opens, w.openpos, w.slots, w.tokc, n, tape, tape_cap, w.res);
-  hipLaunchKernelGGL(k_tape_rules, dim3(blocks_of(n1, TP_THREADS * TW_PER)), dim3(TP_THREADS), 0, s, n, w.tokc, w.slots, tape, tape_cap, w.res);
+  hipLaunchKernelGGL(k_tape_rules, dim3(blocks_of(n1, TP_THREADS * TW_PER)), dim3(TP_THREADS), 0, s, n, w.tokc, w.slots, max_level, tape, tape_cap, w.res);
   const u32 list_grid = grid < 8192u ? grid : 8192u;
   hipLaunchKernelGGL(k_tape_atoms, dim3(list_grid), dim3(TP_THREADS), 0, s, buf, len, idx, n, w.tokc, w.value_list, w.m + 5, w.res);
   hipLaunchKernelGGL(k_tape_numbers, dim3(list_grid), dim3(TP_THREADS), 0, s, buf, len, idx, w.number_list, w.m + 2, tape, tape_cap, w.slow_list,

@@ -28,7 +28,7 @@ int main(int argc, char **argv) {
   const int force_walk = argc > 2 ? atoi(argv[2]) : 0;
   sj_emu::max_concurrent_workgroups = 4;
   if (force_walk) { setenv("SJGPU_STRING_STREAM", "0", 1); } // launch_parse_strings reads the switch per call
-  unsigned long docs = 0, valid = 0, codes[32] = {0}, roads[3] = {0, 0, 0};
+  unsigned long docs = 0, valid = 0, codes[32] = {0}, roads[3] = {0, 0, 0}, reruns = 0;
   std::vector<uint8_t> doc_store, ws_store, tape_store, sbuf_store, idx_store;
   for (;;) {
     uint32_t len;
@@ -96,11 +96,23 @@ int main(int argc, char **argv) {
       uint8_t *sbuf = static_cast<uint8_t *>(aligned(sbuf_store, str_cap, 0x5A));
       strings_result_dev *sres = reinterpret_cast<strings_result_dev *>(ws);
       uint32_t *offsets = reinterpret_cast<uint32_t *>(ws + offs_at);
-      const int *string_tokens = launch_tape_front(doc, len, idx, n, max_depth, ws + tape_at, nullptr);
-      const strings_handoff strs = launch_parse_strings(doc, len, idx, n, false, sbuf, str_cap, offsets, sres, ws + scratch_at, nullptr, string_tokens);
-      launch_tape(doc, len, idx, n, max_depth, offsets, strs, sbuf, tape, tape_cap, ws + tape_at, nullptr);
-      const strings_result_dev hs = *sres;
-      const tape_result_dev ht = *reinterpret_cast<const tape_result_dev *>(ws + tape_at);
+      // (sjgpu_stage2_device's optimistic loop: the stream alone and the sort in one pass first; what a document's results ask for is enqueued again)
+      strings_result_dev hs;
+      tape_result_dev ht;
+      int string_roads = STRINGS_STREAM_ONLY;
+      bool deep = false;
+      for (;;) {
+        const int *string_tokens = launch_tape_front(doc, len, idx, n, max_depth, ws + tape_at, nullptr);
+        const strings_handoff strs = launch_parse_strings(doc, len, idx, n, false, sbuf, str_cap, offsets, sres, ws + scratch_at, nullptr, string_tokens, string_roads);
+        launch_tape(doc, len, idx, n, max_depth, offsets, strs, sbuf, tape, tape_cap, ws + tape_at, nullptr, deep);
+        hs = *sres;
+        ht = *reinterpret_cast<const tape_result_dev *>(ws + tape_at);
+        bool again = false;
+        if (string_roads == STRINGS_STREAM_ONLY && hs.path == 2 && !hs.overflow) { string_roads = STRINGS_WALK_ONLY; again = true; }
+        if (!deep && ht.max_level >= TAPE_ONE_PASS_LEVELS) { deep = true; again = true; }
+        if (!again) { break; }
+        reruns++;
+      }
       roads[hs.path < 3 ? hs.path : 0]++;
       uint64_t key = ht.error_key;
       if (hs.first_bad != 0xFFFFFFFFu) {
@@ -138,6 +150,6 @@ int main(int argc, char **argv) {
   }
   printf("%lu documents, %lu valid, 0 mismatches;", docs, valid);
   for (int k = 0; k < 32; k++) { if (codes[k]) { printf(" code %d: %lu", k, codes[k]); } }
-  printf(" (string roads: stream %lu, per-string %lu)\n", roads[1], roads[2]);
+  printf(" (string roads: stream %lu, per-string %lu; second rounds: %lu)\n", roads[1], roads[2], reruns);
   return 0;
 }

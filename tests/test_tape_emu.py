@@ -126,4 +126,4 @@ def test_escapes_across_chunks_and_segments(emu):
             for esc in (b'\\q', b'\\ud800', b'\\udc00x', b'\\u12G4', b'\\ud83d\\u0041', b'\\ud800\\ud800\\udc00', b'\\udc00\\udc00', b'\\ud83dxude00', b'\\ud83d\\nde00'):
                 bad.append(b'["ok","' + b"a" * (boundary + delta - 7) + esc + b'tail",1]')
     out = emu(bad)
-    assert f"code 5: {len(bad)}" in out and f"per-string {len(bad)})" in out, out
+    assert f"code 5: {len(bad)}" in out and f"per-string {len(bad)};" in out and f"second rounds: {len(bad)})" in out, out  # declined by the stream, run again
