@@ -1547,12 +1547,16 @@ int sjgpu_parse_strings_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
   strings_result_dev *res = reinterpret_cast<strings_result_dev *>(tmp);
   uint32_t *offsets = offsets_dev ? static_cast<uint32_t *>(offsets_dev) : reinterpret_cast<uint32_t *>(tmp + offs_at);
   hipStream_t s = pick(ctx, stream);
-  launch_parse_strings(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, allow_replacement != 0,
-                       static_cast<uint8_t *>(string_buf_dev), string_buf_bytes, offsets, res, tmp + scratch_at, s);
-  SJ_TRY(ctx, hipGetLastError());
+  // optimistic like stage 2: the stream compaction alone; a document it declines (path 2, nothing written) is run again through the per-string kernels
   strings_result_dev h;
-  SJ_TRY(ctx, hipMemcpyAsync(&h, res, sizeof(h), hipMemcpyDeviceToHost, s));
-  SJ_TRY(ctx, hipStreamSynchronize(s));
+  for (int roads = STRINGS_STREAM_ONLY;; roads = STRINGS_WALK_ONLY) {
+    launch_parse_strings(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, allow_replacement != 0,
+                         static_cast<uint8_t *>(string_buf_dev), string_buf_bytes, offsets, res, tmp + scratch_at, s, nullptr, roads);
+    SJ_TRY(ctx, hipGetLastError());
+    SJ_TRY(ctx, hipMemcpyAsync(&h, res, sizeof(h), hipMemcpyDeviceToHost, s));
+    SJ_TRY(ctx, hipStreamSynchronize(s));
+    if (roads == STRINGS_WALK_ONLY || h.path != 2 || h.overflow) { break; }
+  }
   ctx->last_string_path = h.path;
   if (bytes_out) { *bytes_out = h.bytes; }
   if (strings_out) { *strings_out = h.strings; }

@@ -472,6 +472,9 @@ __global__ __launch_bounds__(FIN_THREADS) void k_count_below(const u32 *__restri
 // ---- host side: enqueue the kernels of one finish ------------------------------------------------------------------------------
 static inline u32 blocks_for(u64 n, u32 per) { return u32((n + per - 1) / per); }
 
+// in-place exclusive scan of up to 2^20 ints by one workgroup
+void launch_scan_partials(int *a, u32 count, hipStream_t s) { hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, a, count); }
+
 void enqueue_scan(int *a, u32 n_max, const u32 *n_ptr, int *partial, hipStream_t s) {
   const u32 nb = blocks_for(n_max, FIN_BLOCK);
   hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(FIN_THREADS), 0, s, a, n_ptr, partial);

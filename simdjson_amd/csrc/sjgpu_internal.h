@@ -170,7 +170,7 @@ constexpr size_t STRS_SUMMARY_BYTES = 32, STRS_BASE_BYTES = 16;
 struct strings_scratch {
   void *ctrl;        // 64 bytes: scan lengths, which path writes the buffer, totals (sjgpu_string_stream.hip: strs_ctrl)
   int *partial;      // block sums of the scans
-  int *kord;         // n + 1: string tokens in front of every structural
+  int *kord;         // n + 2 ints of room: string tokens per tile of 4096 structurals (then their prefixes) and one bit per structural (sjgpu_string_stream.hip)
   uint32_t *outq;    // n + 2: where the k-th string's record begins
   void *seg_summary; // per 16 KiB segment of the document
   void *seg_base;
@@ -223,6 +223,8 @@ void launch_match_keys(const uint8_t *buf, uint64_t len, const uint32_t *idx, ui
                        hipStream_t s);
 // in-place exclusive scan of a[0 .. *n_ptr) (n_max >= *n_ptr sizes the grid); partial: blocks_for(n_max, 4096) + 64 ints (sjgpu_finish.hip)
 void enqueue_scan(int *a, uint32_t n_max, const uint32_t *n_ptr, int *partial, hipStream_t s);
+// in-place exclusive scan of a[0 .. count), count <= 2^20, by one workgroup (sjgpu_finish.hip: k_scan_partials)
+void launch_scan_partials(int *a, uint32_t count, hipStream_t s);
 
 } // namespace sjgpu
 #endif

@@ -8,7 +8,7 @@
 // A lane owns 64 bytes, a wave 4 KiB, a wave's share is one 16 KiB segment; loads are the 16-byte row loads of stage 1.
 //   k_strs_count     per segment: output bytes, opening quotes and rejected escapes for both "starts inside / outside a string"
 //   k_strs_resolve   one workgroup: in-string state, output base and string ordinal in front of every segment; totals
-//   k_strs_tokens + scan   which structurals are quotes, and the ordinal of each among them (skipped when the tape has them already)
+//   k_strs_tokens + scan   which structurals are quotes (one bit each) and how many per tile of 4096 (skipped when the tape has counted them already)
 //   k_strs_decide    the stream is taken iff every string is valid, every opening quote of the document is a structural (a quote
 //                    glued to a scalar, a"b", is not: such documents are invalid and take the per-string path) and the buffer fits
 //   k_strs_write     the bytes, through a per-wave LDS window (16-byte stores); where every string begins (by ordinal)
@@ -263,16 +263,40 @@ __global__ __launch_bounds__(RES_THREADS) void k_strs_resolve(const strs_summary
 }
 
 // ---- the structural list: which tokens are strings ------------------------------------------------------------------------------------------
-constexpr u32 TOK_THREADS = 256;
-__global__ __launch_bounds__(TOK_THREADS) void k_strs_tokens(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, int *__restrict__ isq) {
-  const u64 i = u64(blockIdx.x) * TOK_THREADS + threadIdx.x;
-  if (i > n) { return; }
-  int q = 0;
-  if (i < n) {
-    const u32 pos = idx[i];
-    q = (pos < len && buf[pos] == '"') ? 1 : 0;
+// One BIT per token and one count per tile of 4096 (sixteen rows of 256, one token per lane and row: a wave fetches the bytes of 64 consecutive tokens
+// with one instruction); the ordinal of a token among the strings is the tile's prefix + a popcount, computed where it is needed (k_strs_finalize).
+// Rounds 3-4a wrote an int per token, ran the generic three-kernel scan over that array and read it back: 1.0 GB of traffic for a 256 MiB twitter-like
+// document (32 M tokens), 0.26 ms of the stand-alone string pass's 0.79.
+constexpr u32 TOK_THREADS = 256, TOK_ROWS = 16, TOK_TILE = TOK_THREADS * TOK_ROWS, TOK_WAVES = TOK_THREADS / 64;
+static_assert(TOK_TILE == 4096, "carve_strings_scratch (sjgpu_strings.hip) sizes the token pass's room for tiles of 4096");
+static_assert(TOK_ROWS * TOK_WAVES == 64, "a tile's (row, wave) counts are scanned by one wave");
+// qbits[tile * 64 + row * 4 + wave]: bit l = token tile * 4096 + row * 256 + wave * 64 + l is a string; count[tile] = strings of the tile
+// (count has one more entry, zero: the exclusive scan over all of them leaves the number of string tokens there)
+__global__ __launch_bounds__(TOK_THREADS) void k_strs_tokens(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, u64 *__restrict__ qbits,
+                                                            int *__restrict__ count, u32 tiles) {
+  __shared__ u32 sh[TOK_WAVES];
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const u64 tile0 = u64(blockIdx.x) * TOK_TILE;
+  u32 pos[TOK_ROWS];
+#pragma unroll
+  for (u32 row = 0; row < TOK_ROWS; row++) {
+    const u64 i = tile0 + u64(row) * TOK_THREADS + tid;
+    pos[row] = i < n ? idx[i] : 0xFFFFFFFFu;
   }
-  isq[i] = q; // isq[n] = 0: the scan leaves the number of string tokens there
+  u32 mine = 0; // strings of this wave's rows (wave-uniform)
+#pragma unroll
+  for (u32 row = 0; row < TOK_ROWS; row++) {
+    const bool q = pos[row] < len && buf[pos[row]] == '"';
+    const u64 m = __ballot(q);
+    if (lane == 0) { qbits[u64(blockIdx.x) * 64 + row * TOK_WAVES + wave] = m; }
+    mine += u32(popc64(m));
+  }
+  if (lane == 0) { sh[wave] = mine; }
+  __syncthreads();
+  if (tid == 0) {
+    count[blockIdx.x] = int(sh[0] + sh[1] + sh[2] + sh[3]);
+    if (blockIdx.x == 0) { count[tiles] = 0; }
+  }
 }
 
 __global__ void k_strs_decide(strs_ctrl *__restrict__ ctrl, const int *__restrict__ listed_ptr, u32 n, u64 out_cap, u32 *__restrict__ outq, strings_result_dev *__restrict__ res) {
@@ -430,15 +454,42 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__rest
 
 // ---- pass 4: per structural -------------------------------------------------------------------------------------------------------------
 typedef u32 __attribute__((aligned(1))) u32_any; // gfx950 stores a dword at any byte address
-__global__ __launch_bounds__(TOK_THREADS) void k_strs_finalize(const int *__restrict__ kord, u32 n, const u32 *__restrict__ outq, const strs_ctrl *__restrict__ ctrl,
-                                                              u32 *__restrict__ offsets, u8 *__restrict__ out) {
+// count: the exclusive prefixes of the tiles' string counts now (k_scan_partials)
+__global__ __launch_bounds__(TOK_THREADS) void k_strs_finalize(const u64 *__restrict__ qbits, const int *__restrict__ count, u32 n, const u32 *__restrict__ outq,
+                                                              const strs_ctrl *__restrict__ ctrl, u32 *__restrict__ offsets, u8 *__restrict__ out) {
   if (ctrl->go_stream == 0) { return; }
-  const u64 i = u64(blockIdx.x) * TOK_THREADS + threadIdx.x;
-  if (i > n) { return; }
-  const u32 k = u32(kord[i]);
-  const u32 at = outq[k];
-  offsets[i] = at; // CSR: a structural that is no string has an empty record where the next one begins
-  if (i < n && u32(kord[i + 1]) != k) { *reinterpret_cast<u32_any *>(out + at) = outq[k + 1] - at - 5u; }
+  __shared__ u32 sh_w[64];
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const u64 tile0 = u64(blockIdx.x) * TOK_TILE;
+  if (wave == 0) { // the 64 (row, wave) counts of the tile in row-major order = list order: exclusive prefixes
+    const u32 c = u32(popc64(qbits[u64(blockIdx.x) * 64 + lane]));
+    sh_w[lane] = wave_incl_scan(c) - c;
+  }
+  __syncthreads();
+  const u32 front = u32(count[blockIdx.x]);
+  const u64 below = lanemask_lt(lane);
+  u32 k[TOK_ROWS], at[TOK_ROWS], next[TOK_ROWS];
+  u64 bits[TOK_ROWS];
+#pragma unroll
+  for (u32 row = 0; row < TOK_ROWS; row++) {
+    const u64 i = tile0 + u64(row) * TOK_THREADS + tid;
+    bits[row] = qbits[u64(blockIdx.x) * 64 + row * TOK_WAVES + wave];
+    k[row] = front + sh_w[row * TOK_WAVES + wave] + u32(popc64(bits[row] & below)); // string tokens in front of token i
+    at[row] = i <= n ? outq[k[row]] : 0u;
+  }
+#pragma unroll
+  for (u32 row = 0; row < TOK_ROWS; row++) {
+    const u64 i = tile0 + u64(row) * TOK_THREADS + tid;
+    const bool is_string = i < n && ((bits[row] >> lane) & 1ull) != 0;
+    next[row] = is_string ? outq[k[row] + 1] : 0u;
+  }
+#pragma unroll
+  for (u32 row = 0; row < TOK_ROWS; row++) {
+    const u64 i = tile0 + u64(row) * TOK_THREADS + tid;
+    if (i > n) { continue; }
+    offsets[i] = at[row]; // CSR: a structural that is no string has an empty record where the next one begins
+    if (i < n && ((bits[row] >> lane) & 1ull)) { *reinterpret_cast<u32_any *>(out + at[row]) = next[row] - at[row] - 5u; }
+  }
 }
 
 } // namespace
@@ -460,17 +511,20 @@ void enqueue_string_stream(const uint8_t *buf, uint64_t len, const uint32_t *idx
   }
   hipLaunchKernelGGL(k_strs_resolve, dim3(1), dim3(RES_THREADS), 0, s, summ, nseg, base, ctrl);
   const bool own_ordinals = listed == nullptr; // else the caller has counted the string tokens (launch_tape_front) and finishes the records itself
+  const u32 tiles = u32((u64(n1) + TOK_TILE - 1) / TOK_TILE);
+  int *const count = w.kord;                                                                               // tiles + 1 ints
+  u64 *const qbits = reinterpret_cast<u64 *>(w.kord + ((size_t(tiles) + 1 + 63) & ~size_t(63)));           // 64 words per tile: n / 8 bytes (kord has 4 n)
   if (own_ordinals) {
-    hipLaunchKernelGGL(k_strs_tokens, dim3(u32((u64(n1) + TOK_THREADS - 1) / TOK_THREADS)), dim3(TOK_THREADS), 0, s, buf, len, idx, n, w.kord);
-    enqueue_scan(w.kord, n1, &ctrl->n1_scan, w.partial, s);
-    listed = w.kord + n;
+    hipLaunchKernelGGL(k_strs_tokens, dim3(tiles), dim3(TOK_THREADS), 0, s, buf, len, idx, n, qbits, count, tiles);
+    launch_scan_partials(count, tiles + 1, s);
+    listed = count + tiles;
   }
   hipLaunchKernelGGL(k_strs_decide, dim3(1), dim3(1), 0, s, ctrl, listed, n, out_cap, w.outq, res);
   if (nseg) {
     hipLaunchKernelGGL(k_strs_write, dim3((nseg + STRS_WAVES - 1) / STRS_WAVES), dim3(64 * STRS_WAVES), 0, s, buf, len, nseg, a, base, ctrl, out, w.outq);
   }
   if (own_ordinals) {
-    hipLaunchKernelGGL(k_strs_finalize, dim3(u32((u64(n1) + TOK_THREADS - 1) / TOK_THREADS)), dim3(TOK_THREADS), 0, s, w.kord, n, w.outq, ctrl, offsets, out);
+    hipLaunchKernelGGL(k_strs_finalize, dim3(tiles), dim3(TOK_THREADS), 0, s, qbits, count, n, w.outq, ctrl, offsets, out);
   }
 }
 

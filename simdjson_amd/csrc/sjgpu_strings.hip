@@ -485,7 +485,9 @@ strings_scratch carve_strings_scratch(void *base, uint32_t n, uint64_t len) {
   size_t at = 0;
   w.ctrl = b + at; at += 256;
   w.partial = reinterpret_cast<int *>(b + at); at += up256((size_t(n) / 4096 + 72) * 4);
-  w.kord = reinterpret_cast<int *>(b + at); at += up256((size_t(n) + 2) * 4);
+  // (the stream's token pass: one int per tile of 4096 structurals + one, padded to 64 ints, then 64 x 8 bytes per tile -- sjgpu_string_stream.hip)
+  const size_t tok_tiles = (size_t(n) + 1 + 4095) / 4096, tok_bytes = ((tok_tiles + 1 + 63) & ~size_t(63)) * 4 + tok_tiles * 512;
+  w.kord = reinterpret_cast<int *>(b + at); at += up256(tok_bytes > (size_t(n) + 2) * 4 ? tok_bytes : (size_t(n) + 2) * 4);
   w.outq = reinterpret_cast<uint32_t *>(b + at); at += up256((size_t(n) + 2) * 4);
   w.seg_summary = b + at; at += up256(nseg * STRS_SUMMARY_BYTES);
   w.seg_base = b + at; at += up256(nseg * STRS_BASE_BYTES);

@@ -128,6 +128,38 @@ int main(int argc, char **argv) {
                 (unsigned long long)key, int(len > 300 ? 300 : len), (const char *)doc);
         return 1;
       }
+      // ---- the string pass on its own (sjgpu_parse_strings_device: both roads enqueued, its own count of the string tokens, offsets per structural) ----
+      {
+        std::vector<uint8_t> sbuf2_store, ws2_store;
+        uint8_t *ws2 = static_cast<uint8_t *>(aligned(ws2_store, offs_at + (size_t(n) + 1) * 4 + 256, 0xA5));
+        uint8_t *sbuf2 = static_cast<uint8_t *>(aligned(sbuf2_store, str_cap, 0x5A));
+        strings_result_dev *sres2 = reinterpret_cast<strings_result_dev *>(ws2);
+        uint32_t *offsets2 = reinterpret_cast<uint32_t *>(ws2 + offs_at);
+        (void)launch_parse_strings(doc, len, idx, n, false, sbuf2, str_cap, offsets2, sres2, ws2 + scratch_at, nullptr);
+        const strings_result_dev h2 = *sres2;
+        std::vector<uint8_t> want_b(str_cap + 64);
+        std::vector<uint32_t> want_off(size_t(n) + 1);
+        uint64_t wb = 0;
+        uint32_t wstrings = 0, wbad = 0xFFFFFFFFu;
+        (void)sjo_string_buffer(padded.data(), len, idx, n, 0, want_b.data(), want_b.size(), want_off.data(), &wb, &wstrings, &wbad);
+        bool same = h2.first_bad == wbad;
+        if (wbad == 0xFFFFFFFFu) { // all strings valid: the whole buffer and every offset (CSR: a structural that is no string has the next record's)
+          same = same && h2.bytes == wb && h2.strings == wstrings && memcmp(sbuf2, want_b.data(), wb) == 0;
+          if (!same) { size_t k = 0; while (k < wb && sbuf2[k] == want_b[k]) { k++; } fprintf(stderr, "  (the buffer differs at byte %zu: %02x, the oracle %02x)\n", k, sbuf2[k], want_b[k]); }
+          uint32_t next = uint32_t(wb);
+          for (uint32_t i = n; same && i-- > 0;) {
+            if (want_off[i] != 0xFFFFFFFFu) { next = want_off[i]; }
+            same = offsets2[i] == next;
+            if (!same) { fprintf(stderr, "  (offsets[%u] = %u, the oracle %u)\n", i, offsets2[i], next); }
+          }
+          same = same && offsets2[n] == uint32_t(wb);
+        }
+        if (!same) {
+          fprintf(stderr, "MISMATCH: the string pass on its own (road %u): first bad %u (the oracle %u), %llu bytes (%llu), %u strings (%u) (document %lu, %u bytes): %.*s\n", h2.path,
+                  h2.first_bad, wbad, (unsigned long long)h2.bytes, (unsigned long long)wb, h2.strings, wstrings, docs, len, int(len > 300 ? 300 : len), (const char *)doc);
+          return 1;
+        }
+      }
       if (e_want == 0) {
         valid++;
         if (ht.tape_words != tw || memcmp(tape, want.data(), tw * 8) != 0) {
