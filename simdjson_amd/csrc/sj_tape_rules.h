@@ -238,6 +238,49 @@ SJ_HD u32 comma_fine_bits(u64 j, u32 c1, bool have1, u32 c2, bool have2) {
   const bool fine_a = a.k[0] == NO_ERROR_KEY && a.k[1] == NO_ERROR_KEY && a.k[2] == NO_ERROR_KEY;
   return (fine_o ? COMMA_FINE_IN_OBJECT : 0u) | (fine_a ? COMMA_FINE_IN_ARRAY : 0u);
 }
+// the same, spelled out (what k_tok_apply evaluates for every comma; tests/host/test_tape_rules.cpp: equal to comma_fine_bits on every combination)
+SJ_HD u32 comma_fine_bits_direct(u32 c1, bool have1, u32 c2, bool have2) {
+  if (!have1) { return COMMA_FINE_IN_OBJECT | COMMA_FINE_IN_ARRAY; }
+  const bool q1 = c1 == '"';
+  const bool fine_o = q1 && (!have2 || c2 == ':');
+  const bool fine_a = starts_value(c1, false) && c1 != ',' && !(q1 && have2 && !(c2 == ',' || is_close_char(c2)));
+  return (fine_o ? COMMA_FINE_IN_OBJECT : 0u) | (fine_a ? COMMA_FINE_IN_ARRAY : 0u);
+}
+// ---- a token's byte, looked up -------------------------------------------------------------------------------------------------------------
+// Everything k_tok_apply asks about a token's byte -- its contribution to the six counters, which list it goes to, what it is to the comma in front
+// of it -- as bits of ONE table entry (a workgroup builds the 256 entries in LDS from the predicates above, so they cannot drift apart; tests/host/
+// test_tape_rules.cpp compares every use on every byte).  Spelled out, the predicates cost a wave ~20 compares and as many scalar mask operations
+// per token; the kernel issued 2 200 instructions per 1024 tokens and was bound by them.  Not covered: the ROOT token (list index 0), whose number
+// path differs (takes_number_path) -- one token per document, handled by the caller with tok_contribution(c, true).
+enum : u32 { TP_SLOTS = 3u, TP_SORT = 4u, TP_STRING = 8u, TP_OPEN = 16u, TP_CLOSE = 32u, TP_NUMBER = 64u, TP_ATOM = 128u, TP_COMMA = 256u, TP_COLON = 512u,
+              TP_VALUE = 1024u /* starts_value(c, false) */, TP_COMMA_OR_CLOSE = 2048u, TP_KIND_SHIFT = 12u /* sort_kind of a bracket, 0 otherwise: 3 bits */ };
+SJ_HD u32 token_props_of(u32 c) {
+  const tok_packed p = tok_contribution(c, false);
+  const bool bracket = is_open_char(c) || is_close_char(c);
+  return (p.a & 3u) | ((p.a >> 16) ? TP_SORT : 0u) | ((p.b & 0xFFFFu) ? TP_STRING : 0u) | ((p.b >> 16) ? TP_OPEN : 0u) | ((p.c & 0xFFFFu) ? TP_CLOSE : 0u) |
+         ((p.c >> 16) ? TP_NUMBER : 0u) | ((c == 't' || c == 'f' || c == 'n') ? TP_ATOM : 0u) | (c == ',' ? TP_COMMA : 0u) | (c == ':' ? TP_COLON : 0u) |
+         (starts_value(c, false) ? TP_VALUE : 0u) | ((c == ',' || is_close_char(c)) ? TP_COMMA_OR_CLOSE : 0u) | ((bracket ? sort_kind(c, 0) : 0u) << TP_KIND_SHIFT);
+}
+SJ_HD tok_packed tok_contribution_of_props(u32 x) {
+  tok_packed p;
+  p.a = (x & TP_SLOTS) | ((x & TP_SORT) << 14);
+  p.b = ((x >> 3) & 1u) | ((x & TP_OPEN) << 12);
+  p.c = ((x >> 5) & 1u) | ((x & TP_NUMBER) << 10);
+  return p;
+}
+SJ_HD u32 value_list_of_props(u32 x) {
+  return (x & TP_NUMBER) ? u32(LIST_NUMBERS) : ((x & TP_STRING) ? u32(LIST_STRINGS) : (((x & TP_SLOTS) == 1u && !(x & TP_SORT)) ? u32(LIST_REST) : u32(LIST_NONE)));
+}
+SJ_HD u32 comma_fine_bits_of_props(u32 x1, bool have1, u32 x2, bool have2) {
+  if (!have1) { return COMMA_FINE_IN_OBJECT | COMMA_FINE_IN_ARRAY; }
+  const bool q1 = (x1 & TP_STRING) != 0u;
+  const bool fine_o = q1 && (!have2 || (x2 & TP_COLON) != 0u);
+  const bool fine_a = (x1 & TP_VALUE) != 0u && (x1 & TP_COMMA) == 0u && !(q1 && have2 && (x2 & TP_COMMA_OR_CLOSE) == 0u);
+  return (fine_o ? COMMA_FINE_IN_OBJECT : 0u) | (fine_a ? COMMA_FINE_IN_ARRAY : 0u);
+}
+// the sort key of a bracket or comma from its entry (level: clamped by the caller)
+SJ_HD u32 sort_key_of_props(u32 level, u32 x, u32 comma_bits) { return level | (((x & TP_COMMA) ? KIND_COMMA + comma_bits : (x >> TP_KIND_SHIFT) & 7u) << KIND_SHIFT); }
+
 // the list index of the token that writes the tape word at position p (a bracket: one word): tape positions do not decrease along the list and
 // tokens without a word (':' ',') share theirs with the token behind them, so it is the LAST index whose position is p.  tpos: n + 1 entries.
 template <class TPOS> SJ_HD u32 token_at_tape_position(const TPOS &tpos, u32 n, u32 p) {

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(1024) void k_tok_scan_sums(int *__restrict__ sums, 
 // and commas go straight into the sort's input with
 // their level: the depth in front of an opening bracket, the depth behind a closing one, and that of the container a comma separates
 // the members of -- clamped to [0, kmax] (beyond the nesting limit an error is already certain); *m_out = how many went in
-__global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__ tokc, u32 n, u32 kmax, u32 max_depth, const int *__restrict__ sums, u32 nblocks,
+__global__ __launch_bounds__(TS_THREADS, 4) void k_tok_apply(const u8 *__restrict__ tokc, u32 n, u32 kmax, u32 max_depth, const int *__restrict__ sums, u32 nblocks,
                                                          int *__restrict__ tpos, u64 *__restrict__ value_list, unsigned short *__restrict__ key, u32 *__restrict__ tok,
                                                          int *__restrict__ m_out, int *__restrict__ max_level, u64 *__restrict__ number_list,
                                                          const u32 *__restrict__ str_offsets, strings_handoff strs, u8 *__restrict__ string_buf, u64 *__restrict__ tape,
@@ -225,6 +225,10 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
   // the spelling of true / false / null) are gone.
   const bool stream_strings = strs.go_stream != nullptr && *strs.go_stream != 0; // uniform
   __shared__ u32 sh[3][TS_THREADS / 64];
+  __shared__ unsigned short sh_props[256]; // what a token's byte IS, as bits (token_props_of, sj_tape_rules.h): one LDS read instead of ~20 compares per token
+  static_assert(TS_THREADS == 256, "one table entry per thread");
+  sh_props[threadIdx.x] = (unsigned short)token_props_of(threadIdx.x);
+  __syncthreads();
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u64 block0 = u64(blockIdx.x) * TS_BLOCK;
   const int slots0 = sums[0 * nblocks + blockIdx.x], sel0 = sums[1 * nblocks + blockIdx.x], strs0 = sums[2 * nblocks + blockIdx.x];
@@ -233,6 +237,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
   const int rest0 = one_word_rest(slots0, strs0, numbers0, opens0, closes0); // one-word tokens that are neither strings nor brackets
   u32 ra = 0, rb = 0, rc = 0; // what the rows in front of this one hold (packed)
   int top = 0;                // highest level this thread sent into the sort
+  u32 err_index = 0, err_low = 0; // this thread's first error: list index, rank << 4 | code (0 = none)
 #pragma unroll 1
   for (u32 row = 0; row < TS_ROWS; row++) {
     const u64 i0 = block0 + u64(row) * TS_ROW + 4u * tid;
@@ -241,13 +246,18 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
     typedef unsigned short __attribute__((aligned(1))) u16_unaligned_t;
     if (i0 < n) { four = four_tokens(tokc, i0); behind2 = *reinterpret_cast<const u16_unaligned_t *>(tokc + 2 + i0 + 4); } // (tokc has room for n + 9 bytes;
     // what lies behind token n - 1 is only looked at where it is zeros)
-    const u32 six_lo = four, six_hi = behind2; // tokens i0 ... i0 + 5, byte by byte
+    u32 x[6]; // the table entries of tokens i0 ... i0 + 5 (what lies at or behind n: zero -- no token)
+#pragma unroll
+    for (u32 q = 0; q < 6; q++) {
+      const u32 c = q < 4 ? (four >> (8u * q)) & 0xFFu : (behind2 >> (8u * (q - 4))) & 0xFFu;
+      x[q] = i0 + q < n ? u32(sh_props[c]) : 0u;
+    }
     tok_packed p[4];
     u32 ta = 0, tb = 0, tc = 0;
 #pragma unroll
     for (u32 j = 0; j < 4; j++) {
-      p[j] = tok_packed{0u, 0u, 0u};
-      if (i0 + j < n) { p[j] = tok_contribution((four >> (8u * j)) & 0xFFu, i0 + j == 0); }
+      p[j] = tok_contribution_of_props(x[j]);
+      if (i0 + j == 0 && n != 0) { p[j] = tok_contribution(four & 0xFFu, true); } // the root token: its number path differs (one token per document)
       ta += p[j].a; tb += p[j].b; tc += p[j].c;
     }
     const u32 ia = wave_incl_scan(ta), ib = wave_incl_scan(tb), ic = wave_incl_scan(tc);
@@ -278,49 +288,45 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
       u32 sk = 0; // strings of this thread so far
 #pragma unroll
       for (u32 j = 0; j < 4; j++) {
+        // (written for few branches: a wave of 64 x 4 consecutive tokens holds every kind of token, so every branch is taken by somebody and costs its
+        // mask bookkeeping for all -- 1 280 scalar and 940 vector instructions per row before, profiles/r04_tape_kernel_stats.txt; stores of the same
+        // width share one site with a selected address, errors are kept in two registers and reported once)
         const u64 i = i0 + j;
+        const bool live = i < n;
+        const u32 ch = (four >> (8u * j)) & 0xFFu, c1 = j < 3 ? (four >> (8u * (j + 1))) & 0xFFu : behind2 & 0xFFu;
         const int d = depth0 + int(eb >> 16) - int(ec & 0xFFFFu);
         tp[j] = slots0 + int(ea & 0xFFFFu);
         {
-          const u32 ch = (four >> (8u * j)) & 0xFFu, next = j < 3 ? (six_lo >> (8u * (j + 1))) & 0xFFu : six_hi & 0xFFu;
           u32 rank = 0;
-          const u32 g = i < n ? depth_rule(i == 0, ch, i + 1 < n ? next : 0u, d, max_depth, &rank) : 0u;
-          if (g) { report_error(res, error_key(i, rank, g)); }
-          if (i == n && d != 0) { report_error(res, error_key(n, 0, SJ_TAPE_ERROR)); } // the walk meets the sentinel inside a container
+          u32 g = live ? depth_rule(i == 0, ch, i + 1 < n ? c1 : 0u, d, max_depth, &rank) : 0u;
+          if (i == n && d != 0) { g = SJ_TAPE_ERROR; rank = 0; } // the walk meets the sentinel inside a container
+          if (g != 0u && err_low == 0u) { err_index = u32(i); err_low = (rank << 4) | g; } // (a thread meets its tokens in list order: its first error is its smallest key)
         }
         const int strings_before = strs0 + int(eb & 0xFFFFu), numbers_before = numbers0 + int(ec >> 16);
         const int rest_before = rest0 + one_word_rest(int(ea & 0xFFFFu), int(eb & 0xFFFFu), int(ec >> 16), int(eb >> 16), int(ec & 0xFFFFu));
         const int slot = sel0 + int(ea >> 16);
         if (i == n) { *m_out = slot; m_out[2] = numbers_before; m_out[3] = slot + 1; m_out[4] = strings_before; m_out[5] = rest_before; }
-        if (i < n) {
-          const u64 entry = list_entry(u32(tp[j]), u32(i)); // a list entry carries the token's tape position: the value kernels need no gather for it
-          const u32 list = value_list_of(p[j]);
-          const u64 at = u64(u32(tp[j])) + 1u;
-          if (list == LIST_NUMBERS) { number_list[numbers_before] = entry; }               // k_tape_numbers
-          else if (list == LIST_STRINGS) {
-            // (sk is a compile-time-bounded counter: selects, not indexed registers)
-            const u32 begin = sk == 0 ? oq[0] : (sk == 1 ? oq[1] : (sk == 2 ? oq[2] : oq[3]));
-            const u32 next = sk == 0 ? oq[1] : (sk == 1 ? oq[2] : (sk == 2 ? oq[3] : oq[4]));
-            u32 payload = begin;
-            if (stream_strings) { *reinterpret_cast<u32_unaligned_t *>(string_buf + payload) = next - payload - 5u; }
-            else { payload = so[j]; }
-            if (at < tape_cap) { tape[at] = tape_word32('"', payload); }
-            sk++;
-          } else if (list == LIST_REST) {
-            value_list[n - u32(rest_before)] = entry;                                       // k_tape_atoms: the spelling
-            const u32 ch = (four >> (8u * j)) & 0xFFu;
-            if ((ch == 't' || ch == 'f' || ch == 'n') && at < tape_cap) { tape[at] = tape_word32(ch, 0); } // visit_true_atom ..., tape_builder.h:278-329
-          }
+        const u32 list = value_list_of(p[j]); // (of the packed contribution, not of the table entry: the root token's differs)
+        const bool is_number = list == LIST_NUMBERS, is_string = list == LIST_STRINGS, is_rest = list == LIST_REST;
+        const u64 at = u64(u32(tp[j])) + 1u;
+        if (is_number || is_rest) { // a list entry carries the token's tape position: the value kernels need no gather for it
+          u64 *const dst = is_number ? number_list + numbers_before : value_list + (n - u32(rest_before)); // k_tape_numbers / k_tape_atoms (the spelling)
+          *dst = list_entry(u32(tp[j]), u32(i));
         }
-        if (i < n && (p[j].a >> 16)) {
+        // (sk is a compile-time-bounded counter: selects, not indexed registers)
+        const u32 begin = sk == 0 ? oq[0] : (sk == 1 ? oq[1] : (sk == 2 ? oq[2] : oq[3]));
+        const u32 next = sk == 0 ? oq[1] : (sk == 1 ? oq[2] : (sk == 2 ? oq[3] : oq[4]));
+        if (is_string && stream_strings) { *reinterpret_cast<u32_unaligned_t *>(string_buf + begin) = next - begin - 5u; }
+        const bool is_atom = is_rest && (x[j] & TP_ATOM) != 0u; // visit_true_atom ..., tape_builder.h:278-329
+        if ((is_string || is_atom) && at < tape_cap) { tape[at] = is_string ? tape_word32('"', stream_strings ? begin : so[j]) : tape_word32(ch, 0); }
+        sk += is_string ? 1u : 0u;
+        if (live && (p[j].a >> 16)) {
           int k = (p[j].b >> 16) ? d : d - 1;
           k = k < 0 ? 0 : (k > int(kmax) ? int(kmax) : k);
           // a bracket travels with its tape position, a comma with its list index and with what it knows about its two followers (sj_tape_rules.h)
-          const u32 ch = (four >> (8u * j)) & 0xFFu;
-          const bool comma = ch == ',';
-          const u32 c1 = j < 3 ? (six_lo >> (8u * (j + 1))) & 0xFFu : six_hi & 0xFFu, c2 = j < 2 ? (six_lo >> (8u * (j + 2))) & 0xFFu : (six_hi >> (8u * (j - 2))) & 0xFFu;
-          const u32 fine = comma ? comma_fine_bits(i, c1, i + 1 < n, c2, i + 2 < n) : 0u;
-          key[slot] = (unsigned short)sort_key(u32(k), ch, fine);
+          const bool comma = (x[j] & TP_COMMA) != 0u;
+          const u32 fine = comma_fine_bits_of_props(x[j + 1], i + 1 < n, x[j + 2], i + 2 < n);
+          key[slot] = (unsigned short)sort_key_of_props(u32(k), x[j], fine);
           tok[slot] = comma ? u32(i) : u32(tp[j]);
           top = k > top ? k : top;
         }
@@ -333,6 +339,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_apply(const u8 *__restrict__
       }
     }
   }
+  if (err_low != 0u) { report_error(res, (u64(err_index) << 8) | err_low); }
   // one atomic per wave, and only from waves that raise the mark (it decides whether the sort needs its second pass)
   const u32 wave_top = wave_max(u32(top));
   if (lane == 0 && int(wave_top) > __hip_atomic_load(max_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { atomicMax(max_level, int(wave_top)); }

@@ -75,6 +75,40 @@ int main() {
       }
     }
   }
+  for (u32 c1 = 0; c1 < 256; c1++) {
+    for (u32 c2 = 0; c2 < 256; c2++) {
+      for (int have = 0; have < 4; have++) {
+        const bool have1 = (have & 1) != 0, have2 = have1 && (have & 2) != 0; // (a second follower without a first does not occur)
+        if (comma_fine_bits(5, c1, have1, c2, have2) != comma_fine_bits_direct(c1, have1, c2, have2)) {
+          fprintf(stderr, "comma_fine_bits: followers %02x %02x (%d %d): derived %u, direct %u\n", c1, c2, have1, have2, comma_fine_bits(5, c1, have1, c2, have2),
+                  comma_fine_bits_direct(c1, have1, c2, have2));
+          return 1;
+        }
+        checked++;
+      }
+    }
+  }
+  for (u32 c = 0; c < 256; c++) { // the table form of what k_tok_apply asks about a byte
+    const u32 x = token_props_of(c);
+    const tok_packed p = tok_contribution(c, false), q = tok_contribution_of_props(x);
+    const bool same = p.a == q.a && p.b == q.b && p.c == q.c && value_list_of(p) == value_list_of_props(x) && ((x & TP_OPEN) != 0u) == is_open_char(c) &&
+                      ((x & TP_ATOM) != 0u) == (c == 't' || c == 'f' || c == 'n') && ((x & TP_COMMA) != 0u) == (c == ',');
+    bool keys = true;
+    for (u32 level : {0u, 5u, 4095u}) {
+      for (u32 fine = 0; fine < 4; fine++) { if ((p.a >> 16) && sort_key(level, c, c == ',' ? fine : 0u) != sort_key_of_props(level, x, c == ',' ? fine : 0u)) { keys = false; } }
+    }
+    if (!same || !keys) { fprintf(stderr, "byte %02x: the table entry %x disagrees with the predicates\n", c, x); return 1; }
+    for (u32 c2 = 0; c2 < 256; c2++) {
+      for (int have = 0; have < 4; have++) {
+        const bool have1 = (have & 1) != 0, have2 = have1 && (have & 2) != 0;
+        if (comma_fine_bits_direct(c, have1, c2, have2) != comma_fine_bits_of_props(x, have1, token_props_of(c2), have2)) {
+          fprintf(stderr, "comma_fine_bits from table entries: followers %02x %02x (%d %d) disagree\n", c, c2, have1, have2);
+          return 1;
+        }
+        checked++;
+      }
+    }
+  }
   printf("%lu combinations agree\n", checked);
   return 0;
 }
