@@ -37,6 +37,7 @@ namespace {
 
 constexpr u32 TP_THREADS = 256;
 constexpr u32 RADIX_BITS = 6, RADIX_BINS = 1u << RADIX_BITS, RADIX_TILE = 2048; // one wave sorts one tile
+constexpr u32 RADIX_STEPS = RADIX_TILE / 64, RADIX_DEAD = 0xFFFFFFFFu; // (keys have 16 bits)
 static_assert(RADIX_BINS == TAPE_ONE_PASS_LEVELS, "sjgpu_stage2_device decides from max_level whether the second pass is needed");
 
 struct dev_bytes {
@@ -77,19 +78,22 @@ struct wide_window_bytes {
   mutable u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
   mutable u32 at = 0xFFFFFF00u;
   typedef u64 __attribute__((aligned(1))) u64_unaligned;
+  __device__ __forceinline__ void fill(u32 pos) const { // request the 32 bytes from pos on (nothing waits for them here)
+    at = pos;
+    if (u64(pos) + 32u <= len) {
+      const u64_unaligned *p = reinterpret_cast<const u64_unaligned *>(buf + pos);
+      w0 = p[0]; w1 = p[1]; w2 = p[2]; w3 = p[3];
+    } else {
+      u64 w[4] = {0, 0, 0, 0};
+      for (u32 k = 0; k < 32; k++) { w[k >> 3] |= u64(pos + k < len ? u32(buf[pos + k]) : 0x20u) << (8u * (k & 7u)); }
+      w0 = w[0]; w1 = w[1]; w2 = w[2]; w3 = w[3];
+    }
+  }
   __device__ __forceinline__ u32 byte(u32 pos) const {
     u32 d = pos - at;
     if (d >= 32u) {
-      at = pos;
+      fill(pos);
       d = 0;
-      if (u64(pos) + 32u <= len) {
-        const u64_unaligned *p = reinterpret_cast<const u64_unaligned *>(buf + pos);
-        w0 = p[0]; w1 = p[1]; w2 = p[2]; w3 = p[3];
-      } else {
-        u64 w[4] = {0, 0, 0, 0};
-        for (u32 k = 0; k < 32; k++) { w[k >> 3] |= u64(pos + k < len ? u32(buf[pos + k]) : 0x20u) << (8u * (k & 7u)); }
-        w0 = w[0]; w1 = w[1]; w2 = w[2]; w3 = w[3];
-      }
     }
     const u64 lo = d < 8u ? w0 : w1, hi = d < 24u ? w2 : w3;
     return u32((d < 16u ? lo : hi) >> (8u * (d & 7u))) & 0xFFu;
@@ -365,10 +369,17 @@ __global__ __launch_bounds__(64) void k_radix_hist(const unsigned short *__restr
   cnt[1][lane] = 0;
   wave_lds_fence();
   const u32 base = tile * RADIX_TILE;
-  for (u32 r = 0; r < RADIX_TILE; r += 64) {
-    const u32 j = base + r + lane;
-    if (j < m) {
-      const u32 k = key[j];
+  // the tile's keys are requested at once (a wave per tile and a load per step made 32 dependent round trips: there are fewer tiles than the chip holds waves)
+  u32 kk[RADIX_STEPS];
+#pragma unroll
+  for (u32 q = 0; q < RADIX_STEPS; q++) {
+    const u32 j = base + q * 64u + lane;
+    kk[q] = j < m ? u32(key[j]) : RADIX_DEAD;
+  }
+#pragma unroll
+  for (u32 q = 0; q < RADIX_STEPS; q++) {
+    const u32 k = kk[q];
+    if (k != RADIX_DEAD) {
       const u32 d = (k >> shift) & (RADIX_BINS - 1);
       atomicAdd(&cnt[0][d], 1u);
       if (kind_is_open(k >> KIND_SHIFT)) { atomicAdd(&cnt[1][d], 1u); }
@@ -390,10 +401,18 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const unsigned short *__re
   onext[lane] = u32(hist[(RADIX_BINS + lane) * tiles + tile]) - m;
   wave_lds_fence();
   const u32 base = tile * RADIX_TILE;
-  for (u32 r = 0; r < RADIX_TILE; r += 64) { // 64 consecutive elements per step, in order: the sort is stable
-    const u32 j = base + r + lane;
-    const bool live = j < m;
-    const u32 k = live ? u32(key_in[j]) : 0u;
+  // keys and payloads of the whole tile are requested at once (see k_radix_hist), then the 32 steps run out of registers
+  u32 kk[RADIX_STEPS], tt[RADIX_STEPS];
+#pragma unroll
+  for (u32 q = 0; q < RADIX_STEPS; q++) {
+    const u32 j = base + q * 64u + lane;
+    kk[q] = j < m ? u32(key_in[j]) : RADIX_DEAD;
+    tt[q] = j < m ? tok_in[j] : 0u;
+  }
+#pragma unroll
+  for (u32 q = 0; q < RADIX_STEPS; q++) { // 64 consecutive elements per step, in order: the sort is stable
+    const bool live = kk[q] != RADIX_DEAD;
+    const u32 k = live ? kk[q] : 0u;
     const u32 d = (k >> shift) & (RADIX_BINS - 1);
     u64 peers = __ballot(live); // lanes with my digit
 #pragma unroll
@@ -407,7 +426,7 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const unsigned short *__re
     if (live) {
       const u32 at = next[d] + rank;
       key_out[at] = (unsigned short)k;
-      tok_out[at] = tok_in[j];
+      tok_out[at] = tt[q];
       // (valid in the order of the LAST pass that runs; an earlier pass's values are overwritten by it)
       const u32 ob = onext[d] + u32(popc64(open_peers & lanemask_lt(lane))); // opening brackets in front of the element
       opens_before[at] = int(ob);
@@ -576,25 +595,33 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_atoms(const u8 *__restrict_
 }
 
 // the number tokens k_tok_apply listed, one per lane: visit_number (tape_builder.h:213-275) = parse_number (numberparsing.h:859-971, sj_number.h)
+__device__ __forceinline__ void number_token(const wide_window_bytes &src, u32 pos, u64 entry, u64 *__restrict__ tape, u64 tape_cap, u32 *__restrict__ slow_list, u32 slow_cap,
+                                             tape_result_dev *__restrict__ res) {
+  const u32 i = u32(entry);
+  const number_value v = parse_number_token(src, pos, static_cast<bigint *>(nullptr));
+  if (v.error) { report_error(res, error_key(i, 2, v.error)); return; }
+  const u64 at = (entry >> 32) + 1u;
+  if (at + 1 < tape_cap) {
+    tape[at] = tape_word(v.type, 0);
+    tape[at + 1] = v.bits; // sign only when v.slow: k_tape_slow_numbers completes it
+    if (v.slow) {
+      const u32 s = atomicAdd(&res->slow_numbers, 1u);
+      if (s < slow_cap) { slow_list[s] = i; }
+    }
+  }
+}
+// One listed token per lane.  (Two per thread and trip, the fetches of both issued before either is parsed, changed nothing -- 140 -> 148 us: what the
+// kernel waits for is not the latency of a chain a second token could hide; profiles/r04_tape_kernel_stats.txt.)
 __global__ __launch_bounds__(TP_THREADS) void k_tape_numbers(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx,
                                                             const u64 *__restrict__ number_list, const int *__restrict__ count_ptr, u64 *__restrict__ tape, u64 tape_cap,
                                                             u32 *__restrict__ slow_list, u32 slow_cap, tape_result_dev *__restrict__ res) {
   const u32 count = u32(*count_ptr);
   for (u64 k = u64(blockIdx.x) * TP_THREADS + threadIdx.x; k < count; k += u64(gridDim.x) * TP_THREADS) {
     const u64 entry = number_list[k];
-    const u32 i = u32(entry);
+    const u32 pos = idx[u32(entry)];
     const wide_window_bytes src{buf, u32(len)};
-    const number_value v = parse_number_token(src, idx[i], static_cast<bigint *>(nullptr));
-    if (v.error) { report_error(res, error_key(i, 2, v.error)); continue; }
-    const u64 at = (entry >> 32) + 1u;
-    if (at + 1 < tape_cap) {
-      tape[at] = tape_word(v.type, 0);
-      tape[at + 1] = v.bits; // sign only when v.slow: k_tape_slow_numbers completes it
-      if (v.slow) {
-        const u32 s = atomicAdd(&res->slow_numbers, 1u);
-        if (s < slow_cap) { slow_list[s] = i; }
-      }
-    }
+    src.fill(pos);
+    number_token(src, pos, entry, tape, tape_cap, slow_list, slow_cap, res);
   }
 }
 
