@@ -328,7 +328,10 @@ constexpr size_t AUTO_FUSED_BELOW = size_t(8) << 20;
 // (round 4, profiles/r04_pipeline_sweep.txt: with the table launch gone and the emission's shorter chains the split pipeline is the faster one
 // on dense output up to 512 MiB -- 287 against 296 us there, 165 against 175 at 256 MiB -- and the single-pass kernel from 768 MiB on: 408
 // against 422 us, 521 against 556 at 1 GiB; its fixed cost, one iteration to fill and one to drain, is ~35 us.  Was 192 MiB.)
-constexpr size_t AUTO_FUSED_FROM = size_t(640) << 20;
+// (round 4, later: the pipelined kernel with EIGHT waves per workgroup and 128 KiB tiles -- half the per-tile costs per byte -- wins on dense output from
+// 256 MiB on: 155 against 162 us there, 268 against 288 at 512 MiB, 479 against 557 at 1 GiB; at 160 MiB the split pipeline still leads, 103 against 110.
+// On sparse output the split pipeline stays ahead up to 512 MiB and level at 1 GiB.  The rows in profiles/r04_pipeline_sweep.txt.)
+constexpr size_t AUTO_FUSED_FROM = size_t(224) << 20;
 constexpr size_t AUTO_FUSED_FROM_MINIFY = size_t(192) << 20;
 constexpr size_t DIRECT_HOST_MAX = size_t(2) << 20; // sjgpu_stage1 on host buffers: up to here the kernels write the offsets into host memory themselves
 constexpr uint32_t AUTO_DENSE_PERMILLE = 200;

@@ -445,8 +445,10 @@ __device__ __forceinline__ void phase_prio(u32 policy, u32 phase /* 0 scan, 1 lo
 }
 // PWC: chunks per wave and tile: 4 (64 KiB tiles) or 2 (32 KiB tiles: half the fixed cost of filling and draining the pipeline -- one iteration
 // each --, twice the descriptors, look-backs and barriers per byte; A/B: env SJGPU_PIPE_WC)
-template <int OP, bool TRACE = false, u32 PWC = FUSED_WAVE_CHUNKS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fused_pipelined(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc,
+// NW: waves per workgroup: 4, or 8 (128 KiB tiles at the same wave count per CU: half the tickets, look-backs and descriptors per byte, two workgroups per
+// CU instead of four to hide them behind; A/B: env SJGPU_PIPE_WAVES)
+template <int OP, bool TRACE = false, u32 PWC = FUSED_WAVE_CHUNKS, u32 NW = FUSED_WAVES>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fused_pipelined(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc,
                                                          u32 *__restrict__ ticket, u32 ntiles, void *__restrict__ out,
                                                          u64 out_words, scan_result_dev *__restrict__ result, scan_origin org,
                                                          u64 *__restrict__ trace = nullptr) {
@@ -454,17 +456,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const u32 carry = org.carry;
   constexpr u32 WC = PWC;
   static_assert(WC == 2 || WC == 4, "the mask FIFO is written for 2 or 4 chunks per wave");
-  constexpr u32 TILE_BYTES = FUSED_WAVES * WC * CHUNK_BYTES;
+  constexpr u32 TILE_BYTES = NW * WC * CHUNK_BYTES;
   constexpr u32 STAGE_WORDS = (OP == 0) ? emit_stage_words(PIPE_WINDOW) : (MINIFY_STAGE_BYTES / 4);
   constexpr u32 WAVE_BYTES = WC * CHUNK_BYTES;
   __shared__ u32 sh_tile[2];                 // [iteration parity]: the ticket of an iteration is drawn one iteration ahead
-  __shared__ u32 sh_wave[2][FUSED_WAVES][5]; // [iteration parity][wave]: parity, count_if_out, count_if_in, flags, x word (sj_xcarry.h)
+  __shared__ u32 sh_wave[2][NW][5]; // [iteration parity][wave]: parity, count_if_out, count_if_in, flags, x word (sj_xcarry.h)
   __shared__ u32 sh_agg[2][4];               // tile aggregate of the same two tiles (tq, tout, tin, x word)
   __shared__ u32 sh_prefix[4];               // S, B, ok, X of the tile being emitted
-  __shared__ u64 sh_mask_a[FUSED_WAVES][WC][64], sh_mask_b[FUSED_WAVES][WC][64]; // the pending tile's masks
-  __shared__ __attribute__((aligned(16))) u32 sh_stage[FUSED_WAVES][STAGE_WORDS];
+  __shared__ u64 sh_mask_a[NW][WC][64], sh_mask_b[NW][WC][64]; // the pending tile's masks
+  __shared__ __attribute__((aligned(16))) u32 sh_stage[NW][STAGE_WORDS];
   __shared__ u32 sh_lut[MINIFY_LUT_WORDS];
-  __shared__ u32 sh_uq[(OP == 0) ? FUSED_WAVES : 1][(OP == 0) ? 64 : 1]; // left-over UTF-8 list entries between tiles
+  __shared__ u32 sh_uq[(OP == 0) ? NW : 1][(OP == 0) ? 64 : 1]; // left-over UTF-8 list entries between tiles
 
   const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   if (OP == 1) {
@@ -577,7 +579,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (wave == 0) {
       phase_prio(prio_policy, 1);
       if (have) {
-        const tile_agg ta = tile_aggregate<FUSED_WAVES>(sh_wave[cur]);
+        const tile_agg ta = tile_aggregate<NW>(sh_wave[cur]);
         if (lane == 0) {
           desc_store(desc + tile, make_agg(ta.q, ta.c_out, ta.c_in, ta.xw));
           sh_agg[cur][0] = ta.q;
@@ -941,7 +943,13 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
   } else {
     static const bool onchip = []() { const char *v = std::getenv("SJGPU_MINIFY_ONCHIP"); return !v || v[0] != '0'; }(); // A/B: 0 = the re-reading kernel
     const u32 onchip_waves = (op == 1 && onchip) ? 4u : 0u; // (an 8-wave / 64 KiB-tile variant measured slower in round 2 and spilled: gone)
-    const u64 tile_bytes = onchip_waves ? u64(onchip_waves) * ONCHIP_WAVE_CHUNKS * CHUNK_BYTES : u64(FUSED_TILE_BYTES);
+    // Stage 1: EIGHT waves per workgroup, 128 KiB tiles (round 4).  What a tile pays whatever its size -- a ticket, a look-back, a descriptor, three
+    // barriers -- is served at ~17 ns per tile device-wide (scripts/micro/gather_lab.hip: a kernel of 16 384 trivial tiles takes 290 us with them, 130 us
+    // without), a third of a 64 KiB tile's time at 4.5 TB/s; twice the tile at the same number of waves per CU halves it: 520 -> 466-478 us per GiB of
+    // large_random, 173 -> 153-157 us per 256 MiB (profiles/r04_pipe_waves_ab.txt; SJGPU_PIPE_WAVES=4 brings the round-1 shape back).
+    static const unsigned pipe_waves = []() { const char *v = std::getenv("SJGPU_PIPE_WAVES"); return v && std::atoi(v) == 4 ? 4u : 8u; }();
+    const u32 s1_waves = (op == 0 && !trace) ? pipe_waves : FUSED_WAVES;
+    const u64 tile_bytes = onchip_waves ? u64(onchip_waves) * ONCHIP_WAVE_CHUNKS * CHUNK_BYTES : u64(s1_waves) * FUSED_WAVE_CHUNKS * CHUNK_BYTES;
     const u32 ntiles = u32((len - org.begin + tile_bytes - 1) / tile_bytes);
     u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles);
     // result, descriptors and ticket lie back to back (sjgpu_capi.hip): one clear
@@ -987,6 +995,15 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
       mark(ev, 2, stream);
       mark(ev, 3, stream);
       return "k_fused_pipelined<0> (32 KiB tiles)";
+    }
+    if (op == 0 && s1_waves == 8u) {
+      const u32 resident8 = max_workgroups / 2u; // two workgroups of eight waves per CU
+      hipLaunchKernelGGL((k_fused_pipelined<0, false, FUSED_WAVE_CHUNKS, 8>), dim3(cap < resident8 ? cap : resident8), dim3(512), 0, stream, buf, len, desc, ticket, ntiles, out,
+                         out_words, result, org);
+      mark(ev, 1, stream);
+      mark(ev, 2, stream);
+      mark(ev, 3, stream);
+      return "k_fused_pipelined<0> (8 waves, 128 KiB tiles)";
     }
     if (op == 0) {
       hipLaunchKernelGGL((k_fused_pipelined<0>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words, result, org);
