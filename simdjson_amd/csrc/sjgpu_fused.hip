@@ -942,7 +942,11 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
     return op == 0 ? "k_fused<0> (64 KiB tiles)" : "k_fused<1> (64 KiB tiles)";
   } else {
     static const bool onchip = []() { const char *v = std::getenv("SJGPU_MINIFY_ONCHIP"); return !v || v[0] != '0'; }(); // A/B: 0 = the re-reading kernel
-    const u32 onchip_waves = (op == 1 && onchip) ? 4u : 0u; // (an 8-wave / 64 KiB-tile variant measured slower in round 2 and spilled: gone)
+    // minify: EIGHT waves per workgroup, 64 KiB tiles, two workgroups per CU (round 4; same reasoning and same measurement as for stage 1 below: what a tile
+    // pays whatever its size, per byte, halves -- 543 -> 489 us per GiB of large_random, 168 -> 145 us per 256 MiB; sixteen waves, one workgroup per CU with
+    // nobody to hide its look-back behind, are back at 540: profiles/r04_pipe_waves_ab.txt.  Round 2 had measured the 8-wave variant slower: it spilled then.)
+    static const unsigned minify_waves = []() { const char *v = std::getenv("SJGPU_MINIFY_WAVES"); const int w = v ? std::atoi(v) : 8; return (w == 4 || w == 16) ? unsigned(w) : 8u; }(); // A/B
+    const u32 onchip_waves = (op == 1 && onchip) ? minify_waves : 0u;
     // Stage 1: EIGHT waves per workgroup, 128 KiB tiles (round 4).  What a tile pays whatever its size -- a ticket, a look-back, a descriptor, three
     // barriers -- is served at ~17 ns per tile device-wide (scripts/micro/gather_lab.hip: a kernel of 16 384 trivial tiles takes 290 us with them, 130 us
     // without), a third of a 64 KiB tile's time at 4.5 TB/s; twice the tile at the same number of waves per CU halves it: 520 -> 466-478 us per GiB of
@@ -974,13 +978,19 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
     static const bool queue_only = std::getenv("SJGPU_UTF8_QUEUE_ONLY") != nullptr; // A/B switch
     if (queue_only) { org.carry |= CARRY_DEBUG_QUEUE_UTF8; }
     if (onchip_waves) {
-      const u32 resident = max_workgroups / 2u; // max_workgroups = 8 per CU
+      const u32 resident = max_workgroups / (onchip_waves / 2u); // max_workgroups = 8 per CU; 33 KiB of LDS per four waves: sixteen waves per CU
       const u32 g = cap < resident ? cap : resident;
-      hipLaunchKernelGGL((k_minify_onchip<4>), dim3(g), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, static_cast<u8 *>(out), result, org);
+      if (onchip_waves == 8u) {
+        hipLaunchKernelGGL((k_minify_onchip<8>), dim3(g), dim3(512), 0, stream, buf, len, desc, ticket, ntiles, static_cast<u8 *>(out), result, org);
+      } else if (onchip_waves == 16u) {
+        hipLaunchKernelGGL((k_minify_onchip<16>), dim3(g), dim3(1024), 0, stream, buf, len, desc, ticket, ntiles, static_cast<u8 *>(out), result, org);
+      } else {
+        hipLaunchKernelGGL((k_minify_onchip<4>), dim3(g), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, static_cast<u8 *>(out), result, org);
+      }
       mark(ev, 1, stream);
       mark(ev, 2, stream);
       mark(ev, 3, stream);
-      return "k_minify_onchip<4>";
+      return onchip_waves == 8u ? "k_minify_onchip<8>" : (onchip_waves == 16u ? "k_minify_onchip<16>" : "k_minify_onchip<4>");
     }
     static const unsigned pipe_wc = []() { const char *v = std::getenv("SJGPU_PIPE_WC"); return v ? unsigned(std::atoi(v)) : 4u; }(); // A/B switch: 2 = 32 KiB tiles
     if (op == 0 && pipe_wc == 2u) {
