@@ -289,7 +289,7 @@ def leg_parse_strings(cx):
     leg = {"workload": f"twitter_like {L} B, {n} structurals, {strings} strings -> {used} B of [u32 length][bytes][0] records (document::string_buf of the reference)",
            "gpu_ms_per_call": round(gpu_ms, 3), "value": round(L / gpu_ms / 1e6, 1), "unit": "GB/s of document",
            "string_bytes_GBps": round(used / gpu_ms / 1e6, 1),
-           "kernel": ("k_strs_count + k_strs_resolve + k_strs_tokens + scan + k_strs_write + k_strs_finalize (stream compaction of the document, sjgpu_string_stream.hip)"
+           "kernel": ("k_strs_count + k_strs_resolve + k_strs_tokens (one bit per token, a count per tile) + k_scan_partials + k_strs_write + k_strs_finalize (stream compaction of the document, sjgpu_string_stream.hip)"
                       if p.string_path() == 1 else "k_strings<false> + scan + k_strings<true> (per-string walk)"),
            "roofline": {"bound": "hbm", "achieved": round((L + 4 * (n + 1) + used + 4 * (n + 1)) / gpu_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round((L + 4 * (n + 1) + used + 4 * (n + 1)) / gpu_ms / 1e6 / HBM_PEAK_GBS, 4),

@@ -332,6 +332,9 @@ constexpr size_t AUTO_FUSED_BELOW = size_t(8) << 20;
 // 256 MiB on: 155 against 162 us there, 268 against 288 at 512 MiB, 479 against 557 at 1 GiB; at 160 MiB the split pipeline still leads, 103 against 110.
 // On sparse output the split pipeline stays ahead up to 512 MiB and level at 1 GiB.  The rows in profiles/r04_pipeline_sweep.txt.)
 constexpr size_t AUTO_FUSED_FROM = size_t(224) << 20;
+// sparse output (twitter-like 0.12 offsets per byte, NDJSON 0.06): the split pipeline leads up to 512 MiB (185 against 207 us on NDJSON), the eight-wave
+// single-pass kernel at 1 GiB (357 against 370 us, profiles/r04_pipe_waves_ab.txt): its fixed cost of filling and draining the pipeline is paid once
+constexpr size_t AUTO_FUSED_FROM_SPARSE = size_t(896) << 20;
 constexpr size_t AUTO_FUSED_FROM_MINIFY = size_t(192) << 20;
 constexpr size_t DIRECT_HOST_MAX = size_t(2) << 20; // sjgpu_stage1 on host buffers: up to here the kernels write the offsets into host memory themselves
 constexpr uint32_t AUTO_DENSE_PERMILLE = 200;
@@ -339,7 +342,7 @@ bool use_fused(const sjgpu_ctx *ctx, size_t len, int op = 1) { // op 0: stage 1,
   if (ctx->pipeline != 2) { return ctx->pipeline == 1; }
   if (len <= AUTO_FUSED_BELOW) { return true; }
   if (op != 0) { return len >= AUTO_FUSED_FROM_MINIFY; } // minify: the on-chip kernel reads its input once, the split pipeline twice
-  return len >= AUTO_FUSED_FROM && ctx->density_permille >= AUTO_DENSE_PERMILLE;
+  return len >= (ctx->density_permille >= AUTO_DENSE_PERMILLE ? AUTO_FUSED_FROM : AUTO_FUSED_FROM_SPARSE);
 }
 
 // `len` is the END of the scan (bytes [org.begin, len) are scanned); a whole document has org = {0, 0, 0}
