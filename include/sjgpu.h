@@ -120,9 +120,12 @@ int sjgpu_result(sjgpu_ctx *ctx, void *stream, sjgpu_scan_result *out);
  *   FUSED  one kernel, chained scan between tiles: reads every byte once, one launch -- fastest on small inputs
  *          and, in its pipelined form (look-back + emission of a tile deferred behind the scan of the next), on
  *          large ones;
- *   AUTO   FUSED up to 8 MiB (16 KiB tiles) and from 640 MiB (pipelined 64 KiB tiles), SPLIT in between -- and, for
- *          stage 1 from 640 MiB, also when the previous large scan of this context produced fewer than 0.2 offsets
- *          per byte (sparse output: NDJSON, pretty-printed text), where SPLIT is 3-8 % faster.
+ *   AUTO   FUSED up to 8 MiB (16 KiB tiles) and from 224 MiB (pipelined, eight waves per workgroup, 128 KiB tiles),
+ *          SPLIT in between -- and, for stage 1, at every size when the previous large scan of this context produced
+ *          fewer than 0.2 offsets per byte (sparse output: NDJSON, pretty-printed text), where SPLIT is 0-10 % faster
+ *          (profiles/r04_pipeline_sweep.txt).
+ *          (A/B switches, read once per process: SJGPU_PIPE_WAVES=4 / SJGPU_MINIFY_WAVES=4 bring back the four-wave
+ *          shapes of rounds 1-3 -- 64 KiB / 32 KiB tiles.)
  * All produce identical bytes; a single-pass call that raises SJGPU_F_INTERNAL is re-run split by the
  * host-buffer entry points, device-resident callers see the flag in sjgpu_result(). */
 #define SJGPU_PIPELINE_SPLIT 0
@@ -259,7 +262,10 @@ int sjgpu_match_keys_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, con
  * STRING_ERROR 5, T/F/N_ATOM_ERROR 6/7/8, NUMBER_ERROR 9, BIGINT_ERROR 10 (numbers beyond 64 bits: _number_as_string is not
  * offered here) -- the one the reference's serial walk meets FIRST -- or SJGPU_E_OVERFLOW / other negatives.  On SUCCESS
  * tape_dev[0 .. *tape_words_out) and string_buf_dev[0 .. *string_bytes_out) are word for word what the reference's dom parse
- * leaves in dom::document::tape / string_buf.  Waits for the stream (reads 48 bytes back). */
+ * leaves in dom::document::tape / string_buf.  Waits for the stream (reads 56 bytes back).
+ * The call is optimistic: it enqueues the string pass's stream compaction alone and the bracket sort in one pass; a document
+ * the stream declines (a string the reference rejects, quotes glued to scalars) or one nested 64 deep and more says so in the
+ * results read back, and the launches run a second time with the per-string kernels / the sort's second pass enqueued. */
 int sjgpu_stage2_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const void *idx_dev, uint32_t n, uint32_t max_depth, void *tape_dev,
                         size_t tape_cap_words, void *string_buf_dev, size_t string_buf_bytes, void *stream, uint64_t *tape_words_out,
                         uint64_t *string_bytes_out);

@@ -332,9 +332,10 @@ constexpr size_t AUTO_FUSED_BELOW = size_t(8) << 20;
 // 256 MiB on: 155 against 162 us there, 268 against 288 at 512 MiB, 479 against 557 at 1 GiB; at 160 MiB the split pipeline still leads, 103 against 110.
 // On sparse output the split pipeline stays ahead up to 512 MiB and level at 1 GiB.  The rows in profiles/r04_pipeline_sweep.txt.)
 constexpr size_t AUTO_FUSED_FROM = size_t(224) << 20;
-// sparse output (twitter-like 0.12 offsets per byte, NDJSON 0.06): the split pipeline leads up to 512 MiB (185 against 207 us on NDJSON), the eight-wave
-// single-pass kernel at 1 GiB (357 against 370 us, profiles/r04_pipe_waves_ab.txt): its fixed cost of filling and draining the pipeline is paid once
-constexpr size_t AUTO_FUSED_FROM_SPARSE = size_t(896) << 20;
+// sparse output (twitter-like 0.12 offsets per byte, NDJSON 0.06) stays with the split pipeline at every size: it leads up to 512 MiB (185 against 207 us on
+// NDJSON) and at 1 GiB the two are level or the split pipeline ahead depending on the text (357 against 370 us on one synthetic stream, 409 against 372 on
+// another -- the bench's: profiles/r04_pipe_waves_ab.txt)
+constexpr size_t AUTO_FUSED_FROM_SPARSE = ~size_t(0);
 constexpr size_t AUTO_FUSED_FROM_MINIFY = size_t(192) << 20;
 constexpr size_t DIRECT_HOST_MAX = size_t(2) << 20; // sjgpu_stage1 on host buffers: up to here the kernels write the offsets into host memory themselves
 constexpr uint32_t AUTO_DENSE_PERMILLE = 200;
@@ -926,7 +927,12 @@ int sjgpu_profile_read(sjgpu_ctx *ctx, double *ms_sum, uint32_t *calls) {
   for (size_t c = 0; c < ncalls; c++) {
     for (int k = 0; k < PROFILE_SLOTS; k++) {
       float ms = 0.f;
-      SJ_TRY(ctx, hipEventElapsedTime(&ms, ctx->events[c * PROFILE_EVENTS + k], ctx->events[c * PROFILE_EVENTS + k + 1]));
+      const hipError_t e = hipEventElapsedTime(&ms, ctx->events[c * PROFILE_EVENTS + k], ctx->events[c * PROFILE_EVENTS + k + 1]);
+      if (e != hipSuccess) { // a single-kernel call records events 0 and 1 only: its slots 1 and 2 are empty
+        (void)hipGetLastError();
+        if (k == 0) { SJ_TRY(ctx, e); }
+        ms = 0.f;
+      }
       ms_sum[k] += double(ms);
     }
   }

@@ -604,9 +604,7 @@ void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *res
   const u64 nchunks = (len - begin + CHUNK_BYTES - 1) / CHUNK_BYTES;
   const u32 grid = u32(nchunks < 8192 ? nchunks : 8192); // 256 CUs x 32 single-wave workgroups, grid-stride beyond
   hipLaunchKernelGGL(k_validate_utf8, dim3(grid), dim3(64), 0, stream, buf, len, result, begin, more ? 1u : 0u);
-  mark(ev, 1, stream);
-  mark(ev, 2, stream);
-  mark(ev, 3, stream);
+  mark(ev, 1, stream); // (a single kernel: slots 1 and 2 stay unrecorded; sjgpu_profile_read reports them as 0)
 }
 
 void launch_string_parity(const uint8_t *buf, uint64_t len, scan_result_dev *result, uint8_t *workspace, hipStream_t stream) {

@@ -577,6 +577,9 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_rules(u32 n, const u8 *__re
   }
 }
 
+// (Round 4, measured and not kept: the spelling checked inside k_tok_classify, where the token's cache line has just arrived, instead of a list and this
+// kernel -- k_tok_classify 120 -> 244 us for the 52 of this kernel and 28 of the list in k_tok_apply: a second dependent fetch in the one kernel that is
+// bound by the latency of its gather.  profiles/r04_tape_kernel_stats.txt.)
 // the other one-word tokens (listed from the back of value_list): true / false / null -- their words are on the tape (k_tok_apply), here their
 // SPELLING is checked against the document; any other byte here is no token at all and k_tape_rules has said so
 __global__ __launch_bounds__(TP_THREADS) void k_tape_atoms(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, const u8 *__restrict__ tokc,
