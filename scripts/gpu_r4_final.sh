@@ -12,15 +12,17 @@ timeout 900 python bench.py > gpurun_out/r04_bench_default.json 2> gpurun_out/r0
 timeout 900 python bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --share-device --size 268435456 > gpurun_out/r04_bench_n2_dry.json 2> gpurun_out/r04_bench_n2_dry.err; echo "n2 dry rc=$?"
 python3 - <<'PY'
 import json
+def last_line(path):  # the bench line is the last line that starts with a brace (library banners may precede it)
+    return json.loads([l for l in open(path).read().splitlines() if l.startswith("{")][-1])
 try:
-    d = json.load(open("gpurun_out/r04_bench_default.json"))
+    d = last_line("gpurun_out/r04_bench_default.json")
     print({k: d[k] for k in ("metric", "value", "ms_per_step")}, d["roofline"]["frac"], d["roofline"]["kernel"], "failed:", d.get("legs_failed"))
     for k, v in d.get("legs", {}).items():
         r = v.get("roofline") if isinstance(v, dict) else None
         print(k, (r or {}).get("frac"), v.get("value") if isinstance(v, dict) else None)
     t = d["legs"]["next_f3_tape"]
     print("tape", {k: (t[k]["gpu_ms_per_call"], t[k]["roofline"]["frac"]) for k in ("twitter_like", "large_random")})
-    n2 = json.load(open("gpurun_out/r04_bench_n2_dry.json"))
+    n2 = last_line("gpurun_out/r04_bench_n2_dry.json")
     print("n2", n2["value"], n2["n_gpus"], n2.get("parity"), n2.get("n_ranks_seen_by_rccl"), str(n2.get("index_concat"))[:80])
 except Exception as e:
     print("no bench line:", e)
