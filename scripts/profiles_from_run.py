@@ -13,13 +13,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out")
 prof = os.path.join(ROOT, "profiles")
 
-line = json.load(open(os.path.join(out, "r04_bench_default.json")))
+def last_line(path):  # the bench line is the last line that starts with a brace
+    return json.loads([l for l in open(path).read().splitlines() if l.startswith("{")][-1])
+
+
+line = last_line(os.path.join(out, "r04_bench_default.json"))
 json.dump(line, open(os.path.join(prof, "r04_bench_final.json"), "w"))
 n2_text = [l for l in open(os.path.join(out, "r04_bench_n2_dry.json")).read().splitlines() if l.startswith("{")]
 if n2_text:
     json.dump(json.loads(n2_text[-1]), open(os.path.join(prof, "r04_bench_n2_dry.json"), "w"))
 
-prof_line = json.load(open(os.path.join(out, "r04_bench_profiled.json")))
+prof_line = last_line(os.path.join(out, "r04_bench_profiled.json"))
 db = os.path.join(out, "prof_r04_bench_final", "b_results.db")
 cur = sqlite3.connect(db).cursor()
 rows = list(cur.execute("select name, start, end from kernels order by start"))
@@ -29,12 +33,12 @@ for name, s, e in rows:
         continue
     short = name.replace("sjgpu::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     per.setdefault(short, []).append((e - s) / 1000.0)
-head = per.get("k_fused_pipelined<0, false>", [])
+head = per.get("k_fused_pipelined<0, false, 4u, 8u>", []) or per.get("k_fused_pipelined<0, false>", [])  # (eight waves per workgroup since round 4)
 first = head[: prof_line["steps"] + prof_line["warmup"]]
 r = prof_line["roofline"]
 with open(os.path.join(prof, "r04_final_kernel_stats.txt"), "w") as f:
     f.write("# r04 (final): rocprofv3 --kernel-trace -- python bench.py (the default command: N = 1, 20 steps + 3 warm-up, all legs); sjgpu kernels only, from the\n"
-            "# rocpd database rocprofv3 writes (view `kernels`; scripts/profiles_from_run.py).  The headline kernel is k_fused_pipelined<0>: its first 23 dispatches are\n"
+            "# rocpd database rocprofv3 writes (view `kernels`; scripts/profiles_from_run.py).  The headline kernel is k_fused_pipelined<0, false, 4u, 8u> (eight waves, 128 KiB tiles): its first 23 dispatches are\n"
             "# the headline leg (large_random, 1 GiB: 3 warm-up + 20 timed); the others belong to the deep_nesting leg, the 256 MiB documents of the stage-2 legs and\n"
             "# the parity calls, so the mean over all calls mixes workloads.  The comparable figures:\n")
     if first:
