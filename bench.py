@@ -500,7 +500,7 @@ def leg_dom_parse(cx, R, impl):
     reference benchmarker's method (benchmark/benchmarker.h:315-346: parser and document allocated once, best of several parses of the same
     buffer), beside the two roads the plug-in's parse() has -- (A) stage 1 on the GPU + the reference's stage 2 on its list (what documents
     below SJGPU_STAGE2_FROM_KB take; timed as sjgpu_stage1 on the host buffer + the reference's stage2() alone: the shim lends the list, nothing
-    is copied in between) and (B) sjgpu_parse, stage 2 on the device too (from SJGPU_STAGE2_FROM_KB = 2048 on).  The sweep is what the
+    is copied in between) and (B) sjgpu_parse, stage 2 on the device too (from SJGPU_STAGE2_FROM_KB = 1024 on).  The sweep is what the
     threshold rests on."""
     import ctypes
     capi = cx.capi
@@ -544,7 +544,7 @@ def leg_dom_parse(cx, R, impl):
                        "reference_GBps": round(n / t_ref / 1e9, 3), "road_a_GBps": round(n / road_a / 1e9, 3), "road_b_GBps": round(n / best_parse / 1e9, 3),
                        "faster_road": "b" if best_parse < road_a else "a", "tape_words": int(tw.value)}
         del tape, sbuf
-    return {"documents": "twitter-like, seed 91", "reference_kernel": impl.decode(), "threshold_SJGPU_STAGE2_FROM_KB": 2048, "sizes": rows,
+    return {"documents": "twitter-like, seed 91", "reference_kernel": impl.decode(), "threshold_SJGPU_STAGE2_FROM_KB": 1024, "sizes": rows,
             "note": "wall time per parse, host (pageable) buffers on both sides, best of the repetitions; road B includes the upload of the document and the download of "
                     "tape and string buffer (PCIe), road A the upload and the download of the structural list"}
 

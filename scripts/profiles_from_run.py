@@ -34,15 +34,17 @@ for name, s, e in rows:
     short = name.replace("sjgpu::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     per.setdefault(short, []).append((e - s) / 1000.0)
 head = per.get("k_fused_pipelined<0, false, 4u, 8u>", []) or per.get("k_fused_pipelined<0, false>", [])  # (eight waves per workgroup since round 4)
-first = head[: prof_line["steps"] + prof_line["warmup"]]
+# the headline leg's dispatches: --warmup calls, one more (AUTO settles), the clock warm-up's (bench.py: clock_warmup), then the timed steps
+skip = max(prof_line["warmup"], 1) + 1 + int(prof_line.get("clock_warmup_calls") or 0)
+first = head[skip: skip + prof_line["steps"]]
 r = prof_line["roofline"]
 with open(os.path.join(prof, "r04_final_kernel_stats.txt"), "w") as f:
     f.write("# r04 (final): rocprofv3 --kernel-trace -- python bench.py (the default command: N = 1, 20 steps + 3 warm-up, all legs); sjgpu kernels only, from the\n"
-            "# rocpd database rocprofv3 writes (view `kernels`; scripts/profiles_from_run.py).  The headline kernel is k_fused_pipelined<0, false, 4u, 8u> (eight waves, 128 KiB tiles): its first 23 dispatches are\n"
-            "# the headline leg (large_random, 1 GiB: 3 warm-up + 20 timed); the others belong to the deep_nesting leg, the 256 MiB documents of the stage-2 legs and\n"
+            "# rocpd database rocprofv3 writes (view `kernels`; scripts/profiles_from_run.py).  The headline kernel is k_fused_pipelined<0, false, 4u, 8u> (eight waves, 128 KiB tiles): the TIMED dispatches of the\n"
+            "# headline leg (large_random, 1 GiB: behind 3 + 1 warm-up calls and the clock warm-up's) are listed first; the others belong to the deep_nesting leg, the 256 MiB documents of the stage-2 legs and\n"
             "# the parity calls, so the mean over all calls mixes workloads.  The comparable figures:\n")
     if first:
-        f.write(f"#   headline leg, {len(first)} dispatches: mean {sum(first) / len(first):.1f} us, min {min(first):.1f}, max {max(first):.1f}  (kernel alone)\n")
+        f.write(f"#   headline leg, the {len(first)} timed dispatches: mean {sum(first) / len(first):.1f} us, min {min(first):.1f}, max {max(first):.1f}  (kernel alone)\n")
     f.write(f"#   bench.py line of the SAME run: value {prof_line['value']} GB/s, ms_per_step {prof_line['ms_per_step']}, roofline gpu_ms_per_step {r['gpu_ms_per_step']} (HIP events around\n"
             f"#   the clear and the scan kernel of one call), achieved {r['achieved']} GB/s, frac {r['frac']}, kernel {r['kernel']}\n")
     if first:

@@ -64,14 +64,15 @@ const device_list &listed_devices() noexcept {
   return *l;
 }
 
-// dom::parser::parse of documents of SJGPU_STAGE2_FROM_KB kilobytes and more (default 2048; 0 = never) runs stage 2 on the device as well
+// dom::parser::parse of documents of SJGPU_STAGE2_FROM_KB kilobytes and more (default 1024; 0 = never) runs stage 2 on the device as well
 // (sjgpu_parse: the structural list never crosses PCIe, the tape and the string buffer come back instead of it).  Shorter documents,
 // _number_as_string parsers and nesting limits beyond 4095 keep the reference's CPU stage 2.  Read when a parser is made.
 size_t device_stage2_from() noexcept {
-  // 2 MiB: bench.py's plugin_host_path.dom_parse sweep (round 4, twitter-like documents, wall time per parse): the device road costs
-  // ~0.40 ms + 0.045 ms per MiB, stage 1 on the GPU + the reference's stage 2 ~0.05 ms + 0.31 ms per MiB -- they cross near 1.3 MiB
-  // (0.6 MiB: 0.44 vs 0.21 ms; 4 MiB: 0.59 vs 1.34 ms; 256 MiB: 13.3 vs 81.6 ms, the reference alone 101.7 ms)
-  size_t kb = 2048;
+  // 1 MiB: bench.py's plugin_host_path.dom_parse sweep (round 4, twitter-like documents, wall time per parse): the device road costs
+  // ~0.28 ms + 0.045 ms per MiB since its call became optimistic (17 launches; 0.40 ms + ... with 27 launches and 11 memsets: the threshold was
+  // 2 MiB then), stage 1 on the GPU + the reference's stage 2 ~0.05 ms + 0.31 ms per MiB -- they cross near 0.9 MiB
+  // (0.6 MiB: 0.29 vs 0.21 ms; 1 MiB: 0.32 vs 0.34; 4 MiB: 0.44 vs 1.34 ms; 256 MiB: 12.8 vs 81.2 ms, the reference alone 101.4 ms)
+  size_t kb = 1024;
   if (const char *v = std::getenv("SJGPU_STAGE2_FROM_KB")) { kb = size_t(std::strtoull(v, nullptr, 10)); }
   return kb ? kb << 10 : ~size_t(0);
 }
