@@ -73,9 +73,14 @@ static int check_jsonexamples(const implementation *cpu, const implementation *g
     padded_string json;
     CHECK(padded_string::load(dir + "/" + k.file).get(json) == SUCCESS, "cannot load %s/%s", dir.c_str(), k.file);
     get_active_implementation() = gpu;
+    // (this check reads the structural list out of the parser: it wants the road that brings the list home -- stage 1 on the GPU + the reference's stage 2.
+    // From 1 MiB on -- citm_catalog.json has 1.7 -- parse() would run stage 2 on the device too and leave the list there; 2b below checks that road.)
+    setenv("SJGPU_STAGE2_FROM_KB", "0", 1); // read when a parser is made
     dom::parser parser;
     dom::element doc;
-    CHECK(parser.parse(json).get(doc) == SUCCESS, "%s: dom::parser::parse on mi355x", k.file);
+    const error_code parse_error = parser.parse(json).get(doc);
+    unsetenv("SJGPU_STAGE2_FROM_KB");
+    CHECK(parse_error == SUCCESS, "%s: dom::parser::parse on mi355x", k.file);
     const auto &impl = *parser.implementation;
     CHECK(impl.n_structural_indexes == k.n, "%s: n = %u, expected %u", k.file, impl.n_structural_indexes, k.n);
     const uint64_t h = fnv1a64(impl.structural_indexes.get(), (size_t(k.n) + 3) * sizeof(uint32_t));
