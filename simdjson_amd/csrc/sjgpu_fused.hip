@@ -976,7 +976,7 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
     static const bool queue_only = std::getenv("SJGPU_UTF8_QUEUE_ONLY") != nullptr; // A/B switch
     if (queue_only) { org.carry |= CARRY_DEBUG_QUEUE_UTF8; }
     if (onchip_waves) {
-      const u32 resident = max_workgroups / (onchip_waves / 2u); // max_workgroups = 8 per CU; 33 KiB of LDS per four waves: sixteen waves per CU
+      const u32 resident_q = max_workgroups / (onchip_waves / 2u), resident = resident_q ? resident_q : 1u; // max_workgroups = 8 per CU; 33 KiB of LDS per four waves: sixteen waves per CU
       const u32 g = cap < resident ? cap : resident;
       if (onchip_waves == 8u) {
         hipLaunchKernelGGL((k_minify_onchip<8>), dim3(g), dim3(512), 0, stream, buf, len, desc, ticket, ntiles, static_cast<u8 *>(out), result, org);
@@ -1001,7 +1001,7 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
       return "k_fused_pipelined<0> (32 KiB tiles)";
     }
     if (op == 0 && s1_waves == 8u) {
-      const u32 resident8 = max_workgroups / 2u; // two workgroups of eight waves per CU
+      const u32 resident8 = max_workgroups >= 2u ? max_workgroups / 2u : 1u; // two workgroups of eight waves per CU
       hipLaunchKernelGGL((k_fused_pipelined<0, false, FUSED_WAVE_CHUNKS, 8>), dim3(cap < resident8 ? cap : resident8), dim3(512), 0, stream, buf, len, desc, ticket, ntiles, out,
                          out_words, result, org);
       mark(ev, 1, stream); // (a single kernel: slots 1 and 2 stay unrecorded -- two stream markers less per call; sjgpu_profile_read reports them as 0)

@@ -38,6 +38,18 @@ def test_the_committed_bench_line_has_the_contract_s_fields():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
 
 
+def test_the_line_says_how_its_timed_regions_were_reached():
+    """Round 4: 40 ms of untimed calls run in front of every timed region (bench.py: clock_warmup -- the first 30-40 calls after an idle phase run slow); the
+    line says how many, and the per-call legs carry the figure of the first calls beside the sustained one."""
+    d, _ = _final_line()
+    assert isinstance(d.get("clock_warmup_calls"), int) and d["clock_warmup_calls"] >= 8
+    for name in ("next_f3_depth_scan", "next_f3_parse_strings"):
+        leg = d["legs"][name]
+        assert leg["first_reps_ms_per_call"] > 0 and leg["gpu_ms_per_call"] > 0 and "clock_warmup" in leg["timing"], name
+    for kind, leg in d["legs"]["next_f3_tape"].items():
+        assert leg["first_reps_ms_per_call"] > 0 and leg["gpu_ms_per_call"] > 0, kind
+
+
 def test_every_leg_is_there_and_none_failed():
     d, _ = _final_line()
     assert d.get("legs_failed") == []

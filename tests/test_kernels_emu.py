@@ -44,6 +44,16 @@ def test_kernel_sources_against_the_oracle(emu, seed, docs, max_kib):
     assert f"{docs} documents" in p.stdout.decode() and " 0 mismatches" in p.stdout.decode()
 
 
+@pytest.mark.parametrize("waves", ["4", "16"])
+def test_the_other_workgroup_shapes_of_the_single_pass_kernels(emu, waves):
+    """The single-pass kernels run with eight waves per workgroup since round 4 (128 KiB / 64 KiB tiles: half the tickets and look-backs per byte); the
+    four-wave shape of rounds 1-3 (SJGPU_PIPE_WAVES=4, SJGPU_MINIFY_WAVES=4) and minify's sixteen-wave one stay selectable for A/B runs -- and stay right."""
+    env = dict(os.environ, SJGPU_PIPE_WAVES=waves, SJGPU_MINIFY_WAVES=waves)
+    p = subprocess.run([emu, "11", "60", "300", "fused"], capture_output=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout.decode()[-500:], p.stderr.decode()[-3000:])
+    assert "60 documents" in p.stdout.decode() and " 0 mismatches" in p.stdout.decode()
+
+
 @pytest.mark.parametrize("part", [1, 2, 3, 4])
 def test_the_documents_reach_every_part_of_the_escape_carry(tmp_path, part):
     """The kernels carry the escape state in their scan (sj_xcarry.h: spans that assume, an x word per summary).  With a part of the x
