@@ -210,7 +210,7 @@ struct tape_result_dev {
 constexpr uint32_t TAPE_ONE_PASS_LEVELS = 64; // levels one pass of the sort tells apart
 size_t tape_workspace_bytes(uint32_t n, uint64_t len);
 // stage 2 of buf[0..len) from its structural list idx[0..n] (idx[n] = len), in two halves around the string pass: launch_tape_front leaves
-// the token bytes, tape positions, depths, value lists and the sort's input in the workspace and returns the number of string tokens (device);
+// the token bytes and the block totals of the per-token counters in the workspace and returns the number of string tokens (device);
 // launch_tape writes the reference's tape (and the length words of the string records when the stream compaction wrote them).
 // workspace: tape_workspace_bytes(n, len), its first bytes are the tape_result_dev afterwards
 const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, void *workspace, hipStream_t s);
