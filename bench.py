@@ -19,7 +19,7 @@ BASELINE.json measured the same way (each with its own `roofline` and `cpu_basel
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank scans its OWN 1 GiB shard (independent
 documents, SURVEY 8(e): no data-path collective), weak scaling; value = bytes all ranks scanned / max-over-ranks time;
-"config4_ndjson" / "one_document_shards" carry the NDJSON shards with the index concatenation and the one-document path.
+"config3_ndjson_sharded" / "one_document_shards" carry the NDJSON shards (BASELINE configs[3]) with the index concatenation and the one-document path.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -115,9 +115,13 @@ def make_workload(corpus, workload, size, seed):
     return gen(size, seed)
 
 
-def device_leg(cx, op, workload, host, units, steps, warmup, pipeline, fence=None, cpu_iters=None, with_cpu=True, with_parity=None, parity_raises=True):
+def device_leg(cx, op, workload, host, units, steps, warmup, pipeline, fence=None, cpu_iters=None, with_cpu=True, with_parity=None, parity_raises=True,
+               rank=0, world=1):
     """One op over one resident buffer: K timed steps bracketed by synchronize (+ barrier), HIP-event kernel time from
-    libsjgpu, exact parity of the timed buffer's output against the reference (count AND an order-sensitive digest)."""
+    libsjgpu, exact parity of the timed buffer's output against the reference (count AND an order-sensitive digest).
+    Three timed regions, in this order: (1) `steps` steps straight behind the --warmup steps -- what a cold 5 + 20 run gives, the way rounds 1-4a
+    timed (first_reps_ms_per_step / value_first_reps); (2) N > 1 only: rank 0 ALONE over its own buffer while the other ranks wait in a barrier --
+    the same-workload single-rank figure the N-rank value is divided by (n1_same_workload); (3) behind clock_warmup: the sustained figure = `value`."""
     torch, capi = cx.torch, cx.capi
     L = len(host)
     parser = capi.DomParserImplementation(L, device=cx.local_rank)
@@ -146,6 +150,27 @@ def device_leg(cx, op, workload, host, units, steps, warmup, pipeline, fence=Non
     parser.result(stream)
     used = "-" if op == "validate_utf8" else parser.last_pipeline()
     kernel = parser.profile_kernel()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    dt_first = time.perf_counter() - t0
+    solo = None
+    if world > 1:  # every rank passes both fences; between them only rank 0 works
+        sync()
+        if rank == 0:
+            clock_warmup(torch, step)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            dt_solo = time.perf_counter() - t0
+            solo = {"value": round(L * steps / dt_solo / 1e9, 2), "unit": "GB/s", "ms_per_step": round(dt_solo / steps * 1e3, 4), "steps": steps,
+                    "how": "rank 0 alone over its own resident buffer (same workload, same size, same kernels) while every other rank waits in a barrier: "
+                           "what an N = 1 run of THIS workload gives, measured inside this run"}
+        sync()
     warm_calls = clock_warmup(torch, step)
     parser.profile_enable(True)
     sync()
@@ -166,11 +191,13 @@ def device_leg(cx, op, workload, host, units, steps, warmup, pipeline, fence=Non
     leg = {
         "value": round(L * steps / dt / 1e9, 2), "unit": "GB/s", "ms_per_step": round(dt / steps * 1e3, 4), "bytes": L, "units": units,
         "pipeline": used, "structurals": n if op == "stage1" else None, "out_bytes": out_len if op == "minify" else None, "clock_warmup_calls": warm_calls,
+        "first_reps_ms_per_step": round(dt_first / steps * 1e3, 4), "value_first_reps": round(L * steps / dt_first / 1e9, 2), "n1_same_workload": solo,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "algorithmic_bytes_per_launch": alg, "gpu_ms_per_step": round(gpu_ms, 4), "kernel": kernel,
                      "kernel_ms_slots": [round(m / max(calls, 1), 4) for m in ms_sum],
-                     "traffic": cx.traffic.get(tkey), "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this "
-                     "command, separate passes (scripts/gpu_pmc.sh); null = not collected for this workload",
+                     "traffic": cx.traffic.get(tkey), "traffic_static_from_profiles": cx.traffic.get(tkey), "traffic_measured_in_this_run": False,
+                     "traffic_source": "STATIC: read from profiles/traffic.json, not measured by this run -- rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this "
+                     "command in separate counter passes (scripts/gpu_pmc.sh, profiles/r05_pmc_summary.txt); null = not collected for this workload",
                      "timing": "hipEvent pairs around what one call enqueues on the launch stream (slot 0: clears and the scan kernel; slots 1-2: resolve and emit "
                                "kernels of the split pipeline, empty and not counted for a single-pass call), mean over the timed steps"},
     }
@@ -707,20 +734,22 @@ def main():
             torch.cuda.synchronize()
 
     # ---- the headline: one synthetic buffer per rank, resident in HBM before anything is timed ----
-    # N = 1: BASELINE.json configs[1] (large_random).  N > 1: configs[3], the workload that shards -- parse_many-style NDJSON, one
-    # newline-aligned shard per GPU, zero carry-in -- unless the command line names another one.
-    if world > 1 and args.workload is None:
-        args.workload = "amazon_ndjson"
+    # EVERY N takes the same workload by default -- BASELINE.json configs[1], large_random, one independent 1 GiB document per rank (weak scaling, no
+    # data-path collective) -- so that a sweep `bench.py --gpus 1,2,4,8` is ONE workload end to end and value(N) / (N * value(1)) means something.
+    # (Rounds 3-4 switched the N > 1 headline to amazon NDJSON: a curve assembled from those lines jumped workloads between its first and second
+    # point.)  configs[3] -- the NDJSON shards with the RCCL index concatenation -- travels in every line: `legs.config3_amazon_ndjson` at N = 1,
+    # `config3_ndjson_sharded` at N > 1, each N > 1 figure with the same-workload single-rank figure measured inside the same run; and
+    # `--workload amazon_ndjson` makes NDJSON the top-level workload at ANY N, N = 1 included (roofline, cpu_baseline, cpu_baseline_threads).
     if args.workload is None:
         args.workload = "large_random"
     host, units = make_workload(corpus, args.workload, args.size, 1000 + rank)
     L = len(host)
-    # the reference beside it: rank 0 times it (one thread on its own buffer; N > 1 adds all hardware threads on the NDJSON);
+    # the reference beside it: rank 0 times it (one thread on its own buffer; NDJSON adds all hardware threads);
     # EVERY rank checks its own output against the reference, the verdicts are reduced into the line
     with_cpu = rank == 0 and not args.no_cpu_baseline
     with_parity = not args.no_cpu_baseline
     leg = device_leg(cx, args.op, args.workload, host, units, args.steps, args.warmup, args.pipeline, fence=fence, with_cpu=with_cpu, with_parity=with_parity,
-                     parity_raises=world == 1)
+                     parity_raises=world == 1, rank=rank, world=world)
     parity_failed_somewhere = False
     if world > 1:
         mine_ok = 1.0 if leg.get("parity", {}).get("ok", False) else 0.0
@@ -732,18 +761,19 @@ def main():
                                   "note": "every rank compares the output of its own timed buffer with the reference (count + order-sensitive digest); this entry is rank 0's, "
                                           "the counters are the all-reduced verdicts"})
         parity_failed_somewhere = with_parity and int(pv[0].item()) != world
-        if with_cpu and args.op == "stage1" and args.workload == "amazon_ndjson":
-            threads = os.cpu_count() or 1
-            cb = cx.cpu().time_cpu_ndjson_threads(host, threads, 3)
-            if cb is not None:
-                leg["cpu_baseline_threads"] = {"value": round(cb["value"], 2), "unit": "GB/s", "cores": cb["cores"], "kind": cb["kind"],
-                                               "sample": f"rank 0's NDJSON buffer cut at newlines into {cb['cores']} slices, {cb['impl']} kernel, one parser per thread, "
-                                                         f"{threads} hardware threads on the box", "structurals": cb["n"]}
+    if with_cpu and args.op == "stage1" and args.workload == "amazon_ndjson":
+        threads = os.cpu_count() or 1
+        cb = cx.cpu().time_cpu_ndjson_threads(host, threads, 3)
+        if cb is not None:
+            leg["cpu_baseline_threads"] = {"value": round(cb["value"], 2), "unit": "GB/s", "cores": cb["cores"], "kind": cb["kind"],
+                                           "sample": f"rank 0's NDJSON buffer cut at newlines into {cb['cores']} slices, {cb['impl']} kernel, one parser per thread, "
+                                                     f"{threads} hardware threads on the box", "structurals": cb["n"]}
     dt = leg["ms_per_step"] * 1e-3 * args.steps
+    dt_first = leg["first_reps_ms_per_step"] * 1e-3 * args.steps
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, dt_first], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_first = float(t[0].item()), float(t[1].item())
         tot = torch.tensor([float(L)], dtype=torch.float64, device="cuda")
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_bytes = float(tot.item())
@@ -751,9 +781,10 @@ def main():
         total_bytes = float(L)
     line = None
     if rank == 0:
+        value = total_bytes * args.steps / dt / 1e9
         line = {
             "metric": "stage1 GB/s (structural indexing)" if args.op == "stage1" else f"{args.op} GB/s",
-            "value": round(total_bytes * args.steps / dt / 1e9, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.workload} {L} B per GPU (seed 1000+rank), op={args.op}, regular mode, device-resident input and output, "
@@ -761,8 +792,21 @@ def main():
                        "out_bytes": leg["out_bytes"], "parallelism": f"{world} independent shard(s), one rank per GPU, no data-path collective",
                        "library": os.path.basename(capi._paths.LIB_SJGPU)},
             "roofline": leg["roofline"],
-            "clock_warmup_calls": leg.get("clock_warmup_calls"),  # untimed calls in front of the --warmup steps' successors: see clock_warmup()
+            "clock_warmup_calls": leg.get("clock_warmup_calls"),  # untimed calls in front of the timed region, on top of --warmup: see clock_warmup()
+            # the same K steps timed straight behind the --warmup steps, before clock_warmup (MAX over ranks): what a cold `--warmup W --steps K` run gives
+            "first_reps_ms_per_step": round(dt_first / args.steps * 1e3, 4), "value_first_reps": round(total_bytes * args.steps / dt_first / 1e9, 2),
+            "timing": "value / ms_per_step: K steps behind W warm-up steps + clock_warmup (40 ms of the same calls, untimed: the first 30-40 calls after an idle "
+                      "phase run 5-15 % slow, profiles/r04_drift_probe.txt); value_first_reps / first_reps_ms_per_step: the same K steps behind the W warm-up steps alone",
+            "same_workload_at_every_n": f"{args.workload}: `bench.py --gpus N` takes this workload at N = 1 and at N > 1 unless --workload names another one, so "
+                                        "value(N) / (N x value(1)) compares like with like; configs[3] (sharded NDJSON + RCCL index concatenation) is "
+                                        + ("`legs.config3_amazon_ndjson`" if world == 1 else "`config3_ndjson_sharded`") + " of this line",
         }
+        if world > 1 and leg.get("n1_same_workload"):
+            n1 = leg["n1_same_workload"]
+            line["n1_same_workload_GBps"] = n1["value"]
+            line["n1_same_workload"] = n1
+            line["scaling_efficiency"] = round(value / (world * n1["value"]), 4)
+            line["scaling_efficiency_is"] = "value / (n_gpus x n1_same_workload_GBps), both measured in THIS run on THIS workload"
         for k in ("cpu_baseline", "cpu_baseline_threads", "parity"):
             if k in leg:
                 line[k] = leg[k]
@@ -814,7 +858,7 @@ def main():
         line["legs"] = legs
         line["legs_failed"] = sorted(k for k, v in legs.items() if isinstance(v, dict) and "error" in v)  # a swallowed exception must be visible
 
-    # ---- N > 1: BASELINE.json config 4 (parse_many-style NDJSON shards, RCCL concatenation) and the one-document path ----
+    # ---- N > 1: BASELINE.json configs[3] (parse_many-style NDJSON shards, RCCL concatenation) and the one-document path ----
     ndjson = docshards = None
     if world > 1 and args.op == "stage1" and args.ndjson_leg != 0:
         try:
@@ -827,7 +871,7 @@ def main():
             docshards = {"error": repr(e)[:300]}
     if rank == 0:
         if ndjson is not None:
-            line["config4_ndjson"] = ndjson
+            line["config3_ndjson_sharded"] = ndjson
             # what the first multi-GPU run has to show at a glance: did RCCL see all ranks, and which road did the index concatenation take
             line["n_ranks_seen_by_rccl"] = ndjson.get("n_ranks_seen_by_rccl")
             line["index_concat"] = ndjson.get("index_concat")
@@ -903,6 +947,18 @@ def ndjson_leg(args, torch, dist, corpus, capi, rank, world, local_rank, fence):
         step()
     n, flags, _ = scanner.parser.result(stream)
     steps = max(4, args.steps // 2)
+    # the same-workload single-rank figure, inside this run: rank 0 alone over its shard while the others wait in the second fence
+    fence()
+    n1 = None
+    if rank == 0:
+        clock_warmup(torch, step)
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        n1 = L * steps / (_t.perf_counter() - t0) / 1e9
+    fence()
     clock_warmup(torch, step)
     fence()
     t0 = _t.perf_counter()
@@ -910,7 +966,7 @@ def ndjson_leg(args, torch, dist, corpus, capi, rank, world, local_rank, fence):
         step()
     fence()
     dt_scan = _t.perf_counter() - t0
-    out = {"workload": f"amazon_ndjson {L} B per GPU, newline-aligned shards, zero carry-in", "structurals_rank0": n,
+    out = {"workload": f"amazon_ndjson {L} B per GPU, newline-aligned shards, zero carry-in (BASELINE.json configs[3])", "structurals_rank0": n,
            "lines_rank0": lines, "flags_rank0": flags}
     base = torch.tensor([L], dtype=torch.int64, device="cuda")
     sizes = [torch.empty_like(base) for _ in range(world)]
@@ -973,6 +1029,11 @@ def ndjson_leg(args, torch, dist, corpus, capi, rank, world, local_rank, fence):
         out["sorted_global_positions"] = bool((pos[1:] > pos[:-1]).all()) if len(pos) > 1 else True
     out["value_GBps"] = round(total * steps / dt_scan / 1e9, 2)
     out["steps"] = steps
+    if n1 is not None:
+        out["n1_same_workload_GBps"] = round(n1, 2)
+        out["scaling_efficiency"] = round(total * steps / dt_scan / 1e9 / (world * n1), 4)
+        out["scaling_efficiency_is"] = ("value_GBps / (n_gpus x n1_same_workload_GBps): rank 0 alone over its own shard (the others waiting in a barrier) against all ranks "
+                                        "together, same run, same shards, same kernels; with_index_concat_GBps adds the gather to rank 0 and is link-bound")
     if comm is not None:
         comm.close()
     scanner.parser.close()

@@ -97,6 +97,12 @@ int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint3
 int sjgpu_minify(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, uint8_t *dst, size_t *dst_len);
 /* *ok = 1 iff buf[0..len) is well-formed UTF-8 (len == 0 => 1). */
 int sjgpu_validate_utf8(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int *ok);
+/* The same verdict with the input taken in pieces of at most piece_bytes (cut in front of a character's first byte, so every piece
+ * is well-formed or not by itself; 0 = the default, 1 GiB): what sjgpu_validate_utf8 does beyond its piece size, with the size in the
+ * caller's hand.  A piece needs piece_bytes of device memory, not len: the road a caller takes when the one-piece call failed for
+ * want of memory (the plug-in's implementation::validate_utf8 has no error channel -- include/simdjson/implementation.h:118-128 -- and
+ * retries this way before it answers). */
+int sjgpu_validate_utf8_pieces(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, size_t piece_bytes, int *ok);
 
 /* ---- device-resident entry points --------------------------------------------------------------------
  * buf_dev: device pointer, 16-byte aligned, len readable bytes (nothing is read past len).

@@ -218,10 +218,25 @@ def build_oracle():
     _run(["make", "-s", "-C", _paths.ORACLE_DIR, f"REFERENCE={_paths.REFERENCE_DIR}"])
 
 
+LOOPBACK_SRC = os.path.join(_paths.REPO_ROOT, "tests", "stubs", "rccl_loopback.cpp")
+LIB_LOOPBACK_HIP = os.path.join(TEST_BIN_DIR, "librccl_loopback_hip.so")
+
+
+def build_rccl_loopback(force=False):
+    """tests/stubs/rccl_loopback.cpp against the real HIP / RCCL headers -> build/tests/librccl_loopback_hip.so: the stand-in for librccl
+    whose ranks are threads of one process (test infrastructure: SJGPU_RCCL_LIB points libsjgpu's dlopen at it in tests/test_gpu_comm.py, so
+    sjgpu_comm_gather_indices runs with a world of two and three on a one-GPU box).  Host code only; hipcc supplies the include paths."""
+    if force or _stale(LIB_LOOPBACK_HIP, [LOOPBACK_SRC]):
+        os.makedirs(TEST_BIN_DIR, exist_ok=True)
+        _run([HIPCC, "-std=c++17", "-O2", "-fPIC", "-shared", LOOPBACK_SRC, "-o", LIB_LOOPBACK_HIP, "-lpthread"])
+    return LIB_LOOPBACK_HIP
+
+
 def build_all(force=False):
     build_corpus(force)
     build_sjgpu(force)
     build_oracle()
+    build_rccl_loopback(force)
     build_plugin(force)
     build_plugin_test(force)
     build_reference_tests(force)

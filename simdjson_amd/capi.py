@@ -22,7 +22,7 @@ F_UNCLOSED_STRING, F_UNESCAPED_CTRL, F_UTF8_ERROR, F_IDX_OVERFLOW, F_INTERNAL, F
 
 EXPORTS = [
     "sjgpu_device_count", "sjgpu_ctx_create", "sjgpu_ctx_destroy", "sjgpu_set_capacity", "sjgpu_capacity",
-    "sjgpu_last_error", "sjgpu_stage1", "sjgpu_minify", "sjgpu_validate_utf8", "sjgpu_stage1_device",
+    "sjgpu_last_error", "sjgpu_stage1", "sjgpu_minify", "sjgpu_validate_utf8", "sjgpu_validate_utf8_pieces", "sjgpu_stage1_device",
     "sjgpu_minify_device", "sjgpu_validate_utf8_device", "sjgpu_result", "sjgpu_stage1_error_from_flags",
     "sjgpu_stage1_finish_host", "sjgpu_trim_partial_utf8", "sjgpu_profile_enable", "sjgpu_profile_read", "sjgpu_set_pipeline", "sjgpu_debug_trace_stage1",
     "sjgpu_clean_cut", "sjgpu_string_parity_device", "sjgpu_stage1_shard_device", "sjgpu_minify_shard_device",
@@ -88,6 +88,8 @@ def load_library():
     L.sjgpu_minify.argtypes = [vp, vp, sz, vp, ctypes.POINTER(sz)]
     L.sjgpu_validate_utf8.restype = ctypes.c_int
     L.sjgpu_validate_utf8.argtypes = [vp, vp, sz, ctypes.POINTER(ctypes.c_int)]
+    L.sjgpu_validate_utf8_pieces.restype = ctypes.c_int
+    L.sjgpu_validate_utf8_pieces.argtypes = [vp, vp, sz, sz, ctypes.POINTER(ctypes.c_int)]
     L.sjgpu_stage1_device.restype = ctypes.c_int
     L.sjgpu_stage1_device.argtypes = [vp, vp, sz, vp, sz, vp]
     L.sjgpu_minify_device.restype = ctypes.c_int
@@ -251,10 +253,14 @@ class DomParserImplementation:
             raise SjgpuError(f"sjgpu_minify infrastructure error {rc}: {self.last_error()}")
         return rc, dst[: n.value]
 
-    def validate_utf8(self, data):
+    def validate_utf8(self, data, piece_bytes=None):
+        """piece_bytes: sjgpu_validate_utf8_pieces -- the same verdict with the input taken in pieces of that size"""
         a = _as_u8(data)
         ok = ctypes.c_int(0)
-        rc = self.L.sjgpu_validate_utf8(self.h, a.ctypes.data, len(a), ctypes.byref(ok))
+        if piece_bytes is None:
+            rc = self.L.sjgpu_validate_utf8(self.h, a.ctypes.data, len(a), ctypes.byref(ok))
+        else:
+            rc = self.L.sjgpu_validate_utf8_pieces(self.h, a.ctypes.data, len(a), int(piece_bytes), ctypes.byref(ok))
         if rc != 0:
             raise SjgpuError(f"sjgpu_validate_utf8 error {rc}: {self.last_error()}")
         return bool(ok.value)

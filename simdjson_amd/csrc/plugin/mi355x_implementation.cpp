@@ -4,8 +4,12 @@
 #include "sjgpu.h"
 
 #include <atomic>
+#include <climits>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 namespace simdjson {
@@ -223,13 +227,31 @@ public:
     return map_error(rc);
   }
 
+  // "true if and only if the string is valid UTF-8" (include/simdjson/implementation.h:118-128) -- and no error channel.  A failure of the ROAD
+  // (no context to borrow, a HIP call or an allocation that failed) is not a verdict about the bytes, so it is not answered with `false` before
+  // the road has been tried three ways: a pooled context; a FRESH one after the pool's parked memory has been given back (sjgpu_pool_trim);
+  // the input in 16 MiB pieces, which needs 16 MiB of device memory whatever len is.  Only when all three fail -- a device that is gone --
+  // does the call say `false`: there is no CPU path in this backend to ask instead.
   simdjson_warn_unused bool validate_utf8(const char *buf, size_t len) const noexcept final {
-    borrowed_ctx b;
-    if (b.rc != 0) { return false; }
-    int ok = 0;
-    const int rc = sjgpu_validate_utf8(b.ctx, reinterpret_cast<const uint8_t *>(buf), len, &ok);
-    return rc == 0 && ok != 0;
+    // test hook (plugin_test 1c): the first N attempts of every call fail as if HIP had
+    int induced = 0;
+    if (const char *v = std::getenv("SJGPU_DEBUG_UTF8_FAIL_ATTEMPTS")) { induced = std::atoi(v); }
+    for (int attempt = 0; attempt < 3; attempt++) {
+      if (attempt == 1) { (void)sjgpu_pool_trim(); }
+      borrowed_ctx b;
+      int ok = 0;
+      int rc = b.rc;
+      if (rc == 0) {
+        rc = attempt < 2 ? sjgpu_validate_utf8(b.ctx, reinterpret_cast<const uint8_t *>(buf), len, &ok)
+                         : sjgpu_validate_utf8_pieces(b.ctx, reinterpret_cast<const uint8_t *>(buf), len, size_t(16) << 20, &ok);
+      }
+      if (attempt < induced) { rc = SJGPU_E_HIP; }
+      if (rc == 0) { return ok != 0; }
+      validate_utf8_retries_.fetch_add(1, std::memory_order_relaxed);
+    }
+    return false;
   }
+  mutable std::atomic<size_t> validate_utf8_retries_{0}; // attempts that failed for a reason other than the bytes
 };
 
 } // namespace
@@ -243,6 +265,46 @@ bool available() noexcept { return sjgpu_device_count() > 0; }
 
 void register_stream(const uint8_t *buf, size_t len) noexcept { (void)sjgpu_stream_register(buf, len); }
 void unregister_stream(const uint8_t *buf) noexcept { (void)sjgpu_stream_unregister(buf); }
+
+// ---- pinned_padded_string ---------------------------------------------------------------------------------------------------------------
+pinned_padded_string::pinned_padded_string(size_t length) noexcept {
+  const size_t total = length + SIMDJSON_PADDING;
+  if (total < length) { return; } // overflow: data() stays null, like allocate_padded_buffer
+  data_ = static_cast<char *>(sjgpu_host_alloc(total));
+  if (!data_) { return; }
+  std::memset(data_ + length, 0, SIMDJSON_PADDING);
+  size_ = length;
+}
+pinned_padded_string::pinned_padded_string(const char *data, size_t length) noexcept : pinned_padded_string(length) {
+  if (data_ && data && length) { std::memcpy(data_, data, length); }
+}
+pinned_padded_string &pinned_padded_string::operator=(pinned_padded_string &&o) noexcept {
+  if (this != &o) {
+    sjgpu_host_free(data_);
+    size_ = o.size_;
+    data_ = o.data_;
+    o.size_ = 0;
+    o.data_ = nullptr;
+  }
+  return *this;
+}
+pinned_padded_string::~pinned_padded_string() noexcept { sjgpu_host_free(data_); }
+
+simdjson_result<pinned_padded_string> load_pinned(std::string_view path) noexcept {
+  const std::string name(path); // fopen wants a terminator
+  std::FILE *fp = std::fopen(name.c_str(), "rb");
+  if (!fp) { return IO_ERROR; }
+  if (std::fseek(fp, 0, SEEK_END) < 0) { std::fclose(fp); return IO_ERROR; }
+  const long llen = std::ftell(fp);
+  if (llen < 0 || llen == LONG_MAX) { std::fclose(fp); return IO_ERROR; }
+  const size_t len = size_t(llen);
+  pinned_padded_string s(len);
+  if (!s.data()) { std::fclose(fp); return MEMALLOC; }
+  std::rewind(fp);
+  const size_t got = std::fread(s.data(), 1, len, fp);
+  if (std::fclose(fp) != 0 || got != len) { return IO_ERROR; }
+  return s;
+}
 
 simdjson::error_code activate(int device) noexcept {
   if (device < 0 || device >= sjgpu_device_count()) { return UNSUPPORTED_ARCHITECTURE; }

@@ -40,6 +40,48 @@ simdjson::error_code activate(int device = 0) noexcept;
 void register_stream(const uint8_t *buf, size_t len) noexcept;
 void unregister_stream(const uint8_t *buf) noexcept;
 
+/**
+ * A document buffer in PAGE-LOCKED host memory -- SURVEY.md 8(f).1's "pinned-memory padded_string allocator", the C++ face of
+ * sjgpu_host_alloc (include/sjgpu.h).  What it replaces: simdjson::padded_string over internal::allocate_padded_buffer
+ * (/root/reference/include/simdjson/padded_string-inl.h:34-56: `new char[length + SIMDJSON_PADDING]`, padding zeroed).  Ordinary memory has to be
+ * pinned page by page by the HIP runtime on every upload of a buffer it has not seen before, which halves the upload rate (DESIGN.md
+ * section 5, host-buffer path); a buffer allocated here is locked once, when it is made.  Same shape as padded_string where it matters to a
+ * parser: size() bytes of content, SIMDJSON_PADDING zero bytes behind them, converts to padded_string_view, so
+ *     auto json = simdjson::mi355x::load_pinned("big.json");        // or pinned_padded_string(data, length)
+ *     dom::element doc = parser.parse(json.value());                 // no copy, no realloc: the view says the padding is there
+ * Move-only; the memory goes back with sjgpu_host_free.  data() == nullptr after a failed allocation (like padded_string).
+ */
+class pinned_padded_string {
+public:
+  pinned_padded_string() noexcept = default;
+  /** length bytes of uninitialised content + zeroed padding */
+  explicit pinned_padded_string(size_t length) noexcept;
+  /** a copy of data[0..length) */
+  pinned_padded_string(const char *data, size_t length) noexcept;
+  pinned_padded_string(std::string_view sv) noexcept : pinned_padded_string(sv.data(), sv.size()) {}
+  pinned_padded_string(pinned_padded_string &&o) noexcept : size_(o.size_), data_(o.data_) { o.size_ = 0; o.data_ = nullptr; }
+  pinned_padded_string &operator=(pinned_padded_string &&o) noexcept;
+  pinned_padded_string(const pinned_padded_string &) = delete;
+  pinned_padded_string &operator=(const pinned_padded_string &) = delete;
+  ~pinned_padded_string() noexcept;
+
+  size_t size() const noexcept { return size_; }
+  size_t length() const noexcept { return size_; }
+  const char *data() const noexcept { return data_; }
+  char *data() noexcept { return data_; }
+  const uint8_t *u8data() const noexcept { return reinterpret_cast<const uint8_t *>(data_); }
+  /** content + padding: what dom::parser::parse / ondemand::parser::iterate take without copying */
+  operator padded_string_view() const noexcept { return padded_string_view(data_, size_, size_ + SIMDJSON_PADDING); }
+  operator std::string_view() const noexcept { return std::string_view(data_, size_); }
+
+private:
+  size_t size_ = 0;
+  char *data_ = nullptr;
+};
+
+/** padded_string::load (/root/reference/include/simdjson/padded_string-inl.h:175-231) into page-locked memory: IO_ERROR / MEMALLOC as there. */
+simdjson_result<pinned_padded_string> load_pinned(std::string_view path) noexcept;
+
 } // namespace mi355x
 } // namespace simdjson
 

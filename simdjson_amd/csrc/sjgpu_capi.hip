@@ -1813,13 +1813,14 @@ int sjgpu_minify(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, uint8_t *dst, s
 
 // No length limit either (include/simdjson/implementation.h:128): pieces are cut in front of a character's first byte, so
 // each piece is well-formed or not by itself.
-int sjgpu_validate_utf8(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int *ok) {
+int sjgpu_validate_utf8_pieces(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, size_t piece, int *ok) {
   if (!ctx || !ok) { return SJGPU_E_BADARG; }
   *ok = 1;
   if (len == 0) { return 0; }
   if (!buf) { return SJGPU_E_BADARG; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
-  const size_t piece = piece_bytes();
+  if (piece == 0) { piece = piece_bytes(); }
+  if (piece < 64) { piece = 64; }
   size_t at = 0;
   while (at < len) {
     size_t cut = len;
@@ -1835,5 +1836,6 @@ int sjgpu_validate_utf8(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int *ok)
   }
   return 0;
 }
+int sjgpu_validate_utf8(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int *ok) { return sjgpu_validate_utf8_pieces(ctx, buf, len, 0, ok); }
 
 } // extern "C"

@@ -19,6 +19,7 @@
 #include <chrono>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 
@@ -53,6 +54,23 @@ static inline hipError_t hipMemsetD32Async(hipDeviceptr_t p, int v, size_t count
 }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
+// the memory and stream calls of the host-side code that is run here too (sjgpu_comm.hip: tests/host/test_comm_emu.cpp): device memory is
+// the host's, a stream is the calling thread (everything "enqueued" has happened when the call returns), there is one device
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+constexpr unsigned hipHostMallocDefault = 0;
+namespace sj_emu { extern size_t fail_allocations_above; } // test hook: hipMalloc of more bytes than this fails (default: never)
+static inline hipError_t hipMalloc(void **p, size_t n) {
+  if (n > sj_emu::fail_allocations_above) { *p = nullptr; return hipErrorOutOfMemory; }
+  *p = std::malloc(n ? n : 1);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+static inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(dst, src, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 
 namespace sj_emu {
 struct fiber_ids { dim3 tid; unsigned lane, wave; };

@@ -43,6 +43,7 @@ sj_emu_switch:
 namespace sj_emu {
 
 unsigned max_concurrent_workgroups = 4;
+size_t fail_allocations_above = ~size_t(0);
 
 namespace {
 

@@ -6,6 +6,8 @@
 // oracle/_ref/simdjson_ref.o), run on the GPU box by tests/test_plugin.py.
 #include "mi355x_implementation.h"
 
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -332,6 +334,83 @@ int main(int argc, char **argv) {
     std::vector<char> out(16);
     size_t n = 99;
     CHECK(simdjson::minify(unclosed.data(), unclosed.size(), out.data(), n) == UNCLOSED_STRING && n == 0, "minify unclosed");
+  }
+  // 5b. validate_utf8 has no error channel: a failure of the ROAD (context, HIP call, allocation) must not be answered as "invalid UTF-8"
+  //     (include/simdjson/implementation.h:118-128: "true if and only if the string is valid UTF-8").  The hook fails the first N attempts of a call:
+  //     one failure -> the retry on a fresh context answers; two -> the 16 MiB-piece road answers; three -> nothing is left, and only then `false`.
+  for (const char *fails : {"1", "2"}) {
+    setenv("SJGPU_DEBUG_UTF8_FAIL_ATTEMPTS", fails, 1);
+    CHECK(simdjson::validate_utf8(twitter.data(), twitter.size()), "valid UTF-8 answered as invalid after %s failed attempt(s) of the road", fails);
+    CHECK(!simdjson::validate_utf8(badutf.data(), badutf.size()), "invalid UTF-8 accepted after %s failed attempt(s)", fails);
+  }
+  setenv("SJGPU_DEBUG_UTF8_FAIL_ATTEMPTS", "3", 1);
+  CHECK(!simdjson::validate_utf8(twitter.data(), twitter.size()), "a road that fails three ways cannot say true");
+  unsetenv("SJGPU_DEBUG_UTF8_FAIL_ATTEMPTS");
+  CHECK(simdjson::validate_utf8(twitter.data(), twitter.size()), "validate_utf8 after the hook is gone");
+  std::printf("validate_utf8 retries a failing road before it answers: OK\n");
+
+  // 6. the pinned padded_string: same bytes, zeroed padding, converts to padded_string_view, parses to the same document --
+  //    and load_pinned() mirrors padded_string::load
+  {
+    mi355x::pinned_padded_string pinned(twitter.data(), twitter.size());
+    CHECK(pinned.data() != nullptr && pinned.size() == twitter.size() && std::memcmp(pinned.data(), twitter.data(), twitter.size()) == 0, "pinned copy differs");
+    for (size_t i = 0; i < SIMDJSON_PADDING; i++) { CHECK(pinned.data()[pinned.size() + i] == 0, "padding byte %zu is not zero", i); }
+    padded_string_view view = pinned;
+    CHECK(view.size() == twitter.size() && view.padding() >= SIMDJSON_PADDING, "view of the pinned string: %zu bytes, %zu padding", view.size(), view.padding());
+    dom::parser pa, pb;
+    dom::element ea, eb;
+    CHECK(pa.parse(twitter).get(ea) == SUCCESS && pb.parse(view).get(eb) == SUCCESS, "parse of the pinned string");
+    CHECK(simdjson::minify(ea) == simdjson::minify(eb), "the pinned string parses to a different document");
+    mi355x::pinned_padded_string moved(std::move(pinned));
+    CHECK(pinned.data() == nullptr && pinned.size() == 0 && moved.size() == twitter.size(), "move");
+    auto loaded = mi355x::load_pinned(examples + "/twitter.json");
+    auto plain = padded_string::load(examples + "/twitter.json");
+    CHECK(loaded.error() == plain.error(), "load_pinned error %d vs %d", int(loaded.error()), int(plain.error()));
+    if (!plain.error()) {
+      CHECK(loaded.value().size() == plain.value().size() && std::memcmp(loaded.value().data(), plain.value().data(), plain.value().size()) == 0, "load_pinned bytes");
+    }
+    CHECK(mi355x::load_pinned("/nonexistent/file.json").error() == IO_ERROR, "load_pinned of a missing file");
+    std::printf("pinned_padded_string / load_pinned: OK\n");
+  }
+  // 6b. (--bench-pinned, bench.py plugin_host_path.pinned_padded_string) dom::parser::parse of a 256 MiB document from ordinary memory the runtime has
+  //     not seen before (a fresh padded_string per parse: what an application that reads a new document every time pays) against the same bytes in a
+  //     pinned_padded_string
+  for (int i = 1; i < argc; i++) {
+    if (std::strcmp(argv[i], "--bench-pinned") != 0) { continue; }
+    const size_t target = (i + 1 < argc) ? size_t(std::strtoull(argv[i + 1], nullptr, 10)) : (size_t(256) << 20);
+    padded_string big = gen(sjc_twitter_like, target, 91);
+    dom::parser parser;
+    CHECK(parser.allocate(big.size()) == SUCCESS, "allocate");
+    dom::element e;
+    CHECK(parser.parse(big).get(e) == SUCCESS, "warm-up parse");
+    const std::string want = std::to_string(parser.doc.tape[0]) + "/" + std::to_string(simdjson::minify(e).size());
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double best_fresh = 1e9, best_pinned = 1e9, best_same = 1e9;
+    const int reps = 4;
+    std::vector<padded_string> fresh;
+    for (int r = 0; r < reps; r++) { fresh.emplace_back(big.data(), big.size()); } // distinct allocations, never uploaded before
+    for (int r = 0; r < reps; r++) {
+      const double t0 = now();
+      CHECK(parser.parse(fresh[size_t(r)]).get(e) == SUCCESS, "parse (fresh pageable)");
+      best_fresh = std::min(best_fresh, now() - t0);
+    }
+    for (int r = 0; r < reps; r++) {
+      const double t0 = now();
+      CHECK(parser.parse(big).get(e) == SUCCESS, "parse (same pageable buffer again)");
+      best_same = std::min(best_same, now() - t0);
+    }
+    mi355x::pinned_padded_string pinned(big.data(), big.size());
+    CHECK(pinned.data() != nullptr, "page-locked allocation of %zu bytes", big.size());
+    for (int r = 0; r < reps; r++) {
+      const double t0 = now();
+      CHECK(parser.parse(padded_string_view(pinned)).get(e) == SUCCESS, "parse (pinned)");
+      best_pinned = std::min(best_pinned, now() - t0);
+    }
+    const std::string got = std::to_string(parser.doc.tape[0]) + "/" + std::to_string(simdjson::minify(e).size());
+    CHECK(got == want, "the pinned parse left another document (%s vs %s)", got.c_str(), want.c_str());
+    std::printf("{\"pinned_bench\": {\"bytes\": %zu, \"fresh_pageable_ms\": %.3f, \"same_pageable_buffer_again_ms\": %.3f, \"pinned_padded_string_ms\": %.3f, "
+                "\"speedup_vs_fresh_pageable\": %.3f}}\n",
+                big.size(), best_fresh * 1e3, best_same * 1e3, best_pinned * 1e3, best_fresh / best_pinned);
   }
   get_active_implementation() = before;
   std::printf("plugin test OK\n");

@@ -799,6 +799,8 @@ def test_minify_and_validate_in_pieces(orc, monkeypatch):
         oerr, oout = orc.minify(a)
         assert gerr == oerr and np.array_equal(gout, oout), (name, gerr, oerr, len(gout), len(oout))
         assert p.validate_utf8(a) == orc.validate_utf8(a), name
+        for piece in (64, 100_003, 3 << 20):  # sjgpu_validate_utf8_pieces: the piece size in the caller's hand (what the plug-in retries with)
+            assert p.validate_utf8(a[: 2 * M + 4096], piece_bytes=piece) == orc.validate_utf8(a[: 2 * M + 4096]), (name, piece)
     p.close()
 
 
