@@ -235,11 +235,15 @@ void release_staging(sjgpu_ctx *ctx) {
   ctx->d_idx_words = 0;
 }
 
-// [result][tile descriptors][ticket]: one allocation, so that the single-pass launcher clears all of it at once
+// [result][tile descriptors][control words]: one allocation, cleared ONCE, here -- every single-pass kernel puts what it used back to zero when it
+// ends (sjgpu_fused.hip: leave_and_clean), so the calls themselves enqueue no clear (rounds 1-4: a hipMemsetAsync in front of every call)
 int alloc_result(sjgpu_ctx *ctx, size_t for_len) {
   const size_t tiles = for_len ? num_fused_tiles(for_len) : 0;
-  SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_result), sizeof(scan_result_dev) + (tiles + 1) * sizeof(uint64_t)));
+  const size_t bytes = sizeof(scan_result_dev) + (tiles + FUSED_WORKSPACE_EXTRA_WORDS) * sizeof(uint64_t);
+  SJ_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_result), bytes));
   ctx->desc = reinterpret_cast<uint64_t *>(ctx->d_result + 1);
+  SJ_TRY(ctx, hipMemsetAsync(ctx->d_result, 0, bytes, nullptr));
+  SJ_TRY(ctx, hipStreamSynchronize(nullptr)); // (the calls run on other streams: the zeros are there before any of them is enqueued)
   return 0;
 }
 
@@ -353,7 +357,7 @@ void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, 
   if (ctx->enqueue_rc) { return; }
   ctx->last_pipeline = fused ? 1 : 0;
   ctx->pending_scan_bytes = (org.begin == 0 && org.base0 == 0 && len >= AUTO_FUSED_FROM) ? len : 0;
-  if (fused) { ctx->last_kernel = launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, org, ctx->max_workgroups, s, ev); }
+  if (fused) { ctx->last_kernel = launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, org, ctx->max_workgroups, s, ev, true); }
   else {
     launch_stage1(buf, len, ctx->masks, ctx->summ, ctx->pref, idx, idx_words, ctx->d_result, org, s, ev);
     ctx->last_kernel = "k_stage1_summarize+k_resolve_groups+k_resolve_segments+k_stage1_emit";
@@ -365,7 +369,7 @@ void enqueue_minify(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, 
   if (ctx->enqueue_rc) { return; }
   ctx->last_pipeline = fused ? 1 : 0;
   ctx->pending_scan_bytes = 0;
-  if (fused) { ctx->last_kernel = launch_minify_fused(buf, len, ctx->desc, dst, ctx->d_result, org, ctx->max_workgroups, s, ev); }
+  if (fused) { ctx->last_kernel = launch_minify_fused(buf, len, ctx->desc, dst, ctx->d_result, org, ctx->max_workgroups, s, ev, true); }
   else {
     launch_minify(buf, len, ctx->summ, ctx->pref, dst, ctx->d_result, org, s, ev);
     ctx->last_kernel = "k_minify_summarize+k_resolve_groups+k_resolve_segments+k_minify_emit";

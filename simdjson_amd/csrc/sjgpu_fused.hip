@@ -50,6 +50,37 @@ __device__ __forceinline__ u64 make_incl(u32 s, u32 x, u32 base) { return (ST_IN
 __device__ __forceinline__ u64 desc_load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void desc_store(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// ---- the workspace cleans itself (round 5) ----------------------------------------------------------------
+// Rounds 1-4 cleared result, descriptors and ticket with a hipMemsetAsync in front of every call: a fill kernel and a dispatch gap, 10-18 us of
+// a 0.49 ms call and most of a 16 us one.  Now the LAST workgroup to leave a kernel puts everything back to zero for the next call, and a call
+// is ONE dispatch.  Behind the ntiles descriptors lie the control words (fused_ctl_words): [ticket][done][flags][pad].  A workgroup that has
+// finished its last tile -- it will read no descriptor, draw no ticket and raise no flag any more -- adds itself to `done`; the one that
+// finds everybody else gone moves the accumulated flags into the result and zeroes descriptors and control words.  Flags are ORed into the
+// control word, not into the result: the result needs no clearing either (its other two fields are written by the last TILE's owner).
+// The host clears once, when the workspace is allocated (and after a traced / aborted run: fused_workspace::clean in sjgpu_internal.h).
+constexpr u32 FUSED_CTL_WORDS = 2; // u64 words behind the descriptors
+__device__ __forceinline__ u32 *ctl_done(u32 *ticket) { return ticket + 1; }
+__device__ __forceinline__ u32 *ctl_flags(u32 *ticket) { return ticket + 2; }
+// all threads of the workgroup, behind its last tile
+template <u32 THREADS>
+__device__ __forceinline__ void leave_and_clean(u64 *desc, u32 ntiles, u32 *ticket, scan_result_dev *result) {
+  __shared__ u32 sh_last;
+  __threadfence(); // what this wave stored and ORed has been performed device-wide before the workgroup counts itself out
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const bool last = atomicAdd(ctl_done(ticket), 1u) == gridDim.x - 1u;
+    if (last) { // the flags are read BEFORE the barrier that lets the other waves of this workgroup start zeroing (the flag word among the rest)
+      __threadfence();
+      result->flags = __hip_atomic_load(ctl_flags(ticket), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    sh_last = last ? 1u : 0u;
+  }
+  lds_writes_done();
+  __syncthreads();
+  if (sh_last == 0u) { return; }
+  for (u32 i = threadIdx.x; i < ntiles + FUSED_CTL_WORDS; i += THREADS) { desc_store(desc + i, 0ull); }
+}
+
 // Wave-wide look-back for tile `tile` (all 64 lanes of ONE wave call this).  On success S = in-string at
 // the tile start, X = x in front of the tile, B = output cursor at the tile start.
 // State of a walk: the summary of tiles [end, tile) in its compact form (sj_xcarry.h: parity, the two counts, x word), which maps
@@ -341,15 +372,17 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
                 f |= SJGPU_F_IDX_OVERFLOW;
               }
               result->n = total;
+              result->out_len = 0;
             } else {
+              result->n = 0;
               result->out_len = (s_end && !(carry & CARRY_SHARD)) ? 0ull : u64(total); // json_minifier.h:42-47
             }
             if ((carry & CARRY_MORE) && te.x_out) { f |= SJGPU_F_RANGE_CARRY; }
-            if (f) { atomicOr(&result->flags, f); }
+            if (f) { atomicOr(ctl_flags(ticket), f); }
           }
         } else {
           desc_store(desc + tile, ST_POISON << 62);
-          atomicOr(&result->flags, SJGPU_F_INTERNAL);
+          atomicOr(ctl_flags(ticket), SJGPU_F_INTERNAL);
         }
         sh_prefix[0] = S;
         sh_prefix[1] = B;
@@ -370,7 +403,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
       const u32 f = sh_wave[wave][3];
       u32 g = 0;
       if (f & (own.se ? WF_CTRL_IF_IN : WF_CTRL_IF_OUT)) { g |= SJGPU_F_UNESCAPED_CTRL; }
-      if (g && lane == 0) { atomicOr(&result->flags, g); }
+      if (g && lane == 0) { atomicOr(ctl_flags(ticket), g); }
     }
     const u64 flip = own.se ? ~0ull : 0ull;
     const bool patch = OP == 0 && x != 0u && own.dcount != 0; // wave-uniform
@@ -398,13 +431,14 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
                    reinterpret_cast<u8 *>(sh_stage[wave]), sh_lut);
       }
     }
-    if (OP == 0 && __ballot(overflow) && lane == 0) { atomicOr(&result->flags, SJGPU_F_IDX_OVERFLOW); }
+    if (OP == 0 && __ballot(overflow) && lane == 0) { atomicOr(ctl_flags(ticket), SJGPU_F_IDX_OVERFLOW); }
     SJ_STAMP(6); // wave 0 finished emitting
   }
   if (OP == 0) { // what is left of the wave's UTF-8 list, then its verdict
     utf8_drain_rest(uq, buf, len, more, lane);
-    if (uq.error && lane == 0) { atomicOr(&result->flags, SJGPU_F_UTF8_ERROR); }
+    if (uq.error && lane == 0) { atomicOr(ctl_flags(ticket), SJGPU_F_UTF8_ERROR); }
   }
+  leave_and_clean<256>(desc, ntiles, ticket, result);
 #undef SJ_STAMP
 }
 
@@ -609,15 +643,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                   f |= SJGPU_F_IDX_OVERFLOW;
                 }
                 result->n = total;
+                result->out_len = 0;
               } else {
+                result->n = 0;
                 result->out_len = (s_end && !(carry & CARRY_SHARD)) ? 0ull : u64(total);
               }
               if ((carry & CARRY_MORE) && te.x_out) { f |= SJGPU_F_RANGE_CARRY; }
-              if (f) { atomicOr(&result->flags, f); }
+              if (f) { atomicOr(ctl_flags(ticket), f); }
             }
           } else {
             desc_store(desc + pend_tile, ST_POISON << 62);
-            atomicOr(&result->flags, SJGPU_F_INTERNAL);
+            atomicOr(ctl_flags(ticket), SJGPU_F_INTERNAL);
           }
           sh_prefix[0] = S;
           sh_prefix[1] = B;
@@ -642,7 +678,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         const u32 f = sh_wave[cur ^ 1u][wave][3];
         u32 g = 0;
         if (f & (own.se ? WF_CTRL_IF_IN : WF_CTRL_IF_OUT)) { g |= SJGPU_F_UNESCAPED_CTRL; }
-        if (g && lane == 0) { atomicOr(&result->flags, g); }
+        if (g && lane == 0) { atomicOr(ctl_flags(ticket), g); }
         const u64 flip = own.se ? ~0ull : 0ull;
         bool overflow = false;
         if (OP == 0) { // sparse spans leave in one piece, medium ones as two pairs of chunks, dense ones chunk by chunk
@@ -672,7 +708,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                        reinterpret_cast<u8 *>(sh_stage[wave]), sh_lut);
           }
         }
-        if (OP == 0 && __ballot(overflow) && lane == 0) { atomicOr(&result->flags, SJGPU_F_IDX_OVERFLOW); }
+        if (OP == 0 && __ballot(overflow) && lane == 0) { atomicOr(ctl_flags(ticket), SJGPU_F_IDX_OVERFLOW); }
       }
     }
     SJ_PSTAMP(6);
@@ -695,8 +731,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   }
   if (OP == 0) { // what is left of the wave's UTF-8 list, then its verdict
     utf8_drain_rest(uq, buf, len, more, lane);
-    if (uq.error && lane == 0) { atomicOr(&result->flags, SJGPU_F_UTF8_ERROR); }
+    if (uq.error && lane == 0) { atomicOr(ctl_flags(ticket), SJGPU_F_UTF8_ERROR); }
   }
+  leave_and_clean<NW * 64>(desc, ntiles, ticket, result);
 #undef SJ_PSTAMP
 }
 
@@ -824,13 +861,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
             const u32 total = B + xs_count(tout, tin, te), s_end = te.s_out;
             desc_store(desc + pend_tile, make_incl(s_end, te.x_out, total));
             if (pend_tile == ntiles - 1) { // the last tile knows the totals
-              if (s_end) { atomicOr(&result->flags, SJGPU_F_UNCLOSED_STRING); }
-              if ((carry & CARRY_MORE) && te.x_out) { atomicOr(&result->flags, SJGPU_F_RANGE_CARRY); }
+              if (s_end) { atomicOr(ctl_flags(ticket), SJGPU_F_UNCLOSED_STRING); }
+              if ((carry & CARRY_MORE) && te.x_out) { atomicOr(ctl_flags(ticket), SJGPU_F_RANGE_CARRY); }
+              result->n = 0;
               result->out_len = (s_end && !(carry & CARRY_SHARD)) ? 0ull : u64(total); // json_minifier.h:42-47
             }
           } else {
             desc_store(desc + pend_tile, ST_POISON << 62);
-            atomicOr(&result->flags, SJGPU_F_INTERNAL);
+            atomicOr(ctl_flags(ticket), SJGPU_F_INTERNAL);
           }
           sh_prefix[0] = S;
           sh_prefix[1] = B;
@@ -884,6 +922,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     if (threadIdx.x == 0) { sh_tile[cur ^ 1u] = have ? next_ticket : NO_TILE; }
     lds_writes_done(); // see the comment there: the barrier at the loop top must find the ticket in LDS
   }
+  leave_and_clean<NW * 64>(desc, ntiles, ticket, result);
 }
 
 
@@ -894,20 +933,28 @@ static inline void mark(hipEvent_t *ev, int k, hipStream_t stream) {
   if (ev) { (void)hipEventRecord(ev[k], stream); }
 }
 
+// clean: the workspace (result, descriptors, control words) is all zero on the device -- every kernel below leaves it that way -- so
+// nothing is cleared; else (first use after something else wrote there, A/B switch SJGPU_FUSED_MEMSET) one memset in front of the kernel
+static void clear_fused_workspace(scan_result_dev *result, uint64_t *desc, u32 ntiles, bool clean, hipStream_t stream) {
+  static const bool always = std::getenv("SJGPU_FUSED_MEMSET") != nullptr; // A/B switch: the clear of rounds 1-4 in front of every call
+  if (clean && !always) { return; }
+  const size_t words = size_t(ntiles) + FUSED_CTL_WORDS;
+  if (reinterpret_cast<uint64_t *>(result + 1) == desc) { // laid out back to back by the context: one clear
+    (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev) + words * sizeof(u64), stream);
+  } else {
+    (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
+    (void)hipMemsetAsync(desc, 0, words * sizeof(u64), stream);
+  }
+}
+
 template <u32 WC>
 static void launch_fused_wc(int op, const uint8_t *buf, uint64_t len, uint64_t *desc, void *out, uint64_t out_words,
                             scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
-                            hipEvent_t *ev, uint64_t *trace, uint32_t trace_tiles) {
+                            hipEvent_t *ev, uint64_t *trace, uint32_t trace_tiles, bool clean) {
   constexpr u64 tile_bytes = u64(FUSED_WAVES) * WC * CHUNK_BYTES;
   const u32 ntiles = u32((len - org.begin + tile_bytes - 1) / tile_bytes);
   u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles);
-  // result, descriptors and ticket are cleared by ONE memset when the context laid them out back to back
-  if (reinterpret_cast<uint64_t *>(result + 1) == desc) {
-    (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev) + (size_t(ntiles) + 1) * sizeof(u64), stream);
-  } else {
-    (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
-    (void)hipMemsetAsync(desc, 0, (size_t(ntiles) + 1) * sizeof(u64), stream);
-  }
+  clear_fused_workspace(result, desc, ntiles, clean && !trace, stream);
   const u32 grid = ntiles < max_workgroups ? ntiles : max_workgroups;
   u64 *no_trace = nullptr;
   if (trace) {
@@ -929,14 +976,14 @@ uint64_t debug_fused_small_below = FUSED_SMALL_BELOW;
 // returns the name of the scan kernel it launched (sjgpu_profile_kernel)
 static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *desc, void *out, uint64_t out_words,
                                 scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
-                                hipEvent_t *ev, uint64_t *trace = nullptr, uint32_t trace_tiles = 0) {
+                                hipEvent_t *ev, uint64_t *trace = nullptr, uint32_t trace_tiles = 0, bool clean = false) {
   static const bool plain = std::getenv("SJGPU_FUSED_PLAIN") != nullptr; // A/B switch: the non-pipelined large-input kernel
   mark(ev, 0, stream); // slot 0 = everything this call enqueues (the clear, the scan kernel)
   if (len - org.begin <= debug_fused_small_below && !trace) {
-    launch_fused_wc<1>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles);
+    launch_fused_wc<1>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles, clean);
     return op == 0 ? "k_fused<0> (16 KiB tiles)" : "k_fused<1> (16 KiB tiles)";
   } else if (trace || plain) {
-    launch_fused_wc<FUSED_WAVE_CHUNKS>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles);
+    launch_fused_wc<FUSED_WAVE_CHUNKS>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles, clean);
     return op == 0 ? "k_fused<0> (64 KiB tiles)" : "k_fused<1> (64 KiB tiles)";
   } else {
     static const bool onchip = []() { const char *v = std::getenv("SJGPU_MINIFY_ONCHIP"); return !v || v[0] != '0'; }(); // A/B: 0 = the re-reading kernel
@@ -954,15 +1001,7 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
     const u64 tile_bytes = onchip_waves ? u64(onchip_waves) * ONCHIP_WAVE_CHUNKS * CHUNK_BYTES : u64(s1_waves) * FUSED_WAVE_CHUNKS * CHUNK_BYTES;
     const u32 ntiles = u32((len - org.begin + tile_bytes - 1) / tile_bytes);
     u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles);
-    // result, descriptors and ticket lie back to back (sjgpu_capi.hip): one clear
-    const bool contiguous = reinterpret_cast<uint64_t *>(result + 1) == desc;
-    const size_t clear_bytes = sizeof(scan_result_dev) + (size_t(ntiles) + 1) * sizeof(u64);
-    if (contiguous) {
-      (void)hipMemsetAsync(result, 0, clear_bytes, stream);
-    } else {
-      (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
-      (void)hipMemsetAsync(desc, 0, (size_t(ntiles) + 1) * sizeof(u64), stream);
-    }
+    clear_fused_workspace(result, desc, ntiles, clean, stream); // (a clean workspace -- every call but the first -- needs none: leave_and_clean)
     // half as many workgroups as tiles at most: every workgroup should own >= 2 tiles for the deferral to work
     const u32 cap = (ntiles + 1) / 2;
     const u32 grid = cap < max_workgroups ? cap : max_workgroups;
@@ -990,10 +1029,9 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
     }
     static const unsigned pipe_wc = []() { const char *v = std::getenv("SJGPU_PIPE_WC"); return v ? unsigned(std::atoi(v)) : 4u; }(); // A/B switch: 2 = 32 KiB tiles
     if (op == 0 && pipe_wc == 2u) {
-      const u32 nt2 = u32((len - org.begin + FUSED_TILE_BYTES / 2 - 1) / (FUSED_TILE_BYTES / 2));
+      const u32 nt2 = u32((len - org.begin + FUSED_TILE_BYTES / 2 - 1) / (FUSED_TILE_BYTES / 2)); // (the clear above covered fewer, larger tiles: clear again)
       u32 *ticket2 = reinterpret_cast<u32 *>(desc + nt2);
-      const size_t clear2 = sizeof(scan_result_dev) + (size_t(nt2) + 1) * sizeof(u64);
-      if (contiguous) { (void)hipMemsetAsync(result, 0, clear2, stream); } else { (void)hipMemsetAsync(desc, 0, (size_t(nt2) + 1) * sizeof(u64), stream); }
+      clear_fused_workspace(result, desc, nt2, false, stream);
       const u32 cap2 = (nt2 + 1) / 2;
       hipLaunchKernelGGL((k_fused_pipelined<0, false, 2>), dim3(cap2 < max_workgroups ? cap2 : max_workgroups), dim3(256), 0, stream, buf, len, desc, ticket2, nt2, out, out_words,
                          result, org);
@@ -1018,8 +1056,8 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
 }
 
 const char *launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
-                                scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev) {
-  return launch_fused(0, buf, len, desc, idx, idx_words, result, org, max_workgroups, stream, ev);
+                                scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev, bool clean) {
+  return launch_fused(0, buf, len, desc, idx, idx_words, result, org, max_workgroups, stream, ev, nullptr, 0, clean);
 }
 // one traced run of the pipelined stage-1 kernel; trace holds *grid_out x PIPE_TRACE_ITERS x 8 stamps (zero = not reached)
 uint32_t launch_stage1_pipelined_traced(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
@@ -1029,7 +1067,7 @@ uint32_t launch_stage1_pipelined_traced(const uint8_t *buf, uint64_t len, uint64
   const u32 ntiles = u32((len + FUSED_TILE_BYTES - 1) / FUSED_TILE_BYTES);
   u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles);
   (void)hipMemsetAsync(result, 0, sizeof(scan_result_dev), stream);
-  (void)hipMemsetAsync(desc, 0, (size_t(ntiles) + 1) * sizeof(u64), stream);
+  (void)hipMemsetAsync(desc, 0, (size_t(ntiles) + FUSED_CTL_WORDS) * sizeof(u64), stream);
   const u32 cap = (ntiles + 1) / 2;
   u32 grid = cap < max_workgroups ? cap : max_workgroups;
   if (grid > max_records / PIPE_TRACE_ITERS) { return 0; }
@@ -1043,8 +1081,8 @@ void launch_stage1_fused_traced(const uint8_t *buf, uint64_t len, uint64_t *desc
   launch_fused(0, buf, len, desc, idx, idx_words, result, scan_origin{0, 0, 0}, max_workgroups, stream, nullptr, trace, trace_tiles);
 }
 const char *launch_minify_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint8_t *dst, scan_result_dev *result,
-                                scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev) {
-  return launch_fused(1, buf, len, desc, dst, 0, result, org, max_workgroups, stream, ev);
+                                scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev, bool clean) {
+  return launch_fused(1, buf, len, desc, dst, 0, result, org, max_workgroups, stream, ev, nullptr, 0, clean);
 }
 
 } // namespace sjgpu

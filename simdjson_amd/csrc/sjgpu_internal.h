@@ -107,10 +107,14 @@ constexpr size_t SEGMENT_BYTES_TABLE = ((uint64_t(1) << 32) / SEG_BYTES + 1024) 
 // more: the input continues behind len
 void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *result, hipStream_t stream, hipEvent_t *ev,
                           uint64_t begin = 0, bool more = false);
-// single-pass variants: desc holds num_fused_tiles(capacity)+1 words; only profile slot 0 is used
+// single-pass variants: desc holds num_fused_tiles(capacity) + FUSED_WORKSPACE_EXTRA_WORDS words; only profile slot 0 is used.
+// clean: *result, the descriptors and the control words behind them are all zero on the device.  Every (un-traced) single-pass kernel leaves them
+// that way when it ends -- its last workgroup to leave clears what the call used (sjgpu_fused.hip: leave_and_clean) -- so a caller that cleared the
+// whole workspace once, when it allocated it, passes true from then on and a call is ONE dispatch; with false the launcher clears in front of the kernel.
+constexpr uint32_t FUSED_WORKSPACE_EXTRA_WORDS = 2; // control words: ticket, workgroups gone, flags
 const char *launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
                                 scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
-                                hipEvent_t *ev); // -> name of the scan kernel launched
+                                hipEvent_t *ev, bool clean = false); // -> name of the scan kernel launched
 void launch_stage1_fused_traced(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
                                 scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, uint64_t *trace,
                                 uint32_t trace_tiles); // 8 wall_clock64 stamps (100 MHz) per tile
@@ -155,7 +159,7 @@ uint32_t launch_stage1_pipelined_traced(const uint8_t *buf, uint64_t len, uint64
                                         scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream,
                                         uint64_t *trace, uint32_t max_records); // -> workgroups launched (32 records of 8 stamps each)
 const char *launch_minify_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint8_t *dst, scan_result_dev *result,
-                                scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev);
+                                scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev, bool clean = false);
 
 // ---- strings (sjgpu_strings.hip) -------------------------------------------------------------------------------
 struct strings_result_dev {

@@ -196,6 +196,21 @@ struct workspace {
 };
 
 static unsigned long n_checked = 0, n_failed = 0;
+static void report(const char *what, const bytes &doc, const char *detail);
+// the single-pass kernels are launched with clean = true (nothing is cleared in front of them) and must leave the workspace as they found it:
+// descriptors, ticket, the count of workgroups gone and the flag word all zero again (sjgpu_fused.hip: leave_and_clean)
+static void check_workspace_clean(workspace &w, const bytes &doc, const char *what) {
+  n_checked++;
+  for (size_t i = 2; i < w.result_and_desc.size(); i++) {
+    if (w.result_and_desc[i] != 0) {
+      char detail[96];
+      snprintf(detail, sizeof detail, "workspace word %zu is %llx behind the kernel", i - 2, (unsigned long long)w.result_and_desc[i]);
+      report(what, doc, detail);
+      std::fill(w.result_and_desc.begin() + 2, w.result_and_desc.end(), 0);
+      return;
+    }
+  }
+}
 static void report(const char *what, const bytes &doc, const char *detail) {
   n_failed++;
   fprintf(stderr, "MISMATCH %s: len %zu: %s\n", what, doc.size(), detail);
@@ -302,10 +317,14 @@ int main(int argc, char **argv) {
         debug_fused_small_below = large ? 1 : FUSED_SMALL_BELOW; // 1: every document takes the pipelined 64 KiB-tile kernels
         scan_origin org = whole;
         std::fill(w.idx.begin(), w.idx.begin() + len + 8, 0xDEADBEEFu);
-        launch_stage1_fused(w.in, len, w.desc(), w.idx.data(), len + 3, w.result(), org, 6, nullptr, nullptr);
+        *w.result() = scan_result_dev{0xDEADBEEFu, 0xFFFFFFFFu, ~0ull}; // nothing clears the result either: every field is written
+        launch_stage1_fused(w.in, len, w.desc(), w.idx.data(), len + 3, w.result(), org, 6, nullptr, nullptr, true);
         check_stage1(large ? "pipelined stage 1" : "fused stage 1 (16 KiB tiles)", doc, e, w);
-        launch_minify_fused(w.in, len, w.desc(), w.out.data(), w.result(), org, 6, nullptr, nullptr);
+        check_workspace_clean(w, doc, large ? "pipelined stage 1" : "fused stage 1 (16 KiB tiles)");
+        *w.result() = scan_result_dev{0xDEADBEEFu, 0xFFFFFFFFu, ~0ull};
+        launch_minify_fused(w.in, len, w.desc(), w.out.data(), w.result(), org, 6, nullptr, nullptr, true);
         check_minify(large ? "on-chip minify" : "fused minify (16 KiB tiles)", doc, e, w);
+        check_workspace_clean(w, doc, large ? "on-chip minify" : "fused minify (16 KiB tiles)");
       }
       debug_fused_small_below = FUSED_SMALL_BELOW;
     }
@@ -327,7 +346,7 @@ int main(int argc, char **argv) {
           const size_t end = b + RANGE_ALIGN < len ? b + RANGE_ALIGN : len;
           const bool last = end == len;
           scan_origin org{uint64_t(b), cursor, (in_string ? CARRY_IN_STRING : 0u) | (x_carry ? CARRY_X : 0u) | CARRY_SHARD | (last ? 0u : CARRY_MORE)};
-          if (fused) { launch_stage1_fused(w.in, end, w.desc(), w.idx.data(), len + 3, w.result(), org, 6, nullptr, nullptr); }
+          if (fused) { launch_stage1_fused(w.in, end, w.desc(), w.idx.data(), len + 3, w.result(), org, 6, nullptr, nullptr, true); }
           else { launch_stage1(w.in, end, w.masks.data(), w.summ.data(), w.pref.data(), w.idx.data(), len + 3, w.result(), org, nullptr, nullptr); }
           flags |= w.result()->flags & ~(1u | SJGPU_F_RANGE_CARRY);
           cursor = w.result()->n;
