@@ -126,10 +126,12 @@ int sjgpu_result(sjgpu_ctx *ctx, void *stream, sjgpu_scan_result *out);
  *   FUSED  one kernel, chained scan between tiles: reads every byte once, one launch -- fastest on small inputs
  *          and, in its pipelined form (look-back + emission of a tile deferred behind the scan of the next), on
  *          large ones;
- *   AUTO   FUSED up to 8 MiB (16 KiB tiles) and from 224 MiB (pipelined, eight waves per workgroup, 128 KiB tiles),
- *          SPLIT in between -- and, for stage 1, at every size when the previous large scan of this context produced
- *          fewer than 0.2 offsets per byte (sparse output: NDJSON, pretty-printed text), where SPLIT is 0-10 % faster
- *          (profiles/r04_pipeline_sweep.txt).
+ *   AUTO   FUSED up to 8 MiB (16 KiB tiles); beyond that SPLIT, except
+ *            stage 1 from 224 MiB (pipelined, eight waves per workgroup, 128 KiB tiles) when the output is DENSE: the previous
+ *              whole-document scan of more than 8 MiB through this context produced at least 0.2 offsets per byte (a new context
+ *              assumes dense; the figure is taken when that scan's result is read, so it follows the documents a context sees).
+ *              Sparse output (NDJSON, pretty-printed text) stays SPLIT at every size: 0-10 % faster (profiles/r04_pipeline_sweep.txt);
+ *            minify from 192 MiB (k_minify_onchip reads its input once, the split pipeline twice), whatever the density.
  *          (A/B switches, read once per process: SJGPU_PIPE_WAVES=4 / SJGPU_MINIFY_WAVES=4 bring back the four-wave
  *          shapes of rounds 1-3 -- 64 KiB / 32 KiB tiles.)
  * All produce identical bytes; a single-pass call that raises SJGPU_F_INTERNAL is re-run split by the
@@ -358,6 +360,9 @@ int sjgpu_comm_gather_indices(sjgpu_comm *comm, const void *idx_dev, uint32_t n,
  * more whose parity the previous range knows -- /root/reference/src/generic/stage1/json_escape_scanner.h:50-71's one carried
  * bit, handed from call to call).  Offsets stay
  * relative to byte 0 and are appended at idx_dev[n_before...]; result.n / out_len are running totals.
+ * in_string is exactly `flags & (SJGPU_F_UNCLOSED_STRING | SJGPU_F_RANGE_CARRY)` of the previous range's result (0 for the first range);
+ * any other bit is SJGPU_E_BADARG.  (Through round 3 it was "non-zero = inside a string": a caller that passes 2, -1 or a bool other than 1,
+ * or that forwards only bit 0 and so drops the escape carry of a backslash run across the cut, has to be changed -- INTEGRATION.md.)
  * sjgpu_stage1() and sjgpu_minify() drive exactly this for host buffers of 64 MiB and more (env
  * SJGPU_STREAM_FROM_MB / SJGPU_STREAM_CHUNK_MB), with the device-to-host copies on a second thread. */
 int sjgpu_stage1_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin, size_t end, int more, int in_string,
@@ -372,7 +377,12 @@ int sjgpu_minify_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin,
  * [base, base + len) must stay valid and unchanged (the range is page-locked meanwhile unless SJGPU_STREAM_PIN=0).  sjgpu_stage1
  * calls in the streaming_partial / streaming_final modes whose buffer lies inside a registered stream are then answered from a
  * span of 32 MiB scanned once -- identical results, microseconds per window (profiles / bench.py plugin_host_path).  The in-tree
- * patch registers in document_stream::start(); out of tree: simdjson::mi355x::register_stream. */
+ * patch registers in document_stream::start(); out of tree: simdjson::mi355x::register_stream.
+ * Registrations are COUNTED per base address: registering a base again (a second stream over the same buffer) adds a reference, every
+ * registration needs its own sjgpu_stream_unregister, and the range stays page-locked until the last one.  While several are alive the
+ * extent served from spans is the SHORTEST length any of them named (when one leaves, the longest is assumed to have left): a window beyond
+ * it takes the ordinary path -- same results, one upload per window.  A caller that registers a base twice and unregisters once leaks the
+ * reference (and the page-lock) until it unregisters again. */
 int sjgpu_stream_register(const uint8_t *base, size_t len);
 int sjgpu_stream_unregister(const uint8_t *base);
 

@@ -50,14 +50,39 @@ def build_corpus(force=False):
     return _paths.LIB_CORPUS
 
 
+SJGPU_SOURCES = ("sjgpu_kernels.hip", "sjgpu_fused.hip", "sjgpu_small.hip", "sjgpu_finish.hip", "sjgpu_strings.hip", "sjgpu_string_stream.hip", "sjgpu_tape.hip",
+                 "sjgpu_mgpu.hip", "sjgpu_comm.hip", "sjgpu_capi.hip", "stage1_finish.cpp")
+SJGPU_HEADERS = ("sj_block.h", "sj_number.h", "sj_tape_rules.h", "sj_string_stream.h", "sj_xcarry.h", "sj_pow5_table.inc", "sjgpu_internal.h", "sjgpu_device.h")
+
+
+def sjgpu_source_stamp():
+    """sha256 over everything libsjgpu.so is compiled from (names and bytes): what build/tests/STAMP.json records under "libsjgpu.so" when the
+    library is built, and what the tests compare with -- a prebuilt library that travelled with OTHER sources is found out by content, not by mtime."""
+    h = hashlib.sha256()
+    for f in [*_csrc(*SJGPU_SOURCES), *_csrc(*SJGPU_HEADERS), os.path.join(_paths.INCLUDE_DIR, "sjgpu.h")]:
+        h.update(os.path.relpath(f, _paths.REPO_ROOT).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def sjgpu_is_current():
+    path = os.path.join(TEST_BIN_DIR, "STAMP.json")
+    out = os.path.join(_paths.LIB_DIR, "libsjgpu.so")
+    return os.path.exists(path) and os.path.exists(out) and json.load(open(path)).get("libsjgpu.so") == sjgpu_source_stamp()
+
+
 def build_sjgpu(force=False):
     out = os.path.join(_paths.LIB_DIR, "libsjgpu.so")  # always the in-tree default, never an SJGPU_LIB override
-    srcs = _csrc("sjgpu_kernels.hip", "sjgpu_fused.hip", "sjgpu_small.hip", "sjgpu_finish.hip", "sjgpu_strings.hip", "sjgpu_string_stream.hip", "sjgpu_tape.hip", "sjgpu_mgpu.hip", "sjgpu_comm.hip", "sjgpu_capi.hip", "stage1_finish.cpp")
-    deps = srcs + _csrc("sj_block.h", "sj_number.h", "sj_tape_rules.h", "sj_string_stream.h", "sj_pow5_table.inc", "sjgpu_internal.h", "sjgpu_device.h") + [os.path.join(_paths.INCLUDE_DIR, "sjgpu.h")]
-    if force or _stale(out, deps):
+    srcs = _csrc(*SJGPU_SOURCES)
+    if force or not sjgpu_is_current():
         os.makedirs(_paths.LIB_DIR, exist_ok=True)
         _run([HIPCC, f"--offload-arch={GFX_ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
               "-I", _paths.INCLUDE_DIR, "-I", _paths.CSRC_DIR, *srcs, "-o", out, "-ldl"])  # RCCL is opened by sjgpu_comm_* on first use, not linked
+        os.makedirs(TEST_BIN_DIR, exist_ok=True)
+        path = os.path.join(TEST_BIN_DIR, "STAMP.json")
+        d = json.load(open(path)) if os.path.exists(path) else {}
+        d["libsjgpu.so"] = sjgpu_source_stamp()
+        json.dump(d, open(path, "w"), indent=1, sort_keys=True)
     return out
 
 
@@ -232,6 +257,34 @@ def build_rccl_loopback(force=False):
     return LIB_LOOPBACK_HIP
 
 
+SAN_DIR = os.path.join(_paths.REPO_ROOT, "build", "san")
+
+
+def build_sanitizers(force=False):
+    """AddressSanitizer / ThreadSanitizer builds of the host side (scripts/sanitize.sh build: libsjgpu's host code, the plug-in, plugin_test) ->
+    build/san/*, which travel to the GPU box where tests/test_plugin.py::test_sanitizers_over_the_host_shim runs them.  Needs the reference; rebuilt
+    when the library's or the plug-in's sources changed (the stamp in build/tests/STAMP.json); a failure leaves the test skipped, not the build broken."""
+    hdr = os.path.join(_paths.REFERENCE_DIR, "include", "simdjson.h")
+    bins = [os.path.join(SAN_DIR, f"plugin_test_{s}") for s in ("address", "thread")]
+    if not os.path.exists(hdr):
+        return bins if all(os.path.exists(b) for b in bins) else None
+    want = hashlib.sha256((sjgpu_source_stamp() + source_stamp()).encode()).hexdigest()
+    path = os.path.join(TEST_BIN_DIR, "STAMP.json")
+    d = json.load(open(path)) if os.path.exists(path) else {}
+    if not force and d.get("san") == want and all(os.path.exists(b) for b in bins):
+        return bins
+    try:
+        _run(["bash", os.path.join(_paths.REPO_ROOT, "scripts", "sanitize.sh"), "build"])
+    except subprocess.CalledProcessError as e:
+        print("[build] sanitizer builds failed:", e, flush=True)
+        return None
+    d = json.load(open(path)) if os.path.exists(path) else {}
+    d["san"] = want
+    os.makedirs(TEST_BIN_DIR, exist_ok=True)
+    json.dump(d, open(path, "w"), indent=1, sort_keys=True)
+    return bins
+
+
 def build_all(force=False):
     build_corpus(force)
     build_sjgpu(force)
@@ -241,6 +294,7 @@ def build_all(force=False):
     build_plugin_test(force)
     build_reference_tests(force)
     build_intree(force)
+    build_sanitizers(force)
 
 
 if __name__ == "__main__":

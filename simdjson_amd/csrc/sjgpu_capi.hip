@@ -356,7 +356,9 @@ void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, 
   ctx->enqueue_rc = ensure_scan_workspace(ctx, len - org.begin, !fused);
   if (ctx->enqueue_rc) { return; }
   ctx->last_pipeline = fused ? 1 : 0;
-  ctx->pending_scan_bytes = (org.begin == 0 && org.base0 == 0 && len >= AUTO_FUSED_FROM) ? len : 0;
+  // the density AUTO decides by is taken from every whole-document scan beyond the small-input kernels' range (round 4 sampled only scans of
+  // 224 MiB and more: a context that had once seen sparse output stayed on the split pipeline until another scan of that size measured dense)
+  ctx->pending_scan_bytes = (org.begin == 0 && org.base0 == 0 && len > AUTO_FUSED_BELOW) ? len : 0;
   if (fused) { ctx->last_kernel = launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, org, ctx->max_workgroups, s, ev, true); }
   else {
     launch_stage1(buf, len, ctx->masks, ctx->summ, ctx->pref, idx, idx_words, ctx->d_result, org, s, ev);
@@ -834,6 +836,9 @@ int sjgpu_stage1_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin,
   const int bad = check_range(ctx, buf_dev, begin, end);
   if (bad) { return bad; }
   if (!idx_dev || (reinterpret_cast<uintptr_t>(idx_dev) & 15u)) { return SJGPU_E_BADARG; }
+  // in_string is a bit field since round 4 (bit 0: inside a string; SJGPU_F_RANGE_CARRY: the escape carry): a caller of the earlier "any non-zero
+  // value" contract that passes 2 or -1 must hear about it, not get offsets for a range that begins outside a string
+  if (in_string & ~(1 | int(SJGPU_F_RANGE_CARRY))) { return SJGPU_E_BADARG; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
   const scan_origin org{uint64_t(begin), n_before, CARRY_SHARD | ((in_string & 1) ? CARRY_IN_STRING : 0u) | ((in_string & int(SJGPU_F_RANGE_CARRY)) ? CARRY_X : 0u) | (more ? CARRY_MORE : 0u)};
   enqueue_stage1(ctx, use_fused(ctx, end - begin, 0), static_cast<const uint8_t *>(buf_dev), end, static_cast<uint32_t *>(idx_dev), idx_words,
@@ -847,6 +852,9 @@ int sjgpu_minify_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin,
   const int bad = check_range(ctx, buf_dev, begin, end);
   if (bad) { return bad; }
   if (!dst_dev || (reinterpret_cast<uintptr_t>(dst_dev) & 15u)) { return SJGPU_E_BADARG; }
+  // in_string is a bit field since round 4 (bit 0: inside a string; SJGPU_F_RANGE_CARRY: the escape carry): a caller of the earlier "any non-zero
+  // value" contract that passes 2 or -1 must hear about it, not get offsets for a range that begins outside a string
+  if (in_string & ~(1 | int(SJGPU_F_RANGE_CARRY))) { return SJGPU_E_BADARG; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
   const scan_origin org{uint64_t(begin), out_before, CARRY_SHARD | ((in_string & 1) ? CARRY_IN_STRING : 0u) | ((in_string & int(SJGPU_F_RANGE_CARRY)) ? CARRY_X : 0u) | (more ? CARRY_MORE : 0u)};
   enqueue_minify(ctx, use_fused(ctx, end - begin), static_cast<const uint8_t *>(buf_dev), end, static_cast<uint8_t *>(dst_dev),
@@ -1180,6 +1188,7 @@ struct stream_extent {
   bool pinned;
   uint64_t id; // unique per registration: a later stream at the same address must not meet the spans of an earlier one
   uint32_t refs; // registrations alive for this base: two streams over one buffer must not unregister each other
+  std::vector<size_t> lens; // the length every live registration named: `len` is the part of the buffer ALL of them vouch for (their minimum)
 };
 struct stream_registry {
   std::mutex m;
@@ -1355,7 +1364,7 @@ extern "C" {
 
 int sjgpu_stream_register(const uint8_t *base, size_t len) {
   if (!base || len == 0) { return SJGPU_E_BADARG; }
-  stream_extent e{base, len, false, 0, 1};
+  stream_extent e{base, len, false, 0, 1, {len}};
   // Page-locking pays for itself on streams of many megabytes (the upload of a span runs at twice the rate and truly asynchronously);
   // small buffers come and go at addresses the allocator hands out again, and registering / unregistering those by the thousand
   // (the reference's document_stream tests) is what the runtime is not made for: they stay pageable.
@@ -1367,7 +1376,10 @@ int sjgpu_stream_register(const uint8_t *base, size_t len) {
   e.id = r.next_id++;
   for (stream_extent &x : r.list) {
     if (x.base == base) { // registered again (a second stream over the same buffer): spans as good as new, one more unregister to wait for
-      x.len = len > x.len ? len : x.len;
+      // The extent served from spans is what EVERY live registration vouches for.  (Round 4 kept the maximum: when the longer of two streams
+      // left first and its owner freed the tail, the survivor still advertised it and a span upload could read freed bytes -- ADVICE r4.)
+      x.lens.push_back(len);
+      x.len = len < x.len ? len : x.len;
       x.pinned = x.pinned || e.pinned;
       x.id = e.id;
       x.refs++;
@@ -1386,7 +1398,14 @@ int sjgpu_stream_unregister(const uint8_t *base) {
     std::lock_guard<std::mutex> lk(r.m);
     for (size_t i = 0; i < r.list.size(); i++) {
       if (r.list[i].base == base) {
-        if (--r.list[i].refs > 0) { return 0; } // another stream over the same buffer is still at work
+        if (--r.list[i].refs > 0) { // another stream over the same buffer is still at work.  Which registration left is not said: assume the
+          // LONGEST did -- the extent never grows beyond what the remaining ones are known to cover (windows beyond it take the ordinary path)
+          std::vector<size_t> &ls = r.list[i].lens;
+          size_t at = 0;
+          for (size_t k = 1; k < ls.size(); k++) { if (ls[k] > ls[at]) { at = k; } }
+          if (!ls.empty()) { ls.erase(ls.begin() + long(at)); }
+          return 0;
+        }
         pinned = r.list[i].pinned;
         r.list.erase(r.list.begin() + long(i));
         found = true;

@@ -12,10 +12,12 @@
 // through the same descriptors (sj_xcarry.h; sjgpu_device.h: span_carry_assume).
 //
 // MI355X specifics:
-//   * tile = 64 KiB = one 256-thread workgroup = 4 waves x 4 chunks.  Tiles must be big: descriptors live
-//     in other XCDs' L2s, a hand-off costs 1-3 us under load (MI355X_MICROARCH.md, handoff rows), and at
-//     ~5 TB/s a new 64 KiB tile becomes ready every ~13 ns, so the look-back window (256 descriptors per
-//     round trip, 4 coalesced 512-byte loads per wave) must cover "tiles per round trip" (~150).
+//   * tile = 128 KiB = one 512-thread workgroup = 8 waves x 4 chunks (k_fused_pipelined, the large-input kernel since round 4; rounds 1-3:
+//     64 KiB, 4 waves -- SJGPU_PIPE_WAVES=4 brings that shape back; k_fused, the small-input kernel: 16 KiB, 4 waves x 1 chunk;
+//     k_minify_onchip: 64 KiB, 8 waves x 2 chunks).  Tiles must be big: descriptors live in other XCDs' L2s, a hand-off costs 1-3 us under load
+//     (MI355X_MICROARCH.md, handoff rows), a ticket and a look-back cost ~17 ns per tile device-wide whatever the tile does
+//     (profiles/r04_gather_lab.txt), and at ~5 TB/s a new 128 KiB tile becomes ready every ~26 ns, so the look-back window (256
+//     descriptors per round trip, 4 coalesced 512-byte loads per wave) must cover "tiles per round trip" (~75).
 //   * descriptors are single naturally-aligned 8-byte granules written with ONE relaxed agent-scope
 //     atomic store (sc1 write-through) and read with relaxed agent-scope loads: the data is the flag, no
 //     fences (cdna_hip_programming.md G16, form R2).  Dispatch order is not assumed: tile ids come from an
@@ -24,6 +26,8 @@
 //     SJGPU_F_INTERNAL and the host re-runs the call on the split pipeline.
 //   * the per-chunk masks wait for the look-back in a 4-deep register FIFO (rolled loops, no dynamic
 //     register indexing, no LDS), offsets leave through the per-wave LDS window as 16-byte stores.
+//   * a call is ONE dispatch (round 5): nothing is cleared in front of the kernel, its last workgroup to leave puts descriptors, ticket and
+//     flag word back to zero for the next call (leave_and_clean).
 #include "sjgpu_device.h"
 
 #include <cstdlib>
@@ -31,7 +35,8 @@
 namespace sjgpu {
 namespace {
 
-constexpr u32 FUSED_WAVES = 4; // waves per workgroup; each owns WC consecutive chunks of the tile
+constexpr u32 FUSED_WAVES = 4; // waves per workgroup of k_fused (and of the four-wave A/B shapes of the pipelined kernels, whose default is NW = 8: launch_fused);
+                               // each wave owns WC consecutive chunks of the tile
 constexpr u32 LOOKBACK_LOADS = 4;                                                // x64 descriptors per round trip
 constexpr u64 LOOKBACK_TIMEOUT_TICKS = 100ull * 1000 * 1000;                     // wall_clock64 is 100 MHz: 1 s
 

@@ -504,7 +504,9 @@ strings_handoff launch_parse_strings(const uint8_t *buf, uint64_t len, const uin
                                      uint32_t *offsets, strings_result_dev *res, void *scratch, hipStream_t s, const int *listed, int roads) {
   const strings_scratch w = carve_strings_scratch(scratch, n, len);
   const u32 n1 = n + 1;
-  enqueue_string_stream(buf, len, idx, n, allow_replacement, out, out_cap, offsets, res, w, s, listed);
+  // STRINGS_WALK_ONLY is the retry behind a stream that DECLINED the document: its count / resolve / token / scan / write / finalize launches would
+  // all run again only to have their verdict overwritten below (round 4 did that: a declined document paid for the stream twice -- ADVICE r4)
+  if (roads != STRINGS_WALK_ONLY) { enqueue_string_stream(buf, len, idx, n, allow_replacement, out, out_cap, offsets, res, w, s, listed); }
   const u32 *ctrl = static_cast<const u32 *>(w.ctrl); // strs_ctrl: [1] = entries of this path's scan, [3] = it runs
   const char *sw = std::getenv("SJGPU_STRING_STREAM"); // A/B switch, read per call (the tests flip it)
   if (roads == STRINGS_STREAM_ONLY && !(sw && sw[0] == '0')) { return strings_handoff{w.outq, ctrl + 2}; } // a declined document comes back with path == 2

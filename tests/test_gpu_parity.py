@@ -96,6 +96,13 @@ def assert_same_all(p, orc, data, tag="", modes=(0,)):
 
 
 # ---- golden fixtures (reference outputs) ------------------------------------------------------------------
+def test_the_library_on_this_box_was_built_from_these_sources():
+    """The driver's box runs a PREBUILT libsjgpu.so (it travels with the snapshot): its stamp -- the sha256 of the sources it was compiled from,
+    written by simdjson_amd/build.py -- must be the hash of the sources lying next to it, or every result below is about some other tree."""
+    from simdjson_amd import build
+    assert build.sjgpu_is_current(), "simdjson_amd/lib/libsjgpu.so was not built from the sources of this tree (build/tests/STAMP.json)"
+
+
 def test_small_cases_all_modes_golden(gpu):
     for case in load("small_cases.json")["cases"]:
         data = bytes.fromhex(case["hex"])

@@ -28,6 +28,14 @@ def test_exports_match_header(lib):
         assert hasattr(lib, name), name
 
 
+def test_the_library_is_the_one_these_sources_build(lib):
+    """The built libsjgpu.so travels to the GPU box; build/tests/STAMP.json records the hash of the sources it was compiled from and the tests
+    (both tiers: tests/test_gpu_parity.py repeats this on the box) refuse a library that belongs to other sources -- by content, not by mtime."""
+    assert build.sjgpu_is_current()
+    stamp = json.load(open(os.path.join(build.TEST_BIN_DIR, "STAMP.json")))
+    assert stamp["libsjgpu.so"] == build.sjgpu_source_stamp() and len(stamp["libsjgpu.so"]) == 64
+
+
 def test_every_barrier_waits_for_lds(lib):
     """Round 2: hipcc dropped the `s_waitcnt lgkmcnt(0)` of a __syncthreads() at a loop header (k_minify_onchip); the
     workgroup's next ticket, stored to LDS at the end of an iteration, was read before the store had been performed
