@@ -413,6 +413,39 @@ def leg_list_passes(cx, which):
         leg["cpu_baseline"] = {"value": round(n / (time.perf_counter() - t0) / 1e9, 3), "unit": "G structurals/s", "cores": 1, "kind": "port",
                                "sample": "numpy gather + cumsum over the same list on one host core (the reference carries the depth inside its serial stage-2 walk)"}
         assert int(d[-1]) == final_depth
+        # round 5: the same pass fed from the token-byte stream stage 1 can write beside the offsets (sjgpu_stage1_tokens_device) -- one coalesced byte per
+        # entry instead of a gather through the document's 128-byte lines -- and what the stream costs stage 1 (split pipeline, same buffer)
+        tok = torch.empty(L // 2 + 16, dtype=torch.uint8, device="cuda")
+        depth2 = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+        p.set_pipeline("split")
+        run_plain = lambda: p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, stream)
+        run_tok = lambda: p.stage1_tokens_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, tok.data_ptr(), L // 2 + 16, stream)
+        run_tok()
+        nt, ft, _ = p.result(stream)
+        assert (nt, ft) == (n, flags) and bool(torch.equal(idx[: n + 3], keep))
+        run_depth_tok = lambda: p.depth_scan_tokens_device(tok.data_ptr(), n, depth2.data_ptr(), stream)
+        run_depth_tok()
+        if not bool(torch.equal(depth, depth2)):
+            raise SystemExit("PARITY FAILURE: the depth scan from the token stream differs from the depth scan that gathers")
+        clock_warmup(torch, run_plain)
+        ms_plain = event_ms_per_call(torch, run_plain, reps)
+        clock_warmup(torch, run_tok)
+        ms_tok = event_ms_per_call(torch, run_tok, reps)
+        clock_warmup(torch, run_depth_tok)
+        ms_dt = event_ms_per_call(torch, run_depth_tok, reps)
+        alg_t = n + 4 * (n + 1)  # one token byte in, 4 B of depth out, per structural
+        leg["with_token_stream"] = {
+            "depth_scan_ms_per_call": round(ms_dt, 4), "value": round(n / ms_dt / 1e6, 2), "unit": "G structurals/s",
+            "roofline": {"bound": "hbm", "achieved": round(alg_t / ms_dt / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_t / ms_dt / 1e6 / HBM_PEAK_GBS, 4),
+                         "algorithmic_bytes_per_launch": alg_t, "algorithmic_bytes": "1 B of token stream in, 4 B of depth out, per structural",
+                         "frac_by_the_gathering_pass_accounting": round(alg / ms_dt / 1e6 / HBM_PEAK_GBS, 4)},
+            "stage1_split_ms_without_tokens": round(ms_plain, 4), "stage1_split_ms_with_tokens": round(ms_tok, 4),
+            "stage1_cost_of_the_stream": round(ms_tok / ms_plain - 1.0, 4),
+            "stage1_plus_depth_scan_ms": {"gathering": round(ms_plain + gpu_ms, 4), "token_stream": round(ms_tok + ms_dt, 4)},
+            "parity": "same list and flags as sjgpu_stage1_device; depth array identical to the gathering pass's",
+            "note": "sjgpu_stage1_tokens_device + sjgpu_depth_scan_tokens_device: the stream is opt-in (it costs the scan kernel a byte compaction per chunk); "
+                    "what a pipeline of stage 1 + one list pass pays in total is the last entry"}
+        del tok, depth2
     else:
         mode = capi.STREAMING_FINAL
         err, n_kept, nxt = p.stage1_finish_device(buf.data_ptr(), L, mode, idx.data_ptr(), n, flags, stream)

@@ -118,6 +118,17 @@ int sjgpu_stage1_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *i
 int sjgpu_minify_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *dst_dev, void *stream);
 int sjgpu_validate_utf8_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *stream);
 int sjgpu_result(sjgpu_ctx *ctx, void *stream, sjgpu_scan_result *out);
+/* sjgpu_stage1_device with the TOKEN-BYTE STREAM beside the offsets: tok_dev[i] = buf_dev[idx_dev[i]] for i < n (tok_bytes >= idx_words).
+ * Every consumer of the structural list dereferences it -- the reference's stage 2 walks `buf[*next_structural++]`
+ * (/root/reference/src/generic/stage2/json_iterator.h:246-288), find_next_document_index reads the byte under every index
+ * (src/generic/stage1/find_next_document_index.h:39-98) -- and on a GPU that dereference is a gather through 128-byte lines: a pass over the
+ * list of a sparse document fetches the whole document again to pick one byte per structural.  Stage 1 holds those bytes when it decides what
+ * is structural: here they leave with the offsets (compacted by the scan kernel per 16 KiB segment, copied behind the output cursor by the
+ * emission kernel; +1 B written per structural) and list passes read ONE coalesced byte per entry: sjgpu_depth_scan_tokens_device below.
+ * Opt-in because it costs stage 1 (split pipeline only; the byte compaction adds ~40 % to the scan kernel's instructions: DESIGN.md
+ * section 4b has the measured cost and what the consumers get back).  Same result / flags / list as sjgpu_stage1_device. */
+int sjgpu_stage1_tokens_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *idx_dev, size_t idx_words, void *tok_dev, size_t tok_bytes,
+                               void *stream);
 
 /* Pipeline selection (default SJGPU_PIPELINE_AUTO; the environment variable SJGPU_PIPELINE = "split" |
  * "fused" | "auto" sets the default of new contexts):
@@ -223,6 +234,8 @@ int sjgpu_stage1_many(sjgpu_ctx *ctx, sjgpu_doc *docs, size_t count);
 int sjgpu_stage1_finish_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, int mode, void *idx_dev, uint32_t n_raw,
                                uint32_t flags, void *stream, uint32_t *n_io, uint32_t *next_start_out);
 int sjgpu_depth_scan_device(sjgpu_ctx *ctx, const void *buf_dev, const void *idx_dev, uint32_t n, void *depth_dev, void *stream);
+/* the same from the token stream of sjgpu_stage1_tokens_device: neither the document nor the list is read */
+int sjgpu_depth_scan_tokens_device(sjgpu_ctx *ctx, const void *tok_dev, uint32_t n, void *depth_dev, void *stream);
 
 /* ---- the strings of a document, unescaped ----------------------------------------------------------
  * What the reference's stage 2 does at every quote of the structural list: stringparsing::parse_string

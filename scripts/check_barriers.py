@@ -142,6 +142,26 @@ def kernel_resources(lib):
     return out
 
 
+def l2_flushes(lib):
+    """{kernel symbol: number of buffer_wbl2 / buffer_inv instructions}: what an agent-scope fence (__threadfence(), a release / acquire at agent scope)
+    compiles to on gfx942 / gfx950, where an XCD's L2 is not coherent with the others' -- a write-back and an invalidation of the XCD's WHOLE L2.  Round 5: two
+    such fences in the epilogue of the single-pass kernels (one per wave that leaves) cost the headline kernel 0.22 ms of 0.70.  The tile kernels talk to
+    each other through agent-scope ATOMICS (performed past the L2) and waits for their acknowledgements; none of them may hold one of these."""
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for co in code_objects(lib, d):
+            text = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+            func = None
+            for line in text.split("\n"):
+                m = re.match(r"^[0-9a-fA-F]+ <([^>]+)>:", line)
+                if m:
+                    func = m.group(1)
+                    out.setdefault(func, 0)
+                elif func and re.match(r"^\s+buffer_(wbl2|inv)\b", line):
+                    out[func] += 1
+    return out
+
+
 def check(lib):
     with tempfile.TemporaryDirectory() as d:
         found = []

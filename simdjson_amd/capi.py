@@ -23,7 +23,7 @@ F_UNCLOSED_STRING, F_UNESCAPED_CTRL, F_UTF8_ERROR, F_IDX_OVERFLOW, F_INTERNAL, F
 EXPORTS = [
     "sjgpu_device_count", "sjgpu_ctx_create", "sjgpu_ctx_destroy", "sjgpu_set_capacity", "sjgpu_capacity",
     "sjgpu_last_error", "sjgpu_stage1", "sjgpu_minify", "sjgpu_validate_utf8", "sjgpu_validate_utf8_pieces", "sjgpu_stage1_device",
-    "sjgpu_minify_device", "sjgpu_validate_utf8_device", "sjgpu_result", "sjgpu_stage1_error_from_flags",
+    "sjgpu_minify_device", "sjgpu_validate_utf8_device", "sjgpu_result", "sjgpu_stage1_error_from_flags", "sjgpu_stage1_tokens_device", "sjgpu_depth_scan_tokens_device",
     "sjgpu_stage1_finish_host", "sjgpu_trim_partial_utf8", "sjgpu_profile_enable", "sjgpu_profile_read", "sjgpu_set_pipeline", "sjgpu_debug_trace_stage1",
     "sjgpu_clean_cut", "sjgpu_string_parity_device", "sjgpu_stage1_shard_device", "sjgpu_minify_shard_device",
     "sjgpu_stage1_range_device", "sjgpu_minify_range_device",
@@ -96,6 +96,10 @@ def load_library():
     L.sjgpu_minify_device.argtypes = [vp, vp, sz, vp, vp]
     L.sjgpu_validate_utf8_device.restype = ctypes.c_int
     L.sjgpu_validate_utf8_device.argtypes = [vp, vp, sz, vp]
+    L.sjgpu_stage1_tokens_device.restype = ctypes.c_int
+    L.sjgpu_stage1_tokens_device.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp]
+    L.sjgpu_depth_scan_tokens_device.restype = ctypes.c_int
+    L.sjgpu_depth_scan_tokens_device.argtypes = [vp, vp, ctypes.c_uint32, vp, vp]
     L.sjgpu_result.restype = ctypes.c_int
     L.sjgpu_result.argtypes = [vp, vp, ctypes.POINTER(ScanResult)]
     L.sjgpu_stage1_error_from_flags.restype = ctypes.c_int
@@ -272,6 +276,13 @@ class DomParserImplementation:
             raise SjgpuError(f"sjgpu_stage1_device error {rc}: {self.last_error()}")
         return rc
 
+    def stage1_tokens_device(self, buf_ptr, length, idx_ptr, idx_words, tok_ptr, tok_bytes, stream=0):
+        """sjgpu_stage1_tokens_device: stage1_device + tok[i] = buf[idx[i]] beside the offsets (split pipeline)"""
+        rc = self.L.sjgpu_stage1_tokens_device(self.h, buf_ptr, int(length), idx_ptr, int(idx_words), tok_ptr, int(tok_bytes), stream or None)
+        if rc < 0:
+            raise SjgpuError(f"sjgpu_stage1_tokens_device error {rc}: {self.last_error()}")
+        return rc
+
     def minify_device(self, buf_ptr, length, dst_ptr, stream=0):
         rc = self.L.sjgpu_minify_device(self.h, buf_ptr, int(length), dst_ptr, stream or None)
         if rc < 0:
@@ -365,6 +376,11 @@ class DomParserImplementation:
         rc = self.L.sjgpu_depth_scan_device(self.h, buf_ptr, idx_ptr, int(n), depth_ptr, stream or None)
         if rc != 0:
             raise SjgpuError(f"sjgpu_depth_scan_device error {rc}: {self.last_error()}")
+
+    def depth_scan_tokens_device(self, tok_ptr, n, depth_ptr, stream=0):
+        rc = self.L.sjgpu_depth_scan_tokens_device(self.h, tok_ptr, int(n), depth_ptr, stream or None)
+        if rc != 0:
+            raise SjgpuError(f"sjgpu_depth_scan_tokens_device error {rc}: {self.last_error()}")
 
     def parse_strings_device(self, buf_ptr, length, idx_ptr, n, out_ptr, out_bytes, offsets_ptr=0, allow_replacement=False, stream=0):
         """sjgpu_parse_strings_device -> (error_code, string buffer bytes used, strings, index of the first invalid string)"""

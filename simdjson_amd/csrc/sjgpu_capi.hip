@@ -133,6 +133,9 @@ struct sjgpu_ctx {
   size_t d_idx_words = 0;
   uint8_t *d_out = nullptr;
   size_t d_out_bytes = 0;
+  // sjgpu_stage1_tokens_device: where the segments' structural bytes wait between the two kernels of the split pipeline (one byte per input byte at most)
+  uint8_t *d_tokstage = nullptr;
+  size_t d_tokstage_bytes = 0;
   // small documents (sjgpu_small.hip): one page-locked block the one-workgroup kernel reads and writes across PCIe
   uint8_t *h_small = nullptr; // [result 64 B][descriptors][input][output]
   size_t h_small_bytes = 0;
@@ -231,6 +234,8 @@ void release_staging(sjgpu_ctx *ctx) {
   dev_free(ctx->d_in);
   dev_free(ctx->d_idx);
   dev_free(ctx->d_out);
+  dev_free(ctx->d_tokstage);
+  ctx->d_tokstage_bytes = 0;
   ctx->d_in_bytes = ctx->d_out_bytes = 0;
   ctx->d_idx_words = 0;
 }
@@ -351,9 +356,11 @@ bool use_fused(const sjgpu_ctx *ctx, size_t len, int op = 1) { // op 0: stage 1,
 }
 
 // `len` is the END of the scan (bytes [org.begin, len) are scanned); a whole document has org = {0, 0, 0}
+// tok: the token-byte stream beside the offsets (split pipeline only: the caller passes fused = false)
 void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint32_t *idx, size_t idx_words, hipStream_t s,
-                    hipEvent_t *ev, scan_origin org = scan_origin{0, 0, 0}) {
+                    hipEvent_t *ev, scan_origin org = scan_origin{0, 0, 0}, uint8_t *tok = nullptr) {
   ctx->enqueue_rc = ensure_scan_workspace(ctx, len - org.begin, !fused);
+  if (!ctx->enqueue_rc && tok) { ctx->enqueue_rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_tokstage), &ctx->d_tokstage_bytes, size_t(num_segments(grown(len - org.begin))) * SEG_BYTES + 64); }
   if (ctx->enqueue_rc) { return; }
   ctx->last_pipeline = fused ? 1 : 0;
   // the density AUTO decides by is taken from every whole-document scan beyond the small-input kernels' range (round 4 sampled only scans of
@@ -361,8 +368,9 @@ void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, 
   ctx->pending_scan_bytes = (org.begin == 0 && org.base0 == 0 && len > AUTO_FUSED_BELOW) ? len : 0;
   if (fused) { ctx->last_kernel = launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, org, ctx->max_workgroups, s, ev, true); }
   else {
-    launch_stage1(buf, len, ctx->masks, ctx->summ, ctx->pref, idx, idx_words, ctx->d_result, org, s, ev);
-    ctx->last_kernel = "k_stage1_summarize+k_resolve_groups+k_resolve_segments+k_stage1_emit";
+    launch_stage1(buf, len, ctx->masks, ctx->summ, ctx->pref, idx, idx_words, ctx->d_result, org, s, ev, tok ? ctx->d_tokstage : nullptr, tok);
+    ctx->last_kernel = tok ? "k_stage1_summarize<tokens>+k_resolve_groups+k_resolve_segments+k_stage1_emit<tokens>"
+                           : "k_stage1_summarize+k_resolve_groups+k_resolve_segments+k_stage1_emit";
   }
 }
 void enqueue_minify(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint8_t *dst, hipStream_t s, hipEvent_t *ev,
@@ -745,6 +753,20 @@ int sjgpu_stage1_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *i
   SJ_TRY(ctx, hipSetDevice(ctx->device));
   enqueue_stage1(ctx, use_fused(ctx, len, 0), static_cast<const uint8_t *>(buf_dev), len, static_cast<uint32_t *>(idx_dev), idx_words,
                  pick(ctx, stream), next_events(ctx));
+  SJ_ENQUEUED(ctx);
+  return 0;
+}
+
+int sjgpu_stage1_tokens_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *idx_dev, size_t idx_words, void *tok_dev, size_t tok_bytes, void *stream) {
+  if (!ctx || !buf_dev || !idx_dev || !tok_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u) || (reinterpret_cast<uintptr_t>(idx_dev) & 15u)) {
+    return SJGPU_E_BADARG;
+  }
+  if (tok_bytes < idx_words) { return SJGPU_E_BADARG; } // a byte for every word the list may hold
+  if (len > ctx->capacity) { return E_CAPACITY; }
+  if (len == 0) { return E_EMPTY; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  enqueue_stage1(ctx, false, static_cast<const uint8_t *>(buf_dev), len, static_cast<uint32_t *>(idx_dev), idx_words, pick(ctx, stream), next_events(ctx),
+                 scan_origin{0, 0, 0}, static_cast<uint8_t *>(tok_dev));
   SJ_ENQUEUED(ctx);
   return 0;
 }
@@ -1562,6 +1584,16 @@ int sjgpu_depth_scan_device(sjgpu_ctx *ctx, const void *buf_dev, const void *idx
   if (rc) { return rc; }
   launch_depth_scan(static_cast<const uint8_t *>(buf_dev), static_cast<const uint32_t *>(idx_dev), n, static_cast<int32_t *>(depth_dev), ctx->d_tmp,
                     pick(ctx, stream));
+  SJ_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int sjgpu_depth_scan_tokens_device(sjgpu_ctx *ctx, const void *tok_dev, uint32_t n, void *depth_dev, void *stream) {
+  if (!ctx || !tok_dev || !depth_dev) { return SJGPU_E_BADARG; }
+  SJ_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_tmp(ctx, depth_scan_scratch_bytes(n));
+  if (rc) { return rc; }
+  launch_depth_scan(nullptr, nullptr, n, static_cast<int32_t *>(depth_dev), ctx->d_tmp, pick(ctx, stream), static_cast<const uint8_t *>(tok_dev));
   SJ_TRY(ctx, hipGetLastError());
   return 0;
 }

@@ -10,6 +10,13 @@
 #include "sj_block.h"
 #include "sj_xcarry.h"
 
+// occupancy request whose arguments depend on a template parameter (the host compiler of the CPU tier parses attribute arguments it does not know)
+#if defined(SJ_EMU)
+#define SJ_WAVES_PER_EU(...)
+#else
+#define SJ_WAVES_PER_EU(...) __attribute__((amdgpu_waves_per_eu(__VA_ARGS__)))
+#endif
+
 namespace sjgpu {
 namespace {
 

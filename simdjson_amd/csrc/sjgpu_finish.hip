@@ -272,16 +272,19 @@ __global__ __launch_bounds__(FIN_THREADS) void k_tail_balance(const u8 *__restri
 constexpr u32 DP_ROWS = 16, DP_TILE = DP_ROWS * FIN_THREADS;
 static_assert(DP_TILE == FIN_BLOCK, "k_scan_partials' callers count tiles of FIN_BLOCK entries");
 // codes[tile * 256 + thread]: bits 2 r = the entry of row r (tile * 4096 + r * 256 + thread): 1 opens, 2 closes; partial[tile] = opens - closes
+// TOK: the entries' bytes come from the token stream stage 1 wrote beside the list (sjgpu_stage1_tokens_device: tok[e] = buf[idx[e]]) -- one byte per
+// entry, coalesced, instead of the list word AND a 128-byte line of the document per entry (the gather that held this pass at 0.21 of the roofline)
+template <bool TOK>
 __global__ __launch_bounds__(FIN_THREADS) void k_depth_codes(const u8 *__restrict__ buf, const u32 *__restrict__ idx, u32 n, u32 *__restrict__ codes,
-                                                           int *__restrict__ partial) {
+                                                           int *__restrict__ partial, const u8 *__restrict__ tok) {
   __shared__ int sh[FIN_THREADS / 64];
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u64 tile0 = u64(blockIdx.x) * DP_TILE;
-  u32 pos[DP_ROWS];
+  u32 pos[DP_ROWS]; // TOK: the byte itself
 #pragma unroll
   for (u32 row = 0; row < DP_ROWS; row++) {
     const u64 e = tile0 + u64(row) * FIN_THREADS + tid;
-    pos[row] = e < n ? idx[e] : 0xFFFFFFFFu;
+    pos[row] = e < n ? (TOK ? u32(tok[e]) : idx[e]) : 0xFFFFFFFFu;
   }
   u32 c = 0;
   int sum = 0; // of this wave's entries (wave-uniform)
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_depth_codes(const u8 *__restric
   for (u32 row = 0; row < DP_ROWS; row++) {
     u32 code = 0;
     if (pos[row] != 0xFFFFFFFFu) {
-      const u32 kk = classify_byte(buf[pos[row]]);
+      const u32 kk = classify_byte(TOK ? pos[row] : u32(buf[pos[row]]));
       code = is_open(kk) ? 1u : (is_close(kk) ? 2u : 0u);
     }
     c |= code << (2u * row);
@@ -550,11 +553,12 @@ size_t depth_scan_scratch_bytes(uint32_t n) {
   const size_t tiles = blocks_for(u64(n) + 1, DP_TILE);
   return 256 + ((tiles + 64) * 4 + 255) / 256 * 256 + tiles * FIN_THREADS * 4;
 }
-void launch_depth_scan(const uint8_t *buf, const uint32_t *idx, uint32_t n, int32_t *depth, void *scratch, hipStream_t s) {
+void launch_depth_scan(const uint8_t *buf, const uint32_t *idx, uint32_t n, int32_t *depth, void *scratch, hipStream_t s, const uint8_t *tok) {
   const u32 tiles = blocks_for(u64(n) + 1, DP_TILE);
   int *partial = reinterpret_cast<int *>(static_cast<u8 *>(scratch) + 256);
   u32 *codes = reinterpret_cast<u32 *>(static_cast<u8 *>(scratch) + 256 + ((size_t(tiles) + 64) * 4 + 255) / 256 * 256);
-  hipLaunchKernelGGL(k_depth_codes, dim3(tiles), dim3(FIN_THREADS), 0, s, buf, idx, n, codes, partial);
+  if (tok) { hipLaunchKernelGGL(k_depth_codes<true>, dim3(tiles), dim3(FIN_THREADS), 0, s, buf, idx, n, codes, partial, tok); }
+  else { hipLaunchKernelGGL(k_depth_codes<false>, dim3(tiles), dim3(FIN_THREADS), 0, s, buf, idx, n, codes, partial, tok); }
   hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partial, tiles);
   hipLaunchKernelGGL(k_depth_write, dim3(tiles), dim3(FIN_THREADS), 0, s, codes, partial, n, depth);
 }

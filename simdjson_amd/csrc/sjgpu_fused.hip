@@ -70,12 +70,15 @@ __device__ __forceinline__ u32 *ctl_flags(u32 *ticket) { return ticket + 2; }
 template <u32 THREADS>
 __device__ __forceinline__ void leave_and_clean(u64 *desc, u32 ntiles, u32 *ticket, scan_result_dev *result) {
   __shared__ u32 sh_last;
-  __threadfence(); // what this wave stored and ORed has been performed device-wide before the workgroup counts itself out
+  // What this wave ORed into the flag word and stored into descriptors has been PERFORMED before the workgroup counts itself out: all of it went out as
+  // agent-scope atomics (performed at the device's coherence point, past the XCD's L2), so waiting for their acknowledgements is enough.  NOT
+  // __threadfence(): an agent-scope fence is buffer_wbl2 + buffer_inv on this part -- a write-back and an invalidation of the XCD's whole L2 per WAVE that
+  // leaves: the first version of this function cost the headline kernel 0.22 ms of 0.70 (profiles/r05_selfclean_ab.txt).
+  __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) expcnt(0) lgkmcnt(0)
   __syncthreads();
   if (threadIdx.x == 0) {
     const bool last = atomicAdd(ctl_done(ticket), 1u) == gridDim.x - 1u;
     if (last) { // the flags are read BEFORE the barrier that lets the other waves of this workgroup start zeroing (the flag word among the rest)
-      __threadfence();
       result->flags = __hip_atomic_load(ctl_flags(ticket), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     sh_last = last ? 1u : 0u;

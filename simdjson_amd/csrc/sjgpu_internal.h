@@ -32,6 +32,7 @@ constexpr uint32_t SF_CTRL_IF_IN = 4u;  // ... if it starts INSIDE a string
 constexpr uint32_t SF_UTF8 = 8u;        // UTF-8 error in the segment
 constexpr uint32_t SF_RESOLVED = 16u;   // the segment fixed its own in-string carry-in (first control character): its
                                         // mask plane 0 is final and both counts are equal
+constexpr uint32_t SF_TOKENS = 32u;     // launch_stage1 with a token stream: the segment's structural bytes lie in its staging area
 
 struct seg_summary {
   uint32_t count_if_out; // structurals (stage1) / kept bytes (minify) if the segment starts outside a string
@@ -93,8 +94,11 @@ struct scan_origin {
   uint32_t carry;
 };
 constexpr uint64_t RANGE_ALIGN = uint64_t(1) << 20; // one resolve group = 16 large tiles = 64 small tiles
+// tokstage / tok (both or neither): the token-byte stream beside the offsets -- tok[i] = buf[idx[i]] for i < n.  tokstage: scratch of num_segments(len -
+// org.begin) * SEG_BYTES bytes, 16-byte aligned (the segments' structural bytes wait there between the two kernels); tok: room for n bytes
 void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *summ, seg_prefix *pref, uint32_t *idx,
-                   uint64_t idx_words, scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev);
+                   uint64_t idx_words, scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev, uint8_t *tokstage = nullptr,
+                   uint8_t *tok = nullptr);
 void launch_minify(const uint8_t *buf, uint64_t len, seg_summary *summ, seg_prefix *pref, uint8_t *dst,
                    scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev);
 // result->n = parity; workspace: one byte per 16 KiB segment of the buffer (the per-segment parities and x words, folded by a second launch)
@@ -136,7 +140,8 @@ size_t finish_workspace_bytes(uint32_t n);
 void launch_finish(int mode, const uint8_t *buf, uint64_t len, uint32_t *idx, uint32_t n, void *workspace, hipStream_t stream);
 // depth[i] = nesting depth in front of structural i for i in [0, n], depth[n] = behind the last; scratch: depth_scan_scratch_bytes(n)
 size_t depth_scan_scratch_bytes(uint32_t n);
-void launch_depth_scan(const uint8_t *buf, const uint32_t *idx, uint32_t n, int32_t *depth, void *scratch, hipStream_t stream);
+// tok (optional): the token stream of the list (tok[i] = buf[idx[i]]); with it neither buf nor idx is read
+void launch_depth_scan(const uint8_t *buf, const uint32_t *idx, uint32_t n, int32_t *depth, void *scratch, hipStream_t stream, const uint8_t *tok = nullptr);
 
 // ---- one workgroup per document (sjgpu_small.hip) ---------------------------------------------------------------------
 // in_off: byte offset of the document in the input block (a multiple of 64); out_off: first output unit of the document in

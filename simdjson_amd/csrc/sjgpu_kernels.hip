@@ -41,14 +41,29 @@ namespace {
 // ~415 VALU instructions per chunk (profiles/r02_pmc_ndjson.txt: this kernel issues 81 % of the time).  The four
 // leave their left-over rows where they are and go; wave 0 validates all of them together.
 constexpr u32 SUMM_WAVES = 4;
-__global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_stage1_summarize(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ mask0,
+// TOKENS (round 5, sjgpu_stage1_tokens_device): the segment's structural BYTES leave with its masks.  A lane holds the 64 bytes of its block and, in a
+// resolved segment, their final structural mask: the kept bytes of every chunk are compacted through a per-wave LDS window (emit_bytes, the minifier's
+// compaction) into the segment's staging area tokstage[seg * SEG_BYTES ...], in list order; k_stage1_emit, which learns where the segment's offsets go, copies
+// them behind the same cursor.  Every later pass over the LIST then reads one byte per structural instead of fetching the whole document through 128-byte
+// lines to pick that byte.  Segments that could not resolve themselves (no control character in their first chunk: minified text) stage
+// nothing (no SF_TOKENS in their summary): emit gathers their bytes from the document.  Costs this kernel the compaction (~170 VALU per chunk on top of
+// ~410) and 16.5 KiB more LDS per workgroup (four workgroups per CU instead of six): the token stream is opt-in.
+template <bool TOKENS>
+__global__ __launch_bounds__(64 * SUMM_WAVES) SJ_WAVES_PER_EU(TOKENS ? 4 : 6, TOKENS ? 4 : 6) void k_stage1_summarize(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ mask0,
                                                                      u64 *__restrict__ mask1, seg_summary *__restrict__ summ,
-                                                                     scan_origin org, u32 nseg) {
+                                                                     scan_origin org, u32 nseg, u8 *__restrict__ tokstage) {
   const u32 lane = lane_id();
   const u32 wave = threadIdx.x >> 6;
   const u32 seg = blockIdx.x * SUMM_WAVES + wave; // relative to the scan's origin: workspace index
   __shared__ __attribute__((aligned(16))) u32 park[SUMM_WAVES][UTF8P_ROWS * UTF8P_ROW_WORDS]; // the blocks the UTF-8 check still has to look at (utf8_park)
   __shared__ u32 sh_left[SUMM_WAVES]; // rows every wave has left when its segment ends
+  __shared__ __attribute__((aligned(16))) u8 tok_window[TOKENS ? SUMM_WAVES : 1][TOKENS ? MINIFY_STAGE_BYTES : 16]; // TOKENS: the compaction window of each wave
+  __shared__ u32 tok_lut[MINIFY_LUT_WORDS];
+  if (TOKENS) { // (every wave fills the table with the same words: no barrier needed before its own use)
+    init_compaction_lut(tok_lut, lane);
+    clear_minify_stage(tok_window[wave], lane);
+  }
+  u32 tok_run = 0; // TOKENS: structural bytes of this segment staged so far (wave-uniform)
   const bool more = (org.carry & CARRY_MORE) != 0;
   if (seg >= nseg) { // past the last segment (wave-uniform; wave 0 always has one): only the rendezvous below
     if (lane == 0) { sh_left[wave] = 0; }
@@ -104,6 +119,7 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu
       n_a += u32(popc64(structural));
       any_a |= __ballot((m.ctrl & (m.in_string ^ flip)) != 0) != 0;
       keep0[c] = structural;
+      if (TOKENS) { emit_bytes(w, structural, lane, tokstage + size_t(seg) * SEG_BYTES, tok_run, tok_window[wave], tok_lut); }
     } else {
       n_a += u32(popc64(m.cand));
       n_b += u32(popc64(m.cand & m.string_tail));
@@ -150,6 +166,7 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) __attribute__((amdgpu_waves_per_eu
   seg_summary s;
   if (resolved) {
     flags |= SF_RESOLVED;
+    if (TOKENS) { flags |= SF_TOKENS; }
     s.count_if_out = ta;
     s.count_if_in = ta;
     // true carry-in == derived: error iff a control character sits inside a string in the resolved view;
@@ -349,10 +366,14 @@ __device__ __forceinline__ seg_prefix segment_prefix(const seg_summary *__restri
 // =====================================================================================================
 // stage 1, kernel 2: select the right hypothesis per segment, flatten bitmaps to ascending offsets
 // =====================================================================================================
+// TOKENS: tok[i] = buf[idx[i]] for the segment's offsets, behind the same cursor: copied from the staging area k_stage1_summarize<true> filled, or -- a
+// segment that staged nothing, or whose one patched candidate bit (sj_xcarry.h) changes the list the staging was made for -- gathered from the document
+template <bool TOKENS>
 __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask0, const u64 *__restrict__ mask1,
                                                     const seg_summary *__restrict__ summ, const seg_prefix *__restrict__ gpref,
                                                     u64 len, u32 *__restrict__ idx, u64 idx_words,
-                                                    scan_result_dev *__restrict__ result, scan_origin org) {
+                                                    scan_result_dev *__restrict__ result, scan_origin org, const u8 *__restrict__ buf,
+                                                    const u8 *__restrict__ tokstage, u8 *__restrict__ tok) {
   __shared__ __attribute__((aligned(16))) u32 stage[EMIT_STAGE_WORDS];
   const u32 lane = lane_id();
   const u32 seg = blockIdx.x;
@@ -388,8 +409,27 @@ __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask
   for (u32 c = 0; c < SEG_CHUNKS; c++) { st[c] = resolved ? m0[c] : (m0[c] & ~(m1[c] ^ flip)); } // chunks beyond len hold zero masks
   span_patch(st, own.xw, x, t.se, lane);
   const u32 span_count = (org.carry & CARRY_DEBUG_NO_SPAN_HINT) ? 0u : xs_count(own.count_if_out, own.count_if_in, t);
+  const u32 base_before = base;
   emit_span4_adaptive<EMIT_WINDOW>(st, u32(seg_start), lane, idx, idx_words, base, stage, overflow, span_count); // sparse segments go out in one piece
   if (__ballot(overflow) && lane == 0) { atomicOr(&result->flags, SJGPU_F_IDX_OVERFLOW); }
+  if (TOKENS && !__ballot(overflow)) {
+    const u32 cnt = base - base_before; // wave-uniform
+    if ((own.flags & SF_TOKENS) != 0u && t.dcount == 0) {
+      const u8 *src = tokstage + size_t(seg) * SEG_BYTES;
+#pragma unroll 1
+      for (u32 i = lane; i < cnt; i += 64) { tok[size_t(base_before) + i] = src[i]; }
+    } else { // the offsets this WAVE has just written, read back by itself once its stores have been acknowledged (no fence: an agent-scope fence writes
+             // back and invalidates the XCD's L2 -- see leave_and_clean in sjgpu_fused.hip); the road of segments that resolved nothing and of patched bits
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const volatile u32 *back = idx + size_t(base_before);
+#pragma unroll 1
+      for (u32 i = lane; i < cnt; i += 64) {
+        const u32 p = back[i];
+        tok[size_t(base_before) + i] = u64(p) < len ? buf[p] : u8(0x20);
+      }
+    }
+  }
 }
 
 // =====================================================================================================
@@ -556,7 +596,7 @@ static inline void mark(hipEvent_t *ev, int k, hipStream_t stream) {
 }
 
 void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *summ, seg_prefix *pref, uint32_t *idx,
-                   uint64_t idx_words, scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev) {
+                   uint64_t idx_words, scan_result_dev *result, scan_origin org, hipStream_t stream, hipEvent_t *ev, uint8_t *tokstage, uint8_t *tok) {
   const u32 nseg = num_segments(len - org.begin);
   static const bool no_hint = std::getenv("SJGPU_NO_SPAN_HINT") != nullptr; // A/B switch
   if (no_hint) { org.carry |= CARRY_DEBUG_NO_SPAN_HINT; }
@@ -567,8 +607,14 @@ void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *
   mark(ev, 0, stream);
   u64 *mask0 = reinterpret_cast<u64 *>(masks);
   u64 *mask1 = mask0 + size_t(nseg) * (SEG_BYTES / BLOCK_BYTES); // second plane, only written by unresolved segments
-  hipLaunchKernelGGL(k_stage1_summarize, dim3((nseg + SUMM_WAVES - 1) / SUMM_WAVES), dim3(64 * SUMM_WAVES), 0, stream, buf, len, mask0, mask1, summ,
-                     org, nseg);
+  const bool tokens = tokstage != nullptr && tok != nullptr;
+  if (tokens) {
+    hipLaunchKernelGGL(k_stage1_summarize<true>, dim3((nseg + SUMM_WAVES - 1) / SUMM_WAVES), dim3(64 * SUMM_WAVES), 0, stream, buf, len, mask0, mask1, summ,
+                       org, nseg, tokstage);
+  } else {
+    hipLaunchKernelGGL(k_stage1_summarize<false>, dim3((nseg + SUMM_WAVES - 1) / SUMM_WAVES), dim3(64 * SUMM_WAVES), 0, stream, buf, len, mask0, mask1, summ,
+                       org, nseg, static_cast<u8 *>(nullptr));
+  }
   mark(ev, 1, stream);
   const u32 ngroups = (nseg + RESOLVE_GROUP - 1) / RESOLVE_GROUP;
   seg_summary *gsum = summ + nseg; // the group summaries live behind the segment summaries
@@ -576,8 +622,13 @@ void launch_stage1(const uint8_t *buf, uint64_t len, uint4 *masks, seg_summary *
   hipLaunchKernelGGL(k_resolve_segments, dim3(1), dim3(RESOLVE_THREADS), 0, stream, gsum, pref, ngroups, len, idx, idx_words,
                      result, 0, org);
   mark(ev, 2, stream);
-  hipLaunchKernelGGL(k_stage1_emit, dim3(nseg), dim3(64), 0, stream, mask0, mask1, summ, pref, len, idx, idx_words, result,
-                     org);
+  if (tokens) {
+    hipLaunchKernelGGL(k_stage1_emit<true>, dim3(nseg), dim3(64), 0, stream, mask0, mask1, summ, pref, len, idx, idx_words, result, org, buf,
+                       static_cast<const u8 *>(tokstage), tok);
+  } else {
+    hipLaunchKernelGGL(k_stage1_emit<false>, dim3(nseg), dim3(64), 0, stream, mask0, mask1, summ, pref, len, idx, idx_words, result, org, buf,
+                       static_cast<const u8 *>(nullptr), static_cast<u8 *>(nullptr));
+  }
   mark(ev, 3, stream);
 }
 

@@ -169,6 +169,7 @@ struct workspace {
   std::vector<seg_prefix> pref;
   std::vector<uint64_t> result_and_desc; // [result (2 words)][descriptors][ticket]
   std::vector<uint8_t> esc;
+  std::vector<uint8_t> tokstage, tok; // launch_stage1 with a token stream: the staging area between its two kernels, the stream itself
   std::vector<uint32_t> idx;
   std::vector<uint8_t> out;
   uint8_t *in = nullptr; // 16-byte aligned copy of the document, nothing readable... (the kernels must not depend on what lies behind len)
@@ -186,6 +187,8 @@ struct workspace {
       result_and_desc.assign(2 + num_fused_tiles(cap) * 4 + 8, 0);
       esc.assign(SEGMENT_BYTES_TABLE, 0); // launch_string_parity: one byte per segment
       idx.assign(cap + 16, 0);
+      tokstage.assign(size_t(nseg) * SEG_BYTES + 64, 0);
+      tok.assign(cap + 64, 0);
       out.assign(cap + 64, 0);
       in_store.assign(cap + 64, 0);
     }
@@ -261,6 +264,21 @@ static void check_stage1(const char *what, const bytes &doc, const expected &e, 
   const uint32_t L = uint32_t(doc.size());
   if (w.idx[e.n] != L || w.idx[e.n + 1] != L || w.idx[e.n + 2] != 0) { report(what, doc, "sentinels"); }
 }
+// the token stream beside the list: tok[i] = the byte at idx[i]
+static void check_tokens(const char *what, const bytes &doc, const expected &e, workspace &w) {
+  const scan_result_dev r = *w.result();
+  n_checked++;
+  if ((r.flags & 7u) != e.flags || (e.flags & SJGPU_F_UNESCAPED_CTRL) || r.n != e.n) { return; } // check_stage1 has reported it / nobody looks at the list
+  for (uint32_t i = 0; i < e.n; i++) {
+    const uint8_t want = e.idx[i] < doc.size() ? doc[e.idx[i]] : uint8_t(0x20);
+    if (w.tok[i] != want) {
+      char detail[128];
+      snprintf(detail, sizeof detail, "tok[%u] = %#x, the byte at idx[%u] = %u is %#x (n %u)", i, w.tok[i], i, e.idx[i], want, e.n);
+      report(what, doc, detail);
+      return;
+    }
+  }
+}
 static void check_minify(const char *what, const bytes &doc, const expected &e, workspace &w) {
   const scan_result_dev r = *w.result();
   n_checked++;
@@ -306,6 +324,11 @@ int main(int argc, char **argv) {
       std::fill(w.idx.begin(), w.idx.begin() + len + 8, 0xDEADBEEFu);
       launch_stage1(w.in, len, w.masks.data(), w.summ.data(), w.pref.data(), w.idx.data(), len + 3, w.result(), org, nullptr, nullptr);
       check_stage1("split stage 1", doc, e, w);
+      std::fill(w.idx.begin(), w.idx.begin() + len + 8, 0xDEADBEEFu); // the same scan with the token stream beside the offsets
+      std::fill(w.tok.begin(), w.tok.begin() + len + 8, uint8_t(0xEE));
+      launch_stage1(w.in, len, w.masks.data(), w.summ.data(), w.pref.data(), w.idx.data(), len + 3, w.result(), org, nullptr, nullptr, w.tokstage.data(), w.tok.data());
+      check_stage1("split stage 1 with tokens", doc, e, w);
+      check_tokens("split stage 1 with tokens", doc, e, w);
       launch_minify(w.in, len, w.summ.data(), w.pref.data(), w.out.data(), w.result(), org, nullptr, nullptr);
       check_minify("split minify", doc, e, w);
       launch_validate_utf8(w.in, len, w.result(), nullptr, nullptr);

@@ -559,6 +559,83 @@ def test_depth_scan(orc):
     p.close()
 
 
+def _minified(a):
+    """the same document without whitespace outside strings (no control character: every 16 KiB segment must carry both in-string hypotheses)"""
+    import json
+    return np.frombuffer(json.dumps(json.loads(bytes(a)), separators=(",", ":"), ensure_ascii=False).encode(), np.uint8)
+
+
+def test_token_stream_beside_the_offsets(orc):
+    """sjgpu_stage1_tokens_device (round 5): the bytes under the structurals leave stage 1 WITH the offsets -- tok[i] = buf[idx[i]] -- and a list pass reads
+    one coalesced byte per entry instead of gathering it out of the document (the reference's consumers dereference the list the same way:
+    src/generic/stage2/json_iterator.h:246-288, find_next_document_index.h:39-98).  Same list, same flags as sjgpu_stage1_device; the stream checked
+    byte for byte against the document; the depth scan from the stream equal to the depth scan that gathers.  The documents take both roads of
+    the emission kernel: staged by the scan kernel (segments that resolve themselves) and gathered (minified text: no control character; a patched
+    candidate bit behind a 64-byte backslash run)."""
+    import torch
+    p = capi.DomParserImplementation(96 << 20)
+    stream = torch.cuda.current_stream().cuda_stream
+    ex = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jsonexamples")
+    tw = np.fromfile(os.path.join(ex, "twitter.json"), dtype=np.uint8)
+    runs = b'["' + (b"\\" * 40 + b'\" x') * 3000 + b'", 1, "' + b"\\" * 8191 + b'\"", {"k": "' + b"\\" * 32 + b'"}]'
+    docs = {"twitter.json": tw, "twitter.json minified": _minified(tw), "citm": np.fromfile(os.path.join(ex, "citm_catalog.json"), dtype=np.uint8),
+            "twitter_like 24 MiB": corpus.twitter_like(24 << 20, 7)[0], "large_random 24 MiB": corpus.large_random(24 << 20, 8)[0],
+            "amazon_ndjson 24 MiB": corpus.amazon_ndjson(24 << 20, 9)[0], "deep_nesting": corpus.deep_nesting(3 << 20), "escape_heavy 16 MiB": corpus.escape_heavy(16 << 20, 10)[0],
+            "backslash runs across segments": np.frombuffer(runs, np.uint8), "tiny": np.frombuffer(b'{"a":[1,2,{"b":null}]}', np.uint8),
+            "ends inside a string": np.frombuffer(b'[1, 2, "abc', np.uint8), "one segment and a byte": np.frombuffer(b"[" + b"1," * 8191 + b"1]", np.uint8)}
+    for name, a in docs.items():
+        L = len(a)
+        buf = torch.from_numpy(a.copy()).cuda()
+        idx = torch.full((L + 16,), -1, dtype=torch.int32, device="cuda")
+        idx2 = torch.full((L + 16,), -1, dtype=torch.int32, device="cuda")
+        tok = torch.full((L + 16,), 0xEE, dtype=torch.uint8, device="cuda")
+        p.set_pipeline("split")
+        assert p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, stream) == 0
+        n, flags, _ = p.result(stream)
+        assert p.stage1_tokens_device(buf.data_ptr(), L, idx2.data_ptr(), L + 3, tok.data_ptr(), L + 16, stream) == 0
+        n2, flags2, _ = p.result(stream)
+        assert (n2, flags2) == (n, flags), (name, n, n2, flags, flags2)
+        if flags & capi.F_UNESCAPED_CTRL:
+            continue
+        assert torch.equal(idx[: n + 3], idx2[: n + 3]), name
+        oidx, _ = orc.scan(a)
+        assert n == len(oidx), name
+        want = torch.from_numpy(a[oidx].copy()).cuda()
+        assert torch.equal(tok[:n], want), (name, first_diff(tok[:n].cpu().numpy(), want.cpu().numpy()))
+        assert int(tok[n].item()) == 0xEE  # nothing behind the last token
+        depth_a = torch.full((n + 1,), -99, dtype=torch.int32, device="cuda")
+        depth_b = torch.full((n + 1,), -98, dtype=torch.int32, device="cuda")
+        p.depth_scan_device(buf.data_ptr(), idx.data_ptr(), n, depth_a.data_ptr(), stream)
+        p.depth_scan_tokens_device(tok.data_ptr(), n, depth_b.data_ptr(), stream)
+        assert torch.equal(depth_a, depth_b), name
+    p.close()
+
+
+def test_token_stream_at_full_size(orc):
+    """BASELINE configs[3]'s shard (1 GiB of amazon NDJSON) and configs[1] (1 GiB large_random) with the token stream: the list equal to the plain call's,
+    every token byte equal to the byte of the document under its offset (checked on the device: a gather the test does once)."""
+    import torch
+    stream = torch.cuda.current_stream().cuda_stream
+    for kind in ("amazon_ndjson", "large_random"):
+        a, _ = getattr(corpus, kind)(1 << 30, 77)
+        L = len(a)
+        p = capi.DomParserImplementation(L)
+        buf = torch.from_numpy(a).cuda()
+        idx = torch.empty(L // 2 + 16, dtype=torch.int32, device="cuda")
+        tok = torch.empty(L // 2 + 16, dtype=torch.uint8, device="cuda")
+        assert p.stage1_tokens_device(buf.data_ptr(), L, idx.data_ptr(), L // 2, tok.data_ptr(), L // 2 + 16, stream) == 0
+        n, flags, _ = p.result(stream)
+        assert flags == 0 and n > 1000
+        assert torch.equal(tok[:n], buf[idx[:n].to(torch.int64)]), kind
+        idx2 = torch.empty(L // 2 + 16, dtype=torch.int32, device="cuda")
+        p.set_pipeline("split")
+        assert p.stage1_device(buf.data_ptr(), L, idx2.data_ptr(), L // 2, stream) == 0
+        n2, flags2, _ = p.result(stream)
+        assert (n2, flags2) == (n, flags) and torch.equal(idx[: n + 3], idx2[: n + 3]), kind
+        p.close()
+        del buf, idx, idx2, tok
+
+
 # ---- SURVEY 8(f3): the strings of a document, unescaped on the device -----------------------------------------------------------------
 def _device_strings(p, a, allow=False):
     """-> (err, string buffer bytes, CSR offsets[n + 1], strings, first_bad, n, idx) through stage1_device + parse_strings_device"""

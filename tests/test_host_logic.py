@@ -51,6 +51,21 @@ def test_every_barrier_waits_for_lds(lib):
     assert found == []
 
 
+def test_no_tile_kernel_flushes_the_l2(lib):
+    """An agent-scope fence (__threadfence()) is buffer_wbl2 + buffer_inv on this part: a write-back and an invalidation of the XCD's whole L2.  Two of
+    them in the epilogue of the single-pass kernels -- executed once per wave that leaves -- took the headline from 0.49 to 0.72 ms per GiB before any
+    counter was looked at (round 5, profiles/r05_selfclean_ab.txt).  The scan kernels hand data from workgroup to workgroup through agent-scope atomics and
+    wait for acknowledgements; this reads the built code objects and fails if one of them contains either instruction."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_barriers", os.path.join(_paths.REPO_ROOT, "scripts", "check_barriers.py"))
+    cb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cb)
+    counts = cb.l2_flushes(os.path.join(_paths.LIB_DIR, "libsjgpu.so"))
+    hot = {k: v for k, v in counts.items() if any(t in k for t in ("k_fused", "k_minify_onchip", "k_stage1_", "k_minify_", "k_validate_utf8", "k_resolve", "k_docs"))}
+    assert len(hot) >= 12, sorted(hot)
+    assert {k: v for k, v in hot.items() if v} == {}
+
+
 def test_no_kernel_spills(lib):
     """Round 2's review found 20 B of scratch in the headline kernel and in k_stage1_summarize (spills inside the hot loop of a
     kernel that is short of issue slots).  What the code objects of the built library tell the hardware to reserve
@@ -72,8 +87,8 @@ def test_no_kernel_spills(lib):
     for k, v in res.items():
         if "k_fused_pipelined" in k or "k_minify_onchip" in k:
             assert v["vgpr"] <= 128, (k, v)
-        if "k_stage1_summarize" in k:
-            assert v["vgpr"] <= 80, (k, v)
+        if "k_stage1_summarize" in k:  # <true>: the token-stream variant (four waves per SIMD, 39 KiB of LDS: four workgroups per CU)
+            assert v["vgpr"] <= (128 if "ILb1E" in k else 80), (k, v)
 
 
 def test_barrier_check_finds_a_dropped_wait(tmp_path):
