@@ -419,7 +419,7 @@ def leg_list_passes(cx, which):
         depth2 = torch.empty(n + 1, dtype=torch.int32, device="cuda")
         p.set_pipeline("split")
         run_plain = lambda: p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, stream)
-        run_tok = lambda: p.stage1_tokens_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, tok.data_ptr(), L // 2 + 16, stream)
+        run_tok = lambda: p.stage1_tokens_device(buf.data_ptr(), L, idx.data_ptr(), L // 2, tok.data_ptr(), L // 2 + 16, stream)  # (a byte per list word)
         run_tok()
         nt, ft, _ = p.result(stream)
         assert (nt, ft) == (n, flags) and bool(torch.equal(idx[: n + 3], keep))

@@ -822,14 +822,27 @@ __device__ __forceinline__ bool emit_span(const u64 *m, u32 pos0, u32 lane, u32 
     vbase[k] = lane_pos + (k >> 1) * CHUNK_BYTES + (k & 1u) * 32u;
     a[k] *= 4u; // byte addresses from here on: no shift per store
   }
+  // two trips per round: the second store of a chain takes its address from the first one's register plus an IMMEDIATE offset (ds_write_b32 ... offset:4;
+  // the dump slot has a neighbour for it), so a chain's slot advances once per round -- 44 VALU instructions per trip instead of 48 (round 5)
+  char *const stage_c = reinterpret_cast<char *>(stage);
+  u32 t = 0;
 #pragma unroll 1
-  for (u32 t = 0; t < trips; t++) {
+  for (; t + 2u <= trips; t += 2u) {
 #pragma unroll
     for (u32 k = 0; k < NH; k++) {
       const u32 bits = h[k];
-      *reinterpret_cast<u32 *>(reinterpret_cast<char *>(stage) + (bits ? a[k] : 4u * DUMP)) = vbase[k] + ffbl_raw(bits); // (an empty chain's value lands in the dump slot)
-      h[k] = bits & (bits - 1u);
-      a[k] += 4u;
+      *reinterpret_cast<u32 *>(stage_c + (bits ? a[k] : 4u * DUMP)) = vbase[k] + ffbl_raw(bits); // (an empty chain's value lands in the dump slot)
+      const u32 rest = bits & (bits - 1u);
+      *reinterpret_cast<u32 *>(stage_c + (rest ? a[k] : 4u * DUMP) + 4u) = vbase[k] + ffbl_raw(rest);
+      h[k] = rest & (rest - 1u);
+      a[k] += 8u;
+    }
+  }
+  if (t < trips) {
+#pragma unroll
+    for (u32 k = 0; k < NH; k++) {
+      const u32 bits = h[k];
+      *reinterpret_cast<u32 *>(stage_c + (bits ? a[k] : 4u * DUMP)) = vbase[k] + ffbl_raw(bits);
     }
   }
   wave_lds_fence();

@@ -5,6 +5,7 @@
 // tests/dom/basictests.cpp -a <impl>).  Built in the build container (needs the reference headers and
 // oracle/_ref/simdjson_ref.o), run on the GPU box by tests/test_plugin.py.
 #include "mi355x_implementation.h"
+#include "sjgpu.h"
 
 #include <algorithm>
 #include <chrono>
@@ -408,11 +409,32 @@ int main(int argc, char **argv) {
     }
     const std::string got = std::to_string(parser.doc.tape[0]) + "/" + std::to_string(simdjson::minify(e).size());
     CHECK(got == want, "the pinned parse left another document (%s vs %s)", got.c_str(), want.c_str());
+    // ... and with the DOCUMENT's buffers page-locked as well (sjgpu_host_register on what dom::document::allocate reserved,
+    // include/simdjson/dom/document-inl.h:48-56): the tape and the string buffer are what comes BACK, and there is more of it than went up
+    double best_both = 1e9;
+    {
+      const size_t cap = parser.doc.capacity();
+      const size_t tape_bytes = SIMDJSON_ROUNDUP_N(cap + 3, 64) * sizeof(uint64_t), string_bytes = SIMDJSON_ROUNDUP_N(5 * (cap / 3) + SIMDJSON_PADDING, 64);
+      const bool reg = sjgpu_host_register(parser.doc.tape.get(), tape_bytes) == 0 && sjgpu_host_register(parser.doc.string_buf.get(), string_bytes) == 0;
+      for (int r = 0; r < reps && reg; r++) {
+        const double t0 = now();
+        CHECK(parser.parse(padded_string_view(pinned)).get(e) == SUCCESS, "parse (pinned, document buffers registered)");
+        best_both = std::min(best_both, now() - t0);
+      }
+      (void)sjgpu_host_unregister(parser.doc.tape.get());
+      (void)sjgpu_host_unregister(parser.doc.string_buf.get());
+      if (!reg) { best_both = -1e-3; }
+    }
     std::printf("{\"pinned_bench\": {\"bytes\": %zu, \"fresh_pageable_ms\": %.3f, \"same_pageable_buffer_again_ms\": %.3f, \"pinned_padded_string_ms\": %.3f, "
-                "\"speedup_vs_fresh_pageable\": %.3f}}\n",
-                big.size(), best_fresh * 1e3, best_same * 1e3, best_pinned * 1e3, best_fresh / best_pinned);
+                "\"pinned_and_registered_document_ms\": %.3f, \"speedup_vs_fresh_pageable\": %.3f, \"speedup_with_registered_document\": %.3f}}\n",
+                big.size(), best_fresh * 1e3, best_same * 1e3, best_pinned * 1e3, best_both * 1e3, best_fresh / best_pinned, best_both > 0 ? best_fresh / best_both : 0.0);
   }
   get_active_implementation() = before;
+  // give the pooled contexts back (streams, copy threads, page-locked blocks) before the process ends: at exit the HIP runtime tears its own state down
+  // AFTER the sanitizer's device allocator has unloaded, and an AddressSanitizer build then dies in a CHECK of its own (sanitizer_allocator_device.h)
+  // while the runtime frees what was left -- with the verdict below still in a pipe's buffer
+  (void)sjgpu_pool_trim();
   std::printf("plugin test OK\n");
+  std::fflush(stdout);
   return 0;
 }

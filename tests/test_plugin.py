@@ -130,4 +130,8 @@ def test_sanitizers_over_the_host_shim():
             text = out.stdout + out.stderr
             assert "plugin test OK" in out.stdout, (san, route, text[-3000:])
             assert "ERROR: AddressSanitizer" not in text and "WARNING: ThreadSanitizer" not in text, (san, route, text[-4000:])
-            assert out.returncode == 0, (san, route, text[-2000:])
+            # (one exit code is forgiven: ROCm's AddressSanitizer runtime can die in a CHECK of its OWN device allocator -- sanitizer_allocator_device.h,
+            # "dev_runtime_unloaded_" -- when libamdhip64's exit handlers free memory after that allocator has been unloaded: after main has returned, after the
+            # verdict above, no report about this repository's code; seen in round 5 on the overlapped route, gpurun_out/r5b_asan.log)
+            teardown = san == "address" and "sanitizer_allocator_device.h" in text and "__cxa_finalize" in text
+            assert out.returncode == 0 or teardown, (san, route, text[-2000:])
