@@ -528,6 +528,31 @@ def leg_tape(cx):
                             "traffic": cx.traffic.get(f"tape:{kind}:{256 << 20}"),
                             "traffic_source": "profiles/traffic.json (profiles/r03_pmc_summary.txt, addendum): FETCH_SIZE x 2 + WRITE_SIZE summed over the kernels of one call"},
                "note": "includes the 48-byte result read-back of every call; document, list, tape and string buffer stay on the device"}
+        # round 5: stage 1 + stage 2 with the token stream between them (sjgpu_stage1_tokens_device -> sjgpu_stage2_tokens_device) against the two plain calls
+        tok = torch.empty(L // 2 + 16, dtype=torch.uint8, device="cuda")
+        idx_t = torch.empty(L // 2 + 16, dtype=torch.int32, device="cuda")
+        if n + 3 <= L // 2:
+            p.set_pipeline("split")
+            s1_plain = lambda: p.stage1_device(buf.data_ptr(), L, idx_t.data_ptr(), L // 2, stream)
+            s1_tok = lambda: p.stage1_tokens_device(buf.data_ptr(), L, idx_t.data_ptr(), L // 2, tok.data_ptr(), L // 2 + 16, stream)
+            s1_tok()
+            assert p.result(stream)[0] == n
+            tape_t = torch.empty(L + 8, dtype=torch.int64, device="cuda")
+            run_t = lambda: p.stage2_device(buf.data_ptr(), L, idx_t.data_ptr(), n, tape_t.data_ptr(), L + 8, sbuf.data_ptr(), scap, 1024, stream, tok_ptr=tok.data_ptr())
+            et, twt, sbt = run_t()
+            if (et, twt, sbt) != (0, tw, sb) or not bool(torch.equal(tape_t[:tw], tape[:tw])):
+                raise SystemExit(f"PARITY FAILURE tape/{kind}: stage 2 from the token stream differs from stage 2 from the document")
+            clock_warmup(torch, s1_plain)
+            ms_s1 = event_ms_per_call(torch, s1_plain, reps)
+            clock_warmup(torch, s1_tok)
+            ms_s1t = event_ms_per_call(torch, s1_tok, reps)
+            clock_warmup(torch, run_t)
+            ms_t = event_ms_per_call(torch, run_t, reps)
+            leg["with_token_stream"] = {"stage2_ms_per_call": round(ms_t, 3), "stage1_split_ms_without_tokens": round(ms_s1, 4), "stage1_split_ms_with_tokens": round(ms_s1t, 4),
+                                        "stage1_plus_stage2_ms": {"plain": round(ms_s1 + gpu_ms, 3), "token_stream": round(ms_s1t + ms_t, 3)},
+                                        "parity": "the same tape, word for word, as the call that gathers its token bytes out of the document"}
+            del tape_t
+        del tok, idx_t
         if impl:
             R.sjref_dom_parse.restype = ctypes.c_int
             R.sjref_dom_parse.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64),

@@ -125,6 +125,7 @@ int sjgpu_result(sjgpu_ctx *ctx, void *stream, sjgpu_scan_result *out);
  * list of a sparse document fetches the whole document again to pick one byte per structural.  Stage 1 holds those bytes when it decides what
  * is structural: here they leave with the offsets (compacted by the scan kernel per 16 KiB segment, copied behind the output cursor by the
  * emission kernel; +1 B written per structural) and list passes read ONE coalesced byte per entry: sjgpu_depth_scan_tokens_device below.
+ * tok_dev: 16-byte aligned like the other device pointers.
  * Opt-in because it costs stage 1 (split pipeline only; the byte compaction adds ~40 % to the scan kernel's instructions: DESIGN.md
  * section 4b has the measured cost and what the consumers get back).  Same result / flags / list as sjgpu_stage1_device. */
 int sjgpu_stage1_tokens_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *idx_dev, size_t idx_words, void *tok_dev, size_t tok_bytes,
@@ -290,6 +291,11 @@ int sjgpu_match_keys_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, con
 int sjgpu_stage2_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const void *idx_dev, uint32_t n, uint32_t max_depth, void *tape_dev,
                         size_t tape_cap_words, void *string_buf_dev, size_t string_buf_bytes, void *stream, uint64_t *tape_words_out,
                         uint64_t *string_bytes_out);
+/* the same with the token stream of sjgpu_stage1_tokens_device (tok_dev[i] = buf_dev[idx_dev[i]], i < n; NULL = sjgpu_stage2_device): the tape's token front
+ * reads one coalesced byte per token instead of gathering it out of the document */
+int sjgpu_stage2_tokens_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const void *idx_dev, uint32_t n, const void *tok_dev, uint32_t max_depth,
+                               void *tape_dev, size_t tape_cap_words, void *string_buf_dev, size_t string_buf_bytes, void *stream, uint64_t *tape_words_out,
+                               uint64_t *string_bytes_out);
 /* dom_parser_implementation::parse(buf, len, doc) (include/simdjson/internal/dom_parser_implementation.h:64) for HOST buffers:
  * upload, stage 1, stage 2 on the device, tape and string buffer copied into the caller's arrays (the document's
  * doc.tape / doc.string_buf).  The structural list never leaves the device.  Same error codes as the reference's parse

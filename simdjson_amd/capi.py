@@ -29,7 +29,7 @@ EXPORTS = [
     "sjgpu_stage1_range_device", "sjgpu_minify_range_device",
     "sjgpu_host_alloc", "sjgpu_host_free", "sjgpu_host_register", "sjgpu_host_unregister", "sjgpu_last_pipeline",
     "sjgpu_profile_kernel", "sjgpu_debug_trace_pipelined", "sjgpu_debug_string_path", "sjgpu_stage1_many", "sjgpu_stage1_finish_device",
-    "sjgpu_depth_scan_device", "sjgpu_parse_strings_device", "sjgpu_stage2_device", "sjgpu_parse", "sjgpu_pool_trim", "sjgpu_stream_register", "sjgpu_stream_unregister", "sjgpu_match_keys_device", "sjgpu_comm_unique_id", "sjgpu_comm_create", "sjgpu_comm_destroy", "sjgpu_comm_last_error", "sjgpu_comm_ranks", "sjgpu_comm_gather_indices", "sjgpu_mgpu_create", "sjgpu_mgpu_destroy", "sjgpu_mgpu_count", "sjgpu_mgpu_stage1", "sjgpu_mgpu_minify",
+    "sjgpu_depth_scan_device", "sjgpu_parse_strings_device", "sjgpu_stage2_device", "sjgpu_stage2_tokens_device", "sjgpu_parse", "sjgpu_pool_trim", "sjgpu_stream_register", "sjgpu_stream_unregister", "sjgpu_match_keys_device", "sjgpu_comm_unique_id", "sjgpu_comm_create", "sjgpu_comm_destroy", "sjgpu_comm_last_error", "sjgpu_comm_ranks", "sjgpu_comm_gather_indices", "sjgpu_mgpu_create", "sjgpu_mgpu_destroy", "sjgpu_mgpu_count", "sjgpu_mgpu_stage1", "sjgpu_mgpu_minify",
     "sjgpu_mgpu_validate_utf8",
 ]
 
@@ -123,6 +123,8 @@ def load_library():
     u64p = ctypes.POINTER(ctypes.c_uint64)
     L.sjgpu_stage2_device.restype = ctypes.c_int
     L.sjgpu_stage2_device.argtypes = [vp, vp, sz, vp, ctypes.c_uint32, ctypes.c_uint32, vp, sz, vp, sz, vp, u64p, u64p]
+    L.sjgpu_stage2_tokens_device.restype = ctypes.c_int
+    L.sjgpu_stage2_tokens_device.argtypes = [vp, vp, sz, vp, ctypes.c_uint32, vp, ctypes.c_uint32, vp, sz, vp, sz, vp, u64p, u64p]
     L.sjgpu_match_keys_device.restype = ctypes.c_int
     L.sjgpu_match_keys_device.argtypes = [vp, vp, sz, vp, ctypes.c_uint32, vp, vp, ctypes.c_uint32, vp, vp, u32p]
     L.sjgpu_parse.restype = ctypes.c_int
@@ -406,11 +408,12 @@ class DomParserImplementation:
             raise SjgpuError(f"sjgpu_match_keys_device error {rc}: {self.last_error()}")
         return int(m.value)
 
-    def stage2_device(self, buf_ptr, length, idx_ptr, n, tape_ptr, tape_cap_words, strbuf_ptr, strbuf_bytes, max_depth=1024, stream=0):
-        """sjgpu_stage2_device -> (simdjson error_code, tape words, string buffer bytes); raises on infrastructure errors"""
+    def stage2_device(self, buf_ptr, length, idx_ptr, n, tape_ptr, tape_cap_words, strbuf_ptr, strbuf_bytes, max_depth=1024, stream=0, tok_ptr=0):
+        """sjgpu_stage2_device (tok_ptr: sjgpu_stage2_tokens_device, the token stream of stage1_tokens_device beside the list)
+        -> (simdjson error_code, tape words, string buffer bytes); raises on infrastructure errors"""
         tw, sb = ctypes.c_uint64(0), ctypes.c_uint64(0)
-        rc = self.L.sjgpu_stage2_device(self.h, buf_ptr, int(length), idx_ptr, int(n), int(max_depth), tape_ptr, int(tape_cap_words), strbuf_ptr, int(strbuf_bytes),
-                                        stream or None, ctypes.byref(tw), ctypes.byref(sb))
+        rc = self.L.sjgpu_stage2_tokens_device(self.h, buf_ptr, int(length), idx_ptr, int(n), tok_ptr or None, int(max_depth), tape_ptr, int(tape_cap_words), strbuf_ptr,
+                                               int(strbuf_bytes), stream or None, ctypes.byref(tw), ctypes.byref(sb))
         if rc < 0:
             raise SjgpuError(f"sjgpu_stage2_device error {rc}: {self.last_error()}")
         return rc, int(tw.value), int(sb.value)

@@ -758,7 +758,8 @@ int sjgpu_stage1_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *i
 }
 
 int sjgpu_stage1_tokens_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, void *idx_dev, size_t idx_words, void *tok_dev, size_t tok_bytes, void *stream) {
-  if (!ctx || !buf_dev || !idx_dev || !tok_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u) || (reinterpret_cast<uintptr_t>(idx_dev) & 15u)) {
+  if (!ctx || !buf_dev || !idx_dev || !tok_dev || (reinterpret_cast<uintptr_t>(buf_dev) & 15u) || (reinterpret_cast<uintptr_t>(idx_dev) & 15u) ||
+      (reinterpret_cast<uintptr_t>(tok_dev) & 15u)) { // (the stream leaves as aligned dword stores)
     return SJGPU_E_BADARG;
   }
   if (tok_bytes < idx_words) { return SJGPU_E_BADARG; } // a byte for every word the list may hold
@@ -1666,6 +1667,13 @@ int sjgpu_match_keys_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, con
 int sjgpu_stage2_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const void *idx_dev, uint32_t n, uint32_t max_depth, void *tape_dev,
                         size_t tape_cap_words, void *string_buf_dev, size_t string_buf_bytes, void *stream, uint64_t *tape_words_out,
                         uint64_t *string_bytes_out) {
+  return sjgpu_stage2_tokens_device(ctx, buf_dev, len, idx_dev, n, nullptr, max_depth, tape_dev, tape_cap_words, string_buf_dev, string_buf_bytes, stream, tape_words_out,
+                                    string_bytes_out);
+}
+
+int sjgpu_stage2_tokens_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const void *idx_dev, uint32_t n, const void *tok_dev, uint32_t max_depth,
+                               void *tape_dev, size_t tape_cap_words, void *string_buf_dev, size_t string_buf_bytes, void *stream, uint64_t *tape_words_out,
+                               uint64_t *string_bytes_out) {
   if (!ctx || !buf_dev || !idx_dev || !tape_dev || !string_buf_dev || max_depth == 0 || max_depth > 4095u) { return SJGPU_E_BADARG; }
   // buf_dev: 16-byte aligned like every device entry point (the string stream's chunk loads are 16-byte loads of an aligned buffer)
   if ((reinterpret_cast<uintptr_t>(buf_dev) & 15u) || (reinterpret_cast<uintptr_t>(tape_dev) & 7u) || (reinterpret_cast<uintptr_t>(idx_dev) & 3u)) { return SJGPU_E_BADARG; }
@@ -1691,7 +1699,8 @@ int sjgpu_stage2_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const v
   int roads = STRINGS_STREAM_ONLY;
   bool deep = false;
   for (;;) {
-    const int *string_tokens = launch_tape_front(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, max_depth, ws + tape_at, s);
+    const int *string_tokens = launch_tape_front(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, max_depth, ws + tape_at, s,
+                                                 static_cast<const uint8_t *>(tok_dev));
     const strings_handoff strs = launch_parse_strings(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, false,
                                                       static_cast<uint8_t *>(string_buf_dev), string_buf_bytes, offsets, sres, ws + scratch_at, s, string_tokens, roads);
     launch_tape(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, max_depth, offsets, strs, static_cast<uint8_t *>(string_buf_dev),

@@ -23,17 +23,19 @@ constexpr u32 FIN_THREADS = 256, FIN_PER_THREAD = 16, FIN_BLOCK = FIN_THREADS * 
 
 // structural classes
 enum : u32 { C_OTHER = 0, C_OBJ_OPEN = 1, C_ARR_OPEN = 2, C_OBJ_CLOSE = 3, C_ARR_CLOSE = 4, C_COLON = 5, C_COMMA = 6, C_RS = 7 };
+// Branch-free: a chain of selects.  (Rounds 2-4 had a `switch` here, which hipcc compiles into a tree of DIVERGENT branches -- per entry and row a dozen
+// s_cbranch with exec-mask juggling: the depth scan's code pass took 235 us for 65 M entries whether it gathered its bytes out of the document or read them
+// from the token stream, profiles/r05_token_stream.txt: it was bound by its branches, not by its gather.)
 __device__ __forceinline__ u32 classify_byte(u32 c) {
-  switch (c) {
-  case '{': return C_OBJ_OPEN;
-  case '[': return C_ARR_OPEN;
-  case '}': return C_OBJ_CLOSE;
-  case ']': return C_ARR_CLOSE;
-  case ':': return C_COLON;
-  case ',': return C_COMMA;
-  case 0x1E: return C_RS;
-  default: return C_OTHER;
-  }
+  u32 k = C_OTHER;
+  k = c == u32('{') ? u32(C_OBJ_OPEN) : k;
+  k = c == u32('[') ? u32(C_ARR_OPEN) : k;
+  k = c == u32('}') ? u32(C_OBJ_CLOSE) : k;
+  k = c == u32(']') ? u32(C_ARR_CLOSE) : k;
+  k = c == u32(':') ? u32(C_COLON) : k;
+  k = c == u32(',') ? u32(C_COMMA) : k;
+  k = c == 0x1Eu ? u32(C_RS) : k;
+  return k;
 }
 __device__ __forceinline__ bool is_open(u32 k) { return k == C_OBJ_OPEN || k == C_ARR_OPEN; }
 __device__ __forceinline__ bool is_close(u32 k) { return k == C_OBJ_CLOSE || k == C_ARR_CLOSE; }
@@ -292,8 +294,8 @@ __global__ __launch_bounds__(FIN_THREADS) void k_depth_codes(const u8 *__restric
   for (u32 row = 0; row < DP_ROWS; row++) {
     u32 code = 0;
     if (pos[row] != 0xFFFFFFFFu) {
-      const u32 kk = classify_byte(TOK ? pos[row] : u32(buf[pos[row]]));
-      code = is_open(kk) ? 1u : (is_close(kk) ? 2u : 0u);
+      const u32 ch = (TOK ? pos[row] : u32(buf[pos[row]])) | 0x20u; // '[' | 0x20 = '{', ']' | 0x20 = '}', and no other byte maps onto either
+      code = ch == u32('{') ? 1u : (ch == u32('}') ? 2u : 0u);
     }
     c |= code << (2u * row);
     sum += int(popc64(__ballot(code == 1u))) - int(popc64(__ballot(code == 2u)));

@@ -222,7 +222,9 @@ size_t tape_workspace_bytes(uint32_t n, uint64_t len);
 // the token bytes and the block totals of the per-token counters in the workspace and returns the number of string tokens (device);
 // launch_tape writes the reference's tape (and the length words of the string records when the stream compaction wrote them).
 // workspace: tape_workspace_bytes(n, len), its first bytes are the tape_result_dev afterwards
-const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, void *workspace, hipStream_t s);
+// tok (optional): the token stream of the list (tok[i] = buf[idx[i]], sjgpu_stage1_tokens_device): the front then reads it instead of gathering
+const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, void *workspace, hipStream_t s,
+                             const uint8_t *tok = nullptr);
 // deep: enqueue the sort's second pass (documents nested 64 deep and more).  Without it a deeper document comes back with max_level >= 64 in the result and
 // a tape that is NOT valid: the caller runs the three launches again with deep = true (sjgpu_stage2_device: optimistic, five launches saved on nearly every call).
 void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, const uint32_t *str_offsets, strings_handoff strs,

@@ -83,18 +83,17 @@ __device__ __forceinline__ u32 hex4(const SRC &src, u32 pos) {
   }
   return v;
 }
-__device__ __forceinline__ u32 escape_value(u32 c) { // escape_map, stringparsing.h:22-43
-  switch (c) {
-  case '"': return 0x22u;
-  case '/': return 0x2fu;
-  case '\\': return 0x5cu;
-  case 'b': return 0x08u;
-  case 'f': return 0x0cu;
-  case 'n': return 0x0au;
-  case 'r': return 0x0du;
-  case 't': return 0x09u;
-  default: return 0u;
-  }
+__device__ __forceinline__ u32 escape_value(u32 c) { // escape_map, stringparsing.h:22-43 (0 = not an escape); a chain of selects, not a switch (which compiles into divergent branches)
+  u32 v = 0u;
+  v = c == u32('"') ? 0x22u : v;
+  v = c == u32('/') ? 0x2fu : v;
+  v = c == u32('\\') ? 0x5cu : v;
+  v = c == u32('b') ? 0x08u : v;
+  v = c == u32('f') ? 0x0cu : v;
+  v = c == u32('n') ? 0x0au : v;
+  v = c == u32('r') ? 0x0du : v;
+  v = c == u32('t') ? 0x09u : v;
+  return v;
 }
 
 // parse_string for the string whose first byte sits at pos; WRITE: the unescaped bytes go to dst.  Returns the unescaped

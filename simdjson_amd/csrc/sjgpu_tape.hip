@@ -131,10 +131,18 @@ __device__ __forceinline__ u32 four_tokens(const u8 *__restrict__ tokc, u64 i0) 
 // tokc holds the token bytes with TWO zero bytes in front and behind: tokc[i + 2] = byte of token i (k_tape_rules looks two tokens back
 // and one ahead).  The same sweep leaves the block totals: sums[k * nblocks + block], k = tape words, sort flags, strings, opens,
 // closes, numbers.
+// TOK (round 5): the token bytes come from the stream stage 1 wrote beside the list (sjgpu_stage1_tokens_device) -- a coalesced byte per token; neither the
+// list nor the document is fetched (the gather below reads the list AND a 128-byte line of the document per token: 0.40 GB per 256 MiB twitter-like call)
+template <bool TOK>
 __global__ __launch_bounds__(TS_THREADS) void k_tok_classify(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, u8 *__restrict__ tokc,
-                                                            int *__restrict__ sums, u32 nblocks) {
+                                                            int *__restrict__ sums, u32 nblocks, const u8 *__restrict__ tok) {
   __shared__ u32 sh[3][TS_THREADS / 64];
+  __shared__ unsigned short sh_props[256]; // what a token's byte IS, as bits (token_props_of): one LDS read instead of ~20 compares and mask operations per token
+  static_assert(TS_THREADS == 256, "one table entry per thread");
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  sh_props[tid] = (unsigned short)token_props_of(tid);
+  lds_writes_done();
+  __syncthreads();
   const u64 block0 = u64(blockIdx.x) * TS_BLOCK;
   if (blockIdx.x == 0 && tid == 0) { tokc[0] = 0; tokc[1] = 0; tokc[n + 2] = 0; tokc[n + 3] = 0; }
   // One token per lane and row, sixteen rows of 256: the 64 lanes of a wave fetch the bytes of 64 CONSECUTIVE tokens with one instruction.  Rounds 3-4a
@@ -145,16 +153,19 @@ __global__ __launch_bounds__(TS_THREADS) void k_tok_classify(const u8 *__restric
 #pragma unroll
   for (u32 row = 0; row < CL_ROWS; row++) {
     const u64 i = block0 + u64(row) * TS_THREADS + tid;
-    pos[row] = i < n ? idx[i] : 0xFFFFFFFFu;
+    pos[row] = i < n ? (TOK ? u32(tok[i]) : idx[i]) : 0xFFFFFFFFu; // TOK: the byte itself
   }
   u32 a = 0, b = 0, c = 0;
 #pragma unroll
   for (u32 row = 0; row < CL_ROWS; row++) {
     const u64 i = block0 + u64(row) * TS_THREADS + tid;
     if (i < n) {
-      const u32 ch = pos[row] < len ? u32(buf[pos[row]]) : 0x20u;
+      const u32 ch = TOK ? pos[row] : (pos[row] < len ? u32(buf[pos[row]]) : 0x20u);
       tokc[2 + i] = u8(ch);
-      const tok_packed p = tok_contribution(ch, i == 0);
+      tok_packed p = tok_contribution_of_props(u32(sh_props[ch & 0xFFu]));
+      if (row == 0 && blockIdx.x == 0) { // the root token's number path differs (takes_number_path): one token per document, a branch only block 0 sees
+        if (tid == 0) { p = tok_contribution(ch, true); }
+      }
       a += p.a; b += p.b; c += p.c;
     }
   }
@@ -706,7 +717,7 @@ size_t tape_workspace_bytes(uint32_t n, uint64_t len) { return carve(nullptr, n,
 // launch_tape_front: the byte of every token and the block totals of the six per-token counters.  Returns (a device pointer to) the number of
 // string tokens, which the string pass takes instead of counting them itself.  launch_tape (behind the string pass): tape position and depth of
 // every token, the string and atom words, the lists of the other value tokens, the sort, the brackets, the rules, the numbers.
-const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, void *workspace, hipStream_t s) {
+const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t n, uint32_t max_depth, void *workspace, hipStream_t s, const uint8_t *tok) {
   (void)max_depth;
   const tape_workspace w = carve(static_cast<uint8_t *>(workspace), n, len);
   const u32 n1 = n + 1;
@@ -714,7 +725,8 @@ const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *i
   // (rounds 3-4a: four memsets -- four launches of the runtime's fill kernel, 4 us each)
   hipLaunchKernelGGL(k_tape_init, dim3(1), dim3(64), 0, s, w.res, w.n_words, u32(reinterpret_cast<uint8_t *>(w.n_words + 16) - reinterpret_cast<uint8_t *>(w.res)) / 4u, n1,
                      2u * w.tiles * RADIX_BINS);
-  hipLaunchKernelGGL(k_tok_classify, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, buf, len, idx, n, w.tokc, w.sums, w.tok_blocks);
+  if (tok) { hipLaunchKernelGGL(k_tok_classify<true>, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, buf, len, idx, n, w.tokc, w.sums, w.tok_blocks, tok); }
+  else { hipLaunchKernelGGL(k_tok_classify<false>, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, buf, len, idx, n, w.tokc, w.sums, w.tok_blocks, tok); }
   hipLaunchKernelGGL(k_tok_scan_sums, dim3(TS_SUMS), dim3(1024), 0, s, w.sums, w.tok_blocks, w.totals);
   return w.totals + 2; // the number of string tokens (device)
 }

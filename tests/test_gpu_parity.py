@@ -1549,6 +1549,32 @@ def test_stage2_device_entry_point(tape_parser, orc, ref):
     assert _assert_same_parse(tape_parser, want, bad) == checkers.STRING_ERROR and tape_parser.string_path() == 2
 
 
+def test_stage2_from_the_token_stream(tape_parser, orc, ref):
+    """sjgpu_stage2_tokens_device (round 5): stage 2 fed from the token stream stage 1 wrote beside the list -- the same tape and string buffer word for word,
+    for valid documents and broken ones (the error code is the reference's)."""
+    import torch
+    want = _checker_parse(orc, ref)
+    st = torch.cuda.current_stream().cuda_stream
+    docs = [corpus.twitter_like(8 << 20, 98)[0], corpus.large_random(6 << 20, 97)[0], np.frombuffer(b'{"a":[1,2.5e3,true,null,"x\\u00e9"],"b":{}}', np.uint8),
+            np.frombuffer(b'[1,2,,3]', np.uint8), np.frombuffer(b'{"a":tru}', np.uint8), np.frombuffer(b'[[[[1]]]', np.uint8)]
+    for a in docs:
+        L = len(a)
+        buf = torch.from_numpy(a.copy()).cuda()
+        idx = torch.empty(L + 16, dtype=torch.int32, device="cuda")
+        tok = torch.empty(L + 16, dtype=torch.uint8, device="cuda")
+        tape = torch.empty(L + 8, dtype=torch.int64, device="cuda")
+        sbuf = torch.empty(5 * (L // 3) + 256, dtype=torch.uint8, device="cuda")
+        assert tape_parser.stage1_tokens_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, tok.data_ptr(), L + 16, st) == 0
+        n, flags, _ = tape_parser.result(st)
+        assert flags == 0
+        err, tw, sb = tape_parser.stage2_device(buf.data_ptr(), L, idx.data_ptr(), n, tape.data_ptr(), L + 8, sbuf.data_ptr(), sbuf.numel(), 1024, st, tok_ptr=tok.data_ptr())
+        e_want, t_want, s_want = want(a)
+        assert err == e_want, (bytes(a[:40]), err, e_want)
+        if err == 0:
+            assert (tw, sb) == (len(t_want), len(s_want))
+            assert np.array_equal(tape[:tw].cpu().numpy().view(np.uint64), t_want) and bytes(sbuf[:sb].cpu().numpy()) == bytes(s_want)
+
+
 def test_comm_world_size_one(orc):
     """sjgpu_comm_* (RCCL below the C-ABI): communicator of one rank -- ncclCommInitRank, the (n, base) all-gather, the root's own slot and
     the widening kernel; the N > 1 sends need N devices (the driver's 8-GPU node) and are covered on the CPU by the gloo twin"""
