@@ -1087,6 +1087,18 @@ def ndjson_leg(args, torch, dist, corpus, capi, rank, world, local_rank, fence):
         out["sorted_global_positions"] = bool((pos[1:] > pos[:-1]).all()) if len(pos) > 1 else True
     out["value_GBps"] = round(total * steps / dt_scan / 1e9, 2)
     out["steps"] = steps
+    if rank == 0 and not args.no_cpu_baseline:  # the reference over rank 0's shard, one thread and all hardware threads of the box
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import cpu_baseline as cpu  # test infrastructure: the CPU side of the comparison only
+        cb1 = cpu.time_cpu(host, "stage1", 3)
+        out["cpu_baseline"] = {"value": round(cb1["value"], 3), "unit": "GB/s", "cores": cb1["cores"], "kind": cb1["kind"],
+                               "sample": f"rank 0's {L}-byte shard, {cb1['impl']} kernel, 1 thread, best of 3"}
+        threads = os.cpu_count() or 1
+        cbt = cpu.time_cpu_ndjson_threads(host, threads, 3)
+        if cbt is not None:
+            out["cpu_baseline_threads"] = {"value": round(cbt["value"], 2), "unit": "GB/s", "cores": cbt["cores"], "kind": cbt["kind"],
+                                           "sample": f"rank 0's shard cut at newlines into {cbt['cores']} slices, {cbt['impl']} kernel, one parser per thread, "
+                                                     f"{threads} hardware threads on the box", "structurals": cbt["n"]}
     if n1 is not None:
         out["n1_same_workload_GBps"] = round(n1, 2)
         out["scaling_efficiency"] = round(total * steps / dt_scan / 1e9 / (world * n1), 4)

@@ -1,8 +1,8 @@
 // simdjson_amd/csrc/sj_block.h -- per-lane math of the MI355X stage-1 kernels.
 //
 // Mapping: ONE LANE owns ONE 64-byte block of the input (a wave64 owns 4 KiB).  A lane turns its
-// 16 dwords into eight 64-bit BIT PLANES (plane k, bit i = bit k of byte i) with a 3-stage
-// byte-permute / bit-field-insert network (v_perm_b32 + v_bfi_b32, 9 VALU ops per dword), after
+// 16 dwords into eight 64-bit BIT PLANES (plane k, bit i = bit k of byte i) with a network of
+// byte permutes, rotations and bit-field inserts (v_perm_b32 / v_alignbit_b32 / v_bfi_b32, 7.4 VALU ops per dword), after
 // which every character class of the reference is a handful of 64-bit logic ops and the
 // string/escape algebra runs on the same 64-bit masks the reference's CPU kernels use.
 // This is deliberately NOT the reference's pshufb-nibble-table formulation
@@ -79,31 +79,62 @@ SJ_HD int popc64(u64 x) {
 #endif
 }
 
-// One butterfly of the serial->parallel bit transposition.  (s0,s1) hold consecutive bytes; the
-// odd bytes go to t0, the even bytes to t1, then the bit-fields selected by `himask` are merged so
-// that p0 keeps the upper half of every field pair and p1 the lower half, the byte order of the
-// stream being preserved (earlier byte -> lower bit position).
-SJ_HD void s2p_step(u32 s0, u32 s1, u32 himask, int sh, u32 &p0, u32 &p1) {
-  u32 t0 = byte_perm(s1, s0, 0x07050301u);
-  u32 t1 = byte_perm(s1, s0, 0x06040200u);
-  p0 = bfi(himask, t0, t1 >> sh);
-  p1 = bfi(himask, t0 << sh, t1);
+// rotate left by n (0 < n < 32): v_alignbit_b32 with both sources the same register
+SJ_HD u32 rotl32(u32 x, int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(x, x, u32(32 - n));
+#else
+  return (x << n) | (x >> (32 - n));
+#endif
+}
+// One butterfly of the serial->parallel bit transposition: exchanges a register-index bit with the bit-position bit of weight
+// sh.  a and b hold the same byte positions of the two halves of that index bit; x0 receives the fields of width sh that sit
+// LOW in their pair (from a in place, from b moved up), x1 the fields that sit high.  Written with two shifts this is four
+// instructions; here b is ROTATED once and x1 comes out rotated left by sh -- a debt that is the same for both inputs of every
+// later butterfly (it only depends on the index bits already exchanged), that the field masks do not see (their period divides
+// every debt that reaches them: stages run 4, 2, 1) and that is paid once at the end: plane k leaves rotated left by k.
+SJ_HD void s2p_butterfly(u32 a, u32 b, u32 himask, int sh, u32 &x0, u32 &x1) {
+  const u32 u = rotl32(b, sh);
+  x0 = bfi(himask, u, a);
+  x1 = bfi(himask, a, u);
 }
 
-// 32 bytes (8 dwords, little-endian byte order) -> eight 32-bit plane halves.
+// 32 bytes (8 dwords, little-endian byte order) -> eight 32-bit plane halves: 16 byte permutes, 12 butterflies of three
+// instructions, 7 rotations = 59 instructions (rounds 1-4: 12 steps of two permutes, two shifts and two inserts = 72).
+// Two permute stages first bring the two low bits of the byte index into the register index -- r[c] holds bytes c, c + 8,
+// c + 16, c + 24 -- so that what remains is an 8 x 8 bit-matrix transposition in every byte slot, done by butterflies alone.
 SJ_HD void s2p32(const u32 *s, u32 *p) {
-  u32 o[4], e[4], b73[2], b51[2], b62[2], b40[2];
+  u32 a[8], r[8], x[8], y[8], z[8];
 #pragma unroll
-  for (int j = 0; j < 4; j++) { s2p_step(s[2 * j], s[2 * j + 1], 0xAAAAAAAAu, 1, o[j], e[j]); }
+  for (int d2 = 0; d2 < 2; d2++) {
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
-    s2p_step(o[2 * j], o[2 * j + 1], 0xCCCCCCCCu, 2, b73[j], b51[j]);
-    s2p_step(e[2 * j], e[2 * j + 1], 0xCCCCCCCCu, 2, b62[j], b40[j]);
+    for (int d0 = 0; d0 < 2; d0++) { // dwords j and j + 2: even bytes of both, odd bytes of both
+      const int j = 4 * d2 + d0;
+      a[4 * d2 + d0] = byte_perm(s[j + 2], s[j], 0x06040200u);     // byte index = 0 mod 2
+      a[4 * d2 + 2 + d0] = byte_perm(s[j + 2], s[j], 0x07050301u); // 1 mod 2
+    }
   }
-  s2p_step(b73[0], b73[1], 0xF0F0F0F0u, 4, p[7], p[3]);
-  s2p_step(b51[0], b51[1], 0xF0F0F0F0u, 4, p[5], p[1]);
-  s2p_step(b62[0], b62[1], 0xF0F0F0F0u, 4, p[6], p[2]);
-  s2p_step(b40[0], b40[1], 0xF0F0F0F0u, 4, p[4], p[0]);
+#pragma unroll
+  for (int y0 = 0; y0 < 2; y0++) {
+#pragma unroll
+    for (int d0 = 0; d0 < 2; d0++) { // the same pair of the lower and the upper 16 bytes
+      const u32 lo = a[2 * y0 + d0], hi = a[4 + 2 * y0 + d0];
+      r[4 * d0 + y0] = byte_perm(hi, lo, 0x06040200u);     // byte index = 4 d0 + y0 mod 8
+      r[4 * d0 + 2 + y0] = byte_perm(hi, lo, 0x07050301u); // 4 d0 + 2 + y0
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; c++) { s2p_butterfly(r[c], r[c + 4], 0xF0F0F0F0u, 4, x[c], x[4 + c]); }           // x[4 k2 + (byte index mod 4)]
+#pragma unroll
+  for (int k2 = 0; k2 < 2; k2++) {
+#pragma unroll
+    for (int c = 0; c < 2; c++) { s2p_butterfly(x[4 * k2 + c], x[4 * k2 + 2 + c], 0xCCCCCCCCu, 2, y[4 * k2 + c], y[4 * k2 + 2 + c]); } // y[4 k2 + 2 k1 + (mod 2)]
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) { s2p_butterfly(y[2 * k], y[2 * k + 1], 0xAAAAAAAAu, 1, z[2 * k], z[2 * k + 1]); } // z[k], rotated left by k
+  p[0] = z[0];
+#pragma unroll
+  for (int k = 1; k < 8; k++) { p[k] = rotl32(z[k], 32 - k); }
 }
 
 struct planes { u64 b[8]; };
@@ -133,14 +164,13 @@ SJ_HD u64 andn(u64 a, u64 b) {
 SJ_HD classes classify(const planes &P) {
   const u64 b0 = P.b[0], b1 = P.b[1], b2 = P.b[2], b3 = P.b[3], b4 = P.b[4], b5 = P.b[5], b6 = P.b[6], b7 = P.b[7];
   classes c;
-  // 20 three-input functions per 32-bit half for the five classes (the two-input formulation took ~60)
+  // 17 three-input functions per 32-bit half for the five classes (rounds 3-4: 21; the two-input formulation took ~60)
   c.ctrl = lut3<SJ_TT3(~(A3 | B3 | C3))>(b7, b6, b5);                       // 0x00..0x1F
   const u64 g = lut3<SJ_TT3(~(A3 | B3 | C3))>(b7, b6, b4);                  // high nibble 0x0_ or 0x2_
-  const u64 b5_not0 = andn(b5, b0);                                         // 0x2_ / 0x3_ ... with an even low nibble
-  const u64 n321 = lut3<SJ_TT3(~(A3 | B3 | C3))>(b3, b2, b1);
-  const u64 space = lut3<SJ_TT3(A3 & B3 & C3)>(g, b5_not0, n321);           // 0x20
-  const u64 low_001x = lut3<SJ_TT3(~A3 & ~B3 & C3)>(b3, b2, b1);
-  c.quote = lut3<SJ_TT3(A3 & B3 & C3)>(g, b5_not0, low_001x);               // 0x22
+  const u64 h = lut3<SJ_TT3(A3 & ~B3 & ~C3)>(b5, b0, b3);                   // 0x2_ / 0x3_ / 0x6_ / 0x7_ with a low nibble of 0, 2, 4 or 6
+  const u64 sq = lut3<SJ_TT3(A3 & B3 & ~C3)>(g, h, b2);                     // 0x20 or 0x22
+  const u64 space = andn(sq, b1);                                           // 0x20
+  c.quote = sq & b1;                                                        // 0x22
   // 0x09 0x0A 0x0D: high nibble 0, b3 set, low three bits 001, 010 or 101
   const u64 tlc_low = lut3<SJ_TT3((~A3 & (B3 ^ C3)) | (A3 & ~B3 & C3))>(b2, b1, b0);
   const u64 high0_b3 = lut3<SJ_TT3(A3 & ~B3 & C3)>(g, b5, b3);
@@ -150,10 +180,12 @@ SJ_HD classes classify(const planes &P) {
   c.backslash = lut3<SJ_TT3(A3 & B3 & ~C3)>(high_010, mid_111, b1 | b0);    // 0x5C
   // operators (b5 is "don't care": the x86 kernels compare b|0x20, which also admits 0x0C and 0x1A):
   //   2C/0C x0x0 1100   3A/1A x0x1 1010   5B/7B x1x1 1011   5D/7D x1x1 1101
-  // all four: b7 clear, b3 set, b2 != b1; then b6 clear: b0 clear and b4 == b1; b6 set: b4 and b0 set
-  const u64 if_b6_clear = lut3<SJ_TT3(~C3 & ~(A3 ^ B3))>(b4, b1, b0);
-  const u64 by_b6 = lut3<SJ_TT3((A3 & B3) | (~A3 & C3))>(b6, b4 & b0, if_b6_clear);
-  c.op = lut3<SJ_TT3(~A3 & B3 & C3)>(b7, b3, b2 ^ b1) & by_b6;
+  // all four: b7 clear, b3 set, b2 != b1; then b6 clear: b0 clear and b4 == b1; b6 set: b4 and b0 set.  The second half as two functions:
+  // y = (b0 ? b4 : b4 == b1) keeps what either case needs of b4 and b1, and the case itself is b6 == b0 (b6 set wants b0 set, b6 clear wants it clear)
+  const u64 y = lut3<SJ_TT3((C3 & A3) | (~C3 & ~(A3 ^ B3)))>(b4, b1, b0);
+  const u64 by_b6 = lut3<SJ_TT3(A3 & ~(B3 ^ C3))>(y, b6, b0);
+  const u64 b3_b2ne1 = lut3<SJ_TT3(A3 & (B3 ^ C3))>(b3, b2, b1);
+  c.op = lut3<SJ_TT3(A3 & ~B3 & C3)>(b3_b2ne1, b7, by_b6);
   return c;
 }
 
@@ -269,14 +301,24 @@ SJ_HD quote_scalar quotes_and_scalars(const classes &c, u64 escaped) {
   q.nonquote_scalar = lut3<SJ_TT3(~(A3 | B3 | C3))>(c.ws, c.op, q.quote);
   return q;
 }
-// Step 2 (needs the two 1-bit carries of the lane).
-SJ_HD block_masks finish_block(const classes &c, const quote_scalar &q, u32 in_string_carry, u32 prev_scalar_carry) {
+// ({hi, lo} >> n) & 0xFFFFFFFF for 0 < n < 32: v_alignbit_b32
+SJ_HD u32 funnel_shift_right(u32 hi, u32 lo, int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(hi, lo, u32(n));
+#else
+  return (hi << (32 - n)) | (lo >> n);
+#endif
+}
+// Step 2 (needs the two 1-bit carries of the lane; in_string_carry is 0 or 1), `follows` = nonquote_scalar one byte position on
+SJ_HD block_masks finish_block_follows(const classes &c, const quote_scalar &q, u32 in_string_carry, u64 follows) {
   block_masks m;
-  m.in_string = prefix_xor(q.quote) ^ (0 - u64(in_string_carry));
-  const u64 follows = (q.nonquote_scalar << 1) | prev_scalar_carry;
+  m.in_string = prefix_xor(q.quote ^ u64(in_string_carry)); // (the carry as a quote in front of bit 0: it flips everything, itself included)
   m.cand = lut3<SJ_TT3(A3 | (~B3 & ~C3))>(c.op, c.ws, follows); // op | (scalar & ~follows), scalar = ~(ws | op)
   m.string_tail = m.in_string ^ q.quote;
   return m;
+}
+SJ_HD block_masks finish_block(const classes &c, const quote_scalar &q, u32 in_string_carry, u32 prev_scalar_carry) {
+  return finish_block_follows(c, q, in_string_carry, (q.nonquote_scalar << 1) | prev_scalar_carry);
 }
 
 } // namespace sjgpu

@@ -184,7 +184,7 @@ __device__ __forceinline__ wave_carry segment_carry_from(const u8 *__restrict__ 
 // (one word, so that it costs the kernels one scalar register across their chunk loops: they have none to spare)
 struct span_x {
   u32 bits; // [1:0] kind (SPAN_EXACT / SPAN_B / SPAN_C); [2] kind B: everything scanned so far is backslashes; [3] / [4]: the span's last 64 bytes
-            // ask kind B / C of its successor (span_note_chunk on the last chunk); [31:8] kind B: length L of the leading run once it has ended
+            // ask kind B / C of its successor (span_note_tail behind the last chunk); [31:8] kind B: length L of the leading run once it has ended
   __device__ __forceinline__ u32 kind() const { return bits & 3u; }
   __device__ __forceinline__ u32 lead_open() const { return (bits >> 2) & 1u; }
   __device__ __forceinline__ u32 next_b() const { return (bits >> 3) & 1u; }
@@ -220,31 +220,32 @@ __device__ __forceinline__ wave_carry span_carry_assume(u64 start, u32 lane, u32
   }
   return c;
 }
-// per chunk, after its bytes are in w: the leading run of a kind-B span, and on the span's last chunk what the last 64 bytes are.
-// Costs nothing but a scalar test on the chunks of ordinary spans that are not their last.
-__device__ __forceinline__ void span_note_chunk(span_x &sx, const u32 (&w)[16], u32 chunk_off, bool last_chunk, u32 lane) {
-  if (!((sx.bits & SX_LEAD_OPEN) != 0u || last_chunk)) { return; } // wave-uniform
+// per chunk, after its bytes are in w: the leading run of a kind-B span.  Costs nothing but a scalar test on the chunks of ordinary spans.
+__device__ __forceinline__ void span_note_chunk(span_x &sx, const u32 (&w)[16], u32 chunk_off, u32 lane) {
+  if ((sx.bits & SX_LEAD_OPEN) == 0u) { return; } // wave-uniform
   u32 acc = 0;
 #pragma unroll
-  for (int j = 0; j < 15; j++) { acc |= w[j] ^ 0x5C5C5C5Cu; }
-  const u32 lastx = w[15] ^ 0x5C5C5C5Cu;
-  if (sx.bits & SX_LEAD_OPEN) {
-    const u64 other = __ballot((acc | lastx) != 0u);
-    if (other) {
-      const u32 fl = ctz64(other);
-      u32 pos = 0;
+  for (int j = 0; j < 16; j++) { acc |= w[j] ^ 0x5C5C5C5Cu; }
+  const u64 other = __ballot(acc != 0u);
+  if (other) {
+    const u32 fl = ctz64(other);
+    u32 pos = 0;
 #pragma unroll
-      for (int j = 15; j >= 0; j--) { // the lowest dword that holds something else wins
-        const u32 x = w[j] ^ 0x5C5C5C5Cu;
-        if (x) { pos = 4u * u32(j) + (u32(__ffs(int(x)) - 1) >> 3); }
-      }
-      sx.bits = (sx.bits & ~SX_LEAD_OPEN) | ((chunk_off + fl * BLOCK_BYTES + readlane_dyn(pos, fl)) << 8);
+    for (int j = 15; j >= 0; j--) { // the lowest dword that holds something else wins
+      const u32 x = w[j] ^ 0x5C5C5C5Cu;
+      if (x) { pos = 4u * u32(j) + (u32(__ffs(int(x)) - 1) >> 3); }
     }
+    sx.bits = (sx.bits & ~SX_LEAD_OPEN) | ((chunk_off + fl * BLOCK_BYTES + readlane_dyn(pos, fl)) << 8);
   }
-  if (last_chunk) {
-    const u32 a63 = readlane(acc, 63), l63 = readlane(lastx, 63);
-    if ((a63 | l63) == 0u) { sx.bits |= SX_NEXT_B; }
-    if (a63 == 0u && l63 == (0x225C5C5Cu ^ 0x5C5C5C5Cu)) { sx.bits |= SX_NEXT_C; }
+}
+// behind the scan of the span's LAST chunk: what its last 64 bytes are, read off the masks of lane 63 (the scan has them: two v_readlane where rounds
+// 4-5a folded sixteen dwords on every lane) -- 64 backslashes ask kind B of the successor, 63 backslashes and a quote kind C
+__device__ __forceinline__ void span_note_tail(span_x &sx, u64 backslash, u64 quote_raw) {
+  const u32 blo = readlane(u32(backslash), 63);
+  if (blo == ~0u) { // wave-uniform, rare
+    const u32 bhi = readlane(u32(backslash >> 32), 63);
+    if (bhi == ~0u) { sx.bits |= SX_NEXT_B; }
+    else if (bhi == 0x7FFFFFFFu && (readlane(u32(quote_raw >> 32), 63) >> 31) != 0u) { sx.bits |= SX_NEXT_C; }
   }
 }
 // behind the span's last chunk: its x word.  span_bytes = the span's nominal size; scalars: the scan tracks the previous-scalar bit
@@ -357,6 +358,8 @@ struct chunk_masks {
   u64 in_string;   // includes opening quotes, excludes closing quotes
   u64 ws;          // whitespace bytes
   u64 ctrl;        // bytes <= 0x1F
+  u64 backslash;   // the two raw classes span_note_tail asks of a span's last chunk
+  u64 quote_raw;
 };
 
 // =====================================================================================================
@@ -615,23 +618,27 @@ __device__ __forceinline__ chunk_masks scan_chunk(const u32 (&w)[16], wave_carry
   }
 
   const quote_scalar q = quotes_and_scalars(c, escaped);
-  // in-string parity: prefix XOR over lanes by ballot + popcount
+  // in-string parity: prefix XOR over lanes by ballot + "set bits below my lane" (v_mbcnt, the carry as its start value)
   const u64 parm = __ballot((popc64(q.quote) & 1) != 0);
-  const u32 s_in = (u32(popc64(parm & lt)) & 1u) ^ wc.s;
+  const u32 s_in = __builtin_amdgcn_mbcnt_hi(u32(parm >> 32), __builtin_amdgcn_mbcnt_lo(u32(parm), wc.s)) & 1u;
   wc.s ^= u32(popc64(parm)) & 1u;
-  // previous-scalar: bit 63 of the left neighbour
-  u32 p_in = 0;
+  // previous-scalar: bit 63 of the left neighbour comes over as bit 31 of one DPP move (wave_shr:1; lane 0 keeps the carry), and the
+  // shift by one byte position is two funnel shifts -- five instructions where ballot, per-lane 64-bit shift and select took eight
+  u64 follows = 0;
   if (WANT_STRUCTURALS) {
-    const u64 msbm = __ballot((q.nonquote_scalar >> 63) != 0);
-    p_in = lane ? u32((msbm >> ((lane - 1u) & 63u)) & 1ull) : wc.p;
-    wc.p = u32(msbm >> 63);
+    const u32 nq_lo = u32(q.nonquote_scalar), nq_hi = u32(q.nonquote_scalar >> 32);
+    const u32 left_hi = u32(__builtin_amdgcn_update_dpp(int(wc.p << 31), int(nq_hi), 0x138, 0xf, 0xf, false));
+    follows = (u64(funnel_shift_right(nq_hi, nq_lo, 31)) << 32) | u64(funnel_shift_right(nq_lo, left_hi, 31));
+    wc.p = readlane(nq_hi, 63) >> 31;
   }
-  const block_masks m = finish_block(c, q, s_in, p_in);
+  const block_masks m = finish_block_follows(c, q, s_in, follows);
   out.cand = m.cand;
   out.string_tail = m.string_tail;
   out.in_string = m.in_string;
   out.ws = c.ws;
   out.ctrl = c.ctrl;
+  out.backslash = c.backslash;
+  out.quote_raw = c.quote;
 
   return out;
 }

@@ -314,9 +314,10 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
             wc = span_carry_assume(wave_start, lane, lookback, sx);
             uq.pending = utf8_pending_from(lookback, lane);
           }
-          span_note_chunk(sx, w, c * CHUNK_BYTES, c == FUSED_WAVE_CHUNKS - 1, lane);
+          span_note_chunk(sx, w, c * CHUNK_BYTES, lane);
           if (OP == 0) {
             const chunk_masks m = scan_chunk<true, true>(w, wc, lane, &uq, u32(cstart / BLOCK_BYTES));
+            if (c == FUSED_WAVE_CHUNKS - 1) { span_note_tail(sx, m.backslash, m.quote_raw); }
             a = m.cand;
             b = m.string_tail;
             n_out += u32(popc64(a & ~b));
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
             f_co |= __ballot((m.ctrl & ~m.in_string) != 0) != 0;
           } else {
             const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
+            if (c == FUSED_WAVE_CHUNKS - 1) { span_note_tail(sx, m.backslash, m.quote_raw); }
             const u64 valid = valid_mask(pos, len);
             a = valid & m.ws; // drop candidates
             b = m.in_string;
@@ -554,11 +556,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         span_x sx;
         if (OP == 0) { utf8_resume(uq, sh_stage[wave], sh_uq[wave], lane); } // the output window is idle while we scan
         // one chunk through the scanner; its masks enter the FIFO
-        auto scan_one = [&](const u32 (&w)[16], u64 cstart) {
+        auto scan_one = [&](const u32 (&w)[16], u64 cstart, bool last) {
           const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
           u64 a, b;
           if (OP == 0) {
             const chunk_masks m = scan_chunk<true, true>(w, wc, lane, &uq, u32(cstart / BLOCK_BYTES));
+            if (last) { span_note_tail(sx, m.backslash, m.quote_raw); }
             a = m.cand;
             b = m.string_tail;
             n_out += u32(popc64(a & ~b));
@@ -567,6 +570,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             f_co |= __ballot((m.ctrl & ~m.in_string) != 0) != 0;
           } else {
             const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
+            if (last) { span_note_tail(sx, m.backslash, m.quote_raw); }
             const u64 valid = valid_mask(pos, len);
             a = valid & m.ws;
             b = m.in_string;
@@ -589,8 +593,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 wc = span_carry_assume(wave_start, lane, lookback, sx);
                 uq.pending = utf8_pending_from(lookback, lane);
               }
-              span_note_chunk(sx, w, c * CHUNK_BYTES, c == WC - 1, lane);
-              scan_one(w, cstart);
+              span_note_chunk(sx, w, c * CHUNK_BYTES, lane);
+              scan_one(w, cstart, c == WC - 1);
             } else {
               a3 = a2; a2 = a1; a1 = a0; a0 = 0;
               b3 = b2; b2 = b1; b1 = b0; b0 = 0;
@@ -815,7 +819,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
         }
         span_x sx;
         wave_carry wc = span_carry_assume(wave_start, lane, lookback, sx);
-        span_note_chunk(sx, wa, 0u, false, lane);
+        span_note_chunk(sx, wa, 0u, lane);
         {
           const chunk_masks m = scan_chunk<false, false>(wa, wc, lane);
           const u64 valid = valid_mask(pos0, len);
@@ -824,9 +828,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
           n_out += u32(popc64(valid & ~(a0 & ~b0))); // dropped: whitespace outside strings (json_scanner.h:46)
           n_in += u32(popc64(valid & ~(a0 & b0)));
         }
-        span_note_chunk(sx, wb, CHUNK_BYTES, true, lane);
+        span_note_chunk(sx, wb, CHUNK_BYTES, lane);
         {
           const chunk_masks m = scan_chunk<false, false>(wb, wc, lane);
+          span_note_tail(sx, m.backslash, m.quote_raw);
           const u64 valid = valid_mask(pos1, len);
           a1 = valid & m.ws;
           b1 = m.in_string;

@@ -101,8 +101,9 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) SJ_WAVES_PER_EU(TOKENS ? 4 : 6, TO
       wc = span_carry_assume(seg_start, lane, lookback, sx);
       utf8_park_begin(uq, lookback, lane);
     }
-    span_note_chunk(sx, w, c * CHUNK_BYTES, c == SEG_CHUNKS - 1, lane);
+    span_note_chunk(sx, w, c * CHUNK_BYTES, lane);
     const chunk_masks m = scan_chunk<true, true>(w, wc, lane, &uq, u32(cstart / BLOCK_BYTES));
+    if (c == SEG_CHUNKS - 1) { span_note_tail(sx, m.backslash, m.quote_raw); }
     if (c == 0) {
       const u64 cm = __ballot(m.ctrl != 0);
       if (cm) { // wave-uniform
@@ -191,20 +192,32 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) SJ_WAVES_PER_EU(TOKENS ? 4 : 6, TO
 // =====================================================================================================
 constexpr u32 RESOLVE_THREADS = 1024;
 
+// Exclusive scans over the workgroup's threads, one value per thread: a DPP scan inside every wave, the sixteen wave totals through LDS, two barriers
+// (rounds 1-4: ten Hillis-Steele steps through LDS with two barriers each -- sixty barriers for the three scans of k_resolve_segments, most of its 7.7 us)
+constexpr u32 RESOLVE_WAVES = RESOLVE_THREADS / 64;
+__device__ __forceinline__ u32 wave_incl_scan_xor(u32 v) {
+  v ^= u32(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xf, 0xf, false));
+  v ^= u32(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xf, 0xf, false));
+  v ^= u32(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xf, 0xf, false));
+  v ^= u32(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xf, 0xf, false));
+  v ^= u32(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xa, 0xf, false));
+  v ^= u32(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xc, 0xf, false));
+  return v;
+}
 __device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *sh, bool use_xor, u32 &total) {
-  const u32 tid = threadIdx.x;
-  sh[tid] = v;
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const u32 incl = use_xor ? wave_incl_scan_xor(v) : wave_incl_scan(v);
+  if (lane == 63) { sh[wave] = incl; }
   __syncthreads();
-  for (u32 d = 1; d < RESOLVE_THREADS; d <<= 1) {
-    const u32 t = (tid >= d) ? sh[tid - d] : 0u;
-    __syncthreads();
-    sh[tid] = use_xor ? (sh[tid] ^ t) : (sh[tid] + t);
-    __syncthreads();
+  u32 base = 0, sum = 0;
+  for (u32 w = 0; w < RESOLVE_WAVES; w++) {
+    const u32 t = sh[w];
+    if (w < wave) { base = use_xor ? (base ^ t) : (base + t); }
+    sum = use_xor ? (sum ^ t) : (sum + t);
   }
-  const u32 incl = sh[tid];
-  total = sh[RESOLVE_THREADS - 1];
+  total = sum;
   __syncthreads();
-  return use_xor ? (incl ^ v) : (incl - v);
+  return use_xor ? (base ^ incl ^ v) : (base + incl - v);
 }
 
 // the successor function of a summary, x -> c ^ (dep & x), as two bits: bit 0 = f(0), bit 1 = f(1)
@@ -214,20 +227,29 @@ __device__ __forceinline__ u32 xfun_then(u32 a, u32 b) { // first a, then b
   return r0 | (r1 << 1);
 }
 constexpr u32 XFUN_ID = 2u;
-// exclusive scan of function composition over the workgroup's threads
+// exclusive scan of function composition over the workgroup's threads (lanes without a source compose with the identity)
+__device__ __forceinline__ u32 wave_incl_scan_xfun(u32 v) {
+  v = xfun_then(u32(__builtin_amdgcn_update_dpp(int(XFUN_ID), int(v), 0x111, 0xf, 0xf, false)), v);
+  v = xfun_then(u32(__builtin_amdgcn_update_dpp(int(XFUN_ID), int(v), 0x112, 0xf, 0xf, false)), v);
+  v = xfun_then(u32(__builtin_amdgcn_update_dpp(int(XFUN_ID), int(v), 0x114, 0xf, 0xf, false)), v);
+  v = xfun_then(u32(__builtin_amdgcn_update_dpp(int(XFUN_ID), int(v), 0x118, 0xf, 0xf, false)), v);
+  v = xfun_then(u32(__builtin_amdgcn_update_dpp(int(XFUN_ID), int(v), 0x142, 0xa, 0xf, false)), v);
+  v = xfun_then(u32(__builtin_amdgcn_update_dpp(int(XFUN_ID), int(v), 0x143, 0xc, 0xf, false)), v);
+  return v;
+}
 __device__ __forceinline__ u32 block_excl_scan_xfun(u32 v, u32 *sh) {
-  const u32 tid = threadIdx.x;
-  sh[tid] = v;
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const u32 incl = wave_incl_scan_xfun(v);
+  if (lane == 63) { sh[wave] = incl; }
   __syncthreads();
-  for (u32 d = 1; d < RESOLVE_THREADS; d <<= 1) {
-    const u32 t = (tid >= d) ? sh[tid - d] : XFUN_ID;
-    __syncthreads();
-    sh[tid] = xfun_then(t, sh[tid]);
-    __syncthreads();
+  u32 base = XFUN_ID;
+  for (u32 w = 0; w < RESOLVE_WAVES; w++) {
+    if (w < wave) { base = xfun_then(base, sh[w]); }
   }
-  const u32 excl = tid ? sh[tid - 1] : XFUN_ID;
+  // exclusive: everything in front of my wave, then the lanes in front of me
+  u32 prev = u32(__builtin_amdgcn_update_dpp(int(XFUN_ID), int(incl), 0x138, 0xf, 0xf, false)); // wave_shr:1 (lane 0 keeps the identity)
   __syncthreads();
-  return excl;
+  return xfun_then(base, prev);
 }
 
 // what: 0 = stage1 (writes n, flags and the three sentinels), 1 = minify (writes out_len, flags)
@@ -368,6 +390,9 @@ __device__ __forceinline__ seg_prefix segment_prefix(const seg_summary *__restri
 // =====================================================================================================
 // TOKENS: tok[i] = buf[idx[i]] for the segment's offsets, behind the same cursor: copied from the staging area k_stage1_summarize<true> filled, or -- a
 // segment that staged nothing, or whose one patched candidate bit (sj_xcarry.h) changes the list the staging was made for -- gathered from the document
+// (measured in round 5 and not kept: four waves -- four segments -- per workgroup: the dispatcher has a quarter of the workgroups to place, and the kernel
+// is SLOWER, 75 -> 85 us per GiB of NDJSON and 32 -> 46 us on escape_heavy, profiles/r05_scan_steps_ab.txt: a workgroup then waits for four free wave
+// slots and 25 KiB of LDS at once)
 template <bool TOKENS>
 __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask0, const u64 *__restrict__ mask1,
                                                     const seg_summary *__restrict__ summ, const seg_prefix *__restrict__ gpref,
@@ -461,8 +486,9 @@ __global__ __launch_bounds__(64) void k_minify_summarize(const u8 *__restrict__ 
     if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
     else { load_block(buf, pos, len, w); }
     if (c == 0) { wc = span_carry_assume(seg_start, lane, lookback, sx); }
-    span_note_chunk(sx, w, c * CHUNK_BYTES, c == SEG_CHUNKS - 1, lane);
+    span_note_chunk(sx, w, c * CHUNK_BYTES, lane);
     const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
+    if (c == SEG_CHUNKS - 1) { span_note_tail(sx, m.backslash, m.quote_raw); }
     const u64 valid = valid_mask(pos, len);
     kept_out += u32(popc64(valid & ~(m.ws & ~m.in_string))); // dropped: whitespace outside strings (json_scanner.h:46)
     kept_in += u32(popc64(valid & ~(m.ws & m.in_string)));
@@ -569,8 +595,9 @@ __global__ __launch_bounds__(64) void k_string_parity(const u8 *__restrict__ buf
       if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
       else { load_block(buf, pos, len, w); }
       if (c == 0) { wc = span_carry_assume(seg_start, lane, lookback, sx); }
-      span_note_chunk(sx, w, c * CHUNK_BYTES, c == SEG_CHUNKS - 1, lane);
-      (void)scan_chunk<false, false>(w, wc, lane);
+      span_note_chunk(sx, w, c * CHUNK_BYTES, lane);
+      const chunk_masks m = scan_chunk<false, false>(w, wc, lane);
+      if (c == SEG_CHUNKS - 1) { span_note_tail(sx, m.backslash, m.quote_raw); }
     }
     const u32 xw = span_finish(sx, buf, seg_start, SEG_BYTES, len, wc, false);
     if (lane == 0) { seg_bits[seg] = u8(wc.s | ((xw & 7u) << 1)); } // parity under the assumption; c, dep, F

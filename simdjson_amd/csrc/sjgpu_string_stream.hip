@@ -117,9 +117,9 @@ __device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carr
   }
   out.quote = andn(c.quote, escaped);
   const u64 parm = __ballot((popc64(out.quote) & 1) != 0);
-  const u32 s_in = (u32(popc64(parm & lt)) & 1u) ^ wc.s;
+  const u32 s_in = __builtin_amdgcn_mbcnt_hi(u32(parm >> 32), __builtin_amdgcn_mbcnt_lo(u32(parm), wc.s)) & 1u; // set bits below my lane, the carry as the start value
   wc.s ^= u32(popc64(parm)) & 1u;
-  out.in_string = prefix_xor(out.quote) ^ (0 - u64(s_in));
+  out.in_string = prefix_xor(out.quote ^ u64(s_in)); // (the carry as a quote in front of bit 0)
   out.b = no_escapes(out.quote);
   out.k2 = 0; out.k3 = 0; out.k4 = 0;
   const bool pending = wc.t.any(); // wave-uniform: an escape that began in the chunk in front is not finished

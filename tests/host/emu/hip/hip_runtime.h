@@ -177,7 +177,7 @@ static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned add) {
   const unsigned lt = lane <= 32 ? 0u : ((1u << (lane - 32)) - 1u);
   return add + unsigned(__builtin_popcount(mask & lt));
 }
-// DPP (the controls the kernels use): row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143; a lane whose
+// DPP (the controls the kernels use): row_shr:n = 0x110 + n, wave_shr:1 = 0x138, row_bcast:15 = 0x142, row_bcast:31 = 0x143; a lane whose
 // row is not in row_mask, or whose source does not exist (bound_ctrl = false), keeps `old`
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   uint64_t all[64];
@@ -189,6 +189,7 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
     if (in_row >= n) { return int(uint32_t(all[lane - n])); }
     return bound_ctrl ? 0 : old;
   }
+  if (ctrl == 0x138) { return lane ? int(uint32_t(all[lane - 1])) : (bound_ctrl ? 0 : old); } // wave_shr:1
   if (ctrl == 0x142) { return row ? int(uint32_t(all[row * 16 - 1])) : old; }
   if (ctrl == 0x143) { return row >= 2 ? int(uint32_t(all[31])) : old; }
   __builtin_trap(); // a control this emulation does not know

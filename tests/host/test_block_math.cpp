@@ -54,6 +54,22 @@ int main() {
     }
     CHECK(c.backslash == bs && c.quote == q && c.ws == ws && c.op == op && c.ctrl == ct, "classes it %d", it);
   }
+  // 1b. every byte value at every position of a block (the classes are functions of one byte: exhaustive)
+  for (int v = 0; v < 256; v++) {
+    for (int at = 0; at < 64; at++) {
+      uint8_t blk[64];
+      for (int i = 0; i < 64; i++) { blk[i] = uint8_t((v * 7 + i * 13) & 0xFF); }
+      blk[at] = uint8_t(v);
+      u32 w[16];
+      std::memcpy(w, blk, 64);
+      const classes c = classify(transpose64(w));
+      for (int i = 0; i < 64; i++) {
+        const uint8_t b = blk[i];
+        CHECK(((c.backslash >> i) & 1) == u64(b == '\\') && ((c.quote >> i) & 1) == u64(b == '"') && ((c.ws >> i) & 1) == u64(is_ws(b)) &&
+              ((c.op >> i) & 1) == u64(is_op(b)) && ((c.ctrl >> i) & 1) == u64(b <= 0x1F), "class of byte 0x%02X at %d", b, i);
+      }
+    }
+  }
   // 2. escape / in-string / structural chain over multi-block buffers vs the oracle scan, and UTF-8
   for (int it = 0; it < 60000; it++) {
     size_t nblk = 1 + (rnd() >> 60) % 5;
