@@ -1,115 +1,134 @@
-"""A/B of two builds of libsjgpu.so on ONE box (box-to-box variation is +-5 %: figures of different sessions do not compare): every variant in its own process
-(SJGPU_LIB names the library, extra NAME=VALUE pairs go into the environment), alternating, the best of four trials of fifteen calls each per workload,
-a digest of what was written so that a faster kernel that writes something else is found out here.
-    python scripts/lib_ab.py base=build/ab/libsjgpu_base.so new=simdjson_amd/lib/libsjgpu.so [new1=simdjson_amd/lib/libsjgpu.so,SJGPU_EMIT_WAVES=1 ...] [--rounds 2] [--size BYTES]"""
+"""A/B of builds of libsjgpu.so INSIDE ONE PROCESS, calls interleaved (box-to-box variation is +-5 %, and on one box the variant that runs first after an idle
+phase gets other clocks than the one that runs last: processes that take turns -- the first version of this script -- showed 2-3 % between two copies of the
+same kernel).  Every library is loaded under its own copy of simdjson_amd.capi (ctypes opens each file separately), all variants scan the SAME device buffer
+into the SAME list, round after round in turn; per variant the median and the best of the per-round means (HIP events of the launch stream around `reps`
+calls), the kernels' own event slots [scan or summarize, resolve, emit], and a digest of what was written, so that a faster kernel that writes something else
+is found out here.
+    python scripts/lib_ab.py base=build/ab/libsjgpu_base.so new=simdjson_amd/lib/libsjgpu.so [...] [--rounds 12] [--reps 10] [--size BYTES] [--quick]"""
+import importlib.util
 import json
 import os
-import subprocess
+import statistics
 import sys
-import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
-def child(size):
-    sys.path.insert(0, os.getcwd())
-    import torch
-    from simdjson_amd import capi, corpus
-    out = {"variant": os.environ.get("LIB_AB_NAME")}
-    st = torch.cuda.current_stream().cuda_stream
-
-    def best(call, trials=4, reps=15):
-        for _ in range(3):
-            call()
-        torch.cuda.synchronize()
-        dt = 1e9
-        for _ in range(trials):
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                call()
-            torch.cuda.synchronize()
-            dt = min(dt, (time.perf_counter() - t0) / reps)
-        return round(dt * 1e6, 1)
-
-    jobs = (("large_random", "fused"), ("large_random", "split"), ("amazon_ndjson", "split"), ("amazon_ndjson", "fused"), ("twitter_like", "split"),
-            ("escape_heavy", "split"), ("deep_nesting_doc", "fused"))
-    if os.environ.get("LIB_AB_QUICK"):
-        jobs = (("large_random", "fused"), ("amazon_ndjson", "split"), ("amazon_ndjson", "fused"), ("escape_heavy", "split"))
-    made = {}
-    for kind, pipe in jobs:
-        if kind not in made:
-            made.clear()
-            made[kind] = getattr(corpus, kind)(size, 1000)[0]
-        a = made[kind]
-        L = len(a)
-        p = capi.DomParserImplementation(L)
-        p.set_pipeline(pipe)
-        buf = torch.from_numpy(a).cuda()
-        idx = torch.empty(L + 16, dtype=torch.int32, device="cuda")
-        key = f"stage1:{kind}:{pipe}"
-        out[key + ":us"] = best(lambda: p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, st))
-        n, flags, _ = p.result(st)
-        p.profile_enable(True)  # HIP events around the kernels of a call: [scan / summarize, resolve, emit] in us per call
-        for _ in range(12):
-            p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, st)
-        torch.cuda.synchronize()
-        ms, calls = p.profile_read()
-        out[key + ":slots_us"] = [round(1e3 * x / max(calls, 1), 1) for x in ms]
-        p.profile_enable(False)
-        v = idx[:n].to(torch.int64)
-        out[key + ":digest"] = [int(n), int(flags), int((v * torch.arange(1, n + 1, device="cuda", dtype=torch.int64)).sum().item() & ((1 << 62) - 1))]
-        del v
-        if kind == "large_random" and pipe == "fused":
-            dst = torch.empty(L + 64, dtype=torch.uint8, device="cuda")
-            p.set_pipeline("auto")
-            out["minify:large_random:us"] = best(lambda: p.minify_device(buf.data_ptr(), L, dst.data_ptr(), st))
-            _, mflags, out_len = p.result(st)
-            out["minify:large_random:digest"] = [int(out_len), int(mflags), int(dst[:out_len].to(torch.int64).sum().item())]
-            out["validate_utf8:large_random:us"] = best(lambda: p.validate_utf8_device(buf.data_ptr(), L, st))
-            out["validate_utf8:large_random:flags"] = int(p.result(st)[1])
-            del dst
-        if kind == "twitter_like" and not os.environ.get("LIB_AB_QUICK"):  # the string pass and the tape read the same planes
-            m = 256 << 20
-            a2 = corpus.twitter_like(m, 1000)[0]
-            L2 = len(a2)
-            b2 = torch.from_numpy(a2).cuda()
-            q = capi.DomParserImplementation(L2)
-            i2 = torch.empty(L2 + 16, dtype=torch.int32, device="cuda")
-            q.stage1_device(b2.data_ptr(), L2, i2.data_ptr(), L2 + 3, st)
-            n2 = q.result(st)[0]
-            tape = torch.empty(L2 + 8, dtype=torch.int64, device="cuda")
-            scap = 5 * (L2 // 3) + 256
-            sb = torch.empty(scap, dtype=torch.uint8, device="cuda")
-            got = {}
-
-            def stage2():
-                got["v"] = q.stage2_device(b2.data_ptr(), L2, i2.data_ptr(), n2, tape.data_ptr(), L2 + 8, sb.data_ptr(), scap, 1024, st)
-            out["stage2:twitter_like_256MiB:us"] = best(stage2, 3, 8)
-            err, tw, sbn = got["v"]
-            out["stage2:twitter_like_256MiB:digest"] = [int(err), int(tw), int(sbn), int(tape[:tw].sum().item() & ((1 << 62) - 1)), int(sb[:sbn].to(torch.int64).sum().item())]
-            q.close()
-            del b2, i2, tape, sb
-        p.close()
-        del buf, idx
-    print(json.dumps(out), flush=True)
+def capi_for(path, name):
+    """a private copy of simdjson_amd.capi bound to the library at `path`"""
+    import simdjson_amd
+    from simdjson_amd import _paths
+    spec = importlib.util.spec_from_file_location("simdjson_amd.capi_" + name, os.path.join(os.path.dirname(simdjson_amd.__file__), "capi.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    spec.loader.exec_module(mod)
+    keep = _paths.LIB_SJGPU
+    _paths.LIB_SJGPU = os.path.abspath(path)
+    try:
+        mod.load_library()
+    finally:
+        _paths.LIB_SJGPU = keep
+    return mod
 
 
-if __name__ == "__main__":
+def main():
     args = sys.argv[1:]
-    if args and args[0] == "--child":
-        child(int(args[1]))
-        sys.exit(0)
-    rounds, size, variants = 2, 1 << 30, []
+    rounds, reps, size, quick, variants = 12, 10, 1 << 30, False, []
     i = 0
     while i < len(args):
         if args[i] == "--rounds":
             rounds = int(args[i + 1]); i += 2
+        elif args[i] == "--reps":
+            reps = int(args[i + 1]); i += 2
         elif args[i] == "--size":
             size = int(args[i + 1]); i += 2
+        elif args[i] == "--quick":
+            quick = True; i += 1
         else:
-            name, spec = args[i].split("=", 1)
-            parts = spec.split(",")
-            variants.append((name, parts[0], dict(kv.split("=", 1) for kv in parts[1:])))
-            i += 1
-    for _ in range(rounds):
-        for name, lib, env in variants:
-            e = dict(os.environ, SJGPU_LIB=os.path.abspath(lib), LIB_AB_NAME=name, **env)
-            subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(size)], env=e, timeout=900)
+            name, lib = args[i].split("=", 1)
+            variants.append((name, lib)); i += 1
+    import torch
+    from simdjson_amd import corpus
+    mods = {name: capi_for(lib, name) for name, lib in variants}
+    names = [n for n, _ in variants]
+    st = torch.cuda.current_stream().cuda_stream
+    jobs = [("large_random", "fused", "stage1"), ("large_random", "auto", "minify"), ("large_random", "auto", "validate_utf8"), ("large_random", "split", "stage1"),
+            ("amazon_ndjson", "split", "stage1"), ("amazon_ndjson", "fused", "stage1"), ("twitter_like", "split", "stage1"), ("escape_heavy", "split", "stage1"),
+            ("deep_nesting_doc", "fused", "stage1")]
+    if quick:
+        jobs = [j for j in jobs if j[0] in ("large_random", "amazon_ndjson", "escape_heavy") and not (j[0] == "large_random" and j[1] == "split")]
+    table, made = {}, {}
+    for kind, pipe, op in jobs:
+        if kind not in made:
+            made.clear()
+            a = getattr(corpus, kind)(size, 1000)[0]
+            made[kind] = (torch.from_numpy(a).cuda(), len(a))
+        buf, L = made[kind]
+        out = torch.empty(L + 64, dtype=torch.int32 if op == "stage1" else torch.uint8, device="cuda")
+        ps = {}
+        for n in names:
+            p = mods[n].DomParserImplementation(L)
+            p.set_pipeline(pipe)
+            ps[n] = p
+
+        def call(p):
+            if op == "stage1":
+                p.stage1_device(buf.data_ptr(), L, out.data_ptr(), L + 3, st)
+            elif op == "minify":
+                p.minify_device(buf.data_ptr(), L, out.data_ptr(), st)
+            else:
+                p.validate_utf8_device(buf.data_ptr(), L, st)
+        key = f"{op}:{kind}:{pipe}"
+        digests, times, slots = {}, {n: [] for n in names}, {}
+        for n in names:  # warm-up, and what the variant writes
+            out.zero_()
+            for _ in range(3):
+                call(ps[n])
+            r = ps[n].result(st)
+            if op == "stage1":
+                v = out[:r[0]].to(torch.int64)
+                digests[n] = [r[0], r[1], int((v * torch.arange(1, r[0] + 1, device="cuda", dtype=torch.int64)).sum().item() & ((1 << 62) - 1))]
+                del v
+            elif op == "minify":
+                digests[n] = [r[2], r[1], int(out[:r[2]].to(torch.int64).sum().item())]
+            else:
+                digests[n] = [r[1]]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for rnd in range(rounds):
+            order = names if rnd % 2 == 0 else names[::-1]
+            for n in order:
+                e0.record()
+                for _ in range(reps):
+                    call(ps[n])
+                e1.record()
+                e1.synchronize()
+                times[n].append(1e3 * e0.elapsed_time(e1) / reps)
+        for n in names:
+            ps[n].profile_enable(True)
+            for _ in range(reps):
+                call(ps[n])
+            torch.cuda.synchronize()
+            ms, calls = ps[n].profile_read()
+            slots[n] = [round(1e3 * x / max(calls, 1), 1) for x in ms]
+            ps[n].profile_enable(False)
+            ps[n].close()
+        table[key] = {"median_us": {n: round(statistics.median(times[n]), 1) for n in names}, "best_us": {n: round(min(times[n]), 1) for n in names},
+                      "slots_us": slots, "digests_equal": len({json.dumps(d) for d in digests.values()}) == 1, "digest": digests[names[0]]}
+        print(json.dumps({key: table[key]}), flush=True)
+        del out
+    print("%-34s" % "median us per call", *["%11s" % n[:11] for n in names])
+    for key, t in table.items():
+        print("%-34s" % key, *["%11.1f" % t["median_us"][n] for n in names], "" if t["digests_equal"] else "  DIGESTS DIFFER")
+    print("%-34s" % "best round", *["%11s" % n[:11] for n in names])
+    for key, t in table.items():
+        print("%-34s" % key, *["%11.1f" % t["best_us"][n] for n in names])
+    print("%-34s" % "event slots of the split calls", *["%11s" % n[:11] for n in names])
+    for key, t in table.items():
+        if ":split" in key:
+            for s in range(3):
+                print("%-34s" % (key + " slot %d" % s), *["%11.1f" % t["slots_us"][n][s] for n in names])
+
+
+if __name__ == "__main__":
+    main()

@@ -123,6 +123,67 @@ __device__ __forceinline__ u64 valid_mask(u64 pos, u64 len) {
   return (1ull << u32(len - pos)) - 1ull;
 }
 
+// ---- a whole chunk, streamed (round 5) ------------------------------------------------------------------------------------------------
+// The input is read ONCE, front to back, and what the memory system does with a stream it will never see again decides the ceiling of every kernel here: a
+// kernel that only moves stage 1's bytes reaches 5.0-5.1 TB/s with plain loads and 6.0-6.4 TB/s when the loads carry the non-temporal hint (global_load_dwordx4
+// ... nt: the line is the first to leave the caches again) -- read-only 6.2 -> 7.0 (profiles/r05_mix_policy.txt, r05_stream_lab.txt; the same hint on the
+// STORES costs 8 %).  But the hint only pays when ONE instruction consumes whole lines: load_block_full's pattern -- a lane's own 64 bytes, an instruction = a
+// quarter of each of the chunk's 32 lines -- fetches every line four times with it (validate_utf8 181 -> 280 us per GiB).  So the chunk is requested COALESCED
+// (lane i: 16 bytes at chunk + 1024 j + 16 i, an instruction = eight whole lines) and the block-per-lane order the scan needs is restored through 4 KiB of LDS
+// per wave: four 16-byte stores, four 16-byte loads, the quarters of a block rotated by (block / 4) mod 4 so that neither side meets a bank conflict.
+// xbuf: CHUNK_BYTES of LDS owned by this wave (16-byte aligned); the chunk lies wholly inside the input.  SJGPU_STREAM_LOADS=0 at compile time: plain loads.
+#ifndef SJGPU_STREAM_LOADS
+#define SJGPU_STREAM_LOADS 1
+#endif
+__device__ __forceinline__ u32 xbuf_slot(u32 block, u32 quarter) { return block * 4u + ((quarter + (block >> 2)) & 3u); } // 16-byte slots
+// one 16-byte load of a stream read once (the instruction must cover whole lines: consecutive lanes, consecutive 16 bytes)
+__device__ __forceinline__ uint4 load16_stream(const uint4 *p) {
+#if defined(__HIP_DEVICE_COMPILE__) && SJGPU_STREAM_LOADS
+  typedef u32 v4u __attribute__((ext_vector_type(4)));
+  const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+// ... and one 16-byte store of a stream that is read once, by a later kernel (the masks: profiles/r05_split_lab.txt)
+__device__ __forceinline__ void store16_stream(uint4 *p, const uint4 &v) {
+#if defined(__HIP_DEVICE_COMPILE__) && SJGPU_STREAM_LOADS
+  typedef u32 v4u __attribute__((ext_vector_type(4)));
+  const v4u x = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(x, reinterpret_cast<v4u *>(p));
+#else
+  *p = v;
+#endif
+}
+struct chunk_request { uint4 r[4]; };
+// the four loads of a chunk (issue early, consume with load_chunk_finish: the latency lies between the two)
+__device__ __forceinline__ chunk_request load_chunk_issue(const u8 *__restrict__ buf, u64 cstart, u32 lane) {
+  chunk_request q;
+  const uint4 *src = reinterpret_cast<const uint4 *>(buf + cstart) + lane;
+#pragma unroll
+  for (u32 j = 0; j < 4; j++) {
+    q.r[j] = load16_stream(src + 64u * j);
+  }
+  return q;
+}
+__device__ __forceinline__ void load_chunk_finish(const chunk_request &q, u32 lane, uint4 *__restrict__ xbuf, u32 (&w)[16]) {
+#pragma unroll
+  for (u32 j = 0; j < 4; j++) { // piece 64 j + lane = quarter lane % 4 of block 16 j + lane / 4
+    xbuf[xbuf_slot(16u * j + (lane >> 2), lane & 3u)] = q.r[j];
+  }
+  wave_lds_fence();
+#pragma unroll
+  for (u32 k = 0; k < 4; k++) {
+    const uint4 v = xbuf[xbuf_slot(lane, k)];
+    w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+  }
+  wave_lds_fence(); // (the next chunk's stores come behind these loads in the wave's LDS queue: in order)
+}
+__device__ __forceinline__ void load_chunk_stream(const u8 *__restrict__ buf, u64 cstart, u32 lane, uint4 *__restrict__ xbuf, u32 (&w)[16]) {
+  load_chunk_finish(load_chunk_issue(buf, cstart, lane), lane, xbuf, w);
+}
+
 // ---- carries ----------------------------------------------------------------------------------------
 struct wave_carry {
   u32 e;    // first byte of the next block is escaped

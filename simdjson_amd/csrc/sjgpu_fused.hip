@@ -462,6 +462,8 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
 // wait is on an aggregate that some running workgroup will publish without waiting on anyone.
 // =====================================================================================================
 constexpr u32 PIPE_WINDOW = 1280; // 4 x 5 KiB of emission windows + 16 KiB of pending masks -> 4 workgroups per CU
+// (measured in round 5 and not kept: the chunks of this kernel requested coalesced and streamed like the split kernels' (load_chunk_stream, the exchange buffer
+// in the idle emission window): configs[1] 474.9 -> 472.6 us, NDJSON 335.7 -> 356.0, deep nesting 1101 -> 1131 -- this kernel is not waiting for its loads)
 constexpr u32 NO_TILE = 0xFFFFFFFFu;
 
 // (Round 2 carried a variant that requested chunk c+1 while chunk c was classified: two register sets, 128 VGPRs with 20 B of

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) SJ_WAVES_PER_EU(TOKENS ? 4 : 6, TO
   const u32 seg = blockIdx.x * SUMM_WAVES + wave; // relative to the scan's origin: workspace index
   __shared__ __attribute__((aligned(16))) u32 park[SUMM_WAVES][UTF8P_ROWS * UTF8P_ROW_WORDS]; // the blocks the UTF-8 check still has to look at (utf8_park)
   __shared__ u32 sh_left[SUMM_WAVES]; // rows every wave has left when its segment ends
+  __shared__ __attribute__((aligned(16))) uint4 xbuf[SUMM_WAVES][CHUNK_BYTES / 16]; // load_chunk_stream's exchange buffer of each wave
   __shared__ __attribute__((aligned(16))) u8 tok_window[TOKENS ? SUMM_WAVES : 1][TOKENS ? MINIFY_STAGE_BYTES : 16]; // TOKENS: the compaction window of each wave
   __shared__ u32 tok_lut[MINIFY_LUT_WORDS];
   if (TOKENS) { // (every wave fills the table with the same words: no barrier needed before its own use)
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) SJ_WAVES_PER_EU(TOKENS ? 4 : 6, TO
     if (cstart >= len) { break; }
     const u64 pos = cstart + lane_off;
     u32 w[16];
-    if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); } // interior chunk: branch-free loads
+    if (cstart + CHUNK_BYTES <= len) { load_chunk_stream(buf, cstart, lane, xbuf[wave], w); } // interior chunk: coalesced streaming loads, block order through LDS
     else { load_block(buf, pos, len, w); }
     if (c == 0) { // the look-back's latency hid behind the loads above
       wc = span_carry_assume(seg_start, lane, lookback, sx);
@@ -128,20 +129,6 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) SJ_WAVES_PER_EU(TOKENS ? 4 : 6, TO
       any_b |= __ballot((m.ctrl & ~m.in_string) != 0) != 0; // offends if the segment really starts inside a string
       keep0[c] = m.cand;
       keep1[c] = m.string_tail;
-    }
-  }
-  // A segment without a single candidate (the inside of a long string, of a backslash run, of whitespace) publishes two zero counts and
-  // writes NO masks: k_stage1_emit takes the zeros from the summary (escape_heavy: 0.27 GB of masks written and 0.28 GB read back for 300 000
-  // structurals in a GiB -- profiles/r04_pmc_summary.txt -- are gone; ordinary input has no such segments and pays one ballot)
-  if (__ballot(n_a != 0u)) {
-    const size_t at = (size_t(seg) * 64 + lane) * 2; // in 16-byte units: [segment][lane][chunk]
-    uint4 *p0 = reinterpret_cast<uint4 *>(mask0) + at;
-    p0[0] = make_uint4(u32(keep0[0]), u32(keep0[0] >> 32), u32(keep0[1]), u32(keep0[1] >> 32));
-    p0[1] = make_uint4(u32(keep0[2]), u32(keep0[2] >> 32), u32(keep0[3]), u32(keep0[3] >> 32));
-    if (!resolved) {
-      uint4 *p1 = reinterpret_cast<uint4 *>(mask1) + at;
-      p1[0] = make_uint4(u32(keep1[0]), u32(keep1[0] >> 32), u32(keep1[1]), u32(keep1[1] >> 32));
-      p1[1] = make_uint4(u32(keep1[2]), u32(keep1[2] >> 32), u32(keep1[3]), u32(keep1[3] >> 32));
     }
   }
   // left-overs (fewer than UTF8P_DRAIN_AT per wave) are validated by wave 0 with full lanes, straight from the four waves' rows
@@ -183,7 +170,26 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) SJ_WAVES_PER_EU(TOKENS ? 4 : 6, TO
   }
   s.flags = flags;
   s.xw = span_finish(sx, buf, seg_start, SEG_BYTES, len, wc, true, resolved, derived);
-  if (lane == 0) { summ[seg] = s; }
+  if (lane == 0) { summ[seg] = s; } // (in front of the masks: whatever this store has to wait for -- span_finish may have read bytes -- is waited for before they are issued)
+  // The masks leave LAST, behind the rendezvous: in front of it the barrier's fence made every wave wait for the acknowledgement of its own stores (an
+  // s_waitcnt vmcnt(0) -- this ISA counts loads and stores in one in-order counter) with its registers and its share of the LDS held: 69 us of 258 per GiB of
+  // NDJSON (profiles/r05_summarize_lab.txt: the kernel without these stores ran in 189 us).  Nothing behind them waits: the wave ends with its stores in flight.
+  // A segment without a single candidate (the inside of a long string, of a backslash run, of whitespace) publishes two zero counts and
+  // writes NO masks: k_stage1_emit takes the zeros from the summary (escape_heavy: 0.27 GB of masks written and 0.28 GB read back for 300 000
+  // structurals in a GiB -- profiles/r04_pmc_summary.txt -- are gone; ordinary input has no such segments and pays one ballot)
+  if (__ballot(n_a != 0u)) {
+    // in 16-byte units: [segment][chunk pair][lane] -- an instruction of the wave writes (and k_stage1_emit's reads) one contiguous KiB: whole lines
+    // (rounds 1-5a: [segment][lane][chunk], 16 bytes of every 32 per instruction: half of every line, twice)
+    const size_t at = size_t(seg) * 128 + lane;
+    uint4 *p0 = reinterpret_cast<uint4 *>(mask0) + at;
+    store16_stream(p0, make_uint4(u32(keep0[0]), u32(keep0[0] >> 32), u32(keep0[1]), u32(keep0[1] >> 32)));
+    store16_stream(p0 + 64, make_uint4(u32(keep0[2]), u32(keep0[2] >> 32), u32(keep0[3]), u32(keep0[3] >> 32)));
+    if (!resolved) {
+      uint4 *p1 = reinterpret_cast<uint4 *>(mask1) + at;
+      store16_stream(p1, make_uint4(u32(keep1[0]), u32(keep1[0] >> 32), u32(keep1[1]), u32(keep1[1] >> 32)));
+      store16_stream(p1 + 64, make_uint4(u32(keep1[2]), u32(keep1[2] >> 32), u32(keep1[3]), u32(keep1[3] >> 32)));
+    }
+  }
 }
 
 // =====================================================================================================
@@ -411,14 +417,14 @@ __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask
   if (empty && ((own.xw >> XW_D_SHIFT) & 0xFu) == 0u) { return; }  // ... and no bit a wrong assumption could add: nothing to emit
   u64 m0[SEG_CHUNKS] = {0, 0, 0, 0}, m1[SEG_CHUNKS] = {0, 0, 0, 0};
   if (!empty) {
-    const size_t at = (size_t(seg) * 64 + lane) * 2; // [segment][lane][chunk]; chunks beyond len hold zero masks
+    const size_t at = size_t(seg) * 128 + lane; // [segment][chunk pair][lane]; chunks beyond len hold zero masks; read once: streamed
     const uint4 *p0 = reinterpret_cast<const uint4 *>(mask0) + at;
-    const uint4 x = p0[0], y = p0[1];
+    const uint4 x = load16_stream(p0), y = load16_stream(p0 + 64);
     m0[0] = (u64(x.y) << 32) | x.x; m0[1] = (u64(x.w) << 32) | x.z;
     m0[2] = (u64(y.y) << 32) | y.x; m0[3] = (u64(y.w) << 32) | y.z;
     if (!resolved) {
       const uint4 *p1 = reinterpret_cast<const uint4 *>(mask1) + at;
-      const uint4 u = p1[0], v = p1[1];
+      const uint4 u = load16_stream(p1), v = load16_stream(p1 + 64);
       m1[0] = (u64(u.y) << 32) | u.x; m1[1] = (u64(u.w) << 32) | u.z;
       m1[2] = (u64(v.y) << 32) | v.x; m1[3] = (u64(v.w) << 32) | v.z;
     }
@@ -471,6 +477,7 @@ __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask
 // =====================================================================================================
 __global__ __launch_bounds__(64) void k_minify_summarize(const u8 *__restrict__ buf, u64 len, seg_summary *__restrict__ summ,
                                                          scan_origin org) {
+  __shared__ __attribute__((aligned(16))) uint4 xbuf[CHUNK_BYTES / 16]; // load_chunk_stream's exchange buffer
   const u32 lane = lane_id();
   const u32 seg = blockIdx.x;
   const u64 seg_start = org.begin + u64(seg) * SEG_BYTES;
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(64) void k_minify_summarize(const u8 *__restrict__ 
     if (cstart >= len) { break; }
     const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
     u32 w[16];
-    if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
+    if (cstart + CHUNK_BYTES <= len) { load_chunk_stream(buf, cstart, lane, xbuf, w); }
     else { load_block(buf, pos, len, w); }
     if (c == 0) { wc = span_carry_assume(seg_start, lane, lookback, sx); }
     span_note_chunk(sx, w, c * CHUNK_BYTES, lane);
@@ -507,6 +514,7 @@ __global__ __launch_bounds__(64) void k_minify_summarize(const u8 *__restrict__ 
 
 __global__ __launch_bounds__(64) void k_minify_emit(const u8 *__restrict__ buf, u64 len, const seg_summary *__restrict__ summ,
                                                     const seg_prefix *__restrict__ gpref, u8 *__restrict__ dst, scan_origin org) {
+  __shared__ __attribute__((aligned(16))) uint4 xbuf[CHUNK_BYTES / 16]; // load_chunk_stream's exchange buffer
   __shared__ __attribute__((aligned(16))) u8 stage[MINIFY_STAGE_BYTES];
   __shared__ u32 lut[MINIFY_LUT_WORDS];
   const u32 lane = lane_id();
@@ -523,7 +531,7 @@ __global__ __launch_bounds__(64) void k_minify_emit(const u8 *__restrict__ buf, 
     if (cstart >= len) { break; }
     const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
     u32 w[16];
-    if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
+    if (cstart + CHUNK_BYTES <= len) { load_chunk_stream(buf, cstart, lane, xbuf, w); }
     else { load_block(buf, pos, len, w); }
     if (c == 0) { // the same scan as k_minify_summarize's, assumption included; the state it starts from is the EFFECTIVE one: behind the
                   // quote a wrong assumption misjudged both agree with the truth, in front of it there is nothing but backslashes
@@ -544,6 +552,7 @@ __global__ __launch_bounds__(64) void k_minify_emit(const u8 *__restrict__ buf, 
 // by an earlier launch); `more`: the input continues behind len, no end-of-input rule.
 __global__ __launch_bounds__(64) void k_validate_utf8(const u8 *__restrict__ buf, u64 len, scan_result_dev *__restrict__ result, u64 begin,
                                                       u32 more) {
+  __shared__ __attribute__((aligned(16))) uint4 xbuf[CHUNK_BYTES / 16]; // load_chunk_stream's exchange buffer
   const u32 lane = lane_id();
   const u64 nchunks = (len + CHUNK_BYTES - 1) / CHUNK_BYTES;
   bool bad = false;
@@ -551,7 +560,8 @@ __global__ __launch_bounds__(64) void k_validate_utf8(const u8 *__restrict__ buf
     const u64 cstart = ch * CHUNK_BYTES;
     const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
     u32 w[16];
-    load_block(buf, pos, len, w);
+    if (cstart + CHUNK_BYTES <= len) { load_chunk_stream(buf, cstart, lane, xbuf, w); }
+    else { load_block(buf, pos, len, w); }
     u32 hi = 0;
 #pragma unroll
     for (int j = 0; j < 16; j++) { hi |= w[j]; }
@@ -581,6 +591,7 @@ __global__ __launch_bounds__(64) void k_validate_utf8(const u8 *__restrict__ buf
 // general multi-GPU sharding, SURVEY 8(e): the ranks all-gather these bits, then scan with the right carry-in)
 // =====================================================================================================
 __global__ __launch_bounds__(64) void k_string_parity(const u8 *__restrict__ buf, u64 len, u32 nseg, u8 *__restrict__ seg_bits) {
+  __shared__ __attribute__((aligned(16))) uint4 xbuf[CHUNK_BYTES / 16]; // load_chunk_stream's exchange buffer
   const u32 lane = lane_id();
   for (u32 seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const u64 seg_start = u64(seg) * SEG_BYTES;
@@ -592,7 +603,7 @@ __global__ __launch_bounds__(64) void k_string_parity(const u8 *__restrict__ buf
       if (cstart >= len) { break; }
       const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
       u32 w[16];
-      if (cstart + CHUNK_BYTES <= len) { load_block_full(buf, pos, w); }
+      if (cstart + CHUNK_BYTES <= len) { load_chunk_stream(buf, cstart, lane, xbuf, w); }
       else { load_block(buf, pos, len, w); }
       if (c == 0) { wc = span_carry_assume(seg_start, lane, lookback, sx); }
       span_note_chunk(sx, w, c * CHUNK_BYTES, lane);
