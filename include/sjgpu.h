@@ -138,11 +138,11 @@ int sjgpu_stage1_tokens_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
  *   FUSED  one kernel, chained scan between tiles: reads every byte once, one launch -- fastest on small inputs
  *          and, in its pipelined form (look-back + emission of a tile deferred behind the scan of the next), on
  *          large ones;
- *   AUTO   FUSED up to 8 MiB (16 KiB tiles); beyond that SPLIT, except
- *            stage 1 from 224 MiB (pipelined, eight waves per workgroup, 128 KiB tiles) when the output is DENSE: the previous
- *              whole-document scan of more than 8 MiB through this context produced at least 0.2 offsets per byte (a new context
+ *   AUTO   FUSED up to 5 MiB (16 KiB tiles); beyond that SPLIT, except
+ *            stage 1 from 512 MiB (pipelined, eight waves per workgroup, 128 KiB tiles) when the output is DENSE: the previous
+ *              whole-document scan of more than 5 MiB through this context produced at least 0.2 offsets per byte (a new context
  *              assumes dense; the figure is taken when that scan's result is read, so it follows the documents a context sees).
- *              Sparse output (NDJSON, pretty-printed text) stays SPLIT at every size: 0-10 % faster (profiles/r04_pipeline_sweep.txt);
+ *              Sparse output (NDJSON, pretty-printed text) stays SPLIT at every size: 20 % faster at 1 GiB (profiles/r05_pipeline_sweep.txt);
  *            minify from 192 MiB (k_minify_onchip reads its input once, the split pipeline twice), whatever the density.
  *          (A/B switches, read once per process: SJGPU_PIPE_WAVES=4 / SJGPU_MINIFY_WAVES=4 bring back the four-wave
  *          shapes of rounds 1-3 -- 64 KiB / 32 KiB tiles.)

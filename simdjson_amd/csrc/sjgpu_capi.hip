@@ -333,17 +333,21 @@ hipStream_t pick(sjgpu_ctx *, void *stream) { return static_cast<hipStream_t>(st
 // workgroup); above that the pipelined single-pass kernel wins on dense output (1 GiB: 0.52 vs 0.58 ms) and is
 // loses 3-8 % on sparse output (twitter-like 0.12 offsets per byte: 2 180-2 250 vs 2 260-2 320 GB/s; amazon NDJSON 0.06:
 // 2 290-2 440 vs 2 580-2 620), so for stage 1 AUTO goes by the density the previous large scan of this context saw.
-constexpr size_t AUTO_FUSED_BELOW = size_t(8) << 20;
+// (round 5, profiles/r05_pipeline_sweep.txt: with the split kernels streaming their input the 16 KiB-tile kernel leads up to 4 MiB -- 16 against 20-21 us
+// there -- and trails at 8 MiB, 31-37 against 22 us: the limit moved from 8 to 5 MiB)
+constexpr size_t AUTO_FUSED_BELOW = size_t(5) << 20;
 // (round 4, profiles/r04_pipeline_sweep.txt: with the table launch gone and the emission's shorter chains the split pipeline is the faster one
 // on dense output up to 512 MiB -- 287 against 296 us there, 165 against 175 at 256 MiB -- and the single-pass kernel from 768 MiB on: 408
 // against 422 us, 521 against 556 at 1 GiB; its fixed cost, one iteration to fill and one to drain, is ~35 us.  Was 192 MiB.)
 // (round 4, later: the pipelined kernel with EIGHT waves per workgroup and 128 KiB tiles -- half the per-tile costs per byte -- wins on dense output from
 // 256 MiB on: 155 against 162 us there, 268 against 288 at 512 MiB, 479 against 557 at 1 GiB; at 160 MiB the split pipeline still leads, 103 against 110.
 // On sparse output the split pipeline stays ahead up to 512 MiB and level at 1 GiB.  The rows in profiles/r04_pipeline_sweep.txt.)
-constexpr size_t AUTO_FUSED_FROM = size_t(224) << 20;
-// sparse output (twitter-like 0.12 offsets per byte, NDJSON 0.06) stays with the split pipeline at every size: it leads up to 512 MiB (185 against 207 us on
-// NDJSON) and at 1 GiB the two are level or the split pipeline ahead depending on the text (357 against 370 us on one synthetic stream, 409 against 372 on
-// another -- the bench's: profiles/r04_pipe_waves_ab.txt)
+// (round 5: the split kernels request their chunks coalesced and streamed, the masks travel streamed -- profiles/r05_stream_ab.txt -- and lead on dense
+// output up to 384 MiB, 197 against 205 us; level at 512 MiB, 265 : 265; the single-pass kernel from there on: 371 against 394 at 768 MiB, 465 against
+// 515 at 1 GiB.  profiles/r05_pipeline_sweep.txt.  Was 224 MiB.)
+constexpr size_t AUTO_FUSED_FROM = size_t(512) << 20;
+// sparse output (twitter-like 0.12 offsets per byte, NDJSON 0.06) stays with the split pipeline at every size (round 5: 289 against 363 us per GiB of
+// NDJSON, 363 against 436 on twitter-like text; rounds 1-4 had the two within a few per cent of each other at 1 GiB)
 constexpr size_t AUTO_FUSED_FROM_SPARSE = ~size_t(0);
 constexpr size_t AUTO_FUSED_FROM_MINIFY = size_t(192) << 20;
 constexpr size_t DIRECT_HOST_MAX = size_t(2) << 20; // sjgpu_stage1 on host buffers: up to here the kernels write the offsets into host memory themselves

@@ -571,12 +571,15 @@ __device__ __forceinline__ void utf8_drain_rest(utf8_queue &uq, const u8 *__rest
 // other waves' tiles have gone through the 4 MiB L2 of the XCD, the lines are gone, and every noted block costs a 128-byte line
 // of HBM traffic (amazon NDJSON: 11 % of the blocks, 0.23 GB per GiB on top of 1.07: profiles/r03_pmc_summary.txt).  The lane that
 // notes a block HOLDS its 64 bytes; here it parks them (with the dword in front and the block's number: an 80-byte row) and the
-// check reads LDS.  Rows are drained UTF8P_DRAIN_AT at a time (48 of 64 lanes busy: the price of 23 KiB of LDS per workgroup at six
-// workgroups per CU); a chunk that notes more than UTF8_DENSE_FROM blocks is checked in line as before, so at most
-// UTF8P_DRAIN_AT - 1 + UTF8_DENSE_FROM rows are ever parked.
+// check reads LDS.  Rows are drained UTF8P_DRAIN_AT at a time (32 of 64 lanes busy); a chunk that notes more than UTF8P_DENSE_FROM blocks is checked in
+// line as before, so at most UTF8P_DRAIN_AT - 1 + UTF8P_DENSE_FROM rows are ever parked: 48 rows = 3.75 KiB per wave, which with load_chunk_stream's 4 KiB
+// makes 31 KiB per workgroup of k_stage1_summarize -- FIVE workgroups per CU.  (Rounds 4-5a: 48 / 24, 72 rows; with the exchange buffer that was 39 KiB
+// and four workgroups: 291 against 277 us per GiB of NDJSON, profiles/r05_stream_ab.txt.  The kernel is bound by what it has in flight, not by the lanes
+// a drain leaves idle.  Six workgroups would need 80 VGPRs, which this kernel only reaches by spilling: 355 us.)
 constexpr u32 UTF8P_ROW_WORDS = 20; // [0..15] the block, [16] the dword in front of it, [17] its number; 80 bytes: rows stay 16-byte aligned
-constexpr u32 UTF8P_DRAIN_AT = 48;
-constexpr u32 UTF8P_ROWS = UTF8P_DRAIN_AT - 1 + UTF8_DENSE_FROM + 1;
+constexpr u32 UTF8P_DRAIN_AT = 32;
+constexpr u32 UTF8P_DENSE_FROM = 16;
+constexpr u32 UTF8P_ROWS = UTF8P_DRAIN_AT - 1 + UTF8P_DENSE_FROM + 1;
 struct utf8_park {
   u32 *rows;   // LDS, UTF8P_ROWS x UTF8P_ROW_WORDS words owned by this wave
   u32 count;   // wave-uniform
@@ -648,7 +651,7 @@ __device__ __forceinline__ void utf8_park_chunk(utf8_park &uq, const planes &P, 
       row[17] = block0 + lane;
     }
     uq.count += u32(popc64(need));
-    if (uq.count >= UTF8P_DRAIN_AT) { utf8_park_drain(uq, lane, uq.count < 64u ? uq.count : 64u); } // (never more than 71 parked: one round leaves < 48)
+    if (uq.count >= UTF8P_DRAIN_AT) { utf8_park_drain(uq, lane, uq.count < 64u ? uq.count : 64u); } // (never more than 47 parked: one round leaves none)
   }
 }
 

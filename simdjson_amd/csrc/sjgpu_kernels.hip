@@ -78,8 +78,8 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) SJ_WAVES_PER_EU(TOKENS ? 4 : 6, TO
   wave_carry wc{0u, 0u, 0u};
   span_x sx;
   // (the in-line check of dense chunks is part of the design here: it bounds the rows a chunk can park)
-  utf8_park uq{park[wave], 0u, 0u, 0u, 0x20202020u, buf, len, more ? 1u : 0u, UTF8_DENSE_FROM};
-  if (((org.carry >> 16) & 0xFFu) != 0u && ((org.carry >> 16) & 0xFFu) < UTF8_DENSE_FROM) { uq.dense_from = (org.carry >> 16) & 0xFFu; } // A/B: env SJGPU_UTF8_DENSE_FROM (downwards only)
+  utf8_park uq{park[wave], 0u, 0u, 0u, 0x20202020u, buf, len, more ? 1u : 0u, UTF8P_DENSE_FROM};
+  if (((org.carry >> 16) & 0xFFu) != 0u && ((org.carry >> 16) & 0xFFu) < UTF8P_DENSE_FROM) { uq.dense_from = (org.carry >> 16) & 0xFFu; } // A/B: env SJGPU_UTF8_DENSE_FROM (downwards only)
   u32 n_a = 0, n_b = 0; // resolved: n_a = final count; else n_a = candidates, n_b = candidates in a string tail
   bool any_a = false, any_b = false; // wave-uniform: a control character offends under hypothesis a / b (folded per chunk: two
                                      // compares instead of four VGPRs of masks carried through the segment)
