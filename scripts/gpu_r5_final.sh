@@ -16,8 +16,10 @@ timeout 900 python bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --share
 bash scripts/gpu_pmc.sh "--op stage1" r05_headline "fetch write sq1 sq2" > $O/r05_pmc_headline.log 2>&1; echo "pmc headline rc=$?"
 bash scripts/gpu_pmc.sh "--op stage1 --workload amazon_ndjson" r05_ndjson "fetch write sq1 sq2" > $O/r05_pmc_ndjson.log 2>&1; echo "pmc ndjson rc=$?"
 bash scripts/gpu_pmc.sh "--op minify" r05_minify "fetch write sq1" > $O/r05_pmc_minify.log 2>&1; echo "pmc minify rc=$?"
-bash scripts/gpu_pmc_cmd.sh r05_tokens "fetch write sq1" -- python scripts/tokens_once.py amazon_ndjson 1073741824 > $O/r05_pmc_tokens.log 2>&1; echo "pmc tokens rc=$?"
-python3 scripts/pmc_table.py $O/pmc_r05_headline $O/pmc_r05_ndjson $O/pmc_r05_minify $O/pmc_r05_tokens > $O/r05_pmc_tables.txt 2>&1; tail -40 $O/r05_pmc_tables.txt | cut -c1-150
+bash scripts/gpu_pmc.sh "--op stage1 --workload escape_heavy" r05_escape "fetch write sq1" > $O/r05_pmc_escape.log 2>&1; echo "pmc escape rc=$?"
+bash scripts/gpu_pmc.sh "--op validate_utf8" r05_validate "fetch sq1" > $O/r05_pmc_validate.log 2>&1; echo "pmc validate rc=$?"
+bash scripts/gpu_pmc_cmd.sh r05_tokens "fetch write sq1" -- python $GRAFT_REPO_ROOT/scripts/tokens_once.py amazon_ndjson 1073741824 > $O/r05_pmc_tokens.log 2>&1; echo "pmc tokens rc=$?"
+python3 scripts/pmc_table.py $O/pmc_r05_headline $O/pmc_r05_ndjson $O/pmc_r05_minify $O/pmc_r05_escape $O/pmc_r05_validate $O/pmc_r05_tokens > $O/r05_pmc_tables.txt 2>&1; tail -40 $O/r05_pmc_tables.txt | cut -c1-150
 python3 - <<'PY'
 import json
 def last_line(path):

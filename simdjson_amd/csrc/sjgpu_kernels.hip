@@ -560,6 +560,8 @@ __global__ __launch_bounds__(64) void k_validate_utf8(const u8 *__restrict__ buf
     const u64 cstart = ch * CHUNK_BYTES;
     const u64 pos = cstart + u64(lane) * BLOCK_BYTES;
     u32 w[16];
+    // (measured and not kept, round 5: requesting the wave's NEXT chunk before this one is looked at -- 173 -> 193 us per GiB, and the same in
+    // k_stage1_summarize, 16 registers more: 288 -> 306 us per GiB of NDJSON; profiles/r05_stream_ab.txt, session Q)
     if (cstart + CHUNK_BYTES <= len) { load_chunk_stream(buf, cstart, lane, xbuf, w); }
     else { load_block(buf, pos, len, w); }
     u32 hi = 0;
