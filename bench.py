@@ -124,6 +124,10 @@ def device_leg(cx, op, workload, host, units, steps, warmup, pipeline, fence=Non
     the same-workload single-rank figure the N-rank value is divided by (n1_same_workload); (3) behind clock_warmup: the sustained figure = `value`."""
     torch, capi = cx.torch, cx.capi
     L = len(host)
+    # every leg starts from an empty caching allocator: the split pipeline's pace depends on WHERE its buffers lie (profiles/r05_stream_ab.txt, session R: up to
+    # 7 % between two contexts of one library; this line's NDJSON leg 0.303 against 0.349 ms with and without the temporaries of the parity checks of the
+    # legs in front of it in torch's cache) -- a leg must not inherit the blocks an earlier leg's checks left behind
+    torch.cuda.empty_cache()
     parser = capi.DomParserImplementation(L, device=cx.local_rank)
     parser.set_pipeline(pipeline)
     buf = torch.from_numpy(host).cuda()
