@@ -955,6 +955,7 @@ def document_leg(args, torch, dist, capi, corpus, rank, world, local_rank, fence
     import time as _t
     host, _ = corpus.large_random(args.size, 1000 + rank)
     L = len(host)
+    torch.cuda.empty_cache()  # (device_leg: a leg starts from an empty caching allocator)
     buf = torch.from_numpy(host).cuda()
     idx = torch.empty(L + 16, dtype=torch.int32, device="cuda")
     dev = buf.device
@@ -999,6 +1000,7 @@ def ndjson_leg(args, torch, dist, corpus, capi, rank, world, local_rank, fence):
     from simdjson_amd import sharded
     host, lines = corpus.amazon_ndjson(args.size, 2000 + rank)  # each rank's slice of the stream (ends in '\n')
     L = len(host)
+    torch.cuda.empty_cache()  # (device_leg: a leg starts from an empty caching allocator)
     scanner = sharded.GpuShardScanner(L, local_rank)
     scanner.parser.set_pipeline(args.pipeline)  # AUTO learns the density from the warm-up scans
     buf = torch.from_numpy(host).cuda()
