@@ -162,6 +162,29 @@ def l2_flushes(lib):
     return out
 
 
+def stream_hints(lib):
+    """{kernel symbol: {"nt_loads": n, "plain_loads": n, "nt_stores": n, "plain_stores": n}} over the 16-byte global accesses (global_load_dwordx4 /
+    global_store_dwordx4) of every kernel: which of them carry the non-temporal hint.  Round 5: the split kernels and validate_utf8 read their input -- and
+    read and write the masks -- with it (load_chunk_stream, sjgpu_device.h); the hint only pays on instructions that cover whole lines, and costs a factor of
+    four on lane-strided ones, so WHICH loads carry it is part of the design (tests/test_host_logic.py keeps it in place)."""
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for co in code_objects(lib, d):
+            text = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+            func = None
+            for line in text.split("\n"):
+                m = re.match(r"^[0-9a-fA-F]+ <([^>]+)>:", line)
+                if m:
+                    func = m.group(1)
+                    out.setdefault(func, {"nt_loads": 0, "plain_loads": 0, "nt_stores": 0, "plain_stores": 0})
+                    continue
+                m = re.match(r"^\s+global_(load|store)_dwordx4\b(.*)", line)
+                if func and m:
+                    body = m.group(2).split("//")[0]
+                    out[func][("nt_" if re.search(r"\bnt\b", body) else "plain_") + m.group(1) + "s"] += 1
+    return out
+
+
 def check(lib):
     with tempfile.TemporaryDirectory() as d:
         found = []

@@ -66,6 +66,34 @@ def test_no_tile_kernel_flushes_the_l2(lib):
     assert {k: v for k, v in hot.items() if v} == {}
 
 
+def test_the_streaming_hint_sits_where_it_pays(lib):
+    """Round 5: the kernels of the split pipeline and validate_utf8 run at the pace of their traffic, and the traffic has a switch -- the non-temporal hint on
+    loads that consume whole lines ("what the memory system does with a stream"): NDJSON 335 -> 291 us per GiB.  On lane-strided loads the
+    same hint fetches every line four times (validate_utf8 181 -> 280 us).  So: the chunk loads of the streaming kernels carry it (load_chunk_stream: four per
+    interior chunk; the guarded path of a document's LAST chunk keeps its four plain lane-strided loads), the masks are written and read with it, and the
+    offsets -- the output -- are NOT written with it (the hint on the stores costs a pure mover 8 %)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_barriers", os.path.join(_paths.REPO_ROOT, "scripts", "check_barriers.py"))
+    cb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cb)
+    h = cb.stream_hints(os.path.join(_paths.LIB_DIR, "libsjgpu.so"))
+
+    def one(fragment):
+        hits = [v for k, v in h.items() if fragment in k]
+        assert len(hits) == 1, (fragment, [k for k in h if fragment in k])
+        return hits[0]
+    summ = one("k_stage1_summarizeILb0")
+    assert summ["nt_loads"] >= 4 and summ["nt_loads"] >= summ["plain_loads"] and summ["nt_stores"] >= 2, summ  # the input streamed, the masks streamed out
+    emit = one("k_stage1_emitILb0")
+    assert emit["nt_loads"] >= 2 and emit["nt_stores"] == 0 and emit["plain_stores"] >= 1, emit  # the masks streamed in, the offsets stored plainly
+    for name in ("k_validate_utf8", "k_minify_summarize", "k_string_parityEPK"):
+        k = one(name)
+        assert k["nt_loads"] >= 4 and k["nt_loads"] >= k["plain_loads"], (name, k)
+    # the single-pass kernels keep their lane-strided plain loads: the streaming loader was measured in them and not kept
+    pipe = one("k_fused_pipelinedILi0ELb0ELj4ELj8")
+    assert pipe["nt_loads"] == 0 and pipe["plain_loads"] >= 4, pipe
+
+
 def test_no_kernel_spills(lib):
     """Round 2's review found 20 B of scratch in the headline kernel and in k_stage1_summarize (spills inside the hot loop of a
     kernel that is short of issue slots).  What the code objects of the built library tell the hardware to reserve
