@@ -4,7 +4,7 @@ same kernel).  Every library is loaded under its own copy of simdjson_amd.capi (
 into the SAME list, round after round in turn; per variant the median and the best of the per-round means (HIP events of the launch stream around `reps`
 calls), the kernels' own event slots [scan or summarize, resolve, emit], and a digest of what was written, so that a faster kernel that writes something else
 is found out here.
-    python scripts/lib_ab.py base=build/ab/libsjgpu_base.so new=simdjson_amd/lib/libsjgpu.so [...] [--rounds 12] [--reps 10] [--size BYTES] [--quick]"""
+    python scripts/lib_ab.py base=build/ab/libsjgpu_base.so new=simdjson_amd/lib/libsjgpu.so[,ENV=VALUE...] [...] [--rounds 12] [--reps 10] [--size BYTES] [--quick]"""
 import importlib.util
 import json
 import os
@@ -46,12 +46,14 @@ def main():
         elif args[i] == "--quick":
             quick = True; i += 1
         else:
-            name, lib = args[i].split("=", 1)
-            variants.append((name, lib)); i += 1
+            name, spec = args[i].split("=", 1)  # name=path[,ENV=VALUE...]: the environment a library's A/B switches read at their FIRST call
+            parts = spec.split(",")
+            variants.append((name, parts[0], dict(kv.split("=", 1) for kv in parts[1:]))); i += 1
     import torch
     from simdjson_amd import corpus
-    mods = {name: capi_for(lib, name) for name, lib in variants}
-    names = [n for n, _ in variants]
+    mods = {name: capi_for(lib, name) for name, lib, _ in variants}
+    names = [n for n, _, _ in variants]
+    envs = {n: e for n, _, e in variants}
     st = torch.cuda.current_stream().cuda_stream
     jobs = [("large_random", "fused", "stage1"), ("large_random", "auto", "minify"), ("large_random", "auto", "validate_utf8"), ("large_random", "split", "stage1"),
             ("amazon_ndjson", "split", "stage1"), ("amazon_ndjson", "fused", "stage1"), ("twitter_like", "split", "stage1"), ("escape_heavy", "split", "stage1"),
@@ -81,10 +83,17 @@ def main():
                 p.validate_utf8_device(buf.data_ptr(), L, st)
         key = f"{op}:{kind}:{pipe}"
         digests, times, slots = {}, {n: [] for n in names}, {}
-        for n in names:  # warm-up, and what the variant writes
+        for n in names:  # warm-up, and what the variant writes (the switches of a library are static: read once, at its first call)
             out.zero_()
+            keep = {k: os.environ.get(k) for k in envs[n]}
+            os.environ.update(envs[n])
             for _ in range(3):
                 call(ps[n])
+            for k, v in keep.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
             r = ps[n].result(st)
             if op == "stage1":
                 v = out[:r[0]].to(torch.int64)

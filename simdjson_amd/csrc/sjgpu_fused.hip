@@ -463,7 +463,9 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
 // =====================================================================================================
 constexpr u32 PIPE_WINDOW = 1280; // 4 x 5 KiB of emission windows + 16 KiB of pending masks -> 4 workgroups per CU
 // (measured in round 5 and not kept: the chunks of this kernel requested coalesced and streamed like the split kernels' (load_chunk_stream, the exchange buffer
-// in the idle emission window): configs[1] 474.9 -> 472.6 us, NDJSON 335.7 -> 356.0, deep nesting 1101 -> 1131 -- this kernel is not waiting for its loads)
+// in the idle emission window): configs[1] 474.9 -> 472.6 us, NDJSON 335.7 -> 356.0, deep nesting 1101 -> 1131 -- this kernel is not waiting for its loads;
+// nor the wave's NEXT chunk requested into that buffer with global_load_lds_dwordx4 (no registers) while it scans this one: 460.9 -> 458.7 us, NDJSON
+// 335.5 -> 351.1 -- session V; the window grown to 1336 words for the buffer alone cost deep nesting 5 %: its emission rounds are sized by it)
 constexpr u32 NO_TILE = 0xFFFFFFFFu;
 
 // (Round 2 carried a variant that requested chunk c+1 while chunk c was classified: two register sets, 128 VGPRs with 20 B of
