@@ -390,6 +390,9 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__rest
         for (u64 t = open; t; t &= t - 1) { outq[k++] = out_base + (map.at(ctz64(t)) - skew); }
       }
       // the bytes: one LDS store per input byte (those that are dropped go to the lane's dump byte)
+      // (measured in round 5 and not kept: dword by dword the way minify compacts -- one v_perm_b32 per dword through an accumulator, OR-merged into a zeroed
+      // window, an opening quote as a hole of one dword, chunks with two opening quotes in a dword on this road -- 228 -> 276 us per 256 MiB: its per-lane
+      // branches (flush? hole?) and ds_or cost more than 64 branch-free byte stores; scripts/sessions/gpu_r5_x.sh)
       u32 off = map.lane_off;
 #pragma unroll
       for (int j = 0; j < 16; j++) {
