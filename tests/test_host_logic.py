@@ -94,6 +94,29 @@ def test_the_streaming_hint_sits_where_it_pays(lib):
     assert pipe["nt_loads"] == 0 and pipe["plain_loads"] >= 4, pipe
 
 
+def test_the_exchange_buffer_of_load_chunk_stream_meets_no_bank_conflict():
+    """load_chunk_stream (sjgpu_device.h): a chunk arrives as 256 pieces of 16 bytes in request order (piece p = quarter p % 4 of block p / 4) and leaves
+    in block order (lane L reads the four quarters of block L).  Both sides are 16-byte LDS accesses, which the hardware serves sixteen lanes at a time over
+    64 banks of 4 bytes: conflict-free means the sixteen lanes of a phase touch sixteen different 16-byte columns (slot mod 16).  The slot function is read out
+    of the source -- this checks what the kernels compile, not a copy of it."""
+    import re
+    src = open(os.path.join(_paths.CSRC_DIR, "sjgpu_device.h")).read()
+    m = re.search(r"u32 xbuf_slot\(u32 block, u32 quarter\) \{ return (.*?); \}", src)
+    assert m, "xbuf_slot not found"
+    expr = re.sub(r"(\d+)u\b", r"\1", m.group(1))
+    slot = lambda block, quarter: eval(expr, {"block": block, "quarter": quarter})  # noqa: E731
+    assert sorted(slot(b, q) for b in range(64) for q in range(4)) == list(range(256))  # every piece has its own slot
+    for j in range(4):  # the write side: instruction j, lane i stores piece 64 j + i
+        for phase in range(4):
+            lanes = range(16 * phase, 16 * phase + 16)
+            cols = {slot((64 * j + i) >> 2, (64 * j + i) & 3) % 16 for i in lanes}
+            assert len(cols) == 16, ("write", j, phase)
+    for k in range(4):  # the read side: instruction k, lane L loads quarter k of block L
+        for phase in range(4):
+            cols = {slot(L, k) % 16 for L in range(16 * phase, 16 * phase + 16)}
+            assert len(cols) == 16, ("read", k, phase)
+
+
 def test_no_kernel_spills(lib):
     """Round 2's review found 20 B of scratch in the headline kernel and in k_stage1_summarize (spills inside the hot loop of a
     kernel that is short of issue slots).  What the code objects of the built library tell the hardware to reserve
