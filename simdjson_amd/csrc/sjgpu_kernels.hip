@@ -171,9 +171,10 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) SJ_WAVES_PER_EU(TOKENS ? 4 : 6, TO
   s.flags = flags;
   s.xw = span_finish(sx, buf, seg_start, SEG_BYTES, len, wc, true, resolved, derived);
   if (lane == 0) { summ[seg] = s; } // (in front of the masks: whatever this store has to wait for -- span_finish may have read bytes -- is waited for before they are issued)
-  // The masks leave LAST, behind the rendezvous: in front of it the barrier's fence made every wave wait for the acknowledgement of its own stores (an
-  // s_waitcnt vmcnt(0) -- this ISA counts loads and stores in one in-order counter) with its registers and its share of the LDS held: 69 us of 258 per GiB of
-  // NDJSON (profiles/r05_summarize_lab.txt: the kernel without these stores ran in 189 us).  Nothing behind them waits: the wave ends with its stores in flight.
+  // The masks leave LAST, behind the rendezvous and behind the summary: nothing waits behind them, the wave ends with its stores in flight (in front of the
+  // barrier its fence made every wave wait for their acknowledgement -- this ISA counts loads and stores in one in-order counter -- which measured no
+  // different once both orders ran in one process; what the masks cost is their traffic: a lab build that writes none runs 189 against 258 us per GiB of
+  // NDJSON, and a pure mover pays the same for them -- scripts/micro/split_lab.hip).  They are written with the non-temporal hint: read once, by k_stage1_emit.
   // A segment without a single candidate (the inside of a long string, of a backslash run, of whitespace) publishes two zero counts and
   // writes NO masks: k_stage1_emit takes the zeros from the summary (escape_heavy: 0.27 GB of masks written and 0.28 GB read back for 300 000
   // structurals in a GiB -- profiles/r04_pmc_summary.txt -- are gone; ordinary input has no such segments and pays one ballot)
