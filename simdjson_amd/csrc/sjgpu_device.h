@@ -875,8 +875,8 @@ __device__ __forceinline__ bool emit_span(const u64 *m, u32 pos0, u32 lane, u32 
     a[2 * c + 1] = a[2 * c] + n[2 * c];
     mx = max(mx, max(n[2 * c], n[2 * c + 1]));
   }
-#pragma unroll
-  for (u32 k = 0; k < NH; k++) { a[k] = n[k] ? a[k] : DUMP; } // an empty chain parks its (ignored) stores in the dump slot
+  // (an empty chain needs no slot of its own: the loop below sends every store of a chain without bits to the dump slot -- rounds 2-5a also
+  // pre-selected it here, sixteen instructions per span for nothing)
   mx = max(mx, u32(__builtin_amdgcn_update_dpp(0, int(mx), 0x111, 0xf, 0xf, false)));
   mx = max(mx, u32(__builtin_amdgcn_update_dpp(0, int(mx), 0x112, 0xf, 0xf, false)));
   mx = max(mx, u32(__builtin_amdgcn_update_dpp(0, int(mx), 0x114, 0xf, 0xf, false)));

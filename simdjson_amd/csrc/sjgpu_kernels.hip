@@ -449,7 +449,11 @@ __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask
   bool overflow = false;
   u64 st[SEG_CHUNKS];
 #pragma unroll
-  for (u32 c = 0; c < SEG_CHUNKS; c++) { st[c] = resolved ? m0[c] : (m0[c] & ~(m1[c] ^ flip)); } // chunks beyond len hold zero masks
+  for (u32 c = 0; c < SEG_CHUNKS; c++) { st[c] = m0[c]; } // chunks beyond len hold zero masks
+  if (!resolved) { // (wave-uniform: a scalar branch, not eight selects)
+#pragma unroll
+    for (u32 c = 0; c < SEG_CHUNKS; c++) { st[c] = andn(m0[c], m1[c] ^ flip); }
+  }
   span_patch(st, own.xw, x, t.se, lane);
   const u32 span_count = (org.carry & CARRY_DEBUG_NO_SPAN_HINT) ? 0u : xs_count(own.count_if_out, own.count_if_in, t);
   const u32 base_before = base;
