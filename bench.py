@@ -20,7 +20,11 @@ BASELINE.json measured the same way (each with its own `roofline` and `cpu_basel
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank scans its OWN 1 GiB shard (independent
 documents, SURVEY 8(e): no data-path collective), weak scaling; value = bytes all ranks scanned / max-over-ranks time;
 "config3_ndjson_sharded" / "one_document_shards" carry the NDJSON shards (BASELINE configs[3]) with the index concatenation and the one-document path.
-Prints ONE JSON line on rank 0.
+
+Output (round 6): rank 0 prints ONE JSON line, the LAST line of stdout, at most COMPACT_LINE_LIMIT (4096) characters: the contract's fields with numbers and
+short identifiers only (compact_line below) -- the reference's own convention is three figures per stage and run (benchmark/benchmarker.h:408-419).  Everything
+else a leg measures (per-slot kernel times, digests, samples, sweeps) goes to the side-car `bench_detail.json` beside this script (and into gpurun_out/ when
+that directory exists); what the fields MEAN is DESIGN.md section 5, not the line.
 """
 import argparse
 import json
@@ -36,6 +40,119 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 measured copy
 ALL_LEGS = ["config0_twitter_json", "config2_minify", "config2_validate_utf8", "config3_amazon_ndjson", "config4_deep_nesting",
             "config4_escape_heavy", "plugin_host_path", "next_f2_finish_device", "next_f3_depth_scan", "next_f3_parse_strings", "next_f3_tape"]
+
+COMPACT_LINE_LIMIT = 4096  # characters of the ONE line rank 0 prints (round 5's 23 KB line outgrew the driver's capture: BENCH_r05.json parsed = null)
+DETAIL_FILE = "bench_detail.json"
+
+
+def _short(x, n=96):
+    """identifiers stay, sentences are cut: nothing in the printed line explains itself (DESIGN.md section 5 does)"""
+    return x if not isinstance(x, str) or len(x) <= n else x[: n - 1] + "~"
+
+
+def _roofline_compact(r):
+    if not isinstance(r, dict):
+        return None
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "gpu_ms_per_step", "kernel", "traffic_static_from_profiles")
+    return {k: _short(r[k], 64) for k in keep if k in r}
+
+
+def _cpu_compact(c):
+    if not isinstance(c, dict):
+        return None
+    return {"value": c.get("value"), "unit": _short(c.get("unit"), 24), "cores": c.get("cores"), "kind": c.get("kind"), "sample": _short(c.get("sample", ""), 72)}
+
+
+def _leg_compact(name, leg):
+    """one leg of the detail -> at most a dozen numbers"""
+    if not isinstance(leg, dict):
+        return None
+    if "error" in leg:
+        return {"error": _short(leg["error"], 80)}
+    out = {}
+    if "ms_per_step" in leg:  # device_leg: a BASELINE config timed like the headline
+        r = leg.get("roofline") or {}
+        out = {"value": leg.get("value"), "ms_per_step": leg.get("ms_per_step"), "gpu_ms": r.get("gpu_ms_per_step"), "frac": r.get("frac"),
+               "pipeline": leg.get("pipeline"), "parity_ok": (leg.get("parity") or {}).get("ok"), "cpu": (leg.get("cpu_baseline") or {}).get("value")}
+        if "cpu_baseline_threads" in leg:
+            out["cpu_threads"] = [leg["cpu_baseline_threads"].get("value"), leg["cpu_baseline_threads"].get("cores")]
+        return out
+    if name == "config0_twitter_json":
+        return {"n": leg.get("n"), "exact": leg.get("exact_vs_reference"), "device_us": (leg.get("device_resident") or {}).get("gpu_us_per_call"),
+                "host_us": (leg.get("host_buffers") or {}).get("us_per_call"), "cpu": (leg.get("cpu_baseline") or {}).get("value")}
+    if name == "plugin_host_path":
+        doc, win, small = leg.get("document_1GiB_pageable") or {}, leg.get("parse_many_window_1MB") or {}, leg.get("small_documents") or {}
+        return {"doc_1GiB_GBps": doc.get("value"), "window_us": win.get("mi355x_us_per_window"), "window_ref_us": win.get("reference_us_per_window"),
+                "small_doc_us": small.get("one_launch_us_per_document")}
+    if name == "next_f3_tape":
+        for kind, v in leg.items():
+            if isinstance(v, dict):
+                w = v.get("with_token_stream") or {}
+                out[kind] = {"ms": v.get("gpu_ms_per_call"), "frac": (v.get("roofline") or {}).get("frac"), "traffic": (v.get("roofline") or {}).get("traffic"),
+                             "ms_from_tokens": w.get("stage2_ms_per_call"), "cpu": (v.get("cpu_baseline") or {}).get("value")}
+        return out
+    r = leg.get("roofline") or {}
+    out = {"ms": leg.get("gpu_ms_per_call", leg.get("ms_per_call")), "value": leg.get("value"), "unit": _short(leg.get("unit"), 24), "frac": r.get("frac")}
+    w = leg.get("with_token_stream")
+    if isinstance(w, dict):
+        out["ms_from_tokens"] = w.get("depth_scan_ms_per_call")
+    return out
+
+
+def compact_line(d):
+    """The ONE printed line from the full record: the contract's fields, numbers and short identifiers only, <= COMPACT_LINE_LIMIT characters."""
+    c = {k: d.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = d.get("config") or {}
+    c["config"] = {"workload": _short(cfg.get("workload"), 160), "bytes_per_gpu": cfg.get("bytes_per_gpu"), "structurals": cfg.get("structurals"),
+                   "library": cfg.get("library")}
+    c["roofline"] = _roofline_compact(d.get("roofline"))
+    c["cpu_baseline"] = _cpu_compact(d.get("cpu_baseline"))
+    if "cpu_baseline_threads" in d:
+        c["cpu_baseline_threads"] = _cpu_compact(d["cpu_baseline_threads"])
+    p = d.get("parity") or {}
+    c["parity"] = {k: p[k] for k in ("checked", "ok", "ranks_checked", "ranks_ok", "all_ranks_ok") if k in p}
+    for k in ("first_reps_ms_per_step", "value_first_reps", "clock_warmup_calls", "n1_same_workload_GBps", "scaling_efficiency", "n_ranks_seen_by_rccl"):
+        if k in d:
+            c[k] = d[k]
+    if "index_concat" in d:
+        c["index_concat"] = _short(d["index_concat"], 40)
+    if "legs" in d:
+        c["legs"] = {k: _leg_compact(k, v) for k, v in d["legs"].items()}
+        c["legs_failed"] = d.get("legs_failed", [])
+    nd = d.get("config3_ndjson_sharded")
+    if isinstance(nd, dict):
+        c["config3_ndjson_sharded"] = ({"error": _short(nd["error"], 80)} if "error" in nd else
+                                       {k: nd.get(k) for k in ("value_GBps", "with_index_concat_GBps", "n1_same_workload_GBps", "scaling_efficiency", "total_structurals",
+                                                               "sorted_global_positions", "steps") if k in nd})
+        if "cpu_baseline" in nd:
+            c["config3_ndjson_sharded"]["cpu"] = nd["cpu_baseline"].get("value")
+        if "cpu_baseline_threads" in nd:
+            c["config3_ndjson_sharded"]["cpu_threads"] = [nd["cpu_baseline_threads"].get("value"), nd["cpu_baseline_threads"].get("cores")]
+    ds = d.get("one_document_shards")
+    if isinstance(ds, dict):
+        c["one_document_shards"] = {"error": _short(ds["error"], 80)} if "error" in ds else {k: ds.get(k) for k in ("value_GBps", "total_structurals", "steps")}
+    c["detail"] = DETAIL_FILE
+    text = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    if len(text) > COMPACT_LINE_LIMIT:  # never let the line outgrow the capture again: drop what is least needed, say so
+        for victim in ("one_document_shards", "legs"):
+            if victim in c:
+                c[victim] = {"dropped": "see " + DETAIL_FILE}
+                text = json.dumps(c, allow_nan=False, separators=(",", ":"))
+                if len(text) <= COMPACT_LINE_LIMIT:
+                    break
+    assert len(text) <= COMPACT_LINE_LIMIT, len(text)
+    return text
+
+
+def write_detail(d):
+    """the full record beside the script (and under gpurun_out/ when that directory exists, so that it comes home from the GPU box)"""
+    for where in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(where):
+            try:
+                with open(os.path.join(where, DETAIL_FILE), "w") as f:
+                    json.dump(d, f, indent=1)
+            except OSError:
+                pass
 
 
 def position_digest_host(words):
@@ -939,7 +1056,9 @@ def main():
             line["index_concat"] = ndjson.get("index_concat")
         if docshards is not None:
             line["one_document_shards"] = docshards
-        print(json.dumps(line), flush=True)
+        write_detail(line)
+        sys.stdout.flush()
+        print(compact_line(line), flush=True)  # the ONE line, and the last one: <= 4 KB, numbers and identifiers (the full record: bench_detail.json)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

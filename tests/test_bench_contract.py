@@ -10,9 +10,77 @@ from simdjson_amd import _paths
 
 
 def _final_line():
-    files = sorted(glob.glob(os.path.join(_paths.REPO_ROOT, "profiles", "r*_bench_final.json")))
+    """The full record of the final tree's default run.  Round 6 on: `bench_detail.json` as bench.py wrote it, committed as profiles/rNN_bench_detail.json
+    (the printed line is profiles/rNN_bench_final.json); rounds 1-5 printed the full record itself."""
+    files = sorted(glob.glob(os.path.join(_paths.REPO_ROOT, "profiles", "r*_bench_detail.json"))) or \
+        sorted(glob.glob(os.path.join(_paths.REPO_ROOT, "profiles", "r*_bench_final.json")))
     assert files, "no committed bench line"
     return json.load(open(files[-1])), files[-1]
+
+
+def _strict(text):
+    def refuse(x):
+        raise ValueError("non-finite number in the line: " + x)
+    return json.loads(text, parse_constant=refuse)
+
+
+def test_the_printed_line_is_a_record_not_a_document():
+    """round 5's one line had grown to 23 KB and the driver could not parse it (BENCH_r05.json: parsed = null).  The printed line is now
+    compact_line(full record): <= 4096 characters, strict JSON (no NaN / Infinity), the contract's fields, every leg as a handful of numbers; the full record
+    goes to the side-car.  Checked on every full record committed so far (N = 1, N = 2 dry run, NDJSON at N = 1) and on a record whose every string is long."""
+    import sys
+    sys.path.insert(0, _paths.REPO_ROOT)
+    import bench
+    assert bench.COMPACT_LINE_LIMIT == 4096
+    prof = os.path.join(_paths.REPO_ROOT, "profiles")
+    records = [f for f in sorted(glob.glob(os.path.join(prof, "r*_bench_*.json")))  # round 5 on: every record carries cpu_baseline and parity.ok at every N
+               if os.path.basename(f) >= "r05" and (len(open(f).read()) > 4096 or "_detail" in f or "dry" in f or "ndjson" in f)]
+    assert len(records) >= 3
+    for f in records:
+        d = json.load(open(f))
+        if "legs" not in d and "config3_ndjson_sharded" not in d and "roofline" not in d:
+            continue
+        text = bench.compact_line(d)
+        assert len(text) < 4096 and "\n" not in text, (f, len(text))
+        c = _strict(text)
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                    "roofline", "cpu_baseline", "parity"):
+            assert key in c, (f, key)
+        assert c["value"] == d["value"] and c["ms_per_step"] == d["ms_per_step"] and c["roofline"]["frac"] == d["roofline"]["frac"]
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert key in c["roofline"], key
+        for key in ("value", "unit", "cores", "kind", "sample"):
+            assert key in c["cpu_baseline"], key
+        assert "workload" in c["config"] and "model" not in c["config"]
+        if "legs" in d:
+            assert set(c["legs"]) == set(d["legs"]) and c["legs_failed"] == d["legs_failed"]
+            for name, leg in c["legs"].items():
+                assert len(json.dumps(leg)) < 400, name
+            if "config3_amazon_ndjson" in d["legs"]:  # (the mid-round records of round 3 measured a subset of the legs)
+                assert c["legs"]["config3_amazon_ndjson"]["frac"] == d["legs"]["config3_amazon_ndjson"]["roofline"]["frac"]
+            if "ok" in d.get("legs", {}).get("config3_amazon_ndjson", {}).get("parity", {}):  # (round 3's records say "checked" only: a failure raised)
+                assert c["legs"]["config3_amazon_ndjson"]["parity_ok"] is True
+    # a record bloated with prose still yields a line under the limit (legs are dropped with a pointer to the side-car before the limit is crossed)
+    d = json.load(open(records[-1]))
+    fat = json.loads(json.dumps(d).replace("GB/s", "GB/s " + "x" * 300))
+    fat.setdefault("legs", {})
+    for i in range(40):
+        fat["legs"][f"extra_{i}"] = {"ms_per_step": 1.0, "value": 1.0, "pipeline": "p" * 500, "roofline": {"frac": 0.5}}
+    assert len(bench.compact_line(fat)) <= 4096
+
+
+def test_the_committed_printed_line_is_the_compact_one():
+    """From round 6 on profiles/rNN_bench_final.json is the line as PRINTED (what the driver parses), rNN_bench_detail.json the side-car of the same run."""
+    prof = os.path.join(_paths.REPO_ROOT, "profiles")
+    finals = [f for f in sorted(glob.glob(os.path.join(prof, "r*_bench_final.json"))) if os.path.basename(f) >= "r06"]
+    for f in finals:
+        text = open(f).read().strip()
+        assert len(text) < 4096 and "\n" not in text, f
+        c = _strict(text)
+        det = f.replace("_final", "_detail")
+        assert os.path.exists(det), det
+        d = json.load(open(det))
+        assert c["value"] == d["value"] and c["roofline"]["frac"] == d["roofline"]["frac"] and c["detail"] == "bench_detail.json"
 
 
 def test_the_committed_bench_line_has_the_contract_s_fields():
