@@ -399,11 +399,15 @@ int sjgpu_minify_range_device(sjgpu_ctx *ctx, const void *buf_dev, size_t begin,
  * patch registers in document_stream::start(); out of tree: simdjson::mi355x::register_stream.
  * Registrations are COUNTED per base address: registering a base again (a second stream over the same buffer) adds a reference, every
  * registration needs its own sjgpu_stream_unregister, and the range stays page-locked until the last one.  While several are alive the
- * extent served from spans is the SHORTEST length any of them named (when one leaves, the longest is assumed to have left): a window beyond
- * it takes the ordinary path -- same results, one upload per window.  A caller that registers a base twice and unregisters once leaks the
- * reference (and the page-lock) until it unregisters again. */
+ * extent served from spans is the SHORTEST length any of them named: a window beyond it takes the ordinary path -- same results, one upload
+ * per window.  sjgpu_stream_unregister_len(base, len) says WHICH registration leaves (the one made with that len; if none was, the longest),
+ * and the extent becomes the shortest of those that stay; sjgpu_stream_unregister(base) cannot say, so the longest is assumed to have left
+ * (never unsafe, but a short-lived short registration then caps the extent for the life of the long one).  A caller that registers a base
+ * twice and unregisters once leaks the reference (and the page-lock) until it unregisters again. */
 int sjgpu_stream_register(const uint8_t *base, size_t len);
 int sjgpu_stream_unregister(const uint8_t *base);
+int sjgpu_stream_unregister_len(const uint8_t *base, size_t len);
+size_t sjgpu_debug_stream_extent(const uint8_t *base); /* tests: the extent currently served from spans for the registration(s) made AT base; 0 = none */
 
 /* ---- page-locked host memory ("a pinned-memory padded_string allocator") ----------------------
  * The host-buffer entry points accept any memory.  Ordinary (pageable) memory has to be pinned page by page by the

@@ -29,7 +29,7 @@ EXPORTS = [
     "sjgpu_stage1_range_device", "sjgpu_minify_range_device",
     "sjgpu_host_alloc", "sjgpu_host_free", "sjgpu_host_register", "sjgpu_host_unregister", "sjgpu_last_pipeline",
     "sjgpu_profile_kernel", "sjgpu_debug_trace_pipelined", "sjgpu_debug_string_path", "sjgpu_stage1_many", "sjgpu_stage1_finish_device",
-    "sjgpu_depth_scan_device", "sjgpu_parse_strings_device", "sjgpu_stage2_device", "sjgpu_stage2_tokens_device", "sjgpu_parse", "sjgpu_pool_trim", "sjgpu_stream_register", "sjgpu_stream_unregister", "sjgpu_match_keys_device", "sjgpu_comm_unique_id", "sjgpu_comm_create", "sjgpu_comm_destroy", "sjgpu_comm_last_error", "sjgpu_comm_ranks", "sjgpu_comm_gather_indices", "sjgpu_mgpu_create", "sjgpu_mgpu_destroy", "sjgpu_mgpu_count", "sjgpu_mgpu_stage1", "sjgpu_mgpu_minify",
+    "sjgpu_depth_scan_device", "sjgpu_parse_strings_device", "sjgpu_stage2_device", "sjgpu_stage2_tokens_device", "sjgpu_parse", "sjgpu_pool_trim", "sjgpu_stream_register", "sjgpu_stream_unregister", "sjgpu_stream_unregister_len", "sjgpu_debug_stream_extent", "sjgpu_match_keys_device", "sjgpu_comm_unique_id", "sjgpu_comm_create", "sjgpu_comm_destroy", "sjgpu_comm_last_error", "sjgpu_comm_ranks", "sjgpu_comm_gather_indices", "sjgpu_mgpu_create", "sjgpu_mgpu_destroy", "sjgpu_mgpu_count", "sjgpu_mgpu_stage1", "sjgpu_mgpu_minify",
     "sjgpu_mgpu_validate_utf8",
 ]
 
@@ -581,11 +581,21 @@ def stream_register(arr):
     return L.sjgpu_stream_register(arr.ctypes.data, arr.nbytes)
 
 
-def stream_unregister(arr):
+def stream_unregister(arr, named=False):
+    """named: say WHICH registration over that base leaves (sjgpu_stream_unregister_len: the one made with this array's length)"""
     L = load_library()
     L.sjgpu_stream_unregister.restype = ctypes.c_int
     L.sjgpu_stream_unregister.argtypes = [ctypes.c_void_p]
-    return L.sjgpu_stream_unregister(arr.ctypes.data)
+    L.sjgpu_stream_unregister_len.restype = ctypes.c_int
+    L.sjgpu_stream_unregister_len.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    return L.sjgpu_stream_unregister_len(arr.ctypes.data, arr.nbytes) if named else L.sjgpu_stream_unregister(arr.ctypes.data)
+
+
+def stream_extent(arr):
+    L = load_library()
+    L.sjgpu_debug_stream_extent.restype = ctypes.c_size_t
+    L.sjgpu_debug_stream_extent.argtypes = [ctypes.c_void_p]
+    return int(L.sjgpu_debug_stream_extent(arr.ctypes.data))
 
 
 def stage1_error_from_flags(n, flags):

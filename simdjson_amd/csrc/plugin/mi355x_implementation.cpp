@@ -19,6 +19,9 @@ namespace {
 using builtin_parser = simdjson::SIMDJSON_BUILTIN_IMPLEMENTATION::dom_parser_implementation;
 
 std::atomic<int> g_device{0};
+// test hooks (debug_set_test_hooks): relaxed loads of two process-wide atomics -- rounds 3-5 asked the ENVIRONMENT on every parse() / validate_utf8(), a
+// libc walk and a race with any setenv of the host program inside functions whose reference counterparts are re-entrant and lock-free
+std::atomic<int> g_hook_stage2_decline{0}, g_hook_utf8_fail_attempts{0};
 
 // libsjgpu's infrastructure codes -> simdjson::error_code (library must not abort or print,
 // /root/reference/src/implementation.cpp:307)
@@ -101,7 +104,7 @@ public:
       len_ = len;
       uint64_t tw = 0, sb = 0;
       int rc = sjgpu_parse(ctx_, buf, len, uint32_t(_max_depth), doc.tape.get(), tape_words, doc.string_buf.get(), string_bytes, &tw, &sb);
-      if (std::getenv("SJGPU_DEBUG_STAGE2_DECLINE")) { rc = SJGPU_E_HIP; } // test hook (plugin_test 2c): the device road fails after it has run
+      if (g_hook_stage2_decline.load(std::memory_order_relaxed)) { rc = SJGPU_E_HIP; } // test hook (debug_set_test_hooks, plugin_test 2c): the device road fails after it has run
       n_structural_indexes = 0; // the list stayed on the device
       next_structural_index = 0;
       // A verdict about the DOCUMENT is final (SUCCESS, TAPE_ERROR, STRING_ERROR, ...).  What says something about the device road instead
@@ -233,9 +236,9 @@ public:
   // the input in 16 MiB pieces, which needs 16 MiB of device memory whatever len is.  Only when all three fail -- a device that is gone --
   // does the call say `false`: there is no CPU path in this backend to ask instead.
   simdjson_warn_unused bool validate_utf8(const char *buf, size_t len) const noexcept final {
-    // test hook (plugin_test 1c): the first N attempts of every call fail as if HIP had
-    int induced = 0;
-    if (const char *v = std::getenv("SJGPU_DEBUG_UTF8_FAIL_ATTEMPTS")) { induced = std::atoi(v); }
+    // Only what another attempt can change is retried: a HIP call or an allocation that failed (SJGPU_E_HIP, SJGPU_E_NOMEM / MEMALLOC).  A bad argument
+    // or a capacity answer would come back the same three times -- and the second attempt gives back every parked context of the process first.
+    const int induced = g_hook_utf8_fail_attempts.load(std::memory_order_relaxed); // test hook (debug_set_test_hooks, plugin_test 5b): the first N attempts fail as if HIP had
     for (int attempt = 0; attempt < 3; attempt++) {
       if (attempt == 1) { (void)sjgpu_pool_trim(); }
       borrowed_ctx b;
@@ -248,6 +251,7 @@ public:
       if (attempt < induced) { rc = SJGPU_E_HIP; }
       if (rc == 0) { return ok != 0; }
       validate_utf8_retries_.fetch_add(1, std::memory_order_relaxed);
+      if (!(rc == SJGPU_E_HIP || rc == SJGPU_E_NOMEM || rc == int(MEMALLOC))) { break; } // not transient: the same call would fail the same way
     }
     return false;
   }
@@ -263,8 +267,14 @@ const simdjson::implementation *get_implementation() noexcept {
 
 bool available() noexcept { return sjgpu_device_count() > 0; }
 
+void debug_set_test_hooks(int stage2_decline, int utf8_fail_attempts) noexcept {
+  g_hook_stage2_decline.store(stage2_decline, std::memory_order_relaxed);
+  g_hook_utf8_fail_attempts.store(utf8_fail_attempts, std::memory_order_relaxed);
+}
+
 void register_stream(const uint8_t *buf, size_t len) noexcept { (void)sjgpu_stream_register(buf, len); }
 void unregister_stream(const uint8_t *buf) noexcept { (void)sjgpu_stream_unregister(buf); }
+void unregister_stream(const uint8_t *buf, size_t len) noexcept { (void)sjgpu_stream_unregister_len(buf, len); }
 
 // ---- pinned_padded_string ---------------------------------------------------------------------------------------------------------------
 pinned_padded_string::pinned_padded_string(size_t length) noexcept {

@@ -39,6 +39,15 @@ simdjson::error_code activate(int device = 0) noexcept;
  */
 void register_stream(const uint8_t *buf, size_t len) noexcept;
 void unregister_stream(const uint8_t *buf) noexcept;
+/** The same, naming the registration that leaves by its length (two streams over one base: without it the LONGEST is assumed to have left). */
+void unregister_stream(const uint8_t *buf, size_t len) noexcept;
+
+/**
+ * TEST HOOKS (tests/plugin/plugin_test.cpp; never needed by a user).  stage2_decline != 0: the device road of parse() reports a HIP failure AFTER it ran, so
+ * that the fall-back to stage 1 + the reference's stage 2 can be exercised; utf8_fail_attempts = N: the first N attempts of every validate_utf8() call fail
+ * as if HIP had.  Both zero (the initial state): no effect.  Process-wide, stored in atomics; the product's calls read them with one relaxed load.
+ */
+void debug_set_test_hooks(int stage2_decline, int utf8_fail_attempts) noexcept;
 
 /**
  * A document buffer in PAGE-LOCKED host memory -- SURVEY.md 8(f).1's "pinned-memory padded_string allocator", the C++ face of

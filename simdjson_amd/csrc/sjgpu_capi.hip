@@ -141,6 +141,10 @@ struct sjgpu_ctx {
   size_t h_small_bytes = 0;
   bool small_docs = true;     // env SJGPU_SMALL_DOCS=0 sends small documents through the tile pipelines (A/B, tests)
   int enqueue_rc = 0;         // failure of the workspace allocation inside the last enqueue_* (checked by SJ_ENQUEUED)
+  // The single-pass kernels find [result][descriptors][control words] all zero because the kernel before them left them so (leave_and_clean); nothing on
+  // the device says whether that kernel ran to its end.  Whatever makes that doubtful -- a HIP error recorded on this context (fail()), a chain that gave
+  // up (SJGPU_F_INTERNAL), a traced run -- sets this, and the next single-pass call clears the workspace in front of its kernel instead of trusting it.
+  bool ws_dirty = false;
   int device_finish = 1;      // streaming-mode finish: 0 host, 1 device beyond the small-document path, 2 always device
   // scratch of the device-side finish / depth scan (sjgpu_finish.hip), grown on demand
   uint8_t *d_tmp = nullptr;
@@ -192,7 +196,10 @@ namespace {
 constexpr int E_CAPACITY = 1, E_UTF8 = 11, E_EMPTY = 13, E_UNCLOSED = 15, E_UNEXPECTED = 24;
 
 int fail(sjgpu_ctx *ctx, hipError_t e, const char *what) {
-  if (ctx) { std::snprintf(ctx->err, sizeof ctx->err, "%s: %s", what, hipGetErrorString(e)); }
+  if (ctx) {
+    std::snprintf(ctx->err, sizeof ctx->err, "%s: %s", what, hipGetErrorString(e));
+    ctx->ws_dirty = true; // whatever was in flight may not have reached its epilogue
+  }
   static const bool trace = std::getenv("SJGPU_TRACE_ERRORS") != nullptr; // diagnostics: the library itself never prints otherwise
   if (trace) { std::fprintf(stderr, "[sjgpu] %s: %s\n", what, hipGetErrorString(e)); }
   return (e == hipErrorOutOfMemory) ? SJGPU_E_NOMEM : SJGPU_E_HIP;
@@ -249,6 +256,7 @@ int alloc_result(sjgpu_ctx *ctx, size_t for_len) {
   ctx->desc = reinterpret_cast<uint64_t *>(ctx->d_result + 1);
   SJ_TRY(ctx, hipMemsetAsync(ctx->d_result, 0, bytes, nullptr));
   SJ_TRY(ctx, hipStreamSynchronize(nullptr)); // (the calls run on other streams: the zeros are there before any of them is enqueued)
+  ctx->ws_dirty = false;
   return 0;
 }
 
@@ -294,6 +302,7 @@ int fetch_result(sjgpu_ctx *ctx, hipStream_t s, sjgpu_scan_result *out) {
   out->n = ctx->h_result->n;
   out->flags = ctx->h_result->flags;
   out->out_len = ctx->h_result->out_len;
+  if (out->flags & SJGPU_F_INTERNAL) { ctx->ws_dirty = true; } // a chain that gave up: do not trust what its workgroups left behind
   if (ctx->pending_scan_bytes) {
     ctx->density_permille = uint32_t(uint64_t(out->n) * 1000u / ctx->pending_scan_bytes);
     ctx->pending_scan_bytes = 0;
@@ -370,7 +379,10 @@ void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, 
   // the density AUTO decides by is taken from every whole-document scan beyond the small-input kernels' range (round 4 sampled only scans of
   // 224 MiB and more: a context that had once seen sparse output stayed on the split pipeline until another scan of that size measured dense)
   ctx->pending_scan_bytes = (org.begin == 0 && org.base0 == 0 && len > AUTO_FUSED_BELOW) ? len : 0;
-  if (fused) { ctx->last_kernel = launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, org, ctx->max_workgroups, s, ev, true); }
+  if (fused) {
+    ctx->last_kernel = launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, org, ctx->max_workgroups, s, ev, !ctx->ws_dirty);
+    ctx->ws_dirty = false; // (a dirty workspace was cleared in front of the kernel: clear_fused_workspace)
+  }
   else {
     launch_stage1(buf, len, ctx->masks, ctx->summ, ctx->pref, idx, idx_words, ctx->d_result, org, s, ev, tok ? ctx->d_tokstage : nullptr, tok);
     ctx->last_kernel = tok ? "k_stage1_summarize<tokens>+k_resolve_groups+k_resolve_segments+k_stage1_emit<tokens>"
@@ -383,7 +395,10 @@ void enqueue_minify(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, 
   if (ctx->enqueue_rc) { return; }
   ctx->last_pipeline = fused ? 1 : 0;
   ctx->pending_scan_bytes = 0;
-  if (fused) { ctx->last_kernel = launch_minify_fused(buf, len, ctx->desc, dst, ctx->d_result, org, ctx->max_workgroups, s, ev, true); }
+  if (fused) {
+    ctx->last_kernel = launch_minify_fused(buf, len, ctx->desc, dst, ctx->d_result, org, ctx->max_workgroups, s, ev, !ctx->ws_dirty);
+    ctx->ws_dirty = false;
+  }
   else {
     launch_minify(buf, len, ctx->summ, ctx->pref, dst, ctx->d_result, org, s, ev);
     ctx->last_kernel = "k_minify_summarize+k_resolve_groups+k_resolve_segments+k_minify_emit";
@@ -913,6 +928,7 @@ int sjgpu_debug_trace_stage1(sjgpu_ctx *ctx, const void *buf_dev, size_t len, vo
   hipError_t e = hipDeviceSynchronize();
   if (e == hipSuccess) { e = hipMemcpy(trace_host, d_trace, bytes, hipMemcpyDeviceToHost); }
   (void)hipFree(d_trace);
+  ctx->ws_dirty = true; // (a traced kernel cleans up like any other; the next call does not rely on it)
   if (e != hipSuccess) { return fail(ctx, e, "debug_trace"); }
   return 0;
 }
@@ -934,6 +950,7 @@ int sjgpu_debug_trace_pipelined(sjgpu_ctx *ctx, const void *buf_dev, size_t len,
   hipError_t e = hipDeviceSynchronize();
   if (e == hipSuccess) { e = hipMemcpy(trace_host, d_trace, bytes, hipMemcpyDeviceToHost); }
   (void)hipFree(d_trace);
+  ctx->ws_dirty = true;
   if (e != hipSuccess) { return fail(ctx, e, "debug_trace_pipelined"); }
   return *workgroups_out ? 0 : SJGPU_E_BADARG;
 }
@@ -1417,7 +1434,8 @@ int sjgpu_stream_register(const uint8_t *base, size_t len) {
   return 0;
 }
 
-int sjgpu_stream_unregister(const uint8_t *base) {
+// len == 0: the caller does not say which registration over `base` leaves
+static int stream_unregister_impl(const uint8_t *base, size_t len) {
   if (!base) { return SJGPU_E_BADARG; }
   stream_registry &r = streams();
   bool pinned = false, found = false;
@@ -1425,12 +1443,22 @@ int sjgpu_stream_unregister(const uint8_t *base) {
     std::lock_guard<std::mutex> lk(r.m);
     for (size_t i = 0; i < r.list.size(); i++) {
       if (r.list[i].base == base) {
-        if (--r.list[i].refs > 0) { // another stream over the same buffer is still at work.  Which registration left is not said: assume the
-          // LONGEST did -- the extent never grows beyond what the remaining ones are known to cover (windows beyond it take the ordinary path)
+        if (--r.list[i].refs > 0) { // another stream over the same buffer is still at work.  The entry named by `len` leaves; when the caller does not
+          // say (or names a length nobody registered) assume the LONGEST did -- the extent never grows beyond what the remaining ones are known to
+          // cover (windows beyond it take the ordinary path).  The extent served from spans is the shortest of those that STAY.
           std::vector<size_t> &ls = r.list[i].lens;
-          size_t at = 0;
-          for (size_t k = 1; k < ls.size(); k++) { if (ls[k] > ls[at]) { at = k; } }
+          size_t at = ls.size();
+          for (size_t k = 0; k < ls.size() && len != 0; k++) { if (ls[k] == len) { at = k; break; } }
+          if (at == ls.size()) {
+            at = 0;
+            for (size_t k = 1; k < ls.size(); k++) { if (ls[k] > ls[at]) { at = k; } }
+          }
           if (!ls.empty()) { ls.erase(ls.begin() + long(at)); }
+          if (!ls.empty()) {
+            size_t m = ls[0];
+            for (size_t v : ls) { m = v < m ? v : m; }
+            r.list[i].len = m;
+          }
           return 0;
         }
         pinned = r.list[i].pinned;
@@ -1455,6 +1483,12 @@ int sjgpu_stream_unregister(const uint8_t *base) {
   if (pinned) { (void)hipHostUnregister(const_cast<uint8_t *>(base)); }
   return found ? 0 : SJGPU_E_BADARG;
 }
+int sjgpu_stream_unregister(const uint8_t *base) { return stream_unregister_impl(base, 0); }
+size_t sjgpu_debug_stream_extent(const uint8_t *base) { // the span-served extent of the registration(s) over `base` (0: none) -- host logic, for the tests
+  stream_extent e;
+  return (base && find_stream(base, 1, &e) && e.base == base) ? e.len : 0;
+}
+int sjgpu_stream_unregister_len(const uint8_t *base, size_t len) { return stream_unregister_impl(base, len); }
 
 int sjgpu_stage1(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, int mode, uint32_t *idx_out, size_t idx_words, uint32_t *n_io,
                  uint32_t *next_io) {
@@ -1889,6 +1923,7 @@ int sjgpu_validate_utf8_pieces(sjgpu_ctx *ctx, const uint8_t *buf, size_t len, s
   SJ_TRY(ctx, hipSetDevice(ctx->device));
   if (piece == 0) { piece = piece_bytes(); }
   if (piece < 64) { piece = 64; }
+  if (piece > (size_t(2048) << 20)) { piece = size_t(2048) << 20; } // what piece_bytes() allows: one scan addresses 32 bits
   size_t at = 0;
   while (at < len) {
     size_t cut = len;

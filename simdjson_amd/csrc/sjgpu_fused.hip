@@ -62,7 +62,8 @@ __device__ __forceinline__ void desc_store(u64 *p, u64 v) { __hip_atomic_store(p
 // finished its last tile -- it will read no descriptor, draw no ticket and raise no flag any more -- adds itself to `done`; the one that
 // finds everybody else gone moves the accumulated flags into the result and zeroes descriptors and control words.  Flags are ORed into the
 // control word, not into the result: the result needs no clearing either (its other two fields are written by the last TILE's owner).
-// The host clears once, when the workspace is allocated (and after a traced / aborted run: fused_workspace::clean in sjgpu_internal.h).
+// The host clears once, when the workspace is allocated, and in front of the first call after anything that makes the state doubtful -- a HIP error on the
+// context, a chain that gave up, a traced run (sjgpu_ctx::ws_dirty, sjgpu_capi.hip).
 constexpr u32 FUSED_CTL_WORDS = 2; // u64 words behind the descriptors
 __device__ __forceinline__ u32 *ctl_done(u32 *ticket) { return ticket + 1; }
 __device__ __forceinline__ u32 *ctl_flags(u32 *ticket) { return ticket + 2; }

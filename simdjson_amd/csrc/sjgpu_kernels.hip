@@ -47,9 +47,11 @@ constexpr u32 SUMM_WAVES = 4;
 // them behind the same cursor.  Every later pass over the LIST then reads one byte per structural instead of fetching the whole document through 128-byte
 // lines to pick that byte.  Segments that could not resolve themselves (no control character in their first chunk: minified text) stage
 // nothing (no SF_TOKENS in their summary): emit gathers their bytes from the document.  Costs this kernel the compaction (~170 VALU per chunk on top of
-// ~410) and 16.5 KiB more LDS per workgroup (four workgroups per CU instead of six): the token stream is opt-in.
+// ~410) and 16.5 KiB more LDS per workgroup (47 KiB: THREE workgroups per CU instead of five): the token stream is opt-in.
+// Occupancy request = what the LDS allows (160 KiB per CU): 31 KiB -> 5 workgroups of four waves = 5 waves per SIMD (96 VGPRs each), 47 KiB -> 3 (128 VGPRs).
+// (Rounds 4-5 asked for 6 and 4, which the LDS forbids: the compiler warned and fell back to these budgets by itself.)
 template <bool TOKENS>
-__global__ __launch_bounds__(64 * SUMM_WAVES) SJ_WAVES_PER_EU(TOKENS ? 4 : 6, TOKENS ? 4 : 6) void k_stage1_summarize(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ mask0,
+__global__ __launch_bounds__(64 * SUMM_WAVES) SJ_WAVES_PER_EU(TOKENS ? 3 : 5, TOKENS ? 3 : 5) void k_stage1_summarize(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ mask0,
                                                                      u64 *__restrict__ mask1, seg_summary *__restrict__ summ,
                                                                      scan_origin org, u32 nseg, u8 *__restrict__ tokstage) {
   const u32 lane = lane_id();

@@ -224,10 +224,10 @@ int main(int argc, char **argv) {
   }
 
   // 2c. a device road that FAILS (a HIP error, a limit of the device kernels) must not cost the caller the parse: the document takes
-  //     stage 1 on the GPU + the reference's stage 2, like a short one (SJGPU_DEBUG_STAGE2_DECLINE makes the road fail after it ran)
+  //     stage 1 on the GPU + the reference's stage 2, like a short one (debug_set_test_hooks makes the road fail after it ran)
   {
     setenv("SJGPU_STAGE2_FROM_KB", "1", 1);
-    setenv("SJGPU_DEBUG_STAGE2_DECLINE", "1", 1);
+    simdjson::mi355x::debug_set_test_hooks(1, 0);
     get_active_implementation() = cpu;
     dom::parser pc;
     CHECK(pc.parse(twitter).error() == SUCCESS, "reference parse");
@@ -242,7 +242,7 @@ int main(int argc, char **argv) {
     const error_code ec = pc.parse(bad).error();
     get_active_implementation() = gpu;
     CHECK(pg.parse(bad).error() == ec, "declined device stage 2: error code of a broken document");
-    unsetenv("SJGPU_DEBUG_STAGE2_DECLINE");
+    simdjson::mi355x::debug_set_test_hooks(0, 0);
     unsetenv("SJGPU_STAGE2_FROM_KB");
     std::printf("dom::parser::parse with a device stage 2 that fails: falls back to stage 1 + the reference's stage 2: OK\n");
   }
@@ -340,13 +340,13 @@ int main(int argc, char **argv) {
   //     (include/simdjson/implementation.h:118-128: "true if and only if the string is valid UTF-8").  The hook fails the first N attempts of a call:
   //     one failure -> the retry on a fresh context answers; two -> the 16 MiB-piece road answers; three -> nothing is left, and only then `false`.
   for (const char *fails : {"1", "2"}) {
-    setenv("SJGPU_DEBUG_UTF8_FAIL_ATTEMPTS", fails, 1);
+    simdjson::mi355x::debug_set_test_hooks(0, std::atoi(fails));
     CHECK(simdjson::validate_utf8(twitter.data(), twitter.size()), "valid UTF-8 answered as invalid after %s failed attempt(s) of the road", fails);
     CHECK(!simdjson::validate_utf8(badutf.data(), badutf.size()), "invalid UTF-8 accepted after %s failed attempt(s)", fails);
   }
-  setenv("SJGPU_DEBUG_UTF8_FAIL_ATTEMPTS", "3", 1);
+  simdjson::mi355x::debug_set_test_hooks(0, 3);
   CHECK(!simdjson::validate_utf8(twitter.data(), twitter.size()), "a road that fails three ways cannot say true");
-  unsetenv("SJGPU_DEBUG_UTF8_FAIL_ATTEMPTS");
+  simdjson::mi355x::debug_set_test_hooks(0, 0);
   CHECK(simdjson::validate_utf8(twitter.data(), twitter.size()), "validate_utf8 after the hook is gone");
   std::printf("validate_utf8 retries a failing road before it answers: OK\n");
 

@@ -627,6 +627,11 @@ def test_token_stream_at_full_size(orc):
         n, flags, _ = p.result(stream)
         assert flags == 0 and n > 1000
         assert torch.equal(tok[:n], buf[idx[:n].to(torch.int64)]), kind
+        # ... and against the ORACLE, not only against the library's own plain call: the list's digest, and the token bytes as the oracle's list selects them
+        oerr, on, oidx = orc.stage1(a, 0)
+        assert oerr == 0 and on == n and orc.fnv(idx[: n + 3].cpu().numpy().view(np.uint32)) == orc.fnv(oidx), kind
+        assert orc.fnv(tok[:n].cpu().numpy()) == orc.fnv(a[oidx[:n]]), kind
+        del oidx
         idx2 = torch.empty(L // 2 + 16, dtype=torch.int32, device="cuda")
         p.set_pipeline("split")
         assert p.stage1_device(buf.data_ptr(), L, idx2.data_ptr(), L // 2, stream) == 0
