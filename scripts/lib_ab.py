@@ -56,8 +56,10 @@ def main():
     envs = {n: e for n, _, e in variants}
     st = torch.cuda.current_stream().cuda_stream
     jobs = [("large_random", "fused", "stage1"), ("large_random", "auto", "minify"), ("large_random", "auto", "validate_utf8"), ("large_random", "split", "stage1"),
-            ("amazon_ndjson", "split", "stage1"), ("amazon_ndjson", "fused", "stage1"), ("twitter_like", "split", "stage1"), ("escape_heavy", "split", "stage1"),
-            ("deep_nesting_doc", "fused", "stage1")]
+            ("amazon_ndjson", "split", "stage1"), ("amazon_ndjson", "fused", "stage1"), ("twitter_like", "split", "stage1"), ("twitter_like", "fused", "stage1"),
+            ("escape_heavy", "split", "stage1"), ("escape_heavy", "fused", "stage1"), ("deep_nesting_doc", "fused", "stage1")]
+    if os.environ.get("LIB_AB_JOBS"):  # kind:pipeline:op,... -- a session's own selection
+        jobs = [tuple(j.split(":")) for j in os.environ["LIB_AB_JOBS"].split(",")]
     if quick:
         jobs = [j for j in jobs if j[0] in ("large_random", "amazon_ndjson", "escape_heavy") and not (j[0] == "large_random" and j[1] == "split")]
     table, made = {}, {}

@@ -943,6 +943,202 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
   leave_and_clean<NW * 64>(desc, ntiles, ticket, result);
 }
 
+// =====================================================================================================
+// k_stage1_direct (round 6): the split pipeline's scan kernel with the emission INSIDE it -- one pass, no masks in HBM.
+// k_stage1_summarize + k_stage1_emit move the masks out and in again (0.135 + 0.151 GB per GiB of NDJSON, 18 % of everything the
+// pipeline moves; both kernels run at ~0.9 of the copy ceiling on the bytes they move: only fewer bytes help -- VERDICT r05).  Here
+// the workgroup that scanned four segments keeps their masks in REGISTERS (one plane when the segment resolved its own string state
+// at a control character -- every segment of pretty-printed text / NDJSON / large_random -- two otherwise), publishes the tile's
+// aggregate, looks back over its predecessors' descriptors (the single-pass kernels' protocol: same descriptors, same look-back,
+// same x algebra) and emits from the registers through the LDS the chunk loads no longer need (load_chunk_stream's exchange buffer
+// = the emission window).  What distinguishes it from k_fused / k_fused_pipelined:
+//   * NOT persistent: one workgroup per 64 KiB tile, five workgroups (twenty waves) per CU -- a workgroup that waits for its prefix
+//     holds a fifth of the CU's waves while the other four scan; the pipelined kernel hides that wait by deferring a tile's emission
+//     by one iteration, which costs it the masks' trip through LDS and three barriers per tile, and two workgroups per CU;
+//   * the summarize kernel's body: streamed coalesced chunk loads, the UTF-8 rows parked in LDS (nothing is fetched twice), one mask
+//     plane and one count for resolved segments;
+//   * TICKET = false: tiles are taken in blockIdx order.  A tile waits only for tiles with SMALLER numbers; the dispatcher of every
+//     XCD hands out workgroups in ascending order, so the lowest unfinished tile is always resident or next in line on its XCD and
+//     never waits for anyone.  (Should a part ever dispatch otherwise, the look-back's wall-clock bound poisons the chain, the call
+//     reports SJGPU_F_INTERNAL and the host re-runs it on the split pipeline, like every single-pass call.)  TICKET = true: an atomic
+//     ticket per workgroup, the order the other single-pass kernels use.
+// =====================================================================================================
+constexpr u32 DIRECT_WAVES = 4;
+constexpr u32 DIRECT_TILE_BYTES = DIRECT_WAVES * SEG_BYTES;
+constexpr u32 DIRECT_WINDOW = CHUNK_BYTES / 4 - 8; // the exchange buffer's 1024 words minus skew and dump slots (emit_stage_words)
+static_assert(emit_stage_words(DIRECT_WINDOW) * 4 == CHUNK_BYTES && DIRECT_WINDOW % 4 == 0, "the emission window is the exchange buffer");
+template <bool TICKET>
+__global__ __launch_bounds__(64 * DIRECT_WAVES) SJ_WAVES_PER_EU(5, 5) void k_stage1_direct(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc, u32 *__restrict__ ticket,
+                                                                                       u32 ntiles, u32 *__restrict__ idx, u64 idx_words,
+                                                                                       scan_result_dev *__restrict__ result, scan_origin org) {
+  const u32 lane = lane_id();
+  const u32 wave = threadIdx.x >> 6;
+  __shared__ __attribute__((aligned(16))) u32 park[DIRECT_WAVES][UTF8P_ROWS * UTF8P_ROW_WORDS];
+  __shared__ __attribute__((aligned(16))) uint4 xbuf[DIRECT_WAVES][CHUNK_BYTES / 16]; // chunk loads, then the wave's emission window
+  __shared__ u32 sh_left[DIRECT_WAVES];
+  __shared__ u32 sh_wave[DIRECT_WAVES][5]; // parity, count_if_out, count_if_in, WF_* flags, x word
+  __shared__ u32 sh_prefix[4];             // S, B, ok, X
+  __shared__ u32 sh_tile;
+  u32 tile = blockIdx.x;
+  if (TICKET) {
+    if (threadIdx.x == 0) { sh_tile = atomicAdd(ticket, 1u); }
+    lds_writes_done();
+    __syncthreads();
+    tile = sh_tile;
+  }
+  const bool more = (org.carry & CARRY_MORE) != 0;
+  const u64 seg_start = org.begin + (u64(tile) * DIRECT_WAVES + wave) * SEG_BYTES;
+  const bool have = seg_start < len; // wave-uniform (wave 0 always has a segment: tile < ntiles)
+  u64 keep0[SEG_CHUNKS] = {0, 0, 0, 0}, keep1[SEG_CHUNKS] = {0, 0, 0, 0};
+  u32 parity = 0, xw = 0, c_out = 0, c_in = 0, wflags = 0;
+  bool resolved = false;
+  utf8_park uq{park[wave], 0u, 0u, 0u, 0x20202020u, buf, len, more ? 1u : 0u, UTF8P_DENSE_FROM};
+  if (have) {
+    const u64 lane_off = u64(lane) * BLOCK_BYTES;
+    const u32 lookback = lookback_issue(buf, seg_start, lane); // consumed after chunk 0 has been requested
+    wave_carry wc{0u, 0u, 0u};
+    span_x sx;
+    u32 n_a = 0, n_b = 0; // resolved: n_a = final count; else n_a = candidates, n_b = candidates in a string tail
+    bool any_a = false, any_b = false;
+    u32 derived = 0;
+    u64 flip = 0;
+#pragma unroll
+    for (u32 c = 0; c < SEG_CHUNKS; c++) {
+      const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
+      if (cstart >= len) { break; }
+      const u64 pos = cstart + lane_off;
+      u32 w[16];
+      if (cstart + CHUNK_BYTES <= len) { load_chunk_stream(buf, cstart, lane, xbuf[wave], w); }
+      else { load_block(buf, pos, len, w); }
+      if (c == 0) {
+        wc = span_carry_assume(seg_start, lane, lookback, sx);
+        utf8_park_begin(uq, lookback, lane);
+      }
+      span_note_chunk(sx, w, c * CHUNK_BYTES, lane);
+      const chunk_masks m = scan_chunk<true, true>(w, wc, lane, &uq, u32(cstart / BLOCK_BYTES));
+      if (c == SEG_CHUNKS - 1) { span_note_tail(sx, m.backslash, m.quote_raw); }
+      if (c == 0) { // the first control character pins the segment's string state (sjgpu_kernels.hip: k_stage1_summarize)
+        const u64 cm = __ballot(m.ctrl != 0);
+        if (cm) {
+          const u32 lc = ctz64(cm);
+          u32 v = 0;
+          if (lane == lc) { v = u32(m.in_string >> ctz64(m.ctrl)) & 1u; }
+          derived = readlane_dyn(v, lc);
+          resolved = true;
+          flip = derived ? ~0ull : 0ull;
+        }
+      }
+      if (resolved) {
+        const u64 structural = m.cand & ~(m.string_tail ^ flip);
+        n_a += u32(popc64(structural));
+        any_a |= __ballot((m.ctrl & (m.in_string ^ flip)) != 0) != 0;
+        keep0[c] = structural;
+      } else {
+        n_a += u32(popc64(m.cand));
+        n_b += u32(popc64(m.cand & m.string_tail));
+        any_a |= __ballot((m.ctrl & m.in_string) != 0) != 0;
+        any_b |= __ballot((m.ctrl & ~m.in_string) != 0) != 0;
+        keep0[c] = m.cand;
+        keep1[c] = m.string_tail;
+      }
+    }
+    const u32 ta = wave_sum(n_a), tb = wave_sum(n_b);
+    parity = wc.s;
+    if (resolved) {
+      c_out = c_in = ta;
+      const bool ok_view = !any_a; // (k_stage1_summarize: true carry-in == derived: error iff a control character sits in a string of the resolved view; else the resolving character itself does)
+      if (derived ? true : !ok_view) { wflags |= WF_CTRL_IF_OUT; }
+      if (derived ? !ok_view : true) { wflags |= WF_CTRL_IF_IN; }
+    } else {
+      c_out = ta - tb;
+      c_in = tb;
+      if (any_a) { wflags |= WF_CTRL_IF_OUT; }
+      if (any_b) { wflags |= WF_CTRL_IF_IN; }
+    }
+    xw = span_finish(sx, buf, seg_start, SEG_BYTES, len, wc, true, resolved, derived);
+  }
+  if (lane == 0) {
+    sh_left[wave] = uq.count;
+    sh_wave[wave][0] = parity;
+    sh_wave[wave][1] = c_out;
+    sh_wave[wave][2] = c_in;
+    sh_wave[wave][3] = wflags;
+    sh_wave[wave][4] = xw;
+  }
+  lds_writes_done();
+  __syncthreads();
+  // ---- wave 0: the rows the four waves have left, the tile's aggregate, the look-back, the inclusive prefix ----
+  if (wave == 0) {
+    const tile_agg ta = tile_aggregate<DIRECT_WAVES>(sh_wave);
+    if (lane == 0) { desc_store(desc + tile, make_agg(ta.q, ta.c_out, ta.c_in, ta.xw)); } // first: successors wait for it
+    const u32 n0 = sh_left[0], n1 = n0 + sh_left[1], n2 = n1 + sh_left[2], total = n2 + sh_left[3];
+    for (u32 done = 0; done < total; done += 64) {
+      const u32 g = done + lane;
+      bool bad = false;
+      if (g < total) {
+        const u32 v = (g >= n0) + (g >= n1) + (g >= n2);
+        const u32 r = g - (v == 0 ? 0u : (v == 1 ? n0 : (v == 2 ? n1 : n2)));
+        bad = utf8_check_row(park[v] + r * UTF8P_ROW_WORDS, len, more);
+      }
+      if (__ballot(bad)) { uq.error = 1u; }
+    }
+    u32 S = 0, X = 0, B = 0;
+    const bool ok = lookback(desc, tile, lane, S, X, B, org);
+    if (lane == 0) {
+      if (ok) {
+        const xs_step te = xs_apply(ta.q, ta.xw, S, X);
+        const u32 total_out = B + xs_count(ta.c_out, ta.c_in, te), s_end = te.s_out;
+        desc_store(desc + tile, make_incl(s_end, te.x_out, total_out));
+        if (tile == ntiles - 1) { // the last tile knows the totals: n, unclosed string, sentinels (json_structural_indexer.h:284-286)
+          u32 f = s_end ? SJGPU_F_UNCLOSED_STRING : 0u;
+          if (u64(total_out) + 3 <= idx_words) {
+            idx[total_out] = u32(len);
+            idx[total_out + 1] = u32(len);
+            idx[total_out + 2] = 0;
+          } else {
+            f |= SJGPU_F_IDX_OVERFLOW;
+          }
+          result->n = total_out;
+          result->out_len = 0;
+          if ((org.carry & CARRY_MORE) && te.x_out) { f |= SJGPU_F_RANGE_CARRY; }
+          if (f) { atomicOr(ctl_flags(ticket), f); }
+        }
+      } else {
+        desc_store(desc + tile, ST_POISON << 62);
+        atomicOr(ctl_flags(ticket), SJGPU_F_INTERNAL);
+      }
+      sh_prefix[0] = S;
+      sh_prefix[1] = B;
+      sh_prefix[2] = ok ? 1u : 0u;
+      sh_prefix[3] = X;
+    }
+  }
+  if (uq.error && lane == 0) { atomicOr(ctl_flags(ticket), SJGPU_F_UTF8_ERROR); }
+  lds_writes_done();
+  __syncthreads();
+  // ---- every wave: its carry-in from the tile's prefix, then its offsets from the registers ----
+  if (have && sh_prefix[2] != 0u) {
+    u32 s = sh_prefix[0], x = sh_prefix[3], base = sh_prefix[1];
+    wave_state(sh_wave, wave, s, x, base);
+    const xs_step own = xs_apply(parity, xw, s, x);
+    if ((wflags & (own.se ? WF_CTRL_IF_IN : WF_CTRL_IF_OUT)) && lane == 0) { atomicOr(ctl_flags(ticket), SJGPU_F_UNESCAPED_CTRL); }
+    u64 st[SEG_CHUNKS];
+#pragma unroll
+    for (u32 c = 0; c < SEG_CHUNKS; c++) { st[c] = keep0[c]; }
+    if (!resolved) {
+      const u64 flip = own.se ? ~0ull : 0ull;
+#pragma unroll
+      for (u32 c = 0; c < SEG_CHUNKS; c++) { st[c] = andn(keep0[c], keep1[c] ^ flip); }
+    }
+    span_patch(st, xw, x, own.se, lane);
+    const u32 span_count = (org.carry & CARRY_DEBUG_NO_SPAN_HINT) ? 0u : xs_count(c_out, c_in, own);
+    bool overflow = false;
+    emit_span4_adaptive<DIRECT_WINDOW>(st, u32(seg_start), lane, idx, idx_words, base, reinterpret_cast<u32 *>(xbuf[wave]), overflow, span_count);
+    if (__ballot(overflow) && lane == 0) { atomicOr(ctl_flags(ticket), SJGPU_F_IDX_OVERFLOW); }
+  }
+  leave_and_clean<64 * DIRECT_WAVES>(desc, ntiles, ticket, result);
+}
+
 
 } // namespace
 
@@ -1044,6 +1240,17 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
       }
       mark(ev, 1, stream); // (a single kernel: slots 1 and 2 stay unrecorded -- two stream markers less per call; sjgpu_profile_read reports them as 0)
       return onchip_waves == 8u ? "k_minify_onchip<8>" : (onchip_waves == 16u ? "k_minify_onchip<16>" : "k_minify_onchip<4>");
+    }
+    // round 6: the one-pass kernel derived from the split pipeline's scan (k_stage1_direct); env SJGPU_DIRECT: 0 off, 1 blockIdx order, 2 tickets
+    static const unsigned direct = []() { const char *v = std::getenv("SJGPU_DIRECT"); return v ? unsigned(std::atoi(v)) : 0u; }();
+    if (op == 0 && direct != 0u) {
+      const u32 nt = u32((len - org.begin + DIRECT_TILE_BYTES - 1) / DIRECT_TILE_BYTES);
+      u32 *tk = reinterpret_cast<u32 *>(desc + nt);
+      if (nt != ntiles) { clear_fused_workspace(result, desc, nt, clean, stream); } // (only a dirty workspace is cleared at all; the control words lie behind THIS kernel's tiles)
+      if (direct == 2u) { hipLaunchKernelGGL((k_stage1_direct<true>), dim3(nt), dim3(64 * DIRECT_WAVES), 0, stream, buf, len, desc, tk, nt, static_cast<u32 *>(out), out_words, result, org); }
+      else { hipLaunchKernelGGL((k_stage1_direct<false>), dim3(nt), dim3(64 * DIRECT_WAVES), 0, stream, buf, len, desc, tk, nt, static_cast<u32 *>(out), out_words, result, org); }
+      mark(ev, 1, stream);
+      return direct == 2u ? "k_stage1_direct<ticket> (4 waves, 64 KiB tiles)" : "k_stage1_direct (4 waves, 64 KiB tiles)";
     }
     static const unsigned pipe_wc = []() { const char *v = std::getenv("SJGPU_PIPE_WC"); return v ? unsigned(std::atoi(v)) : 4u; }(); // A/B switch: 2 = 32 KiB tiles
     if (op == 0 && pipe_wc == 2u) {

@@ -33,6 +33,9 @@ constexpr uint32_t SF_UTF8 = 8u;        // UTF-8 error in the segment
 constexpr uint32_t SF_RESOLVED = 16u;   // the segment fixed its own in-string carry-in (first control character): its
                                         // mask plane 0 is final and both counts are equal
 constexpr uint32_t SF_TOKENS = 32u;     // launch_stage1 with a token stream: the segment's structural bytes lie in its staging area
+constexpr uint32_t SF_SPARSE = 64u;     // round 6: at most SPARSE_MAX candidates in the segment: the start of its plane-0 area holds them as a LIST of words
+                                        // (bits 0-13 the candidate's byte offset inside the segment, bit 31 its string_tail bit) instead of 2 x 2 KiB of planes
+constexpr uint32_t SPARSE_MAX = 32u;    // one 128-byte line of list words per sparse segment
 
 struct seg_summary {
   uint32_t count_if_out; // structurals (stage1) / kept bytes (minify) if the segment starts outside a string

@@ -172,6 +172,9 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) SJ_WAVES_PER_EU(TOKENS ? 3 : 5, TO
   }
   s.flags = flags;
   s.xw = span_finish(sx, buf, seg_start, SEG_BYTES, len, wc, true, resolved, derived);
+  // round 6: a handful of candidates leave as a list, not as planes (below); not for segments whose x word patches a candidate bit (the patch is defined on planes)
+  const bool sparse = !TOKENS && ta != 0u && ta <= SPARSE_MAX && ((s.xw >> XW_D_SHIFT) & 0xFu) == 0u; // wave-uniform (ta: resolved: the final count; else every candidate)
+  if (sparse) { s.flags |= SF_SPARSE; }
   if (lane == 0) { summ[seg] = s; } // (in front of the masks: whatever this store has to wait for -- span_finish may have read bytes -- is waited for before they are issued)
   // The masks leave LAST, behind the rendezvous and behind the summary: nothing waits behind them, the wave ends with its stores in flight (in front of the
   // barrier its fence made every wave wait for their acknowledgement -- this ISA counts loads and stores in one in-order counter -- which measured no
@@ -180,6 +183,29 @@ __global__ __launch_bounds__(64 * SUMM_WAVES) SJ_WAVES_PER_EU(TOKENS ? 3 : 5, TO
   // A segment without a single candidate (the inside of a long string, of a backslash run, of whitespace) publishes two zero counts and
   // writes NO masks: k_stage1_emit takes the zeros from the summary (escape_heavy: 0.27 GB of masks written and 0.28 GB read back for 300 000
   // structurals in a GiB -- profiles/r04_pmc_summary.txt -- are gone; ordinary input has no such segments and pays one ballot)
+  // Round 6: a segment with a HANDFUL of candidates (a string boundary between two long backslash runs, the one comma in 16 KiB of text: escape_heavy holds
+  // ~2 structurals per segment and shipped 2 x 2 KiB of planes for them -- 0.14 GB written and 0.15 GB read back per GiB, profiles/r05_pmc_summary.txt) ships
+  // them as a list: one word per candidate in ascending order -- its offset in the segment, bit 31 its string_tail bit -- in the first line of the segment's
+  // plane-0 area.  k_stage1_emit selects by hypothesis and copies.
+  if (sparse) {
+    // per-chunk counts packed into one word (each <= 32: no carry between the 8-bit fields), one scan for the four chunks' exclusive prefixes
+    const u32 packed = u32(popc64(keep0[0])) | (u32(popc64(keep0[1])) << 8) | (u32(popc64(keep0[2])) << 16) | (u32(popc64(keep0[3])) << 24);
+    const u32 incl = wave_incl_scan(packed), tot = readlane(incl, 63), excl = incl - packed;
+    u32 *list = reinterpret_cast<u32 *>(mask0) + size_t(seg) * (SEG_BYTES / BLOCK_BYTES * 2u); // the segment's 2 KiB of plane 0, as words
+    u32 chunk_base = 0;
+#pragma unroll
+    for (u32 c = 0; c < SEG_CHUNKS; c++) {
+      u32 slot = chunk_base + ((excl >> (8u * c)) & 0xFFu);
+      u64 bits = keep0[c];
+      while (bits) { // (a few lanes, a few bits)
+        const u32 b = ctz64(bits);
+        bits &= bits - 1;
+        list[slot++] = (c * CHUNK_BYTES + lane * BLOCK_BYTES + b) | (u32((keep1[c] >> b) & 1ull) << 31);
+      }
+      chunk_base += (tot >> (8u * c)) & 0xFFu;
+    }
+    return;
+  }
   if (__ballot(n_a != 0u)) {
     // in 16-byte units: [segment][chunk pair][lane] -- an instruction of the wave writes (and k_stage1_emit's reads) one contiguous KiB: whole lines
     // (rounds 1-5a: [segment][lane][chunk], 16 bytes of every 32 per instruction: half of every line, twice)
@@ -372,6 +398,10 @@ __global__ __launch_bounds__(64) void k_resolve_groups(const seg_summary *__rest
     gsum[blockIdx.x] = s;
   }
 }
+// (Round 6, measured and not kept: both levels in ONE launch -- every wave folds a group, the workgroup that finds all others done scans the group
+// summaries.  The hand-over needs a release fence behind the group summaries and an acquire fence in front of the scan, and an agent-scope fence on this
+// part writes back and invalidates the XCD's L2, which at that moment holds what k_stage1_summarize has just written: the resolve step went from 12 to
+// 30 us per call, every workload -- profiles/r06_split_ab.txt.)
 
 // carry-in (in-string bit, x, output cursor) of segment `seg`: its group's prefix + the segments in front of
 // it inside the group
@@ -429,6 +459,22 @@ __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask
   const bool resolved = (own.flags & SF_RESOLVED) != 0; // masks are already final
   const bool empty = own.count_if_out == 0u && own.count_if_in == 0u; // no candidate at all: k_stage1_summarize wrote no masks
   if (empty && ((own.xw >> XW_D_SHIFT) & 0xFu) == 0u) { return; }  // ... and no bit a wrong assumption could add: nothing to emit
+  if (own.flags & SF_SPARSE) { // a list of at most SPARSE_MAX candidates instead of planes (k_stage1_summarize): select by hypothesis, copy
+    const u32 ncand = resolved ? own.count_if_out : own.count_if_out + own.count_if_in;
+    const u32 *list = reinterpret_cast<const u32 *>(mask0) + size_t(seg) * (SEG_BYTES / BLOCK_BYTES * 2u);
+    const u32 e = lane < ncand ? list[lane] : 0u; // requested before the prefix fold: one round trip for both
+    const seg_prefix pf = segment_prefix(summ, gpref, seg, lane);
+    const xs_step t = xs_apply(own.flags & SF_PARITY, own.xw, pf.in_string & 1u, pf.in_string >> 1); // (no patched bit: sparse segments have d = 0)
+    const bool keep = lane < ncand && (resolved || (e >> 31) == t.se); // structural = candidate & ~(string_tail ^ hypothesis)
+    const u64 km = __ballot(keep);
+    const u64 at = u64(pf.base) + u32(popc64(km & lanemask_lt(lane)));
+    if (u64(pf.base) + u32(popc64(km)) > idx_words) {
+      if (lane == 0) { atomicOr(&result->flags, SJGPU_F_IDX_OVERFLOW); }
+    } else if (keep) {
+      idx[at] = u32(seg_start) + (e & 0x7FFFFFFFu);
+    }
+    return;
+  }
   u64 m0[SEG_CHUNKS] = {0, 0, 0, 0}, m1[SEG_CHUNKS] = {0, 0, 0, 0};
   if (!empty) {
     const size_t at = size_t(seg) * 128 + lane; // [segment][chunk pair][lane]; chunks beyond len hold zero masks; read once: streamed

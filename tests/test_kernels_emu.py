@@ -54,6 +54,18 @@ def test_the_other_workgroup_shapes_of_the_single_pass_kernels(emu, waves):
     assert "60 documents" in p.stdout.decode() and " 0 mismatches" in p.stdout.decode()
 
 
+@pytest.mark.parametrize("direct", ["1", "2"])
+def test_the_direct_kernel(emu, direct):
+    """Round 6: k_stage1_direct (sjgpu_fused.hip; SJGPU_DIRECT=1 tiles in blockIdx order, =2 by ticket) -- the split pipeline's scan with the look-back and
+    the emission inside it.  Measured slower than both pipelines on the GPU (profiles/r06_direct_ab.txt) and not selected by AUTO; it stays an A/B road,
+    and stays right."""
+    env = dict(os.environ, SJGPU_DIRECT=direct)
+    for seed, docs, kib in (("11", "60", "300"), ("7", "10", "2500")):
+        p = subprocess.run([emu, seed, docs, kib, "fused"], capture_output=True, timeout=900, env=env)
+        assert p.returncode == 0, (p.stdout.decode()[-500:], p.stderr.decode()[-3000:])
+        assert f"{docs} documents" in p.stdout.decode() and " 0 mismatches" in p.stdout.decode()
+
+
 @pytest.mark.parametrize("part", [1, 2, 3, 4])
 def test_the_documents_reach_every_part_of_the_escape_carry(tmp_path, part):
     """The kernels carry the escape state in their scan (sj_xcarry.h: spans that assume, an x word per summary).  With a part of the x
