@@ -509,7 +509,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   constexpr u32 STAGE_WORDS = (OP == 0) ? emit_stage_words(PIPE_WINDOW) : (MINIFY_STAGE_BYTES / 4);
   constexpr u32 WAVE_BYTES = WC * CHUNK_BYTES;
   __shared__ u32 sh_tile[2];                 // [iteration parity]: the ticket of an iteration is drawn one iteration ahead
-  __shared__ u32 sh_wave[2][NW][5]; // [iteration parity][wave]: parity, count_if_out, count_if_in, flags, x word (sj_xcarry.h)
+  __shared__ u32 sh_wave[3][NW][5]; // [iteration mod 3][wave]: parity, count_if_out, count_if_in, flags, x word (sj_xcarry.h); three, so that a wave that is an
+                                    // iteration ahead (there is no barrier at the loop top since round 6) does not write the rows a slower one still reads
   __shared__ u32 sh_agg[2][4];               // tile aggregate of the same two tiles (tq, tout, tin, x word)
   __shared__ u32 sh_prefix[4];               // S, B, ok, X of the tile being emitted
   __shared__ u64 sh_mask_a[NW][WC][64], sh_mask_b[NW][WC][64]; // the pending tile's masks
@@ -535,12 +536,25 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   // waits are on smaller tile numbers; the owner of the smallest unpublished tile is therefore never blocked.
   u32 next_ticket = 0;
   const bool early = (org.carry & CARRY_DEBUG_LATE_TICKET) == 0;
+  // Round 6: TWO barriers per iteration, not three.  The one at the loop top handed over the next ticket and kept a fast wave's next summary row from
+  // landing in the array a slow wave was still reading; the ticket now crosses with the barrier behind wave 0's publication (it is known since the top of
+  // the iteration), the summary rows are triple-buffered, and everything else in LDS is either owned by one wave or written between the two remaining
+  // barriers and read behind the second.  A wave that has emitted starts loading its next span at once -- which pays for minify and costs stage 1 on dense
+  // output 2 % (its waves' emission phases fall out of step): the launcher keeps the third barrier for stage 1 (CARRY_DEBUG_TOP_BARRIER, launch_fused).
+  const bool top_barrier = (org.carry & CARRY_DEBUG_TOP_BARRIER) != 0;
   if (threadIdx.x == 0 && early) { sh_tile[0] = atomicAdd(ticket, 1u); }
+  lds_writes_done();
+  __syncthreads();
   for (u32 iter = 0;; iter++) {
-    const u32 cur = iter & 1u;
+    const u32 cur = iter & 1u, cw = iter % 3u, pw = (iter + 2u) % 3u; // ticket / aggregate slot; summary rows of this iteration's tile and of the pending one
     SJ_PSTAMP(0);
-    if (!early && threadIdx.x == 0) { sh_tile[cur] = atomicAdd(ticket, 1u); }
-    __syncthreads();
+    if (!early) {
+      if (threadIdx.x == 0) { sh_tile[cur] = atomicAdd(ticket, 1u); }
+      lds_writes_done();
+      __syncthreads();
+    } else if (top_barrier) {
+      __syncthreads();
+    }
     const u32 tile = sh_tile[cur];
     const bool have = tile < ntiles;
     const bool pend = pend_tile != NO_TILE;
@@ -616,21 +630,32 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
       if (f_ci) { f |= WF_CTRL_IF_OUT; }
       if (f_co) { f |= WF_CTRL_IF_IN; }
       if (lane == 0) {
-        sh_wave[cur][wave][0] = parity;
-        sh_wave[cur][wave][1] = t_out;
-        sh_wave[cur][wave][2] = t_in;
-        sh_wave[cur][wave][3] = f;
-        sh_wave[cur][wave][4] = xw;
+        sh_wave[cw][wave][0] = parity;
+        sh_wave[cw][wave][1] = t_out;
+        sh_wave[cw][wave][2] = t_in;
+        sh_wave[cw][wave][3] = f;
+        sh_wave[cw][wave][4] = xw;
       }
+    }
+    // Round 6: the pending tile's look-back needs nothing of the tile just scanned -- wave 0 walks the descriptors BEFORE the barrier, while the other
+    // seven waves finish their spans (the phase trace: they arrive 0.9-1.6 us behind wave 0, the walk takes 1.9-2.9), and behind the barrier only
+    // publishes: the aggregate of the new tile, the inclusive prefix of the pending one.  Progress holds: the owner of the SMALLEST tile whose
+    // aggregate is unpublished waits, in this walk, only for tiles smaller than its pending one -- all published -- so it reaches the barrier and publishes.
+    u32 lb_S = 0, lb_X = 0, lb_B = 0;
+    bool lb_ok = false;
+    const bool early_lb = (carry & CARRY_DEBUG_LATE_LOOKBACK) == 0;
+    if (wave == 0 && pend && early_lb) {
+      phase_prio(prio_policy, 1);
+      lb_ok = lookback(desc, pend_tile, lane, lb_S, lb_X, lb_B, org);
     }
     __syncthreads();
     SJ_PSTAMP(3);
 
-    // ---- wave 0: publish the new tile's aggregate, then resolve the PENDING tile's prefix -------------------------
+    // ---- wave 0: publish the new tile's aggregate and the PENDING tile's inclusive prefix -------------------------
     if (wave == 0) {
       phase_prio(prio_policy, 1);
       if (have) {
-        const tile_agg ta = tile_aggregate<NW>(sh_wave[cur]);
+        const tile_agg ta = tile_aggregate<NW>(sh_wave[cw]);
         if (lane == 0) {
           desc_store(desc + tile, make_agg(ta.q, ta.c_out, ta.c_in, ta.xw));
           sh_agg[cur][0] = ta.q;
@@ -641,8 +666,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
       }
       if (pend) {
         const u32 tq = sh_agg[cur ^ 1u][0], tout = sh_agg[cur ^ 1u][1], tin = sh_agg[cur ^ 1u][2], txw = sh_agg[cur ^ 1u][3];
-        u32 S = 0, X = 0, B = 0;
-        const bool ok = lookback(desc, pend_tile, lane, S, X, B, org);
+        u32 S = lb_S, X = lb_X, B = lb_B;
+        const bool ok = early_lb ? lb_ok : lookback(desc, pend_tile, lane, S, X, B, org);
         if (lane == 0) {
           if (ok) {
             const xs_step te = xs_apply(tq, txw, S, X);
@@ -678,8 +703,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
           sh_prefix[3] = X;
         }
       }
+      if (lane == 0 && early) { sh_tile[cur ^ 1u] = have ? next_ticket : NO_TILE; } // the next iteration's ticket crosses with this barrier
       SJ_PSTAMP(4);
     }
+    lds_writes_done();
     __syncthreads();
     SJ_PSTAMP(5);
 
@@ -688,11 +715,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     if (pend && sh_prefix[2] != 0u) {
       const u64 wave_start = org.begin + u64(pend_tile) * TILE_BYTES + u64(wave) * WAVE_BYTES;
       u32 s = sh_prefix[0], x = sh_prefix[3], base = sh_prefix[1];
-      wave_state(sh_wave[cur ^ 1u], wave, s, x, base);
+      wave_state(sh_wave[pw], wave, s, x, base);
       if (wave_start < len) {
-        const u32 pxw = sh_wave[cur ^ 1u][wave][4];
-        const xs_step own = xs_apply(sh_wave[cur ^ 1u][wave][0], pxw, s, x); // which hypothesis holds for my span, and the bit a wrong assumption toggles
-        const u32 f = sh_wave[cur ^ 1u][wave][3];
+        const u32 pxw = sh_wave[pw][wave][4];
+        const xs_step own = xs_apply(sh_wave[pw][wave][0], pxw, s, x); // which hypothesis holds for my span, and the bit a wrong assumption toggles
+        const u32 f = sh_wave[pw][wave][3];
         u32 g = 0;
         if (f & (own.se ? WF_CTRL_IF_IN : WF_CTRL_IF_OUT)) { g |= SJGPU_F_UNESCAPED_CTRL; }
         if (g && lane == 0) { atomicOr(ctl_flags(ticket), g); }
@@ -703,7 +730,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #pragma unroll
           for (u32 c = 0; c < WC; c++) { st[c] = sh_mask_a[wave][c][lane] & ~(sh_mask_b[wave][c][lane] ^ flip); } // zero beyond len
           span_patch(st, pxw, x, own.se, lane);
-          const u32 span_count = (carry & CARRY_DEBUG_NO_SPAN_HINT) ? 0u : xs_count(sh_wave[cur ^ 1u][wave][1], sh_wave[cur ^ 1u][wave][2], own);
+          const u32 span_count = (carry & CARRY_DEBUG_NO_SPAN_HINT) ? 0u : xs_count(sh_wave[pw][wave][1], sh_wave[pw][wave][2], own);
           if constexpr (WC == 4) {
             emit_span4_adaptive<PIPE_WINDOW>(st, u32(wave_start), lane, static_cast<u32 *>(out), out_words, base, sh_stage[wave], overflow, span_count);
           } else { // two chunks: in one piece when they fit the window, else chunk by chunk
@@ -742,7 +769,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
       }
     }
     pend_tile = have ? tile : NO_TILE;
-    if (threadIdx.x == 0 && early) { sh_tile[cur ^ 1u] = have ? next_ticket : NO_TILE; } // visible behind the barrier at the loop top
     lds_writes_done();
     SJ_PSTAMP(7);
   }
@@ -781,7 +807,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
   constexpr u32 TILE_BYTES = NW * WAVE_BYTES;
   const u32 carry = org.carry;
   __shared__ u32 sh_tile[2];
-  __shared__ u32 sh_wave[2][NW][5]; // [iteration parity][wave]: quote parity, kept if out, kept if in, (unused), x word (sj_xcarry.h)
+  __shared__ u32 sh_wave[3][NW][5]; // [iteration mod 3][wave]: quote parity, kept if out, kept if in, (unused), x word (sj_xcarry.h); three: no barrier at the loop top (k_fused_pipelined)
   __shared__ u32 sh_agg[2][4];
   __shared__ u32 sh_prefix[4];
   __shared__ __attribute__((aligned(16))) u8 sh_bytes[NW][WC][ONCHIP_REGION_BYTES];
@@ -793,10 +819,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
   u32 pend_tile = NO_TILE;
   u64 pa0 = 0, pa1 = 0, pb0 = 0, pb1 = 0; // the pending tile's masks: droppable-if-outside-a-string, in-string (relative)
   u32 next_ticket = 0;
+  const bool top_barrier = (org.carry & CARRY_DEBUG_TOP_BARRIER) != 0; // (round 6: two barriers per iteration -- see k_fused_pipelined)
   if (threadIdx.x == 0) { sh_tile[0] = atomicAdd(ticket, 1u); }
+  lds_writes_done();
+  __syncthreads();
   for (u32 iter = 0;; iter++) {
-    const u32 cur = iter & 1u;
-    __syncthreads();
+    const u32 cur = iter & 1u, cw = iter % 3u, pw = (iter + 2u) % 3u;
+    if (top_barrier) { __syncthreads(); }
     const u32 tile = sh_tile[cur];
     const bool have = tile < ntiles;
     const bool pend = pend_tile != NO_TILE;
@@ -848,19 +877,24 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
       }
       const u32 t_out = wave_sum(n_out), t_in = wave_sum(n_in);
       if (lane == 0) {
-        sh_wave[cur][wave][0] = parity;
-        sh_wave[cur][wave][1] = t_out;
-        sh_wave[cur][wave][2] = t_in;
-        sh_wave[cur][wave][3] = 0;
-        sh_wave[cur][wave][4] = xw;
+        sh_wave[cw][wave][0] = parity;
+        sh_wave[cw][wave][1] = t_out;
+        sh_wave[cw][wave][2] = t_in;
+        sh_wave[cw][wave][3] = 0;
+        sh_wave[cw][wave][4] = xw;
       }
     }
+    // (round 6: the pending tile's look-back in front of the barrier, while the other waves finish scanning: k_fused_pipelined)
+    u32 lb_S = 0, lb_X = 0, lb_B = 0;
+    bool lb_ok = false;
+    const bool early_lb = (carry & CARRY_DEBUG_LATE_LOOKBACK) == 0;
+    if (wave == 0 && pend && early_lb) { lb_ok = lookback(desc, pend_tile, lane, lb_S, lb_X, lb_B, org); }
     __syncthreads();
 
-    // ---- wave 0: publish the new tile's aggregate, then resolve the PENDING tile's prefix -------------------------
+    // ---- wave 0: publish the new tile's aggregate and the PENDING tile's inclusive prefix -------------------------
     if (wave == 0) {
       if (have) {
-        const tile_agg ta = tile_aggregate<NW>(sh_wave[cur]);
+        const tile_agg ta = tile_aggregate<NW>(sh_wave[cw]);
         if (lane == 0) {
           desc_store(desc + tile, make_agg(ta.q, ta.c_out, ta.c_in, ta.xw));
           sh_agg[cur][0] = ta.q;
@@ -871,8 +905,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
       }
       if (pend) {
         const u32 tq = sh_agg[cur ^ 1u][0], tout = sh_agg[cur ^ 1u][1], tin = sh_agg[cur ^ 1u][2], txw = sh_agg[cur ^ 1u][3];
-        u32 S = 0, X = 0, B = 0;
-        const bool ok = lookback(desc, pend_tile, lane, S, X, B, org);
+        u32 S = lb_S, X = lb_X, B = lb_B;
+        const bool ok = early_lb ? lb_ok : lookback(desc, pend_tile, lane, S, X, B, org);
         if (lane == 0) {
           if (ok) {
             const xs_step te = xs_apply(tq, txw, S, X);
@@ -894,7 +928,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
           sh_prefix[3] = X;
         }
       }
+      if (lane == 0) { sh_tile[cur ^ 1u] = have ? next_ticket : NO_TILE; } // the next iteration's ticket crosses with this barrier
     }
+    lds_writes_done();
     __syncthreads();
 
     // ---- every wave: compact its two parked chunks of the pending tile ----------------------------------------------
@@ -902,8 +938,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     if (pend && sh_prefix[2] != 0u) {
       const u64 wave_start = org.begin + u64(pend_tile) * TILE_BYTES + u64(wave) * WAVE_BYTES;
       u32 s = sh_prefix[0], x = sh_prefix[3], base = sh_prefix[1];
-      wave_state(sh_wave[cur ^ 1u], wave, s, x, base);
-      const u64 flip = xs_apply(sh_wave[cur ^ 1u][wave][0], sh_wave[cur ^ 1u][wave][4], s, x).se ? ~0ull : 0ull; // the effective hypothesis of my span
+      wave_state(sh_wave[pw], wave, s, x, base);
+      const u64 flip = xs_apply(sh_wave[pw][wave][0], sh_wave[pw][wave][4], s, x).se ? ~0ull : 0ull; // the effective hypothesis of my span
 #pragma unroll
       for (u32 c = 0; c < WC; c++) {
         const u64 cstart = wave_start + u64(c) * CHUNK_BYTES;
@@ -937,8 +973,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     }
     pa0 = a0; pa1 = a1; pb0 = b0; pb1 = b1;
     pend_tile = have ? tile : NO_TILE;
-    if (threadIdx.x == 0) { sh_tile[cur ^ 1u] = have ? next_ticket : NO_TILE; }
-    lds_writes_done(); // see the comment there: the barrier at the loop top must find the ticket in LDS
+    lds_writes_done();
   }
   leave_and_clean<NW * 64>(desc, ntiles, ticket, result);
 }
@@ -1224,6 +1259,14 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
     org.carry |= prio << 24;
     static const bool late_ticket = std::getenv("SJGPU_LATE_TICKET") != nullptr;                                       // A/B switch
     if (late_ticket) { org.carry |= CARRY_DEBUG_LATE_TICKET; }
+    // The barrier at the top of the pipelined kernels' loop (rounds 1-5 needed it; since round 6 the kernels are correct without).  Measured with and
+    // without, one process (profiles/r06_pipelined_ab.txt): minify 467 -> 456 us per GiB without it (a wave that has compacted its chunks starts loading at
+    // once), stage 1 on dense output 471 -> 480 WITH it gone (its emission phases fall out of step), sparse output 331 -> 329.  So: stage 1 keeps it,
+    // minify does not; env SJGPU_TOP_BARRIER=0 / 1 forces either.
+    static const int top_barrier_env = []() { const char *v = std::getenv("SJGPU_TOP_BARRIER"); return v ? (v[0] != '0' ? 1 : 0) : -1; }();
+    if (top_barrier_env >= 0 ? top_barrier_env == 1 : op == 0) { org.carry |= CARRY_DEBUG_TOP_BARRIER; }
+    static const bool late_lookback = std::getenv("SJGPU_LATE_LOOKBACK") != nullptr; // A/B switch: the look-back behind the scan's barrier (rounds 1-5)
+    if (late_lookback) { org.carry |= CARRY_DEBUG_LATE_LOOKBACK; }
     static const bool no_hint = std::getenv("SJGPU_NO_SPAN_HINT") != nullptr; // A/B switch
     if (no_hint) { org.carry |= CARRY_DEBUG_NO_SPAN_HINT; }
     static const bool queue_only = std::getenv("SJGPU_UTF8_QUEUE_ONLY") != nullptr; // A/B switch

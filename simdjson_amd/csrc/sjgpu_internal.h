@@ -87,6 +87,8 @@ constexpr uint32_t CARRY_MORE = 4u;      // the scan does not end at the end of 
 constexpr uint32_t CARRY_X = 8u;         // x in front of the first span (sj_xcarry.h): SJGPU_F_RANGE_CARRY of the range in front
 constexpr uint32_t CARRY_DEBUG_LATE_TICKET = 0x100u; // A/B switch of the pipelined kernel (env SJGPU_LATE_TICKET)
 constexpr uint32_t CARRY_DEBUG_NO_SPAN_HINT = 0x200u; // A/B switch: emission counts the span itself (env SJGPU_NO_SPAN_HINT)
+constexpr uint32_t CARRY_DEBUG_LATE_LOOKBACK = 0x800u; // A/B switch of the pipelined kernels: the pending tile's look-back BEHIND the scan's barrier, as in rounds 1-5 (env SJGPU_LATE_LOOKBACK)
+constexpr uint32_t CARRY_DEBUG_TOP_BARRIER = 0x1000u;  // A/B switch of the pipelined kernels: the third barrier, at the loop top, as in rounds 1-5 (env SJGPU_TOP_BARRIER)
 constexpr uint32_t CARRY_DEBUG_QUEUE_UTF8 = 0x400u;   // A/B switch: dense non-ASCII chunks are queued like sparse ones (env SJGPU_UTF8_QUEUE_ONLY)
 // A scan covers bytes [begin, len) of a buffer whose bytes [0, begin) are resident too (the look-back of escapes,
 // previous scalar and UTF-8 state reads them); begin is a multiple of RANGE_ALIGN.  Offsets stay relative to byte 0
