@@ -59,18 +59,80 @@ static inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 constexpr unsigned hipHostMallocDefault = 0;
 namespace sj_emu { extern size_t fail_allocations_above; } // test hook: hipMalloc of more bytes than this fails (default: never)
+#ifdef SJ_EMU_DEVICES
+namespace sj_emu { int &current_device(); void note_alloc(const void *p, size_t n, int device); }
+#endif
 static inline hipError_t hipMalloc(void **p, size_t n) {
   if (n > sj_emu::fail_allocations_above) { *p = nullptr; return hipErrorOutOfMemory; }
   *p = std::malloc(n ? n : 1);
+#ifdef SJ_EMU_DEVICES
+  if (*p) { sj_emu::note_alloc(*p, n ? n : 1, sj_emu::current_device()); }
+#endif
   return *p ? hipSuccess : hipErrorOutOfMemory;
 }
+#ifndef SJ_EMU_DEVICES
 static inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
+#endif
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
+#ifndef SJ_EMU_DEVICES
 static inline hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(dst, src, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+#else
+// ---- SEVERAL fake devices (-DSJ_EMU_DEVICES=N; tests/host/test_mgpu_emu.cpp: sjgpu_mgpu.hip with distinct devices on a box that has none) ----
+// What a one-GPU box cannot show: code that allocates, copies or launches while ANOTHER device is current.  Here every thread has a current device
+// (hipSetDevice), every allocation and every stream belongs to the device that was current when it was made, and every call that names a stream or a
+// device pointer checks that it is used under its own device -- a violation is counted (sj_emu::device_violations) and described on stderr, the call
+// still happens.  Memory is the host's, a stream is the calling thread.
+namespace sj_emu {
+int &current_device();                                  // of the calling thread; starts at 0, like HIP's
+void note_alloc(const void *p, size_t n, int device);
+void drop_alloc(const void *p);
+int device_of(const void *p);                           // -1: not device memory (host memory)
+void device_violation(const char *what, int expected, int current);
+extern int device_violations;
+struct stream_rec { int device; };
+} // namespace sj_emu
+constexpr unsigned hipStreamNonBlocking = 1;
+static inline hipError_t hipSetDevice(int d) {
+  if (d < 0 || d >= SJ_EMU_DEVICES) { return hipErrorUnknown; }
+  sj_emu::current_device() = d;
+  return hipSuccess;
+}
+static inline hipError_t hipGetDevice(int *d) { *d = sj_emu::current_device(); return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = SJ_EMU_DEVICES; return hipSuccess; }
+static inline hipError_t hipFree(void *p) {
+  if (p) {
+    const int d = sj_emu::device_of(p);
+    if (d != sj_emu::current_device()) { sj_emu::device_violation("hipFree of another device's memory", d, sj_emu::current_device()); }
+    sj_emu::drop_alloc(p);
+  }
+  std::free(p);
+  return hipSuccess;
+}
+static inline void sj_emu_check_stream(hipStream_t s, const char *what) {
+  const int d = s ? static_cast<sj_emu::stream_rec *>(s)->device : 0; // the null stream belongs to device 0's thread in these tests
+  if (d != sj_emu::current_device()) { sj_emu::device_violation(what, d, sj_emu::current_device()); }
+}
+static inline void sj_emu_check_ptr(const void *p, const char *what) {
+  const int d = sj_emu::device_of(p);
+  if (d >= 0 && d != sj_emu::current_device()) { sj_emu::device_violation(what, d, sj_emu::current_device()); }
+}
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new sj_emu::stream_rec{sj_emu::current_device()}; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { sj_emu_check_stream(s, "hipStreamDestroy under another device"); delete static_cast<sj_emu::stream_rec *>(s); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t s) { sj_emu_check_stream(s, "hipStreamSynchronize under another device"); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind kind, hipStream_t s) {
+  sj_emu_check_stream(s, "hipMemcpyAsync on another device's stream");
+  sj_emu_check_ptr(dst, "hipMemcpyAsync into another device's memory");
+  sj_emu_check_ptr(src, "hipMemcpyAsync from another device's memory");
+  if (kind == hipMemcpyHostToDevice && (sj_emu::device_of(dst) < 0 || sj_emu::device_of(src) >= 0)) { sj_emu::device_violation("hipMemcpyHostToDevice: wrong kinds of memory", -1, -1); }
+  if (kind == hipMemcpyDeviceToHost && (sj_emu::device_of(src) < 0 || sj_emu::device_of(dst) >= 0)) { sj_emu::device_violation("hipMemcpyDeviceToHost: wrong kinds of memory", -1, -1); }
+  std::memcpy(dst, src, n);
+  return hipSuccess;
+}
+#endif
 
 namespace sj_emu {
 struct fiber_ids { dim3 tid; unsigned lane, wave; };
@@ -89,7 +151,11 @@ extern unsigned max_concurrent_workgroups; // OS threads per launch (default 4)
 #define threadIdx (::sj_emu::ids().tid)
 #define blockIdx (::sj_emu::block_idx())
 #define gridDim (::sj_emu::grid_dim())
+#ifndef SJ_EMU_DEVICES
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) ::sj_emu::launch((grid), (block), [=]() { kern(__VA_ARGS__); })
+#else
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) (sj_emu_check_stream((stream), "kernel launch on another device's stream"), ::sj_emu::launch((grid), (block), [=]() { kern(__VA_ARGS__); }))
+#endif
 
 using std::max;
 using std::min;

@@ -285,6 +285,10 @@ pool_t pool;
 
 void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
   if (grid.x == 0) { return; }
+  // one launch at a time: the pool is one set of workgroup threads (host threads that launch concurrently -- sjgpu_mgpu.hip's shard threads under
+  // tests/host/test_mgpu_emu.cpp -- take turns, as kernels of different streams may on a device)
+  static std::mutex one_launch;
+  std::lock_guard<std::mutex> lk(one_launch);
   pool.run(grid, block, body, std::min(grid.x, std::max(1u, max_concurrent_workgroups)));
 }
 

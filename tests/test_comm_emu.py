@@ -54,3 +54,34 @@ def test_without_the_library_the_entry_points_say_so(built):
     if p.returncode == 0:
         pytest.skip("a real librccl is on the loader's path of this box: the fallback search found it")
     assert p.returncode == 2 and b"sjgpu_comm_unique_id failed" in p.stderr
+
+
+def test_the_stand_in_exports_what_the_product_binds_and_the_real_library_has_it():
+    """the loop-back library must not drift from RCCL.  Three facts, no GPU needed: (1) the entry points sjgpu_comm.hip binds with dlsym
+    (its SJ_SYM list) are EXACTLY the nccl* symbols the stand-in exports -- one more or one less on either side fails; (2) each of them is exported by the
+    real librccl of this image; (3) their SIGNATURES agree with the real header: the stand-in is compiled by hipcc against <rccl/rccl.h> itself
+    (build.build_rccl_loopback), where a definition that disagrees with the header's extern "C" prototype is a compile error -- rebuilt here from scratch
+    so that the claim is checked, not inherited from a prebuilt file."""
+    import re
+    import shutil
+    import subprocess
+    from simdjson_amd import _paths, build
+    src = open(os.path.join(_paths.CSRC_DIR, "sjgpu_comm.hip")).read()
+    bound = set(re.findall(r'SJ_SYM\(\w+, "(nccl\w+)"\)', src))
+    assert len(bound) == 10 and {"ncclSend", "ncclRecv", "ncclAllGather", "ncclGroupStart", "ncclGroupEnd", "ncclCommInitRank"} <= bound, bound
+    # every binding's type comes from the header too: decltype(&ncclX) in struct rccl_api
+    assert set(re.findall(r"decltype\(&(nccl\w+)\)", src)) == bound
+
+    def exported(lib):
+        out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, check=True).stdout.decode()
+        return {l.split()[-1].split("@")[0] for l in out.splitlines() if l.split() and l.split()[-1].startswith("nccl")}
+    if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+        lib = build.build_rccl_loopback(force=True)  # against the real <rccl/rccl.h>: signature drift does not compile
+    else:
+        lib = build.LIB_LOOPBACK_HIP
+    assert os.path.exists(lib)
+    assert exported(lib) == bound, (sorted(exported(lib) ^ bound))
+    real = next((p for p in ("/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so") if os.path.exists(p)), None)
+    if real is None:
+        pytest.skip("no librccl in this image")
+    assert bound <= exported(real), sorted(bound - exported(real))
