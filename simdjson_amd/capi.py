@@ -279,7 +279,7 @@ class DomParserImplementation:
         return rc
 
     def stage1_tokens_device(self, buf_ptr, length, idx_ptr, idx_words, tok_ptr, tok_bytes, stream=0):
-        """sjgpu_stage1_tokens_device: stage1_device + tok[i] = buf[idx[i]] beside the offsets (split pipeline)"""
+        """sjgpu_stage1_tokens_device: stage1_device + tok[i] = buf[idx[i]] beside the offsets (either pipeline; AUTO: the split one beyond the small-input limit)"""
         rc = self.L.sjgpu_stage1_tokens_device(self.h, buf_ptr, int(length), idx_ptr, int(idx_words), tok_ptr, int(tok_bytes), stream or None)
         if rc < 0:
             raise SjgpuError(f"sjgpu_stage1_tokens_device error {rc}: {self.last_error()}")

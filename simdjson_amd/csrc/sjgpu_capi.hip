@@ -368,19 +368,25 @@ bool use_fused(const sjgpu_ctx *ctx, size_t len, int op = 1) { // op 0: stage 1,
   return len >= (ctx->density_permille >= AUTO_DENSE_PERMILLE ? AUTO_FUSED_FROM : AUTO_FUSED_FROM_SPARSE);
 }
 
+// sjgpu_stage1_tokens_device: pipeline 0 / 1 as the caller set it; AUTO: the small-input kernel up to its limit (one launch), the split pipeline beyond
+bool tokens_fused(const sjgpu_ctx *ctx, size_t len) {
+  if (ctx->pipeline != 2) { return ctx->pipeline == 1; }
+  return len <= AUTO_FUSED_BELOW;
+}
+
 // `len` is the END of the scan (bytes [org.begin, len) are scanned); a whole document has org = {0, 0, 0}
-// tok: the token-byte stream beside the offsets (split pipeline only: the caller passes fused = false)
+// tok: the token-byte stream beside the offsets (split pipeline: staged by the scan kernel, copied by the emission kernel; single-pass: gathered at emission)
 void enqueue_stage1(sjgpu_ctx *ctx, bool fused, const uint8_t *buf, size_t len, uint32_t *idx, size_t idx_words, hipStream_t s,
                     hipEvent_t *ev, scan_origin org = scan_origin{0, 0, 0}, uint8_t *tok = nullptr) {
   ctx->enqueue_rc = ensure_scan_workspace(ctx, len - org.begin, !fused);
-  if (!ctx->enqueue_rc && tok) { ctx->enqueue_rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_tokstage), &ctx->d_tokstage_bytes, size_t(num_segments(grown(len - org.begin))) * SEG_BYTES + 64); }
+  if (!ctx->enqueue_rc && tok && !fused) { ctx->enqueue_rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_tokstage), &ctx->d_tokstage_bytes, size_t(num_segments(grown(len - org.begin))) * SEG_BYTES + 64); }
   if (ctx->enqueue_rc) { return; }
   ctx->last_pipeline = fused ? 1 : 0;
   // the density AUTO decides by is taken from every whole-document scan beyond the small-input kernels' range (round 4 sampled only scans of
   // 224 MiB and more: a context that had once seen sparse output stayed on the split pipeline until another scan of that size measured dense)
   ctx->pending_scan_bytes = (org.begin == 0 && org.base0 == 0 && len > AUTO_FUSED_BELOW) ? len : 0;
   if (fused) {
-    ctx->last_kernel = launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, org, ctx->max_workgroups, s, ev, !ctx->ws_dirty);
+    ctx->last_kernel = launch_stage1_fused(buf, len, ctx->desc, idx, idx_words, ctx->d_result, org, ctx->max_workgroups, s, ev, !ctx->ws_dirty, tok);
     ctx->ws_dirty = false; // (a dirty workspace was cleared in front of the kernel: clear_fused_workspace)
   }
   else {
@@ -785,7 +791,9 @@ int sjgpu_stage1_tokens_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
   if (len > ctx->capacity) { return E_CAPACITY; }
   if (len == 0) { return E_EMPTY; }
   SJ_TRY(ctx, hipSetDevice(ctx->device));
-  enqueue_stage1(ctx, false, static_cast<const uint8_t *>(buf_dev), len, static_cast<uint32_t *>(idx_dev), idx_words, pick(ctx, stream), next_events(ctx),
+  // Which road: the split pipeline stages the structural bytes while it holds them (costs its scan kernel a compaction per chunk), the single-pass kernels
+  // gather them out of the document when they emit (costs a second trip of the tile's lines).  Measured (profiles/r06_tokens_fused.txt): see tokens_fused().
+  enqueue_stage1(ctx, tokens_fused(ctx, len), static_cast<const uint8_t *>(buf_dev), len, static_cast<uint32_t *>(idx_dev), idx_words, pick(ctx, stream), next_events(ctx),
                  scan_origin{0, 0, 0}, static_cast<uint8_t *>(tok_dev));
   SJ_ENQUEUED(ctx);
   return 0;

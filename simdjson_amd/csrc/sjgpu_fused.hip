@@ -243,6 +243,21 @@ __device__ __forceinline__ void wave_state(const u32 (*wv)[5], u32 wave, u32 &s,
   }
 }
 
+// TOKENS (round 6, sjgpu_stage1_tokens_device on the single-pass road): tok[i] = buf[idx[i]] for the offsets a wave has just written, idx[from .. to).  The
+// wave reads its own stores back once they have been acknowledged (no fence: an agent-scope fence writes back and invalidates the XCD's L2 -- leave_and_clean)
+// and gathers the bytes out of the document -- the road k_stage1_emit<true> takes for segments that staged nothing.  The tile was read an iteration ago; its
+// lines come back from wherever they still are (the Infinity Cache, mostly): what that costs is measured, not assumed (profiles/r06_tokens_fused.txt).
+__device__ __forceinline__ void gather_tokens(const u8 *__restrict__ buf, u64 len, const u32 *idx, u8 *__restrict__ tok, u32 from, u32 to, u32 lane) {
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const volatile u32 *back = idx;
+#pragma unroll 1
+  for (u32 i = from + lane; i < to; i += 64) {
+    const u32 p = back[i];
+    tok[i] = u64(p) < len ? buf[p] : u8(0x20);
+  }
+}
+
 // what a wave tells its workgroup about its 16 KiB span (UTF-8 verdicts go straight to the result: utf8_queue)
 constexpr u32 WF_CTRL_IF_OUT = 1u, WF_CTRL_IF_IN = 2u;
 
@@ -252,11 +267,11 @@ constexpr u32 WF_CTRL_IF_OUT = 1u, WF_CTRL_IF_IN = 2u;
 constexpr u32 TRACE_STAMPS = 8;
 // WC = chunks per wave: 4 (64 KiB tiles) for throughput, 1 (16 KiB tiles) for small inputs, where the serial
 // latency of one tile (WC loads + scans, then WC emits) is the whole call.
-template <int OP, bool TRACE, u32 WC>
+template <int OP, bool TRACE, u32 WC, bool TOKENS = false>
 __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc,
                                                u32 *__restrict__ ticket, u32 ntiles, void *__restrict__ out, u64 out_words,
                                                scan_result_dev *__restrict__ result, u64 *__restrict__ trace, u32 trace_tiles,
-                                               scan_origin org) {
+                                               scan_origin org, u8 *__restrict__ tok = nullptr) {
   const u32 carry = org.carry;
 #define SJ_STAMP(k) do { if (TRACE && threadIdx.x == 0 && tile < trace_tiles) { trace[u64(tile) * TRACE_STAMPS + (k)] = wall_clock64(); } } while (0)
   constexpr u32 STAGE_WORDS = (OP == 0) ? EMIT_STAGE_WORDS : (MINIFY_STAGE_BYTES / 4);
@@ -420,6 +435,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
     const bool patch = OP == 0 && x != 0u && own.dcount != 0; // wave-uniform
     const u32 patch_at = xw_patch_pos(xw);
     bool overflow = false;
+    const u32 base_before = base;
 #pragma unroll 1
     for (u32 c = 0; c < FUSED_WAVE_CHUNKS; c++) {
       // oldest chunk first: after WC pushes chunk c sits in slot WC-1-c
@@ -443,6 +459,7 @@ __global__ __launch_bounds__(256) void k_fused(const u8 *__restrict__ buf, u64 l
       }
     }
     if (OP == 0 && __ballot(overflow) && lane == 0) { atomicOr(ctl_flags(ticket), SJGPU_F_IDX_OVERFLOW); }
+    if (OP == 0 && TOKENS && !__ballot(overflow)) { gather_tokens(buf, len, static_cast<const u32 *>(out), tok, base_before, base, lane); }
     SJ_STAMP(6); // wave 0 finished emitting
   }
   if (OP == 0) { // what is left of the wave's UTF-8 list, then its verdict
@@ -496,11 +513,11 @@ __device__ __forceinline__ void phase_prio(u32 policy, u32 phase /* 0 scan, 1 lo
 // each --, twice the descriptors, look-backs and barriers per byte; A/B: env SJGPU_PIPE_WC)
 // NW: waves per workgroup: 4, or 8 (128 KiB tiles at the same wave count per CU: half the tickets, look-backs and descriptors per byte, two workgroups per
 // CU instead of four to hide them behind; A/B: env SJGPU_PIPE_WAVES)
-template <int OP, bool TRACE = false, u32 PWC = FUSED_WAVE_CHUNKS, u32 NW = FUSED_WAVES>
+template <int OP, bool TRACE = false, u32 PWC = FUSED_WAVE_CHUNKS, u32 NW = FUSED_WAVES, bool TOKENS = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fused_pipelined(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc,
                                                          u32 *__restrict__ ticket, u32 ntiles, void *__restrict__ out,
                                                          u64 out_words, scan_result_dev *__restrict__ result, scan_origin org,
-                                                         u64 *__restrict__ trace = nullptr) {
+                                                         u64 *__restrict__ trace = nullptr, u8 *__restrict__ tok = nullptr) {
 #define SJ_PSTAMP(k) do { if (TRACE && threadIdx.x == 0 && iter < PIPE_TRACE_ITERS) { trace[(u64(blockIdx.x) * PIPE_TRACE_ITERS + iter) * TRACE_STAMPS + (k)] = wall_clock64(); } } while (0)
   const u32 carry = org.carry;
   constexpr u32 WC = PWC;
@@ -725,6 +742,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         if (g && lane == 0) { atomicOr(ctl_flags(ticket), g); }
         const u64 flip = own.se ? ~0ull : 0ull;
         bool overflow = false;
+        const u32 base_before = base;
         if (OP == 0) { // sparse spans leave in one piece, medium ones as two pairs of chunks, dense ones chunk by chunk
           u64 st[WC];
 #pragma unroll
@@ -753,6 +771,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
           }
         }
         if (OP == 0 && __ballot(overflow) && lane == 0) { atomicOr(ctl_flags(ticket), SJGPU_F_IDX_OVERFLOW); }
+        if (OP == 0 && TOKENS && !__ballot(overflow)) { gather_tokens(buf, len, static_cast<const u32 *>(out), tok, base_before, base, lane); }
       }
     }
     SJ_PSTAMP(6);
@@ -1199,7 +1218,7 @@ static void clear_fused_workspace(scan_result_dev *result, uint64_t *desc, u32 n
 template <u32 WC>
 static void launch_fused_wc(int op, const uint8_t *buf, uint64_t len, uint64_t *desc, void *out, uint64_t out_words,
                             scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
-                            hipEvent_t *ev, uint64_t *trace, uint32_t trace_tiles, bool clean) {
+                            hipEvent_t *ev, uint64_t *trace, uint32_t trace_tiles, bool clean, uint8_t *tok = nullptr) {
   constexpr u64 tile_bytes = u64(FUSED_WAVES) * WC * CHUNK_BYTES;
   const u32 ntiles = u32((len - org.begin + tile_bytes - 1) / tile_bytes);
   u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles);
@@ -1208,13 +1227,16 @@ static void launch_fused_wc(int op, const uint8_t *buf, uint64_t len, uint64_t *
   u64 *no_trace = nullptr;
   if (trace) {
     hipLaunchKernelGGL((k_fused<0, true, WC>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words,
-                       result, trace, trace_tiles, org);
+                       result, trace, trace_tiles, org, static_cast<u8 *>(nullptr));
+  } else if (op == 0 && tok) {
+    hipLaunchKernelGGL((k_fused<0, false, WC, true>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words,
+                       result, no_trace, 0u, org, tok);
   } else if (op == 0) {
     hipLaunchKernelGGL((k_fused<0, false, WC>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words,
-                       result, no_trace, 0u, org);
+                       result, no_trace, 0u, org, static_cast<u8 *>(nullptr));
   } else {
     hipLaunchKernelGGL((k_fused<1, false, WC>), dim3(grid), dim3(256), 0, stream, buf, len, desc, ticket, ntiles, out, out_words,
-                       result, no_trace, 0u, org);
+                       result, no_trace, 0u, org, static_cast<u8 *>(nullptr));
   }
   mark(ev, 1, stream); // (a single kernel: slots 1 and 2 stay unrecorded; sjgpu_profile_read reports them as 0)
 }
@@ -1225,13 +1247,13 @@ uint64_t debug_fused_small_below = FUSED_SMALL_BELOW;
 // returns the name of the scan kernel it launched (sjgpu_profile_kernel)
 static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *desc, void *out, uint64_t out_words,
                                 scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
-                                hipEvent_t *ev, uint64_t *trace = nullptr, uint32_t trace_tiles = 0, bool clean = false) {
+                                hipEvent_t *ev, uint64_t *trace = nullptr, uint32_t trace_tiles = 0, bool clean = false, uint8_t *tok = nullptr) {
   static const bool plain = std::getenv("SJGPU_FUSED_PLAIN") != nullptr; // A/B switch: the non-pipelined large-input kernel
   mark(ev, 0, stream); // slot 0 = everything this call enqueues (the clear, the scan kernel)
   if (len - org.begin <= debug_fused_small_below && !trace) {
-    launch_fused_wc<1>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles, clean);
-    return op == 0 ? "k_fused<0> (16 KiB tiles)" : "k_fused<1> (16 KiB tiles)";
-  } else if (trace || plain) {
+    launch_fused_wc<1>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles, clean, tok);
+    return op == 0 ? (tok ? "k_fused<0, tokens> (16 KiB tiles)" : "k_fused<0> (16 KiB tiles)") : "k_fused<1> (16 KiB tiles)";
+  } else if (trace || (plain && !tok)) {
     launch_fused_wc<FUSED_WAVE_CHUNKS>(op, buf, len, desc, out, out_words, result, org, max_workgroups, stream, ev, trace, trace_tiles, clean);
     return op == 0 ? "k_fused<0> (64 KiB tiles)" : "k_fused<1> (64 KiB tiles)";
   } else {
@@ -1246,7 +1268,7 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
     // without), a third of a 64 KiB tile's time at 4.5 TB/s; twice the tile at the same number of waves per CU halves it: 520 -> 466-478 us per GiB of
     // large_random, 173 -> 153-157 us per 256 MiB (profiles/r04_pipe_waves_ab.txt; SJGPU_PIPE_WAVES=4 brings the round-1 shape back).
     static const unsigned pipe_waves = []() { const char *v = std::getenv("SJGPU_PIPE_WAVES"); return v && std::atoi(v) == 4 ? 4u : 8u; }();
-    const u32 s1_waves = (op == 0 && !trace) ? pipe_waves : FUSED_WAVES;
+    const u32 s1_waves = (op == 0 && !trace) ? (tok ? 8u : pipe_waves) : FUSED_WAVES;
     const u64 tile_bytes = onchip_waves ? u64(onchip_waves) * ONCHIP_WAVE_CHUNKS * CHUNK_BYTES : u64(s1_waves) * FUSED_WAVE_CHUNKS * CHUNK_BYTES;
     const u32 ntiles = u32((len - org.begin + tile_bytes - 1) / tile_bytes);
     u32 *ticket = reinterpret_cast<u32 *>(desc + ntiles);
@@ -1285,6 +1307,13 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
       return onchip_waves == 8u ? "k_minify_onchip<8>" : (onchip_waves == 16u ? "k_minify_onchip<16>" : "k_minify_onchip<4>");
     }
     // round 6: the one-pass kernel derived from the split pipeline's scan (k_stage1_direct); env SJGPU_DIRECT: 0 off, 1 blockIdx order, 2 tickets
+    if (op == 0 && tok) { // the token stream: the default shape only (no A/B shapes)
+      const u32 resident8 = max_workgroups >= 2u ? max_workgroups / 2u : 1u;
+      hipLaunchKernelGGL((k_fused_pipelined<0, false, FUSED_WAVE_CHUNKS, 8, true>), dim3(cap < resident8 ? cap : resident8), dim3(512), 0, stream, buf, len, desc, ticket, ntiles, out,
+                         out_words, result, org, static_cast<u64 *>(nullptr), tok);
+      mark(ev, 1, stream);
+      return "k_fused_pipelined<0, tokens> (8 waves, 128 KiB tiles)";
+    }
     static const unsigned direct = []() { const char *v = std::getenv("SJGPU_DIRECT"); return v ? unsigned(std::atoi(v)) : 0u; }();
     if (op == 0 && direct != 0u) {
       const u32 nt = u32((len - org.begin + DIRECT_TILE_BYTES - 1) / DIRECT_TILE_BYTES);
@@ -1324,8 +1353,8 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
 }
 
 const char *launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
-                                scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev, bool clean) {
-  return launch_fused(0, buf, len, desc, idx, idx_words, result, org, max_workgroups, stream, ev, nullptr, 0, clean);
+                                scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev, bool clean, uint8_t *tok) {
+  return launch_fused(0, buf, len, desc, idx, idx_words, result, org, max_workgroups, stream, ev, nullptr, 0, clean, tok);
 }
 // one traced run of the pipelined stage-1 kernel; trace holds *grid_out x PIPE_TRACE_ITERS x 8 stamps (zero = not reached)
 uint32_t launch_stage1_pipelined_traced(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,

@@ -123,7 +123,7 @@ void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *res
 constexpr uint32_t FUSED_WORKSPACE_EXTRA_WORDS = 2; // control words: ticket, workgroups gone, flags
 const char *launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
                                 scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
-                                hipEvent_t *ev, bool clean = false); // -> name of the scan kernel launched
+                                hipEvent_t *ev, bool clean = false, uint8_t *tok = nullptr); // tok: the token-byte stream beside the offsets (round 6: gathered at emission) // -> name of the scan kernel launched
 void launch_stage1_fused_traced(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
                                 scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, uint64_t *trace,
                                 uint32_t trace_tiles); // 8 wall_clock64 stamps (100 MHz) per tile

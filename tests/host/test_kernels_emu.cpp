@@ -344,6 +344,13 @@ int main(int argc, char **argv) {
         launch_stage1_fused(w.in, len, w.desc(), w.idx.data(), len + 3, w.result(), org, 6, nullptr, nullptr, true);
         check_stage1(large ? "pipelined stage 1" : "fused stage 1 (16 KiB tiles)", doc, e, w);
         check_workspace_clean(w, doc, large ? "pipelined stage 1" : "fused stage 1 (16 KiB tiles)");
+        std::fill(w.idx.begin(), w.idx.begin() + len + 8, 0xDEADBEEFu); // the same scan with the token stream beside the offsets (round 6: gathered at emission)
+        std::fill(w.tok.begin(), w.tok.begin() + len + 8, uint8_t(0xEE));
+        *w.result() = scan_result_dev{0xDEADBEEFu, 0xFFFFFFFFu, ~0ull};
+        launch_stage1_fused(w.in, len, w.desc(), w.idx.data(), len + 3, w.result(), org, 6, nullptr, nullptr, true, w.tok.data());
+        check_stage1(large ? "pipelined stage 1 with tokens" : "fused stage 1 with tokens", doc, e, w);
+        check_tokens(large ? "pipelined stage 1 with tokens" : "fused stage 1 with tokens", doc, e, w);
+        check_workspace_clean(w, doc, large ? "pipelined stage 1 with tokens" : "fused stage 1 with tokens");
         *w.result() = scan_result_dev{0xDEADBEEFu, 0xFFFFFFFFu, ~0ull};
         launch_minify_fused(w.in, len, w.desc(), w.out.data(), w.result(), org, 6, nullptr, nullptr, true);
         check_minify(large ? "on-chip minify" : "fused minify (16 KiB tiles)", doc, e, w);

@@ -565,8 +565,10 @@ def _minified(a):
     return np.frombuffer(json.dumps(json.loads(bytes(a)), separators=(",", ":"), ensure_ascii=False).encode(), np.uint8)
 
 
-def test_token_stream_beside_the_offsets(orc):
-    """sjgpu_stage1_tokens_device (round 5): the bytes under the structurals leave stage 1 WITH the offsets -- tok[i] = buf[idx[i]] -- and a list pass reads
+@pytest.mark.parametrize("road", ["split", "fused", "auto"])
+def test_token_stream_beside_the_offsets(orc, road):
+    """(round 6: on BOTH roads -- the split pipeline stages the bytes in its scan kernel, the single-pass kernels gather them when they emit -- and under AUTO.)
+    sjgpu_stage1_tokens_device (round 5): the bytes under the structurals leave stage 1 WITH the offsets -- tok[i] = buf[idx[i]] -- and a list pass reads
     one coalesced byte per entry instead of gathering it out of the document (the reference's consumers dereference the list the same way:
     src/generic/stage2/json_iterator.h:246-288, find_next_document_index.h:39-98).  Same list, same flags as sjgpu_stage1_device; the stream checked
     byte for byte against the document; the depth scan from the stream equal to the depth scan that gathers.  The documents take both roads of
@@ -592,7 +594,10 @@ def test_token_stream_beside_the_offsets(orc):
         p.set_pipeline("split")
         assert p.stage1_device(buf.data_ptr(), L, idx.data_ptr(), L + 3, stream) == 0
         n, flags, _ = p.result(stream)
+        p.set_pipeline(road)
         assert p.stage1_tokens_device(buf.data_ptr(), L, idx2.data_ptr(), L + 3, tok.data_ptr(), L + 16, stream) == 0
+        if road != "auto":
+            assert p.last_pipeline() == road, (name, p.last_pipeline())
         n2, flags2, _ = p.result(stream)
         assert (n2, flags2) == (n, flags), (name, n, n2, flags, flags2)
         if flags & capi.F_UNESCAPED_CTRL:
@@ -611,8 +616,9 @@ def test_token_stream_beside_the_offsets(orc):
     p.close()
 
 
-def test_token_stream_at_full_size(orc):
-    """BASELINE configs[3]'s shard (1 GiB of amazon NDJSON) and configs[1] (1 GiB large_random) with the token stream: the list equal to the plain call's,
+@pytest.mark.parametrize("road", ["split", "fused"])
+def test_token_stream_at_full_size(orc, road):
+    """(round 6: both roads.)  BASELINE configs[3]'s shard (1 GiB of amazon NDJSON) and configs[1] (1 GiB large_random) with the token stream: the list equal to the plain call's,
     every token byte equal to the byte of the document under its offset (checked on the device: a gather the test does once)."""
     import torch
     stream = torch.cuda.current_stream().cuda_stream
@@ -623,9 +629,10 @@ def test_token_stream_at_full_size(orc):
         buf = torch.from_numpy(a).cuda()
         idx = torch.empty(L // 2 + 16, dtype=torch.int32, device="cuda")
         tok = torch.empty(L // 2 + 16, dtype=torch.uint8, device="cuda")
+        p.set_pipeline(road)
         assert p.stage1_tokens_device(buf.data_ptr(), L, idx.data_ptr(), L // 2, tok.data_ptr(), L // 2 + 16, stream) == 0
         n, flags, _ = p.result(stream)
-        assert flags == 0 and n > 1000
+        assert flags == 0 and n > 1000 and p.last_pipeline() == road
         assert torch.equal(tok[:n], buf[idx[:n].to(torch.int64)]), kind
         # ... and against the ORACLE, not only against the library's own plain call: the list's digest, and the token bytes as the oracle's list selects them
         oerr, on, oidx = orc.stage1(a, 0)
