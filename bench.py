@@ -318,7 +318,7 @@ def device_leg(cx, op, workload, host, units, steps, warmup, pipeline, fence=Non
                      "kernel_ms_slots": [round(m / max(calls, 1), 4) for m in ms_sum],
                      "traffic": cx.traffic.get(tkey), "traffic_static_from_profiles": cx.traffic.get(tkey), "traffic_measured_in_this_run": False,
                      "traffic_source": "STATIC: read from profiles/traffic.json, not measured by this run -- rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this "
-                     "command in separate counter passes (scripts/gpu_pmc.sh, profiles/r05_pmc_summary.txt); null = not collected for this workload",
+                     "command in separate counter passes (scripts/gpu_pmc.sh, profiles/r06_pmc_summary.txt); null = not collected for this workload",
                      "timing": "hipEvent pairs around what one call enqueues on the launch stream (slot 0: clears and the scan kernel; slots 1-2: resolve and emit "
                                "kernels of the split pipeline, empty and not counted for a single-pass call), mean over the timed steps"},
     }
@@ -647,7 +647,7 @@ def leg_tape(cx):
                             "algorithmic_bytes_per_launch": alg,
                             "algorithmic_bytes": "document + 4 (n + 1) list in, 8 tape words + string records out; all kernels of one sjgpu_stage2_device call together",
                             "traffic": cx.traffic.get(f"tape:{kind}:{256 << 20}"),
-                            "traffic_source": "profiles/traffic.json (profiles/r03_pmc_summary.txt, addendum): FETCH_SIZE x 2 + WRITE_SIZE summed over the kernels of one call"},
+                            "traffic_source": "profiles/traffic.json (profiles/r06_pmc_summary.txt): FETCH_SIZE x 2 + WRITE_SIZE summed over the kernels of one call"},
                "note": "includes the 48-byte result read-back of every call; document, list, tape and string buffer stay on the device"}
         # round 5: stage 1 + stage 2 with the token stream between them (sjgpu_stage1_tokens_device -> sjgpu_stage2_tokens_device) against the two plain calls
         tok = torch.empty(L // 2 + 16, dtype=torch.uint8, device="cuda")

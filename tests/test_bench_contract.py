@@ -1,5 +1,5 @@
-"""CPU tier: the shape of bench.py's one JSON line, checked on the line the final tree of the round produced on the GPU box
-(profiles/r05_bench_final.json; the N = 2 dry run and the NDJSON line at N = 1 beside it) -- the fields the driver and the judge read (metric / value / unit / n_gpus / steps / warmup /
+"""CPU tier: the shape of bench.py's one JSON line, checked on what the final tree of the round produced on the GPU box
+(profiles/r06_bench_final.json = the printed line, r06_bench_detail.json = the full record; the N = 2 dry run and the NDJSON line at N = 1 beside them) -- the fields the driver and the judge read (metric / value / unit / n_gpus / steps / warmup /
 ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload / roofline / cpu_baseline), every leg with its
 own roofline where one is defined, no leg failed, and the arithmetic the line claims (frac = achieved / peak, value = bytes / time)."""
 import glob
@@ -169,7 +169,7 @@ def test_the_n2_dry_run_line_is_a_measurement():
     launched WITHOUT a launcher (it became one) on a one-GPU box: both ranks on the one device over gloo, so RCCL cannot have seen two ranks -- the line
     must say that, too -- and two ranks sharing one device are worth one: the efficiency of the dry run is near 1/2, which is what makes it a check of
     the arithmetic."""
-    path = os.path.join(_paths.REPO_ROOT, "profiles", "r05_bench_n2_dry.json")
+    path = sorted(glob.glob(os.path.join(_paths.REPO_ROOT, "profiles", "r*_bench_n2_dry_detail.json")))[-1]  # the full record (round 6 on; the printed line beside it)
     d = json.load(open(path))
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "large_random" in d["config"]["workload"]
     for key in ("roofline", "cpu_baseline", "parity", "config3_ndjson_sharded", "one_document_shards", "index_concat", "n_ranks_seen_by_rccl", "n1_same_workload_GBps",
@@ -189,7 +189,7 @@ def test_the_n2_dry_run_line_is_a_measurement():
 def test_the_ndjson_line_at_one_gpu_is_first_class():
     """`--workload amazon_ndjson` at `--gpus 1` is a headline of its own -- roofline, the reference on one thread AND on all hardware
     threads of the box -- so that a sweep `--gpus 1,2,4,8 --workload amazon_ndjson` is one workload end to end."""
-    d = json.load(open(os.path.join(_paths.REPO_ROOT, "profiles", "r05_bench_ndjson_n1.json")))
+    d = json.load(open(sorted(glob.glob(os.path.join(_paths.REPO_ROOT, "profiles", "r*_bench_ndjson_n1_detail.json")))[-1]))
     assert d["n_gpus"] == 1 and "amazon_ndjson" in d["config"]["workload"] and "amazon_ndjson" in d["same_workload_at_every_n"]
     assert 0.3 < d["roofline"]["frac"] < 1 and d["parity"]["ok"]
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline_threads"]["cores"] > 1 and d["cpu_baseline_threads"]["value"] > d["cpu_baseline"]["value"]
