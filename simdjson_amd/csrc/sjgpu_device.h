@@ -79,6 +79,18 @@ __device__ __forceinline__ void lds_writes_done() {
 #endif
 }
 
+// A workgroup barrier for data that lives in LDS only: the caller has waited for its LDS writes (lds_writes_done), nothing global needs ordering.
+// __syncthreads() would add a release fence, which waits for every outstanding global store and atomic of the wave to be acknowledged.
+__device__ __forceinline__ void workgroup_barrier_lds_only() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#else
+  __syncthreads();
+#endif
+}
+
 // ---- loads ----------------------------------------------------------------------------------------
 // A lane's 64 bytes as 16 dwords.  Bytes at or beyond len read as 0x20, exactly the reference's
 // space-padded last block (/root/reference/src/generic/stage1/buf_block_reader.h:99-104); nothing

@@ -998,201 +998,249 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
 }
 
 // =====================================================================================================
-// k_stage1_direct (round 6): the split pipeline's scan kernel with the emission INSIDE it -- one pass, no masks in HBM.
-// k_stage1_summarize + k_stage1_emit move the masks out and in again (0.135 + 0.151 GB per GiB of NDJSON, 18 % of everything the
-// pipeline moves; both kernels run at ~0.9 of the copy ceiling on the bytes they move: only fewer bytes help -- VERDICT r05).  Here
-// the workgroup that scanned four segments keeps their masks in REGISTERS (one plane when the segment resolved its own string state
-// at a control character -- every segment of pretty-printed text / NDJSON / large_random -- two otherwise), publishes the tile's
-// aggregate, looks back over its predecessors' descriptors (the single-pass kernels' protocol: same descriptors, same look-back,
-// same x algebra) and emits from the registers through the LDS the chunk loads no longer need (load_chunk_stream's exchange buffer
-// = the emission window).  What distinguishes it from k_fused / k_fused_pipelined:
-//   * NOT persistent: one workgroup per 64 KiB tile, five workgroups (twenty waves) per CU -- a workgroup that waits for its prefix
-//     holds a fifth of the CU's waves while the other four scan; the pipelined kernel hides that wait by deferring a tile's emission
-//     by one iteration, which costs it the masks' trip through LDS and three barriers per tile, and two workgroups per CU;
-//   * the summarize kernel's body: streamed coalesced chunk loads, the UTF-8 rows parked in LDS (nothing is fetched twice), one mask
-//     plane and one count for resolved segments;
-//   * TICKET = false: tiles are taken in blockIdx order.  A tile waits only for tiles with SMALLER numbers; the dispatcher of every
-//     XCD hands out workgroups in ascending order, so the lowest unfinished tile is always resident or next in line on its XCD and
-//     never waits for anyone.  (Should a part ever dispatch otherwise, the look-back's wall-clock bound poisons the chain, the call
-//     reports SJGPU_F_INTERNAL and the host re-runs it on the split pipeline, like every single-pass call.)  TICKET = true: an atomic
-//     ticket per workgroup, the order the other single-pass kernels use.
+// k_stage1_direct (round 6): the split pipeline's scan with the emission INSIDE it -- one pass, no masks in HBM -- for PLAIN input.
+//
+// k_stage1_summarize + k_stage1_emit move the masks out and in again (0.135 + 0.151 GB per GiB of NDJSON, 18 % of everything the pipeline moves; both kernels
+// run at ~0.9 of the copy ceiling on the bytes they move: only fewer bytes help -- VERDICT r05).  A segment whose first chunk holds a control character pins
+// its own string state there (k_stage1_summarize: "resolved"): one final mask plane, ONE count whatever the state in front of it.  When EVERY segment of an
+// input is like that and no span had to assume its escape carry (x word 0) -- pretty-printed text, NDJSON, large_random: "plain" input -- the two quantities
+// that cross segments are ADDITIVE: the output cursor is a sum of counts, the string state a sum of quote parities mod 2.  Sums need no chain of
+// compositions: every tile adds (1 arrival, parity, count) to the word of its group of 64 tiles with one atomicAdd, and a tile's prefix is two kinds of
+// coalesced loads -- the tiles in front inside its group, the groups in front -- complete when the arrival fields say so.  No look-back walk, no
+// aggregate / inclusive protocol.
+//   * persistent workgroups of EIGHT waves (a wave = one 16 KiB segment, k_stage1_summarize's body: streamed coalesced chunk loads, UTF-8 rows parked in
+//     LDS), 128 KiB tiles by atomic ticket drawn one iteration ahead.  (Four waves and 64 KiB tiles -- 16 384 tickets and 2 x 16 384 adds per GiB -- sat at
+//     67 ns per TILE whatever the tile did, 1.1 ms per GiB with ideal traffic: atomics on one address are served at ~30 ns each on this part.)
+//   * a tile's emission is DEFERRED by one iteration (the first version of this kernel emitted at once: every workgroup waited for the slowest of its
+//     ~1280 in-flight predecessors and the kernel lost 20-45 % to both pipelines, profiles/r06_direct_ab.txt): the pending segment's final masks wait in
+//     eight VGPRs per lane while the wave scans its next segment; by then the tiles in front have long published;
+//   * the offsets leave through the LDS the chunk loads do not need between two scans (load_chunk_stream's exchange buffer = the emission window);
+//   * a segment that is NOT plain (no control character in its first chunk: minified text, brackets only; or an x word) cannot be summed: the kernel
+//     raises SJGPU_F_INTERNAL and the call is re-run on the split pipeline like every single-pass call that gives up; AUTO only comes here for contexts
+//     whose previous scan found the input plain (sjgpu_capi.hip).
+// Workspace (the single-pass kernels' descriptor array): [ntiles tile words][group words][control words: ticket, done, flags].
+//   tile word:   [63] published, [32] quote parity of the tile, [31:0] its count        (one relaxed agent-scope store)
+//   group word:  [63:48] arrivals, [47:32] sum of parities, [31:0] sum of counts        (agent-scope atomicAdd, one per tile)
+// MEASURED (profiles/r06_direct_ab.txt), and why AUTO does not select it: correct and with IDEAL traffic (1.081 GB fetched + 0.271 written for 1.336 algorithmic
+// per GiB of NDJSON: the masks' round trip is gone) it takes 447 us per GiB of NDJSON against 287 for the split pipeline and 335 for k_fused_pipelined, 588
+// against 472 on large_random.  Thread 0's wall-clock per phase: a wave scans 56 % of the time (prefix 5 us and publication 2 us per 27 us iteration, emission
+// 4-17), and a scan that is bound by what it has IN FLIGHT -- one 4 KiB chunk per scanning wave -- runs at the fraction of its waves that are scanning:
+// k_stage1_summarize keeps 20 waves per CU loading all the time, this kernel ~9 of 16.  The split pipeline wins on this part BECAUSE its kernels have one phase.
 // =====================================================================================================
-constexpr u32 DIRECT_WAVES = 4;
+constexpr u32 DIRECT_WAVES = 8;  // (four waves and 64 KiB tiles, 16 384 tickets and 2 x 16 384 adds per GiB: the atomics on the ticket and on the sum words are served at
+                                 // ~30 ns each per ADDRESS and the kernel sat at 67 ns per tile whatever it did -- 1.1 ms per GiB with ideal traffic, session J)
 constexpr u32 DIRECT_TILE_BYTES = DIRECT_WAVES * SEG_BYTES;
+constexpr u32 DIRECT_GROUP = 64; // tiles per group (8 MiB): one sum word per group, 128 of them per GiB
 constexpr u32 DIRECT_WINDOW = CHUNK_BYTES / 4 - 8; // the exchange buffer's 1024 words minus skew and dump slots (emit_stage_words)
 static_assert(emit_stage_words(DIRECT_WINDOW) * 4 == CHUNK_BYTES && DIRECT_WINDOW % 4 == 0, "the emission window is the exchange buffer");
-template <bool TICKET>
-__global__ __launch_bounds__(64 * DIRECT_WAVES) SJ_WAVES_PER_EU(5, 5) void k_stage1_direct(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc, u32 *__restrict__ ticket,
+constexpr u64 DIRECT_VALID = 1ull << 63;
+__host__ __device__ inline u32 direct_groups(u32 ntiles) { return (ntiles + DIRECT_GROUP - 1) / DIRECT_GROUP; }
+__host__ __device__ inline u32 direct_words(u32 ntiles) { return ntiles + direct_groups(ntiles); } // in front of the control words
+
+// prefix (count, parity) of tile `tile` = everything in front of it: wave-wide, all 64 lanes.  false: timed out
+__device__ __forceinline__ bool direct_prefix(const u64 *__restrict__ desc, u32 ntiles, u32 tile, u32 lane, u32 &B, u32 &S, scan_origin org) {
+  const u64 *A = desc, *G = desc + ntiles;
+  const u32 g = tile / DIRECT_GROUP, na = tile % DIRECT_GROUP; // groups in front of mine; tiles in front of me inside my group
+  const u64 t_start = wall_clock64();
+  for (;;) {
+    const u64 a = lane < na ? desc_load(A + g * DIRECT_GROUP + lane) : DIRECT_VALID;
+    u32 cnt = lane < na ? u32(a) : 0u, par = lane < na ? u32(a >> 32) & 1u : 0u;
+    bool ready = (a >> 63) != 0;
+#pragma unroll 1
+    for (u32 j = lane; j < g; j += 64u) { // 128 groups per GiB: two rounds (wave-uniform trip count up to the last round)
+      const u64 gg = desc_load(G + j);
+      ready = ready && (gg >> 48) == DIRECT_GROUP;
+      cnt += u32(gg);
+      par += u32(gg >> 32) & 0xFFFFu;
+    }
+    if (!__ballot(!ready)) {
+      B = org.base0 + wave_sum(cnt);
+      S = (wave_sum(par) & 1u) ^ (org.carry & CARRY_IN_STRING);
+      return true;
+    }
+    if (wall_clock64() - t_start > LOOKBACK_TIMEOUT_TICKS) { return false; }
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+
+#ifndef SJGPU_DIRECT_EU
+#define SJGPU_DIRECT_EU 4 // waves per SIMD the kernel is compiled for: 4 = 128 VGPRs (24 B of cold scratch), 5 = 96 VGPRs (136 B); lab builds override it
+#endif
+__global__ __launch_bounds__(64 * DIRECT_WAVES) SJ_WAVES_PER_EU(SJGPU_DIRECT_EU, SJGPU_DIRECT_EU) void k_stage1_direct(const u8 *__restrict__ buf, u64 len, u64 *__restrict__ desc, u32 *__restrict__ ticket,
                                                                                        u32 ntiles, u32 *__restrict__ idx, u64 idx_words,
                                                                                        scan_result_dev *__restrict__ result, scan_origin org) {
   const u32 lane = lane_id();
   const u32 wave = threadIdx.x >> 6;
   __shared__ __attribute__((aligned(16))) u32 park[DIRECT_WAVES][UTF8P_ROWS * UTF8P_ROW_WORDS];
-  __shared__ __attribute__((aligned(16))) uint4 xbuf[DIRECT_WAVES][CHUNK_BYTES / 16]; // chunk loads, then the wave's emission window
-  __shared__ u32 sh_left[DIRECT_WAVES];
-  __shared__ u32 sh_wave[DIRECT_WAVES][5]; // parity, count_if_out, count_if_in, WF_* flags, x word
-  __shared__ u32 sh_prefix[4];             // S, B, ok, X
-  __shared__ u32 sh_tile;
-  u32 tile = blockIdx.x;
-  if (TICKET) {
-    if (threadIdx.x == 0) { sh_tile = atomicAdd(ticket, 1u); }
-    lds_writes_done();
-    __syncthreads();
-    tile = sh_tile;
-  }
+  __shared__ __attribute__((aligned(16))) uint4 xbuf[DIRECT_WAVES][CHUNK_BYTES / 16]; // chunk loads while a wave scans, its emission window in between
+  __shared__ u32 sh_wave[2][DIRECT_WAVES][2]; // [iteration parity][wave]: count, quote parity
+  __shared__ u32 sh_prefix[3];                // B, S, ok of the pending tile
+  __shared__ u32 sh_tile[2];
   const bool more = (org.carry & CARRY_MORE) != 0;
-  const u64 seg_start = org.begin + (u64(tile) * DIRECT_WAVES + wave) * SEG_BYTES;
-  const bool have = seg_start < len; // wave-uniform (wave 0 always has a segment: tile < ntiles)
-  u64 keep0[SEG_CHUNKS] = {0, 0, 0, 0}, keep1[SEG_CHUNKS] = {0, 0, 0, 0};
-  u32 parity = 0, xw = 0, c_out = 0, c_in = 0, wflags = 0;
-  bool resolved = false;
-  utf8_park uq{park[wave], 0u, 0u, 0u, 0x20202020u, buf, len, more ? 1u : 0u, UTF8P_DENSE_FROM};
-  if (have) {
-    const u64 lane_off = u64(lane) * BLOCK_BYTES;
-    const u32 lookback = lookback_issue(buf, seg_start, lane); // consumed after chunk 0 has been requested
-    wave_carry wc{0u, 0u, 0u};
-    span_x sx;
-    u32 n_a = 0, n_b = 0; // resolved: n_a = final count; else n_a = candidates, n_b = candidates in a string tail
-    bool any_a = false, any_b = false;
-    u32 derived = 0;
-    u64 flip = 0;
-#pragma unroll
-    for (u32 c = 0; c < SEG_CHUNKS; c++) {
-      const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
-      if (cstart >= len) { break; }
-      const u64 pos = cstart + lane_off;
-      u32 w[16];
-      if (cstart + CHUNK_BYTES <= len) { load_chunk_stream(buf, cstart, lane, xbuf[wave], w); }
-      else { load_block(buf, pos, len, w); }
-      if (c == 0) {
-        wc = span_carry_assume(seg_start, lane, lookback, sx);
-        utf8_park_begin(uq, lookback, lane);
-      }
-      span_note_chunk(sx, w, c * CHUNK_BYTES, lane);
-      const chunk_masks m = scan_chunk<true, true>(w, wc, lane, &uq, u32(cstart / BLOCK_BYTES));
-      if (c == SEG_CHUNKS - 1) { span_note_tail(sx, m.backslash, m.quote_raw); }
-      if (c == 0) { // the first control character pins the segment's string state (sjgpu_kernels.hip: k_stage1_summarize)
-        const u64 cm = __ballot(m.ctrl != 0);
-        if (cm) {
-          const u32 lc = ctz64(cm);
-          u32 v = 0;
-          if (lane == lc) { v = u32(m.in_string >> ctz64(m.ctrl)) & 1u; }
-          derived = readlane_dyn(v, lc);
-          resolved = true;
-          flip = derived ? ~0ull : 0ull;
+  u64 *const G = desc + ntiles;
+  // the pending segment (what this wave scanned an iteration ago and has not emitted yet)
+  u64 keep_prev[SEG_CHUNKS] = {0, 0, 0, 0};
+  u32 pend_tile = NO_TILE, pend_count = 0, pend_wflags = 0, pend_base_rel = 0, pend_par_rel = 0;
+  u32 pend_tile_count = 0, pend_tile_par = 0; // (wave 0: the whole pending tile)
+  u32 utf8_error = 0;
+  u32 next_ticket = 0;
+  if (threadIdx.x == 0) { sh_tile[0] = atomicAdd(ticket, 1u); }
+  lds_writes_done();
+  __syncthreads();
+  for (u32 iter = 0;; iter++) {
+    const u32 cur = iter & 1u;
+    const u32 tile = sh_tile[cur];
+    const bool have = tile < ntiles, pend = pend_tile != NO_TILE; // workgroup-uniform
+    if (!have && !pend) { break; }
+    if (threadIdx.x == 0 && have) { next_ticket = atomicAdd(ticket, 1u); }
+    // ---- scan my segment of the new tile (k_stage1_summarize's body); its final masks stay in registers ----
+    const u64 seg_start = org.begin + (u64(tile) * DIRECT_WAVES + wave) * SEG_BYTES;
+    const bool mine = have && seg_start < len; // wave-uniform
+    u64 keep[SEG_CHUNKS] = {0, 0, 0, 0};
+    u32 count = 0, parity = 0, wflags = 0;
+    utf8_park uq{park[wave], 0u, 0u, 0u, 0x20202020u, buf, len, more ? 1u : 0u, UTF8P_DENSE_FROM};
+    if (mine) {
+      const u64 lane_off = u64(lane) * BLOCK_BYTES;
+      const u32 lookback = lookback_issue(buf, seg_start, lane);
+      wave_carry wc{0u, 0u, 0u};
+      span_x sx;
+      u32 n_a = 0;
+      bool any_a = false, resolved = false;
+      u32 derived = 0;
+      u64 flip = 0;
+      // (a rolled loop over the four chunks, their masks in a register FIFO -- no dynamic register indexing: unrolled like k_stage1_summarize's, the kernel is
+      // 57 KB of code with the emission inlined behind it; rolled, 31 KB)
+      u64 k0 = 0, k1 = 0, k2 = 0, k3 = 0; // slot 3 = oldest chunk
+#pragma unroll 1
+      for (u32 c = 0; c < SEG_CHUNKS; c++) {
+        const u64 cstart = seg_start + u64(c) * CHUNK_BYTES;
+        u64 structural = 0;
+        if (cstart < len) { // wave-uniform
+          const u64 pos = cstart + lane_off;
+          u32 w[16];
+          if (cstart + CHUNK_BYTES <= len) { load_chunk_stream(buf, cstart, lane, xbuf[wave], w); }
+          else { load_block(buf, pos, len, w); }
+          if (c == 0) {
+            wc = span_carry_assume(seg_start, lane, lookback, sx);
+            utf8_park_begin(uq, lookback, lane);
+          }
+          span_note_chunk(sx, w, c * CHUNK_BYTES, lane);
+          const chunk_masks m = scan_chunk<true, true>(w, wc, lane, &uq, u32(cstart / BLOCK_BYTES));
+          if (c == SEG_CHUNKS - 1) { span_note_tail(sx, m.backslash, m.quote_raw); }
+          if (c == 0) { // the first control character pins the segment's string state (k_stage1_summarize)
+            const u64 cm = __ballot(m.ctrl != 0);
+            if (cm) {
+              const u32 lc = ctz64(cm);
+              u32 v = 0;
+              if (lane == lc) { v = u32(m.in_string >> ctz64(m.ctrl)) & 1u; }
+              derived = readlane_dyn(v, lc);
+              resolved = true;
+              flip = derived ? ~0ull : 0ull;
+            }
+          }
+          // (an unresolved segment makes the call give up below: what is kept of it does not matter)
+          structural = m.cand & ~(m.string_tail ^ flip);
+          n_a += u32(popc64(structural));
+          any_a |= __ballot((m.ctrl & (m.in_string ^ flip)) != 0) != 0;
         }
+        k3 = k2; k2 = k1; k1 = k0; k0 = structural;
       }
-      if (resolved) {
-        const u64 structural = m.cand & ~(m.string_tail ^ flip);
-        n_a += u32(popc64(structural));
-        any_a |= __ballot((m.ctrl & (m.in_string ^ flip)) != 0) != 0;
-        keep0[c] = structural;
-      } else {
-        n_a += u32(popc64(m.cand));
-        n_b += u32(popc64(m.cand & m.string_tail));
-        any_a |= __ballot((m.ctrl & m.in_string) != 0) != 0;
-        any_b |= __ballot((m.ctrl & ~m.in_string) != 0) != 0;
-        keep0[c] = m.cand;
-        keep1[c] = m.string_tail;
-      }
-    }
-    const u32 ta = wave_sum(n_a), tb = wave_sum(n_b);
-    parity = wc.s;
-    if (resolved) {
-      c_out = c_in = ta;
-      const bool ok_view = !any_a; // (k_stage1_summarize: true carry-in == derived: error iff a control character sits in a string of the resolved view; else the resolving character itself does)
+      keep[0] = k3; keep[1] = k2; keep[2] = k1; keep[3] = k0;
+      // the rows this wave has left are validated by itself, now (k_stage1_summarize hands them to wave 0 behind its one barrier: here that would be eight
+      // waves standing by in every iteration, and the row check's registers in a kernel that has none to spare)
+      if (uq.count) { utf8_park_drain(uq, lane, uq.count); }
+      count = wave_sum(n_a);
+      parity = wc.s;
+      const bool ok_view = !any_a; // (k_stage1_summarize: the carry-in that matches `derived` errs iff a control character sits in a string of the resolved view; the other one always)
       if (derived ? true : !ok_view) { wflags |= WF_CTRL_IF_OUT; }
       if (derived ? !ok_view : true) { wflags |= WF_CTRL_IF_IN; }
-    } else {
-      c_out = ta - tb;
-      c_in = tb;
-      if (any_a) { wflags |= WF_CTRL_IF_OUT; }
-      if (any_b) { wflags |= WF_CTRL_IF_IN; }
+      const u32 xw = span_finish(sx, buf, seg_start, SEG_BYTES, len, wc, true, resolved, derived);
+      if ((!resolved || xw != 0u) && lane == 0) { atomicOr(ctl_flags(ticket), SJGPU_F_INTERNAL); } // not plain: sums do not describe this input (the split pipeline does)
+      if (uq.error) { utf8_error = 1u; }
     }
-    xw = span_finish(sx, buf, seg_start, SEG_BYTES, len, wc, true, resolved, derived);
-  }
-  if (lane == 0) {
-    sh_left[wave] = uq.count;
-    sh_wave[wave][0] = parity;
-    sh_wave[wave][1] = c_out;
-    sh_wave[wave][2] = c_in;
-    sh_wave[wave][3] = wflags;
-    sh_wave[wave][4] = xw;
-  }
-  lds_writes_done();
-  __syncthreads();
-  // ---- wave 0: the rows the four waves have left, the tile's aggregate, the look-back, the inclusive prefix ----
-  if (wave == 0) {
-    const tile_agg ta = tile_aggregate<DIRECT_WAVES>(sh_wave);
-    if (lane == 0) { desc_store(desc + tile, make_agg(ta.q, ta.c_out, ta.c_in, ta.xw)); } // first: successors wait for it
-    const u32 n0 = sh_left[0], n1 = n0 + sh_left[1], n2 = n1 + sh_left[2], total = n2 + sh_left[3];
-    for (u32 done = 0; done < total; done += 64) {
-      const u32 g = done + lane;
-      bool bad = false;
-      if (g < total) {
-        const u32 v = (g >= n0) + (g >= n1) + (g >= n2);
-        const u32 r = g - (v == 0 ? 0u : (v == 1 ? n0 : (v == 2 ? n1 : n2)));
-        bad = utf8_check_row(park[v] + r * UTF8P_ROW_WORDS, len, more);
-      }
-      if (__ballot(bad)) { uq.error = 1u; }
-    }
-    u32 S = 0, X = 0, B = 0;
-    const bool ok = lookback(desc, tile, lane, S, X, B, org);
     if (lane == 0) {
-      if (ok) {
-        const xs_step te = xs_apply(ta.q, ta.xw, S, X);
-        const u32 total_out = B + xs_count(ta.c_out, ta.c_in, te), s_end = te.s_out;
-        desc_store(desc + tile, make_incl(s_end, te.x_out, total_out));
-        if (tile == ntiles - 1) { // the last tile knows the totals: n, unclosed string, sentinels (json_structural_indexer.h:284-286)
-          u32 f = s_end ? SJGPU_F_UNCLOSED_STRING : 0u;
-          if (u64(total_out) + 3 <= idx_words) {
-            idx[total_out] = u32(len);
-            idx[total_out + 1] = u32(len);
-            idx[total_out + 2] = 0;
-          } else {
-            f |= SJGPU_F_IDX_OVERFLOW;
-          }
-          result->n = total_out;
-          result->out_len = 0;
-          if ((org.carry & CARRY_MORE) && te.x_out) { f |= SJGPU_F_RANGE_CARRY; }
-          if (f) { atomicOr(ctl_flags(ticket), f); }
+      sh_wave[cur][wave][0] = count;
+      sh_wave[cur][wave][1] = parity;
+    }
+    // ---- wave 0: the pending tile's prefix, while the other waves finish scanning (its predecessors published an iteration ago) ----
+    u32 pB = 0, pS = 0;
+    bool p_ok = false;
+    if (wave == 0 && pend) { p_ok = direct_prefix(desc, ntiles, pend_tile, lane, pB, pS, org); }
+    lds_writes_done();
+    __syncthreads();
+    // ---- every wave: where its segment lies inside the new tile (kept for the next iteration); wave 0: publish, broadcast ----
+    u32 base_rel = 0, par_rel = 0, tile_count = 0, tile_par = 0;
+#pragma unroll
+    for (u32 v = 0; v < DIRECT_WAVES; v++) {
+      const u32 c = sh_wave[cur][v][0], q = sh_wave[cur][v][1];
+      if (v < wave) { base_rel += c; par_rel ^= q; }
+      tile_count += c;
+      tile_par ^= q;
+    }
+    if (wave == 0) {
+      if (have) {
+        if (lane == 0) {
+          const u64 add = (1ull << 48) | (u64(tile_par & 1u) << 32) | u64(tile_count);
+          desc_store(desc + tile, DIRECT_VALID | (u64(tile_par & 1u) << 32) | u64(tile_count));
+          (void)__hip_atomic_fetch_add(G + tile / DIRECT_GROUP, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-      } else {
-        desc_store(desc + tile, ST_POISON << 62);
-        atomicOr(ctl_flags(ticket), SJGPU_F_INTERNAL);
       }
-      sh_prefix[0] = S;
-      sh_prefix[1] = B;
-      sh_prefix[2] = ok ? 1u : 0u;
-      sh_prefix[3] = X;
+      if (pend && lane == 0) {
+        if (p_ok) {
+          if (pend_tile == ntiles - 1) { // the last tile knows the totals: n, unclosed string, sentinels (json_structural_indexer.h:284-286)
+            const u32 total_out = pB + pend_tile_count, s_end = pS ^ pend_tile_par;
+            u32 f = s_end ? SJGPU_F_UNCLOSED_STRING : 0u;
+            if (u64(total_out) + 3 <= idx_words) {
+              idx[total_out] = u32(len);
+              idx[total_out + 1] = u32(len);
+              idx[total_out + 2] = 0;
+            } else {
+              f |= SJGPU_F_IDX_OVERFLOW;
+            }
+            result->n = total_out;
+            result->out_len = 0;
+            if (f) { atomicOr(ctl_flags(ticket), f); }
+          }
+        } else {
+          atomicOr(ctl_flags(ticket), SJGPU_F_INTERNAL);
+        }
+        sh_prefix[0] = pB;
+        sh_prefix[1] = pS;
+        sh_prefix[2] = p_ok ? 1u : 0u;
+      }
+      if (lane == 0) { sh_tile[cur ^ 1u] = have ? next_ticket : NO_TILE; } // the next iteration's ticket crosses with this barrier
     }
-  }
-  if (uq.error && lane == 0) { atomicOr(ctl_flags(ticket), SJGPU_F_UTF8_ERROR); }
-  lds_writes_done();
-  __syncthreads();
-  // ---- every wave: its carry-in from the tile's prefix, then its offsets from the registers ----
-  if (have && sh_prefix[2] != 0u) {
-    u32 s = sh_prefix[0], x = sh_prefix[3], base = sh_prefix[1];
-    wave_state(sh_wave, wave, s, x, base);
-    const xs_step own = xs_apply(parity, xw, s, x);
-    if ((wflags & (own.se ? WF_CTRL_IF_IN : WF_CTRL_IF_OUT)) && lane == 0) { atomicOr(ctl_flags(ticket), SJGPU_F_UNESCAPED_CTRL); }
-    u64 st[SEG_CHUNKS];
-#pragma unroll
-    for (u32 c = 0; c < SEG_CHUNKS; c++) { st[c] = keep0[c]; }
-    if (!resolved) {
-      const u64 flip = own.se ? ~0ull : 0ull;
-#pragma unroll
-      for (u32 c = 0; c < SEG_CHUNKS; c++) { st[c] = andn(keep0[c], keep1[c] ^ flip); }
+    // (not __syncthreads(): its release fence waits for the acknowledgement of the store and the add above -- a round trip to the device's coherence point
+    // with eight waves standing by; what crosses here lives in LDS, whose writes are waited for, and leave_and_clean waits for everything global at the end)
+    lds_writes_done();
+    workgroup_barrier_lds_only();
+    // ---- every wave: the pending segment's offsets from the registers, through the idle exchange buffer ----
+    if (pend && pend_count != 0u && sh_prefix[2] != 0u) {
+      u32 base = sh_prefix[0] + pend_base_rel;
+      const u32 s = sh_prefix[1] ^ pend_par_rel;
+      if ((pend_wflags & (s ? WF_CTRL_IF_IN : WF_CTRL_IF_OUT)) && lane == 0) { atomicOr(ctl_flags(ticket), SJGPU_F_UNESCAPED_CTRL); }
+      const u64 pend_start = org.begin + (u64(pend_tile) * DIRECT_WAVES + wave) * SEG_BYTES;
+      bool overflow = false;
+      emit_span4_adaptive<DIRECT_WINDOW>(keep_prev, u32(pend_start), lane, idx, idx_words, base, reinterpret_cast<u32 *>(xbuf[wave]), overflow, pend_count);
+      if (__ballot(overflow) && lane == 0) { atomicOr(ctl_flags(ticket), SJGPU_F_IDX_OVERFLOW); }
+    } else if (pend && sh_prefix[2] != 0u) { // nothing to emit: the error bit of an empty segment still counts
+      const u32 s = sh_prefix[1] ^ pend_par_rel;
+      if ((pend_wflags & (s ? WF_CTRL_IF_IN : WF_CTRL_IF_OUT)) && lane == 0) { atomicOr(ctl_flags(ticket), SJGPU_F_UNESCAPED_CTRL); }
     }
-    span_patch(st, xw, x, own.se, lane);
-    const u32 span_count = (org.carry & CARRY_DEBUG_NO_SPAN_HINT) ? 0u : xs_count(c_out, c_in, own);
-    bool overflow = false;
-    emit_span4_adaptive<DIRECT_WINDOW>(st, u32(seg_start), lane, idx, idx_words, base, reinterpret_cast<u32 *>(xbuf[wave]), overflow, span_count);
-    if (__ballot(overflow) && lane == 0) { atomicOr(ctl_flags(ticket), SJGPU_F_IDX_OVERFLOW); }
+    // ---- the segment scanned in this iteration becomes the pending one ----
+#pragma unroll
+    for (u32 c = 0; c < SEG_CHUNKS; c++) { keep_prev[c] = keep[c]; }
+    pend_tile = have ? tile : NO_TILE;
+    pend_count = count;
+    pend_wflags = mine ? wflags : 0u;
+    pend_base_rel = base_rel;
+    pend_par_rel = par_rel;
+    pend_tile_count = tile_count;
+    pend_tile_par = tile_par;
   }
-  leave_and_clean<64 * DIRECT_WAVES>(desc, ntiles, ticket, result);
+  if (utf8_error && lane == 0) { atomicOr(ctl_flags(ticket), SJGPU_F_UTF8_ERROR); }
+  leave_and_clean<64 * DIRECT_WAVES>(desc, direct_words(ntiles), ticket, result);
 }
-
 
 } // namespace
 
@@ -1243,6 +1291,22 @@ static void launch_fused_wc(int op, const uint8_t *buf, uint64_t len, uint64_t *
 
 // test hook (tests/host/test_kernels_emu.cpp lowers it so that small documents take the large-input kernels); never changed by the library
 uint64_t debug_fused_small_below = FUSED_SMALL_BELOW;
+
+// k_stage1_direct: persistent workgroups of four waves, five per CU (max_workgroups = 8 per CU)
+static const char *launch_direct(const uint8_t *buf, uint64_t len, uint64_t *desc, u32 *idx, uint64_t idx_words, scan_result_dev *result, scan_origin org,
+                                 uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev, bool clean, u32 cleared_tiles) {
+  const u32 nt = u32((len - org.begin + DIRECT_TILE_BYTES - 1) / DIRECT_TILE_BYTES);
+  const u32 words = direct_words(nt);
+  u32 *tk = reinterpret_cast<u32 *>(desc + words);
+  if (words != cleared_tiles) { clear_fused_workspace(result, desc, words, clean, stream); } // (only a dirty workspace is cleared at all; the control words lie behind THIS kernel's words)
+  static const unsigned per_cu8 = []() { const char *v = std::getenv("SJGPU_DIRECT_WG"); const int x = v ? std::atoi(v) : 2; return (x >= 1 && x <= 8) ? unsigned(x) : 2u; }(); // A/B: workgroups per CU (two of eight waves)
+  const u32 resident = max_workgroups * per_cu8 / 8u ? max_workgroups * per_cu8 / 8u : 1u;
+  const u32 cap = (nt + 1) / 2; // every workgroup should own >= 2 tiles for the deferral to work
+  const u32 grid = cap < resident ? (cap ? cap : 1u) : resident;
+  hipLaunchKernelGGL(k_stage1_direct, dim3(grid), dim3(64 * DIRECT_WAVES), 0, stream, buf, len, desc, tk, nt, idx, idx_words, result, org);
+  mark(ev, 1, stream);
+  return "k_stage1_direct (8 waves, 128 KiB tiles, deferred emission)";
+}
 
 // returns the name of the scan kernel it launched (sjgpu_profile_kernel)
 static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64_t *desc, void *out, uint64_t out_words,
@@ -1314,16 +1378,9 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
       mark(ev, 1, stream);
       return "k_fused_pipelined<0, tokens> (8 waves, 128 KiB tiles)";
     }
-    static const unsigned direct = []() { const char *v = std::getenv("SJGPU_DIRECT"); return v ? unsigned(std::atoi(v)) : 0u; }();
-    if (op == 0 && direct != 0u) {
-      const u32 nt = u32((len - org.begin + DIRECT_TILE_BYTES - 1) / DIRECT_TILE_BYTES);
-      u32 *tk = reinterpret_cast<u32 *>(desc + nt);
-      if (nt != ntiles) { clear_fused_workspace(result, desc, nt, clean, stream); } // (only a dirty workspace is cleared at all; the control words lie behind THIS kernel's tiles)
-      if (direct == 2u) { hipLaunchKernelGGL((k_stage1_direct<true>), dim3(nt), dim3(64 * DIRECT_WAVES), 0, stream, buf, len, desc, tk, nt, static_cast<u32 *>(out), out_words, result, org); }
-      else { hipLaunchKernelGGL((k_stage1_direct<false>), dim3(nt), dim3(64 * DIRECT_WAVES), 0, stream, buf, len, desc, tk, nt, static_cast<u32 *>(out), out_words, result, org); }
-      mark(ev, 1, stream);
-      return direct == 2u ? "k_stage1_direct<ticket> (4 waves, 64 KiB tiles)" : "k_stage1_direct (4 waves, 64 KiB tiles)";
-    }
+    // round 6: the one-pass kernel for plain input (k_stage1_direct); env SJGPU_DIRECT=1 forces it here (AUTO: launch_stage1_direct below, by the context's hint)
+    static const bool direct = []() { const char *v = std::getenv("SJGPU_DIRECT"); return v && v[0] != '0'; }();
+    if (op == 0 && direct) { return launch_direct(buf, len, desc, static_cast<u32 *>(out), out_words, result, org, max_workgroups, stream, ev, clean, ntiles); }
     static const unsigned pipe_wc = []() { const char *v = std::getenv("SJGPU_PIPE_WC"); return v ? unsigned(std::atoi(v)) : 4u; }(); // A/B switch: 2 = 32 KiB tiles
     if (op == 0 && pipe_wc == 2u) {
       const u32 nt2 = u32((len - org.begin + FUSED_TILE_BYTES / 2 - 1) / (FUSED_TILE_BYTES / 2)); // (the clear above covered fewer, larger tiles: clear again)
@@ -1376,6 +1433,12 @@ void launch_stage1_fused_traced(const uint8_t *buf, uint64_t len, uint64_t *desc
                                 scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, uint64_t *trace,
                                 uint32_t trace_tiles) {
   launch_fused(0, buf, len, desc, idx, idx_words, result, scan_origin{0, 0, 0}, max_workgroups, stream, nullptr, trace, trace_tiles);
+}
+// the one-pass kernel for PLAIN input (k_stage1_direct): a call whose input is not plain reports SJGPU_F_INTERNAL and is re-run on the split pipeline
+const char *launch_stage1_direct(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words, scan_result_dev *result, scan_origin org,
+                                 uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev, bool clean) {
+  mark(ev, 0, stream);
+  return launch_direct(buf, len, desc, idx, idx_words, result, org, max_workgroups, stream, ev, clean, 0xFFFFFFFFu);
 }
 const char *launch_minify_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint8_t *dst, scan_result_dev *result,
                                 scan_origin org, uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev, bool clean) {

@@ -124,6 +124,11 @@ constexpr uint32_t FUSED_WORKSPACE_EXTRA_WORDS = 2; // control words: ticket, wo
 const char *launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
                                 scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
                                 hipEvent_t *ev, bool clean = false, uint8_t *tok = nullptr); // tok: the token-byte stream beside the offsets (round 6: gathered at emission) // -> name of the scan kernel launched
+// round 6: the one-pass kernel for PLAIN input (every 16 KiB segment pins its own string state at a control character of its first chunk, no span assumed its
+// escape carry): additive prefixes, emission deferred by one tile (sjgpu_fused.hip: k_stage1_direct).  Input that is not plain: SJGPU_F_INTERNAL in the result.
+// Needs num_direct_words(len) + FUSED_WORKSPACE_EXTRA_WORDS descriptor words (never more than num_fused_tiles(len) from 8 MiB on).
+const char *launch_stage1_direct(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words, scan_result_dev *result, scan_origin org,
+                                 uint32_t max_workgroups, hipStream_t stream, hipEvent_t *ev, bool clean = false);
 void launch_stage1_fused_traced(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
                                 scan_result_dev *result, uint32_t max_workgroups, hipStream_t stream, uint64_t *trace,
                                 uint32_t trace_tiles); // 8 wall_clock64 stamps (100 MHz) per tile

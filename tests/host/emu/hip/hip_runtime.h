@@ -278,6 +278,7 @@ static inline uint64_t wall_clock64() {
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_SEQ_CST)
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 template <class T, class U> static inline T atomicAdd(T *p, U v) { return __atomic_fetch_add(p, T(v), __ATOMIC_SEQ_CST); }
 template <class T, class U> static inline T atomicOr(T *p, U v) { return __atomic_fetch_or(p, T(v), __ATOMIC_SEQ_CST); }

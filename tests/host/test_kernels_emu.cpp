@@ -85,9 +85,11 @@ static void value(bytes &d, int depth) { // a valid JSON value
     d.push_back('}');
   }
 }
+static bool g_mostly_plain = false; // the "direct" road: three documents in four are NDJSON-like (plain: every 16 KiB segment meets a newline in its first chunk)
 static bytes make_document(size_t target) {
   bytes d;
-  const uint32_t kind = rnd_below(11);
+  uint32_t kind = rnd_below(11);
+  if (g_mostly_plain && rnd_below(4)) { kind = 1; }
   while (d.size() < target) {
     switch (kind) {
     case 0: soup(d, 1 + rnd_below(400)); break;
@@ -244,6 +246,7 @@ static expected oracle(const bytes &doc) {
   return e;
 }
 
+static long n_direct_done = 0, n_direct_gave_up = 0;
 static void check_stage1(const char *what, const bytes &doc, const expected &e, workspace &w) {
   const scan_result_dev r = *w.result();
   n_checked++;
@@ -302,6 +305,7 @@ int main(int argc, char **argv) {
   const size_t max_kib = argc > 3 ? size_t(atol(argv[3])) : 200;
   const std::string what = argc > 4 ? argv[4] : "all";
   const bool all = what == "all";
+  g_mostly_plain = what == "direct";
   workspace w;
   size_t total_bytes = 0;
   for (long k = 0; k < docs; k++) {
@@ -310,6 +314,13 @@ int main(int argc, char **argv) {
     if (rnd_below(4)) { target = 1 + target % (96 * 1024); }
     if (rnd_below(10) == 0) { target = rnd_below(300); }
     bytes doc = make_document(target);
+    if (g_mostly_plain && rnd_below(3) == 0 && doc.size() > 100) { // ... some of them broken: a raw control character inside a string, a bad UTF-8 byte, an unclosed string
+      const uint32_t how = rnd_below(3);
+      const size_t at = doc.size() / 2 + rnd_below(uint32_t(doc.size() / 3));
+      if (how == 0) { static const char bad[] = "\"a\x01z\" "; doc.insert(doc.begin() + long(at), bad, bad + 6); }
+      else if (how == 1) { doc[at] = 0xFF; }
+      else { put(doc, "\"open , "); }
+    }
     if (const char *path = getenv("SJ_EMU_DOC")) { // one document from a file (debugging a reported mismatch)
       doc.clear();
       if (FILE *f = fopen(path, "rb")) { int c; while ((c = fgetc(f)) != EOF) { doc.push_back(uint8_t(c)); } fclose(f); }
@@ -358,6 +369,15 @@ int main(int argc, char **argv) {
       }
       debug_fused_small_below = FUSED_SMALL_BELOW;
     }
+    if ((all || what == "direct") && len >= 4096) { // round 6: the one-pass kernel for plain input -- it answers exactly, or it gives up (SJGPU_F_INTERNAL) and leaves the workspace clean
+      scan_origin org = whole;
+      std::fill(w.idx.begin(), w.idx.begin() + len + 8, 0xDEADBEEFu);
+      *w.result() = scan_result_dev{0xDEADBEEFu, 0xFFFFFFFFu, ~0ull};
+      launch_stage1_direct(w.in, len, w.desc(), w.idx.data(), len + 3, w.result(), org, 6, nullptr, nullptr, true);
+      if (w.result()->flags & SJGPU_F_INTERNAL) { n_direct_gave_up++; n_checked++; }
+      else { n_direct_done++; check_stage1("direct stage 1", doc, e, w); }
+      check_workspace_clean(w, doc, "direct stage 1");
+    }
     if ((all || what == "docs") && len <= (size_t(1) << 20)) {
       scan_result_dev r{0, 0, 0};
       std::fill(w.idx.begin(), w.idx.begin() + len + 8, 0xDEADBEEFu);
@@ -394,6 +414,7 @@ int main(int argc, char **argv) {
     }
     if (n_failed > 20) { break; }
   }
+  if (n_direct_done + n_direct_gave_up) { printf("direct: %ld completed, %ld gave up\n", n_direct_done, n_direct_gave_up); }
   printf("%ld documents, %zu bytes: %lu comparisons with the oracle, %lu mismatches\n", docs, total_bytes, n_checked, n_failed);
   return n_failed ? 1 : 0;
 }

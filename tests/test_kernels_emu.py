@@ -54,16 +54,18 @@ def test_the_other_workgroup_shapes_of_the_single_pass_kernels(emu, waves):
     assert "60 documents" in p.stdout.decode() and " 0 mismatches" in p.stdout.decode()
 
 
-@pytest.mark.parametrize("direct", ["1", "2"])
-def test_the_direct_kernel(emu, direct):
-    """Round 6: k_stage1_direct (sjgpu_fused.hip; SJGPU_DIRECT=1 tiles in blockIdx order, =2 by ticket) -- the split pipeline's scan with the look-back and
-    the emission inside it.  Measured slower than both pipelines on the GPU (profiles/r06_direct_ab.txt) and not selected by AUTO; it stays an A/B road,
-    and stays right."""
-    env = dict(os.environ, SJGPU_DIRECT=direct)
-    for seed, docs, kib in (("11", "60", "300"), ("7", "10", "2500")):
-        p = subprocess.run([emu, seed, docs, kib, "fused"], capture_output=True, timeout=900, env=env)
-        assert p.returncode == 0, (p.stdout.decode()[-500:], p.stderr.decode()[-3000:])
-        assert f"{docs} documents" in p.stdout.decode() and " 0 mismatches" in p.stdout.decode()
+def test_the_direct_kernel(emu):
+    """Round 6: k_stage1_direct (sjgpu_fused.hip) -- the split pipeline's scan with additive prefixes and the emission inside it, for PLAIN input (every 16 KiB
+    segment pins its own string state at a control character of its first chunk).  Three documents in four here are NDJSON-like, a third of them broken
+    (control character inside a string, bad UTF-8, unclosed string): the kernel answers exactly what the oracle says -- list, count, flags -- or gives up
+    (SJGPU_F_INTERNAL: the caller re-runs the split pipeline) and either way leaves the self-cleaning workspace as it found it.  Most must complete."""
+    import re
+    for seed, docs, kib in (("11", "80", "300"), ("7", "24", "2500"), ("2026", "60", "700")):
+        p = subprocess.run([emu, seed, docs, kib, "direct"], capture_output=True, timeout=1800)
+        out = p.stdout.decode()
+        assert p.returncode == 0 and f"{docs} documents" in out and " 0 mismatches" in out, (out[-500:], p.stderr.decode()[-3000:])
+        m = re.search(r"direct: (\d+) completed, (\d+) gave up", out)
+        assert m and int(m.group(1)) >= int(docs) // 2 and int(m.group(2)) >= 1, out[-300:]
 
 
 @pytest.mark.parametrize("part", [1, 2, 3, 4])
