@@ -64,9 +64,18 @@ __device__ __forceinline__ void desc_store(u64 *p, u64 v) { __hip_atomic_store(p
 // control word, not into the result: the result needs no clearing either (its other two fields are written by the last TILE's owner).
 // The host clears once, when the workspace is allocated, and in front of the first call after anything that makes the state doubtful -- a HIP error on the
 // context, a chain that gave up, a traced run (sjgpu_ctx::ws_dirty, sjgpu_capi.hip).
-constexpr u32 FUSED_CTL_WORDS = 2; // u64 words behind the descriptors
+constexpr u32 FUSED_CTL_WORDS = FUSED_WORKSPACE_EXTRA_WORDS; // u64 words behind the descriptors: [ticket, done][flags, -] ... and, a 128-byte line further, the second ticket counter
 __device__ __forceinline__ u32 *ctl_done(u32 *ticket) { return ticket + 1; }
 __device__ __forceinline__ u32 *ctl_flags(u32 *ticket) { return ticket + 2; }
+// Tickets from TWO counters (round 6, A/B: env SJGPU_TWO_TICKETS): workgroups with an even blockIdx draw the even tiles, the others the odd ones.  Atomics on ONE
+// address are served at ~30 ns each on this part (profiles/r06_direct_ab.txt), k_minify_onchip draws 16 384 tickets per GiB in ~450 us: two counters in two lines
+// halve what each has to serve.  Progress: a tile still waits only for smaller tiles; those of the other stream are drawn by workgroups that wait for nobody
+// larger, so the smallest unfinished tile of either stream always moves.
+__device__ __forceinline__ u32 draw_ticket(u32 *ticket, bool two) {
+  if (!two) { return atomicAdd(ticket, 1u); }
+  const u32 odd = blockIdx.x & 1u;
+  return 2u * atomicAdd(ticket + 32u * odd, 1u) + odd;
+}
 // all threads of the workgroup, behind its last tile
 template <u32 THREADS>
 __device__ __forceinline__ void leave_and_clean(u64 *desc, u32 ntiles, u32 *ticket, scan_result_dev *result) {
@@ -559,14 +568,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   // barriers and read behind the second.  A wave that has emitted starts loading its next span at once -- which pays for minify and costs stage 1 on dense
   // output 2 % (its waves' emission phases fall out of step): the launcher keeps the third barrier for stage 1 (CARRY_DEBUG_TOP_BARRIER, launch_fused).
   const bool top_barrier = (org.carry & CARRY_DEBUG_TOP_BARRIER) != 0;
-  if (threadIdx.x == 0 && early) { sh_tile[0] = atomicAdd(ticket, 1u); }
+  const bool two_tickets = (org.carry & CARRY_DEBUG_TWO_TICKETS) != 0 && gridDim.x >= 2u; // (both parities need a workgroup)
+  if (threadIdx.x == 0 && early) { sh_tile[0] = draw_ticket(ticket, two_tickets); }
   lds_writes_done();
   __syncthreads();
   for (u32 iter = 0;; iter++) {
     const u32 cur = iter & 1u, cw = iter % 3u, pw = (iter + 2u) % 3u; // ticket / aggregate slot; summary rows of this iteration's tile and of the pending one
     SJ_PSTAMP(0);
     if (!early) {
-      if (threadIdx.x == 0) { sh_tile[cur] = atomicAdd(ticket, 1u); }
+      if (threadIdx.x == 0) { sh_tile[cur] = draw_ticket(ticket, two_tickets); }
       lds_writes_done();
       __syncthreads();
     } else if (top_barrier) {
@@ -576,7 +586,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const bool have = tile < ntiles;
     const bool pend = pend_tile != NO_TILE;
     if (!have && !pend) { break; }
-    if (threadIdx.x == 0 && have && early) { next_ticket = atomicAdd(ticket, 1u); } // consumed at the end of this iteration
+    if (threadIdx.x == 0 && have && early) { next_ticket = draw_ticket(ticket, two_tickets); } // consumed at the end of this iteration
     SJ_PSTAMP(1);
 
     // ---- scan the new tile into the register FIFO ------------------------------------------------------------
@@ -839,7 +849,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
   u64 pa0 = 0, pa1 = 0, pb0 = 0, pb1 = 0; // the pending tile's masks: droppable-if-outside-a-string, in-string (relative)
   u32 next_ticket = 0;
   const bool top_barrier = (org.carry & CARRY_DEBUG_TOP_BARRIER) != 0; // (round 6: two barriers per iteration -- see k_fused_pipelined)
-  if (threadIdx.x == 0) { sh_tile[0] = atomicAdd(ticket, 1u); }
+  const bool two_tickets = (org.carry & CARRY_DEBUG_TWO_TICKETS) != 0 && gridDim.x >= 2u; // (both parities need a workgroup)
+  if (threadIdx.x == 0) { sh_tile[0] = draw_ticket(ticket, two_tickets); }
   lds_writes_done();
   __syncthreads();
   for (u32 iter = 0;; iter++) {
@@ -849,7 +860,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const bool have = tile < ntiles;
     const bool pend = pend_tile != NO_TILE;
     if (!have && !pend) { break; }
-    if (threadIdx.x == 0 && have) { next_ticket = atomicAdd(ticket, 1u); }
+    if (threadIdx.x == 0 && have) { next_ticket = draw_ticket(ticket, two_tickets); }
 
     // ---- scan the new tile; its bytes stay in wa / wb until the pending tile has left the LDS ------------------------
     phase_prio(prio_policy, 0);
@@ -1349,6 +1360,11 @@ static const char *launch_fused(int op, const uint8_t *buf, uint64_t len, uint64
     // without, one process (profiles/r06_pipelined_ab.txt): minify 467 -> 456 us per GiB without it (a wave that has compacted its chunks starts loading at
     // once), stage 1 on dense output 471 -> 480 WITH it gone (its emission phases fall out of step), sparse output 331 -> 329.  So: stage 1 keeps it,
     // minify does not; env SJGPU_TOP_BARRIER=0 / 1 forces either.
+    // tickets from two counters (draw_ticket): measured in one process (profiles/r06_pipelined_ab.txt): minify 456 -> 451 us per GiB, stage 1 472 -> 469 on large_random,
+    // 333 -> 328 on NDJSON, 1104 -> 1124 on deep nesting (one offset per byte: its emission phases want the tiles in step).  So: minify takes two, stage 1 one;
+    // env SJGPU_TWO_TICKETS=0 / 1 forces either.
+    static const int two_tickets_env = []() { const char *v = std::getenv("SJGPU_TWO_TICKETS"); return v ? (v[0] != '0' ? 1 : 0) : -1; }();
+    if (two_tickets_env >= 0 ? two_tickets_env == 1 : op == 1) { org.carry |= CARRY_DEBUG_TWO_TICKETS; }
     static const int top_barrier_env = []() { const char *v = std::getenv("SJGPU_TOP_BARRIER"); return v ? (v[0] != '0' ? 1 : 0) : -1; }();
     if (top_barrier_env >= 0 ? top_barrier_env == 1 : op == 0) { org.carry |= CARRY_DEBUG_TOP_BARRIER; }
     static const bool late_lookback = std::getenv("SJGPU_LATE_LOOKBACK") != nullptr; // A/B switch: the look-back behind the scan's barrier (rounds 1-5)

@@ -89,6 +89,7 @@ constexpr uint32_t CARRY_DEBUG_LATE_TICKET = 0x100u; // A/B switch of the pipeli
 constexpr uint32_t CARRY_DEBUG_NO_SPAN_HINT = 0x200u; // A/B switch: emission counts the span itself (env SJGPU_NO_SPAN_HINT)
 constexpr uint32_t CARRY_DEBUG_LATE_LOOKBACK = 0x800u; // A/B switch of the pipelined kernels: the pending tile's look-back BEHIND the scan's barrier, as in rounds 1-5 (env SJGPU_LATE_LOOKBACK)
 constexpr uint32_t CARRY_DEBUG_TOP_BARRIER = 0x1000u;  // A/B switch of the pipelined kernels: the third barrier, at the loop top, as in rounds 1-5 (env SJGPU_TOP_BARRIER)
+constexpr uint32_t CARRY_DEBUG_TWO_TICKETS = 0x2000u;  // A/B switch of the pipelined kernels: tickets from two counters, even / odd tiles by the workgroup's parity (env SJGPU_TWO_TICKETS)
 constexpr uint32_t CARRY_DEBUG_QUEUE_UTF8 = 0x400u;   // A/B switch: dense non-ASCII chunks are queued like sparse ones (env SJGPU_UTF8_QUEUE_ONLY)
 // A scan covers bytes [begin, len) of a buffer whose bytes [0, begin) are resident too (the look-back of escapes,
 // previous scalar and UTF-8 state reads them); begin is a multiple of RANGE_ALIGN.  Offsets stay relative to byte 0
@@ -120,7 +121,7 @@ void launch_validate_utf8(const uint8_t *buf, uint64_t len, scan_result_dev *res
 // clean: *result, the descriptors and the control words behind them are all zero on the device.  Every (un-traced) single-pass kernel leaves them
 // that way when it ends -- its last workgroup to leave clears what the call used (sjgpu_fused.hip: leave_and_clean) -- so a caller that cleared the
 // whole workspace once, when it allocated it, passes true from then on and a call is ONE dispatch; with false the launcher clears in front of the kernel.
-constexpr uint32_t FUSED_WORKSPACE_EXTRA_WORDS = 2; // control words: ticket, workgroups gone, flags
+constexpr uint32_t FUSED_WORKSPACE_EXTRA_WORDS = 18; // control words: [ticket, workgroups gone][flags, -], fourteen words of distance, [second ticket counter] (its own 128-byte line)
 const char *launch_stage1_fused(const uint8_t *buf, uint64_t len, uint64_t *desc, uint32_t *idx, uint64_t idx_words,
                                 scan_result_dev *result, scan_origin org, uint32_t max_workgroups, hipStream_t stream,
                                 hipEvent_t *ev, bool clean = false, uint8_t *tok = nullptr); // tok: the token-byte stream beside the offsets (round 6: gathered at emission) // -> name of the scan kernel launched

@@ -186,7 +186,7 @@ struct workspace {
       masks.assign(nseg * (SEG_BYTES / BLOCK_BYTES), uint4{0, 0, 0, 0});
       summ.assign(nseg + num_groups(cap), seg_summary{0, 0, 0, 0});
       pref.assign(nseg, seg_prefix{0, 0});
-      result_and_desc.assign(2 + num_fused_tiles(cap) * 4 + 8, 0);
+      result_and_desc.assign(2 + num_fused_tiles(cap) * 4 + 8 + FUSED_WORKSPACE_EXTRA_WORDS, 0);
       esc.assign(SEGMENT_BYTES_TABLE, 0); // launch_string_parity: one byte per segment
       idx.assign(cap + 16, 0);
       tokstage.assign(size_t(nseg) * SEG_BYTES + 64, 0);
