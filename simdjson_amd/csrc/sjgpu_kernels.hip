@@ -465,7 +465,11 @@ __global__ __launch_bounds__(64) void k_stage1_emit(const u64 *__restrict__ mask
     const u32 e = lane < ncand ? list[lane] : 0u; // requested before the prefix fold: one round trip for both
     const seg_prefix pf = segment_prefix(summ, gpref, seg, lane);
     const xs_step t = xs_apply(own.flags & SF_PARITY, own.xw, pf.in_string & 1u, pf.in_string >> 1); // (no patched bit: sparse segments have d = 0)
+#ifndef SJGPU_SELFTEST_SPARSE_IGNORES_HYPOTHESIS // tests/test_kernels_emu.py: with the selection dropped the sparse-segment documents must FAIL
     const bool keep = lane < ncand && (resolved || (e >> 31) == t.se); // structural = candidate & ~(string_tail ^ hypothesis)
+#else
+    const bool keep = lane < ncand && (resolved || (e >> 31) == 0u);
+#endif
     const u64 km = __ballot(keep);
     const u64 at = u64(pf.base) + u32(popc64(km & lanemask_lt(lane)));
     if (u64(pf.base) + u32(popc64(km)) > idx_words) {

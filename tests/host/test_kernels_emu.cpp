@@ -85,11 +85,13 @@ static void value(bytes &d, int depth) { // a valid JSON value
     d.push_back('}');
   }
 }
+static bool g_sparse_only = false;  // the "sparse" road: every document is of kind 11
 static bool g_mostly_plain = false; // the "direct" road: three documents in four are NDJSON-like (plain: every 16 KiB segment meets a newline in its first chunk)
 static bytes make_document(size_t target) {
   bytes d;
-  uint32_t kind = rnd_below(11);
+  uint32_t kind = rnd_below(12);
   if (g_mostly_plain && rnd_below(4)) { kind = 1; }
+  if (g_sparse_only) { kind = 11; }
   while (d.size() < target) {
     switch (kind) {
     case 0: soup(d, 1 + rnd_below(400)); break;
@@ -150,6 +152,28 @@ static bytes make_document(size_t target) {
       d.push_back('"');
       for (uint32_t i = 0, n = rnd_below(3000); i < n; i++) { put(d, rnd_below(2) ? "\xe6\x97\xa5" : "\xd0\x96"); if (rnd_below(300) == 0) { d.push_back(0xE6); } }
       put(d, "\"\n");
+      break;
+    }
+    case 11: { // round 6: a HANDFUL of candidates per 16 KiB segment -- k_stage1_summarize ships such segments as a list of <= 32 words, not as planes.  Segments
+      // are filled with filler (spaces: nothing; letters: one scalar run; the inside of a string; backslashes in a string) and exactly k candidates are
+      // dropped at random places, k around the limit: 0, 1, 2, 31, 32, 33, 40, 64; some segments get a newline in their first chunk (resolved), some none
+      // (two hypotheses: the list carries the string_tail bits), quotes open and close across segments so that both hypotheses are selected
+      static const uint32_t counts[] = {0, 1, 2, 3, 16, 31, 32, 32, 33, 34, 40, 64, 200};
+      const size_t seg_end = (d.size() / SEG_BYTES + 1) * SEG_BYTES;
+      const uint32_t k = counts[rnd_below(sizeof counts / sizeof counts[0])];
+      const uint32_t filler = rnd_below(4);
+      const uint8_t fill = filler == 0 ? ' ' : (filler == 1 ? 'x' : (filler == 2 ? 'y' : '\\'));
+      if (filler >= 2 && rnd_below(2)) { d.push_back('"'); } // the rest of the segment lies inside a string (or closes one that was open)
+      const size_t begin = d.size();
+      d.insert(d.end(), seg_end > begin ? seg_end - begin : 0, fill);
+      if (fill == '\\' && ((seg_end - begin) & 1u)) { d.back() = 'z'; } // (an even run: what follows is not escaped)
+      if (rnd_below(2) && seg_end - begin > 64) { d[begin + rnd_below(uint32_t(std::min<size_t>(seg_end - begin, 4000)))] = '\n'; } // resolved -- unless inside a string: then the document is an error and nobody compares
+      for (uint32_t i = 0; i < k && seg_end - begin > 8; i++) {
+        const size_t at = begin + 2 + rnd_below(uint32_t(seg_end - begin - 4));
+        static const char cands[] = ",:[]{}\"\"17";
+        d[at] = uint8_t(cands[rnd_below(sizeof cands - 1)]);
+        if (rnd_below(3) == 0) { d[at - 1] = ' '; } // a scalar behind whitespace starts a token
+      }
       break;
     }
     default: // one enormous backslash run
@@ -306,6 +330,7 @@ int main(int argc, char **argv) {
   const std::string what = argc > 4 ? argv[4] : "all";
   const bool all = what == "all";
   g_mostly_plain = what == "direct";
+  g_sparse_only = what == "sparse";
   workspace w;
   size_t total_bytes = 0;
   for (long k = 0; k < docs; k++) {
@@ -330,7 +355,7 @@ int main(int argc, char **argv) {
     const expected e = oracle(doc);
     w.fit(doc);
     const scan_origin whole{0, 0, 0};
-    if (all || what == "split") {
+    if (all || what == "split" || what == "sparse") {
       scan_origin org = whole;
       std::fill(w.idx.begin(), w.idx.begin() + len + 8, 0xDEADBEEFu);
       launch_stage1(w.in, len, w.masks.data(), w.summ.data(), w.pref.data(), w.idx.data(), len + 3, w.result(), org, nullptr, nullptr);

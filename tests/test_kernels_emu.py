@@ -54,6 +54,25 @@ def test_the_other_workgroup_shapes_of_the_single_pass_kernels(emu, waves):
     assert "60 documents" in p.stdout.decode() and " 0 mismatches" in p.stdout.decode()
 
 
+def test_segments_with_a_handful_of_candidates(emu):
+    """Round 6: k_stage1_summarize ships a segment with at most 32 candidates as a LIST (one word per candidate: offset in the segment, bit 31 its string_tail bit)
+    instead of two mask planes, k_stage1_emit selects by hypothesis and copies.  Documents made of such segments only: 0, 1, 2, 31, 32, 33, 34, 64 ... candidates per
+    16 KiB, in whitespace, inside scalar runs, inside strings, behind backslashes; resolved by a newline in the first chunk or not (then the list carries both
+    hypotheses); quotes opening and closing across segments, so that both hypotheses get selected -- the split pipeline against the oracle, list and flags."""
+    for seed, docs, kib in (("5", "60", "400"), ("77", "30", "1500")):
+        p = subprocess.run([emu, seed, docs, kib, "sparse"], capture_output=True, timeout=1800)
+        assert p.returncode == 0, (p.stdout.decode()[-500:], p.stderr.decode()[-3000:])
+        assert f"{docs} documents" in p.stdout.decode() and " 0 mismatches" in p.stdout.decode()
+
+
+def test_the_sparse_documents_reach_the_list_road(tmp_path):
+    """... and the check has teeth: with the list road's selection by hypothesis compiled out (every segment taken as if it began outside a string) the same
+    documents must fail -- they do reach the list road, with segments that begin inside strings."""
+    exe = _build(tmp_path, ("-DSJGPU_SELFTEST_SPARSE_IGNORES_HYPOTHESIS",))
+    p = subprocess.run([exe, "5", "60", "400", "sparse"], capture_output=True, timeout=1800)
+    assert p.returncode != 0 and "MISMATCH" in p.stderr.decode(), "the split pipeline passes without the list road's selection"
+
+
 def test_the_direct_kernel(emu):
     """Round 6: k_stage1_direct (sjgpu_fused.hip) -- the split pipeline's scan with additive prefixes and the emission inside it, for PLAIN input (every 16 KiB
     segment pins its own string state at a control character of its first chunk).  Three documents in four here are NDJSON-like, a third of them broken
