@@ -640,8 +640,8 @@ def leg_tape(cx):
         alg = L + 4 * (n + 1) + 8 * tw + sb
         leg = {"workload": f"{kind} {L} B, {n} structurals -> {tw} tape words + {sb} B of string records (dom::document of the reference)",
                "gpu_ms_per_call": round(gpu_ms, 3), "first_reps_ms_per_call": round(first_ms, 3), "timing": FIRST_REPS_NOTE, "value": round(L / gpu_ms / 1e6, 1),
-               "unit": "GB/s of document", "kernel": "k_tok_classify / scan_sums + string buffer (" + ("stream compaction: k_strs_count / resolve / write" if p.string_path() == 1 else "per-string walk")
-                         + ") + k_tok_apply (tape positions, string and atom words) + k_radix_hist / scatter (container ordinals) + k_tape_match / rules / atoms / numbers + 1 scan (sjgpu_tape.hip, "
+               "unit": "GB/s of document", "kernel": "k_tok_stage (token bytes, atoms and numbers from one staged pass over the document) / scan_sums + string buffer (" + ("stream compaction: k_strs_count / resolve / write" if p.string_path() == 1 else "per-string walk")
+                         + ") + k_tok_apply (tape positions, string, atom and number words) + k_radix_hist / scatter (container ordinals) + k_tape_match / rules + 1 scan (sjgpu_tape.hip, "
                            "sjgpu_string_stream.hip)",
                "roofline": {"bound": "hbm", "achieved": round(alg / gpu_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / gpu_ms / 1e6 / HBM_PEAK_GBS, 4),
                             "algorithmic_bytes_per_launch": alg,

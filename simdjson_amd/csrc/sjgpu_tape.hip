@@ -13,19 +13,19 @@
 // The first error of the serial walk is the smallest (list index, rank) over all tokens that break their rule: one atomicMin.
 //
 // Passes (all asynchronous on the caller's stream; one 32-byte result is read back by the caller):
-//   k_tok_classify / k_tok_scan_sums   the byte of every token, the block totals of the six per-token counters
+//   k_tok_stage / k_tok_scan_sums      the byte of every token, the block totals of the six per-token counters -- and, from the same staged bytes of the
+//                     document, the spelling of true / false / null and the VALUES of the number tokens (round 6: the document is fetched once for all of them)
 //   (the string buffer: sjgpu_strings.hip / sjgpu_string_stream.hip, which take the number of string tokens from here)
 //   k_tok_apply       tape position and nesting depth of every token in one sweep over the token bytes (the depth stays in registers: what it
 //                     decides -- the root value has ended, the nesting limit -- is said here); the tape words of the strings (the
-//                     k-th string token's record is the k-th of the buffer) and of the atoms; (level, kind, token) of every bracket and
-//                     comma into the sort's input; numbers and atoms into lists
+//                     k-th string token's record is the k-th of the buffer), of the atoms and of the numbers (values parked by k_tok_stage);
+//                     (level, kind, token) of every bracket and comma into the sort's input
 //   radix passes      stable LSD radix sort on the level, 6 bits per pass: histogram, scan, scatter   1 wave / 2048 elements;
 //                     the second pass only runs for documents nested 64 deep and more
 //   (container ordinal per sorted element and sorted position of every open: written by the sort's last scatter from a second histogram)
 //   k_tape_match      commas judge the two tokens behind them by their container's kind; closes write BOTH bracket words (count, partner
 //                     index), kinds checked
 //   k_tape_rules      per token: the part of the walk's rule a token can check from the two bytes in front of it; root words
-//   k_tape_atoms / k_tape_numbers    the spelling of true / false / null; the number words, one listed token per lane (lists by k_tok_apply)
 //   k_tape_slow_numbers  the handful of number tokens whose rounding needs exact big-integer arithmetic (sj_number.h)
 // Parity: tests/test_gpu_parity.py::test_tape_* against the live reference's dom::parser::parse (tape and string_buf word for word,
 // error codes of broken documents); the same steps run on the CPU in tests/host/test_tape_model.cpp.
@@ -119,7 +119,7 @@ __global__ void k_tape_init(tape_result_dev *__restrict__ res, u32 *__restrict__
 // Their exclusive prefix sums are the token's tape position, its slot in the sort's input, its ordinal among the strings and
 // (opens - closes) its nesting depth.  The first version wrote three int arrays and ran the generic three-kernel scan over each
 // (profiles/r03_pmc_summary.txt: 2.6 GB of the 9.2 GB a twitter-like call moved); all five sums are functions of ONE byte per token,
-// so here a block of 4096 tokens adds them up while it fetches its token bytes (k_tok_classify) and reads the 4 KiB of bytes once more
+// so here a block of 4096 tokens adds them up while it fetches its token bytes (k_tok_stage) and reads the 4 KiB of bytes once more
 // for the prefixes (k_tok_apply) -- nothing else.  Inside a block the five counters travel packed in three dwords (each field < 2^16).
 constexpr u32 TS_THREADS = 256, TS_ROW = TS_THREADS * 4, TS_ROWS = 4, TS_BLOCK = TS_ROW * TS_ROWS, TS_SUMS = 6;
 // (tok_packed / tok_contribution, the kinds of the sort's elements and the placement of the value lists live in sj_tape_rules.h: the CPU
@@ -128,48 +128,278 @@ typedef u32 __attribute__((aligned(1))) u32_unaligned_t;
 // the four token bytes i0 ... i0 + 3 (tokc is two bytes off the dword grid: one unaligned load)
 __device__ __forceinline__ u32 four_tokens(const u8 *__restrict__ tokc, u64 i0) { return *reinterpret_cast<const u32_unaligned_t *>(tokc + 2 + i0); }
 
+// ---- the staged token front (round 6) ------------------------------------------------------------------------------------------------------------
+// Rounds 3-5 fetched the document once per kernel that looks at a token's bytes: k_tok_classify (one byte per token: a 128-byte line each, the whole
+// document on dense lists), k_tape_numbers (32 bytes per listed number behind two dependent round trips -- list entry, idx[i], the bytes --: 93 % of its
+// cycles waiting for memory), k_tape_atoms (the same for true / false / null): 0.95 GB of the 3.4 GB a twitter-like call moved and 1.35 of the 5.8 of
+// large_random, 345 / 680 us of 1300 / 2230 (profiles/r06_pmc_summary.txt, r06_final_kernel_stats.txt).  The list is SORTED, so the bytes a run of
+// consecutive tokens needs are one contiguous span of the document.  Here a wave owns SG_WAVE_TOKENS consecutive tokens (one row of k_tok_apply), parks
+// their offsets in LDS, and works through them in GROUPS of whole rows of 64 tokens: as many rows as have their span (first token ... last token + SG_OVER
+// bytes) inside SG_WINDOW bytes are staged with coalesced 16-byte loads into the wave's LDS window, and everything that asks for a token's bytes asks the
+// window: the token byte (-> tokc and the six counters, as before), the spelling of the atoms (eight bytes at the token, compared as words), and the
+// NUMBERS -- the group's number tokens are gathered in an LDS list (ballot + mbcnt: list order) and parsed one per lane with every lane busy (parse_number,
+// sj_number.h, through a 32-byte register window filled from LDS).  Nothing waits for a second round trip and the document comes in once, line by line.
+// A row whose 64 tokens span more than the window (sparse text: more than ~60 bytes per token) is read in place like before -- there a gather touches few
+// lines per token anyway; a number that runs over the staged bytes (more than SG_OVER digits) continues from memory.
+// Where the values go: a number's tape position is not known yet (k_tok_scan_sums comes next), so the parsed value waits in numbits / numtype at
+// [first token of the wave + ordinal of the number inside the wave's 1024 tokens]; k_tok_apply, whose rows are the same 1024 tokens, knows that ordinal
+// from its own scan and writes both tape words.  The lists of rounds 3-5 (number_list, value_list: 8 bytes per value token written and read back) are gone.
+constexpr u32 SG_WAVE_TOKENS = TS_ROW, SG_ROWS = SG_WAVE_TOKENS / 64u;
+constexpr u32 SG_OVER = 64; // bytes staged behind a group's last token: the longest number that is parsed without leaving the window
+#ifndef SJGPU_STAGE_WINDOW
+#define SJGPU_STAGE_WINDOW 4096
+#endif
+constexpr u32 SG_WINDOW = SJGPU_STAGE_WINDOW; // bytes of LDS per wave (a multiple of 1024: every lane stores 16 bytes per staging step)
+constexpr u32 SG_STEPS = SG_WINDOW / 1024u;
+static_assert(SG_WINDOW % 1024u == 0 && SG_WINDOW >= 1024u, "a staging step is 64 lanes x 16 bytes");
+
+// The document through the wave's window: bytes [a0, a0 + span) are staged (bytes at or beyond len as the spaces of a padded_string).  A byte is ONE LDS
+// read (ds_read_u8) and three VALU instructions, without a branch: an offset beyond the staged bytes is clamped to the byte BEHIND them, a zero, which ends
+// every digit run -- and the accessor remembers how far it was asked (`reach`): a token that asked beyond the window is parsed AGAIN, from memory, by the
+// caller (wide_window_bytes; more than SG_OVER bytes of number: a handful per document at most).  The first version kept 32 bytes of the token in registers
+// (the window of k_tape_numbers, filled from LDS) and paid ~15 VALU instructions per byte for the selects and the 64-bit shift that pick a byte out of
+// them, the second branched per byte between LDS and memory (600 global loads and 950 branches in the kernel's code): the kernel is VALU-bound
+// (profiles/r06_tape_stage.txt: 251 M / 214 M instructions per large_random call at four cycles each, 59 % of the SIMDs' time).
+struct staged_bytes {
+  const u8 *win; // the window (LDS): its first byte is byte a0 of the document, win[span] = 0
+  u32 a0, span;
+  mutable u32 reach = 0; // the largest offset asked for
+  __device__ __forceinline__ u32 byte(u32 pos) const {
+    const u32 off = pos - a0;
+    reach = off > reach ? off : reach;
+    return u32(win[off < span ? off : span]);
+  }
+};
+// bytes [a0, a0 + bytes) of the document into the window (a0 and bytes: multiples of 16, bytes <= SG_WINDOW): all loads issued, then all stores
+__device__ __forceinline__ void stage_window(const u8 *__restrict__ buf, u32 len, u32 a0, u32 bytes, u32 lane, uint4 *__restrict__ win) {
+  uint4 v[SG_STEPS];
+#pragma unroll
+  for (u32 j = 0; j < SG_STEPS; j++) {
+    const u32 off = 1024u * j + 16u * lane;
+    v[j] = make_uint4(0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u);
+    if (off < bytes) {
+      const u64 p = u64(a0) + off;
+      if (p + 16u <= len) { v[j] = *reinterpret_cast<const uint4 *>(buf + p); }
+      else if (p < len) { // the input ends inside this piece: what lies behind it reads as spaces
+        u32 w[4] = {0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
+        for (u32 k = 0; k < 16u && p + k < len; k++) { w[k >> 2] = (w[k >> 2] & ~(0xFFu << (8u * (k & 3u)))) | (u32(buf[p + k]) << (8u * (k & 3u))); }
+        v[j] = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+  }
+#pragma unroll
+  for (u32 j = 0; j < SG_STEPS; j++) {
+    const u32 off = 1024u * j + 16u * lane;
+    if (off < bytes) { win[off >> 4] = v[j]; }
+  }
+}
+// the eight bytes of the document at p (bytes at or beyond len: spaces), read in place
+__device__ __forceinline__ uint2 eight_bytes_in_place(const u8 *__restrict__ buf, u32 len, u32 p) {
+  typedef u64 __attribute__((aligned(1))) u64_unaligned;
+  if (u64(p) + 8u <= len) {
+    const u64 x = *reinterpret_cast<const u64_unaligned *>(buf + p);
+    return make_uint2(u32(x), u32(x >> 32));
+  }
+  u64 x = 0;
+  for (u32 k = 0; k < 8; k++) { x |= u64(u64(p) + k < len ? u32(buf[p + k]) : 0x20u) << (8u * k); }
+  return make_uint2(u32(x), u32(x >> 32));
+}
+// true / false / null at a token whose first eight bytes are {lo, hi}: 0, or the error the reference's visitor raises (atomparsing.h: the letters, then a
+// structural or whitespace byte; atom_matches of sj_number.h says the same byte by byte -- tests/host/test_tape_rules.cpp compares the two)
+__device__ __forceinline__ u32 atom_error_of(u32 lo, u32 hi) {
+  const u32 c = lo & 0xFFu;
+  if (c == 't') { return (lo == 0x65757274u && !not_structural_or_whitespace(hi & 0xFFu)) ? 0u : u32(SJ_T_ATOM_ERROR); }
+  if (c == 'f') { return (lo == 0x736C6166u && (hi & 0xFFu) == 'e' && !not_structural_or_whitespace((hi >> 8) & 0xFFu)) ? 0u : u32(SJ_F_ATOM_ERROR); }
+  if (c == 'n') { return (lo == 0x6C6C756Eu && !not_structural_or_whitespace(hi & 0xFFu)) ? 0u : u32(SJ_N_ATOM_ERROR); }
+  return 0u;
+}
+
+// a parsed number token i: its error, or its value where k_tok_apply will look for it
+__device__ __forceinline__ void park_number(const number_value &v, u32 i, u64 at, u64 *__restrict__ numbits, u8 *__restrict__ numtype, u32 *__restrict__ slow_list,
+                                            u32 slow_cap, tape_result_dev *__restrict__ res) {
+  if (v.error) { report_error(res, error_key(i, 2, v.error)); return; }
+  numbits[at] = v.bits; // sign only when v.slow: k_tape_slow_numbers completes the word on the tape
+  numtype[at] = u8(v.type);
+  if (v.slow) {
+    const u32 s = atomicAdd(&res->slow_numbers, 1u);
+    if (s < slow_cap) { slow_list[s] = i; }
+  }
+}
 // tokc holds the token bytes with TWO zero bytes in front and behind: tokc[i + 2] = byte of token i (k_tape_rules looks two tokens back
 // and one ahead).  The same sweep leaves the block totals: sums[k * nblocks + block], k = tape words, sort flags, strings, opens,
 // closes, numbers.
-// TOK (round 5): the token bytes come from the stream stage 1 wrote beside the list (sjgpu_stage1_tokens_device) -- a coalesced byte per token; neither the
-// list nor the document is fetched (the gather below reads the list AND a 128-byte line of the document per token: 0.40 GB per 256 MiB twitter-like call)
-template <bool TOK>
-__global__ __launch_bounds__(TS_THREADS) void k_tok_classify(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, u8 *__restrict__ tokc,
-                                                            int *__restrict__ sums, u32 nblocks, const u8 *__restrict__ tok) {
+// LDS per wave: the tokens' offsets as 16-bit distances from the first token of their row of 64 (a row that spans 64 KiB is read in place and asks the list
+// again), the starts of the rows, the number list, the window: 8.3 KiB with a 4 KiB window -- four workgroups per CU.
+#ifndef SJGPU_STAGE_OCC
+#define SJGPU_STAGE_OCC 4
+#endif
+__global__ __launch_bounds__(TS_THREADS, SJGPU_STAGE_OCC) void k_tok_stage(const u8 *__restrict__ buf, u32 len, const u32 *__restrict__ idx, u32 n, u8 *__restrict__ tokc,
+                                                            int *__restrict__ sums, u32 nblocks, u64 *__restrict__ numbits, u8 *__restrict__ numtype,
+                                                            u32 *__restrict__ slow_list, u32 slow_cap, tape_result_dev *__restrict__ res) {
   __shared__ u32 sh[3][TS_THREADS / 64];
-  __shared__ unsigned short sh_props[256]; // what a token's byte IS, as bits (token_props_of): one LDS read instead of ~20 compares and mask operations per token
-  static_assert(TS_THREADS == 256, "one table entry per thread");
+  __shared__ uint4 sh_tab[256]; // what a token's byte IS: its packed contribution to the six counters (tok_packed) and its properties (token_props_of) -- one 16-byte
+                                // LDS read per token instead of ~20 compares, or of the nine VALU instructions that unpack the contribution from the properties
+  __shared__ unsigned short sh_rel[TS_THREADS / 64][SG_WAVE_TOKENS];  // the wave's offsets, relative to the first token of their row (0xFFFF: 64 KiB and more)
+  __shared__ unsigned short sh_list[TS_THREADS / 64][SG_WAVE_TOKENS]; // its number tokens (which of its tokens), in list order
+  __shared__ u32 sh_row[TS_THREADS / 64][32];                        // where its rows begin
+  __shared__ uint4 sh_win[TS_THREADS / 64][SG_WINDOW / 16u + 1u];     // its window
+  static_assert(TS_THREADS == 256 && TS_BLOCK == 4u * SG_WAVE_TOKENS && SG_ROWS <= 31u, "one table entry per thread; a wave per row of k_tok_apply");
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  sh_props[tid] = (unsigned short)token_props_of(tid);
+  {
+    const u32 x = token_props_of(tid);
+    const tok_packed pk = tok_contribution_of_props(x);
+    sh_tab[tid] = make_uint4(pk.a, pk.b, pk.c, x);
+  }
   lds_writes_done();
   __syncthreads();
-  const u64 block0 = u64(blockIdx.x) * TS_BLOCK;
   if (blockIdx.x == 0 && tid == 0) { tokc[0] = 0; tokc[1] = 0; tokc[n + 2] = 0; tokc[n + 3] = 0; }
-  // One token per lane and row, sixteen rows of 256: the 64 lanes of a wave fetch the bytes of 64 CONSECUTIVE tokens with one instruction.  Rounds 3-4a
-  // gave a thread four consecutive tokens (one 16-byte list load): a wave's gather then reached over four times the span with a quarter of the lanes
-  // per cache line and came back to every line four times (scripts/micro/gather_lab.hip: +34 % on a sparse list).
-  constexpr u32 CL_ROWS = TS_BLOCK / TS_THREADS;
-  u32 pos[CL_ROWS];
-#pragma unroll
-  for (u32 row = 0; row < CL_ROWS; row++) {
-    const u64 i = block0 + u64(row) * TS_THREADS + tid;
-    pos[row] = i < n ? (TOK ? u32(tok[i]) : idx[i]) : 0xFFFFFFFFu; // TOK: the byte itself
-  }
+  const u64 t0_64 = u64(blockIdx.x) * TS_BLOCK + u64(wave) * SG_WAVE_TOKENS;
+  const u32 cnt = t0_64 < n ? (n - u32(t0_64) < SG_WAVE_TOKENS ? n - u32(t0_64) : SG_WAVE_TOKENS) : 0u; // wave-uniform
+  const u32 t0 = u32(t0_64);
+  unsigned short *const rel = sh_rel[wave];
+  unsigned short *const list = sh_list[wave];
+  u32 *const row_start = sh_row[wave];
+  uint4 *const win = sh_win[wave];
+  const u32 *const win32 = reinterpret_cast<const u32 *>(win);
+  const u8 *const win8 = reinterpret_cast<const u8 *>(win);
+  u8 *const tokc_w = tokc + 2u + t0_64;
+  const u32 *const idx_w = idx + t0_64;
   u32 a = 0, b = 0, c = 0;
+  if (cnt) { // (wave-uniform; a wave without tokens only takes part in the block's sums)
+    const u32 rows = (cnt + 63u) / 64u;
+    u32 E = 0; // lane l < rows: where row l begins; lane rows: where the wave's span ends (behind its last token)
+    {
+      u32 v[SG_ROWS];
 #pragma unroll
-  for (u32 row = 0; row < CL_ROWS; row++) {
-    const u64 i = block0 + u64(row) * TS_THREADS + tid;
-    if (i < n) {
-      const u32 ch = TOK ? pos[row] : (pos[row] < len ? u32(buf[pos[row]]) : 0x20u);
-      tokc[2 + i] = u8(ch);
-      tok_packed p = tok_contribution_of_props(u32(sh_props[ch & 0xFFu]));
-      if (row == 0 && blockIdx.x == 0) { // the root token's number path differs (takes_number_path): one token per document, a branch only block 0 sees
-        if (tid == 0) { p = tok_contribution(ch, true); }
+      for (u32 r = 0; r < SG_ROWS; r++) {
+        const u32 tl = 64u * r + lane;
+        v[r] = tl < cnt ? idx_w[tl] : 0xFFFFFFFFu;
       }
-      a += p.a; b += p.b; c += p.c;
+      const u32 last_row = (cnt - 1u) >> 6, last_lane = (cnt - 1u) & 63u;
+#pragma unroll
+      for (u32 r = 0; r < SG_ROWS; r++) {
+        const u32 first = readlane(v[r], 0);
+        if (lane == r && r <= last_row) { E = first; }
+        if (r == last_row) { // wave-uniform
+          const u32 end = readlane_dyn(v[r], last_lane) + 1u;
+          if (lane == r + 1u) { E = end; }
+        }
+        const u32 d = v[r] - first;
+        rel[64u * r + lane] = (unsigned short)(d < 0xFFFFu ? d : 0xFFFFu);
+      }
+      if (lane <= rows) { row_start[lane] = E; }
+    }
+    wave_lds_fence();
+    const bool first_wave = t0 == 0u; // holds the root token
+    u32 ncount = 0; // number tokens listed so far (wave-uniform)
+    u32 ra = 0;
+#pragma unroll 1
+    while (ra < rows) {
+      const u32 a0 = readlane_dyn(E, ra) & ~15u;
+      // rows ra ... l - 1 fit the window: their last token lies in front of E[l], and SG_OVER bytes from it on are wanted (positions ascend: the lanes that fit
+      // are ra + 1 ... rb)
+      const bool fits = lane > ra && lane <= rows && (E - a0) + (SG_OVER - 1u) + 4u <= SG_WINDOW;
+      const u32 nfit = u32(popc64(__ballot(fits)));
+      const bool staged = nfit != 0u; // wave-uniform
+      const u32 rb = staged ? ra + nfit : ra + 1u;
+      u32 span = 0;
+      if (staged) {
+        const u32 want = (readlane_dyn(E, rb) - a0) + (SG_OVER - 1u) + 4u; // <= SG_WINDOW
+        const u32 bytes = (want + 15u) & ~15u;
+        stage_window(buf, len, a0, bytes, lane, win);
+        span = bytes;
+        if (lane == 0) { reinterpret_cast<u32 *>(win)[bytes >> 2] = 0u; } // what an offset beyond the staged bytes reads (staged_bytes): no digit
+        wave_lds_fence();
+      }
+      const u32 g0 = ncount;
+#pragma unroll 1
+      for (u32 r = ra; r < rb; r++) {
+        const u32 tl = 64u * r + lane;
+        const bool live = tl < cnt;
+        u32 lo, hi;
+        if (staged) {
+          const u32 rs = readlane_dyn(E, r) - a0; // the row's first token inside the window (wave-uniform)
+          const u32 off = live ? rs + u32(rel[tl]) : 0u, sft = off & 3u;
+          const u32 *q = win32 + (off >> 2);
+          const u32 d0 = q[0], d1 = q[1], d2 = q[2];
+          lo = __builtin_amdgcn_alignbyte(d1, d0, sft);
+          hi = __builtin_amdgcn_alignbyte(d2, d1, sft);
+        } else {
+          const uint2 x = eight_bytes_in_place(buf, len, live ? idx_w[tl] : 0u);
+          lo = x.x; hi = x.y;
+        }
+        const u32 ch = lo & 0xFFu;
+        uint4 tab = sh_tab[ch];
+        if (first_wave && r == 0u) { // wave-uniform: the root token's number path differs (takes_number_path) -- one token per document
+          if (lane == 0) {
+            const tok_packed pk = tok_contribution(ch, true);
+            tab.x = pk.a; tab.y = pk.b; tab.z = pk.c;
+          }
+        }
+        if (live) {
+          tokc_w[tl] = u8(ch);
+          a += tab.x; b += tab.y; c += tab.z;
+        }
+        const bool is_number = live && (tab.z >> 16) != 0u;
+        const bool is_atom = live && (tab.w & TP_ATOM) != 0u;
+        if (__ballot(is_atom)) { // wave-uniform: rows without true / false / null skip the spelling
+          const u32 g = is_atom ? atom_error_of(lo, hi) : 0u; // visit_true_atom ..., tape_builder.h:278-329 (the words themselves: k_tok_apply)
+          if (g) { report_error(res, error_key(t0 + tl, 2, g)); }
+        }
+        const u64 nm = __ballot(is_number);
+        const u32 k = __builtin_amdgcn_mbcnt_hi(u32(nm >> 32), __builtin_amdgcn_mbcnt_lo(u32(nm), 0u));
+        if (is_number) { list[ncount + k] = (unsigned short)tl; }
+        ncount += u32(popc64(nm));
+      }
+      wave_lds_fence();
+      // the group's numbers, one per lane: visit_number (tape_builder.h:213-275) = parse_number (numberparsing.h:859-971, sj_number.h).  First from the window;
+      // a token that reaches beyond it -- and every token of a row read in place -- is flagged in the list and parsed from memory in a second sweep.
+      u32 again = staged ? 0u : 1u; // wave-uniform
+#ifdef SJGPU_LAB_SKIP_NUMBERS
+      again = 0;
+#endif
+      if (staged
+#ifdef SJGPU_LAB_SKIP_NUMBERS
+          && false
+#endif
+      ) {
+#pragma unroll 1
+        for (u32 k0 = g0; k0 < ncount; k0 += 64u) {
+          const u32 k = k0 + lane;
+          bool redo = false;
+          if (k < ncount) {
+            const u32 tl = list[k];
+            const u32 p = row_start[tl >> 6] + u32(rel[tl]);
+            const staged_bytes src{win8, a0, span};
+            const number_value v = parse_number_token(src, p, static_cast<bigint *>(nullptr));
+            redo = src.reach >= span;
+            if (redo) { list[k] = (unsigned short)(tl | 0x8000u); }
+            else { park_number(v, t0 + tl, t0_64 + k, numbits, numtype, slow_list, slow_cap, res); }
+          }
+          if (__ballot(redo)) { again = 1u; }
+        }
+      }
+      if (again) { // (wave-uniform, rare in ordinary text)
+        wave_lds_fence();
+#pragma unroll 1
+        for (u32 k0 = g0; k0 < ncount; k0 += 64u) {
+          const u32 k = k0 + lane;
+          if (k < ncount) {
+            const u32 e = list[k], tl = e & 0x7FFFu;
+            if (!staged || (e & 0x8000u)) { // through the 32-byte register window, like k_tape_numbers did
+              const u32 p = idx_w[tl];
+              const wide_window_bytes src{buf, len};
+              src.fill(p);
+              park_number(parse_number_token(src, p, static_cast<bigint *>(nullptr)), t0 + tl, t0_64 + k, numbits, numtype, slow_list, slow_cap, res);
+            }
+          }
+        }
+      }
+      wave_lds_fence(); // (the next group's staging overwrites the window: LDS traffic of one wave stays in order)
+      ra = rb;
     }
   }
-  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); // a wave: at most 64 x 16 tokens x 2 words: the fields do not overflow
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); // a wave: at most 1024 tokens x 2 words: the fields do not overflow
   if (lane == 0) { sh[0][wave] = a; sh[1][wave] = b; sh[2][wave] = c; }
   __syncthreads();
   if (tid == 0) {
@@ -216,19 +446,18 @@ __global__ __launch_bounds__(1024) void k_tok_scan_sums(int *__restrict__ sums, 
     __syncthreads();
   }
 }
-// tpos[i] for i in [0, n] (entry n = the total).  The tokens that write a value word are LISTED by kind, so that each kind is
-// finished by a dense kernel of its own instead of a branch of a per-token kernel: numbers (number_list, m_out[2] of them), strings
-// (value_list from the front: the k-th string token, m_out[4] of them = its ordinal in the string buffer) and the one-word rest -- atoms, and
-// bytes that are no token at all -- (value_list from the back: entry n - k, m_out[5] of them; their count in front of a token follows from the
-// other prefix sums: words = strings + rest + 2 numbers + brackets).  The brackets
+// tpos[i] for i in [0, n] (entry n = the total).  Every token that writes a VALUE word writes it here, where its tape position sits in a register:
+// strings (the k-th string token's record is the k-th of the string buffer), atoms (the spelling was checked by k_tok_stage) and -- round 6 -- numbers,
+// whose values k_tok_stage parked at [first token of this row + ordinal of the number inside the row] (rounds 3-5 LISTED numbers and atoms for dense
+// kernels of their own, 8 bytes per value token written here and read there).  The brackets
 // and commas go straight into the sort's input with
 // their level: the depth in front of an opening bracket, the depth behind a closing one, and that of the container a comma separates
 // the members of -- clamped to [0, kmax] (beyond the nesting limit an error is already certain); *m_out = how many went in
 __global__ __launch_bounds__(TS_THREADS, 4) void k_tok_apply(const u8 *__restrict__ tokc, u32 n, u32 kmax, u32 max_depth, const int *__restrict__ sums, u32 nblocks,
-                                                         int *__restrict__ tpos, u64 *__restrict__ value_list, unsigned short *__restrict__ key, u32 *__restrict__ tok,
-                                                         int *__restrict__ m_out, int *__restrict__ max_level, u64 *__restrict__ number_list,
-                                                         const u32 *__restrict__ str_offsets, strings_handoff strs, u8 *__restrict__ string_buf, u64 *__restrict__ tape,
-                                                         u64 tape_cap, tape_result_dev *__restrict__ res) {
+                                                         int *__restrict__ tpos, unsigned short *__restrict__ key, u32 *__restrict__ tok,
+                                                         int *__restrict__ m_out, int *__restrict__ max_level, const u64 *__restrict__ numbits,
+                                                         const u8 *__restrict__ numtype, const u32 *__restrict__ str_offsets, strings_handoff strs,
+                                                         u8 *__restrict__ string_buf, u64 *__restrict__ tape, u64 tape_cap, tape_result_dev *__restrict__ res) {
   // Round 4, second half: the nesting depth is not written anywhere.  What it decides -- "the root value has ended" and the nesting limit
   // (depth_rule, sj_tape_rules.h) and "the list ends inside a container" -- is said HERE, where it sits in a register; the levels of the brackets and
   // commas go into the sort's keys as before.  (k_tape_rules read 4 B per token for it, this kernel wrote them.)
@@ -248,8 +477,7 @@ __global__ __launch_bounds__(TS_THREADS, 4) void k_tok_apply(const u8 *__restric
   const u64 block0 = u64(blockIdx.x) * TS_BLOCK;
   const int slots0 = sums[0 * nblocks + blockIdx.x], sel0 = sums[1 * nblocks + blockIdx.x], strs0 = sums[2 * nblocks + blockIdx.x];
   const int opens0 = sums[3 * nblocks + blockIdx.x], closes0 = sums[4 * nblocks + blockIdx.x];
-  const int depth0 = opens0 - closes0, numbers0 = sums[5 * nblocks + blockIdx.x];
-  const int rest0 = one_word_rest(slots0, strs0, numbers0, opens0, closes0); // one-word tokens that are neither strings nor brackets
+  const int depth0 = opens0 - closes0;
   u32 ra = 0, rb = 0, rc = 0; // what the rows in front of this one hold (packed)
   int top = 0;                // highest level this thread sent into the sort
   u32 err_index = 0, err_low = 0; // this thread's first error: list index, rank << 4 | code (0 = none)
@@ -278,6 +506,7 @@ __global__ __launch_bounds__(TS_THREADS, 4) void k_tok_apply(const u8 *__restric
     const u32 ia = wave_incl_scan(ta), ib = wave_incl_scan(tb), ic = wave_incl_scan(tc);
     if (lane == 63) { sh[0][wave] = ia; sh[1][wave] = ib; sh[2][wave] = ic; }
     __syncthreads();
+    const u32 rc_row = rc; // what the rows in front hold: (ec - rc_row) >> 16 = the number tokens of THIS row in front of the thread's four
     u32 ea = ra + ia - ta, eb = rb + ib - tb, ec = rc + ic - tc;
     for (u32 w = 0; w < TS_THREADS / 64; w++) {
       if (w < wave) { ea += sh[0][w]; eb += sh[1][w]; ec += sh[2][w]; }
@@ -300,7 +529,15 @@ __global__ __launch_bounds__(TS_THREADS, 4) void k_tok_apply(const u8 *__restric
           for (u32 q = 0; q < 4; q++) { if (i0 + q < n) { so[q] = str_offsets[i0 + q]; } }
         }
       }
-      u32 sk = 0; // strings of this thread so far
+      // the values of this thread's number tokens: consecutive entries of what k_tok_stage parked for this row (requested at once, like the records above)
+      u64 nbits[4] = {0, 0, 0, 0};
+      u32 ntypes = 0; // one byte each
+      if ((tc >> 16) != 0u) {
+        const u64 at0 = (block0 + u64(row) * TS_ROW) + ((ec - rc_row) >> 16);
+#pragma unroll
+        for (u32 q = 0; q < 4; q++) { if (at0 + q <= n && q < (tc >> 16)) { nbits[q] = numbits[at0 + q]; ntypes |= u32(numtype[at0 + q]) << (8u * q); } }
+      }
+      u32 sk = 0, nk = 0; // strings / numbers of this thread so far
 #pragma unroll
       for (u32 j = 0; j < 4; j++) {
         // (written for few branches: a wave of 64 x 4 consecutive tokens holds every kind of token, so every branch is taken by somebody and costs its
@@ -317,17 +554,18 @@ __global__ __launch_bounds__(TS_THREADS, 4) void k_tok_apply(const u8 *__restric
           if (i == n && d != 0) { g = SJ_TAPE_ERROR; rank = 0; } // the walk meets the sentinel inside a container
           if (g != 0u && err_low == 0u) { err_index = u32(i); err_low = (rank << 4) | g; } // (a thread meets its tokens in list order: its first error is its smallest key)
         }
-        const int strings_before = strs0 + int(eb & 0xFFFFu), numbers_before = numbers0 + int(ec >> 16);
-        const int rest_before = rest0 + one_word_rest(int(ea & 0xFFFFu), int(eb & 0xFFFFu), int(ec >> 16), int(eb >> 16), int(ec & 0xFFFFu));
+        const int strings_before = strs0 + int(eb & 0xFFFFu);
         const int slot = sel0 + int(ea >> 16);
-        if (i == n) { *m_out = slot; m_out[2] = numbers_before; m_out[3] = slot + 1; m_out[4] = strings_before; m_out[5] = rest_before; }
+        if (i == n) { *m_out = slot; m_out[3] = slot + 1; m_out[4] = strings_before; }
         const u32 list = value_list_of(p[j]); // (of the packed contribution, not of the table entry: the root token's differs)
         const bool is_number = list == LIST_NUMBERS, is_string = list == LIST_STRINGS, is_rest = list == LIST_REST;
         const u64 at = u64(u32(tp[j])) + 1u;
-        if (is_number || is_rest) { // a list entry carries the token's tape position: the value kernels need no gather for it
-          u64 *const dst = is_number ? number_list + numbers_before : value_list + (n - u32(rest_before)); // k_tape_numbers / k_tape_atoms (the spelling)
-          *dst = list_entry(u32(tp[j]), u32(i));
+        if (is_number && at + 1 < tape_cap) { // visit_number, tape_builder.h:213-275: the type word, then the value (a number k_tok_stage rejected left nothing: the
+          // document is in error and its tape is nobody's)
+          tape[at] = tape_word32((ntypes >> (8u * nk)) & 0xFFu, 0);
+          tape[at + 1] = nk == 0 ? nbits[0] : (nk == 1 ? nbits[1] : (nk == 2 ? nbits[2] : nbits[3]));
         }
+        nk += is_number ? 1u : 0u;
         // (sk is a compile-time-bounded counter: selects, not indexed registers)
         const u32 begin = sk == 0 ? oq[0] : (sk == 1 ? oq[1] : (sk == 2 ? oq[2] : oq[3]));
         const u32 next = sk == 0 ? oq[1] : (sk == 1 ? oq[2] : (sk == 2 ? oq[3] : oq[4]));
@@ -370,15 +608,11 @@ __global__ __launch_bounds__(TS_THREADS, 4) void k_tok_apply(const u8 *__restric
 // twitter-like call) are gone: the last scatter writes both arrays on its way.
 __global__ __launch_bounds__(64) void k_radix_hist(const unsigned short *__restrict__ key, const int *__restrict__ m_ptr, u32 shift, u32 tiles, int *__restrict__ hist,
                                                    const int *__restrict__ max_level, u32 *__restrict__ second_scan_len) {
-  __shared__ u32 cnt[2][RADIX_BINS];
   const u32 lane = threadIdx.x, tile = blockIdx.x;
   const bool one_pass = u32(*max_level) < RADIX_BINS;
   if (shift == 0 && tile == 0 && lane == 0) { *second_scan_len = one_pass ? 0u : 2u * tiles * RADIX_BINS; }
   if (shift != 0 && one_pass) { return; }
   const u32 m = u32(*m_ptr);
-  cnt[0][lane] = 0;
-  cnt[1][lane] = 0;
-  wave_lds_fence();
   const u32 base = tile * RADIX_TILE;
   // the tile's keys are requested at once (a wave per tile and a load per step made 32 dependent round trips: there are fewer tiles than the chip holds waves)
   u32 kk[RADIX_STEPS];
@@ -387,18 +621,30 @@ __global__ __launch_bounds__(64) void k_radix_hist(const unsigned short *__restr
     const u32 j = base + q * 64u + lane;
     kk[q] = j < m ? u32(key[j]) : RADIX_DEAD;
   }
+  // Round 6: lane l counts bin l in a register -- the elements of a step whose digit is l are an AND of the six ballots of the digit's bits (each taken or
+  // complemented by the bit of l), no LDS and no atomic.  Rounds 3-5 added every element to an LDS word with an atomic: the 64 elements of a step hold two
+  // or three different levels in ordinary text, and 64 atomics on two or three words are served one after the other (large_random: 27 M bank-conflict cycles
+  // per call, 133 us for a kernel of 9 M VALU instructions, profiles/r06_pmc_summary.txt); a loop over the DISTINCT digits of a step took that to 83 us and
+  // twitter-like, with six to eight levels per step, from 39 to 53 (profiles/r06_tape_stage.txt).
+  u32 c0 = 0, c1 = 0;
+  if (base < m) { // (wave-uniform: tiles behind the elements only write their zeros)
 #pragma unroll
-  for (u32 q = 0; q < RADIX_STEPS; q++) {
-    const u32 k = kk[q];
-    if (k != RADIX_DEAD) {
+    for (u32 q = 0; q < RADIX_STEPS; q++) {
+      const u32 k = kk[q];
+      const bool live = k != RADIX_DEAD;
       const u32 d = (k >> shift) & (RADIX_BINS - 1);
-      atomicAdd(&cnt[0][d], 1u);
-      if (kind_is_open(k >> KIND_SHIFT)) { atomicAdd(&cnt[1][d], 1u); }
+      u64 mine = __ballot(live);
+#pragma unroll
+      for (u32 bit = 0; bit < RADIX_BITS; bit++) {
+        const u64 ones = __ballot(live && ((d >> bit) & 1u));
+        mine &= ((lane >> bit) & 1u) ? ones : ~ones;
+      }
+      c0 += u32(popc64(mine));
+      c1 += u32(popc64(mine & __ballot(live && kind_is_open(k >> KIND_SHIFT))));
     }
   }
-  wave_lds_fence();
-  hist[lane * tiles + tile] = int(cnt[0][lane]);
-  hist[(RADIX_BINS + lane) * tiles + tile] = int(cnt[1][lane]);
+  hist[lane * tiles + tile] = int(c0);
+  hist[(RADIX_BINS + lane) * tiles + tile] = int(c1);
 }
 __global__ __launch_bounds__(64) void k_radix_scatter(const unsigned short *__restrict__ key_in, const u32 *__restrict__ tok_in, const int *__restrict__ m_ptr, u32 shift,
                                                       u32 tiles, const int *__restrict__ hist, unsigned short *__restrict__ key_out, u32 *__restrict__ tok_out,
@@ -588,57 +834,9 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_rules(u32 n, const u8 *__re
   }
 }
 
-// (Round 4, measured and not kept: the spelling checked inside k_tok_classify, where the token's cache line has just arrived, instead of a list and this
-// kernel -- k_tok_classify 120 -> 244 us for the 52 of this kernel and 28 of the list in k_tok_apply: a second dependent fetch in the one kernel that is
-// bound by the latency of its gather.  profiles/r04_tape_kernel_stats.txt.)
-// the other one-word tokens (listed from the back of value_list): true / false / null -- their words are on the tape (k_tok_apply), here their
-// SPELLING is checked against the document; any other byte here is no token at all and k_tape_rules has said so
-__global__ __launch_bounds__(TP_THREADS) void k_tape_atoms(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, u32 n, const u8 *__restrict__ tokc,
-                                                          const u64 *__restrict__ value_list, const int *__restrict__ count_ptr, tape_result_dev *__restrict__ res) {
-  const u32 count = u32(*count_ptr);
-  for (u64 k = u64(blockIdx.x) * TP_THREADS + threadIdx.x; k < count; k += u64(gridDim.x) * TP_THREADS) {
-    const u64 entry = value_list[n - u32(k)];
-    const u32 i = u32(entry);
-    const u32 c = tokc[i + 2];
-    if (c != 't' && c != 'f' && c != 'n') { continue; }
-    const windowed_bytes src{buf, u32(len)};
-    const bool ok = c == 't' ? atom_matches(src, idx[i], 't', 'r', 'u', 'e', 0)
-                             : (c == 'f' ? atom_matches(src, idx[i], 'f', 'a', 'l', 's', 'e') : atom_matches(src, idx[i], 'n', 'u', 'l', 'l', 0));
-    if (!ok) { report_error(res, error_key(i, 2, c == 't' ? SJ_T_ATOM_ERROR : (c == 'f' ? SJ_F_ATOM_ERROR : SJ_N_ATOM_ERROR))); }
-  }
-}
-
-// the number tokens k_tok_apply listed, one per lane: visit_number (tape_builder.h:213-275) = parse_number (numberparsing.h:859-971, sj_number.h)
-__device__ __forceinline__ void number_token(const wide_window_bytes &src, u32 pos, u64 entry, u64 *__restrict__ tape, u64 tape_cap, u32 *__restrict__ slow_list, u32 slow_cap,
-                                             tape_result_dev *__restrict__ res) {
-  const u32 i = u32(entry);
-  const number_value v = parse_number_token(src, pos, static_cast<bigint *>(nullptr));
-  if (v.error) { report_error(res, error_key(i, 2, v.error)); return; }
-  const u64 at = (entry >> 32) + 1u;
-  if (at + 1 < tape_cap) {
-    tape[at] = tape_word(v.type, 0);
-    tape[at + 1] = v.bits; // sign only when v.slow: k_tape_slow_numbers completes it
-    if (v.slow) {
-      const u32 s = atomicAdd(&res->slow_numbers, 1u);
-      if (s < slow_cap) { slow_list[s] = i; }
-    }
-  }
-}
-// One listed token per lane.  (Two per thread and trip, the fetches of both issued before either is parsed, changed nothing -- 140 -> 148 us: what the
-// kernel waits for is not the latency of a chain a second token could hide; profiles/r04_tape_kernel_stats.txt.)
-__global__ __launch_bounds__(TP_THREADS) void k_tape_numbers(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx,
-                                                            const u64 *__restrict__ number_list, const int *__restrict__ count_ptr, u64 *__restrict__ tape, u64 tape_cap,
-                                                            u32 *__restrict__ slow_list, u32 slow_cap, tape_result_dev *__restrict__ res) {
-  const u32 count = u32(*count_ptr);
-  for (u64 k = u64(blockIdx.x) * TP_THREADS + threadIdx.x; k < count; k += u64(gridDim.x) * TP_THREADS) {
-    const u64 entry = number_list[k];
-    const u32 pos = idx[u32(entry)];
-    const wide_window_bytes src{buf, u32(len)};
-    src.fill(pos);
-    number_token(src, pos, entry, tape, tape_cap, slow_list, slow_cap, res);
-  }
-}
-
+// (Rounds 3-5 had two dense kernels here, k_tape_atoms and k_tape_numbers, fed from lists k_tok_apply wrote: one listed token per lane, the token's offset
+// and then its bytes fetched through two dependent round trips.  Round 4 tried the spelling inside the gathering classifier -- 120 -> 244 us, a second
+// dependent fetch in a kernel bound by the latency of its gather; round 6 staged the document's bytes in LDS (k_tok_stage) and both kernels are gone.)
 // Number tokens with more than 19 significant digits whose two bracketing conversions disagree: the exact decision needs two
 // big integers of 516 bytes each per thread (private memory) -- kept out of k_tape_numbers, which then needs no scratch at all.
 __global__ __launch_bounds__(64) void k_tape_slow_numbers(const u8 *__restrict__ buf, u64 len, const u32 *__restrict__ idx, const int *__restrict__ tpos, const u32 *__restrict__ slow_list,
@@ -667,11 +865,11 @@ struct tape_workspace {
   u32 *n_words;       // [0] = n + 1 (scan lengths), [1] = n (upper bound of the sorted elements + 1 for the opens scan), [2] = hist length per pass
   u8 *tokc;
   int *slots;                // tape position of every token (entry n: the total)
-  u64 *value_list;           // (tape position << 32 | token): string tokens from the front, the other one-word tokens from the back
   int *m;                    // brackets and commas = elements of the sort
-  int *sums;                 // k_tok_classify's block totals (6 rows)
+  int *sums;                 // k_tok_stage's block totals (6 rows)
   int *totals;               // ... and the sums of the rows (k_tok_scan_sums): [2] = the string tokens of the list
-  u64 *number_list;          // the number tokens, same form
+  u64 *numbits;              // the value words of the number tokens as k_tok_stage parked them: [first token of the wave's row + ordinal inside the row]
+  u8 *numtype;               // ... and their types ('l', 'u', 'd')
   u32 tok_blocks;
   unsigned short *key_a, *key_b;
   u32 *tok_a, *tok_b, *openpos, *slow_list;
@@ -689,12 +887,12 @@ static tape_workspace carve(uint8_t *base, uint32_t n, uint64_t len) {
   w.res = reinterpret_cast<tape_result_dev *>(take(sizeof(tape_result_dev)));
   w.n_words = reinterpret_cast<u32 *>(take(128)); // (behind the result: launch_tape_front clears both with one memset)
   w.totals = reinterpret_cast<int *>(w.n_words) + 16; // [16 .. 21]
-  w.m = reinterpret_cast<int *>(w.n_words) + 8; // [8] = m, [9] = highest level in the sort, [10] = number tokens, [11] = m + 1 (length of the opens scan), [12] = string tokens,
-  // [13] = other one-word tokens; n_words[2] = length of the second pass's scan
+  w.m = reinterpret_cast<int *>(w.n_words) + 8; // [8] = m, [9] = highest level in the sort, [11] = m + 1 (length of the opens scan), [12] = string tokens;
+  // n_words[2] = length of the second pass's scan
   w.tokc = take(n1 + 8);
   w.slots = reinterpret_cast<int *>(take(n1 * 4 + 64));
-  w.value_list = reinterpret_cast<u64 *>(take(n1 * 8 + 64));
-  w.number_list = reinterpret_cast<u64 *>(take(n1 * 8 + 64));
+  w.numbits = reinterpret_cast<u64 *>(take(n1 * 8 + 64));
+  w.numtype = take(n1 + 64);
   w.tok_blocks = blocks_of(n1, TS_BLOCK);
   w.sums = reinterpret_cast<int *>(take(size_t(w.tok_blocks) * TS_SUMS * 4 + 64));
   w.key_a = reinterpret_cast<unsigned short *>(take(n1 * 2 + 64));
@@ -725,8 +923,11 @@ const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *i
   // (rounds 3-4a: four memsets -- four launches of the runtime's fill kernel, 4 us each)
   hipLaunchKernelGGL(k_tape_init, dim3(1), dim3(64), 0, s, w.res, w.n_words, u32(reinterpret_cast<uint8_t *>(w.n_words + 16) - reinterpret_cast<uint8_t *>(w.res)) / 4u, n1,
                      2u * w.tiles * RADIX_BINS);
-  if (tok) { hipLaunchKernelGGL(k_tok_classify<true>, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, buf, len, idx, n, w.tokc, w.sums, w.tok_blocks, tok); }
-  else { hipLaunchKernelGGL(k_tok_classify<false>, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, buf, len, idx, n, w.tokc, w.sums, w.tok_blocks, tok); }
+  // (tok: since round 6 the front stages the document's bytes for the numbers and the atoms anyway and takes the token bytes from the same window; the
+  // stream is accepted and not read)
+  (void)tok;
+  hipLaunchKernelGGL(k_tok_stage, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, buf, u32(len), idx, n, w.tokc, w.sums, w.tok_blocks, w.numbits, w.numtype, w.slow_list, w.slow_cap,
+                     w.res);
   hipLaunchKernelGGL(k_tok_scan_sums, dim3(TS_SUMS), dim3(1024), 0, s, w.sums, w.tok_blocks, w.totals);
   return w.totals + 2; // the number of string tokens (device)
 }
@@ -738,11 +939,10 @@ void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t
                  uint8_t *string_buf, uint64_t *tape, uint64_t tape_cap, void *workspace, hipStream_t s, bool deep) {
   const tape_workspace w = carve(static_cast<uint8_t *>(workspace), n, len);
   const u32 n1 = n + 1;
-  const u32 grid = blocks_of(n1, TP_THREADS);
   const int *m_ptr = w.m;
   const u32 kmax = max_depth < 4095u ? max_depth : 4095u;
-  hipLaunchKernelGGL(k_tok_apply, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, w.tokc, n, kmax, max_depth, w.sums, w.tok_blocks, w.slots, w.value_list, w.key_a, w.tok_a, w.m, w.m + 1,
-                     w.number_list, str_offsets, strs, string_buf, tape, tape_cap, w.res);
+  hipLaunchKernelGGL(k_tok_apply, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, w.tokc, n, kmax, max_depth, w.sums, w.tok_blocks, w.slots, w.key_a, w.tok_a, w.m, w.m + 1,
+                     w.numbits, w.numtype, str_offsets, strs, string_buf, tape, tape_cap, w.res);
   // two passes of six bits cover levels up to 4095; the second one only runs for documents nested 64 deep and more
   const int *max_level = w.m + 1;
   hipLaunchKernelGGL(k_radix_hist, dim3(w.tiles), dim3(64), 0, s, w.key_a, m_ptr, 0u, w.tiles, w.hist, max_level, w.n_words + 2);
@@ -759,10 +959,6 @@ void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t
   // containers: the ordinals came with the last scatter
   hipLaunchKernelGGL(k_tape_match, dim3(blocks_of(n1, TP_THREADS * TM_PER)), dim3(TP_THREADS), 0, s, sorted, m_ptr, w.opens, w.openpos, w.slots, w.tokc, n, tape, tape_cap, w.res);
   hipLaunchKernelGGL(k_tape_rules, dim3(blocks_of(n1, TP_THREADS * TW_PER)), dim3(TP_THREADS), 0, s, n, w.tokc, w.slots, max_level, tape, tape_cap, w.res);
-  const u32 list_grid = grid < 8192u ? grid : 8192u;
-  hipLaunchKernelGGL(k_tape_atoms, dim3(list_grid), dim3(TP_THREADS), 0, s, buf, len, idx, n, w.tokc, w.value_list, w.m + 5, w.res);
-  hipLaunchKernelGGL(k_tape_numbers, dim3(list_grid), dim3(TP_THREADS), 0, s, buf, len, idx, w.number_list, w.m + 2, tape, tape_cap, w.slow_list,
-                     w.slow_cap, w.res);
   hipLaunchKernelGGL(k_tape_slow_numbers, dim3(64), dim3(64), 0, s, buf, len, idx, w.slots, w.slow_list, w.slow_cap, tape, tape_cap, w.res);
 }
 

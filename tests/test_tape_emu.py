@@ -127,3 +127,56 @@ def test_escapes_across_chunks_and_segments(emu):
                 bad.append(b'["ok","' + b"a" * (boundary + delta - 7) + esc + b'tail",1]')
     out = emu(bad)
     assert f"code 5: {len(bad)}" in out and f"per-string {len(bad)};" in out and f"second rounds: {len(bad)})" in out, out  # declined by the stream, run again
+
+
+def _staged_front_documents(rng):
+    """What k_tok_stage's grouping has to get right: tokens packed densely and far apart in one list (staged groups and rows read in place, side by
+    side), numbers and atoms at the last bytes of a window and of the document, numbers longer than the bytes staged behind a group's last token."""
+    docs = []
+    longs = ["1" * 70 + ".0", "0." + "7" * 90, "-" + "9" * 18, "1" + "0" * 200 + "e-190", "3." + "1" * 400 + "e5", "1" * 25 + "e0", "12345678901234567890", "0.000000000000000000000000000001e31"]
+    for gap in (0, 1, 7, 40, 61, 64, 70, 200, 1000, 5000):
+        pad = b" " * gap
+        for sep_in in (b"", pad):
+            items = []
+            for k in range(300):
+                kind = int(rng.integers(0, 7))
+                if kind == 0: items.append(str(int(rng.integers(-10**9, 10**9))).encode())
+                elif kind == 1: items.append(repr(float(rng.random() * 10.0 ** int(rng.integers(-20, 20)))).encode())
+                elif kind == 2: items.append([b"true", b"false", b"null"][int(rng.integers(0, 3))])
+                elif kind == 3: items.append(b'"s%d"' % k)
+                elif kind == 4: items.append(b'{"a":' + sep_in + b'1.5e3,"b":[true,null]}')
+                elif kind == 5: items.append(longs[int(rng.integers(0, len(longs)))].encode())
+                else: items.append(b"[]")
+            docs.append(b"[" + (b"," + pad).join(items) + pad + b"]")
+    # the end of the document: no byte behind the token
+    docs += [b"123", b"-0", b"1.5", b"true", b"false", b"null", b"[1,2,3", b"[true", b'{"a":null', b"1" * 70, b"[" + b"1" * 70 + b"]", b"[1.0" + b"0" * 100 + b"]", b"[1," + b" " * 4000 + b"-" + b"9" * 19 + b"]",
+             b"1." + b"5" * 70, b"[0" + b" " * 61 + b",1" + b"2" * 62 + b".5," + b"3" * 17 + b"]"]
+    # a long run of dense tokens, a gap, dense again: groups of every size
+    for gap in (3000, 4090, 4100, 9000, 70000):
+        docs.append(b"[" + b",".join(b"%d.5" % k for k in range(3000)) + b"," + b" " * gap + b",".join(b"true" for _ in range(2000)) + b"," + b" " * gap + b'"x",1e5]')
+    return docs
+
+
+def test_staged_token_front(emu):
+    rng = np.random.default_rng(14)
+    docs = _staged_front_documents(rng)
+    out = emu(docs)
+    assert "code 0:" in out, out
+    # broken spellings and numbers at the same places: the same error codes as the oracle's walk (compared inside the program)
+    bad = []
+    for d in docs[:40]:
+        for _ in range(3):
+            bad.append(jsongen.mutate(rng, d))
+    emu(bad)
+
+
+def test_staged_token_front_with_a_small_window(tmp_path_factory):
+    """the same sources with a 1 KiB window: every wave of a dense document works through many groups, most rows of ordinary text are read in place"""
+    exe = build(tmp_path_factory.mktemp("tape_emu_w1k"), defines=("-DSJGPU_STAGE_WINDOW=1024",))
+    rng = np.random.default_rng(15)
+    docs = _staged_front_documents(rng) + [_big(rng, 50, 600) for _ in range(6)]
+    docs += [open(os.path.join(_paths.REPO_ROOT, "tests", "golden", "jsonexamples", "twitter.json"), "rb").read()]
+    blob = b"".join(struct.pack("<I", len(d)) + d for d in docs)
+    p = subprocess.run([exe, "1024", "0"], input=blob, capture_output=True, timeout=1500)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    assert " 0 mismatches" in p.stdout.decode()
