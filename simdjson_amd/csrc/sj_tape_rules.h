@@ -281,6 +281,35 @@ SJ_HD u32 comma_fine_bits_of_props(u32 x1, bool have1, u32 x2, bool have2) {
 // the sort key of a bracket or comma from its entry (level: clamped by the caller)
 SJ_HD u32 sort_key_of_props(u32 level, u32 x, u32 comma_bits) { return level | (((x & TP_COMMA) ? KIND_COMMA + comma_bits : (x >> TP_KIND_SHIFT) & 7u) << KIND_SHIFT); }
 
+// ---- the token's own verdict from ONE table entry per byte (round 6) ------------------------------------------------------------------------------
+// token_rule_self asks three tables (what a byte is, the state behind a byte, what a state accepts) in a kernel of its own (k_tape_rules, rounds 3-5: 44
+// VALU instructions per token, the token bytes read once more).  k_tok_apply already holds every token's table entry in a register; with the state behind
+// a byte and "the states that accept this byte" (the accept table turned around: bit s of the entry <=> byte_props_of(v) & state_accepts(s)) in the entry's
+// upper half, the verdict is a dozen instructions on three registers and k_tape_rules is gone.
+// entry of byte v: [15:0] token_props_of(v), [19:16] state_behind_byte(v), [20 + s] a byte v is accepted in state s (s < ST_COUNT <= 12)
+constexpr u32 TE_STATE_SHIFT = 16, TE_ACCEPT_SHIFT = 20;
+static_assert(ST_COUNT <= 12, "the accept bits of a token entry");
+SJ_HD u32 token_entry_of(u32 v) {
+  u32 e = token_props_of(v) | (state_behind_byte(v) << TE_STATE_SHIFT);
+  const u32 pv = byte_props_of(v);
+  for (u32 st = 0; st < ST_COUNT; st++) { if (pv & state_accepts(st)) { e |= 1u << (TE_ACCEPT_SHIFT + st); } }
+  return e;
+}
+// token_rule_self from the entries of the token (xc), of the token in front (xprev) and of the one in front of that (xprev2); entries of bytes that are no
+// token (in front of the list: the entry of byte 0) behave like the bytes themselves
+SJ_HD u32 token_rule_self_entries(bool first, u32 xc, u32 xprev, u32 xprev2, u32 *rank) {
+  *rank = 0;
+  const bool prev_comma = (xprev & TP_COMMA) != 0u, prev_quote = (xprev & TP_STRING) != 0u;
+  if (!first && (prev_comma || (prev_quote && (xprev2 & TP_COMMA) != 0u))) { return 0; } // judged_by_comma
+  u32 st = (xprev >> TE_STATE_SHIFT) & 15u;
+  const u32 kind2 = (xprev2 >> TP_KIND_SHIFT) & 7u, kind1 = (xprev >> TP_KIND_SHIFT) & 7u;
+  st = st == ST_BEHIND_QUOTE ? (kind2 == KIND_OPEN_OBJECT ? u32(ST_BEHIND_KEY) : u32(ST_BEHIND_VALUE)) : st;
+  st = first ? u32(ST_ROOT) : st;
+  if (((xc >> (TE_ACCEPT_SHIFT + st)) & 1u) == 0u) { return SJ_TAPE_ERROR; }
+  if (!first && (xc & TP_COMMA) != 0u && (kind1 == KIND_OPEN_ARRAY || (xprev & TP_COLON) != 0u)) { *rank = 2; return SJ_NUMBER_ERROR; }
+  return 0;
+}
+
 // the list index of the token that writes the tape word at position p (a bracket: one word): tape positions do not decrease along the list and
 // tokens without a word (':' ',') share theirs with the token behind them, so it is the LAST index whose position is p.  tpos: n + 1 entries.
 template <class TPOS> SJ_HD u32 token_at_tape_position(const TPOS &tpos, u32 n, u32 p) {

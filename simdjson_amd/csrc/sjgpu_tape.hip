@@ -25,7 +25,6 @@
 //   (container ordinal per sorted element and sorted position of every open: written by the sort's last scatter from a second histogram)
 //   k_tape_match      commas judge the two tokens behind them by their container's kind; closes write BOTH bracket words (count, partner
 //                     index), kinds checked
-//   k_tape_rules      per token: the part of the walk's rule a token can check from the two bytes in front of it; root words
 //   k_tape_slow_numbers  the handful of number tokens whose rounding needs exact big-integer arithmetic (sj_number.h)
 // Parity: tests/test_gpu_parity.py::test_tape_* against the live reference's dom::parser::parse (tape and string_buf word for word,
 // error codes of broken documents); the same steps run on the CPU in tests/host/test_tape_model.cpp.
@@ -468,13 +467,15 @@ __global__ __launch_bounds__(TS_THREADS, 4) void k_tok_apply(const u8 *__restric
   // per-string kernels left the offsets per token.  k_tape_strings, the list it read and the tape stores of k_tape_atoms (which still checks
   // the spelling of true / false / null) are gone.
   const bool stream_strings = strs.go_stream != nullptr && *strs.go_stream != 0; // uniform
+  const u32 cap32 = tape_cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : u32(tape_cap); // (tape positions are ints)
   __shared__ u32 sh[3][TS_THREADS / 64];
-  __shared__ unsigned short sh_props[256]; // what a token's byte IS, as bits (token_props_of, sj_tape_rules.h): one LDS read instead of ~20 compares per token
+  __shared__ u32 sh_props[256]; // what a token's byte IS, as bits (token_entry_of, sj_tape_rules.h: its properties, the walk's state behind it, the states that
+                                // accept it): one LDS read instead of ~20 compares per token -- and, round 6, all that the token's own rule needs
   static_assert(TS_THREADS == 256, "one table entry per thread");
-  sh_props[threadIdx.x] = (unsigned short)token_props_of(threadIdx.x);
+  sh_props[threadIdx.x] = token_entry_of(threadIdx.x);
   __syncthreads();
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const u64 block0 = u64(blockIdx.x) * TS_BLOCK;
+  const u32 block0 = blockIdx.x * TS_BLOCK; // (32-bit list indexes throughout: n < 2^32 - 16, sjgpu_stage2_device, and the last block ends below n + 4096)
   const int slots0 = sums[0 * nblocks + blockIdx.x], sel0 = sums[1 * nblocks + blockIdx.x], strs0 = sums[2 * nblocks + blockIdx.x];
   const int opens0 = sums[3 * nblocks + blockIdx.x], closes0 = sums[4 * nblocks + blockIdx.x];
   const int depth0 = opens0 - closes0;
@@ -483,25 +484,32 @@ __global__ __launch_bounds__(TS_THREADS, 4) void k_tok_apply(const u8 *__restric
   u32 err_index = 0, err_low = 0; // this thread's first error: list index, rank << 4 | code (0 = none)
 #pragma unroll 1
   for (u32 row = 0; row < TS_ROWS; row++) {
-    const u64 i0 = block0 + u64(row) * TS_ROW + 4u * tid;
-    u32 four = 0;
-    u32 behind2 = 0; // the two tokens behind this thread's four (depth_rule looks at the token behind an opening bracket, a comma at its two followers)
-    typedef unsigned short __attribute__((aligned(1))) u16_unaligned_t;
-    if (i0 < n) { four = four_tokens(tokc, i0); behind2 = *reinterpret_cast<const u16_unaligned_t *>(tokc + 2 + i0 + 4); } // (tokc has room for n + 9 bytes;
-    // what lies behind token n - 1 is only looked at where it is zeros)
+    const u32 i0 = block0 + row * TS_ROW + 4u * tid;
+    // the bytes of tokens i0 - 2 ... i0 + 5 in one load (tokc[2 + i] = token i: two zero bytes lead the array, and it has room for n + 9 bytes; what lies behind
+    // token n - 1 is only looked at where it is zeros): the thread's four, the two behind them (depth_rule looks at the token behind an opening bracket, a comma at
+    // its two followers) and the two in front (the token's own rule, token_rule_self_entries: k_tape_rules of rounds 3-5)
+    typedef u64 __attribute__((aligned(1))) u64_unaligned_t;
+    u64 around8 = 0;
+    if (i0 < n) { around8 = *reinterpret_cast<const u64_unaligned_t *>(tokc + i0); }
+    const u32 four = u32(around8 >> 16), behind2 = u32(around8 >> 48);
+    const u32 xm2 = sh_props[u32(around8) & 0xFFu], xm1 = sh_props[(u32(around8) >> 8) & 0xFFu]; // the entries of tokens i0 - 2, i0 - 1 (in front of the list: of byte 0)
     u32 x[6]; // the table entries of tokens i0 ... i0 + 5 (what lies at or behind n: zero -- no token)
 #pragma unroll
     for (u32 q = 0; q < 6; q++) {
       const u32 c = q < 4 ? (four >> (8u * q)) & 0xFFu : (behind2 >> (8u * (q - 4))) & 0xFFu;
-      x[q] = i0 + q < n ? u32(sh_props[c]) : 0u;
+      x[q] = i0 + q < n ? sh_props[c] : 0u;
     }
-    tok_packed p[4];
+    // (a token's contribution is unpacked from its entry here and again where it is applied: twelve registers across the scan cost more than nine instructions)
+    auto contribution = [&](u32 j) {
+      tok_packed pj = tok_contribution_of_props(x[j]);
+      if (j == 0 && i0 == 0 && n != 0) { pj = tok_contribution(four & 0xFFu, true); } // the root token: its number path differs (one token per document)
+      return pj;
+    };
     u32 ta = 0, tb = 0, tc = 0;
 #pragma unroll
     for (u32 j = 0; j < 4; j++) {
-      p[j] = tok_contribution_of_props(x[j]);
-      if (i0 + j == 0 && n != 0) { p[j] = tok_contribution(four & 0xFFu, true); } // the root token: its number path differs (one token per document)
-      ta += p[j].a; tb += p[j].b; tc += p[j].c;
+      const tok_packed pj = contribution(j);
+      ta += pj.a; tb += pj.b; tc += pj.c;
     }
     const u32 ia = wave_incl_scan(ta), ib = wave_incl_scan(tb), ic = wave_incl_scan(tc);
     if (lane == 63) { sh[0][wave] = ia; sh[1][wave] = ib; sh[2][wave] = ic; }
@@ -519,21 +527,21 @@ __global__ __launch_bounds__(TS_THREADS, 4) void k_tok_apply(const u8 *__restric
       // requested HERE, all at once, not one by one inside the loop below (as dependent loads they made this kernel 120 us longer than the
       // separate pass over a list of string tokens had been: profiles/r04_tape_kernel_stats.txt)
       const u32 k0 = u32(strs0) + (eb & 0xFFFFu);
-      u32 oq[5] = {0u, 0u, 0u, 0u, 0u}, so[4] = {0u, 0u, 0u, 0u};
+      u32 oq[5] = {0u, 0u, 0u, 0u, 0u}; // stream: the record starts of strings k0 ... k0 + 4; else (the same registers): the offsets the per-string kernels left for tokens i0 ... i0 + 3
       if (((tb & 0xFFFFu) != 0u)) { // this thread holds string tokens
         if (stream_strings) {
 #pragma unroll
-          for (u32 q = 0; q < 5; q++) { if (u64(k0) + q <= u64(n) + 1u) { oq[q] = strs.outq[k0 + q]; } } // (outq has n + 2 entries)
+          for (u32 q = 0; q < 5; q++) { if (k0 + q <= n + 1u) { oq[q] = strs.outq[k0 + q]; } } // (outq has n + 2 entries)
         } else {
 #pragma unroll
-          for (u32 q = 0; q < 4; q++) { if (i0 + q < n) { so[q] = str_offsets[i0 + q]; } }
+          for (u32 q = 0; q < 4; q++) { if (i0 + q < n) { oq[q] = str_offsets[i0 + q]; } }
         }
       }
       // the values of this thread's number tokens: consecutive entries of what k_tok_stage parked for this row (requested at once, like the records above)
       u64 nbits[4] = {0, 0, 0, 0};
       u32 ntypes = 0; // one byte each
       if ((tc >> 16) != 0u) {
-        const u64 at0 = (block0 + u64(row) * TS_ROW) + ((ec - rc_row) >> 16);
+        const u32 at0 = (block0 + row * TS_ROW) + ((ec - rc_row) >> 16);
 #pragma unroll
         for (u32 q = 0; q < 4; q++) { if (at0 + q <= n && q < (tc >> 16)) { nbits[q] = numbits[at0 + q]; ntypes |= u32(numtype[at0 + q]) << (8u * q); } }
       }
@@ -543,24 +551,28 @@ __global__ __launch_bounds__(TS_THREADS, 4) void k_tok_apply(const u8 *__restric
         // (written for few branches: a wave of 64 x 4 consecutive tokens holds every kind of token, so every branch is taken by somebody and costs its
         // mask bookkeeping for all -- 1 280 scalar and 940 vector instructions per row before, profiles/r04_tape_kernel_stats.txt; stores of the same
         // width share one site with a selected address, errors are kept in two registers and reported once)
-        const u64 i = i0 + j;
+        const u32 i = i0 + j;
         const bool live = i < n;
+        const tok_packed pj = contribution(j);
         const u32 ch = (four >> (8u * j)) & 0xFFu, c1 = j < 3 ? (four >> (8u * (j + 1))) & 0xFFu : behind2 & 0xFFu;
         const int d = depth0 + int(eb >> 16) - int(ec & 0xFFFFu);
         tp[j] = slots0 + int(ea & 0xFFFFu);
         {
-          u32 rank = 0;
+          u32 rank = 0, rank_self = 0;
           u32 g = live ? depth_rule(i == 0, ch, i + 1 < n ? c1 : 0u, d, max_depth, &rank) : 0u;
           if (i == n && d != 0) { g = SJ_TAPE_ERROR; rank = 0; } // the walk meets the sentinel inside a container
-          if (g != 0u && err_low == 0u) { err_index = u32(i); err_low = (rank << 4) | g; } // (a thread meets its tokens in list order: its first error is its smallest key)
+          // what the token says about itself from the two tokens in front of it (the followers of a comma are judged by the comma: k_tape_match)
+          const u32 gs = live ? token_rule_self_entries(i == 0, x[j], j == 0 ? xm1 : x[j > 0 ? j - 1 : 0], j == 0 ? xm2 : (j == 1 ? xm1 : x[j > 1 ? j - 2 : 0]), &rank_self) : 0u;
+          const u32 low_d = g ? (rank << 4) | g : 0xFFFFu, low_s = gs ? (rank_self << 4) | gs : 0xFFFFu, low = low_d < low_s ? low_d : low_s; // the smaller key of one token
+          if (low != 0xFFFFu && err_low == 0u) { err_index = i; err_low = low; } // (a thread meets its tokens in list order: its first error is its smallest key)
         }
         const int strings_before = strs0 + int(eb & 0xFFFFu);
         const int slot = sel0 + int(ea >> 16);
         if (i == n) { *m_out = slot; m_out[3] = slot + 1; m_out[4] = strings_before; }
-        const u32 list = value_list_of(p[j]); // (of the packed contribution, not of the table entry: the root token's differs)
+        const u32 list = value_list_of(pj); // (of the packed contribution, not of the table entry: the root token's differs)
         const bool is_number = list == LIST_NUMBERS, is_string = list == LIST_STRINGS, is_rest = list == LIST_REST;
-        const u64 at = u64(u32(tp[j])) + 1u;
-        if (is_number && at + 1 < tape_cap) { // visit_number, tape_builder.h:213-275: the type word, then the value (a number k_tok_stage rejected left nothing: the
+        const u32 at = u32(tp[j]) + 1u; // (tape positions are ints: below 2^31)
+        if (is_number && at + 1u < cap32) { // visit_number, tape_builder.h:213-275: the type word, then the value (a number k_tok_stage rejected left nothing: the
           // document is in error and its tape is nobody's)
           tape[at] = tape_word32((ntypes >> (8u * nk)) & 0xFFu, 0);
           tape[at + 1] = nk == 0 ? nbits[0] : (nk == 1 ? nbits[1] : (nk == 2 ? nbits[2] : nbits[3]));
@@ -571,19 +583,19 @@ __global__ __launch_bounds__(TS_THREADS, 4) void k_tok_apply(const u8 *__restric
         const u32 next = sk == 0 ? oq[1] : (sk == 1 ? oq[2] : (sk == 2 ? oq[3] : oq[4]));
         if (is_string && stream_strings) { *reinterpret_cast<u32_unaligned_t *>(string_buf + begin) = next - begin - 5u; }
         const bool is_atom = is_rest && (x[j] & TP_ATOM) != 0u; // visit_true_atom ..., tape_builder.h:278-329
-        if ((is_string || is_atom) && at < tape_cap) { tape[at] = is_string ? tape_word32('"', stream_strings ? begin : so[j]) : tape_word32(ch, 0); }
+        if ((is_string || is_atom) && at < cap32) { tape[at] = is_string ? tape_word32('"', stream_strings ? begin : oq[j]) : tape_word32(ch, 0); }
         sk += is_string ? 1u : 0u;
-        if (live && (p[j].a >> 16)) {
-          int k = (p[j].b >> 16) ? d : d - 1;
+        if (live && (pj.a >> 16)) {
+          int k = (pj.b >> 16) ? d : d - 1;
           k = k < 0 ? 0 : (k > int(kmax) ? int(kmax) : k);
           // a bracket travels with its tape position, a comma with its list index and with what it knows about its two followers (sj_tape_rules.h)
           const bool comma = (x[j] & TP_COMMA) != 0u;
           const u32 fine = comma_fine_bits_of_props(x[j + 1], i + 1 < n, x[j + 2], i + 2 < n);
           key[slot] = (unsigned short)sort_key_of_props(u32(k), x[j], fine);
-          tok[slot] = comma ? u32(i) : u32(tp[j]);
+          tok[slot] = comma ? i : u32(tp[j]);
           top = k > top ? k : top;
         }
-        ea += p[j].a; eb += p[j].b; ec += p[j].c;
+        ea += pj.a; eb += pj.b; ec += pj.c;
       }
       if (i0 + 3 <= n) {
         *reinterpret_cast<int4 *>(tpos + i0) = make_int4(tp[0], tp[1], tp[2], tp[3]);
@@ -654,6 +666,9 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const unsigned short *__re
   const u32 lane = threadIdx.x, tile = blockIdx.x;
   if (shift != 0 && u32(*max_level) < RADIX_BINS) { return; }
   const u32 m = u32(*m_ptr);
+  // the grid is sized for n + 1 elements (m is only known on the device): a tile behind the m that exist has nothing to move.  Rounds 3-5 let it run its 32
+  // steps of ballots over dead lanes -- two tiles in three of large_random's grid, 226 us for the kernel (profiles/r06_tape_stage.txt)
+  if (tile * RADIX_TILE >= m) { return; }
   next[lane] = u32(hist[lane * tiles + tile]);
   onext[lane] = u32(hist[(RADIX_BINS + lane) * tiles + tile]) - m;
   wave_lds_fence();
@@ -722,6 +737,19 @@ constexpr u32 TM_PER = 4;
 __global__ __launch_bounds__(TP_THREADS) void k_tape_match(sorted_pairs sorted, const int *__restrict__ m_ptr, const int *__restrict__ opens_before,
                                                           const u32 *__restrict__ openpos, const int *__restrict__ tpos, const u8 *__restrict__ tokc, u32 n,
                                                           u64 *__restrict__ tape, u64 tape_cap, tape_result_dev *__restrict__ res) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) { // what belongs to no token (k_tape_rules' last thread, rounds 3-5): the root words, the sizes, the root container's end
+    const u64 words = u64(u32(tpos[n])) + 2;
+    res->tape_words = words;
+    res->max_level = u32(*sorted.max_level);
+    if (words <= tape_cap) {
+      tape[0] = tape_word('r', words);           // visit_document_end, tape_builder.h:160-165
+      tape[words - 1] = tape_word('r', 0);
+    } else {
+      res->overflow = 1;
+    }
+    const u32 c0 = tokc[2], last = tokc[n + 1];
+    if ((c0 == '{' && last != '}') || (c0 == '[' && last != ']')) { report_error(res, error_key(0, 0, SJ_TAPE_ERROR)); } // json_iterator.h:138-143
+  }
   const unsigned short *__restrict__ key = sorted.key();
   const u32 *__restrict__ tok = sorted.tok();
   const u64 j0 = (u64(blockIdx.x) * TP_THREADS + threadIdx.x) * TM_PER;
@@ -781,59 +809,9 @@ __global__ __launch_bounds__(TP_THREADS) void k_tape_match(sorted_pairs sorted, 
   }
 }
 
-// ---- per token: the walk's rule and the nesting limit --------------------------------------------------------------------------------------
-// Only the rule: the value words are written by the dense kernels below, one per kind of token (k_tape_strings, k_tape_atoms,
-// k_tape_numbers), the bracket words by k_tape_match.  The first version did all of it per token: a wave of 64 consecutive tokens then
-// executes every kind's branch (counters of that kernel: 250 M scalar and 100 M vector instructions per twitter-like call, waves waiting
-// for issue a third of their time, four tokens per thread and 32-bit arithmetic changed nothing: profiles/r03_pmc_summary.txt).
-constexpr u32 TW_PER = 4;
-// byte k (0 ... 7) of the eight bytes {hi:lo}, k known at compile time
-__device__ __forceinline__ u32 byte_of(u32 lo, u32 hi, u32 k) { return ((k < 4u ? lo : hi) >> (8u * (k & 3u))) & 0xFFu; }
-__device__ __forceinline__ void check_token(const rule_tables &T, u32 i, u32 c, u32 prev, u32 prev2, tape_result_dev *__restrict__ res) {
-  u32 rank = 0;
-  const u32 g = token_rule_self(T, i == 0, c, prev, prev2, &rank); // (sj_tape_rules.h: the token's own verdict; the depth's is k_tok_apply's, the commas' k_tape_match's)
-  if (g) { report_error(res, error_key(i, rank, g)); }
-}
-__global__ __launch_bounds__(TP_THREADS) void k_tape_rules(u32 n, const u8 *__restrict__ tokc, const int *__restrict__ tpos, const int *__restrict__ max_level,
-                                                          u64 *__restrict__ tape, u64 tape_cap, tape_result_dev *__restrict__ res) {
-  __shared__ unsigned short sh_props[256], sh_accepts[16];
-  __shared__ u8 sh_state[256];
-  static_assert(TP_THREADS == 256 && ST_COUNT <= 16, "one table entry per thread");
-  rule_table_entry(threadIdx.x, sh_props, sh_state, sh_accepts);
-  __syncthreads();
-  const rule_tables T{sh_props, sh_state, sh_accepts};
-  const u64 first = (u64(blockIdx.x) * TP_THREADS + threadIdx.x) * TW_PER;
-  if (first > n) { return; }
-  const u32 i0 = u32(first);
-  if (n - i0 < TW_PER) { // the thread that holds "behind the last token": the root words and the check that belongs to no token
-    const u64 words = u64(u32(tpos[n])) + 2;
-    res->tape_words = words;
-    res->max_level = u32(*max_level);
-    if (words <= tape_cap) {
-      tape[0] = tape_word('r', words);           // visit_document_end, tape_builder.h:160-165
-      tape[words - 1] = tape_word('r', 0);
-    } else {
-      res->overflow = 1;
-    }
-    const u32 c0 = tokc[2], last = tokc[n + 1];
-    if ((c0 == '{' && last != '}') || (c0 == '[' && last != ']')) { report_error(res, error_key(0, 0, SJ_TAPE_ERROR)); } // json_iterator.h:138-143
-  }
-  if (i0 >= 2 && n - i0 >= TW_PER) { // the common case: four whole tokens, one wide load
-    typedef u64 __attribute__((aligned(1))) u64_unaligned_t;
-    const u64 around8 = *reinterpret_cast<const u64_unaligned_t *>(tokc + i0);   // bytes of tokens i0 - 2 ... i0 + 5
-    const uint2 around = make_uint2(u32(around8), u32(around8 >> 32));
-#pragma unroll
-    for (u32 j = 0; j < TW_PER; j++) {
-      check_token(T, i0 + j, byte_of(around.x, around.y, j + 2), byte_of(around.x, around.y, j + 1), byte_of(around.x, around.y, j), res);
-    }
-    return;
-  }
-  for (u32 i = i0; i - i0 < TW_PER && i < n; i++) { // the first and the last tokens of the list: one by one
-    const u32 around = *reinterpret_cast<const u32_unaligned_t *>(tokc + i); // the bytes of tokens i - 2 ... i + 1 (two zero bytes lead the array)
-    check_token(T, i, (around >> 16) & 0xFFu, (around >> 8) & 0xFFu, around & 0xFFu, res);
-  }
-}
-
+// (Rounds 3-5 had a kernel per token here, k_tape_rules: the part of the walk's rule a token can check from the two bytes in front of it, from three LDS
+// tables -- 144 us per large_random call and the token bytes read once more.  Round 6: k_tok_apply holds every token's table entry anyway and says it there
+// (token_rule_self_entries); the root words and the check that belongs to no token moved to k_tape_match's first thread.)
 // (Rounds 3-5 had two dense kernels here, k_tape_atoms and k_tape_numbers, fed from lists k_tok_apply wrote: one listed token per lane, the token's offset
 // and then its bytes fetched through two dependent round trips.  Round 4 tried the spelling inside the gathering classifier -- 120 -> 244 us, a second
 // dependent fetch in a kernel bound by the latency of its gather; round 6 staged the document's bytes in LDS (k_tok_stage) and both kernels are gone.)
@@ -958,7 +936,6 @@ void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t
   const sorted_pairs sorted{deep ? w.key_a : nullptr, w.key_b, deep ? w.tok_a : nullptr, w.tok_b, max_level};
   // containers: the ordinals came with the last scatter
   hipLaunchKernelGGL(k_tape_match, dim3(blocks_of(n1, TP_THREADS * TM_PER)), dim3(TP_THREADS), 0, s, sorted, m_ptr, w.opens, w.openpos, w.slots, w.tokc, n, tape, tape_cap, w.res);
-  hipLaunchKernelGGL(k_tape_rules, dim3(blocks_of(n1, TP_THREADS * TW_PER)), dim3(TP_THREADS), 0, s, n, w.tokc, w.slots, max_level, tape, tape_cap, w.res);
   hipLaunchKernelGGL(k_tape_slow_numbers, dim3(64), dim3(64), 0, s, buf, len, idx, w.slots, w.slow_list, w.slow_cap, tape, tape_cap, w.res);
 }
 

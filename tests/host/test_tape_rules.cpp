@@ -109,6 +109,25 @@ int main() {
       }
     }
   }
+  { // round 6: the token's own verdict from one table entry per byte (what k_tok_apply evaluates) against token_rule_self, on EVERY triple of bytes
+    u32 entry[256];
+    for (u32 v = 0; v < 256; v++) { entry[v] = token_entry_of(v); if ((entry[v] & 0xFFFFu) != token_props_of(v)) { fprintf(stderr, "entry %02x: lower half\n", v); return 1; } }
+    for (u32 c = 0; c < 256; c++) {
+      for (u32 prev = 0; prev < 256; prev++) {
+        for (u32 prev2 = 0; prev2 < 256; prev2++) {
+          for (int first = 0; first < 2; first++) {
+            u32 r1 = 9, r2 = 9;
+            const u32 e1 = token_rule_self(T, first != 0, c, prev, prev2, &r1), e2 = token_rule_self_entries(first != 0, entry[c], entry[prev], entry[prev2], &r2);
+            if (e1 != e2 || r1 != r2) {
+              fprintf(stderr, "c %02x prev %02x prev2 %02x first %d: token_rule_self says %u (rank %u), the entries say %u (rank %u)\n", c, prev, prev2, first, e1, r1, e2, r2);
+              return 1;
+            }
+            checked++;
+          }
+        }
+      }
+    }
+  }
   printf("%lu combinations agree\n", checked);
   return 0;
 }
