@@ -298,16 +298,17 @@ SJ_HD u32 token_entry_of(u32 v) {
 // token_rule_self from the entries of the token (xc), of the token in front (xprev) and of the one in front of that (xprev2); entries of bytes that are no
 // token (in front of the list: the entry of byte 0) behave like the bytes themselves
 SJ_HD u32 token_rule_self_entries(bool first, u32 xc, u32 xprev, u32 xprev2, u32 *rank) {
-  *rank = 0;
-  const bool prev_comma = (xprev & TP_COMMA) != 0u, prev_quote = (xprev & TP_STRING) != 0u;
-  if (!first && (prev_comma || (prev_quote && (xprev2 & TP_COMMA) != 0u))) { return 0; } // judged_by_comma
-  u32 st = (xprev >> TE_STATE_SHIFT) & 15u;
+  // (written without a branch: every token of a wave takes the same dozen instructions)
+  const u32 prev_comma = (xprev / TP_COMMA) & 1u, prev_quote = (xprev / TP_STRING) & 1u, prev2_comma = (xprev2 / TP_COMMA) & 1u;
+  const u32 judged = first ? 0u : (prev_comma | (prev_quote & prev2_comma)); // judged_by_comma: not here
   const u32 kind2 = (xprev2 >> TP_KIND_SHIFT) & 7u, kind1 = (xprev >> TP_KIND_SHIFT) & 7u;
+  u32 st = (xprev >> TE_STATE_SHIFT) & 15u;
   st = st == ST_BEHIND_QUOTE ? (kind2 == KIND_OPEN_OBJECT ? u32(ST_BEHIND_KEY) : u32(ST_BEHIND_VALUE)) : st;
   st = first ? u32(ST_ROOT) : st;
-  if (((xc >> (TE_ACCEPT_SHIFT + st)) & 1u) == 0u) { return SJ_TAPE_ERROR; }
-  if (!first && (xc & TP_COMMA) != 0u && (kind1 == KIND_OPEN_ARRAY || (xprev & TP_COLON) != 0u)) { *rank = 2; return SJ_NUMBER_ERROR; }
-  return 0;
+  const u32 refused = ((xc >> (TE_ACCEPT_SHIFT + st)) & 1u) ^ 1u;
+  const u32 comma_for_value = first ? 0u : (((xc / TP_COMMA) & 1u) & ((kind1 == KIND_OPEN_ARRAY ? 1u : 0u) | ((xprev / TP_COLON) & 1u)));
+  *rank = (judged | refused) ? 0u : (comma_for_value ? 2u : 0u);
+  return judged ? 0u : (refused ? u32(SJ_TAPE_ERROR) : (comma_for_value ? u32(SJ_NUMBER_ERROR) : 0u));
 }
 
 // the list index of the token that writes the tape word at position p (a bracket: one word): tape positions do not decrease along the list and

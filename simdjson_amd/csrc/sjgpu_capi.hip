@@ -125,7 +125,7 @@ struct sjgpu_ctx {
   const char *last_kernel = "";     // its dominant kernel(s), as the launcher reported them (sjgpu_profile_kernel)
   uint32_t max_workgroups = 2048;
   scan_result_dev *d_result = nullptr;
-  scan_result_dev *h_result = nullptr; // pinned
+  scan_result_dev *h_result = nullptr; // pinned, 256 bytes: the scan's result; stage 2 reads its two results back at +64 and +128
   // staging for the host-buffer entry points (allocated on first use)
   uint8_t *d_in = nullptr;
   size_t d_in_bytes = 0;
@@ -692,7 +692,7 @@ extern "C" int sjgpu_ctx_create(int device, size_t capacity, sjgpu_ctx **out) {
     }
   }
   if (e == hipSuccess) { e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking); }
-  if (e == hipSuccess) { e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_result), sizeof(scan_result_dev), hipHostMallocDefault); }
+  if (e == hipSuccess) { e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_result), 256, hipHostMallocDefault); } // [0] the scan's result, [64] / [128] stage 2's two results
   if (e == hipSuccess) { e = hipMalloc(reinterpret_cast<void **>(&ctx->esc_tab), SEGMENT_BYTES_TABLE); }
   if (e == hipSuccess) { e = hipMemset(ctx->esc_tab, 0, SEGMENT_BYTES_TABLE); } // entry 0 and the pass flag start at zero
   if (e != hipSuccess) {
@@ -1752,9 +1752,14 @@ int sjgpu_stage2_tokens_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
     launch_tape(static_cast<const uint8_t *>(buf_dev), len, static_cast<const uint32_t *>(idx_dev), n, max_depth, offsets, strs, static_cast<uint8_t *>(string_buf_dev),
                 static_cast<uint64_t *>(tape_dev), tape_cap_words, ws + tape_at, s, deep);
     SJ_TRY(ctx, hipGetLastError());
-    SJ_TRY(ctx, hipMemcpyAsync(&hs, sres, sizeof(hs), hipMemcpyDeviceToHost, s));
-    SJ_TRY(ctx, hipMemcpyAsync(&ht, ws + tape_at, sizeof(ht), hipMemcpyDeviceToHost, s));
+    // (into page-locked memory: a copy into a variable on the stack goes through the runtime's staging buffer and waits for it, twice per call)
+    uint8_t *const pinned = reinterpret_cast<uint8_t *>(ctx->h_result);
+    static_assert(sizeof(strings_result_dev) <= 64 && sizeof(tape_result_dev) <= 64, "the pinned block's slots");
+    SJ_TRY(ctx, hipMemcpyAsync(pinned + 64, sres, sizeof(hs), hipMemcpyDeviceToHost, s));
+    SJ_TRY(ctx, hipMemcpyAsync(pinned + 128, ws + tape_at, sizeof(ht), hipMemcpyDeviceToHost, s));
     SJ_TRY(ctx, hipStreamSynchronize(s));
+    memcpy(&hs, pinned + 64, sizeof(hs));
+    memcpy(&ht, pinned + 128, sizeof(ht));
     bool again = false;
     if (roads == STRINGS_STREAM_ONLY && hs.path == 2 && !hs.overflow) { roads = STRINGS_WALK_ONLY; again = true; }
     if (!deep && ht.max_level >= TAPE_ONE_PASS_LEVELS) { deep = true; again = true; }

@@ -237,10 +237,14 @@ __global__ __launch_bounds__(RES_THREADS) void k_strs_resolve(const strs_summary
   const u32 t = threadIdx.x;
   u32 s_run = 0, opens_run = 0, bad = 0; // in front of the tile
   u64 bytes_run = 0;
+  // (round 6: the NEXT tile's summaries are requested before this tile's three scans -- one workgroup walks the 16 384 segments of a 256 MiB document in 16
+  // steps, and each step used to begin with a round trip to memory: 34 us per call, profiles/r06_tape_stage.txt)
+  const strs_summary none{0u, 0u, 0u, 0u, 0u, {0u, 0u, 0u}};
+  strs_summary ahead = t < nseg ? summ[t] : none;
   for (u32 tile = 0; tile < nseg; tile += RES_THREADS) {
     const u32 i = tile + t;
-    strs_summary v{0u, 0u, 0u, 0u, 0u, {0u, 0u, 0u}};
-    if (i < nseg) { v = summ[i]; }
+    const strs_summary v = ahead;
+    if (u64(i) + RES_THREADS < nseg) { ahead = summ[i + RES_THREADS]; } else { ahead = none; }
     u32 par_total, bytes_total, opens_total;
     const u32 s = (s_run + block_excl_scan1024(v.flags & 1u, sh, par_total)) & 1u;
     const u32 my_bytes = s ? v.bytes1 : v.bytes0, my_opens = s ? v.quotes - v.opens0 : v.opens0;

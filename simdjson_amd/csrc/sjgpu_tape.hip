@@ -426,7 +426,17 @@ __global__ __launch_bounds__(1024) void k_tok_scan_sums(int *__restrict__ sums, 
     const u32 k = blockIdx.x;
     int *row = sums + size_t(k) * nblocks;
     int sum = 0;
-    for (u32 i = lo; i < hi; i++) { sum += row[i]; }
+    { // (round 6: eight entries requested at a time -- one dependent load per entry made this kernel 26 us for large_random's 20 000 blocks)
+      u32 i = lo;
+      for (; i + 8 <= hi; i += 8) {
+        int v[8];
+#pragma unroll
+        for (u32 q = 0; q < 8; q++) { v[q] = row[i + q]; }
+#pragma unroll
+        for (u32 q = 0; q < 8; q++) { sum += v[q]; }
+      }
+      for (; i < hi; i++) { sum += row[i]; }
+    }
     sh[threadIdx.x] = sum;
     __syncthreads();
     for (u32 d = 1; d < 1024; d <<= 1) {
@@ -437,10 +447,20 @@ __global__ __launch_bounds__(1024) void k_tok_scan_sums(int *__restrict__ sums, 
     }
     int run = sh[threadIdx.x] - sum;
     if (threadIdx.x == 1023) { totals[k] = sh[1023]; }
-    for (u32 i = lo; i < hi; i++) {
-      const int x = row[i];
-      row[i] = run;
-      run += x;
+    {
+      u32 i = lo;
+      for (; i + 8 <= hi; i += 8) {
+        int v[8];
+#pragma unroll
+        for (u32 q = 0; q < 8; q++) { v[q] = row[i + q]; }
+#pragma unroll
+        for (u32 q = 0; q < 8; q++) { row[i + q] = run; run += v[q]; }
+      }
+      for (; i < hi; i++) {
+        const int x = row[i];
+        row[i] = run;
+        run += x;
+      }
     }
     __syncthreads();
   }
