@@ -62,8 +62,18 @@ SJ_HD int clz64_nonzero(u64 x) {
 }
 
 // jsoncharutils::is_not_structural_or_whitespace (/root/reference/src/internal/jsoncharutils_tables.cpp:14-29)
-SJ_HD bool not_structural_or_whitespace(u32 c) {
+SJ_HD bool not_structural_or_whitespace_spelled(u32 c) {
   return !(c == 0x20u || c == 0x09u || c == 0x0Au || c == 0x0Du || c == ',' || c == ':' || c == '[' || c == ']' || c == '{' || c == '}');
+}
+// the same from two 32-bit masks (tab, LF, CR | space, ',', ':') and one expression for the four brackets ('[' = 0x5B, ']' = 0x5D, '{' = 0x7B, '}' = 0x7D:
+// (c | 0x20) ^ 0x7B is 0 for the opening and 6 for the closing ones, and for no other byte): eight instructions where the ten compares above cost twenty
+// (round 6: every number token ends with this test, and the kernel that parses them is bound by its instruction count).  tests/host/test_number.cpp
+// compares the two on every byte value.
+SJ_HD bool not_structural_or_whitespace(u32 c) {
+  const u32 low = c < 32u ? (0x00002600u >> c) & 1u : 0u;                          // 0x09, 0x0A, 0x0D
+  const u32 mid = (c - 32u) < 32u ? (0x04001001u >> (c - 32u)) & 1u : 0u;          // 0x20, ',' (0x2C), ':' (0x3A)
+  const u32 t = (c | 0x20u) ^ 0x7Bu;                                               // '{' '[' -> 0, '}' ']' -> 6
+  return (low | mid | ((t == 0u || t == 6u) ? 1u : 0u)) == 0u;
 }
 
 // w * 10^q, w != 0, q in [POW5_SMALLEST, POW5_LARGEST] -> the bits of the nearest binary64 (ties to even), sign excluded.
@@ -254,7 +264,19 @@ SJ_HD number_value parse_number_token(const SRC &src, u32 pos, bigint *big, numb
   const u32 start_digits = p;
   u64 i = 0;
   u32 c = src.byte(p);
-  while (c - '0' <= 9u) { i = 10u * i + (c - '0'); c = src.byte(++p); } // may wrap; the digit count decides below
+  // i = i * 10 + digit for every digit, modulo 2^64 (may wrap; the digit count decides below) -- accumulated in 32-bit chunks of up to nine digits: chunk and
+  // scale take two full-rate instructions per digit each, the 64-bit multiply-add (two quarter-rate instructions) runs once per chunk instead of once per
+  // digit (round 6; multiplication modulo 2^64 is a ring homomorphism: i * 10^k + chunk is the same number)
+  u32 chunk = 0, scale = 1;
+  auto eat_digit = [&]() {
+    chunk = 10u * chunk + (c - '0');
+    scale *= 10u;
+    c = src.byte(++p);
+    if (scale == 1000000000u) { i = i * scale + chunk; chunk = 0; scale = 1; }
+  };
+  auto flush_digits = [&]() { i = i * scale + chunk; chunk = 0; scale = 1; };
+  while (c - '0' <= 9u) { eat_digit(); }
+  flush_digits();
   u32 digit_count = p - start_digits;
   if (digit_count == 0 || (src.byte(start_digits) == '0' && digit_count > 1)) { r.error = SJ_NUMBER_ERROR; return r; }
   bool is_float = false;
@@ -266,7 +288,8 @@ SJ_HD number_value parse_number_token(const SRC &src, u32 pos, bigint *big, numb
     s.dot = p;
     const u32 first = ++p;
     c = src.byte(p);
-    while (c - '0' <= 9u) { i = 10u * i + (c - '0'); c = src.byte(++p); }
+    while (c - '0' <= 9u) { eat_digit(); }
+    flush_digits();
     if (p == first) { r.error = SJ_NUMBER_ERROR; return r; } // "1." (:659-672)
     exp10 = -(long long)(p - first);
   }

@@ -30,6 +30,10 @@
 // error codes of broken documents); the same steps run on the CPU in tests/host/test_tape_model.cpp.
 #include "sjgpu_device.h"
 #include "sj_tape_rules.h"
+#ifdef SJGPU_LAB_STAGE_PHASES
+#include <vector>
+#include <algorithm>
+#endif
 
 namespace sjgpu {
 namespace {
@@ -152,21 +156,21 @@ constexpr u32 SG_WINDOW = SJGPU_STAGE_WINDOW; // bytes of LDS per wave (a multip
 constexpr u32 SG_STEPS = SG_WINDOW / 1024u;
 static_assert(SG_WINDOW % 1024u == 0 && SG_WINDOW >= 1024u, "a staging step is 64 lanes x 16 bytes");
 
-// The document through the wave's window: bytes [a0, a0 + span) are staged (bytes at or beyond len as the spaces of a padded_string).  A byte is ONE LDS
-// read (ds_read_u8) and three VALU instructions, without a branch: an offset beyond the staged bytes is clamped to the byte BEHIND them, a zero, which ends
-// every digit run -- and the accessor remembers how far it was asked (`reach`): a token that asked beyond the window is parsed AGAIN, from memory, by the
-// caller (wide_window_bytes; more than SG_OVER bytes of number: a handful per document at most).  The first version kept 32 bytes of the token in registers
-// (the window of k_tape_numbers, filled from LDS) and paid ~15 VALU instructions per byte for the selects and the 64-bit shift that pick a byte out of
-// them, the second branched per byte between LDS and memory (600 global loads and 950 branches in the kernel's code): the kernel is VALU-bound
-// (profiles/r06_tape_stage.txt: 251 M / 214 M instructions per large_random call at four cycles each, 59 % of the SIMDs' time).
+// The document through the wave's window, in the window's own coordinates: bytes [0, span) are staged (bytes at or beyond len as the spaces of a
+// padded_string), byte `span` is a zero.  A byte is ONE LDS read (ds_read_u8) and two VALU instructions, without a branch and without a clamp: parse_number
+// reads a token front to back and stops at the first byte that is no digit -- the zero at the latest -- and everything else it looks at lies in front of
+// that byte, so no read goes beyond `span`.  The accessor remembers how far it was asked (`reach`): a token that reached the zero is parsed AGAIN, from
+// memory, by the caller (wide_window_bytes; more than SG_OVER bytes of number: a handful per document at most).  The first version kept 32 bytes of the
+// token in registers (the window of k_tape_numbers, filled from LDS) and paid ~15 VALU instructions per byte for the selects and the 64-bit shift that
+// pick a byte out of them, the second branched per byte between LDS and memory (600 global loads and 950 branches in the kernel's code), the third clamped:
+// the kernel is bound by its instruction count (profiles/r06_tape_stage.txt: 251 M / 214 M / 180 M VALU instructions per large_random call at four cycles
+// each; the phase clocks of scripts/lab/stage_phases.py: a wave spends its time issuing, not waiting).
 struct staged_bytes {
-  const u8 *win; // the window (LDS): its first byte is byte a0 of the document, win[span] = 0
-  u32 a0, span;
+  const u8 *win; // the window (LDS)
   mutable u32 reach = 0; // the largest offset asked for
-  __device__ __forceinline__ u32 byte(u32 pos) const {
-    const u32 off = pos - a0;
+  __device__ __forceinline__ u32 byte(u32 off) const {
     reach = off > reach ? off : reach;
-    return u32(win[off < span ? off : span]);
+    return u32(win[off]);
   }
 };
 // bytes [a0, a0 + bytes) of the document into the window (a0 and bytes: multiples of 16, bytes <= SG_WINDOW): all loads issued, then all stores
@@ -213,6 +217,13 @@ __device__ __forceinline__ u32 atom_error_of(u32 lo, u32 hi) {
   return 0u;
 }
 
+#ifdef SJGPU_LAB_STAGE_PHASES
+constexpr u32 LAB_WAVES = 131072;
+__device__ u32 d_stage_trace[LAB_WAVES][8]; // per wave: ticks per phase, no atomics
+#define PHASE(k) do { const u64 now_ = wall_clock64(); acc_phase[k] += u32(now_ - t_phase); t_phase = now_; } while (0)
+#else
+#define PHASE(k) do { } while (0)
+#endif
 // a parsed number token i: its error, or its value where k_tok_apply will look for it
 __device__ __forceinline__ void park_number(const number_value &v, u32 i, u64 at, u64 *__restrict__ numbits, u8 *__restrict__ numtype, u32 *__restrict__ slow_list,
                                             u32 slow_cap, tape_result_dev *__restrict__ res) {
@@ -264,6 +275,10 @@ __global__ __launch_bounds__(TS_THREADS, SJGPU_STAGE_OCC) void k_tok_stage(const
   u8 *const tokc_w = tokc + 2u + t0_64;
   const u32 *const idx_w = idx + t0_64;
   u32 a = 0, b = 0, c = 0;
+#ifdef SJGPU_LAB_STAGE_PHASES
+  u64 t_phase = wall_clock64();
+  u32 acc_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   if (cnt) { // (wave-uniform; a wave without tokens only takes part in the block's sums)
     const u32 rows = (cnt + 63u) / 64u;
     u32 E = 0; // lane l < rows: where row l begins; lane rows: where the wave's span ends (behind its last token)
@@ -289,6 +304,7 @@ __global__ __launch_bounds__(TS_THREADS, SJGPU_STAGE_OCC) void k_tok_stage(const
       if (lane <= rows) { row_start[lane] = E; }
     }
     wave_lds_fence();
+    PHASE(0); // the list rows have arrived and are parked
     const bool first_wave = t0 == 0u; // holds the root token
     u32 ncount = 0; // number tokens listed so far (wave-uniform)
     u32 ra = 0;
@@ -310,6 +326,7 @@ __global__ __launch_bounds__(TS_THREADS, SJGPU_STAGE_OCC) void k_tok_stage(const
         if (lane == 0) { reinterpret_cast<u32 *>(win)[bytes >> 2] = 0u; } // what an offset beyond the staged bytes reads (staged_bytes): no digit
         wave_lds_fence();
       }
+      PHASE(1); // staged
       const u32 g0 = ncount;
 #pragma unroll 1
       for (u32 r = ra; r < rb; r++) {
@@ -351,6 +368,7 @@ __global__ __launch_bounds__(TS_THREADS, SJGPU_STAGE_OCC) void k_tok_stage(const
         ncount += u32(popc64(nm));
       }
       wave_lds_fence();
+      PHASE(2); // rows
       // the group's numbers, one per lane: visit_number (tape_builder.h:213-275) = parse_number (numberparsing.h:859-971, sj_number.h).  First from the window;
       // a token that reaches beyond it -- and every token of a row read in place -- is flagged in the list and parsed from memory in a second sweep.
       u32 again = staged ? 0u : 1u; // wave-uniform
@@ -368,8 +386,8 @@ __global__ __launch_bounds__(TS_THREADS, SJGPU_STAGE_OCC) void k_tok_stage(const
           bool redo = false;
           if (k < ncount) {
             const u32 tl = list[k];
-            const u32 p = row_start[tl >> 6] + u32(rel[tl]);
-            const staged_bytes src{win8, a0, span};
+            const u32 p = (row_start[tl >> 6] - a0) + u32(rel[tl]); // inside the window: p + SG_OVER <= span
+            const staged_bytes src{win8};
             const number_value v = parse_number_token(src, p, static_cast<bigint *>(nullptr));
             redo = src.reach >= span;
             if (redo) { list[k] = (unsigned short)(tl | 0x8000u); }
@@ -395,12 +413,24 @@ __global__ __launch_bounds__(TS_THREADS, SJGPU_STAGE_OCC) void k_tok_stage(const
         }
       }
       wave_lds_fence(); // (the next group's staging overwrites the window: LDS traffic of one wave stays in order)
+      PHASE(3); // numbers
+#ifdef SJGPU_LAB_STAGE_PHASES
+      acc_phase[6]++;
+#endif
       ra = rb;
     }
   }
   a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); // a wave: at most 1024 tokens x 2 words: the fields do not overflow
   if (lane == 0) { sh[0][wave] = a; sh[1][wave] = b; sh[2][wave] = c; }
   __syncthreads();
+  PHASE(4); // waiting for the workgroup's other waves
+#ifdef SJGPU_LAB_STAGE_PHASES
+  { const u32 wid = blockIdx.x * 4u + wave; if (lane < 8 && wid < LAB_WAVES) { u32 vv = 0;
+#pragma unroll
+      for (u32 q = 0; q < 8; q++) { if (lane == q) { vv = acc_phase[q]; } }
+      if (lane == 7) { vv = 1u; }
+      d_stage_trace[wid][lane] = vv; } }
+#endif
   if (tid == 0) {
     u32 slots = 0, sel = 0, strs = 0, opens = 0, closes = 0, numbers = 0;
     for (u32 w = 0; w < TS_THREADS / 64; w++) {
@@ -855,6 +885,17 @@ __global__ __launch_bounds__(64) void k_tape_slow_numbers(const u8 *__restrict__
 
 } // namespace
 
+#ifdef SJGPU_LAB_STAGE_PHASES
+extern "C" int sjgpu_lab_stage_phases(unsigned long long *out) { // sums the per-wave records (ticks of 10 ns; [6] groups, [7] waves) and clears them
+  static std::vector<u32> host;
+  host.resize(size_t(LAB_WAVES) * 8);
+  if (hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(d_stage_trace), host.size() * 4) != hipSuccess) { return -1; }
+  for (u32 k = 0; k < 8; k++) { out[k] = 0; }
+  for (size_t w = 0; w < LAB_WAVES; w++) { for (u32 k = 0; k < 8; k++) { out[k] += host[w * 8 + k]; } }
+  std::fill(host.begin(), host.end(), 0u);
+  return hipMemcpyToSymbol(HIP_SYMBOL(d_stage_trace), host.data(), host.size() * 4) == hipSuccess ? 0 : -1;
+}
+#endif
 static inline u32 blocks_of(u64 n, u32 per) { return u32((n + per - 1) / per); }
 
 // Workspace layout for n structurals (every array 256-byte aligned): see tape_workspace below.

@@ -17,6 +17,9 @@ struct text_bytes {
 };
 
 int main() {
+  for (u32 c = 0; c < 256; c++) { // the terminator test from masks against the spelled-out one
+    if (not_structural_or_whitespace(c) != not_structural_or_whitespace_spelled(c)) { fprintf(stderr, "not_structural_or_whitespace(%02x): the two forms disagree\n", c); return 1; }
+  }
   std::string line;
   static bigint big[2];
   unsigned long slow_tokens = 0;
