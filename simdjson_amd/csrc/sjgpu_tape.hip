@@ -106,9 +106,19 @@ struct wide_window_bytes {
 __device__ __forceinline__ void report_error(tape_result_dev *res, u64 key) { atomicMin(reinterpret_cast<unsigned long long *>(&res->error_key), (unsigned long long)key); }
 
 // the result and the control words: `words` dwords from res on are cleared, then the three that are not zero
-__global__ void k_tape_init(tape_result_dev *__restrict__ res, u32 *__restrict__ n_words, u32 words, u32 n1, u32 scan_len) {
+// ... and the two tables of "what a token's byte is" (round 6): rounds 3-5 had every workgroup of the token kernels build its LDS table from the predicates of
+// sj_tape_rules.h -- one entry per thread, ~400 instructions with their branches for an entry of k_tok_apply's table, a tenth of all that kernel issued
+// (a workgroup only handles 16 tokens per thread).  Built once per call here, loaded with one instruction there.
+__global__ void k_tape_init(tape_result_dev *__restrict__ res, u32 *__restrict__ n_words, u32 words, u32 n1, u32 scan_len, u32 *__restrict__ entry_tab,
+                            uint4 *__restrict__ stage_tab) {
   u32 *w = reinterpret_cast<u32 *>(res);
   for (u32 k = threadIdx.x; k < words; k += 64u) { w[k] = 0u; } // (launched with 64 threads)
+  for (u32 v = threadIdx.x; v < 256u; v += 64u) {
+    const u32 x = token_props_of(v);
+    const tok_packed pk = tok_contribution_of_props(x);
+    entry_tab[v] = token_entry_of(v);               // k_tok_apply
+    stage_tab[v] = make_uint4(pk.a, pk.b, pk.c, x); // k_tok_stage
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     res->error_key = NO_ERROR_KEY;
@@ -245,7 +255,8 @@ __device__ __forceinline__ void park_number(const number_value &v, u32 i, u64 at
 #endif
 __global__ __launch_bounds__(TS_THREADS, SJGPU_STAGE_OCC) void k_tok_stage(const u8 *__restrict__ buf, u32 len, const u32 *__restrict__ idx, u32 n, u8 *__restrict__ tokc,
                                                             int *__restrict__ sums, u32 nblocks, u64 *__restrict__ numbits, u8 *__restrict__ numtype,
-                                                            u32 *__restrict__ slow_list, u32 slow_cap, tape_result_dev *__restrict__ res) {
+                                                            u32 *__restrict__ slow_list, u32 slow_cap, tape_result_dev *__restrict__ res,
+                                                            const uint4 *__restrict__ stage_tab) {
   __shared__ u32 sh[3][TS_THREADS / 64];
   __shared__ uint4 sh_tab[256]; // what a token's byte IS: its packed contribution to the six counters (tok_packed) and its properties (token_props_of) -- one 16-byte
                                 // LDS read per token instead of ~20 compares, or of the nine VALU instructions that unpack the contribution from the properties
@@ -255,11 +266,7 @@ __global__ __launch_bounds__(TS_THREADS, SJGPU_STAGE_OCC) void k_tok_stage(const
   __shared__ uint4 sh_win[TS_THREADS / 64][SG_WINDOW / 16u + 1u];     // its window
   static_assert(TS_THREADS == 256 && TS_BLOCK == 4u * SG_WAVE_TOKENS && SG_ROWS <= 31u, "one table entry per thread; a wave per row of k_tok_apply");
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  {
-    const u32 x = token_props_of(tid);
-    const tok_packed pk = tok_contribution_of_props(x);
-    sh_tab[tid] = make_uint4(pk.a, pk.b, pk.c, x);
-  }
+  sh_tab[tid] = stage_tab[tid]; // (k_tape_init built it)
   lds_writes_done();
   __syncthreads();
   if (blockIdx.x == 0 && tid == 0) { tokc[0] = 0; tokc[1] = 0; tokc[n + 2] = 0; tokc[n + 3] = 0; }
@@ -506,7 +513,8 @@ __global__ __launch_bounds__(TS_THREADS, 4) void k_tok_apply(const u8 *__restric
                                                          int *__restrict__ tpos, unsigned short *__restrict__ key, u32 *__restrict__ tok,
                                                          int *__restrict__ m_out, int *__restrict__ max_level, const u64 *__restrict__ numbits,
                                                          const u8 *__restrict__ numtype, const u32 *__restrict__ str_offsets, strings_handoff strs,
-                                                         u8 *__restrict__ string_buf, u64 *__restrict__ tape, u64 tape_cap, tape_result_dev *__restrict__ res) {
+                                                         u8 *__restrict__ string_buf, u64 *__restrict__ tape, u64 tape_cap, tape_result_dev *__restrict__ res,
+                                                         const u32 *__restrict__ entry_tab) {
   // Round 4, second half: the nesting depth is not written anywhere.  What it decides -- "the root value has ended" and the nesting limit
   // (depth_rule, sj_tape_rules.h) and "the list ends inside a container" -- is said HERE, where it sits in a register; the levels of the brackets and
   // commas go into the sort's keys as before.  (k_tape_rules read 4 B per token for it, this kernel wrote them.)
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(TS_THREADS, 4) void k_tok_apply(const u8 *__restric
   __shared__ u32 sh_props[256]; // what a token's byte IS, as bits (token_entry_of, sj_tape_rules.h: its properties, the walk's state behind it, the states that
                                 // accept it): one LDS read instead of ~20 compares per token -- and, round 6, all that the token's own rule needs
   static_assert(TS_THREADS == 256, "one table entry per thread");
-  sh_props[threadIdx.x] = token_entry_of(threadIdx.x);
+  sh_props[threadIdx.x] = entry_tab[threadIdx.x]; // (k_tape_init built it)
   __syncthreads();
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u32 block0 = blockIdx.x * TS_BLOCK; // (32-bit list indexes throughout: n < 2^32 - 16, sjgpu_stage2_device, and the last block ends below n + 4096)
@@ -909,6 +917,8 @@ struct tape_workspace {
   int *totals;               // ... and the sums of the rows (k_tok_scan_sums): [2] = the string tokens of the list
   u64 *numbits;              // the value words of the number tokens as k_tok_stage parked them: [first token of the wave's row + ordinal inside the row]
   u8 *numtype;               // ... and their types ('l', 'u', 'd')
+  u32 *entry_tab;            // token_entry_of of every byte value (k_tok_apply's table), built by k_tape_init
+  uint4 *stage_tab;          // k_tok_stage's table
   u32 tok_blocks;
   unsigned short *key_a, *key_b;
   u32 *tok_a, *tok_b, *openpos, *slow_list;
@@ -926,6 +936,8 @@ static tape_workspace carve(uint8_t *base, uint32_t n, uint64_t len) {
   w.res = reinterpret_cast<tape_result_dev *>(take(sizeof(tape_result_dev)));
   w.n_words = reinterpret_cast<u32 *>(take(128)); // (behind the result: launch_tape_front clears both with one memset)
   w.totals = reinterpret_cast<int *>(w.n_words) + 16; // [16 .. 21]
+  w.entry_tab = reinterpret_cast<u32 *>(take(256 * 4));
+  w.stage_tab = reinterpret_cast<uint4 *>(take(256 * 16));
   w.m = reinterpret_cast<int *>(w.n_words) + 8; // [8] = m, [9] = highest level in the sort, [11] = m + 1 (length of the opens scan), [12] = string tokens;
   // n_words[2] = length of the second pass's scan
   w.tokc = take(n1 + 8);
@@ -961,12 +973,12 @@ const int *launch_tape_front(const uint8_t *buf, uint64_t len, const uint32_t *i
   // one small kernel for the result and the control words behind it (they share the first 512 bytes of the workspace): all zero but three words
   // (rounds 3-4a: four memsets -- four launches of the runtime's fill kernel, 4 us each)
   hipLaunchKernelGGL(k_tape_init, dim3(1), dim3(64), 0, s, w.res, w.n_words, u32(reinterpret_cast<uint8_t *>(w.n_words + 16) - reinterpret_cast<uint8_t *>(w.res)) / 4u, n1,
-                     2u * w.tiles * RADIX_BINS);
+                     2u * w.tiles * RADIX_BINS, w.entry_tab, w.stage_tab);
   // (tok: since round 6 the front stages the document's bytes for the numbers and the atoms anyway and takes the token bytes from the same window; the
   // stream is accepted and not read)
   (void)tok;
   hipLaunchKernelGGL(k_tok_stage, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, buf, u32(len), idx, n, w.tokc, w.sums, w.tok_blocks, w.numbits, w.numtype, w.slow_list, w.slow_cap,
-                     w.res);
+                     w.res, w.stage_tab);
   hipLaunchKernelGGL(k_tok_scan_sums, dim3(TS_SUMS), dim3(1024), 0, s, w.sums, w.tok_blocks, w.totals);
   return w.totals + 2; // the number of string tokens (device)
 }
@@ -981,7 +993,7 @@ void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t
   const int *m_ptr = w.m;
   const u32 kmax = max_depth < 4095u ? max_depth : 4095u;
   hipLaunchKernelGGL(k_tok_apply, dim3(w.tok_blocks), dim3(TS_THREADS), 0, s, w.tokc, n, kmax, max_depth, w.sums, w.tok_blocks, w.slots, w.key_a, w.tok_a, w.m, w.m + 1,
-                     w.numbits, w.numtype, str_offsets, strs, string_buf, tape, tape_cap, w.res);
+                     w.numbits, w.numtype, str_offsets, strs, string_buf, tape, tape_cap, w.res, w.entry_tab);
   // two passes of six bits cover levels up to 4095; the second one only runs for documents nested 64 deep and more
   const int *max_level = w.m + 1;
   hipLaunchKernelGGL(k_radix_hist, dim3(w.tiles), dim3(64), 0, s, w.key_a, m_ptr, 0u, w.tiles, w.hist, max_level, w.n_words + 2);
