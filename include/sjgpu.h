@@ -291,8 +291,10 @@ int sjgpu_match_keys_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, con
 int sjgpu_stage2_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const void *idx_dev, uint32_t n, uint32_t max_depth, void *tape_dev,
                         size_t tape_cap_words, void *string_buf_dev, size_t string_buf_bytes, void *stream, uint64_t *tape_words_out,
                         uint64_t *string_bytes_out);
-/* the same with the token stream of sjgpu_stage1_tokens_device (tok_dev[i] = buf_dev[idx_dev[i]], i < n; NULL = sjgpu_stage2_device): the tape's token front
- * reads one coalesced byte per token instead of gathering it out of the document */
+/* the same with the token stream of sjgpu_stage1_tokens_device (tok_dev[i] = buf_dev[idx_dev[i]], i < n; NULL = sjgpu_stage2_device).  Round 5: the tape's token
+ * front read one coalesced byte per token instead of gathering it out of the document.  Since round 6 the front stages the document's bytes in LDS for the
+ * numbers and the atoms and takes the token bytes from the same window (k_tok_stage): the stream is accepted and NOT read -- same results, same time as
+ * sjgpu_stage2_device; the consumer that still profits from the stream is sjgpu_depth_scan_tokens_device */
 int sjgpu_stage2_tokens_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, const void *idx_dev, uint32_t n, const void *tok_dev, uint32_t max_depth,
                                void *tape_dev, size_t tape_cap_words, void *string_buf_dev, size_t string_buf_bytes, void *stream, uint64_t *tape_words_out,
                                uint64_t *string_bytes_out);

@@ -133,7 +133,7 @@ def test_no_kernel_spills(lib):
     # number tokens whose rounding needs exact arithmetic (sj_number.h); it exists so that the kernel that parses the numbers (k_tok_stage since round 6) needs none
     spilling = {k: v["scratch"] for k, v in res.items() if v.get("scratch", 0) != 0 and "k_tape_slow_numbers" not in k}
     assert spilling == {}, spilling
-    assert any("k_tok_stage" in k for k in res) and any("k_tape_rules" in k for k in res)
+    assert any("k_tok_stage" in k for k in res) and any("k_tape_match" in k for k in res)
     # the occupancy the launch bounds ask for is the occupancy the register count allows (MI355X_MICROARCH.md, register file table)
     for k, v in res.items():
         if "k_fused_pipelined" in k or "k_minify_onchip" in k:
