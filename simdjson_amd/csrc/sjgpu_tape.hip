@@ -669,7 +669,7 @@ __global__ __launch_bounds__(TS_THREADS, 4) void k_tok_apply(const u8 *__restric
 }
 
 // ---- stable radix sort on the level, one digit of RADIX_BITS per pass ----------------------------------------------------------------
-// m = number of elements = selpos[n] (device memory).  hist is digit-major: hist[d * tiles + t], so that ONE exclusive scan of the
+// m = number of elements = selpos[n] (device memory).  hist is digit-major: hist[d * live + t] (live = the tiles that hold elements), so that ONE exclusive scan of the
 // whole table yields, for every (digit, tile), where that tile's elements with that digit begin in the output.
 // second pass (shift > 0): nothing to do when every level fits into the first digit; the first pass tells the second's scan how long it is
 // Round 4: a SECOND table behind the first counts the opening brackets per (digit, tile): scanned with the first (one scan over both), it
@@ -677,12 +677,21 @@ __global__ __launch_bounds__(TS_THREADS, 4) void k_tok_apply(const u8 *__restric
 // sorted keys, the scan over m + 1 flags and the pass that listed the opens' positions (k_tape_opens / k_tape_openpos, 110 us per
 // twitter-like call) are gone: the last scatter writes both arrays on its way.
 __global__ __launch_bounds__(64) void k_radix_hist(const unsigned short *__restrict__ key, const int *__restrict__ m_ptr, u32 shift, u32 tiles, int *__restrict__ hist,
-                                                   const int *__restrict__ max_level, u32 *__restrict__ second_scan_len) {
+                                                   const int *__restrict__ max_level, u32 *__restrict__ scan_len) {
   const u32 lane = threadIdx.x, tile = blockIdx.x;
   const bool one_pass = u32(*max_level) < RADIX_BINS;
-  if (shift == 0 && tile == 0 && lane == 0) { *second_scan_len = one_pass ? 0u : 2u * tiles * RADIX_BINS; }
-  if (shift != 0 && one_pass) { return; }
   const u32 m = u32(*m_ptr);
+  // Round 6: the tables are as wide as the tiles that HOLD elements (live = ceil(m / 2048), known on the device only; the grid and the room are sized for
+  // n + 1 tokens): the scans run over 128 x live entries and the tiles behind write nothing -- large_random: two tiles in three, each 128 scattered words of
+  // zeros per call (0.18 GB of partial lines) for the scan to read.  The first pass tells both scans their lengths.
+  const u32 live = (m + RADIX_TILE - 1u) / RADIX_TILE;
+  (void)tiles;
+  if (shift == 0 && tile == 0 && lane == 0) {
+    scan_len[0] = 2u * live * RADIX_BINS;                   // this pass's scan (n_words[1])
+    scan_len[1] = one_pass ? 0u : 2u * live * RADIX_BINS;   // the second pass's (n_words[2])
+  }
+  if (shift != 0 && one_pass) { return; }
+  if (tile >= live) { return; }
   const u32 base = tile * RADIX_TILE;
   // the tile's keys are requested at once (a wave per tile and a load per step made 32 dependent round trips: there are fewer tiles than the chip holds waves)
   u32 kk[RADIX_STEPS];
@@ -697,7 +706,7 @@ __global__ __launch_bounds__(64) void k_radix_hist(const unsigned short *__restr
   // per call, 133 us for a kernel of 9 M VALU instructions, profiles/r06_pmc_summary.txt); a loop over the DISTINCT digits of a step took that to 83 us and
   // twitter-like, with six to eight levels per step, from 39 to 53 (profiles/r06_tape_stage.txt).
   u32 c0 = 0, c1 = 0;
-  if (base < m) { // (wave-uniform: tiles behind the elements only write their zeros)
+  {
 #pragma unroll
     for (u32 q = 0; q < RADIX_STEPS; q++) {
       const u32 k = kk[q];
@@ -713,8 +722,8 @@ __global__ __launch_bounds__(64) void k_radix_hist(const unsigned short *__restr
       c1 += u32(popc64(mine & __ballot(live && kind_is_open(k >> KIND_SHIFT))));
     }
   }
-  hist[lane * tiles + tile] = int(c0);
-  hist[(RADIX_BINS + lane) * tiles + tile] = int(c1);
+  hist[lane * live + tile] = int(c0);
+  hist[(RADIX_BINS + lane) * live + tile] = int(c1);
 }
 __global__ __launch_bounds__(64) void k_radix_scatter(const unsigned short *__restrict__ key_in, const u32 *__restrict__ tok_in, const int *__restrict__ m_ptr, u32 shift,
                                                       u32 tiles, const int *__restrict__ hist, unsigned short *__restrict__ key_out, u32 *__restrict__ tok_out,
@@ -727,8 +736,10 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const unsigned short *__re
   // the grid is sized for n + 1 elements (m is only known on the device): a tile behind the m that exist has nothing to move.  Rounds 3-5 let it run its 32
   // steps of ballots over dead lanes -- two tiles in three of large_random's grid, 226 us for the kernel (profiles/r06_tape_stage.txt)
   if (tile * RADIX_TILE >= m) { return; }
-  next[lane] = u32(hist[lane * tiles + tile]);
-  onext[lane] = u32(hist[(RADIX_BINS + lane) * tiles + tile]) - m;
+  const u32 live = (m + RADIX_TILE - 1u) / RADIX_TILE; // the tables' width: k_radix_hist
+  (void)tiles;
+  next[lane] = u32(hist[lane * live + tile]);
+  onext[lane] = u32(hist[(RADIX_BINS + lane) * live + tile]) - m;
   wave_lds_fence();
   const u32 base = tile * RADIX_TILE;
   // keys and payloads of the whole tile are requested at once (see k_radix_hist), then the 32 steps run out of registers
@@ -996,11 +1007,11 @@ void launch_tape(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint32_t
                      w.numbits, w.numtype, str_offsets, strs, string_buf, tape, tape_cap, w.res, w.entry_tab);
   // two passes of six bits cover levels up to 4095; the second one only runs for documents nested 64 deep and more
   const int *max_level = w.m + 1;
-  hipLaunchKernelGGL(k_radix_hist, dim3(w.tiles), dim3(64), 0, s, w.key_a, m_ptr, 0u, w.tiles, w.hist, max_level, w.n_words + 2);
+  hipLaunchKernelGGL(k_radix_hist, dim3(w.tiles), dim3(64), 0, s, w.key_a, m_ptr, 0u, w.tiles, w.hist, max_level, w.n_words + 1);
   enqueue_scan(w.hist, 2 * w.tiles * RADIX_BINS, w.n_words + 1, w.partial, s);
   hipLaunchKernelGGL(k_radix_scatter, dim3(w.tiles), dim3(64), 0, s, w.key_a, w.tok_a, m_ptr, 0u, w.tiles, w.hist, w.key_b, w.tok_b, max_level, w.opens, w.openpos);
   if (deep) {
-    hipLaunchKernelGGL(k_radix_hist, dim3(w.tiles), dim3(64), 0, s, w.key_b, m_ptr, RADIX_BITS, w.tiles, w.hist, max_level, w.n_words + 2);
+    hipLaunchKernelGGL(k_radix_hist, dim3(w.tiles), dim3(64), 0, s, w.key_b, m_ptr, RADIX_BITS, w.tiles, w.hist, max_level, w.n_words + 1);
     enqueue_scan(w.hist, 2 * w.tiles * RADIX_BINS, w.n_words + 2, w.partial, s);
     hipLaunchKernelGGL(k_radix_scatter, dim3(w.tiles), dim3(64), 0, s, w.key_b, w.tok_b, m_ptr, RADIX_BITS, w.tiles, w.hist, w.key_a, w.tok_a, max_level, w.opens, w.openpos);
   }

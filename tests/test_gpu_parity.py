@@ -1496,6 +1496,26 @@ def test_tape_numbers(tape_parser, orc, ref):
     assert _assert_same_parse(tape_parser, want, b"[" + b",\n".join(good) + b"]") == 0
 
 
+def test_tape_staged_token_front(tape_parser, orc, ref):
+    """k_tok_stage's groups on the hardware (round 6; the emulator runs the same documents through the same source, tests/test_tape_emu.py): tokens packed
+    densely and far apart in one list -- staged groups beside rows read in place --, numbers and atoms at the last bytes of a window and of the document,
+    numbers longer than the 64 bytes staged behind a group's last token (parsed again from memory), and the same places broken."""
+    import test_tape_emu
+    want = _checker_parse(orc, ref)
+    rng = np.random.default_rng(14)
+    docs = test_tape_emu._staged_front_documents(rng)
+    valid = sum(1 for d in docs if _assert_same_parse(tape_parser, want, np.frombuffer(d, dtype=np.uint8)) == 0)
+    assert valid >= 30, valid
+    seen = {}
+    for d in docs[:40]:
+        for _ in range(3):
+            m = jsongen.mutate(rng, d)
+            if len(m):
+                e = _assert_same_parse(tape_parser, want, np.frombuffer(bytes(m), dtype=np.uint8))
+                seen[e] = seen.get(e, 0) + 1
+    assert len(seen) >= 2, seen
+
+
 def test_tape_depth_limits(tape_parser, orc, ref):
     want = _checker_parse(orc, ref)
     for max_depth in (1, 2, 3, 16, 1024):
