@@ -671,7 +671,8 @@ def leg_tape(cx):
             ms_t = event_ms_per_call(torch, run_t, reps)
             leg["with_token_stream"] = {"stage2_ms_per_call": round(ms_t, 3), "stage1_split_ms_without_tokens": round(ms_s1, 4), "stage1_split_ms_with_tokens": round(ms_s1t, 4),
                                         "stage1_plus_stage2_ms": {"plain": round(ms_s1 + gpu_ms, 3), "token_stream": round(ms_s1t + ms_t, 3)},
-                                        "parity": "the same tape, word for word, as the call that gathers its token bytes out of the document"}
+                                        "parity": "the same tape, word for word, as the call that gathers its token bytes out of the document",
+                                        "note": "since round 6 the tape's token front (k_tok_stage) takes the token bytes from the staged document: the stream is accepted and not read"}
             del tape_t
         del tok, idx_t
         if impl:

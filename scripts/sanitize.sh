@@ -18,7 +18,7 @@ case ${1:-build} in
     for san in address thread; do
       $HIPCC --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -pthread -fsanitize=$san -I include -I $S \
         $S/sjgpu_kernels.hip $S/sjgpu_fused.hip $S/sjgpu_small.hip $S/sjgpu_finish.hip $S/sjgpu_strings.hip $S/sjgpu_string_stream.hip $S/sjgpu_tape.hip \
-        $S/sjgpu_mgpu.hip $S/sjgpu_comm.hip $S/sjgpu_capi.hip $S/stage1_finish.cpp -ldl \
+        $S/sjgpu_mgpu.hip $S/sjgpu_comm.hip $S/sjgpu_capi.hip $S/sjgpu_capi_host.hip $S/sjgpu_capi_stage2.hip $S/stage1_finish.cpp -ldl \
         -o build/san/libsjgpu_$san.so || exit 1
       $CLANG -O1 -g -std=c++17 -fsanitize=$san -DSIMDJSON_THREADS_ENABLED=1 -I $REF/include -I $REF/src -c $REF/src/simdjson.cpp -o build/san/simdjson_$san.o || exit 1
       $CLANG -O1 -g -std=c++17 -fsanitize=$san -DSIMDJSON_THREADS_ENABLED=1 -I $REF/include -I $S/plugin -I include \

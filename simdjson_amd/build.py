@@ -51,8 +51,8 @@ def build_corpus(force=False):
 
 
 SJGPU_SOURCES = ("sjgpu_kernels.hip", "sjgpu_fused.hip", "sjgpu_small.hip", "sjgpu_finish.hip", "sjgpu_strings.hip", "sjgpu_string_stream.hip", "sjgpu_tape.hip",
-                 "sjgpu_mgpu.hip", "sjgpu_comm.hip", "sjgpu_capi.hip", "stage1_finish.cpp")
-SJGPU_HEADERS = ("sj_block.h", "sj_number.h", "sj_tape_rules.h", "sj_string_stream.h", "sj_xcarry.h", "sj_pow5_table.inc", "sjgpu_internal.h", "sjgpu_device.h")
+                 "sjgpu_mgpu.hip", "sjgpu_comm.hip", "sjgpu_capi.hip", "sjgpu_capi_host.hip", "sjgpu_capi_stage2.hip", "stage1_finish.cpp")
+SJGPU_HEADERS = ("sj_block.h", "sj_number.h", "sj_tape_rules.h", "sj_string_stream.h", "sj_xcarry.h", "sj_pow5_table.inc", "sjgpu_internal.h", "sjgpu_device.h", "sjgpu_ctx.h")
 
 
 def sjgpu_source_stamp():

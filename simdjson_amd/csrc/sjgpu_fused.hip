@@ -63,7 +63,7 @@ __device__ __forceinline__ void desc_store(u64 *p, u64 v) { __hip_atomic_store(p
 // finds everybody else gone moves the accumulated flags into the result and zeroes descriptors and control words.  Flags are ORed into the
 // control word, not into the result: the result needs no clearing either (its other two fields are written by the last TILE's owner).
 // The host clears once, when the workspace is allocated, and in front of the first call after anything that makes the state doubtful -- a HIP error on the
-// context, a chain that gave up, a traced run (sjgpu_ctx::ws_dirty, sjgpu_capi.hip).
+// context, a chain that gave up, a traced run (sjgpu_ctx::ws_dirty, sjgpu_ctx.h).
 constexpr u32 FUSED_CTL_WORDS = FUSED_WORKSPACE_EXTRA_WORDS; // u64 words behind the descriptors: [ticket, done][flags, -] ... and, a 128-byte line further, the second ticket counter
 __device__ __forceinline__ u32 *ctl_done(u32 *ticket) { return ticket + 1; }
 __device__ __forceinline__ u32 *ctl_flags(u32 *ticket) { return ticket + 2; }

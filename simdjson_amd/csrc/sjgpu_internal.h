@@ -1,4 +1,4 @@
-// simdjson_amd/csrc/sjgpu_internal.h -- launch interface between the C-ABI (sjgpu_capi.hip) and the
+// simdjson_amd/csrc/sjgpu_internal.h -- launch interface between the C-ABI (sjgpu_capi*.hip, sjgpu_ctx.h) and the
 // gfx950 kernels (sjgpu_kernels.hip).  Geometry:
 //
 //   block   = 64 input bytes                = one lane

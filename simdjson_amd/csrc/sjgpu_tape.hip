@@ -972,7 +972,7 @@ static tape_workspace carve(uint8_t *base, uint32_t n, uint64_t len) {
 }
 size_t tape_workspace_bytes(uint32_t n, uint64_t len) { return carve(nullptr, n, len).bytes; }
 
-// Stage 2 in two halves, the string buffer in between (sjgpu_capi.hip: sjgpu_stage2_device).  idx[0 .. n] (n >= 1; idx[n] = len, stage 1's first
+// Stage 2 in two halves, the string buffer in between (sjgpu_capi_stage2.hip: sjgpu_stage2_device).  idx[0 .. n] (n >= 1; idx[n] = len, stage 1's first
 // sentinel); workspace: tape_workspace_bytes(n, len), its first bytes are the tape_result_dev afterwards.
 // launch_tape_front: the byte of every token and the block totals of the six per-token counters.  Returns (a device pointer to) the number of
 // string tokens, which the string pass takes instead of counting them itself.  launch_tape (behind the string pass): tape position and depth of

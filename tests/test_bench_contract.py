@@ -204,4 +204,6 @@ def test_the_token_stream_s_cost_and_gain_are_in_the_line():
     assert t["roofline"]["frac"] >= 0.30  # what VERDICT r04 asked of the depth scan
     for kind, leg in d["legs"]["next_f3_tape"].items():
         w = leg["with_token_stream"]
-        assert w["stage2_ms_per_call"] < leg["gpu_ms_per_call"] and "word for word" in w["parity"], kind
+        # (round 5: faster with the stream.  Since round 6 the tape's token front stages the document's bytes for numbers and atoms anyway and takes the token
+        # bytes from the same window: the stream is accepted and not read -- the same tape in the same time)
+        assert w["stage2_ms_per_call"] < 1.05 * leg["gpu_ms_per_call"] and "word for word" in w["parity"], kind
