@@ -92,7 +92,7 @@ SJ_HD bool decimal_to_binary64(u64 w, int q, u64 &bits) {
   const u32 upper = u32(hi >> 63);
   u64 m = hi >> (upper + 9); // 54 bits: 53 + one rounding bit
   // binary exponent of 10^q's leading bit: floor(log2(5^q)) + q = (217706 q) >> 16 for every q of the table
-  long long e = ((217706ll * q) >> 16) + 1024 + 63 - lz - int(1u ^ upper);
+  int e = ((217706 * q) >> 16) + 1024 + 63 - lz - int(1u ^ upper); // (32-bit: |217706 q| < 2^27)
   if (e <= 0) { // subnormal (or zero): shift the rounding position up
     if (-e + 1 >= 64) { bits = 0; return true; }
     m >>= u32(-e + 1);
@@ -315,11 +315,18 @@ SJ_HD number_value parse_number_token(const SRC &src, u32 pos, bigint *big, numb
   if (is_float) {
     r.type = 'd';
     const bool dirty_end = not_structural_or_whitespace(c);
-    // significant digits: everything from the first non-zero digit on
-    u32 q = start_digits;
-    while (q < s.digits_end && (src.byte(q) == '0' || src.byte(q) == '.')) { q++; }
-    s.first_sig = q;
-    s.sig_digits = (s.digits_end - q) - ((s.dot >= q && s.dot < s.digits_end) ? 1u : 0u);
+    // significant digits: everything from the first non-zero digit on.  A text of at most 19 digits needs no second look (round 6: three or four more bytes
+    // read per number of ordinary text): i holds them exactly, and all that is asked of their count is "none" (i == 0) and "at most 19"
+    const u32 all_digits = (s.digits_end - start_digits) - (s.dot < s.digits_end ? 1u : 0u);
+    if (all_digits <= 19u && shape_out == nullptr) {
+      s.first_sig = start_digits;
+      s.sig_digits = i == 0 ? 0u : all_digits;
+    } else {
+      u32 q = start_digits;
+      while (q < s.digits_end && (src.byte(q) == '0' || src.byte(q) == '.')) { q++; }
+      s.first_sig = q;
+      s.sig_digits = (s.digits_end - q) - ((s.dot >= q && s.dot < s.digits_end) ? 1u : 0u);
+    }
     s.exp10 = exp10;
     if (shape_out) { *shape_out = s; }
     const u64 sign = negative ? (u64(1) << 63) : 0;
