@@ -264,6 +264,7 @@ SJ_HD number_value parse_number_token(const SRC &src, u32 pos, bigint *big, numb
   const u32 start_digits = p;
   u64 i = 0;
   u32 c = src.byte(p);
+  const u32 first_digit = c; // (kept: the leading-zero rule below asked the source for this byte again)
   // i = i * 10 + digit for every digit, modulo 2^64 (may wrap; the digit count decides below) -- accumulated in 32-bit chunks of up to nine digits: chunk and
   // scale take two full-rate instructions per digit each, the 64-bit multiply-add (two quarter-rate instructions) runs once per chunk instead of once per
   // digit (round 6; multiplication modulo 2^64 is a ring homomorphism: i * 10^k + chunk is the same number)
@@ -278,7 +279,7 @@ SJ_HD number_value parse_number_token(const SRC &src, u32 pos, bigint *big, numb
   while (c - '0' <= 9u) { eat_digit(); }
   flush_digits();
   u32 digit_count = p - start_digits;
-  if (digit_count == 0 || (src.byte(start_digits) == '0' && digit_count > 1)) { r.error = SJ_NUMBER_ERROR; return r; }
+  if (digit_count == 0 || (first_digit == '0' && digit_count > 1)) { r.error = SJ_NUMBER_ERROR; return r; }
   bool is_float = false;
   number_shape s;
   s.dot = 0xFFFFFFFFu;

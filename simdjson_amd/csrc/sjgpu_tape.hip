@@ -630,18 +630,20 @@ __global__ __launch_bounds__(TS_THREADS, 4) void k_tok_apply(const u8 *__restric
         const u32 list = value_list_of(pj); // (of the packed contribution, not of the table entry: the root token's differs)
         const bool is_number = list == LIST_NUMBERS, is_string = list == LIST_STRINGS, is_rest = list == LIST_REST;
         const u32 at = u32(tp[j]) + 1u; // (tape positions are ints: below 2^31)
-        if (is_number && at + 1u < cap32) { // visit_number, tape_builder.h:213-275: the type word, then the value (a number k_tok_stage rejected left nothing: the
-          // document is in error and its tape is nobody's)
-          tape[at] = tape_word32((ntypes >> (8u * nk)) & 0xFFu, 0);
-          tape[at + 1] = nk == 0 ? nbits[0] : (nk == 1 ? nbits[1] : (nk == 2 ? nbits[2] : nbits[3]));
-        }
-        nk += is_number ? 1u : 0u;
         // (sk is a compile-time-bounded counter: selects, not indexed registers)
         const u32 begin = sk == 0 ? oq[0] : (sk == 1 ? oq[1] : (sk == 2 ? oq[2] : oq[3]));
         const u32 next = sk == 0 ? oq[1] : (sk == 1 ? oq[2] : (sk == 2 ? oq[3] : oq[4]));
         if (is_string && stream_strings) { *reinterpret_cast<u32_unaligned_t *>(string_buf + begin) = next - begin - 5u; }
         const bool is_atom = is_rest && (x[j] & TP_ATOM) != 0u; // visit_true_atom ..., tape_builder.h:278-329
-        if ((is_string || is_atom) && at < cap32) { tape[at] = is_string ? tape_word32('"', stream_strings ? begin : oq[j]) : tape_word32(ch, 0); }
+        // the token's (first) value word -- ONE store site for strings, atoms and numbers (visit_number, tape_builder.h:213-275: the type word, then the value; a
+        // number k_tok_stage rejected left nothing: the document is in error and its tape is nobody's)
+        if ((is_string || is_atom || is_number) && at < cap32) {
+          const u32 hi = is_number ? ((ntypes >> (8u * nk)) & 0xFFu) << 24 : (is_string ? u32('"') << 24 : ch << 24);
+          const u32 lo = is_string ? (stream_strings ? begin : oq[j]) : 0u;
+          tape[at] = (u64(hi) << 32) | lo;
+        }
+        if (is_number && at + 1u < cap32) { tape[at + 1] = nk == 0 ? nbits[0] : (nk == 1 ? nbits[1] : (nk == 2 ? nbits[2] : nbits[3])); }
+        nk += is_number ? 1u : 0u;
         sk += is_string ? 1u : 0u;
         if (live && (pj.a >> 16)) {
           int k = (pj.b >> 16) ? d : d - 1;
