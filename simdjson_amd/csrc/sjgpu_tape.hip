@@ -335,8 +335,63 @@ __global__ __launch_bounds__(TS_THREADS, SJGPU_STAGE_OCC) void k_tok_stage(const
       }
       PHASE(1); // staged
       const u32 g0 = ncount;
+      // Dense text (large_random: 3.4 bytes per token) stages ALL 1024 tokens of a full wave at once.  Then a lane takes FOUR consecutive tokens per step (four
+      // steps instead of sixteen rows): their offsets are one 8-byte LDS read, their bytes one dword store, the numbers among them are placed by one wave scan
+      // of the lanes' counts instead of a ballot and a v_mbcnt per row -- the row loop below issues ~64 instructions per 64 tokens whatever they hold, and
+      // the kernel is bound by what it issues (profiles/r06_tape_stage.txt).
+      const bool dense = staged && ra == 0u && rb == SG_ROWS && cnt == SG_WAVE_TOKENS; // wave-uniform
+      if (dense) {
 #pragma unroll 1
-      for (u32 r = ra; r < rb; r++) {
+        for (u32 sr = 0; sr < SG_ROWS / 4u; sr++) {
+          const u32 tl0 = 256u * sr + 4u * lane; // the lane's four tokens lie in one row of 64: row 4 sr + lane / 16
+          const uint2 r4 = *reinterpret_cast<const uint2 *>(rel + tl0);
+          const u32 rs = row_start[4u * sr + (lane >> 4)] - a0;
+          const u32 offs[4] = {rs + (r4.x & 0xFFFFu), rs + (r4.x >> 16), rs + (r4.y & 0xFFFFu), rs + (r4.y >> 16)};
+          u32 lo[4], hi[4];
+#pragma unroll
+          for (u32 j = 0; j < 4; j++) {
+            const u32 sft = offs[j] & 3u;
+            const u32 *q = win32 + (offs[j] >> 2);
+            const u32 d0 = q[0], d1 = q[1], d2 = q[2];
+            lo[j] = __builtin_amdgcn_alignbyte(d1, d0, sft);
+            hi[j] = __builtin_amdgcn_alignbyte(d2, d1, sft);
+          }
+          uint4 tab[4];
+#pragma unroll
+          for (u32 j = 0; j < 4; j++) { tab[j] = sh_tab[lo[j] & 0xFFu]; }
+          if (first_wave && sr == 0u) { // wave-uniform: the root token's number path differs (takes_number_path) -- one token per document
+            if (lane == 0) {
+              const tok_packed pk = tok_contribution(lo[0] & 0xFFu, true);
+              tab[0].x = pk.a; tab[0].y = pk.b; tab[0].z = pk.c;
+            }
+          }
+          *reinterpret_cast<u32_unaligned_t *>(tokc_w + tl0) = (lo[0] & 0xFFu) | ((lo[1] & 0xFFu) << 8) | ((lo[2] & 0xFFu) << 16) | (lo[3] << 24);
+          u32 mine = 0, atoms = 0; // number tokens of the lane, atoms of the lane
+#pragma unroll
+          for (u32 j = 0; j < 4; j++) {
+            a += tab[j].x; b += tab[j].y; c += tab[j].z;
+            mine += tab[j].z >> 16;
+            atoms |= tab[j].w & TP_ATOM;
+          }
+          if (__ballot(atoms != 0u)) { // wave-uniform: steps without true / false / null skip the spelling
+#pragma unroll
+            for (u32 j = 0; j < 4; j++) {
+              const u32 g = (tab[j].w & TP_ATOM) ? atom_error_of(lo[j], hi[j]) : 0u;
+              if (g) { report_error(res, error_key(t0 + tl0 + j, 2, g)); }
+            }
+          }
+          const u32 incl = wave_incl_scan(mine);
+          u32 at = ncount + incl - mine;
+#pragma unroll
+          for (u32 j = 0; j < 4; j++) {
+            if (tab[j].z >> 16) { list[at] = (unsigned short)(tl0 + j); }
+            at += tab[j].z >> 16;
+          }
+          ncount += readlane(incl, 63);
+        }
+      }
+#pragma unroll 1
+      for (u32 r = dense ? rb : ra; r < rb; r++) {
         const u32 tl = 64u * r + lane;
         const bool live = tl < cnt;
         u32 lo, hi;
@@ -410,10 +465,9 @@ __global__ __launch_bounds__(TS_THREADS, SJGPU_STAGE_OCC) void k_tok_stage(const
           const u32 k = k0 + lane;
           if (k < ncount) {
             const u32 e = list[k], tl = e & 0x7FFFu;
-            if (!staged || (e & 0x8000u)) { // through the 32-byte register window, like k_tape_numbers did
+            if (!staged || (e & 0x8000u)) { // through the 8-byte register window (k_tape_numbers' 32-byte one costs this kernel, whose registers are its occupancy, 40 more)
               const u32 p = idx_w[tl];
-              const wide_window_bytes src{buf, len};
-              src.fill(p);
+              const windowed_bytes src{buf, len};
               park_number(parse_number_token(src, p, static_cast<bigint *>(nullptr)), t0 + tl, t0_64 + k, numbits, numtype, slow_list, slow_cap, res);
             }
           }
