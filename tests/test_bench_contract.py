@@ -205,5 +205,6 @@ def test_the_token_stream_s_cost_and_gain_are_in_the_line():
     for kind, leg in d["legs"]["next_f3_tape"].items():
         w = leg["with_token_stream"]
         # (round 5: faster with the stream.  Since round 6 the tape's token front stages the document's bytes for numbers and atoms anyway and takes the token
-        # bytes from the same window: the stream is accepted and not read -- the same tape in the same time)
-        assert w["stage2_ms_per_call"] < 1.05 * leg["gpu_ms_per_call"] and "word for word" in w["parity"], kind
+        # bytes from the same window: the stream is accepted and not read -- the same tape in the same time; two timed regions of one run differ by up
+        # to 9 % with the clocks they meet: session r06f 1.508 / 1.640 ms, r06e 1.577 / 1.586)
+        assert w["stage2_ms_per_call"] < 1.15 * leg["gpu_ms_per_call"] and "word for word" in w["parity"], kind
