@@ -93,7 +93,9 @@ int sjgpu_stage2_tokens_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
   int rc = grow(ctx, reinterpret_cast<void **>(&ctx->d_stage2), &ctx->d_stage2_bytes, tape_at + tape_workspace_bytes(n, len));
   if (rc) { return rc; }
   uint8_t *ws = ctx->d_stage2;
-  strings_result_dev *sres = reinterpret_cast<strings_result_dev *>(ws);
+  // the string pass's result lives in the tape workspace's first slot, 64 bytes behind the tape's own result (the slot has 256; k_tape_init clears it, k_strs_init
+  // -- later in the stream -- fills it): both results come back in ONE copy (each copy is a 5 us launch of the runtime's copy kernel)
+  strings_result_dev *sres = reinterpret_cast<strings_result_dev *>(ws + tape_at + 64);
   uint32_t *offsets = reinterpret_cast<uint32_t *>(ws + offs_at);
   hipStream_t s = pick(ctx, stream);
   // Optimistic: the string buffer by the stream compaction alone, the sort in one pass -- what nearly every document needs.  A document the stream declines
@@ -114,11 +116,10 @@ int sjgpu_stage2_tokens_device(sjgpu_ctx *ctx, const void *buf_dev, size_t len, 
     // (into page-locked memory: a copy into a variable on the stack goes through the runtime's staging buffer and waits for it, twice per call)
     uint8_t *const pinned = reinterpret_cast<uint8_t *>(ctx->h_result);
     static_assert(sizeof(strings_result_dev) <= 64 && sizeof(tape_result_dev) <= 64, "the pinned block's slots");
-    SJ_TRY(ctx, hipMemcpyAsync(pinned + 64, sres, sizeof(hs), hipMemcpyDeviceToHost, s));
-    SJ_TRY(ctx, hipMemcpyAsync(pinned + 128, ws + tape_at, sizeof(ht), hipMemcpyDeviceToHost, s));
+    SJ_TRY(ctx, hipMemcpyAsync(pinned + 64, ws + tape_at, 128, hipMemcpyDeviceToHost, s));
     SJ_TRY(ctx, hipStreamSynchronize(s));
-    memcpy(&hs, pinned + 64, sizeof(hs));
-    memcpy(&ht, pinned + 128, sizeof(ht));
+    memcpy(&ht, pinned + 64, sizeof(ht));
+    memcpy(&hs, pinned + 128, sizeof(hs));
     bool again = false;
     if (roads == STRINGS_STREAM_ONLY && hs.path == 2 && !hs.overflow) { roads = STRINGS_WALK_ONLY; again = true; }
     if (!deep && ht.max_level >= TAPE_ONE_PASS_LEVELS) { deep = true; again = true; }

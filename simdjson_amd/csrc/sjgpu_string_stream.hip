@@ -7,7 +7,7 @@
 // replaced by 4 + 1 bytes and the escapes by what they stand for (sj_string_stream.h): the job has the shape of minify.
 // A lane owns 64 bytes, a wave 4 KiB, a wave's share is one 16 KiB segment; loads are the 16-byte row loads of stage 1.
 //   k_strs_count     per segment: output bytes, opening quotes and rejected escapes for both "starts inside / outside a string"
-//   k_strs_resolve   one workgroup: in-string state, output base and string ordinal in front of every segment; totals
+//   k_strs_resolve   a workgroup per 1024 segments: in-string state, output base and string ordinal in front of every segment; totals
 //   k_strs_tokens + scan   which structurals are quotes (one bit each) and how many per tile of 4096 (skipped when the tape has counted them already)
 //   k_strs_decide    the stream is taken iff every string is valid, every opening quote of the document is a structural (a quote
 //                    glued to a scalar, a"b", is not: such documents are invalid and take the per-string path) and the buffer fits
@@ -147,8 +147,34 @@ __device__ __forceinline__ strs_chunk string_chunk(const u32 (&w)[16], strs_carr
   return out;
 }
 
+// ---- the control block of the stream (written by pass 2) ------------------------------------------------------------------------------------
+struct strs_ctrl {
+  u32 n1_scan;   // entries of the ordinal scan (n + 1)
+  u32 n1_old;    // entries of the per-string path's scan: n + 1 if it runs, else 0 (its scan kernels then do nothing)
+  u32 go_stream; // the stream writes the buffer
+  u32 go_old;    // the per-string kernels write it
+  u32 opens;     // opening quotes of the document
+  u32 bad;       // a rejected escape inside a string, or the document ends inside one
+  u64 total;     // output bytes
+};
+__device__ __forceinline__ void strs_init(strings_result_dev *__restrict__ res, strs_ctrl *__restrict__ ctrl, u32 n1) {
+  strings_result_dev r{};
+  r.first_bad = 0xFFFFFFFFu; // NO_STRING
+  *res = r;
+  strs_ctrl c{};
+  c.n1_scan = n1;
+  *ctrl = c;
+  u32 *tail = reinterpret_cast<u32 *>(ctrl) + sizeof(strs_ctrl) / 4; // the control block has 64 bytes
+  for (u32 k = 0; k < (64 - sizeof(strs_ctrl)) / 4; k++) { tail[k] = 0u; }
+}
+// (a launch of its own only for a document without a segment: else the first thread of k_strs_count does it -- nothing reads either block before k_strs_resolve)
+__global__ void k_strs_init(strings_result_dev *__restrict__ res, strs_ctrl *__restrict__ ctrl, u32 n1) {
+  if (threadIdx.x == 0) { strs_init(res, ctrl, n1); }
+}
 // ---- pass 1: what every segment contributes, for both carry-ins ------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_count(const u8 *__restrict__ buf, u64 len, u32 nseg, u32 allow_replacement, strs_summary *__restrict__ summ) {
+__global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_count(const u8 *__restrict__ buf, u64 len, u32 nseg, u32 allow_replacement, strs_summary *__restrict__ summ,
+                                                               strings_result_dev *__restrict__ res, strs_ctrl *__restrict__ ctrl, u32 n1) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) { strs_init(res, ctrl, n1); }
   (void)allow_replacement; // (a lone surrogate is flagged whatever the option says: the per-string road knows the replacement character)
   const u32 lane = threadIdx.x & 63u;
   const u32 seg = blockIdx.x * STRS_WAVES + (threadIdx.x >> 6);
@@ -192,78 +218,109 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_count(const u8 *__rest
   }
 }
 
-// ---- pass 2: one workgroup walks the segment summaries ------------------------------------------------------------------------------------
-struct strs_ctrl {
-  u32 n1_scan;   // entries of the ordinal scan (n + 1)
-  u32 n1_old;    // entries of the per-string path's scan: n + 1 if it runs, else 0 (its scan kernels then do nothing)
-  u32 go_stream; // the stream writes the buffer
-  u32 go_old;    // the per-string kernels write it
-  u32 opens;     // opening quotes of the document
-  u32 bad;       // a rejected escape inside a string, or the document ends inside one
-  u64 total;     // output bytes
-};
-__global__ void k_strs_init(strings_result_dev *__restrict__ res, strs_ctrl *__restrict__ ctrl, u32 n1) {
-  if (threadIdx.x == 0) {
-    strings_result_dev r{};
-    r.first_bad = 0xFFFFFFFFu; // NO_STRING
-    *res = r;
-    strs_ctrl c{};
-    c.n1_scan = n1;
-    *ctrl = c;
-    u32 *tail = reinterpret_cast<u32 *>(ctrl) + sizeof(strs_ctrl) / 4; // the control block has 64 bytes
-    for (u32 k = 0; k < (64 - sizeof(strs_ctrl)) / 4; k++) { tail[k] = 0u; }
+constexpr u32 RES_THREADS = 1024, RES_WAVES = RES_THREADS / 64, RES_MAX_TILES = 256; // (a document has at most 4 GiB / 16 KiB = 262 144 segments)
+// The segments in tiles of 1024, a thread per segment, a WORKGROUP PER TILE: the in-string state in front of every segment (a prefix XOR of the parities),
+// which selects the segment's counts, then the prefix sums of those.  Rounds 3-6a walked the tiles with ONE workgroup: 1.8 us per tile, 30 us per 256 MiB
+// document during which 255 CUs waited -- and neither fewer barriers nor summaries requested four tiles ahead moved it (sessions AN-AP): 16 waves of
+// ~200 instructions on one CU are 3 000 cycles per tile.  Now a tile computes, from its own summaries, its totals for BOTH states it may start in, publishes
+// them -- two 64-bit words in the padding of its first two summaries (k_strs_count has zeroed them; the top bit says "written": the data is the flag, as
+// in sjgpu_fused.hip) -- and reads the words of the tiles in front of it (one thread each; workgroups are dispatched in order, so those run or have
+// run); a walk over at most 255 pairs of totals gives the tile its state and its bases.  A tile holds at most 1024 x 2.5 x 16 KiB = 40 MiB (26 bits)
+// and 8 M opening quotes (23 bits).
+__device__ __forceinline__ u64 *tile_word(strs_summary *summ, u32 tile, u32 which) { return reinterpret_cast<u64 *>(&summ[u64(tile) * RES_THREADS + which].pad[1]); }
+static_assert(sizeof(strs_summary) == 32 && offsetof(strs_summary, pad) == 20, "tile_word: an aligned 64-bit word inside the padding");
+constexpr u64 TILE_WRITTEN = u64(1) << 63;
+__device__ __forceinline__ void strs_decide(strs_ctrl *__restrict__ ctrl, const int *__restrict__ listed_ptr, u32 n, u64 out_cap, u32 *__restrict__ outq, strings_result_dev *__restrict__ res);
+__global__ __launch_bounds__(RES_THREADS) void k_strs_resolve(strs_summary *__restrict__ summ, u32 nseg, strs_base *__restrict__ base, strs_ctrl *__restrict__ ctrl,
+                                                          const int *__restrict__ listed_ptr, u32 n, u64 out_cap, u32 *__restrict__ outq, strings_result_dev *__restrict__ res) {
+  __shared__ u32 sh_par[RES_WAVES];
+  __shared__ u32 sh_bad[RES_WAVES];          // bit 0 / 1: a segment of the wave declines, the tile starting outside / inside a string
+  __shared__ u64 sh_tot[2][RES_WAVES];       // per wave, for the tile starting outside / inside a string: bytes | opening quotes << 32
+  __shared__ u64 sh_back[2][RES_MAX_TILES];  // the words of the tiles in front
+  __shared__ u64 sh_front[2];                // what the walk found: state in front of the tile; bytes (high: unused) -- and opening quotes
+  __shared__ u32 sh_state;
+  const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  const u32 tile = blockIdx.x, ntiles = gridDim.x;
+  const u64 i = u64(tile) * RES_THREADS + t;
+  uint4 counts{0u, 0u, 0u, 0u}; // bytes0, bytes1, opens0, quotes
+  u32 flags = 0;
+  if (i < nseg) {
+    counts = *reinterpret_cast<const uint4 *>(summ + i);
+    flags = summ[i].flags;
   }
-}
-constexpr u32 RES_THREADS = 1024, RES_WAVES = RES_THREADS / 64;
-// exclusive prefix over the workgroup of one value per thread (wave scans + one pass over the 16 wave totals); total = the sum
-__device__ __forceinline__ u32 block_excl_scan1024(u32 v, u32 *sh /*[RES_WAVES]*/, u32 &total) {
-  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const u32 incl = wave_incl_scan(v);
-  if (lane == 63) { sh[wave] = incl; }
+  // the state of every segment relative to the tile's first
+  const u64 odd = __ballot((flags & 1u) != 0);
+  if (lane == 0) { sh_par[wave] = u32(popc64(odd)); }
   __syncthreads();
-  u32 base = 0, sum = 0;
+  u32 par_front = 0, par_total = 0;
   for (u32 w = 0; w < RES_WAVES; w++) {
-    if (w < wave) { base += sh[w]; }
-    sum += sh[w];
+    const u32 p = sh_par[w];
+    par_front += w < wave ? p : 0u;
+    par_total += p;
   }
-  total = sum;
+  const u32 rel = (par_front + u32(popc64(odd & ((u64(1) << lane) - 1)))) & 1u;
+  // what the segment adds if the TILE starts outside (h = 0: the segment's state is rel) or inside a string (h = 1)
+  const u32 in_b = counts.y, in_o = counts.w - counts.z; // the segment starts inside a string
+  const u32 b0 = rel ? in_b : counts.x, o0 = rel ? in_o : counts.z;
+  const u32 b1 = rel ? counts.x : in_b, o1 = rel ? counts.z : in_o;
+  const u32 ib0 = wave_incl_scan(b0), io0 = wave_incl_scan(o0), ib1 = wave_incl_scan(b1), io1 = wave_incl_scan(o1);
+  // bit 1 / 2 of the flags: an escape the reference rejects inside a string if the SEGMENT starts outside / inside; bit 3: it declines anyway
+  const u32 out_bad = ((flags >> 1) | (flags >> 3)) & 1u, in_bad = ((flags >> 2) | (flags >> 3)) & 1u;
+  const u64 bad0 = __ballot((rel ? in_bad : out_bad) != 0), bad1 = __ballot((rel ? out_bad : in_bad) != 0);
+  if (lane == 63) {
+    sh_tot[0][wave] = u64(ib0) | (u64(io0) << 32);
+    sh_tot[1][wave] = u64(ib1) | (u64(io1) << 32);
+    sh_bad[wave] = (bad0 ? 1u : 0u) | (bad1 ? 2u : 0u);
+  }
   __syncthreads();
-  return base + incl - v;
-}
-// The segments in tiles of 1024, a thread per segment (consecutive threads read consecutive summaries): first the in-string state in front
-// of every segment (a prefix XOR of the parities), which selects the segment's counts, then the prefix sums of those.
-__global__ __launch_bounds__(RES_THREADS) void k_strs_resolve(const strs_summary *__restrict__ summ, u32 nseg, strs_base *__restrict__ base, strs_ctrl *__restrict__ ctrl) {
-  __shared__ u32 sh[RES_WAVES];
-  const u32 t = threadIdx.x;
-  u32 s_run = 0, opens_run = 0, bad = 0; // in front of the tile
-  u64 bytes_run = 0;
-  // (round 6: the NEXT tile's summaries are requested before this tile's three scans -- one workgroup walks the 16 384 segments of a 256 MiB document in 16
-  // steps, and each step used to begin with a round trip to memory: 34 us per call, profiles/r06_tape_stage.txt)
-  const strs_summary none{0u, 0u, 0u, 0u, 0u, {0u, 0u, 0u}};
-  strs_summary ahead = t < nseg ? summ[t] : none;
-  for (u32 tile = 0; tile < nseg; tile += RES_THREADS) {
-    const u32 i = tile + t;
-    const strs_summary v = ahead;
-    if (u64(i) + RES_THREADS < nseg) { ahead = summ[i + RES_THREADS]; } else { ahead = none; }
-    u32 par_total, bytes_total, opens_total;
-    const u32 s = (s_run + block_excl_scan1024(v.flags & 1u, sh, par_total)) & 1u;
-    const u32 my_bytes = s ? v.bytes1 : v.bytes0, my_opens = s ? v.quotes - v.opens0 : v.opens0;
-    const u32 b0 = block_excl_scan1024(my_bytes, sh, bytes_total); // a tile: at most 1024 x 2.5 x 16 KiB = 40 MiB
-    const u32 o0 = block_excl_scan1024(my_opens, sh, opens_total);
-    if (i < nseg) {
-      base[i] = strs_base{u32(bytes_run + b0), opens_run + o0, s, 0u};
-      bad |= (s ? (v.flags >> 2) & 1u : (v.flags >> 1) & 1u) | ((v.flags >> 3) & 1u);
+  u64 tot0 = 0, tot1 = 0;
+  u32 tile_bad = 0;
+  if (t == 0) { // the tile's own words first: nobody behind it waits for what it is about to wait for
+    for (u32 w = 0; w < RES_WAVES; w++) { tot0 += sh_tot[0][w]; tot1 += sh_tot[1][w]; tile_bad |= sh_bad[w]; }
+    if (tile + 1 < ntiles) { // (a tile with a tile behind it is full: its second summary exists)
+      const u64 a = (tot0 & 0x3FFFFFFull) | ((tot1 & 0x3FFFFFFull) << 26) | (u64(par_total & 1u) << 52) | (u64(tile_bad) << 53) | TILE_WRITTEN;
+      const u64 b = (tot0 >> 32) | ((tot1 >> 32) << 23) | TILE_WRITTEN;
+      __hip_atomic_store(tile_word(summ, tile, 0), a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(tile_word(summ, tile, 1), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    s_run = (s_run + par_total) & 1u;
-    bytes_run += bytes_total;
-    opens_run += opens_total;
   }
-  const u32 any_bad = __syncthreads_or(int(bad));
+  if (t < tile) { // the tiles in front: their words, when they are written
+    u64 a, b;
+    do { a = __hip_atomic_load(tile_word(summ, t, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(a & TILE_WRITTEN));
+    do { b = __hip_atomic_load(tile_word(summ, t, 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(b & TILE_WRITTEN));
+    sh_back[0][t] = a;
+    sh_back[1][t] = b;
+  }
+  __syncthreads();
   if (t == 0) {
-    ctrl->total = bytes_run;
-    ctrl->opens = opens_run;
-    ctrl->bad = (any_bad ? 1u : 0u) | s_run; // s_run: the state behind the last byte
+    u32 s = 0, opens = 0, bad = 0;
+    u64 bytes = 0;
+    for (u32 w = 0; w < tile; w++) {
+      const u64 a = sh_back[0][w], b = sh_back[1][w];
+      bytes += s ? (a >> 26) & 0x3FFFFFFull : a & 0x3FFFFFFull;
+      opens += u32(s ? (b >> 23) & 0x7FFFFFull : b & 0x7FFFFFull);
+      bad |= u32(a >> (53u + s)) & 1u;
+      s ^= u32(a >> 52) & 1u;
+    }
+    sh_state = s;
+    sh_front[0] = bytes;
+    sh_front[1] = opens;
+    if (tile + 1 == ntiles) { // the totals of the document, the state behind its last byte
+      const u64 own = s ? tot1 : tot0;
+      ctrl->total = bytes + (own & 0xFFFFFFFFull);
+      ctrl->opens = opens + u32(own >> 32);
+      ctrl->bad = bad | ((tile_bad >> s) & 1u) | ((s ^ par_total) & 1u); // a segment that declines, or the document ends inside a string
+      if (listed_ptr) { strs_decide(ctrl, listed_ptr, n, out_cap, outq, res); } // (the string tokens were counted in front: the tape's call)
+    }
   }
+  __syncthreads();
+  const u32 s_tile = sh_state;
+  const u32 s = rel ^ s_tile;
+  u64 front = 0;
+  for (u32 w = 0; w < RES_WAVES; w++) { front += w < wave ? sh_tot[s_tile][w] : u64(0); }
+  const u32 mine_b = s_tile ? b1 : b0, mine_o = s_tile ? o1 : o0;
+  const u32 excl_b = u32(front & 0xFFFFFFFFull) + (s_tile ? ib1 : ib0) - mine_b, excl_o = u32(front >> 32) + (s_tile ? io1 : io0) - mine_o;
+  if (i < nseg) { base[i] = strs_base{u32(sh_front[0] + excl_b), u32(sh_front[1]) + excl_o, s, 0u}; }
 }
 
 // ---- the structural list: which tokens are strings ------------------------------------------------------------------------------------------
@@ -303,7 +360,7 @@ __global__ __launch_bounds__(TOK_THREADS) void k_strs_tokens(const u8 *__restric
   }
 }
 
-__global__ void k_strs_decide(strs_ctrl *__restrict__ ctrl, const int *__restrict__ listed_ptr, u32 n, u64 out_cap, u32 *__restrict__ outq, strings_result_dev *__restrict__ res) {
+__device__ __forceinline__ void strs_decide(strs_ctrl *__restrict__ ctrl, const int *__restrict__ listed_ptr, u32 n, u64 out_cap, u32 *__restrict__ outq, strings_result_dev *__restrict__ res) {
   const u32 listed = u32(*listed_ptr); // string tokens of the list
   const bool ok = ctrl->bad == 0 && listed == ctrl->opens;
   if (ok && ctrl->total > out_cap) {
@@ -323,11 +380,16 @@ __global__ void k_strs_decide(strs_ctrl *__restrict__ ctrl, const int *__restric
     res->strings = listed;
   }
 }
+// (a launch of its own when the string tokens are counted BEHIND k_strs_resolve -- the stand-alone string pass; the tape has counted them before, and
+// k_strs_resolve's last tile decides)
+__global__ void k_strs_decide(strs_ctrl *__restrict__ ctrl, const int *__restrict__ listed_ptr, u32 n, u64 out_cap, u32 *__restrict__ outq, strings_result_dev *__restrict__ res) {
+  strs_decide(ctrl, listed_ptr, n, out_cap, outq, res);
+}
 
 // ---- pass 3: the bytes ----------------------------------------------------------------------------------------------------------------------
 // A chunk's output: at most 2.5 bytes per input byte ("" -> 5), plus the skew that lines the window up with the destination
 constexpr u32 STRS_WINDOW = 16 + (CHUNK_BYTES / 2) * 5 + 16;
-constexpr u32 STRS_STAGE_BYTES = STRS_WINDOW + 64; // + one dump byte per lane (stores of bytes that are not kept land there)
+constexpr u32 STRS_STAGE_BYTES = STRS_WINDOW + 64; // + slack behind the window: the last lane's trailing dropped bytes land on the byte behind the chunk's output
 
 // window offset of the lane's byte p: one slot per kept byte and closing quote in front of it, four per opening quote
 struct window_map {
@@ -358,7 +420,6 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__rest
   if (seg >= nseg) { return; }
   u8 *const stage = sh_stage[wave];
   u32 *const plist = sh_patch[wave];
-  u8 *const dump = stage + STRS_WINDOW + lane;
   const u64 seg_start = u64(seg) * SEG_BYTES;
   const plain_doc src{buf, u32(len)};
   const u32 lookback = lookback_issue(buf, seg_start, lane);
@@ -393,25 +454,37 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__rest
         u32 k = ordinal + (oincl - nopen);
         for (u64 t = open; t; t &= t - 1) { outq[k++] = out_base + (map.at(ctz64(t)) - skew); }
       }
-      // the bytes: one LDS store per input byte (those that are dropped go to the lane's dump byte)
+      // the bytes: one LDS store per input byte, EVERY byte at the lane's running offset -- a byte that is dropped does not advance the offset and is overwritten by
+      // the lane's next byte that stays (stores of one lane land in program order); an opening quote lands in its own hole of four.  What is left over is the
+      // lane's trailing dropped bytes at the offset where the NEXT lane's share begins: a lane whose share begins with a byte (not with a hole) stores that byte
+      // once more behind the sweep (requested from the document in front of the sweep: the line is in L1 / L2).  Rounds 3-6a selected a dump byte per
+      // dropped byte instead: 8 vector instructions per byte, 4 here.
       // (measured in round 5 and not kept: dword by dword the way minify compacts -- one v_perm_b32 per dword through an accumulator, OR-merged into a zeroed
       // window, an opening quote as a hole of one dword, chunks with two opening quotes in a dword on this road -- 228 -> 276 us per 256 MiB: its per-lane
       // branches (flush? hole?) and ds_or cost more than 64 branch-free byte stores; scripts/sessions/gpu_r5_x.sh)
-      u32 off = map.lane_off;
+      const u32 first_one = one ? ctz64(one) : 0u;
+      u32 first_byte = 0;
+      if (one) { first_byte = ((closing >> first_one) & 1u) ? 0u : (pos + first_one < len ? u32(buf[pos + first_one]) : 0x20u); }
+      u8 *at = stage + map.lane_off;
+      u8 *const at0 = at;
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         // a closing quote leaves as a zero byte: clear it in the dword (bit k of the nibble -> byte k: one multiply spreads the bits)
         const u32 close4 = u32(closing >> (4 * j)) & 0xFu;
-        const u32 wj = w[j] & ~(((close4 * 0x00204081u) & 0x01010101u) * 0xFFu);
+        const u32 lsb = (close4 * 0x00204081u) & 0x01010101u;
+        u32 fill = lsb << 8; // ... x 0xFF as a shift and a subtraction (the compiler folds them back into a 32-bit multiply, four issue slots, unless it loses sight of one)
+        asm("" : "+v"(fill));
+        const u32 wj = w[j] & ~(fill - lsb);
 #pragma unroll
         for (int b = 0; b < 4; b++) {
           const int i = 4 * j + b;
           const u32 is_one = u32(one >> i) & 1u, is_open = u32(open >> i) & 1u;
-          u8 *const at = is_one ? stage + off : dump;
           *at = u8(wj >> (8 * b));
-          off += is_one + 4u * is_open;
+          at += is_one + 4u * is_open;
         }
       }
+      wave_lds_fence();
+      if (one) { at0[4u * u32(popc64(open & ((u64(1) << first_one) - 1)))] = u8(first_byte); }
       wave_lds_fence();
       // the few bytes whose value is not the input's: escaped b f n r t, and what \\u escapes stand for -- listed by their owners, worked off one per lane
       const u64 k2 = m.k2 & kept, k3 = m.k3 & kept, k4 = m.k4 & kept, rm = m.b.remap & kept;
@@ -510,23 +583,26 @@ void enqueue_string_stream(const uint8_t *buf, uint64_t len, const uint32_t *idx
   const u32 nseg = num_segments(len), n1 = n + 1;
   const u32 a = allow_replacement ? 1u : 0u;
   // the result and the control block in one small launch (rounds 3-4a: four memsets, i.e. four launches of the runtime's fill kernel)
-  hipLaunchKernelGGL(k_strs_init, dim3(1), dim3(64), 0, s, res, ctrl, n1);
+  // (round 6: by k_strs_count's first thread -- a launch of its own, 5 us, only for a document without a segment)
   strs_summary *summ = static_cast<strs_summary *>(w.seg_summary);
   strs_base *base = static_cast<strs_base *>(w.seg_base);
   if (nseg) {
-    hipLaunchKernelGGL(k_strs_count, dim3((nseg + STRS_WAVES - 1) / STRS_WAVES), dim3(64 * STRS_WAVES), 0, s, buf, len, nseg, a, summ);
+    hipLaunchKernelGGL(k_strs_count, dim3((nseg + STRS_WAVES - 1) / STRS_WAVES), dim3(64 * STRS_WAVES), 0, s, buf, len, nseg, a, summ, res, ctrl, n1);
+  } else {
+    hipLaunchKernelGGL(k_strs_init, dim3(1), dim3(64), 0, s, res, ctrl, n1);
   }
-  hipLaunchKernelGGL(k_strs_resolve, dim3(1), dim3(RES_THREADS), 0, s, summ, nseg, base, ctrl);
   const bool own_ordinals = listed == nullptr; // else the caller has counted the string tokens (launch_tape_front) and finishes the records itself
   const u32 tiles = u32((u64(n1) + TOK_TILE - 1) / TOK_TILE);
   int *const count = w.kord;                                                                               // tiles + 1 ints
   u64 *const qbits = reinterpret_cast<u64 *>(w.kord + ((size_t(tiles) + 1 + 63) & ~size_t(63)));           // 64 words per tile: n / 8 bytes (kord has 4 n)
+  // (the tape's call knows the number of string tokens already: the last tile of k_strs_resolve decides, no launch for one thread)
+  hipLaunchKernelGGL(k_strs_resolve, dim3(nseg ? (nseg + RES_THREADS - 1) / RES_THREADS : 1u), dim3(RES_THREADS), 0, s, summ, nseg, base, ctrl, listed, n, out_cap, w.outq, res);
   if (own_ordinals) {
     hipLaunchKernelGGL(k_strs_tokens, dim3(tiles), dim3(TOK_THREADS), 0, s, buf, len, idx, n, qbits, count, tiles);
     launch_scan_partials(count, tiles + 1, s);
     listed = count + tiles;
+    hipLaunchKernelGGL(k_strs_decide, dim3(1), dim3(1), 0, s, ctrl, listed, n, out_cap, w.outq, res);
   }
-  hipLaunchKernelGGL(k_strs_decide, dim3(1), dim3(1), 0, s, ctrl, listed, n, out_cap, w.outq, res);
   if (nseg) {
     hipLaunchKernelGGL(k_strs_write, dim3((nseg + STRS_WAVES - 1) / STRS_WAVES), dim3(64 * STRS_WAVES), 0, s, buf, len, nseg, a, base, ctrl, out, w.outq);
   }
