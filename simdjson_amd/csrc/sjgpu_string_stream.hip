@@ -33,6 +33,21 @@ struct plain_doc {
   __device__ __forceinline__ u32 byte(u32 pos) const { return pos < len ? u32(buf[pos]) : 0x20u; }
 };
 
+// The same for ONE kept byte of a \\u escape at position q: u_escape_byte reads q - 8 ... q + 2, so the sixteen bytes from q - 8 on, requested at once (two
+// unaligned 8-byte loads), serve every byte() it asks for.  Through plain_doc the function's loads form a chain of two or three round trips to L1 / L2
+// (the digits decide which bytes are read next), and a wave that patches a chunk waits for every one of them: 92 of k_strs_write's 222 us on the 256 MiB
+// twitter-like text (session AS: the kernel with the patch rounds compiled out), one round trip with the window.
+struct escape_window {
+  u64 lo, hi;
+  u32 base; // position of the window's first byte
+  typedef u64 __attribute__((aligned(1))) u64_any;
+  __device__ __forceinline__ escape_window(const u8 *buf, u32 q) : lo(*reinterpret_cast<const u64_any *>(buf + q - 8)), hi(*reinterpret_cast<const u64_any *>(buf + q)), base(q - 8u) {}
+  __device__ __forceinline__ u32 byte(u32 pos) const {
+    const u32 d = pos - base;
+    return u32((d < 8u ? lo : hi) >> (8u * (d & 7u))) & 0xFFu;
+  }
+};
+
 // per segment, from its bytes alone (hypothesis 0 = the segment starts outside a string)
 struct strs_summary {
   u32 bytes0, bytes1; // output bytes if it starts outside / inside a string
@@ -387,8 +402,9 @@ __global__ void k_strs_decide(strs_ctrl *__restrict__ ctrl, const int *__restric
 }
 
 // ---- pass 3: the bytes ----------------------------------------------------------------------------------------------------------------------
-// A chunk's output: at most 2.5 bytes per input byte ("" -> 5), plus the skew that lines the window up with the destination
-constexpr u32 STRS_WINDOW = 16 + (CHUNK_BYTES / 2) * 5 + 16;
+// Half a chunk's output: at most 2.5 bytes per input byte ("" -> 5), plus the skew that lines the window up with the destination
+constexpr u32 STRS_WINDOW_DATA = (CHUNK_BYTES / 4) * 5; // what 32 lanes can produce
+constexpr u32 STRS_WINDOW = 16 + STRS_WINDOW_DATA + 16;
 constexpr u32 STRS_STAGE_BYTES = STRS_WINDOW + 64; // + slack behind the window: the last lane's trailing dropped bytes land on the byte behind the chunk's output
 
 // window offset of the lane's byte p: one slot per kept byte and closing quote in front of it, four per opening quote
@@ -408,7 +424,8 @@ constexpr u32 PATCH_PER_LANE = 8, PATCH_LIST = 64 * PATCH_PER_LANE;
 enum : u32 { PATCH_REMAP = 3u }; // roles 0 ... 2: the byte sits on hex digit 2 ... 4 of a \\u escape
 __device__ __forceinline__ u32 patch_entry(u32 window_offset, u32 chunk_offset, u32 role) { return (window_offset << 14) | (chunk_offset << 2) | role; }
 
-__global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__restrict__ buf, u64 len, u32 nseg, u32 allow_replacement,
+// (five waves per SIMD: what 29 KB of LDS per workgroup allow; left alone the allocator takes 105 registers, four waves)
+__global__ __launch_bounds__(64 * STRS_WAVES) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_strs_write(const u8 *__restrict__ buf, u64 len, u32 nseg, u32 allow_replacement,
                                                                const strs_base *__restrict__ base, const strs_ctrl *__restrict__ ctrl, u8 *__restrict__ out,
                                                                u32 *__restrict__ outq) {
   __shared__ __attribute__((aligned(16))) u8 sh_stage[STRS_WAVES][STRS_STAGE_BYTES];
@@ -447,13 +464,31 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__rest
     const u32 nopen = u32(popc64(open));
     const u32 oincl = wave_incl_scan(nopen);
     if (total) {
-      const u32 skew = out_base & 15u; // window offset and destination address agree modulo 16
-      const window_map map{skew + (incl - cnt), one, open};
-      // where the strings of this lane begin
+      // where the strings of this lane begin (offsets in the buffer: the window plays no part)
       {
+        const window_map whole{incl - cnt, one, open};
         u32 k = ordinal + (oincl - nopen);
-        for (u64 t = open; t; t &= t - 1) { outq[k++] = out_base + (map.at(ctz64(t)) - skew); }
+        for (u64 t = open; t; t &= t - 1) { outq[k++] = out_base + whole.at(ctz64(t)); }
       }
+      // The window holds what HALF a chunk can produce (32 lanes x 160 bytes: "" is five bytes of output for two of input); a chunk whose output fits -- every
+      // chunk of a document that is not made of empty strings -- goes through it in one pass, the others in two, 32 lanes at a time.  (Through session AT the
+      // window held a whole chunk's worst case, 10 KiB per wave: 49.5 KB of LDS per workgroup, three workgroups per CU where the registers allow five.)
+      const bool halves = total > STRS_WINDOW_DATA; // wave-uniform
+      const u32 first_of_upper = readlane(incl - cnt, 32);
+#pragma unroll 1
+      for (u32 pass = 0; pass < (halves ? 2u : 1u); pass++) {
+      // (the masks pass through an empty asm: everything the sweep derives from them -- 128 bit tests, 16 masked dwords -- is invariant in this loop, and hoisted out of
+      // it the kernel needs 256 registers)
+      u32 one_lo = u32(one), one_hi = u32(one >> 32), open_lo = u32(open), open_hi = u32(open >> 32), closing_lo = u32(closing), closing_hi = u32(closing >> 32);
+      asm volatile("" : "+v"(one_lo), "+v"(one_hi), "+v"(open_lo), "+v"(open_hi), "+v"(closing_lo), "+v"(closing_hi));
+      const u64 one_p = u64(one_lo) | (u64(one_hi) << 32), open_p = u64(open_lo) | (u64(open_hi) << 32), closing_p = u64(closing_lo) | (u64(closing_hi) << 32);
+      const bool active = !halves || (lane >> 5) == pass;
+      const u32 pass_first = (halves && pass) ? first_of_upper : 0u;                                  // output of the chunk in front of this pass
+      const u32 pass_total = halves ? (pass ? total - first_of_upper : first_of_upper) : total;
+      if (pass_total == 0u) { continue; }
+      const u32 pass_out = out_base + pass_first;
+      const u32 skew = pass_out & 15u; // window offset and destination address agree modulo 16
+      const window_map map{skew + (incl - cnt) - pass_first, one_p, open_p}; // (of the pass's lanes)
       // the bytes: one LDS store per input byte, EVERY byte at the lane's running offset -- a byte that is dropped does not advance the offset and is overwritten by
       // the lane's next byte that stays (stores of one lane land in program order); an opening quote lands in its own hole of four.  What is left over is the
       // lane's trailing dropped bytes at the offset where the NEXT lane's share begins: a lane whose share begins with a byte (not with a hole) stores that byte
@@ -462,33 +497,35 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__rest
       // (measured in round 5 and not kept: dword by dword the way minify compacts -- one v_perm_b32 per dword through an accumulator, OR-merged into a zeroed
       // window, an opening quote as a hole of one dword, chunks with two opening quotes in a dword on this road -- 228 -> 276 us per 256 MiB: its per-lane
       // branches (flush? hole?) and ds_or cost more than 64 branch-free byte stores; scripts/sessions/gpu_r5_x.sh)
-      const u32 first_one = one ? ctz64(one) : 0u;
+      const u32 first_one = one_p ? ctz64(one_p) : 0u;
       u32 first_byte = 0;
-      if (one) { first_byte = ((closing >> first_one) & 1u) ? 0u : (pos + first_one < len ? u32(buf[pos + first_one]) : 0x20u); }
-      u8 *at = stage + map.lane_off;
-      u8 *const at0 = at;
+      if (active && one_p) { first_byte = ((closing_p >> first_one) & 1u) ? 0u : (pos + first_one < len ? u32(buf[pos + first_one]) : 0x20u); }
+      u8 *const at0 = stage + map.lane_off;
+      if (active) {
+        u8 *at = at0;
 #pragma unroll
-      for (int j = 0; j < 16; j++) {
-        // a closing quote leaves as a zero byte: clear it in the dword (bit k of the nibble -> byte k: one multiply spreads the bits)
-        const u32 close4 = u32(closing >> (4 * j)) & 0xFu;
-        const u32 lsb = (close4 * 0x00204081u) & 0x01010101u;
-        u32 fill = lsb << 8; // ... x 0xFF as a shift and a subtraction (the compiler folds them back into a 32-bit multiply, four issue slots, unless it loses sight of one)
-        asm("" : "+v"(fill));
-        const u32 wj = w[j] & ~(fill - lsb);
+        for (int j = 0; j < 16; j++) {
+          // a closing quote leaves as a zero byte: clear it in the dword (bit k of the nibble -> byte k: one multiply spreads the bits)
+          const u32 close4 = u32(closing_p >> (4 * j)) & 0xFu;
+          const u32 lsb = (close4 * 0x00204081u) & 0x01010101u;
+          u32 fill = lsb << 8; // ... x 0xFF as a shift and a subtraction (the compiler folds them back into a 32-bit multiply, four issue slots, unless it loses sight of one)
+          asm("" : "+v"(fill));
+          const u32 wj = w[j] & ~(fill - lsb);
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-          const int i = 4 * j + b;
-          const u32 is_one = u32(one >> i) & 1u, is_open = u32(open >> i) & 1u;
-          *at = u8(wj >> (8 * b));
-          at += is_one + 4u * is_open;
+          for (int b = 0; b < 4; b++) {
+            const int i = 4 * j + b;
+            const u32 is_one = u32(one_p >> i) & 1u, is_open = u32(open_p >> i) & 1u;
+            *at = u8(wj >> (8 * b));
+            at += is_one + 4u * is_open;
+          }
         }
       }
-      wave_lds_fence();
-      if (one) { at0[4u * u32(popc64(open & ((u64(1) << first_one) - 1)))] = u8(first_byte); }
+      wave_lds_fence(); // (outside the branch: every lane of the wave passes every fence)
+      if (active && one_p) { at0[4u * u32(popc64(open_p & ((u64(1) << first_one) - 1)))] = u8(first_byte); }
       wave_lds_fence();
       // the few bytes whose value is not the input's: escaped b f n r t, and what \\u escapes stand for -- listed by their owners, worked off one per lane
       const u64 k2 = m.k2 & kept, k3 = m.k3 & kept, k4 = m.k4 & kept, rm = m.b.remap & kept;
-      u64 todo = k2 | k3 | k4 | rm;
+      u64 todo = active ? (k2 | k3 | k4 | rm) : u64(0);
       while (__ballot(todo != 0)) { // wave-uniform
         const u32 mine = min(u32(popc64(todo)), PATCH_PER_LANE);
         const u32 pincl = wave_incl_scan(mine);
@@ -505,14 +542,18 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__rest
           const u32 entry = plist[e];
           const u32 role = entry & 3u, q = u32(cstart) + ((entry >> 2) & 0xFFFu);
           u8 *const at = stage + (entry >> 14);
-          *at = u8(role == PATCH_REMAP ? simple_escape_value(*at) : u_escape_byte(src, q, role + 2u)); // (the scatter put the escaped letter itself there)
+          u32 value;
+          if (role == PATCH_REMAP) { value = simple_escape_value(*at); } // (the scatter put the escaped letter itself there)
+          else if (q >= 8u && u64(q) + 8u <= len) { value = u_escape_byte(escape_window(buf, q), q, role + 2u); }
+          else { value = u_escape_byte(src, q, role + 2u); } // (the document's first and last bytes)
+          *at = u8(value);
         }
         wave_lds_fence();
       }
       wave_lds_fence();
       // the window leaves as 16-byte stores (emit_bytes' write-out); the 4-byte holes of the lengths carry whatever the window held
-      u8 *const g0 = out + (u64(out_base) - skew);
-      const u32 end = skew + total;
+      u8 *const g0 = out + (u64(pass_out) - skew);
+      const u32 end = skew + pass_total;
       const u32 v_first = (skew + 15u) >> 4, v_last = end >> 4;
       if (v_last > v_first) {
 #pragma unroll 1
@@ -526,6 +567,7 @@ __global__ __launch_bounds__(64 * STRS_WAVES) void k_strs_write(const u8 *__rest
         for (u32 i = skew + lane; i < end; i += 64) { g0[i] = stage[i]; }
       }
       wave_lds_fence();
+      }
       out_base += total;
       ordinal += readlane(oincl, 63);
     }

@@ -777,7 +777,11 @@ def test_string_stream_takes_valid_documents_and_only_those(orc, monkeypatch):
     docs["a run of 62 in front of a segment"] = b'["' + b'a' * (S - 2 - 62) + b'\\' * 62 + b'", "x"]'  # the look-back settles it: the stream takes it
     docs["a long run behind a u within ten bytes of a segment"] = b'["' + b'a' * (S - 2 - 80 - 3) + b'\\' * 79 + b'u00' + b'41", "x"]'  # declined: is that u escaped?
     declined = {"long runs of backslashes", "a run that fills the look-back in front of a segment", "a long run behind a u within ten bytes of a segment"}
-    docs["nothing but empty strings"] = b'[' + b'"",' * 20000 + b'""]'
+    docs["nothing but empty strings"] = b'[' + b'"",' * 20000 + b'""]'  # five bytes out of three: k_strs_write's window takes such chunks in two passes of 32 lanes
+    for phase in range(0, 64, 9):
+        docs[f"empty strings beside text, phase {phase}"] = (b"[" + b" " * phase + b'"",' * 900 + b'"ab\\u00e9\\n\\ud83d\\ude00c",' * 40 + b'"",' * 2100
+                                                             + b'"x\\ty",' + b'"lorem \\" ipsum",' * 300 + b'"z"]')
+    docs["empty keys and values"] = b'{' + b'"":"",' * 60000 + b'"k":""}'
     docs["no strings at all"] = b'[' + b'1,' * 20000 + b'2]'
     docs["twitter_like 3 MiB"] = corpus.twitter_like(3 << 20, 11)[0].tobytes()
     taken = {1: 0, 2: 0}

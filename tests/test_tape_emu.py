@@ -118,6 +118,11 @@ def test_escapes_across_chunks_and_segments(emu):
             parts.append(ESCAPES[int(rng.integers(0, len(ESCAPES)))] if rng.integers(0, 12) else b"x" * int(rng.integers(1, 70)))
             size += len(parts[-1])
         docs.append(b'{"k":"' + b"".join(parts) + b'","n":[1,2,"' + b"".join(parts[:50]) + b'"]}')
+    # chunks whose output does not fit k_strs_write's window (empty strings: five bytes out of three) go through it in two passes of 32 lanes: at every
+    # phase against the lanes, beside chunks that take one pass, with escapes to patch in both halves
+    for phase in range(0, 64, 9):
+        docs.append(b"[" + b" " * phase + b'"",' * 900 + b'"ab\\u00e9\\n\\ud83d\\ude00c",' * 40 + b'"",' * 2100 + b'"x\\ty","z"]')
+    docs.append(b'{' + b'"":"",' * 6000 + b'"k":""}')
     out = emu(docs)
     assert f"{len(docs)} documents, {len(docs)} valid" in out and f"stream {len(docs)}," in out, out
     bad = []
