@@ -417,12 +417,18 @@ struct window_map {
   }
 };
 // The bytes whose value is not the document's -- escaped b f n r t, and the kept bytes of \\u escapes -- are PATCHED in the window after the
-// scatter, one byte per lane: the lanes that own such bytes list them (window offset, position in the chunk, which hex digit of its escape the
-// byte sits on), at most PATCH_PER_LANE each per round, and the wave works the list off 64 entries at a time.  Text without escapes lists
-// nothing; the synthetic twitter-like text ~20 entries per chunk (one round, one pass); a string of nothing but \\uXXXX 2 048 (four rounds).
+// scatter: the lanes that own such bytes list them -- one entry per run of neighbours: window offset, position in the chunk, length --, at most
+// PATCH_PER_LANE each per round, and the wave works the list off 64 entries at a time.  Text without escapes lists nothing; the synthetic
+// twitter-like text ~10 entries per chunk (one round, one pass); a string of nothing but \\uXXXX 683 (two rounds).
 constexpr u32 PATCH_PER_LANE = 8, PATCH_LIST = 64 * PATCH_PER_LANE;
-enum : u32 { PATCH_REMAP = 3u }; // roles 0 ... 2: the byte sits on hex digit 2 ... 4 of a \\u escape
-__device__ __forceinline__ u32 patch_entry(u32 window_offset, u32 chunk_offset, u32 role) { return (window_offset << 14) | (chunk_offset << 2) | role; }
+__device__ __forceinline__ u32 patch_entry(u32 window_offset, u32 chunk_offset, u32 more) { return (window_offset << 14) | (chunk_offset << 2) | more; } // more: bytes of the run behind its first
+
+// the value of a listed byte at document position q (k_strs_write's patch rounds): escaped b f n r t, or a kept byte of an accepted \\u escape
+template <class SRC> __device__ __forceinline__ u32 patched_byte(const SRC &src, u32 q) {
+  if (src.byte(q - 1u) == u32('\\')) { return simple_escape_value(src.byte(q)); }
+  const u32 k = src.byte(q - 2u) == u32('u') ? 2u : (src.byte(q - 3u) == u32('u') ? 3u : 4u); // (hex digits in between: none of them is a 'u')
+  return u_escape_byte(src, q, k);
+}
 
 // (five waves per SIMD: what 29 KB of LDS per workgroup allow; left alone the allocator takes 105 registers, four waves)
 __global__ __launch_bounds__(64 * STRS_WAVES) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_strs_write(const u8 *__restrict__ buf, u64 len, u32 nseg, u32 allow_replacement,
@@ -525,28 +531,34 @@ __global__ __launch_bounds__(64 * STRS_WAVES) __attribute__((amdgpu_waves_per_eu
       wave_lds_fence();
       // the few bytes whose value is not the input's: escaped b f n r t, and what \\u escapes stand for -- listed by their owners, worked off one per lane
       const u64 k2 = m.k2 & kept, k3 = m.k3 & kept, k4 = m.k4 & kept, rm = m.b.remap & kept;
-      u64 todo = active ? (k2 | k3 | k4 | rm) : u64(0);
-      while (__ballot(todo != 0)) { // wave-uniform
-        const u32 mine = min(u32(popc64(todo)), PATCH_PER_LANE);
+      // Listed per RUN of such bytes inside a lane (the two or three bytes a \\u escape leaves are neighbours, in the document and in the window): the wave pays
+      // for the lane with the most trips, and a lane of three CJK escapes made nine trips -- and a second round -- with one entry per byte (session AS: the patch
+      // rounds were 92 of the kernel's 222 us on the twitter-like text).  What a byte becomes is read off the DOCUMENT by whoever works the entry off: a backslash
+      // in front of it -- one of b f n r t; else it sits on the 2nd, 3rd or 4th hex digit of an accepted escape, and the nearest 'u' in front says which.
+      const u64 todo = active ? (k2 | k3 | k4 | rm) : u64(0);
+      u64 starts = todo & ~(todo << 1);
+      while (__ballot(starts != 0)) { // wave-uniform
+        const u32 mine = min(u32(popc64(starts)), PATCH_PER_LANE);
         const u32 pincl = wave_incl_scan(mine);
         const u32 entries = readlane(pincl, 63);
         u32 slot = pincl - mine;
         for (u32 r = 0; r < mine; r++) {
-          const u32 i = ctz64(todo);
-          todo &= todo - 1;
-          const u32 role = ((k2 >> i) & 1u) ? 0u : (((k3 >> i) & 1u) ? 1u : (((k4 >> i) & 1u) ? 2u : u32(PATCH_REMAP)));
-          plist[slot++] = patch_entry(map.at(i), lane * BLOCK_BYTES + i, role);
+          const u32 i = ctz64(starts);
+          starts &= starts - 1;
+          const u32 run = min(u32(ctz64(~(todo >> i))), 3u); // (an escape leaves at most three bytes)
+          plist[slot++] = patch_entry(map.at(i), lane * BLOCK_BYTES + i, run - 1u);
         }
         wave_lds_fence();
         for (u32 e = lane; e < entries; e += 64) {
           const u32 entry = plist[e];
-          const u32 role = entry & 3u, q = u32(cstart) + ((entry >> 2) & 0xFFFu);
+          const u32 run = (entry & 3u) + 1u, q = u32(cstart) + ((entry >> 2) & 0xFFFu);
           u8 *const at = stage + (entry >> 14);
-          u32 value;
-          if (role == PATCH_REMAP) { value = simple_escape_value(*at); } // (the scatter put the escaped letter itself there)
-          else if (q >= 8u && u64(q) + 8u <= len) { value = u_escape_byte(escape_window(buf, q), q, role + 2u); }
-          else { value = u_escape_byte(src, q, role + 2u); } // (the document's first and last bytes)
-          *at = u8(value);
+          if (q >= 8u && u64(q) + 8u <= len) {
+            const escape_window win(buf, q); // covers q - 8 ... q + 7: every byte the run's (at most three) values are functions of
+            for (u32 b = 0; b < run; b++) { at[b] = u8(patched_byte(win, q + b)); }
+          } else { // (the document's first and last bytes)
+            for (u32 b = 0; b < run; b++) { at[b] = u8(patched_byte(src, q + b)); }
+          }
         }
         wave_lds_fence();
       }
